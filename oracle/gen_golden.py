@@ -1,0 +1,305 @@
+"""Generate ``tests/golden/*.npz`` by EXECUTING THE REFERENCE'S OWN PYTHON (build container only).
+
+ORACLE / TEST INFRASTRUCTURE ONLY.  Run:  ``python oracle/gen_golden.py``  (needs ``/root/reference``).
+
+The reference is imported from where it lies (``oracle/refshim/install.py`` supplies stand-ins for
+its missing third-party imports); nothing of it is copied.  Inputs come from the seeded generators in
+``mulactseg_amd/synth.py`` so the fixtures hold only seeds, tiny inputs' checksums and the
+reference's OUTPUTS.  The fixtures are data: arrays in, arrays out.
+
+Fixtures:
+  g1_pixbal_city.npz   PixBal + ban-ignore scorer, Cityscapes-shaped (C=20), 3 images / batch 2,
+                       selection walk with fair counting                         (rows a-1..a-6)
+  g2_voc.npz           VOC-shaped plumbing: my_bvsb (with/without 'predignore') and
+                       my_bvsb_predclsbal_pwr (C=21, S=150, odd image size)      (row a-5, config 1)
+  g3_losses.npz        stage-1 losses fwd + dz for every in-scope loss class      (rows a-7, a-8, a-11)
+  g5_miou.npz          MeanIoU / IoUIgnore counters incl. an unseen class         (row a-12)
+"""
+import hashlib
+import importlib.util
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "oracle", "refshim"))
+import install as refshim  # noqa: E402
+
+from mulactseg_amd import synth  # noqa: E402
+
+OUT = os.path.join(ROOT, "tests", "golden")
+
+
+def digest(*arrays):
+    h = hashlib.sha256()
+    for a in arrays:
+        h.update(np.ascontiguousarray(a).tobytes())
+    return np.frombuffer(h.digest()[:8], dtype=np.uint64)[0]
+
+
+class CaptureLocals:
+    """Grab the local variables of one reference function at its return (no source edits)."""
+
+    def __init__(self, func_name, file_suffix):
+        self.func_name, self.file_suffix, self.locals = func_name, file_suffix, None
+
+    def __enter__(self):
+        def prof(frame, event, arg):
+            if event == 'return' and frame.f_code.co_name == self.func_name \
+                    and frame.f_code.co_filename.endswith(self.file_suffix):
+                self.locals = dict(frame.f_locals)
+        sys.setprofile(prof)
+        return self
+
+    def __exit__(self, *a):
+        sys.setprofile(None)
+
+
+class FakePool(torch.utils.data.Dataset):
+    """Pool dataset whose 'images' ARE the logits (the fake trainer's net is the identity)."""
+
+    def __init__(self, logits, spx, im_idx, suppix):
+        self.logits, self.spx, self.im_idx, self.suppix = logits, spx, im_idx, suppix
+
+    def __len__(self):
+        return len(self.im_idx)
+
+    def __getitem__(self, i):
+        return {'images': self.logits[i], 'spx': self.spx[i]}
+
+
+def pool_inputs(seed, n_img, C, H, W, S, n_removed):
+    z = synth.logits(seed, n_img, C, H, W)
+    spx = np.stack([synth.superpixel_map(seed * 31 + i, H, W, S, n_missing=(1 if i == 1 else 0))
+                    for i in range(n_img)])
+    # datalist order is ascending in the path strings, like the reference's sorted datalist
+    im_idx = [["leftImg8bit/train/c/img_%04d.png" % i, "gtFine/train/c/lbl_%04d.png" % i,
+               "superpixel/train/c/spx_%04d.pkl" % i] for i in range(n_img)]
+    rs = np.random.RandomState(seed + 5)
+    suppix = {}
+    for i in range(n_img):
+        present = sorted(set(np.unique(spx[i]).tolist()))
+        removed = set(rs.choice(present, size=n_removed, replace=False).tolist())
+        suppix[im_idx[i][2]] = [s for s in present if s not in removed]
+    return z, spx, im_idx, suppix
+
+
+def tuples_to_arrays(tuples, im_idx):
+    paths = {','.join(k): n for n, k in enumerate(im_idx)}
+    return (np.array([t[0] for t in tuples], dtype=np.float64),
+            np.array([paths[t[1]] for t in tuples], dtype=np.int64),
+            np.array([t[2] for t in tuples], dtype=np.int64))
+
+
+def load_region_active_dataset():
+    path = os.path.join(refshim.REFERENCE_ROOT, "dataloader", "region_active_dataset.py")
+    spec = importlib.util.spec_from_file_location("_ref_region_active_dataset", path)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod.RegionActiveDataset
+
+
+def gen_g1():
+    from active_selection import my_bvsb_predclsbal_pwr_banignore as sel
+    seed, n_img, C, H, W, S, bs = 11, 3, 20, 48, 64, 64, 2
+    z, spx, im_idx, suppix = pool_inputs(seed, n_img, C, H, W, S, n_removed=5)
+    # make "undefined" (last channel) dominant somewhere so that the ban fires
+    z[0, C - 1, :16, :24] += 1.5
+    args = types.SimpleNamespace(val_batch_size=bs, val_num_workers=0, nseg=S, active_method='x',
+                                 num_classes=C - 1, ce_temp=0.1, cls_weight_coeff=6.0,
+                                 method='active_joint_multi_predignore_lossdecomp', save_scores=False)
+    pool = FakePool(torch.from_numpy(z), torch.from_numpy(spx), [list(k) for k in im_idx],
+                    {k: list(v) for k, v in suppix.items()})
+    trainer = types.SimpleNamespace(net=torch.nn.Identity(), device='cpu')
+    selector = sel.RegionSelector(args)
+    with CaptureLocals('calculate_scores', 'my_bvsb_predclsbal_pwr_banignore.py') as cap:
+        scores = selector.calculate_scores(trainer, pool)
+    loc = cap.locals
+    sc, si, sid = tuples_to_arrays(scores, im_idx)
+
+    # selection walk through the reference's own RegionActiveDataset.expand_training_set
+    RegionActiveDataset = load_region_active_dataset()
+    mh = np.stack([synth.multi_hot_targets(seed * 13 + i, S, C) for i in range(n_img)])
+    label = types.SimpleNamespace(im_idx=[], suppix={}, multi_hot_cls=mh,
+                                  id_to_index={"spx_%04d" % i: i for i in range(n_img)})
+    import tempfile
+    tmp = tempfile.mkdtemp()
+    aargs = types.SimpleNamespace(fair_counting=True, or_labeling=True, model_save_dir=tmp,
+                                  finetune_itrs=1, wandb=types.SimpleNamespace(log=lambda *a, **k: None))
+    pool.isselected = np.zeros((n_img, S), dtype=np.uint8)
+    active = RegionActiveDataset(aargs, pool, label)
+    active.selection_iter = 1
+    budget = 40
+    ordered = sorted(scores, reverse=True)            # active_selection/base.py:37
+    active.expand_training_set(ordered, budget, 'pixbal')
+    import pickle
+    with open(os.path.join(tmp, 'pixbal_selection_01.pkl'), 'rb') as f:
+        consumed = pickle.load(f)
+    oc, oi, oid = tuples_to_arrays(ordered[:60], im_idx)
+    cc, ci, cid = tuples_to_arrays(consumed, im_idx)
+    np.savez_compressed(
+        os.path.join(OUT, "g1_pixbal_city.npz"),
+        seed=seed, n_img=n_img, C=C, H=H, W=W, S=S, batch_size=bs, ce_temp=0.1, coeff=6.0,
+        n_removed=5, budget=budget, input_digest=digest(z, spx),
+        cum=loc['cumulated_pred_prob'].numpy(), cls_weight=loc['cls_weight'].numpy(),
+        region_ntop1=loc['top1nclasses'].view(n_img, S, C).numpy(),
+        scores_tensor=loc['scores_tensor'].numpy(),
+        list_score=sc, list_img=si, list_id=sid,
+        sorted_score=oc, sorted_img=oi, sorted_id=oid,
+        consumed_score=cc, consumed_img=ci, consumed_id=cid,
+        isselected=pool.isselected, multi_hot=mh)
+    print("g1: %d tuples, %d consumed, banned=%d" % (
+        len(scores), len(consumed), int((loc['scores_tensor'] == 0).sum())))
+
+
+def gen_g2():
+    from active_selection import my_bvsb, my_bvsb_predclsbal_pwr
+    seed, n_img, C, H, W, S, bs = 23, 3, 21, 33, 37, 150, 2
+    z, spx, im_idx, suppix = pool_inputs(seed, n_img, C, H, W, S, n_removed=3)
+    out = dict(seed=seed, n_img=n_img, C=C, H=H, W=W, S=S, batch_size=bs, ce_temp=0.1, coeff=12.0,
+               n_removed=3, input_digest=digest(z, spx))
+    trainer = types.SimpleNamespace(net=torch.nn.Identity(), device='cpu')
+
+    def mk_pool():
+        return FakePool(torch.from_numpy(z), torch.from_numpy(spx), [list(k) for k in im_idx],
+                        {k: list(v) for k, v in suppix.items()})
+
+    for tag, method in (('plain', 'active_joint_multi_lossdecomp'),
+                        ('strip', 'active_joint_multi_predignore_lossdecomp')):
+        args = types.SimpleNamespace(val_batch_size=bs, val_num_workers=0, nseg=S, active_method='x',
+                                     num_classes=C, ce_temp=0.1, cls_weight_coeff=12.0,
+                                     method=method, save_scores=False)
+        with CaptureLocals('calculate_scores', 'my_bvsb.py') as cap:
+            scores = my_bvsb.RegionSelector(args).calculate_scores(trainer, mk_pool())
+        sc, si, sid = tuples_to_arrays(scores, im_idx)
+        out['bvsb_%s_scores_tensor' % tag] = cap.locals['scores_tensor'].numpy()
+        out['bvsb_%s_list_score' % tag] = sc
+        out['bvsb_%s_list_img' % tag] = si
+        out['bvsb_%s_list_id' % tag] = sid
+    args = types.SimpleNamespace(val_batch_size=bs, val_num_workers=0, nseg=S, active_method='x',
+                                 num_classes=C, ce_temp=0.1, cls_weight_coeff=12.0,
+                                 method='active_joint_multi_lossdecomp', save_scores=False)
+    with CaptureLocals('calculate_scores', 'my_bvsb_predclsbal_pwr.py') as cap:
+        scores = my_bvsb_predclsbal_pwr.RegionSelector(args).calculate_scores(trainer, mk_pool())
+    loc = cap.locals
+    sc, si, sid = tuples_to_arrays(scores, im_idx)
+    out.update(pwr_cum=loc['cumulated_pred_prob'].numpy(), pwr_cls_weight=loc['cls_weight'].numpy(),
+               pwr_region_ntop1=loc['top1nclasses'].view(n_img, S, C).numpy(),
+               pwr_scores_tensor=loc['scores_tensor'].numpy(),
+               pwr_list_score=sc, pwr_list_img=si, pwr_list_id=sid)
+    np.savez_compressed(os.path.join(OUT, "g2_voc.npz"), **out)
+    print("g2: ok")
+
+
+def loss_inputs(seed, N, C, H, W, S):
+    z = synth.logits(seed, N, C, H, W)
+    spx, msk = [], []
+    for i in range(N):
+        s, m = synth.train_crop(seed * 17 + i, H, W, S, frac_selected=0.25)
+        spx.append(s)
+        msk.append(m)
+    spx, msk = np.stack(spx), np.stack(msk)
+    tgt = np.stack([synth.multi_hot_targets(seed * 19 + i, S, C) for i in range(N)])
+    # image 2: nothing selected (skip path); image 3: only one-hot regions selected
+    msk[2] = False
+    onehot = tgt[3].sum(axis=1) == 1
+    msk[3] &= np.concatenate([onehot, [False]])[spx[3]]
+    return z, tgt, spx, msk
+
+
+def gen_g3():
+    import utils.loss as L
+    from trainer.active_joint_multi_predignore import MultiChoiceCE_, GroupMultiLabelCE_
+    from trainer.active_joint_multi_predignore_lossdecomp import OnehotCEMultihotChoice
+    from trainer.active_joint_multi_predignore_mclossablation2 import GroupMultiLabelCE_onlymulti
+    seed, N, C, H, W, S, T = 37, 4, 20, 40, 44, 48, 0.1
+    z, tgt, spx, msk = loss_inputs(seed, N, C, H, W, S)
+    out = dict(seed=seed, N=N, C=C, H=H, W=W, S=S, temp=T, input_digest=digest(z, tgt, spx, msk))
+    tt, ts, tm = torch.from_numpy(tgt), torch.from_numpy(spx), torch.from_numpy(msk)
+
+    def run(tag, fn):
+        zt = torch.from_numpy(z).clone().requires_grad_(True)
+        res = fn(zt)
+        res = res if isinstance(res, tuple) else (res,)
+        for k, r in enumerate(res):
+            out['%s_loss%d' % (tag, k)] = np.float32(float(r))
+            if torch.is_tensor(r) and r.requires_grad:
+                (g,) = torch.autograd.grad(r, zt, retain_graph=True)
+                out['%s_grad%d' % (tag, k)] = g.numpy()
+            else:
+                out['%s_grad%d' % (tag, k)] = np.zeros_like(z)
+
+    run('decomp', lambda zt: OnehotCEMultihotChoice(num_class=C - 1, temperature=T)(zt, tt, ts, tm))
+    run('onlymulti', lambda zt: GroupMultiLabelCE_onlymulti(args=None, num_class=C - 1, num_superpixel=S,
+                                                            temperature=T)(zt, tt, ts, tm))
+    run('mc_predignore', lambda zt: MultiChoiceCE_(num_class=C - 1, temperature=T)(zt, tt, ts, tm))
+    run('group_predignore', lambda zt: GroupMultiLabelCE_(args=None, num_class=C - 1, num_superpixel=S,
+                                                          temperature=T)(zt, tt, ts, tm))
+    # base classes (utils/loss.py) drop the last target column: C logits <-> C+1 target columns
+    tgt_b = np.concatenate([tgt, np.zeros((N, S, 1), np.uint8)], axis=2)
+    ttb = torch.from_numpy(tgt_b)
+    run('mc_base', lambda zt: L.MultiChoiceCE(num_class=C, temperature=T)(zt, ttb, ts, tm))
+    run('group_base', lambda zt: L.GroupMultiLabelCE(args=None, num_class=C, num_superpixel=S,
+                                                     temperature=T)(zt, ttb, ts, tm))
+    # production combination of train_impl: 16*ce + 8*mc + 1*group  (lossdecomp.py:102-104)
+    zt = torch.from_numpy(z).clone().requires_grad_(True)
+    group = GroupMultiLabelCE_onlymulti(args=None, num_class=C - 1, num_superpixel=S, temperature=T)(zt, tt, ts, tm)
+    ce, mc = OnehotCEMultihotChoice(num_class=C - 1, temperature=T)(zt, tt, ts, tm)
+    total = 16.0 * ce + 8.0 * mc + 1.0 * group
+    total.backward()
+    out['total_loss'] = np.float32(float(total))
+    out['total_grad'] = zt.grad.numpy()
+    # stage-2 temperature CE (utils/loss.py:10-21)
+    rs = np.random.RandomState(seed + 3)
+    y = rs.randint(0, C, size=(N, H, W)).astype(np.int64)
+    y[rs.uniform(size=y.shape) < 0.2] = 255
+    zt = torch.from_numpy(z).clone().requires_grad_(True)
+    l2 = L.MyCrossEntropyLoss(ignore_index=255, temperature=T)(zt, torch.from_numpy(y))
+    l2.backward()
+    out['tce_loss'] = np.float32(float(l2))
+    out['tce_grad'] = zt.grad.numpy()
+    out['tce_digest'] = digest(y)
+    np.savez_compressed(os.path.join(OUT, "g3_losses.npz"), **out)
+    print("g3:", {k: float(v) for k, v in out.items() if k.endswith(('loss0', 'loss1', '_loss'))})
+
+
+def gen_g5():
+    from utils.miou import MeanIoU
+    from utils.miou_evalignore import IoUIgnore
+    seed, B, H, W, nc = 41, 2, 24, 32, 19
+    rs = np.random.RandomState(seed)
+    logits = rs.standard_normal(size=(2, B, nc + 1, H, W)).astype(np.float32)
+    labels = rs.randint(0, nc, size=(2, B, H, W)).astype(np.int64)
+    labels[labels == 7] = 3                     # class 7 never seen -> IoU counts as 100
+    labels[rs.uniform(size=labels.shape) < 0.15] = 255
+    m, g = MeanIoU(nc, 255), IoUIgnore(num_classes=nc, ignore_label=255)
+    m._before_epoch()
+    for step in range(2):
+        p = torch.from_numpy(logits[step])
+        t = torch.from_numpy(labels[step])
+        m._after_step({'outputs': p[:, :-1].max(dim=1)[1], 'targets': t})   # predignore.py:200-203
+        g._after_step({'outputs': p.max(dim=1)[1], 'targets': t})
+    ious = m._after_epoch()
+    np.savez_compressed(os.path.join(OUT, "g5_miou.npz"), seed=seed, B=B, H=H, W=W, nc=nc,
+                        input_digest=digest(logits, labels),
+                        seen=m.total_seen, correct=m.total_correct, positive=m.total_positive,
+                        ious=np.array(ious, dtype=np.float64), miou=np.float64(np.mean(ious)),
+                        ign=np.array([g.total_seen, g.total_correct, g.total_positive], dtype=np.float64),
+                        ign_iou=np.float64(g._after_epoch()))
+    print("g5: miou", np.mean(ious))
+
+
+if __name__ == "__main__":
+    refshim.install()
+    os.makedirs(OUT, exist_ok=True)
+    torch.set_num_threads(1)      # the goldens do not depend on it; keeps the run reproducible
+    gen_g1()
+    gen_g2()
+    gen_g3()
+    gen_g5()
+    for f in sorted(os.listdir(OUT)):
+        print(f, os.path.getsize(os.path.join(OUT, f)))
