@@ -1,0 +1,186 @@
+#!/usr/bin/env python
+"""bench.py -- MulActSeg hot path on MI355X: superpixels scored/sec (+ train-iter images/sec).
+
+Contract (driver):  python bench.py --gpus N --steps K --warmup W
+  N > 1 is launched by the driver as `python -m torch.distributed.run --nproc-per-node N ... bench.py`,
+  one rank per GPU; the pool of unlabeled images is sharded across ranks (no data-path collective in
+  the scan; the two tiny exchanges of the acquisition round -- class sums, scores -- are RCCL
+  collectives inside the timed region).
+
+Workload "acquisition-scan" (BASELINE.json metric "superpixels scored/sec"): one step = one reference
+batch (val_batch_size = 4 pool images, logits [4,20,1024,2048] f32 + superpixel ids, already resident
+in HBM) through the scorer hot path: K2 class-prior pass, K1+K3 region accumulation with class
+weights, finalize + ban-ignore (reference: active_selection/my_bvsb_predclsbal_pwr_banignore.py:35-84).
+value = steps * 4 * 2048 * n_gpus / seconds.
+
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6.3 TB/s is achievable
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=4, help="pool images per step (reference val_batch_size)")
+    ap.add_argument("--height", type=int, default=1024)
+    ap.add_argument("--width", type=int, default=2048)
+    ap.add_argument("--classes", type=int, default=20, help="logit channels (19 classes + undefined)")
+    ap.add_argument("--nseg", type=int, default=2048)
+    ap.add_argument("--id-dtype", default="int64", choices=["int64", "int32", "int16"],
+                    help="superpixel id element type (the reference data layer yields int64)")
+    ap.add_argument("--nbuf", type=int, default=3, help="distinct resident batches rotated through")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU-baseline budget")
+    return ap.parse_args()
+
+
+def make_batch(seed, B, C, H, W, S, id_dtype, device):
+    """Synthetic Cityscapes-shaped batch generated on the device (plumbing): cosine-like logits with a
+    blocky class layout, jittered-grid superpixel map (mulactseg_amd.synth)."""
+    from mulactseg_amd import synth
+    g = torch.Generator(device=device)
+    g.manual_seed(seed)
+    z = 0.35 * torch.randn((B, C, H, W), generator=g, device=device, dtype=torch.float32)
+    cm = torch.randint(0, C, (B, 1, H // 32 + 1, W // 32 + 1), generator=g, device=device)
+    cm = cm.repeat_interleave(32, 2).repeat_interleave(32, 3)[:, :, :H, :W]
+    z.scatter_add_(1, cm, torch.full_like(cm, 0.6, dtype=torch.float32))
+    spx = np.stack([synth.superpixel_map(seed * 131 + i, H, W, S) for i in range(B)])
+    return z.contiguous(), torch.from_numpy(spx).to(getattr(torch, id_dtype)).to(device)
+
+
+def cpu_baseline(args, budget_s):
+    """Reference CPU path ("port": oracle/port.py, the torch-CPU restatement pinned bit-exact to the
+    executed reference) on a bounded sample of the same workload, all host cores."""
+    from mulactseg_amd import synth
+    from oracle import port
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    C, H, W, S = args.classes, args.height, args.width, args.nseg
+
+    def sample(n):
+        z = torch.from_numpy(synth.logits(7, n, C, H, W))
+        spx = torch.from_numpy(np.stack([synth.superpixel_map(900 + i, H, W, S) for i in range(n)]))
+        return z, spx
+
+    z, spx = sample(1)
+    t0 = time.perf_counter()
+    port.pixbal_scores(z, spx, args.batch, 0.1, 6.0, S, ban_ignore=True)
+    t1 = time.perf_counter() - t0
+    n = int(max(1, min(16, budget_s // max(t1, 1e-3))))
+    if n > 1:
+        z, spx = sample(n)
+        t0 = time.perf_counter()
+        port.pixbal_scores(z, spx, args.batch, 0.1, 6.0, S, ban_ignore=True)
+        t1 = time.perf_counter() - t0
+    return {"value": n * S / t1, "unit": "superpixels/s", "cores": cores, "kind": "port",
+            "sample": "%d synthetic %dx%dx%d images, nseg %d, both passes + ban (oracle/port.py, torch %s CPU), %.1f s"
+                      % (n, C, H, W, S, torch.__version__, t1)}
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        torch.cuda.set_device(local)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    dev = torch.device("cuda", local)
+    torch.cuda.set_device(dev)
+
+    from mulactseg_amd import ops
+    B, C, H, W, S = args.batch, args.classes, args.height, args.width, args.nseg
+    invT = ops.inv_temperature(0.1)
+    bufs = [make_batch(1000 * rank + 17 * i + 1, B, C, H, W, S, args.id_dtype, dev) for i in range(args.nbuf)]
+    cls_w = torch.linspace(0.3, 1.0, C, device=dev)
+
+    n_total = args.steps + args.warmup
+    prob = torch.zeros((n_total, B, C), dtype=torch.int64, device=dev)
+    ssum = torch.zeros((n_total, B, S), dtype=torch.int64, device=dev)
+    hist = torch.zeros((n_total, B, S, C), dtype=torch.int32, device=dev)
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(n_total)]
+    ev2 = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(n_total)]
+    scores = []
+
+    def step(i):
+        z, spx = bufs[i % args.nbuf]
+        ev2[i][0].record()
+        ops.class_prob_sum(z, invT, out=prob[i])                       # K2
+        ev2[i][1].record()
+        ev[i][0].record()
+        ops.bvsb_region_accum(z, spx, cls_w, S, invT, score_sum=ssum[i], hist=hist[i])   # K1+K3
+        ev[i][1].record()
+        scores.append(ops.region_finalize(ssum[i], hist[i], ban_class=C - 1)[0])          # mean + ban
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            import torch.distributed as dist
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        step(i)
+    fence()
+    t0 = time.perf_counter()
+    for i in range(args.warmup, n_total):
+        step(i)
+    fence()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        import torch.distributed as dist
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    k3_ms = float(np.mean([a.elapsed_time(b) for a, b in ev[args.warmup:]]))
+    k2_ms = float(np.mean([a.elapsed_time(b) for a, b in ev2[args.warmup:]]))
+    id_bytes = {"int64": 8, "int32": 4, "int16": 2}[args.id_dtype]
+    # algorithmic bytes of one K3 launch: logits + ids read once, (sum + hist) written once
+    k3_bytes = B * (C * H * W * 4 + H * W * id_bytes + S * (8 + 4 * C))
+    k2_bytes = B * (C * H * W * 4)
+    ach = k3_bytes / (k3_ms * 1e-3) / 1e9
+    out = {
+        "metric": "superpixels scored/sec", "value": args.steps * B * S * world / dt, "unit": "superpixels/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "acquisition-scan: PixBal+ban-ignore scorer (K2 class prior, K1+K3 region accumulation, "
+                               "finalize) on resident logits, Cityscapes pool shape",
+                   "images_per_step": B, "logits": [B, C, H, W], "nseg": S, "id_dtype": args.id_dtype,
+                   "temperature": 0.1, "sharding": "pool images across ranks"},
+        "roofline": {"bound": "hbm", "kernel": "k_bvsb_region_accum", "achieved": ach, "peak": HBM_PEAK_GBS,
+                     "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": None,
+                     "bytes_per_launch": k3_bytes, "avg_launch_ms": k3_ms},
+        "kernels": {"k_class_prob_sum": {"avg_launch_ms": k2_ms, "achieved_GBs": k2_bytes / (k2_ms * 1e-3) / 1e9,
+                                         "bytes_per_launch": k2_bytes}},
+    }
+    if rank == 0:
+        if not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline(args, args.cpu_seconds)
+        else:
+            out["cpu_baseline"] = None
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        import torch.distributed as dist
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,60 @@
+"""ctypes binding of libmulactseg_hip.so (the C ABI declared in include/mulactseg_hip.h).
+
+The product path has NO fallback: if the shared library is missing or a call fails, this module
+raises.  PyTorch is used only for device memory and streams (tensor.data_ptr(), current stream).
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libmulactseg_hip.so")
+
+ID_I64, ID_I32, ID_U16 = 0, 1, 2
+MAX_CLASSES = 32
+SCORE_FRAC, PROB_FRAC, LOSS_FRAC = 40, 31, 32
+
+_c = ctypes
+_vp, _i, _f, _i64 = _c.c_void_p, _c.c_int, _c.c_float, _c.c_int64
+
+# name -> (restype, argtypes); mirrors include/mulactseg_hip.h one to one
+SIGNATURES = {
+    "mas_abi_version": (_i, []),
+    "mas_error_string": (_c.c_char_p, [_i]),
+    "mas_class_prob_sum": (_i, [_vp, _i, _i, _i, _i, _f, _vp, _vp]),
+    "mas_bvsb_region_accum": (_i, [_vp, _vp, _i, _vp, _i, _i, _i, _i, _i, _f, _vp, _vp, _vp]),
+    "mas_region_finalize": (_i, [_vp, _vp, _i64, _i, _i, _vp, _vp, _vp, _vp, _vp]),
+}
+
+_lib = None
+
+
+class MulActSegHipError(RuntimeError):
+    pass
+
+
+def load():
+    """Load the HIP library once; raise loudly when it is not built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    # PyTorch-ROCm bundles its own HIP runtime (same SONAME as /opt/rocm's).  It must be the one that is
+    # resident before this library is mapped, otherwise two runtimes end up in the process and the second
+    # one sees no device ("no ROCm-capable device is detected").
+    import torch  # noqa: F401
+    if not os.path.exists(LIB_PATH):
+        raise MulActSegHipError(
+            "libmulactseg_hip.so is not built (%s). Run `python -c 'import __graft_entry__ as g; g.build()'` "
+            "or `make -C mulactseg_amd/csrc`. There is no CPU fallback." % LIB_PATH)
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)      # AttributeError if the .so does not export a declared symbol
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(code, what):
+    if code != 0:
+        msg = load().mas_error_string(code)
+        raise MulActSegHipError("%s failed with code %d: %s" % (what, code, msg.decode() if msg else "?"))

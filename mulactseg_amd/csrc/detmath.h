@@ -1,0 +1,139 @@
+/*
+ * detmath.h -- the ARITHMETIC SPECIFICATION of the hot path.
+ *
+ * Every floating-point value the HIP kernels produce is defined by the functions in this header,
+ * which use only IEEE-754 correctly-rounded primitives (add, mul, fma, int<->float conversions and
+ * bit manipulation).  The same header compiles as device code (hipcc, gfx950) and as plain C
+ * (gcc, the CPU restatement in oracle/exact.c), so GPU and CPU results are bit-identical -- this is
+ * what makes "selected-region set bit-identical" a testable statement for a massively parallel
+ * reduction (hard part 1).
+ *
+ * Rules for users of this header:
+ *   - compile with -ffp-contract=off (no implicit fusion) and without -ffast-math;
+ *   - fused operations are written explicitly with mas_fmaf();
+ *   - region / loss accumulators are unsigned fixed-point integers (order-independent sums).
+ *
+ * exp/log follow the classic Cephes single-precision kernels (range reduction by ln2 split into
+ * hi/lo, degree-5 / degree-8 minimax polynomials); accuracy is about 1 ulp, checked against libm in
+ * tests/test_detmath.py.  They stand in for ATen's softmax / log in the reference
+ * (active_selection/my_bvsb.py:20, utils/loss.py:563,581), whose own f32 bits are not reproducible
+ * across thread counts either (tests/test_oracle_golden.py).
+ */
+#ifndef MULACTSEG_DETMATH_H
+#define MULACTSEG_DETMATH_H
+
+#include <stdint.h>
+
+#if defined(__HIPCC__)
+#define MAS_HD __host__ __device__ __forceinline__
+#else
+#define MAS_HD static inline
+#endif
+
+MAS_HD float mas_fmaf(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
+
+MAS_HD uint32_t mas_f2u(float f) {
+    union { float f; uint32_t u; } v;
+    v.f = f;
+    return v.u;
+}
+MAS_HD float mas_u2f(uint32_t u) {
+    union { float f; uint32_t u; } v;
+    v.u = u;
+    return v.f;
+}
+
+/* 2^n for n in [-126, 127] */
+MAS_HD float mas_pow2i(int n) { return mas_u2f((uint32_t)(n + 127) << 23); }
+
+/* exp(x), f32, ~1 ulp.  x < -104 -> 0 ; x > 88.72 -> +inf. */
+MAS_HD float mas_expf(float x) {
+    if (!(x >= -104.0f)) return (x != x) ? x : 0.0f;
+    if (x > 88.72f) return mas_u2f(0x7f800000u);
+    /* n = round-to-nearest-even(x * log2(e)) via the 1.5*2^23 magic constant */
+    float t = mas_fmaf(x, 1.44269504088896341f, 12582912.0f);
+    float n = t - 12582912.0f;
+    float r = mas_fmaf(n, -0.693359375f, x);
+    r = mas_fmaf(n, 2.12194440e-4f, r);
+    float p = 1.9875691500e-4f;
+    p = mas_fmaf(p, r, 1.3981999507e-3f);
+    p = mas_fmaf(p, r, 8.3334519073e-3f);
+    p = mas_fmaf(p, r, 4.1665795894e-2f);
+    p = mas_fmaf(p, r, 1.6666665459e-1f);
+    p = mas_fmaf(p, r, 5.0000001201e-1f);
+    float y = mas_fmaf(p, r * r, r) + 1.0f;
+    int ni = (int)n;
+    int h = ni / 2;               /* two exact power-of-two scalings: single final rounding */
+    return (y * mas_pow2i(h)) * mas_pow2i(ni - h);
+}
+
+/* log(x) for finite x > 0, f32, ~1 ulp. */
+MAS_HD float mas_logf(float x) {
+    int e = 0;
+    if (x < 1.17549435e-38f) {   /* subnormal: rescale exactly */
+        x = x * 8388608.0f;
+        e = -23;
+    }
+    uint32_t b = mas_f2u(x);
+    e += (int)((b >> 23) & 0xffu) - 126;
+    float m = mas_u2f((b & 0x007fffffu) | 0x3f000000u);   /* [0.5, 1) */
+    if (m < 0.707106781186547524f) {
+        e -= 1;
+        m = (m + m) - 1.0f;
+    } else {
+        m = m - 1.0f;
+    }
+    float z = m * m;
+    float p = 7.0376836292e-2f;
+    p = mas_fmaf(p, m, -1.1514610310e-1f);
+    p = mas_fmaf(p, m, 1.1676998740e-1f);
+    p = mas_fmaf(p, m, -1.2420140846e-1f);
+    p = mas_fmaf(p, m, 1.4249322787e-1f);
+    p = mas_fmaf(p, m, -1.6668057665e-1f);
+    p = mas_fmaf(p, m, 2.0000714765e-1f);
+    p = mas_fmaf(p, m, -2.4999993993e-1f);
+    p = mas_fmaf(p, m, 3.3333331174e-1f);
+    float fe = (float)e;
+    float y = (p * m) * z;
+    y = mas_fmaf(fe, -2.12194440e-4f, y);
+    y = mas_fmaf(z, -0.5f, y);
+    float r = m + y;
+    return mas_fmaf(fe, 0.693359375f, r);
+}
+
+/* Unsigned fixed point: floor(v * 2^FRAC) for finite v in [0, 2^(63-FRAC)); exact (no rounding other
+ * than the floor).  Written with integer shifts on the f32 bit pattern so that host and device agree
+ * without relying on float->int64 conversion sequences. */
+MAS_HD uint64_t mas_fix(float v, int frac) {
+    uint32_t b = mas_f2u(v);
+    if (b >> 31) return 0;                   /* negative / -0 -> 0 */
+    int e = (int)(b >> 23);
+    if (e == 0) return 0;                    /* zero or subnormal: below 2^-126 */
+    uint64_t m = (uint64_t)((b & 0x007fffffu) | 0x00800000u);
+    int sh = e - 150 + frac;                 /* value = m * 2^(e-150) */
+    if (sh >= 0) return (sh > 39) ? ~(uint64_t)0 : (m << sh);
+    return (sh < -24) ? 0 : (m >> (-sh));
+}
+
+#define MAS_SCORE_FRAC 40   /* per-region sum of weighted BvSB: v in (0, 1.0000001], <= 2^23 px/region */
+#define MAS_PROB_FRAC  31   /* per-image class-probability sums: p in [0, 1.0000001], <= 2^32 px/image */
+#define MAS_LOSS_FRAC  32   /* loss sums: l in [0, 18.5], <= 2^27 selected px / batch */
+
+/* mean = floor(sum / count) * 2^-FRAC rounded once to f32 (count > 0) */
+MAS_HD float mas_fixed_mean(uint64_t sum, uint64_t count, int frac) {
+    uint64_t q = sum / count;
+    /* q < 2^53 always holds for the accumulators above, so the u64 -> f64 conversion is exact */
+    union { double d; uint64_t u; } s;
+    s.u = (uint64_t)(1023 - frac) << 52;     /* 2^-frac, exact scaling */
+    return (float)((double)q * s.d);
+}
+
+/* Per-pixel Best-vs-Second-Best margin from the two largest logits (z1 >= z2):
+ *   reference: softmax(z/T) -> top-2 -> p2/p1 + 1e-8   (active_selection/my_bvsb.py:20-24)
+ *   here:      exp(z2*invT - z1*invT) + 1e-8           (same quantity, softmax denominator cancels) */
+MAS_HD float mas_bvsb(float z1, float z2, float invT) {
+    float d = (z2 * invT) - (z1 * invT);
+    return mas_expf(d) + 1e-8f;
+}
+
+#endif /* MULACTSEG_DETMATH_H */

@@ -1,0 +1,95 @@
+"""Tensor-level wrappers over the C ABI: contiguous ROCm tensors in, ROCm tensors out.
+
+Every function launches on the current torch stream and never synchronises with the host.
+These are the only callers of ``_lib``; the plugin-level code (``active_selection``, ``utils.loss``)
+is written against this module.
+"""
+import numpy as np
+import torch
+
+from . import _lib
+
+_ID_CODES = {torch.int64: _lib.ID_I64, torch.int32: _lib.ID_I32, torch.uint16: _lib.ID_U16,
+             torch.int16: _lib.ID_U16}
+
+
+def inv_temperature(T):
+    """invT as the ABI defines it: float32(1 / float32(T))."""
+    return float(np.float32(1.0) / np.float32(T))
+
+
+def _stream(t):
+    return torch.cuda.current_stream(t.device).cuda_stream
+
+
+def _need(t, name, dtype=None):
+    if not t.is_cuda:
+        raise _lib.MulActSegHipError("%s must live on the GPU (no CPU path exists)" % name)
+    if dtype is not None and t.dtype != dtype:
+        raise TypeError("%s must be %s, got %s" % (name, dtype, t.dtype))
+    if not t.is_contiguous():
+        raise ValueError("%s must be contiguous" % name)
+    return t
+
+
+def _id_code(spx):
+    try:
+        return _ID_CODES[spx.dtype]
+    except KeyError:
+        raise TypeError("superpixel ids must be int64, int32 or uint16, got %s" % spx.dtype)
+
+
+def class_prob_sum(z, invT, out=None):
+    """K2: per-image fixed-point class-probability sums ``[B,C]`` (int64 holding uint64 bits).
+    Reference: my_bvsb_predclsbal_pwr_banignore.py:41-42."""
+    _need(z, "z", torch.float32)
+    B, C, H, W = z.shape
+    if out is None:
+        out = torch.zeros((B, C), dtype=torch.int64, device=z.device)
+    with torch.cuda.device(z.device):
+        _lib.check(_lib.load().mas_class_prob_sum(z.data_ptr(), B, C, H, W, invT, out.data_ptr(), _stream(z)),
+                   "mas_class_prob_sum")
+    return out
+
+
+def bvsb_region_accum(z, spx, cls_w, S, invT, score_sum=None, hist=None):
+    """K1+K3: fixed-point region sums ``[B,S]`` (int64 bits of uint64) and arg-max-class histogram
+    ``[B,S,C]`` (int32 bits of uint32).  Reference: my_bvsb.py:19-27, ..._pwr_banignore.py:57-69."""
+    _need(z, "z", torch.float32)
+    _need(spx, "spx")
+    B, C, H, W = z.shape
+    if tuple(spx.shape) != (B, H, W):
+        raise ValueError("spx shape %s does not match logits %s" % (tuple(spx.shape), tuple(z.shape)))
+    if cls_w is not None:
+        _need(cls_w, "cls_w", torch.float32)
+        if cls_w.numel() != C:
+            raise ValueError("cls_w must have C=%d entries" % C)
+    if score_sum is None:
+        score_sum = torch.zeros((B, S), dtype=torch.int64, device=z.device)
+    if hist is None:
+        hist = torch.zeros((B, S, C), dtype=torch.int32, device=z.device)
+    with torch.cuda.device(z.device):
+        _lib.check(_lib.load().mas_bvsb_region_accum(
+            z.data_ptr(), spx.data_ptr(), _id_code(spx), cls_w.data_ptr() if cls_w is not None else None,
+            B, C, H, W, S, invT, score_sum.data_ptr(), hist.data_ptr(), _stream(z)), "mas_bvsb_region_accum")
+    return score_sum, hist
+
+
+def region_finalize(score_sum, hist, ban_class=-1, want_hist_i64=False):
+    """K3 tail + ban: returns (score f32, dominant i32, count i32, hist_i64 or None), shaped like
+    ``score_sum``.  Reference: ..._pwr_banignore.py:79-84."""
+    _need(score_sum, "score_sum", torch.int64)
+    _need(hist, "hist", torch.int32)
+    C = hist.shape[-1]
+    n = score_sum.numel()
+    dev = score_sum.device
+    score = torch.empty(score_sum.shape, dtype=torch.float32, device=dev)
+    dom = torch.empty(score_sum.shape, dtype=torch.int32, device=dev)
+    cnt = torch.empty(score_sum.shape, dtype=torch.int32, device=dev)
+    h64 = torch.empty(hist.shape, dtype=torch.int64, device=dev) if want_hist_i64 else None
+    with torch.cuda.device(dev):
+        _lib.check(_lib.load().mas_region_finalize(
+            score_sum.data_ptr(), hist.data_ptr(), n, C, ban_class, score.data_ptr(), dom.data_ptr(),
+            cnt.data_ptr(), h64.data_ptr() if h64 is not None else None, _stream(score_sum)),
+            "mas_region_finalize")
+    return score, dom, cnt, h64

@@ -1,0 +1,111 @@
+"""ctypes wrapper of oracle/libexact.so (the plain-C restatement in the normative arithmetic).
+
+ORACLE / TEST INFRASTRUCTURE ONLY -- see oracle/exact.c.  numpy in, numpy out.
+"""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+
+def build():
+    subprocess.check_call(["make", "-s", "-C", _HERE, "libexact.so"])
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        path = os.path.join(_HERE, "libexact.so")
+        if not os.path.exists(path):
+            build()
+        _LIB = ctypes.CDLL(path)
+    return _LIB
+
+
+def _p(a):
+    return a.ctypes.data_as(ctypes.c_void_p)
+
+
+def _c(a, dtype):
+    return np.ascontiguousarray(a, dtype=dtype)
+
+
+def inv_temperature(T):
+    """invT exactly as the product computes it: float32(1 / float32(T))."""
+    return np.float32(1.0) / np.float32(T)
+
+
+def class_prob_sum(z, invT):
+    z = _c(z, np.float32)
+    B, C, H, W = z.shape
+    out = np.zeros((B, C), dtype=np.uint64)
+    lib().exact_class_prob_sum(_p(z), B, C, H, W, ctypes.c_float(invT), _p(out))
+    return out
+
+
+def class_weight(prob_sum, HW, batch_of, n_batches, coeff):
+    prob_sum = _c(prob_sum, np.uint64)
+    n_img, C = prob_sum.shape
+    batch_of = _c(batch_of, np.int32)
+    cum = np.zeros(C, dtype=np.float64)
+    w = np.zeros(C, dtype=np.float32)
+    lib().exact_class_weight(_p(prob_sum), n_img, C, ctypes.c_int64(HW), _p(batch_of), n_batches,
+                             ctypes.c_double(coeff), _p(cum), _p(w))
+    return cum, w
+
+
+def bvsb_region_accum(z, spx, cls_w, S, invT):
+    z = _c(z, np.float32)
+    spx = _c(spx, np.int64)
+    B, C, H, W = z.shape
+    ssum = np.zeros((B, S), dtype=np.uint64)
+    hist = np.zeros((B, S, C), dtype=np.uint32)
+    w = None if cls_w is None else _c(cls_w, np.float32)
+    lib().exact_bvsb_region_accum(_p(z), _p(spx), None if w is None else _p(w), B, C, H, W, S,
+                                  ctypes.c_float(invT), _p(ssum), _p(hist))
+    return ssum, hist
+
+
+def region_finalize(score_sum, hist, ban_class):
+    score_sum = _c(score_sum, np.uint64)
+    hist = _c(hist, np.uint32)
+    C = hist.shape[-1]
+    n = score_sum.size
+    score = np.zeros(score_sum.shape, dtype=np.float32)
+    dom = np.zeros(score_sum.shape, dtype=np.int32)
+    cnt = np.zeros(score_sum.shape, dtype=np.uint32)
+    lib().exact_region_finalize(_p(score_sum), _p(hist), ctypes.c_int64(n), C, ban_class, _p(score), _p(dom), _p(cnt))
+    return score, dom, cnt
+
+
+def expf(x):
+    x = _c(x, np.float32)
+    y = np.empty_like(x)
+    lib().exact_expf_array(_p(x), _p(y), ctypes.c_int64(x.size))
+    return y
+
+
+def logf(x):
+    x = _c(x, np.float32)
+    y = np.empty_like(x)
+    lib().exact_logf_array(_p(x), _p(y), ctypes.c_int64(x.size))
+    return y
+
+
+def fix(x, frac):
+    x = _c(x, np.float32)
+    y = np.empty(x.shape, dtype=np.uint64)
+    lib().exact_fix_array(_p(x), frac, _p(y), ctypes.c_int64(x.size))
+    return y
+
+
+def softmax_rows(z, invT):
+    z = _c(z, np.float32)
+    n, C = z.shape
+    p = np.empty_like(z)
+    lib().exact_softmax_rows(_p(z), ctypes.c_int64(n), C, ctypes.c_float(invT), _p(p))
+    return p

@@ -1,0 +1,113 @@
+"""GPU parity: HIP scorer kernels (through the C ABI) vs the plain-C restatement (oracle/exact.c).
+Bit-exact on every output -- integer AND float -- because both sides evaluate the arithmetic of
+csrc/detmath.h and accumulate in fixed point."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from mulactseg_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+
+def _gpu():
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from mulactseg_amd import ops
+    return ops
+
+
+def _case(seed, B, C, H, W, S):
+    z = synth.logits(seed, B, C, H, W)
+    spx = np.stack([synth.superpixel_map(seed * 31 + i, H, W, S) for i in range(B)])
+    return z, spx
+
+
+CASES = [
+    # B, C, H, W, S
+    (2, 20, 64, 512, 128),      # vector path, two tile columns
+    (3, 20, 48, 64, 64),        # narrower than a tile
+    (2, 21, 33, 37, 150),       # VOC-like, odd sizes -> scalar path
+    (1, 19, 40, 260, 32),       # stripped channel count, ragged tile edge
+    (2, 7, 24, 36, 16),         # generic (runtime-C) instantiation
+    (1, 20, 256, 1024, 2048),   # Cityscapes-like density of regions
+]
+
+
+@pytest.mark.parametrize("B,C,H,W,S", CASES)
+@pytest.mark.parametrize("weighted", [False, True])
+def test_region_accum_bit_exact(B, C, H, W, S, weighted):
+    ops = _gpu()
+    from oracle import exact
+    z, spx = _case(100 + C + W, B, C, H, W, S)
+    invT = ops.inv_temperature(0.1)
+    w = None
+    if weighted:
+        w = (np.random.RandomState(5).uniform(0.2, 1.0, size=C)).astype(np.float32)
+    es, eh = exact.bvsb_region_accum(z, spx, w, S, np.float32(invT))
+    zt = torch.from_numpy(z).cuda()
+    wt = torch.from_numpy(w).cuda() if weighted else None
+    for dtype in (torch.int64, torch.int32, torch.int16):
+        st = torch.from_numpy(spx).to(dtype).cuda()
+        gs, gh = ops.bvsb_region_accum(zt, st, wt, S, invT)
+        assert np.array_equal(gs.cpu().numpy().view(np.uint64), es), dtype
+        assert np.array_equal(gh.cpu().numpy().view(np.uint32), eh), dtype
+    score, dom, cnt, h64 = ops.region_finalize(gs, gh, ban_class=C - 1, want_hist_i64=True)
+    escore, edom, ecnt = exact.region_finalize(es, eh, C - 1)
+    assert np.array_equal(score.cpu().numpy(), escore)
+    assert np.array_equal(dom.cpu().numpy(), edom)
+    assert np.array_equal(cnt.cpu().numpy().view(np.uint32), ecnt)
+    assert np.array_equal(h64.cpu().numpy(), eh.astype(np.int64))
+    assert int(cnt.sum()) == B * H * W
+
+
+@pytest.mark.parametrize("B,C,H,W,S", CASES)
+def test_class_prob_sum_bit_exact(B, C, H, W, S):
+    ops = _gpu()
+    from oracle import exact
+    z, _ = _case(200 + C + W, B, C, H, W, S)
+    invT = ops.inv_temperature(0.1)
+    e = exact.class_prob_sum(z, np.float32(invT))
+    g = ops.class_prob_sum(torch.from_numpy(z).cuda(), invT)
+    assert np.array_equal(g.cpu().numpy().view(np.uint64), e)
+    # probabilities sum to one: the integer sums add up to about HW * 2^31 per image
+    tot = g.cpu().numpy().view(np.uint64).sum(axis=1).astype(np.float64) / 2.0 ** 31 / (H * W)
+    assert np.all(np.abs(tot - 1.0) < 1e-5)
+
+
+def test_out_of_range_ids_are_skipped():
+    ops = _gpu()
+    from oracle import exact
+    B, C, H, W, S = 1, 20, 32, 256, 16
+    z, spx = _case(7, B, C, H, W, S)
+    spx[:, :, 200:] = S          # pad id, like training crops
+    spx[:, 5, :10] = -1
+    invT = ops.inv_temperature(0.1)
+    es, eh = exact.bvsb_region_accum(z, spx, None, S, np.float32(invT))
+    gs, gh = ops.bvsb_region_accum(torch.from_numpy(z).cuda(), torch.from_numpy(spx).cuda(), None, S, invT)
+    assert np.array_equal(gs.cpu().numpy().view(np.uint64), es)
+    assert np.array_equal(gh.cpu().numpy().view(np.uint32), eh)
+    assert int(gh.sum()) == int((spx >= 0).sum() - (spx >= S).sum())
+
+
+def test_exact_tie_lowest_index_wins():
+    ops = _gpu()
+    B, C, H, W, S = 1, 20, 8, 64, 4
+    z = np.zeros((B, C, H, W), dtype=np.float32)       # every class ties everywhere
+    spx = np.zeros((B, H, W), dtype=np.int64)
+    gs, gh = ops.bvsb_region_accum(torch.from_numpy(z).cuda(), torch.from_numpy(spx).cuda(), None, S,
+                                   ops.inv_temperature(0.1))
+    h = gh.cpu().numpy()
+    assert h[0, 0, 0] == H * W and h.sum() == H * W     # top1 = class 0
+    score, dom, cnt, _ = ops.region_finalize(gs, gh)
+    assert abs(float(score[0, 0]) - 1.0) < 1e-6         # p2/p1 = 1 (+1e-8)
+    assert float(score[0, 1]) == 0.0 and int(dom[0, 1]) == 0
+
+
+def test_cpu_tensor_is_refused():
+    ops = _gpu()
+    from mulactseg_amd import _lib
+    with pytest.raises(_lib.MulActSegHipError):
+        ops.class_prob_sum(torch.zeros(1, 20, 4, 4), 10.0)
