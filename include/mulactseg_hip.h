@@ -83,6 +83,65 @@ int mas_region_finalize(const uint64_t* score_sum, const uint32_t* hist, int64_t
                         float* score /* [n_regions] */, int32_t* dominant, uint32_t* count, int64_t* hist_i64,
                         void* stream);
 
+/* =============================================================================================
+ * Stage-1 partial-label losses (K5 merged-positive CE, K6 group / MIL max-pool CE)
+ * ============================================================================================= */
+
+/* `flags` of the loss entry points */
+#define MAS_LOSS_CE 1               /* compute the merged-positive CE sums */
+#define MAS_LOSS_GROUP 2            /* compute the group (max-pool) loss */
+#define MAS_LOSS_GROUP_ONLY_MULTI 4 /* group loss only over superpixels with > 1 target bit
+                                       (GroupMultiLabelCE_onlymulti, ..._mclossablation2.py:36,51-53) */
+#define MAS_LOSS_DECOMP 8           /* separate one-hot (ce) / multi-hot (mc) sums and normalisers
+                                       (OnehotCEMultihotChoice, ..._lossdecomp.py:58-72); otherwise one
+                                       merged sum (MultiChoiceCE_, active_joint_multi_predignore.py:59-61) */
+
+/* layout of the caller-zeroed accumulator `acc` (8 x uint64) */
+#define MAS_ACC_SUM_CE 0     /* fixed point, 32 fractional bits */
+#define MAS_ACC_SUM_MC 1
+#define MAS_ACC_N_CE 2
+#define MAS_ACC_N_MC 3
+#define MAS_ACC_N_EMPTY 4    /* selected pixels whose superpixel has no target bit (the reference asserts
+                                there are none, ..._lossdecomp.py:67) */
+#define MAS_ACC_SUM_GROUP 5
+#define MAS_ACC_N_GROUP 6
+#define MAS_ACC_WORDS 8
+
+/* Multi-hot target rows u8 [n_rows, cols_stored] -> one bit mask per row over the first `cols_used`
+ * columns (cols_used = cols_stored for the "predignore" losses, cols_stored-1 for the base classes of
+ * utils/loss.py:104,124,571 which drop the last column). */
+int mas_target_bits(const uint8_t* targets, int64_t n_rows, int cols_stored, int cols_used,
+                    uint32_t* bits /* [n_rows] */, void* stream);
+
+/* Forward scan.  Replaces the bodies of
+ *   OnehotCEMultihotChoice.forward   trainer/active_joint_multi_predignore_lossdecomp.py:21-72
+ *   GroupMultiLabelCE_onlymulti.fwd  trainer/active_joint_multi_predignore_mclossablation2.py:22-75
+ *   (and MultiChoiceCE_/GroupMultiLabelCE_, utils/loss.py base classes via `flags`).
+ * z [N,C,H,W] f32; spx [N,H,W]; mask [N,H,W] u8/bool (selected pixels); bits [N,S] from mas_target_bits.
+ * Adds fixed-point sums / counts into acc[0..4]; fills gmax [N,S,C] (caller-zeroed) with packed words
+ * (float bits of max_p softmax_c) << 32 | (0xffffffff - arg pixel index), 0 = no entry. */
+int mas_partial_loss_fwd(const float* z, const void* spx, int spx_dtype, const uint8_t* mask, const uint32_t* bits,
+                         int N, int C, int H, int W, int S, float invT, int flags,
+                         uint64_t* gmax /* [N,S,C] */, uint64_t* acc /* [8] */, void* stream);
+
+/* sum over table entries of -log(max + 1e-8) and their count -> acc[5], acc[6]
+ * (..._mclossablation2.py:67-73). */
+int mas_group_finalize(const uint64_t* gmax, int64_t n_entries, uint64_t* acc, void* stream);
+
+/* losses[0..2] = ce, mc, group (DECOMP) or merged-positive, 0, group: sum / (1 + n), f32 on device. */
+int mas_loss_values(const uint64_t* acc, int flags, float* losses /* [3] */, void* stream);
+
+/* scale[k] = grad_out[k] / (1 + n_k): the factor the backward scan multiplies in (device-side, so the
+ * training step needs no host synchronisation between forward and backward). */
+int mas_loss_scales(const uint64_t* acc, const float* grad_out /* [3] */, int flags, float* scale /* [3] */, void* stream);
+
+/* Backward scan: writes dz [N,C,H,W] completely (zeros outside the mask).  Autograd equivalent of the
+ * reference losses; the group loss sends gradient only to the arg-max pixel of each (superpixel, class)
+ * (torch_scatter scatter_max backward). */
+int mas_partial_loss_bwd(const float* z, const void* spx, int spx_dtype, const uint8_t* mask, const uint32_t* bits,
+                         const uint64_t* gmax, const float* scale /* [3] */,
+                         int N, int C, int H, int W, int S, float invT, int flags, float* dz, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

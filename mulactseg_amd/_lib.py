@@ -12,6 +12,8 @@ LIB_PATH = os.path.join(_HERE, "libmulactseg_hip.so")
 ID_I64, ID_I32, ID_U16 = 0, 1, 2
 MAX_CLASSES = 32
 SCORE_FRAC, PROB_FRAC, LOSS_FRAC = 40, 31, 32
+LOSS_CE, LOSS_GROUP, LOSS_GROUP_ONLY_MULTI, LOSS_DECOMP = 1, 2, 4, 8
+ACC_WORDS = 8
 
 _c = ctypes
 _vp, _i, _f, _i64 = _c.c_void_p, _c.c_int, _c.c_float, _c.c_int64
@@ -23,6 +25,12 @@ SIGNATURES = {
     "mas_class_prob_sum": (_i, [_vp, _i, _i, _i, _i, _f, _vp, _vp]),
     "mas_bvsb_region_accum": (_i, [_vp, _vp, _i, _vp, _i, _i, _i, _i, _i, _f, _vp, _vp, _vp]),
     "mas_region_finalize": (_i, [_vp, _vp, _i64, _i, _i, _vp, _vp, _vp, _vp, _vp]),
+    "mas_target_bits": (_i, [_vp, _i64, _i, _i, _vp, _vp]),
+    "mas_partial_loss_fwd": (_i, [_vp, _vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _f, _i, _vp, _vp, _vp]),
+    "mas_group_finalize": (_i, [_vp, _i64, _vp, _vp]),
+    "mas_loss_values": (_i, [_vp, _i, _vp, _vp]),
+    "mas_loss_scales": (_i, [_vp, _vp, _i, _vp, _vp]),
+    "mas_partial_loss_bwd": (_i, [_vp, _vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _i, _vp, _vp]),
 }
 
 _lib = None

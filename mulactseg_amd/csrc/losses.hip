@@ -1,0 +1,479 @@
+// losses.hip -- stage-1 partial-label losses (K5 merged-positive CE, K6 group/MIL max-pool CE) for gfx950.
+//
+//   k_target_bits        multi-hot target rows u8[rows, cols] -> one u32 bit mask per superpixel.
+//   k_partial_loss_fwd   ONE streaming pass over mask + ids (+ logits of the selected pixels only):
+//                        per-pixel softmax in registers, fixed-point CE sums, and the segmented
+//                        per-(superpixel, class) max with arg-pixel through a per-workgroup LDS table
+//                        of packed (prob bits << 32 | ~pixel) words combined with 64-bit atomic max.
+//   k_group_finalize     -log(max + eps) over the (superpixel, class) table.
+//   k_loss_values        fixed-point sums -> the reference's mean-normalised f32 losses.
+//   k_loss_scales        upstream gradients / (1 + n) -> per-loss scale factors (no host sync).
+//   k_partial_loss_bwd   one pass writing dz[N,C,H,W] completely (zeros off-mask), softmax recomputed,
+//                        group-loss gradient gathered from the arg-pixel table (no atomics).
+//
+// Reference semantics: trainer/active_joint_multi_predignore_lossdecomp.py:21-72 (OnehotCEMultihotChoice),
+// trainer/active_joint_multi_predignore_mclossablation2.py:22-79 (GroupMultiLabelCE_onlymulti),
+// trainer/active_joint_multi_predignore.py:21-128, utils/loss.py:91-141,543-588 (base classes).
+#include "common.h"
+
+namespace {
+
+constexpr int kThreads = 256;
+constexpr int kTileW = 256;
+constexpr int kTileH = 16;
+constexpr int kLogSlots = 6;
+constexpr int kSlots = 1 << kLogSlots;
+
+// accumulator slots of the u64 `acc` array
+enum { ACC_SUM_CE = 0, ACC_SUM_MC = 1, ACC_N_CE = 2, ACC_N_MC = 3, ACC_N_EMPTY = 4, ACC_SUM_GROUP = 5, ACC_N_GROUP = 6 };
+
+__device__ __forceinline__ mas_u64 pack_max(float p, unsigned pix) {
+    return ((mas_u64)mas_f2u(p) << 32) | (mas_u64)(0xffffffffu - pix);
+}
+
+__device__ __forceinline__ int table_slot(int* keys, int id) {
+    unsigned h = ((unsigned)id * 2654435769u) >> (32 - kLogSlots);
+    for (int probe = 0; probe < kSlots; ++probe) {
+        int k = __hip_atomic_load(&keys[h], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (k == id) return (int)h;
+        if (k == -1) {
+            int old = atomicCAS(&keys[h], -1, id);
+            if (old == -1 || old == id) return (int)h;
+        }
+        h = (h + 1) & (kSlots - 1);
+    }
+    return -1;
+}
+
+__global__ __launch_bounds__(kThreads) void k_target_bits(const unsigned char* __restrict__ tgt, long long n_rows,
+                                                           int cols_stored, int cols_used, unsigned* __restrict__ bits) {
+    const long long r = (long long)blockIdx.x * kThreads + threadIdx.x;
+    if (r >= n_rows) return;
+    const unsigned char* t = tgt + r * cols_stored;
+    unsigned b = 0;
+    for (int c = 0; c < cols_used; ++c) b |= (t[c] ? 1u : 0u) << c;
+    bits[r] = b;
+}
+
+template <int CT, bool EXACT, typename IdT, bool VEC>
+__global__ __launch_bounds__(kThreads) void k_partial_loss_fwd(const float* __restrict__ z, const IdT* __restrict__ spx,
+                                                                const unsigned char* __restrict__ mask,
+                                                                const unsigned* __restrict__ bits, int C, int H, int W, int S,
+                                                                float invT, int flags, int tiles_x, int tiles_y,
+                                                                mas_u64* __restrict__ gmax, mas_u64* __restrict__ acc) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    mas_u64* t_max = reinterpret_cast<mas_u64*>(smem);                       // [kSlots * C]
+    int* t_keys = reinterpret_cast<int*>(smem + sizeof(mas_u64) * kSlots * C);  // [kSlots]
+    mas_u64* s_red = reinterpret_cast<mas_u64*>(smem + sizeof(mas_u64) * kSlots * C + sizeof(int) * kSlots);  // [4][5]
+
+    const bool do_ce = flags & MAS_LOSS_CE;
+    const bool do_group = flags & MAS_LOSS_GROUP;
+    const bool only_multi = flags & MAS_LOSS_GROUP_ONLY_MULTI;
+    if (do_group) {
+        for (int i = threadIdx.x; i < kSlots; i += kThreads) t_keys[i] = -1;
+        for (int i = threadIdx.x; i < kSlots * C; i += kThreads) t_max[i] = 0;
+        __syncthreads();
+    }
+
+    int bid = blockIdx.x;
+    const int tx = bid % tiles_x; bid /= tiles_x;
+    const int ty = bid % tiles_y;
+    const int n = bid / tiles_y;
+    const int HW = H * W;
+    const float* zb = z + (size_t)n * C * HW;
+    const IdT* sb = spx + (size_t)n * HW;
+    const unsigned char* mb = mask + (size_t)n * HW;
+    const unsigned* bb = bits + (size_t)n * S;
+    mas_u64* gm = gmax + (size_t)n * S * C;
+    const int lane = threadIdx.x & (MAS_WAVE - 1);
+    const int wave = threadIdx.x / MAS_WAVE;
+
+    mas_u64 sum_ce = 0, sum_mc = 0;
+    unsigned n_ce = 0, n_mc = 0, n_empty = 0;
+
+    for (int it = 0; it < kTileH / 4; ++it) {
+        const int y = ty * kTileH + it * 4 + wave;
+        if (y >= H) break;
+        const size_t row = (size_t)y * W;
+        int xs[4], id[4];
+        bool m[4];
+        bool any = false;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            xs[k] = tx * kTileW + (VEC ? (lane * 4 + k) : (k * MAS_WAVE + lane));
+            m[k] = (xs[k] < W) && (mb[row + (xs[k] < W ? xs[k] : 0)] != 0);
+            id[k] = m[k] ? mas_load_id(sb, row + xs[k]) : -1;
+            if (id[k] < 0 || id[k] >= S) m[k] = false;
+            any |= m[k];
+        }
+        if (!__any(any)) continue;       // wave-uniform: nothing selected here, no logit traffic at all
+        float v[4][CT];
+#pragma unroll
+        for (int c = 0; c < CT; ++c) {
+            if (VEC) {
+                float4 q = make_float4(0.f, 0.f, 0.f, 0.f);
+                if ((EXACT || c < C) && any) q = *reinterpret_cast<const float4*>(zb + (size_t)c * HW + row + xs[0]);
+                v[0][c] = q.x; v[1][c] = q.y; v[2][c] = q.z; v[3][c] = q.w;
+            } else {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) v[k][c] = ((EXACT || c < C) && m[k]) ? zb[(size_t)c * HW + row + xs[k]] : 0.f;
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            if (!m[k]) continue;
+            mas_softmax_regs<CT, EXACT>(v[k], C, invT);
+            const unsigned Y = bb[id[k]];
+            const int nb = __popc(Y);
+            if (nb == 0) { n_empty += 1; continue; }
+            if (do_ce) {
+                float pos = 0.0f;
+#pragma unroll
+                for (int c = 0; c < CT; ++c)
+                    if (EXACT || c < C) pos = ((Y >> c) & 1u) ? (pos + v[k][c]) : pos;
+                const float l = -mas_logf(pos + 1e-8f);
+                const mas_u64 q = mas_fix(l, MAS_LOSS_FRAC);
+                if (nb == 1) { sum_ce += q; n_ce += 1; } else { sum_mc += q; n_mc += 1; }
+            }
+            if (do_group && (!only_multi || nb > 1)) {
+                const unsigned pix = (unsigned)(row + xs[k]);
+                const int s = table_slot(t_keys, id[k]);
+#pragma unroll
+                for (int c = 0; c < CT; ++c) {
+                    if ((EXACT || c < C) && ((Y >> c) & 1u)) {
+                        const mas_u64 w = pack_max(v[k][c], pix);
+                        if (s >= 0) atomicMax(&t_max[s * C + c], w);
+                        else atomicMax(&gm[(size_t)id[k] * C + c], w);
+                    }
+                }
+            }
+        }
+    }
+
+    // block reduction of the five scalar accumulators
+    mas_u64 r[5] = {sum_ce, sum_mc, (mas_u64)n_ce, (mas_u64)n_mc, (mas_u64)n_empty};
+#pragma unroll
+    for (int i = 0; i < 5; ++i) {
+#pragma unroll
+        for (int off = MAS_WAVE / 2; off > 0; off >>= 1) r[i] += __shfl_down(r[i], off, MAS_WAVE);
+        if (lane == 0) s_red[wave * 5 + i] = r[i];
+    }
+    __syncthreads();
+    if (threadIdx.x < 5) {
+        mas_u64 a = 0;
+        for (int w = 0; w < kThreads / MAS_WAVE; ++w) a += s_red[w * 5 + threadIdx.x];
+        if (a) atomicAdd(&acc[threadIdx.x], a);
+    }
+    if (do_group) {
+        for (int i = threadIdx.x; i < kSlots * C; i += kThreads) {
+            const mas_u64 w = t_max[i];
+            if (w) {
+                const int s = i / C;
+                atomicMax(&gm[(size_t)t_keys[s] * C + (i - s * C)], w);
+            }
+        }
+    }
+}
+
+__global__ __launch_bounds__(kThreads) void k_group_finalize(const mas_u64* __restrict__ gmax, long long n_entries,
+                                                              mas_u64* __restrict__ acc) {
+    __shared__ mas_u64 s_red[kThreads / MAS_WAVE][2];
+    mas_u64 sum = 0, cnt = 0;
+    for (long long i = (long long)blockIdx.x * kThreads + threadIdx.x; i < n_entries; i += (long long)gridDim.x * kThreads) {
+        const mas_u64 w = gmax[i];
+        const unsigned pb = (unsigned)(w >> 32);
+        if (pb) {            // a (superpixel, class) with target bit set whose max prob is non-zero
+            const float l = -mas_logf(mas_u2f(pb) + 1e-8f);
+            sum += mas_fix(l, MAS_LOSS_FRAC);
+            cnt += 1;
+        }
+    }
+    const int lane = threadIdx.x & (MAS_WAVE - 1), wave = threadIdx.x / MAS_WAVE;
+#pragma unroll
+    for (int off = MAS_WAVE / 2; off > 0; off >>= 1) {
+        sum += __shfl_down(sum, off, MAS_WAVE);
+        cnt += __shfl_down(cnt, off, MAS_WAVE);
+    }
+    if (lane == 0) { s_red[wave][0] = sum; s_red[wave][1] = cnt; }
+    __syncthreads();
+    if (threadIdx.x < 2) {
+        mas_u64 a = 0;
+        for (int w = 0; w < kThreads / MAS_WAVE; ++w) a += s_red[w][threadIdx.x];
+        if (a) atomicAdd(&acc[threadIdx.x == 0 ? ACC_SUM_GROUP : ACC_N_GROUP], a);
+    }
+}
+
+// loss = (sum * 2^-32) / (1 + n) in f64, rounded once to f32
+__device__ __forceinline__ float loss_value(mas_u64 sum, mas_u64 n) {
+    union { double d; mas_u64 u; } s;
+    s.u = (mas_u64)(1023 - MAS_LOSS_FRAC) << 52;
+    return (float)(((double)sum * s.d) / (double)(n + 1));
+}
+
+__global__ void k_loss_values(const mas_u64* __restrict__ acc, int flags, float* __restrict__ out) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    if (flags & MAS_LOSS_DECOMP) {
+        out[0] = loss_value(acc[ACC_SUM_CE], acc[ACC_N_CE]);
+        out[1] = loss_value(acc[ACC_SUM_MC], acc[ACC_N_MC]);
+    } else {
+        out[0] = loss_value(acc[ACC_SUM_CE] + acc[ACC_SUM_MC], acc[ACC_N_CE] + acc[ACC_N_MC]);
+        out[1] = 0.0f;
+    }
+    out[2] = loss_value(acc[ACC_SUM_GROUP], acc[ACC_N_GROUP]);
+}
+
+// scale_k = upstream_k / (1 + n_k)   (f32 division, correctly rounded)
+__global__ void k_loss_scales(const mas_u64* __restrict__ acc, const float* __restrict__ grad_out, int flags,
+                              float* __restrict__ scale) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    if (flags & MAS_LOSS_DECOMP) {
+        scale[0] = grad_out[0] / (float)(acc[ACC_N_CE] + 1);
+        scale[1] = grad_out[1] / (float)(acc[ACC_N_MC] + 1);
+    } else {
+        const float s = grad_out[0] / (float)(acc[ACC_N_CE] + acc[ACC_N_MC] + 1);
+        scale[0] = s;
+        scale[1] = s;
+    }
+    scale[2] = grad_out[2] / (float)(acc[ACC_N_GROUP] + 1);
+}
+
+template <int CT, bool EXACT, typename IdT, bool VEC>
+__global__ __launch_bounds__(kThreads) void k_partial_loss_bwd(const float* __restrict__ z, const IdT* __restrict__ spx,
+                                                                const unsigned char* __restrict__ mask,
+                                                                const unsigned* __restrict__ bits,
+                                                                const mas_u64* __restrict__ gmax,
+                                                                const float* __restrict__ scale, int C, int H, int W, int S,
+                                                                float invT, int flags, int tiles_x, int tiles_y,
+                                                                float* __restrict__ dz) {
+    const bool do_ce = flags & MAS_LOSS_CE;
+    const bool do_group = flags & MAS_LOSS_GROUP;
+    const bool only_multi = flags & MAS_LOSS_GROUP_ONLY_MULTI;
+    int bid = blockIdx.x;
+    const int tx = bid % tiles_x; bid /= tiles_x;
+    const int ty = bid % tiles_y;
+    const int n = bid / tiles_y;
+    const int HW = H * W;
+    const float* zb = z + (size_t)n * C * HW;
+    float* db = dz + (size_t)n * C * HW;
+    const IdT* sb = spx + (size_t)n * HW;
+    const unsigned char* mb = mask + (size_t)n * HW;
+    const unsigned* bb = bits + (size_t)n * S;
+    const mas_u64* gm = gmax + (size_t)n * S * C;
+    const int lane = threadIdx.x & (MAS_WAVE - 1);
+    const int wave = threadIdx.x / MAS_WAVE;
+    const float a_ce = scale[0] * invT, a_mc = scale[1] * invT, g6 = scale[2] * invT;
+
+    for (int it = 0; it < kTileH / 4; ++it) {
+        const int y = ty * kTileH + it * 4 + wave;
+        if (y >= H) break;
+        const size_t row = (size_t)y * W;
+        int xs[4], id[4];
+        bool ok[4], m[4];
+        bool any = false;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            xs[k] = tx * kTileW + (VEC ? (lane * 4 + k) : (k * MAS_WAVE + lane));
+            ok[k] = xs[k] < W;
+            m[k] = ok[k] && (mb[row + (ok[k] ? xs[k] : 0)] != 0);
+            id[k] = m[k] ? mas_load_id(sb, row + xs[k]) : -1;
+            if (id[k] < 0 || id[k] >= S) m[k] = false;
+            any |= m[k];
+        }
+        float v[4][CT];
+        if (__any(any)) {
+#pragma unroll
+            for (int c = 0; c < CT; ++c) {
+                if (VEC) {
+                    float4 q = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if ((EXACT || c < C) && any) q = *reinterpret_cast<const float4*>(zb + (size_t)c * HW + row + xs[0]);
+                    v[0][c] = q.x; v[1][c] = q.y; v[2][c] = q.z; v[3][c] = q.w;
+                } else {
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) v[k][c] = ((EXACT || c < C) && m[k]) ? zb[(size_t)c * HW + row + xs[k]] : 0.f;
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                unsigned Y = 0;
+                int nb = 0;
+                if (m[k]) { Y = bb[id[k]]; nb = __popc(Y); }
+                if (!m[k] || nb == 0) {
+#pragma unroll
+                    for (int c = 0; c < CT; ++c) v[k][c] = 0.0f;
+                    continue;
+                }
+                mas_softmax_regs<CT, EXACT>(v[k], C, invT);
+                float coef = 0.0f, pos = 0.0f;
+                if (do_ce) {
+#pragma unroll
+                    for (int c = 0; c < CT; ++c)
+                        if (EXACT || c < C) pos = ((Y >> c) & 1u) ? (pos + v[k][c]) : pos;
+                    coef = ((nb == 1) ? a_ce : a_mc) * (1.0f / (pos + 1e-8f));
+                }
+                // group loss: classes of Y whose arg-max pixel is this pixel
+                unsigned A = 0;
+                float u = 0.0f;
+                float t[CT];
+                if (do_group && (!only_multi || nb > 1)) {
+                    const unsigned key = 0xffffffffu - (unsigned)(row + xs[k]);
+#pragma unroll
+                    for (int c = 0; c < CT; ++c) {
+                        t[c] = 0.0f;
+                        if ((EXACT || c < C) && ((Y >> c) & 1u)) {
+                            const mas_u64 w = gm[(size_t)id[k] * C + c];
+                            if ((unsigned)w == key && (unsigned)(w >> 32) != 0u) {
+                                A |= 1u << c;
+                                t[c] = -(g6 / (v[k][c] + 1e-8f));
+                                u = u + t[c] * v[k][c];
+                            }
+                        }
+                    }
+                }
+#pragma unroll
+                for (int c = 0; c < CT; ++c) {
+                    if (EXACT || c < C) {
+                        const float p = v[k][c];
+                        const float yj = ((Y >> c) & 1u) ? 1.0f : 0.0f;
+                        float d = coef * (p * (pos - yj));
+                        if (A) {
+                            if ((A >> c) & 1u) d = d + t[c] * p;
+                            d = d - p * u;
+                        }
+                        v[k][c] = d;
+                    }
+                }
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+#pragma unroll
+                for (int c = 0; c < CT; ++c) v[k][c] = 0.0f;
+        }
+#pragma unroll
+        for (int c = 0; c < CT; ++c) {
+            if (EXACT || c < C) {
+                if (VEC) {
+                    if (ok[0]) *reinterpret_cast<float4*>(db + (size_t)c * HW + row + xs[0]) = make_float4(v[0][c], v[1][c], v[2][c], v[3][c]);
+                } else {
+#pragma unroll
+                    for (int k = 0; k < 4; ++k)
+                        if (ok[k]) db[(size_t)c * HW + row + xs[k]] = v[k][c];
+                }
+            }
+        }
+    }
+}
+
+inline size_t fwd_smem_bytes(int C) { return sizeof(mas_u64) * kSlots * (size_t)C + sizeof(int) * kSlots + sizeof(mas_u64) * 4 * 5; }
+
+struct LossArgs {
+    const float* z; const void* spx; const unsigned char* mask; const unsigned* bits;
+    int N, C, H, W, S; float invT; int flags;
+    mas_u64* gmax; mas_u64* acc; const float* scale; float* dz;
+};
+
+template <int CT, bool EXACT, typename IdT>
+int launch_loss(const LossArgs& a, bool backward, hipStream_t st) {
+    const int tiles_x = (a.W + kTileW - 1) / kTileW;
+    const int tiles_y = (a.H + kTileH - 1) / kTileH;
+    const long long nblk = (long long)a.N * tiles_x * tiles_y;
+    if (nblk <= 0 || nblk > 0x7fffffffLL) return MAS_ERR_SHAPE;
+    const IdT* ids = static_cast<const IdT*>(a.spx);
+    const bool vec = (a.W % 4 == 0) && (((uintptr_t)a.z & 15) == 0) && (!backward || (((uintptr_t)a.dz & 15) == 0));
+    const dim3 grid((unsigned)nblk), block(kThreads);
+    if (!backward) {
+        const size_t smem = fwd_smem_bytes(a.C);
+        if (vec)
+            hipLaunchKernelGGL((k_partial_loss_fwd<CT, EXACT, IdT, true>), grid, block, smem, st, a.z, ids, a.mask, a.bits, a.C, a.H,
+                               a.W, a.S, a.invT, a.flags, tiles_x, tiles_y, a.gmax, a.acc);
+        else
+            hipLaunchKernelGGL((k_partial_loss_fwd<CT, EXACT, IdT, false>), grid, block, smem, st, a.z, ids, a.mask, a.bits, a.C, a.H,
+                               a.W, a.S, a.invT, a.flags, tiles_x, tiles_y, a.gmax, a.acc);
+    } else {
+        if (vec)
+            hipLaunchKernelGGL((k_partial_loss_bwd<CT, EXACT, IdT, true>), grid, block, 0, st, a.z, ids, a.mask, a.bits, a.gmax, a.scale,
+                               a.C, a.H, a.W, a.S, a.invT, a.flags, tiles_x, tiles_y, a.dz);
+        else
+            hipLaunchKernelGGL((k_partial_loss_bwd<CT, EXACT, IdT, false>), grid, block, 0, st, a.z, ids, a.mask, a.bits, a.gmax, a.scale,
+                               a.C, a.H, a.W, a.S, a.invT, a.flags, tiles_x, tiles_y, a.dz);
+    }
+    return mas_launch_status();
+}
+
+template <int CT, bool EXACT>
+int dispatch_loss_ids(const LossArgs& a, int spx_dtype, bool backward, hipStream_t st) {
+    switch (spx_dtype) {
+        case MAS_ID_I64: return launch_loss<CT, EXACT, long long>(a, backward, st);
+        case MAS_ID_I32: return launch_loss<CT, EXACT, int>(a, backward, st);
+        case MAS_ID_U16: return launch_loss<CT, EXACT, unsigned short>(a, backward, st);
+        default: return MAS_ERR_DTYPE;
+    }
+}
+
+int dispatch_loss(const LossArgs& a, int spx_dtype, bool backward, hipStream_t st) {
+    if (a.N <= 0 || a.H <= 0 || a.W <= 0 || a.S <= 0 || (long long)a.H * a.W > 0x7fffffffLL / 2) return MAS_ERR_SHAPE;
+    if (a.C < 2 || a.C > MAS_MAX_CLASSES) return MAS_ERR_CLASSES;
+    switch (a.C) {
+        case 19: return dispatch_loss_ids<19, true>(a, spx_dtype, backward, st);
+        case 20: return dispatch_loss_ids<20, true>(a, spx_dtype, backward, st);
+        case 21: return dispatch_loss_ids<21, true>(a, spx_dtype, backward, st);
+        default: return dispatch_loss_ids<MAS_MAX_CLASSES, false>(a, spx_dtype, backward, st);
+    }
+}
+
+}  // namespace
+
+extern "C" int mas_target_bits(const uint8_t* targets, int64_t n_rows, int cols_stored, int cols_used, uint32_t* bits,
+                               void* stream) {
+    if (!targets || !bits) return MAS_ERR_NULL;
+    if (n_rows <= 0 || cols_stored <= 0) return MAS_ERR_SHAPE;
+    if (cols_used < 1 || cols_used > cols_stored || cols_used > MAS_MAX_CLASSES) return MAS_ERR_CLASSES;
+    const long long nblk = (n_rows + kThreads - 1) / kThreads;
+    hipLaunchKernelGGL(k_target_bits, dim3((unsigned)nblk), dim3(kThreads), 0, static_cast<hipStream_t>(stream), targets,
+                       (long long)n_rows, cols_stored, cols_used, bits);
+    return mas_launch_status();
+}
+
+extern "C" int mas_partial_loss_fwd(const float* z, const void* spx, int spx_dtype, const uint8_t* mask, const uint32_t* bits,
+                                    int N, int C, int H, int W, int S, float invT, int flags, uint64_t* gmax, uint64_t* acc,
+                                    void* stream) {
+    if (!z || !spx || !mask || !bits || !acc) return MAS_ERR_NULL;
+    if ((flags & MAS_LOSS_GROUP) && !gmax) return MAS_ERR_NULL;
+    LossArgs a{z, spx, mask, bits, N, C, H, W, S, invT, flags, reinterpret_cast<mas_u64*>(gmax),
+               reinterpret_cast<mas_u64*>(acc), nullptr, nullptr};
+    return dispatch_loss(a, spx_dtype, false, static_cast<hipStream_t>(stream));
+}
+
+extern "C" int mas_group_finalize(const uint64_t* gmax, int64_t n_entries, uint64_t* acc, void* stream) {
+    if (!gmax || !acc) return MAS_ERR_NULL;
+    if (n_entries <= 0) return MAS_ERR_SHAPE;
+    long long nblk = (n_entries + kThreads - 1) / kThreads;
+    if (nblk > 1024) nblk = 1024;
+    hipLaunchKernelGGL(k_group_finalize, dim3((unsigned)nblk), dim3(kThreads), 0, static_cast<hipStream_t>(stream),
+                       reinterpret_cast<const mas_u64*>(gmax), (long long)n_entries, reinterpret_cast<mas_u64*>(acc));
+    return mas_launch_status();
+}
+
+extern "C" int mas_loss_values(const uint64_t* acc, int flags, float* losses, void* stream) {
+    if (!acc || !losses) return MAS_ERR_NULL;
+    hipLaunchKernelGGL(k_loss_values, dim3(1), dim3(64), 0, static_cast<hipStream_t>(stream),
+                       reinterpret_cast<const mas_u64*>(acc), flags, losses);
+    return mas_launch_status();
+}
+
+extern "C" int mas_loss_scales(const uint64_t* acc, const float* grad_out, int flags, float* scale, void* stream) {
+    if (!acc || !grad_out || !scale) return MAS_ERR_NULL;
+    hipLaunchKernelGGL(k_loss_scales, dim3(1), dim3(64), 0, static_cast<hipStream_t>(stream),
+                       reinterpret_cast<const mas_u64*>(acc), grad_out, flags, scale);
+    return mas_launch_status();
+}
+
+extern "C" int mas_partial_loss_bwd(const float* z, const void* spx, int spx_dtype, const uint8_t* mask, const uint32_t* bits,
+                                    const uint64_t* gmax, const float* scale, int N, int C, int H, int W, int S, float invT,
+                                    int flags, float* dz, void* stream) {
+    if (!z || !spx || !mask || !bits || !scale || !dz) return MAS_ERR_NULL;
+    if ((flags & MAS_LOSS_GROUP) && !gmax) return MAS_ERR_NULL;
+    LossArgs a{z, spx, mask, bits, N, C, H, W, S, invT, flags,
+               const_cast<mas_u64*>(reinterpret_cast<const mas_u64*>(gmax)), nullptr, scale, dz};
+    return dispatch_loss(a, spx_dtype, true, static_cast<hipStream_t>(stream));
+}

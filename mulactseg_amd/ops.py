@@ -93,3 +93,71 @@ def region_finalize(score_sum, hist, ban_class=-1, want_hist_i64=False):
             cnt.data_ptr(), h64.data_ptr() if h64 is not None else None, _stream(score_sum)),
             "mas_region_finalize")
     return score, dom, cnt, h64
+
+
+# ------------------------------------------------------------------------------------------------
+# stage-1 partial-label losses
+# ------------------------------------------------------------------------------------------------
+def target_bits(targets, cols_used=None):
+    """u8 multi-hot rows [..., cols] -> int32 bit masks [...] over the first ``cols_used`` columns."""
+    _need(targets, "targets", torch.uint8)
+    cols = targets.shape[-1]
+    cols_used = cols if cols_used is None else cols_used
+    bits = torch.empty(targets.shape[:-1], dtype=torch.int32, device=targets.device)
+    with torch.cuda.device(targets.device):
+        _lib.check(_lib.load().mas_target_bits(targets.data_ptr(), bits.numel(), cols, cols_used, bits.data_ptr(),
+                                               _stream(targets)), "mas_target_bits")
+    return bits
+
+
+def _mask_u8(mask):
+    if mask.dtype == torch.bool:
+        mask = mask.view(torch.uint8)
+    return _need(mask, "spmasks", torch.uint8)
+
+
+def partial_loss_fwd(z, spx, mask, bits, invT, flags):
+    """Forward scan + group finalize + loss values.  Returns (losses f32[3], acc i64[8], gmax i64[N,S,C])
+    -- all on the device, no host synchronisation."""
+    _need(z, "inputs", torch.float32)
+    _need(spx, "superpixels")
+    mask = _mask_u8(mask)
+    _need(bits, "bits", torch.int32)
+    N, C, H, W = z.shape
+    S = bits.shape[1]
+    if tuple(spx.shape) != (N, H, W) or tuple(mask.shape) != (N, H, W) or bits.shape[0] != N:
+        raise ValueError("shape mismatch between inputs %s, superpixels %s, spmasks %s, targets %s"
+                         % (tuple(z.shape), tuple(spx.shape), tuple(mask.shape), tuple(bits.shape)))
+    dev = z.device
+    acc = torch.zeros(_lib.ACC_WORDS, dtype=torch.int64, device=dev)
+    gmax = torch.zeros((N, S, C), dtype=torch.int64, device=dev) if flags & _lib.LOSS_GROUP else None
+    losses = torch.empty(3, dtype=torch.float32, device=dev)
+    lib = _lib.load()
+    with torch.cuda.device(dev):
+        st = _stream(z)
+        _lib.check(lib.mas_partial_loss_fwd(z.data_ptr(), spx.data_ptr(), _id_code(spx), mask.data_ptr(), bits.data_ptr(),
+                                            N, C, H, W, S, invT, flags, gmax.data_ptr() if gmax is not None else None,
+                                            acc.data_ptr(), st), "mas_partial_loss_fwd")
+        if gmax is not None:
+            _lib.check(lib.mas_group_finalize(gmax.data_ptr(), gmax.numel(), acc.data_ptr(), st), "mas_group_finalize")
+        _lib.check(lib.mas_loss_values(acc.data_ptr(), flags, losses.data_ptr(), st), "mas_loss_values")
+    return losses, acc, gmax
+
+
+def partial_loss_bwd(z, spx, mask, bits, gmax, acc, grad_out, invT, flags):
+    """Backward scan: dz [N,C,H,W] for upstream gradients ``grad_out`` f32[3] (device tensor)."""
+    mask = _mask_u8(mask)
+    _need(grad_out, "grad_out", torch.float32)
+    N, C, H, W = z.shape
+    S = bits.shape[1]
+    dev = z.device
+    scale = torch.empty(3, dtype=torch.float32, device=dev)
+    dz = torch.empty_like(z)
+    lib = _lib.load()
+    with torch.cuda.device(dev):
+        st = _stream(z)
+        _lib.check(lib.mas_loss_scales(acc.data_ptr(), grad_out.data_ptr(), flags, scale.data_ptr(), st), "mas_loss_scales")
+        _lib.check(lib.mas_partial_loss_bwd(z.data_ptr(), spx.data_ptr(), _id_code(spx), mask.data_ptr(), bits.data_ptr(),
+                                            gmax.data_ptr() if gmax is not None else None, scale.data_ptr(),
+                                            N, C, H, W, S, invT, flags, dz.data_ptr(), st), "mas_partial_loss_bwd")
+    return dz

@@ -1,0 +1,178 @@
+"""Loss modules of the reference's ``utils/loss.py`` (and the production subclasses defined inside the
+reference's trainer files), backed by the HIP kernels of ``csrc/losses.hip``.
+
+Same class names, constructor arguments and ``forward(inputs, targets, superpixels, spmasks)``
+signature as the reference, so the trainer plugins read like the reference's:
+
+=============================  =================================================================
+class here                     reference definition
+=============================  =================================================================
+``MyCrossEntropyLoss``         ``utils/loss.py:10-21``
+``JointMultiLoss``             ``utils/loss.py:44-63``  ('mean' reduction only, Appendix D)
+``GroupMultiLabelCE``          ``utils/loss.py:81-141``  (drops the last target column)
+``MultiChoiceCE``              ``utils/loss.py:535-588`` (drops the last target column)
+``MultiChoiceCE_``             ``trainer/active_joint_multi_predignore.py:17-73``
+``GroupMultiLabelCE_``         ``trainer/active_joint_multi_predignore.py:74-128``
+``OnehotCEMultihotChoice``     ``trainer/active_joint_multi_predignore_lossdecomp.py:16-72``
+``GroupMultiLabelCE_onlymulti````trainer/active_joint_multi_predignore_mclossablation2.py:17-79``
+``FusedPartialLabelLoss``      (new) the three production losses from ONE forward scan and ONE
+                               backward scan -- what ``train_impl`` of the production trainer uses
+=============================  =================================================================
+
+Inputs must be ROCm tensors; there is no CPU path (``_lib.MulActSegHipError`` otherwise).
+"""
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from .. import _lib, ops
+
+
+class _PartialLossFn(torch.autograd.Function):
+    """(ce, mc, group) = f(inputs): forward scan saves the fixed-point accumulators and the arg-pixel
+    table; backward is one scan writing dz.  No host synchronisation in either direction."""
+
+    @staticmethod
+    def forward(ctx, inputs, bits, superpixels, spmasks, invT, flags):
+        z = inputs.contiguous()
+        spx = superpixels.contiguous()
+        msk = spmasks.contiguous()
+        losses, acc, gmax = ops.partial_loss_fwd(z, spx, msk, bits, invT, flags)
+        ctx.save_for_backward(z, spx, msk, bits, acc, gmax if gmax is not None else acc)
+        ctx.has_gmax = gmax is not None
+        ctx.invT, ctx.flags = invT, flags
+        ctx.mark_non_differentiable(acc)
+        return losses[0], losses[1], losses[2], acc
+
+    @staticmethod
+    def backward(ctx, g_ce, g_mc, g_group, _g_acc):
+        z, spx, msk, bits, acc, gmax = ctx.saved_tensors
+        grad_out = torch.stack([g_ce, g_mc, g_group]).to(torch.float32).contiguous()
+        dz = ops.partial_loss_bwd(z, spx, msk, bits, gmax if ctx.has_gmax else None, acc, grad_out, ctx.invT, ctx.flags)
+        return dz, None, None, None, None, None
+
+
+def _run(inputs, targets, superpixels, spmasks, temp, flags, drop_last_column):
+    if targets.dtype != torch.uint8:
+        targets = targets.to(torch.uint8)
+    cols = targets.shape[-1]
+    bits = ops.target_bits(targets.contiguous(), cols - 1 if drop_last_column else cols)
+    return _PartialLossFn.apply(inputs, bits, superpixels, spmasks, ops.inv_temperature(temp), flags)
+
+
+class MyCrossEntropyLoss(nn.CrossEntropyLoss):
+    """Cross entropy with a temperature (stage-2 training) -- reference ``utils/loss.py:10-21``."""
+
+    def __init__(self, ignore_index, reduction='mean', temperature=1.0):
+        super().__init__(ignore_index=ignore_index, reduction=reduction)
+        self.temperature = temperature
+
+    def forward(self, input, target):
+        return super().forward(input / self.temperature, target)
+
+
+class MultiChoiceCE(nn.Module):
+    """Merged-positive CE -- reference ``utils/loss.py:535-588`` (last target column dropped)."""
+    _drop_last = True
+    _flags = _lib.LOSS_CE
+
+    def __init__(self, num_class, temperature=1.0, reduction='mean'):
+        super().__init__()
+        if reduction != 'mean':
+            raise NotImplementedError("only reduction='mean' is on the hot path")
+        self.num_class = num_class
+        self.reduction = reduction
+        self.eps = 1e-8
+        self.temp = temperature
+
+    def forward(self, inputs, targets, superpixels, spmasks):
+        ce, _, _, _ = _run(inputs, targets, superpixels, spmasks, self.temp, self._flags, self._drop_last)
+        return ce
+
+
+class MultiChoiceCE_(MultiChoiceCE):
+    """All target columns (incl. "undefined") -- ``trainer/active_joint_multi_predignore.py:17-73``."""
+    _drop_last = False
+
+
+class OnehotCEMultihotChoice(MultiChoiceCE):
+    """Returns (ce over one-hot superpixels, mc over multi-hot superpixels) --
+    ``trainer/active_joint_multi_predignore_lossdecomp.py:16-72``."""
+    _drop_last = False
+    _flags = _lib.LOSS_CE | _lib.LOSS_DECOMP
+
+    def forward(self, inputs, targets, superpixels, spmasks):
+        ce, mc, _, _ = _run(inputs, targets, superpixels, spmasks, self.temp, self._flags, self._drop_last)
+        return ce, mc
+
+
+class GroupMultiLabelCE(nn.Module):
+    """Group / MIL loss: -log of the per-superpixel class-wise max probability --
+    reference ``utils/loss.py:81-141`` (last target column dropped)."""
+    _drop_last = True
+    _flags = _lib.LOSS_GROUP
+
+    def __init__(self, args, num_class, num_superpixel, temperature=1.0, reduction='mean'):
+        super().__init__()
+        if reduction != 'mean':
+            raise NotImplementedError("only reduction='mean' is on the hot path")
+        self.args = args
+        self.num_class = num_class
+        self.num_superpixel = num_superpixel
+        self.eps = 1e-8
+        self.temp = temperature
+        self.reduction = reduction
+
+    def forward(self, inputs, targets, superpixels, spmasks):
+        if targets.shape[1] != self.num_superpixel:
+            raise ValueError("targets carry %d superpixels, loss was built for %d" % (targets.shape[1], self.num_superpixel))
+        _, _, group, _ = _run(inputs, targets, superpixels, spmasks, self.temp, self._flags, self._drop_last)
+        return group
+
+
+class GroupMultiLabelCE_(GroupMultiLabelCE):
+    """``trainer/active_joint_multi_predignore.py:74-128``."""
+    _drop_last = False
+
+
+class GroupMultiLabelCE_onlymulti(GroupMultiLabelCE_):
+    """Only superpixels with more than one target bit --
+    ``trainer/active_joint_multi_predignore_mclossablation2.py:17-79``."""
+    _flags = _lib.LOSS_GROUP | _lib.LOSS_GROUP_ONLY_MULTI
+
+
+class JointMultiLoss(nn.Module):
+    """``utils/loss.py:44-63`` ('mean' path): returns (loss_group, loss_pos)."""
+
+    def __init__(self, group_multi_loss, multi_pos_loss, reduction='mean'):
+        super().__init__()
+        if reduction != 'mean':
+            raise NotImplementedError("the reference's 'none' branch is broken (wrong arity, utils/loss.py:57-61)")
+        self.group_multi_loss = group_multi_loss
+        self.multi_pos_loss = multi_pos_loss
+        self.reduction = reduction
+
+    def forward(self, inputs, targets, superpixels, spmasks):
+        return (self.group_multi_loss(inputs, targets, superpixels, spmasks),
+                self.multi_pos_loss(inputs, targets, superpixels, spmasks))
+
+
+class FusedPartialLabelLoss(nn.Module):
+    """The production stage-1 objective from one forward scan and one backward scan:
+    returns (group_loss, ce_loss, mc_loss) exactly as
+    ``GroupMultiLabelCE_onlymulti`` + ``OnehotCEMultihotChoice`` would
+    (``trainer/active_joint_multi_predignore_lossdecomp.py:102-103``), reading the logits once."""
+
+    def __init__(self, num_superpixel, group_temperature=1.0, multi_temperature=1.0, only_multi=True, decomp=True):
+        super().__init__()
+        if group_temperature != multi_temperature:
+            raise ValueError("the fused scan shares one softmax: group_ce_temp must equal multi_ce_temp "
+                             "(both 0.1 in the reference scripts)")
+        self.num_superpixel = num_superpixel
+        self.temp = multi_temperature
+        self.flags = _lib.LOSS_CE | _lib.LOSS_GROUP | (_lib.LOSS_GROUP_ONLY_MULTI if only_multi else 0) \
+            | (_lib.LOSS_DECOMP if decomp else 0)
+
+    def forward(self, inputs, targets, superpixels, spmasks):
+        ce, mc, group, self.last_acc = _run(inputs, targets, superpixels, spmasks, self.temp, self.flags, False)
+        return group, ce, mc

@@ -135,3 +135,164 @@ void exact_softmax_rows(const float* z, int64_t n, int C, float invT, float* p) 
     int64_t i;
     for (i = 0; i < n; ++i) softmax_row(z + i * C, 1, C, invT, p + i * C);
 }
+
+/* =============================================================================================
+ * Stage-1 partial-label losses
+ * ============================================================================================= */
+#define LOSS_CE 1
+#define LOSS_GROUP 2
+#define LOSS_GROUP_ONLY_MULTI 4
+#define LOSS_DECOMP 8
+enum { ACC_SUM_CE = 0, ACC_SUM_MC = 1, ACC_N_CE = 2, ACC_N_MC = 3, ACC_N_EMPTY = 4, ACC_SUM_GROUP = 5, ACC_N_GROUP = 6 };
+
+static int popcount32(uint32_t v) { int n = 0; while (v) { n += (int)(v & 1u); v >>= 1; } return n; }
+
+/* multi-hot rows -> bit masks over the first cols_used columns (utils/loss.py:104,124,571 drop the
+ * last column in the base classes; the predignore subclasses use every column). */
+void exact_target_bits(const uint8_t* tgt, int64_t n_rows, int cols_stored, int cols_used, uint32_t* bits) {
+    int64_t r;
+    int c;
+    for (r = 0; r < n_rows; ++r) {
+        uint32_t b = 0;
+        for (c = 0; c < cols_used; ++c) b |= (tgt[r * cols_stored + c] ? 1u : 0u) << c;
+        bits[r] = b;
+    }
+}
+
+/* K5 + K6 forward over the selected pixels.
+ *   K5: pos = sum_{c in Y} softmax_c ; l = -log(pos + 1e-8); one-hot rows -> ce, multi-hot -> mc
+ *       (trainer/active_joint_multi_predignore_lossdecomp.py:53-70)
+ *   K6: M[s,c] = max over the selected pixels of superpixel s (onlymulti: only if #Y_s > 1) of softmax_c,
+ *       first pixel wins ties (trainer/active_joint_multi_predignore_mclossablation2.py:51-60) */
+void exact_partial_loss_fwd(const float* z, const int64_t* spx, const uint8_t* mask, const uint32_t* bits, int N, int C, int H,
+                            int W, int S, float invT, int flags, uint64_t* gmax, uint64_t* acc) {
+    const size_t HW = (size_t)H * W;
+    float p[MAXC];
+    int n, c;
+    size_t i;
+    for (n = 0; n < N; ++n)
+        for (i = 0; i < HW; ++i) {
+            if (!mask[(size_t)n * HW + i]) continue;
+            const int64_t id = spx[(size_t)n * HW + i];
+            if (id < 0 || id >= S) continue;
+            const uint32_t Y = bits[(size_t)n * S + id];
+            const int nb = popcount32(Y);
+            if (nb == 0) { acc[ACC_N_EMPTY] += 1; continue; }
+            softmax_row(z + (size_t)n * C * HW + i, HW, C, invT, p);
+            if (flags & LOSS_CE) {
+                float pos = 0.0f;
+                for (c = 0; c < C; ++c)
+                    if ((Y >> c) & 1u) pos = pos + p[c];
+                const float l = -mas_logf(pos + 1e-8f);
+                const uint64_t q = mas_fix(l, MAS_LOSS_FRAC);
+                if (nb == 1) { acc[ACC_SUM_CE] += q; acc[ACC_N_CE] += 1; }
+                else { acc[ACC_SUM_MC] += q; acc[ACC_N_MC] += 1; }
+            }
+            if ((flags & LOSS_GROUP) && (!(flags & LOSS_GROUP_ONLY_MULTI) || nb > 1)) {
+                for (c = 0; c < C; ++c)
+                    if ((Y >> c) & 1u) {
+                        const uint64_t w = ((uint64_t)mas_f2u(p[c]) << 32) | (uint64_t)(0xffffffffu - (uint32_t)i);
+                        uint64_t* g = &gmax[((size_t)n * S + id) * C + c];
+                        if (w > *g) *g = w;
+                    }
+            }
+        }
+}
+
+/* sum of -log(M + 1e-8) over the non-zero table entries and their count (..._mclossablation2.py:67-73) */
+void exact_group_finalize(const uint64_t* gmax, int64_t n_entries, uint64_t* acc) {
+    int64_t i;
+    for (i = 0; i < n_entries; ++i) {
+        const uint32_t pb = (uint32_t)(gmax[i] >> 32);
+        if (pb) {
+            const float l = -mas_logf(mas_u2f(pb) + 1e-8f);
+            acc[ACC_SUM_GROUP] += mas_fix(l, MAS_LOSS_FRAC);
+            acc[ACC_N_GROUP] += 1;
+        }
+    }
+}
+
+static float loss_value(uint64_t sum, uint64_t n) {
+    union { double d; uint64_t u; } s;
+    s.u = (uint64_t)(1023 - MAS_LOSS_FRAC) << 52;
+    return (float)(((double)sum * s.d) / (double)(n + 1));
+}
+
+/* loss / num_valid with num_valid starting at 1 (utils/loss.py:106,556; lossdecomp.py:32-35,72) */
+void exact_loss_values(const uint64_t* acc, int flags, float* out) {
+    if (flags & LOSS_DECOMP) {
+        out[0] = loss_value(acc[ACC_SUM_CE], acc[ACC_N_CE]);
+        out[1] = loss_value(acc[ACC_SUM_MC], acc[ACC_N_MC]);
+    } else {
+        out[0] = loss_value(acc[ACC_SUM_CE] + acc[ACC_SUM_MC], acc[ACC_N_CE] + acc[ACC_N_MC]);
+        out[1] = 0.0f;
+    }
+    out[2] = loss_value(acc[ACC_SUM_GROUP], acc[ACC_N_GROUP]);
+}
+
+void exact_loss_scales(const uint64_t* acc, const float* grad_out, int flags, float* scale) {
+    if (flags & LOSS_DECOMP) {
+        scale[0] = grad_out[0] / (float)(acc[ACC_N_CE] + 1);
+        scale[1] = grad_out[1] / (float)(acc[ACC_N_MC] + 1);
+    } else {
+        const float s = grad_out[0] / (float)(acc[ACC_N_CE] + acc[ACC_N_MC] + 1);
+        scale[0] = s;
+        scale[1] = s;
+    }
+    scale[2] = grad_out[2] / (float)(acc[ACC_N_GROUP] + 1);
+}
+
+/* d(sum_k scale_k * loss_k) / dz: analytic gradient of the losses above.
+ *   CE part   : dz_j = scale*invT/(pos+eps) * p_j * (pos - Y_j)
+ *   group part: for every class c whose arg-max pixel is this pixel:
+ *               dz_j += t_c * p_c * (delta_cj - p_j),  t_c = -(scale_g*invT) / (p_c + eps)  */
+void exact_partial_loss_bwd(const float* z, const int64_t* spx, const uint8_t* mask, const uint32_t* bits, const uint64_t* gmax,
+                            const float* scale, int N, int C, int H, int W, int S, float invT, int flags, float* dz) {
+    const size_t HW = (size_t)H * W;
+    const float a_ce = scale[0] * invT, a_mc = scale[1] * invT, g6 = scale[2] * invT;
+    float p[MAXC], t[MAXC];
+    int n, c;
+    size_t i;
+    memset(dz, 0, sizeof(float) * (size_t)N * C * HW);
+    for (n = 0; n < N; ++n)
+        for (i = 0; i < HW; ++i) {
+            if (!mask[(size_t)n * HW + i]) continue;
+            const int64_t id = spx[(size_t)n * HW + i];
+            if (id < 0 || id >= S) continue;
+            const uint32_t Y = bits[(size_t)n * S + id];
+            const int nb = popcount32(Y);
+            if (nb == 0) continue;
+            softmax_row(z + (size_t)n * C * HW + i, HW, C, invT, p);
+            float coef = 0.0f, pos = 0.0f;
+            if (flags & LOSS_CE) {
+                for (c = 0; c < C; ++c)
+                    if ((Y >> c) & 1u) pos = pos + p[c];
+                coef = ((nb == 1) ? a_ce : a_mc) * (1.0f / (pos + 1e-8f));
+            }
+            uint32_t A = 0;
+            float u = 0.0f;
+            if ((flags & LOSS_GROUP) && (!(flags & LOSS_GROUP_ONLY_MULTI) || nb > 1)) {
+                const uint32_t key = 0xffffffffu - (uint32_t)i;
+                for (c = 0; c < C; ++c) {
+                    t[c] = 0.0f;
+                    if ((Y >> c) & 1u) {
+                        const uint64_t w = gmax[((size_t)n * S + id) * C + c];
+                        if ((uint32_t)w == key && (uint32_t)(w >> 32) != 0u) {
+                            A |= 1u << c;
+                            t[c] = -(g6 / (p[c] + 1e-8f));
+                            u = u + t[c] * p[c];
+                        }
+                    }
+                }
+            }
+            for (c = 0; c < C; ++c) {
+                const float yj = ((Y >> c) & 1u) ? 1.0f : 0.0f;
+                float d = coef * (p[c] * (pos - yj));
+                if (A) {
+                    if ((A >> c) & 1u) d = d + t[c] * p[c];
+                    d = d - p[c] * u;
+                }
+                dz[((size_t)n * C + c) * HW + i] = d;
+            }
+        }
+}

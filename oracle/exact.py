@@ -109,3 +109,56 @@ def softmax_rows(z, invT):
     p = np.empty_like(z)
     lib().exact_softmax_rows(_p(z), ctypes.c_int64(n), C, ctypes.c_float(invT), _p(p))
     return p
+
+
+# ------------------------------------------------------------------------------------------------
+# stage-1 losses
+# ------------------------------------------------------------------------------------------------
+LOSS_CE, LOSS_GROUP, LOSS_GROUP_ONLY_MULTI, LOSS_DECOMP = 1, 2, 4, 8
+
+
+def target_bits(targets, cols_used=None):
+    t = _c(targets, np.uint8)
+    cols = t.shape[-1]
+    cols_used = cols if cols_used is None else cols_used
+    bits = np.zeros(t.shape[:-1], dtype=np.uint32)
+    lib().exact_target_bits(_p(t), ctypes.c_int64(bits.size), cols, cols_used, _p(bits))
+    return bits
+
+
+def partial_loss_fwd(z, spx, mask, bits, invT, flags):
+    """Returns (acc u64[8], gmax u64[N,S,C], losses f32[3])."""
+    z = _c(z, np.float32)
+    spx = _c(spx, np.int64)
+    mask = _c(mask, np.uint8)
+    bits = _c(bits, np.uint32)
+    N, C, H, W = z.shape
+    S = bits.shape[1]
+    gmax = np.zeros((N, S, C), dtype=np.uint64)
+    acc = np.zeros(8, dtype=np.uint64)
+    lib().exact_partial_loss_fwd(_p(z), _p(spx), _p(mask), _p(bits), N, C, H, W, S, ctypes.c_float(invT), flags,
+                                 _p(gmax), _p(acc))
+    if flags & LOSS_GROUP:
+        lib().exact_group_finalize(_p(gmax), ctypes.c_int64(gmax.size), _p(acc))
+    losses = np.zeros(3, dtype=np.float32)
+    lib().exact_loss_values(_p(acc), flags, _p(losses))
+    return acc, gmax, losses
+
+
+def partial_loss_bwd(z, spx, mask, bits, gmax, acc, grad_out, invT, flags):
+    """Returns (scale f32[3], dz f32[N,C,H,W])."""
+    z = _c(z, np.float32)
+    spx = _c(spx, np.int64)
+    mask = _c(mask, np.uint8)
+    bits = _c(bits, np.uint32)
+    gmax = _c(gmax, np.uint64)
+    acc = _c(acc, np.uint64)
+    grad_out = _c(grad_out, np.float32)
+    N, C, H, W = z.shape
+    S = bits.shape[1]
+    scale = np.zeros(3, dtype=np.float32)
+    lib().exact_loss_scales(_p(acc), _p(grad_out), flags, _p(scale))
+    dz = np.empty_like(z)
+    lib().exact_partial_loss_bwd(_p(z), _p(spx), _p(mask), _p(bits), _p(gmax), _p(scale), N, C, H, W, S,
+                                 ctypes.c_float(invT), flags, _p(dz))
+    return scale, dz
