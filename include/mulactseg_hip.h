@@ -142,6 +142,34 @@ int mas_partial_loss_bwd(const float* z, const void* spx, int spx_dtype, const u
                          const uint64_t* gmax, const float* scale /* [3] */,
                          int N, int C, int H, int W, int S, float invT, int flags, float* dz, void* stream);
 
+/* =============================================================================================
+ * K4  ordering of the region scores and the budgeted selection walk
+ * ============================================================================================= */
+
+/* One 64-bit key per region, [order-preserving f32 score bits : 32 | path rank : 32-b | id : b],
+ * b = bits of S-1; DESCENDING key order == the reference's `sorted(scores, reverse=True)` over
+ * (score, "img,lbl,spx", id) tuples (active_selection/base.py:37).  img_rank[i] = rank of image i's
+ * joined path string in ascending order.  valid (u8 [n_img*S], may be NULL) marks the ids still in
+ * pool_set.suppix (active_selection/my_bvsb.py:41-46); other regions get key 0. */
+int mas_region_keys(const float* score, const uint8_t* valid, const int32_t* img_rank, int64_t n_img, int S,
+                    uint64_t* keys /* [n_img*S] */, void* stream);
+
+/* bytes of caller-owned scratch needed by mas_sort_keys_desc / mas_budget_walk for n keys (host call) */
+size_t mas_select_workspace_bytes(int64_t n);
+
+/* keys_out = keys_in sorted descending (device radix sort; keys_in and keys_out must not overlap). */
+int mas_sort_keys_desc(const uint64_t* keys_in, int64_t n, uint64_t* keys_out, void* workspace, size_t ws_bytes,
+                       void* stream);
+
+/* The walk of RegionActiveDataset.expand_training_set (dataloader/region_active_dataset.py:31-73) over
+ * descending keys: cost_i = popcount(cost_bits[img*S+id]) (fair counting + or-labeling; NULL -> 1);
+ * the region that makes the running cost exceed `budget` is the last one taken.  Writes the number of
+ * taken regions to *n_selected (device) and decodes the first max_out keys (entries past n_selected
+ * are -1).  img_of_rank inverts img_rank. */
+int mas_budget_walk(const uint64_t* sorted_keys, int64_t n, const uint32_t* cost_bits, const int32_t* img_of_rank,
+                    int S, int64_t budget, int64_t max_out, int64_t* n_selected,
+                    int32_t* sel_img, int32_t* sel_id, float* sel_score, void* workspace, size_t ws_bytes, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -161,3 +161,70 @@ def partial_loss_bwd(z, spx, mask, bits, gmax, acc, grad_out, invT, flags):
                                             gmax.data_ptr() if gmax is not None else None, scale.data_ptr(),
                                             N, C, H, W, S, invT, flags, dz.data_ptr(), st), "mas_partial_loss_bwd")
     return dz
+
+
+# ------------------------------------------------------------------------------------------------
+# K4: ordering + budgeted selection walk
+# ------------------------------------------------------------------------------------------------
+def path_ranks(paths):
+    """Rank of every image's joined path string in ascending (Python ``str``) order -- the tie-break
+    the reference's tuple sort applies after the score (``active_selection/base.py:37``).
+    Returns (img_rank[n], img_of_rank[n]) as int32 numpy arrays."""
+    order = sorted(range(len(paths)), key=lambda i: paths[i])
+    img_of_rank = np.asarray(order, dtype=np.int32)
+    img_rank = np.empty(len(paths), dtype=np.int32)
+    img_rank[img_of_rank] = np.arange(len(paths), dtype=np.int32)
+    return img_rank, img_of_rank
+
+
+def region_keys(scores, valid, img_rank):
+    """64-bit sort keys [n_img*S] (int64 bits of uint64) for scores [n_img,S] f32."""
+    _need(scores, "scores", torch.float32)
+    _need(img_rank, "img_rank", torch.int32)
+    n_img, S = scores.shape
+    if valid is not None:
+        valid = _mask_u8(valid)
+        if tuple(valid.shape) != (n_img, S):
+            raise ValueError("valid must be [n_img, S]")
+    keys = torch.empty(n_img * S, dtype=torch.int64, device=scores.device)
+    with torch.cuda.device(scores.device):
+        _lib.check(_lib.load().mas_region_keys(scores.data_ptr(), valid.data_ptr() if valid is not None else None,
+                                               img_rank.data_ptr(), n_img, S, keys.data_ptr(), _stream(scores)),
+                   "mas_region_keys")
+    return keys
+
+
+def sort_keys_desc(keys):
+    _need(keys, "keys", torch.int64)
+    n = keys.numel()
+    lib = _lib.load()
+    ws = torch.empty(lib.mas_select_workspace_bytes(n), dtype=torch.uint8, device=keys.device)
+    out = torch.empty_like(keys)
+    with torch.cuda.device(keys.device):
+        _lib.check(lib.mas_sort_keys_desc(keys.data_ptr(), n, out.data_ptr(), ws.data_ptr(), ws.numel(), _stream(keys)),
+                   "mas_sort_keys_desc")
+    return out
+
+
+def budget_walk(sorted_keys, cost_bits, img_of_rank, S, budget, max_out=None):
+    """Returns (n_selected int64[1] on device, sel_img i32[max_out], sel_id i32[max_out], sel_score f32[max_out])."""
+    _need(sorted_keys, "sorted_keys", torch.int64)
+    _need(img_of_rank, "img_of_rank", torch.int32)
+    if cost_bits is not None:
+        _need(cost_bits, "cost_bits", torch.int32)
+    n = sorted_keys.numel()
+    # every region costs >= 1 when costs are popcounts of non-empty rows; budget+1 outputs always suffice then
+    max_out = n if max_out is None else min(n, max_out)
+    dev = sorted_keys.device
+    lib = _lib.load()
+    ws = torch.empty(lib.mas_select_workspace_bytes(n), dtype=torch.uint8, device=dev)
+    nsel = torch.empty(1, dtype=torch.int64, device=dev)
+    sel_img = torch.empty(max_out, dtype=torch.int32, device=dev)
+    sel_id = torch.empty(max_out, dtype=torch.int32, device=dev)
+    sel_score = torch.empty(max_out, dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        _lib.check(lib.mas_budget_walk(sorted_keys.data_ptr(), n, cost_bits.data_ptr() if cost_bits is not None else None,
+                                       img_of_rank.data_ptr(), S, int(budget), max_out, nsel.data_ptr(), sel_img.data_ptr(),
+                                       sel_id.data_ptr(), sel_score.data_ptr(), ws.data_ptr(), ws.numel(), _stream(sorted_keys)),
+                   "mas_budget_walk")
+    return nsel, sel_img, sel_id, sel_score
