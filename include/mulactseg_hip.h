@@ -162,13 +162,19 @@ int mas_sort_keys_desc(const uint64_t* keys_in, int64_t n, uint64_t* keys_out, v
                        void* stream);
 
 /* The walk of RegionActiveDataset.expand_training_set (dataloader/region_active_dataset.py:31-73) over
- * descending keys: cost_i = popcount(cost_bits[img*S+id]) (fair counting + or-labeling; NULL -> 1);
+ * descending keys: cost_i = region_cost[img*S+id] (= multi_hot_cls[img,id].sum() under fair counting +
+ * or-labeling; NULL -> 1);
  * the region that makes the running cost exceed `budget` is the last one taken.  Writes the number of
  * taken regions to *n_selected (device) and decodes the first max_out keys (entries past n_selected
  * are -1).  img_of_rank inverts img_rank. */
-int mas_budget_walk(const uint64_t* sorted_keys, int64_t n, const uint32_t* cost_bits, const int32_t* img_of_rank,
+int mas_budget_walk(const uint64_t* sorted_keys, int64_t n, const uint8_t* region_cost, const int32_t* img_of_rank,
                     int S, int64_t budget, int64_t max_out, int64_t* n_selected,
                     int32_t* sel_img, int32_t* sel_id, float* sel_score, void* workspace, size_t ws_bytes, void* stream);
+
+/* In-place min-max normalisation of the plain BvSB selector (active_selection/my_bvsb.py:79-81):
+ *   u <- (u - min(u[u != 0])) / max(u - min(u[u != 0]))     over all n region scores.
+ * scratch2: 2 x uint32 of caller-owned device scratch. */
+int mas_minmax_normalize(float* scores, int64_t n, uint32_t* scratch2, void* stream);
 
 #ifdef __cplusplus
 }

@@ -1,0 +1,211 @@
+"""Acquisition-round engine: the device-side state and the multi-GPU sharding behind the
+``RegionSelector`` plugins.
+
+One process per GPU.  The unlabeled pool is sharded over ranks in whole *reference batches*
+(``val_batch_size`` consecutive pool images, ``active_selection/utils.py:47-57``) so that the
+reference's "mean of per-batch means" class prior (``my_bvsb_predclsbal_pwr_banignore.py:42-45``)
+and the (image rank, id) tie-break keys are identical for any number of GPUs.  The scan itself needs
+no collective; the round has exactly two tiny exchanges:
+
+  1. after pass 1: all-gather of the per-image fixed-point class sums  [N_img, C] int64  (476 KB for
+     the Cityscapes pool) -> every rank derives the same class weights in f64 on the host;
+  2. after pass 2: all-gather of the per-image region scores [N_img, S] f32 (24 MB) -> every rank
+     runs the same K4 ordering + budget walk (replicated, deterministic).
+
+Both are latency-bound RCCL collectives over xGMI (``torch.distributed`` backend "nccl").
+
+The compute backend is an explicit object.  The only backend in this package is ``HipBackend``
+(the C ABI of ``libmulactseg_hip.so``); it raises if the library or a GPU is missing -- there is no
+CPU fallback.  (The CPU test-suite injects an oracle-backed stand-in to exercise the sharding and
+merge logic under ``gloo``.)
+"""
+import numpy as np
+import torch
+
+
+# ------------------------------------------------------------------------------------------------
+# sharding
+# ------------------------------------------------------------------------------------------------
+class ShardPlan:
+    """Contiguous blocks of whole reference batches per rank."""
+
+    def __init__(self, n_img, batch_size, rank=0, world=1):
+        self.n_img, self.batch_size, self.rank, self.world = n_img, batch_size, rank, world
+        self.n_batches = (n_img + batch_size - 1) // batch_size
+        per = (self.n_batches + world - 1) // world
+        self.batch_lo = min(rank * per, self.n_batches)
+        self.batch_hi = min((rank + 1) * per, self.n_batches)
+        self.img_lo = min(self.batch_lo * batch_size, n_img)
+        self.img_hi = min(self.batch_hi * batch_size, n_img)
+        self.per_rank_imgs = per * batch_size                      # padded shard length for gathers
+        self.batch_of = (np.arange(n_img) // batch_size).astype(np.int32)
+
+    @property
+    def local_indices(self):
+        return list(range(self.img_lo, self.img_hi))
+
+    @property
+    def n_local(self):
+        return self.img_hi - self.img_lo
+
+
+def _dist():
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized():
+        return dist
+    return None
+
+
+def current_rank_world():
+    d = _dist()
+    return (d.get_rank(), d.get_world_size()) if d else (0, 1)
+
+
+def gather_rows(local, plan):
+    """All-gather row blocks ``local`` [n_local, ...] into [n_img, ...] (identical on every rank)."""
+    d = _dist()
+    if d is None or plan.world == 1:
+        return local
+    pad = torch.zeros((plan.per_rank_imgs,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+    pad[:plan.n_local] = local
+    out = torch.empty((plan.world * plan.per_rank_imgs,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+    d.all_gather_into_tensor(out, pad)
+    return out[:plan.n_img].contiguous()
+
+
+# ------------------------------------------------------------------------------------------------
+# host arithmetic between the passes
+# ------------------------------------------------------------------------------------------------
+def class_weight_from_sums(prob_sum, hw, batch_of, n_batches, coeff):
+    """Reference: ``cum = sum_b mean_b / len(loader)``; ``cls_weight = (coeff*cum + 1)**-2``
+    (``my_bvsb_predclsbal_pwr_banignore.py:42,45,47``), evaluated in f64 from the integer per-image
+    sums (31 fractional bits) and rounded once to f32.  Same operation order as
+    ``oracle/exact.c:exact_class_weight`` (bit-identical)."""
+    prob_sum = np.ascontiguousarray(prob_sum).view(np.uint64)
+    n_img, C = prob_sum.shape
+    cum = np.zeros(C, dtype=np.float64)
+    for c in range(C):
+        acc = np.float64(0.0)
+        for b in range(n_batches):
+            sel = batch_of == b
+            n = int(sel.sum())
+            if n:
+                s = np.uint64(prob_sum[sel, c].sum(dtype=np.uint64))
+                acc = acc + (np.float64(s) / np.float64(2147483648.0)) / (np.float64(n) * np.float64(hw))
+        cum[c] = acc / np.float64(n_batches)
+    t = np.float64(coeff) * cum + np.float64(1.0)
+    return cum, (np.float64(1.0) / (t * t)).astype(np.float32)
+
+
+# ------------------------------------------------------------------------------------------------
+# backend
+# ------------------------------------------------------------------------------------------------
+class HipBackend:
+    """The C ABI of libmulactseg_hip.so on one GPU (see include/mulactseg_hip.h)."""
+    name = "hip"
+
+    def __init__(self, device):
+        from .. import _lib, ops
+        self.device = torch.device(device)
+        if self.device.type != 'cuda':
+            raise _lib.MulActSegHipError("HipBackend needs a ROCm device, got %s (no CPU path exists)" % device)
+        _lib.load()
+        self.ops = ops
+
+    def inv_temperature(self, T):
+        return self.ops.inv_temperature(T)
+
+    def class_prob_sum(self, logits, invT, out):
+        self.ops.class_prob_sum(logits, invT, out=out)
+
+    def region_accum(self, logits, spx, cls_w, S, invT, score_sum, hist):
+        self.ops.bvsb_region_accum(logits, spx, cls_w, S, invT, score_sum=score_sum, hist=hist)
+
+    def finalize(self, score_sum, hist, ban_class, want_hist_i64=False):
+        return self.ops.region_finalize(score_sum, hist, ban_class, want_hist_i64)
+
+    def minmax_normalize_(self, scores):
+        return self.ops.minmax_normalize_(scores)
+
+    def select(self, scores, valid, img_rank, img_of_rank, region_cost, budget, max_out):
+        keys = self.ops.region_keys(scores, valid, img_rank)
+        skeys = self.ops.sort_keys_desc(keys)
+        nsel, simg, sid, ssc = self.ops.budget_walk(skeys, region_cost, img_of_rank, scores.shape[1], budget, max_out)
+        n = int(nsel.item())               # the round's single host synchronisation
+        return n, simg[:n].cpu().numpy(), sid[:n].cpu().numpy(), ssc[:n].cpu().numpy()
+
+
+def default_backend(device):
+    return HipBackend(device)
+
+
+# ------------------------------------------------------------------------------------------------
+# one acquisition round
+# ------------------------------------------------------------------------------------------------
+class AcquisitionRound:
+    """Per-round accumulators for the images of this rank plus the two exchanges.
+
+    Usage (what the selector plugins do):
+        rnd = AcquisitionRound(n_img, C, S, batch_size, temperature, backend)
+        for k, logits in pass 1:  rnd.add_prior(first_local_row, logits)
+        w = rnd.class_weights(coeff)                 # exchange 1
+        for k, logits in pass 2:  rnd.add_regions(first_local_row, logits, spx, w)
+        scores = rnd.scores(ban_class)               # exchange 2 -> [n_img, S] on every rank
+    """
+
+    def __init__(self, n_img, n_channels, n_superpixels, batch_size, temperature, backend, rank=None, world=None):
+        r, w = current_rank_world()
+        self.plan = ShardPlan(n_img, batch_size, r if rank is None else rank, w if world is None else world)
+        self.C, self.S = n_channels, n_superpixels
+        self.backend = backend
+        self.invT = backend.inv_temperature(temperature)
+        dev = backend.device
+        nl = max(self.plan.n_local, 1)
+        self.prob_sum = torch.zeros((nl, n_channels), dtype=torch.int64, device=dev)
+        self.score_sum = torch.zeros((nl, n_superpixels), dtype=torch.int64, device=dev)
+        self.hist = torch.zeros((nl, n_superpixels, n_channels), dtype=torch.int32, device=dev)
+        self.hw = None
+
+    def _rows(self, row0, logits):
+        B = logits.shape[0]
+        if row0 < 0 or row0 + B > self.plan.n_local:
+            raise IndexError("batch rows [%d,%d) outside this rank's shard of %d images" % (row0, row0 + B, self.plan.n_local))
+        hw = logits.shape[2] * logits.shape[3]
+        if self.hw is None:
+            self.hw = hw
+        elif self.hw != hw:
+            raise ValueError("all pool images of one round must share H*W (the class prior is a pixel mean)")
+        return slice(row0, row0 + B)
+
+    def add_prior(self, row0, logits):
+        r = self._rows(row0, logits)
+        self.backend.class_prob_sum(logits.contiguous(), self.invT, self.prob_sum[r])
+
+    def class_weights(self, coeff):
+        allsum = gather_rows(self.prob_sum[:self.plan.n_local], self.plan)        # exchange 1
+        hw = self.hw
+        d = _dist()
+        if d is not None and self.plan.world > 1:
+            t = torch.tensor([hw or 0], dtype=torch.int64, device=allsum.device)
+            d.all_reduce(t, op=d.ReduceOp.MAX)
+            hw = int(t.item())
+        cum, w = class_weight_from_sums(allsum.cpu().numpy(), hw, self.plan.batch_of, self.plan.n_batches, coeff)
+        self.cum = cum
+        return torch.from_numpy(w).to(self.backend.device)
+
+    def add_regions(self, row0, logits, spx, cls_w):
+        r = self._rows(row0, logits)
+        self.backend.region_accum(logits.contiguous(), spx.contiguous(), cls_w, self.S, self.invT, self.score_sum[r], self.hist[r])
+
+    def scores(self, ban_class=-1, want_hist=False):
+        n = self.plan.n_local
+        if n == 0:      # more ranks than reference batches: this rank only takes part in the exchanges
+            dev = self.backend.device
+            score = torch.zeros((0, self.S), dtype=torch.float32, device=dev)
+            h64 = torch.zeros((0, self.S, self.C), dtype=torch.int64, device=dev)
+        else:
+            score, dom, cnt, h64 = self.backend.finalize(self.score_sum[:n], self.hist[:n], ban_class, want_hist)
+        full = gather_rows(score, self.plan)                                      # exchange 2
+        if want_hist:
+            return full, gather_rows(h64, self.plan)
+        return full

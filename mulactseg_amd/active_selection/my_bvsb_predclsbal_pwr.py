@@ -1,0 +1,40 @@
+"""BvSB + pixel-wise class balancing ("PixBal", the proposed acquisition of Hwang et al.) --
+reference ``active_selection/my_bvsb_predclsbal_pwr.py`` (VOC form: C = num_classes, no ban).
+
+Pass 1 estimates the predicted class prior (K2, ``k_class_prob_sum``), the host turns the integer
+sums into ``cls_weight = (coeff*prior + 1)**-2``; pass 2 averages ``bvsb * cls_weight[top1]`` per
+superpixel and histograms the arg-max class (K1+K3, ``k_bvsb_region_accum``).
+"""
+import torch
+
+from . import my_bvsb
+from .engine import AcquisitionRound
+
+
+class RegionSelector(my_bvsb.RegionSelector):
+    extra_channels = 0        # C = num_classes (my_bvsb_predclsbal_pwr.py:32,68)
+    ban_ignore = False
+
+    def __init__(self, args):
+        super().__init__(args)
+
+    def calculate_scores_tensor(self, trainer, pool_set, want_hist=False):
+        backend = self._backend(trainer)
+        n_img = len(pool_set.im_idx)
+        C = self.num_class + self.extra_channels
+        rnd = AcquisitionRound(n_img, C, self.num_superpixels, self.batch_size, self.args.ce_temp, backend)
+        for row, preds, _ in self._iterate(trainer, pool_set, rnd):                 # pass 1 (:35-43)
+            self._check_channels(preds, C)
+            rnd.add_prior(row, preds)
+        cls_w = rnd.class_weights(self.args.cls_weight_coeff)                       # (:45-47)
+        self.cumulated_pred_prob, self.cls_weight = rnd.cum, cls_w
+        for row, preds, spx in self._iterate(trainer, pool_set, rnd):               # pass 2 (:49-72)
+            rnd.add_regions(row, preds, spx, cls_w)
+        ban = C - 1 if self.ban_ignore else -1                                      # (:79-84)
+        self._round = rnd
+        return rnd.scores(ban_class=ban, want_hist=want_hist)
+
+    @staticmethod
+    def _check_channels(preds, C):
+        if preds.shape[1] != C:
+            raise ValueError("model emits %d channels, selector expects %d" % (preds.shape[1], C))

@@ -53,7 +53,7 @@ __global__ __launch_bounds__(kThreads) void k_region_keys(const float* __restric
 }
 
 __global__ __launch_bounds__(kThreads) void k_walk_cost(const mas_u64* __restrict__ keys, long long n,
-                                                         const unsigned* __restrict__ cost_bits,
+                                                         const unsigned char* __restrict__ region_cost,
                                                          const int* __restrict__ img_of_rank, int S, int id_bits,
                                                          unsigned* __restrict__ cost) {
     const long long i = (long long)blockIdx.x * kThreads + threadIdx.x;
@@ -62,11 +62,11 @@ __global__ __launch_bounds__(kThreads) void k_walk_cost(const mas_u64* __restric
     unsigned c = 0;
     if (k) {
         c = 1;
-        if (cost_bits) {
+        if (region_cost) {
             const unsigned lo = (unsigned)k;
             const int id = (int)(lo & ((1u << id_bits) - 1u));
             const int img = img_of_rank[lo >> id_bits];
-            c = (unsigned)__popc(cost_bits[(long long)img * S + id]);
+            c = (unsigned)region_cost[(long long)img * S + id];
         }
     }
     cost[i] = c;
@@ -108,6 +108,38 @@ __global__ __launch_bounds__(kThreads) void k_walk_emit(const mas_u64* __restric
 }
 
 __global__ void k_set_u64(unsigned long long* p, unsigned long long v) { *p = v; }
+
+// min over the non-zero entries and max over all entries, as order-preserving bit patterns
+__global__ __launch_bounds__(kThreads) void k_minmax_nonzero(const float* __restrict__ u, long long n, unsigned* __restrict__ mm) {
+    unsigned lo = 0xffffffffu, hi = 0u;
+    for (long long i = (long long)blockIdx.x * kThreads + threadIdx.x; i < n; i += (long long)gridDim.x * kThreads) {
+        const float v = u[i];
+        const unsigned o = order_bits(v);
+        if (v != 0.0f) lo = o < lo ? o : lo;
+        hi = o > hi ? o : hi;
+    }
+#pragma unroll
+    for (int off = MAS_WAVE / 2; off > 0; off >>= 1) {
+        const unsigned l2 = __shfl_down(lo, off, MAS_WAVE), h2 = __shfl_down(hi, off, MAS_WAVE);
+        lo = l2 < lo ? l2 : lo;
+        hi = h2 > hi ? h2 : hi;
+    }
+    if ((threadIdx.x & (MAS_WAVE - 1)) == 0) {
+        atomicMin(&mm[0], lo);
+        atomicMax(&mm[1], hi);
+    }
+}
+
+__global__ void k_minmax_init(unsigned* mm) { mm[0] = 0xffffffffu; mm[1] = 0u; }
+
+// u <- (u - min_nonzero) / (max - min_nonzero)      (my_bvsb.py:79-81)
+__global__ __launch_bounds__(kThreads) void k_minmax_apply(float* __restrict__ u, long long n, const unsigned* __restrict__ mm) {
+    const long long i = (long long)blockIdx.x * kThreads + threadIdx.x;
+    if (i >= n) return;
+    const float mn = unorder_bits(mm[0]);
+    const float mx = unorder_bits(mm[1]) - mn;
+    u[i] = (u[i] - mn) / mx;
+}
 
 inline size_t align_up(size_t v) { return (v + 255) & ~(size_t)255; }
 
@@ -158,12 +190,12 @@ extern "C" int mas_sort_keys_desc(const uint64_t* keys_in, int64_t n, uint64_t* 
     return e == hipSuccess ? mas_launch_status() : (int)e;
 }
 
-extern "C" int mas_budget_walk(const uint64_t* sorted_keys, int64_t n, const uint32_t* cost_bits, const int32_t* img_of_rank,
+extern "C" int mas_budget_walk(const uint64_t* sorted_keys, int64_t n, const uint8_t* region_cost, const int32_t* img_of_rank,
                                int S, int64_t budget, int64_t max_out, int64_t* n_selected, int32_t* sel_img, int32_t* sel_id,
                                float* sel_score, void* workspace, size_t ws_bytes, void* stream) {
     if (!sorted_keys || !img_of_rank || !n_selected || !sel_img || !sel_id || !sel_score || !workspace) return MAS_ERR_NULL;
     if (n <= 0 || S <= 0 || max_out <= 0 || budget < 0) return MAS_ERR_SHAPE;
-    if (n > (1LL << 27)) return MAS_ERR_RANGE;   // 32-bit prefix sums: n * 32 classes < 2^32
+    if (n > (1LL << 24)) return MAS_ERR_RANGE;   // 32-bit prefix sums: n * 255 < 2^32
     if (ws_bytes < mas_select_workspace_bytes(n)) return MAS_ERR_WORKSPACE;
     hipStream_t st = static_cast<hipStream_t>(stream);
     const int b = id_bits_for(S);
@@ -177,7 +209,7 @@ extern "C" int mas_budget_walk(const uint64_t* sorted_keys, int64_t n, const uin
     unsigned long long* nsel = reinterpret_cast<unsigned long long*>(n_selected);
     const long long nblk = (n + kThreads - 1) / kThreads;
     hipLaunchKernelGGL(k_set_u64, dim3(1), dim3(1), 0, st, nsel, (unsigned long long)n);
-    hipLaunchKernelGGL(k_walk_cost, dim3((unsigned)nblk), dim3(kThreads), 0, st, keys, (long long)n, cost_bits, img_of_rank, S, b, cost);
+    hipLaunchKernelGGL(k_walk_cost, dim3((unsigned)nblk), dim3(kThreads), 0, st, keys, (long long)n, region_cost, img_of_rank, S, b, cost);
     hipError_t e = rocprim::inclusive_scan(ws, temp, cost, prefix, (size_t)n, rocprim::plus<unsigned>(), st);
     if (e != hipSuccess) return (int)e;
     hipLaunchKernelGGL(k_walk_find, dim3((unsigned)nblk), dim3(kThreads), 0, st, keys, prefix, (long long)n,
@@ -185,5 +217,16 @@ extern "C" int mas_budget_walk(const uint64_t* sorted_keys, int64_t n, const uin
     const long long oblk = (max_out + kThreads - 1) / kThreads;
     hipLaunchKernelGGL(k_walk_emit, dim3((unsigned)oblk), dim3(kThreads), 0, st, keys, nsel, (long long)max_out, img_of_rank, b,
                        sel_img, sel_id, sel_score);
+    return mas_launch_status();
+}
+
+extern "C" int mas_minmax_normalize(float* scores, int64_t n, uint32_t* scratch2, void* stream) {
+    if (!scores || !scratch2) return MAS_ERR_NULL;
+    if (n <= 0) return MAS_ERR_SHAPE;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    long long nblk = (n + kThreads - 1) / kThreads;
+    hipLaunchKernelGGL(k_minmax_init, dim3(1), dim3(1), 0, st, scratch2);
+    hipLaunchKernelGGL(k_minmax_nonzero, dim3((unsigned)(nblk > 1024 ? 1024 : nblk)), dim3(kThreads), 0, st, scores, (long long)n, scratch2);
+    hipLaunchKernelGGL(k_minmax_apply, dim3((unsigned)nblk), dim3(kThreads), 0, st, scores, (long long)n, scratch2);
     return mas_launch_status();
 }

@@ -1,0 +1,53 @@
+"""``collate_fn`` and ``DataProvider`` with the behaviour of the reference's ``dataloader/utils.py:10-62``
+(the reference's own ``DataProvider`` calls ``iterator.next()``, which no longer exists in torch 2)."""
+import numpy as np
+import torch
+from torch.utils.data import DataLoader
+
+_STACKED = ('images', 'image_weak', 'spx', 'spx_weak', 'spmask', 'spmask_weak', 'labels', 'spx_small',
+            'spx_small_weak', 'target', 'nseg_list')
+_LISTED = ('image_list', 'fnames', 'imsizes')
+
+
+def collate_fn(inputs):
+    """Stack tensor-like entries, keep file names / sizes as lists -- ``dataloader/utils.py:10-25``."""
+    batch = {}
+    for key in inputs[0].keys():
+        vals = [item[key] for item in inputs]
+        if key in _STACKED:
+            if isinstance(vals[0], np.ndarray):
+                vals = [torch.from_numpy(v) for v in vals]
+            batch[key] = torch.stack(vals)
+        elif key in _LISTED or 'mseg_' in key:
+            batch[key] = vals
+        else:
+            raise NotImplementedError("collate_fn: unknown batch key %r" % key)
+    return batch
+
+
+class DataProvider:
+    """Endless iterator over a DataLoader (epoch counter, restart on exhaustion) --
+    ``dataloader/utils.py:28-62``."""
+
+    def __init__(self, dataset, batch_size, num_workers, drop_last, shuffle, pin_memory):
+        self.dataset = dataset
+        self.iteration = 0
+        self.epoch = 0
+        self.batch_size, self.num_workers = batch_size, num_workers
+        self.drop_last, self.shuffle, self.pin_memory = drop_last, shuffle, pin_memory
+        self.dataloader = DataLoader(dataset, batch_size=batch_size, collate_fn=collate_fn, shuffle=shuffle,
+                                     num_workers=num_workers, drop_last=drop_last, pin_memory=pin_memory)
+        self.dataiter = iter(self.dataloader)
+
+    def __len__(self):
+        return len(self.dataloader)
+
+    def __next__(self):
+        try:
+            batch = next(self.dataiter)
+        except StopIteration:
+            self.epoch += 1
+            self.dataiter = iter(self.dataloader)
+            batch = next(self.dataiter)
+        self.iteration += 1
+        return batch

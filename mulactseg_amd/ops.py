@@ -206,12 +206,14 @@ def sort_keys_desc(keys):
     return out
 
 
-def budget_walk(sorted_keys, cost_bits, img_of_rank, S, budget, max_out=None):
-    """Returns (n_selected int64[1] on device, sel_img i32[max_out], sel_id i32[max_out], sel_score f32[max_out])."""
+def budget_walk(sorted_keys, region_cost, img_of_rank, S, budget, max_out=None):
+    """Returns (n_selected int64[1] on device, sel_img i32[max_out], sel_id i32[max_out], sel_score f32[max_out]).
+    ``region_cost`` u8 [n_img*S] (``multi_hot_cls[img, id].sum()``) or None for unit cost."""
     _need(sorted_keys, "sorted_keys", torch.int64)
     _need(img_of_rank, "img_of_rank", torch.int32)
+    cost_bits = region_cost
     if cost_bits is not None:
-        _need(cost_bits, "cost_bits", torch.int32)
+        _need(cost_bits, "region_cost", torch.uint8)
     n = sorted_keys.numel()
     # every region costs >= 1 when costs are popcounts of non-empty rows; budget+1 outputs always suffice then
     max_out = n if max_out is None else min(n, max_out)
@@ -228,3 +230,13 @@ def budget_walk(sorted_keys, cost_bits, img_of_rank, S, budget, max_out=None):
                                        sel_id.data_ptr(), sel_score.data_ptr(), ws.data_ptr(), ws.numel(), _stream(sorted_keys)),
                    "mas_budget_walk")
     return nsel, sel_img, sel_id, sel_score
+
+
+def minmax_normalize_(scores):
+    """In place: (u - min(u[u != 0])) / max(...) over all region scores -- my_bvsb.py:79-81."""
+    _need(scores, "scores", torch.float32)
+    scratch = torch.empty(2, dtype=torch.int32, device=scores.device)
+    with torch.cuda.device(scores.device):
+        _lib.check(_lib.load().mas_minmax_normalize(scores.data_ptr(), scores.numel(), scratch.data_ptr(), _stream(scores)),
+                   "mas_minmax_normalize")
+    return scores

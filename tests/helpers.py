@@ -1,0 +1,82 @@
+"""Test helpers: an oracle-backed stand-in for the HIP backend (CPU tests of the host logic only) and
+tiny fake trainer / pool objects shaped like the reference's plugin arguments."""
+import types
+
+import numpy as np
+import torch
+
+from oracle import exact, port
+
+
+class OracleBackend:
+    """Implements the backend protocol of mulactseg_amd.active_selection.engine with the CPU oracle.
+    TEST INFRASTRUCTURE: lives under tests/, is never importable from the product package."""
+    name = "oracle"
+
+    def __init__(self):
+        self.device = torch.device('cpu')
+
+    def inv_temperature(self, T):
+        return float(exact.inv_temperature(T))
+
+    def class_prob_sum(self, logits, invT, out):
+        out += torch.from_numpy(exact.class_prob_sum(logits.numpy(), np.float32(invT)).view(np.int64))
+
+    def region_accum(self, logits, spx, cls_w, S, invT, score_sum, hist):
+        s, h = exact.bvsb_region_accum(logits.numpy(), spx.numpy(), None if cls_w is None else cls_w.numpy(), S,
+                                       np.float32(invT))
+        score_sum += torch.from_numpy(s.view(np.int64))
+        hist += torch.from_numpy(h.view(np.int32))
+
+    def finalize(self, score_sum, hist, ban_class, want_hist_i64=False):
+        score, dom, cnt = exact.region_finalize(score_sum.numpy().view(np.uint64), hist.numpy().view(np.uint32), ban_class)
+        h64 = hist.to(torch.int64) if want_hist_i64 else None
+        return torch.from_numpy(score), torch.from_numpy(dom), torch.from_numpy(cnt.view(np.int32)), h64
+
+    def minmax_normalize_(self, scores):
+        u = scores.numpy()
+        mn = u[u != 0].min()
+        u -= mn
+        u /= u.max()
+        return scores
+
+    def select(self, scores, valid, img_rank, img_of_rank, region_cost, budget, max_out):
+        # reference semantics: Python tuple sort with the rank standing in for the path string
+        s, v = scores.numpy(), valid.numpy()
+        rank = img_rank.numpy()
+        tuples = [(float(s[i, r]), int(rank[i]), r) for i in range(s.shape[0]) for r in range(s.shape[1]) if v[i, r]]
+        inv = img_of_rank.numpy()
+        cost = None if region_cost is None else region_cost.numpy()
+        fn = None if cost is None else (lambda rk, rid: int(cost[inv[rk], rid]))
+        taken = port.select_regions(tuples, budget, fn)
+        return (len(taken), np.array([inv[t[1]] for t in taken], dtype=np.int32),
+                np.array([t[2] for t in taken], dtype=np.int32), np.array([t[0] for t in taken], dtype=np.float32))
+
+
+class FakePool(torch.utils.data.Dataset):
+    """Pool dataset whose 'images' ARE the logits (the fake trainer's net is the identity)."""
+
+    def __init__(self, logits, spx, im_idx, suppix):
+        self.logits, self.spx = torch.from_numpy(logits), torch.from_numpy(spx)
+        self.im_idx = [list(k) for k in im_idx]
+        self.suppix = {k: list(v) for k, v in suppix.items()}
+
+    def __len__(self):
+        return len(self.im_idx)
+
+    def __getitem__(self, i):
+        return {'images': self.logits[i], 'spx': self.spx[i]}
+
+
+def fake_trainer(device='cpu', save_dir=None):
+    return types.SimpleNamespace(net=torch.nn.Identity(), device=torch.device(device), model_save_dir=save_dir,
+                                 selection_iter=1)
+
+
+def selector_args(**kw):
+    base = dict(val_batch_size=2, val_num_workers=0, nseg=64, active_method='x', num_classes=19, ce_temp=0.1,
+                cls_weight_coeff=6.0, method='active_joint_multi_predignore_lossdecomp', save_scores=False,
+                fair_counting=True, or_labeling=True, model_save_dir=None, finetune_itrs=1,
+                wandb=types.SimpleNamespace(log=lambda *a, **k: None))
+    base.update(kw)
+    return types.SimpleNamespace(**base)

@@ -25,7 +25,7 @@ def _device_select(ops, scores, valid, paths, cost_bits, budget, max_out=None):
     keys = ops.region_keys(torch.from_numpy(scores).cuda(), None if valid is None else torch.from_numpy(valid).cuda(),
                            torch.from_numpy(img_rank).cuda())
     skeys = ops.sort_keys_desc(keys)
-    cb = None if cost_bits is None else torch.from_numpy(cost_bits.astype(np.int32)).cuda()
+    cb = None if cost_bits is None else torch.from_numpy(cost_bits.astype(np.uint8)).cuda()
     nsel, simg, sid, ssc = ops.budget_walk(skeys, cb, torch.from_numpy(img_of_rank).cuda(), S, budget, max_out)
     n = int(nsel.item())
     return n, simg.cpu().numpy(), sid.cpu().numpy(), ssc.cpu().numpy()
@@ -53,8 +53,7 @@ def test_g1_selection_matches_executed_reference():
     paths = ["leftImg8bit/train/c/img_%04d.png,gtFine/train/c/lbl_%04d.png,superpixel/train/c/spx_%04d.pkl" % (i, i, i)
              for i in range(n_img)]
     mh = g['multi_hot']
-    bits = (mh.astype(np.uint32) << np.arange(mh.shape[2], dtype=np.uint32)).sum(axis=2).astype(np.uint32)
-    n, simg, sid, ssc = _device_select(ops, scores, valid, paths, bits, int(g['budget']))
+    n, simg, sid, ssc = _device_select(ops, scores, valid, paths, mh.sum(axis=2), int(g['budget']))
     assert n == len(g['consumed_img'])
     assert np.array_equal(simg[:n], g['consumed_img']) and np.array_equal(sid[:n], g['consumed_id'])
     assert np.array_equal(ssc[:n].astype(np.float64), g['consumed_score'])
@@ -78,7 +77,7 @@ def test_tie_heavy_random_pools(n_img, S, budget, fair):
     names = rs.permutation(n_img)
     paths = ["a/img_%d.png,b/lbl_%d.png,c/spx_%d.pkl" % (k, k, k) for k in names]   # "img_10" < "img_9" etc.
     cost = rs.randint(1, 5, size=(n_img, S))
-    bits = ((1 << cost) - 1).astype(np.uint32)          # popcount(bits) == cost
+    bits = cost
     ref = _python_select(scores, valid, paths, cost if fair else None, budget)
     n, simg, sid, ssc = _device_select(ops, scores, valid, paths, bits if fair else None, budget, max_out=budget + 1)
     assert n == len(ref)
@@ -95,3 +94,17 @@ def test_negative_and_zero_scores_order():
     n, simg, sid, _ = _device_select(ops, scores, None, paths, None, 100)
     assert n == 8
     assert [(int(a), int(b)) for a, b in zip(simg[:n], sid[:n])] == [(a, b) for a, b, _ in ref]
+
+
+def test_minmax_normalize_matches_plain_bvsb_reference():
+    """my_bvsb.py:79-81 on the golden's un-normalised region means is not stored; check the formula
+    against numpy f32 arithmetic instead (sub and div are correctly rounded on both sides)."""
+    ops = _gpu()
+    rs = np.random.RandomState(3)
+    u = rs.uniform(1e-8, 0.9, size=(7, 150)).astype(np.float32)
+    u[rs.uniform(size=u.shape) < 0.2] = 0.0
+    mn = u[u != 0].min()
+    ref = (u - mn)
+    ref = ref / ref.max()
+    out = ops.minmax_normalize_(torch.from_numpy(u.copy()).cuda()).cpu().numpy()
+    assert np.array_equal(out, ref)

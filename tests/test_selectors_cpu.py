@@ -1,0 +1,154 @@
+"""Host logic of the selector plugins (plugin surface, sharding-free path, tuple lists, selection walk,
+active-set bookkeeping) on CPU, with the oracle standing in for the GPU backend.  Expected values are
+the golden vectors produced by executing the reference (tests/golden/g1, g2)."""
+import os
+import pickle
+import tempfile
+import types
+
+import numpy as np
+import pytest
+import torch
+
+from helpers import FakePool, OracleBackend, fake_trainer, selector_args
+from test_oracle_golden import GOLDEN, g1_inputs, g2_inputs, tuples_to_arrays
+
+RTOL = 1e-5      # floats: exact-arithmetic oracle vs the reference's ATen f32 (observed ~4e-7)
+
+
+def _selector(modname, args):
+    import importlib
+    mod = importlib.import_module("mulactseg_amd.active_selection." + modname)
+    sel = mod.RegionSelector(args)
+    sel.backend = OracleBackend()
+    return sel
+
+
+def test_pixbal_banignore_plugin_matches_reference_g1():
+    g = np.load(os.path.join(GOLDEN, "g1_pixbal_city.npz"))
+    z, spx, im_idx, suppix = g1_inputs(g)
+    n_img, S = int(g['n_img']), int(g['S'])
+    args = selector_args(val_batch_size=int(g['batch_size']), nseg=S)
+    sel = _selector("my_bvsb_predclsbal_pwr_banignore", args)
+    pool = FakePool(z, spx, im_idx, suppix)
+    scores, hist = sel.calculate_scores_tensor(fake_trainer(), pool, want_hist=True)
+    assert np.array_equal(hist.numpy(), g['region_ntop1'])                       # integer output: exact
+    assert np.allclose(sel.cumulated_pred_prob, g['cum'], rtol=RTOL, atol=1e-8)
+    assert np.allclose(sel.cls_weight.numpy(), g['cls_weight'], rtol=RTOL)
+    ref = g['scores_tensor']
+    assert np.array_equal(scores.numpy() == 0, ref == 0)                         # same banned / absent regions
+    assert np.allclose(scores.numpy(), ref, rtol=RTOL, atol=1e-9)
+    # drop-in tuple list API
+    tuples = sel.calculate_scores(fake_trainer(), pool)
+    sc, si, sid = tuples_to_arrays(tuples, im_idx)
+    assert np.array_equal(si, g['list_img']) and np.array_equal(sid, g['list_id'])
+    assert np.allclose(sc, g['list_score'], rtol=RTOL, atol=1e-9)
+    # ordering identical to the reference's sorted(reverse=True)
+    oc, oi, oid = tuples_to_arrays(sorted(tuples, reverse=True)[:60], im_idx)
+    assert np.array_equal(oi, g['sorted_img']) and np.array_equal(oid, g['sorted_id'])
+
+
+def _active_set(g, z, spx, im_idx, suppix, tmp):
+    from mulactseg_amd.dataloader import RegionActiveDataset
+    n_img, S = int(g['n_img']), int(g['S'])
+    pool = FakePool(z, spx, im_idx, suppix)
+    pool.isselected = np.zeros((n_img, S), dtype=np.uint8)
+    label = types.SimpleNamespace(im_idx=[], suppix={}, multi_hot_cls=g['multi_hot'],
+                                  id_to_index={"spx_%04d" % i: i for i in range(n_img)})
+    args = selector_args(val_batch_size=int(g['batch_size']), nseg=S, model_save_dir=tmp)
+    active = RegionActiveDataset(args, pool, label)
+    active.selection_iter = 1
+    return args, active
+
+
+def test_select_next_batch_reproduces_reference_selection_g1():
+    g = np.load(os.path.join(GOLDEN, "g1_pixbal_city.npz"))
+    z, spx, im_idx, suppix = g1_inputs(g)
+    tmp = tempfile.mkdtemp()
+    args, active = _active_set(g, z, spx, im_idx, suppix, tmp)
+    args.active_method = 'pixbal'
+    sel = _selector("my_bvsb_predclsbal_pwr_banignore", args)
+    n_pool_before = sum(len(v) for v in active.trg_pool_dataset.suppix.values())
+    sel.select_next_batch(fake_trainer(save_dir=tmp), active, int(g['budget']))
+    with open(os.path.join(tmp, 'pixbal_selection_01.pkl'), 'rb') as f:
+        consumed = pickle.load(f)
+    cc, ci, cid = tuples_to_arrays(consumed, im_idx)
+    assert np.array_equal(ci, g['consumed_img']) and np.array_equal(cid, g['consumed_id'])      # bit-exact set+order
+    assert np.allclose(cc, g['consumed_score'], rtol=RTOL)
+    assert np.array_equal(active.trg_pool_dataset.isselected, g['isselected'])
+    n_pool_after = sum(len(v) for v in active.trg_pool_dataset.suppix.values())
+    assert n_pool_before - n_pool_after == len(consumed)
+    lab = active.trg_label_dataset
+    assert sum(len(v) for v in lab.suppix.values()) == len(consumed)
+    # datalist round trip
+    active.dump_datalist()
+    pool_idx = list(active.trg_pool_dataset.im_idx)
+    active.trg_pool_dataset.im_idx = []
+    active.load_datalist()
+    assert active.trg_pool_dataset.im_idx == pool_idx
+
+
+def test_voc_selectors_match_reference_g2():
+    g = np.load(os.path.join(GOLDEN, "g2_voc.npz"))
+    z, spx, im_idx, suppix = g2_inputs(g)
+    S, C = int(g['S']), int(g['C'])
+    tr = fake_trainer()
+    for tag, method, ncls, zz in (('plain', 'active_joint_multi_lossdecomp', C, z),
+                                  ('strip', 'active_joint_multi_predignore_lossdecomp', C - 1, z)):
+        args = selector_args(val_batch_size=int(g['batch_size']), nseg=S, num_classes=ncls, method=method,
+                             cls_weight_coeff=12.0)
+        sel = _selector("my_bvsb", args)
+        s = sel.calculate_scores_tensor(tr, FakePool(zz, spx, im_idx, suppix)).numpy()
+        ref = g['bvsb_%s_scores_tensor' % tag]
+        assert np.allclose(s, ref, rtol=1e-4, atol=2e-6)      # the (u-min)/max normalisation amplifies 1-ulp noise near 0
+        tuples = sel.calculate_scores(tr, FakePool(zz, spx, im_idx, suppix))
+        sc, si, sid = tuples_to_arrays(tuples, im_idx)
+        assert np.array_equal(sid, g['bvsb_%s_list_id' % tag]) and np.array_equal(si, g['bvsb_%s_list_img' % tag])
+    args = selector_args(val_batch_size=int(g['batch_size']), nseg=S, num_classes=C, cls_weight_coeff=12.0,
+                         method='active_joint_multi_lossdecomp')
+    sel = _selector("my_bvsb_predclsbal_pwr", args)
+    scores, hist = sel.calculate_scores_tensor(tr, FakePool(z, spx, im_idx, suppix), want_hist=True)
+    assert np.array_equal(hist.numpy(), g['pwr_region_ntop1'])
+    assert np.allclose(sel.cls_weight.numpy(), g['pwr_cls_weight'], rtol=RTOL)
+    assert np.allclose(scores.numpy(), g['pwr_scores_tensor'], rtol=RTOL, atol=1e-9)
+
+
+def test_random_and_dummy_selectors():
+    g = np.load(os.path.join(GOLDEN, "g1_pixbal_city.npz"))
+    z, spx, im_idx, suppix = g1_inputs(g)
+    tmp = tempfile.mkdtemp()
+    args, active = _active_set(g, z, spx, im_idx, suppix, tmp)
+    args.active_method = 'my_random'
+    from mulactseg_amd.active_selection import dummy, my_random
+    import random
+    random.seed(0)
+    sel = my_random.RegionSelector(args)
+    sel.select_next_batch(fake_trainer(save_dir=tmp), active, 25)
+    with open(os.path.join(tmp, 'my_random_selection_01.pkl'), 'rb') as f:
+        consumed = pickle.load(f)
+    cost = sum(int(g['multi_hot'][int(p.split('spx_')[1][:4]), i].sum()) for _, p, i in consumed)
+    assert cost > 25 and cost - int(g['multi_hot'][int(consumed[-1][1].split('spx_')[1][:4]), consumed[-1][2]].sum()) <= 25
+    dummy.RegionSelector(args).select_next_batch(None, None, 0)
+
+
+def test_class_weight_host_arithmetic_matches_c_oracle():
+    from mulactseg_amd.active_selection.engine import class_weight_from_sums
+    from oracle import exact
+    rs = np.random.RandomState(0)
+    n_img, C, hw = 7, 20, 1024 * 2048
+    ps = (rs.uniform(0, 1, size=(n_img, C)) * hw * 2 ** 31 / C).astype(np.uint64)
+    batch_of = (np.arange(n_img) // 4).astype(np.int32)
+    cum_c, w_c = exact.class_weight(ps, hw, batch_of, 2, 6.0)
+    cum_p, w_p = class_weight_from_sums(ps.view(np.int64), hw, batch_of, 2, 6.0)
+    assert np.array_equal(cum_c, cum_p) and np.array_equal(w_c, w_p)
+
+
+def test_product_package_never_imports_the_oracle():
+    """The oracle is test infrastructure: nothing under mulactseg_amd/ may import or load it."""
+    root = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "mulactseg_amd")
+    for dirpath, _, files in os.walk(root):
+        for f in files:
+            if f.endswith(('.py', '.hip', '.h')):
+                text = open(os.path.join(dirpath, f)).read()
+                for needle in ('from oracle', 'import oracle', 'libexact', 'oracle/port', 'oracle.port'):
+                    assert needle not in text, (f, needle)

@@ -1,0 +1,91 @@
+"""The selector plugins end to end on the GPU (real HipBackend through the C ABI): plugin surface of the
+reference, expected values from the executed reference (g1, g2), bit-exact equality with the C oracle."""
+import os
+import pickle
+import tempfile
+import types
+
+import numpy as np
+import pytest
+import torch
+
+from helpers import FakePool, fake_trainer, selector_args
+from test_oracle_golden import GOLDEN, g1_inputs, g2_inputs, tuples_to_arrays
+
+pytestmark = pytest.mark.gpu
+RTOL = 1e-5
+
+
+def _need_gpu():
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+
+
+def test_pixbal_banignore_on_gpu_matches_reference_and_oracle():
+    _need_gpu()
+    from mulactseg_amd.active_selection import my_bvsb_predclsbal_pwr_banignore as banignore
+    from mulactseg_amd.active_selection.engine import HipBackend
+    from mulactseg_amd.dataloader import RegionActiveDataset
+    from helpers import OracleBackend
+    g = np.load(os.path.join(GOLDEN, "g1_pixbal_city.npz"))
+    z, spx, im_idx, suppix = g1_inputs(g)
+    n_img, S = int(g['n_img']), int(g['S'])
+    tmp = tempfile.mkdtemp()
+    args = selector_args(val_batch_size=int(g['batch_size']), nseg=S, model_save_dir=tmp, active_method='pixbal')
+    sel = banignore.RegionSelector(args)
+    tr = fake_trainer('cuda:0', tmp)
+    scores, hist = sel.calculate_scores_tensor(tr, FakePool(z, spx, im_idx, suppix), want_hist=True)
+    assert isinstance(sel.backend, HipBackend)                       # the native path ran, nothing else
+    assert np.array_equal(hist.cpu().numpy(), g['region_ntop1'])
+    assert np.allclose(scores.cpu().numpy(), g['scores_tensor'], rtol=RTOL, atol=1e-9)
+    assert np.array_equal(scores.cpu().numpy() == 0, g['scores_tensor'] == 0)
+    # bit-exact against the C oracle driven through the same host logic
+    ref = banignore.RegionSelector(args)
+    ref.backend = OracleBackend()
+    rs, rh = ref.calculate_scores_tensor(fake_trainer(), FakePool(z, spx, im_idx, suppix), want_hist=True)
+    assert np.array_equal(scores.cpu().numpy(), rs.numpy()) and np.array_equal(hist.cpu().numpy(), rh.numpy())
+    assert np.array_equal(sel.cls_weight.cpu().numpy(), ref.cls_weight.numpy())
+    # selection through the reference-shaped driver call
+    pool = FakePool(z, spx, im_idx, suppix)
+    pool.isselected = np.zeros((n_img, S), dtype=np.uint8)
+    label = types.SimpleNamespace(im_idx=[], suppix={}, multi_hot_cls=g['multi_hot'],
+                                  id_to_index={"spx_%04d" % i: i for i in range(n_img)})
+    active = RegionActiveDataset(args, pool, label)
+    active.selection_iter = 1
+    sel.select_next_batch(tr, active, int(g['budget']))
+    with open(os.path.join(tmp, 'pixbal_selection_01.pkl'), 'rb') as f:
+        consumed = pickle.load(f)
+    cc, ci, cid = tuples_to_arrays(consumed, im_idx)
+    assert np.array_equal(ci, g['consumed_img']) and np.array_equal(cid, g['consumed_id'])
+    assert np.array_equal(pool.isselected, g['isselected'])
+
+
+def test_voc_selectors_on_gpu_match_reference():
+    _need_gpu()
+    from mulactseg_amd.active_selection import my_bvsb, my_bvsb_predclsbal_pwr
+    g = np.load(os.path.join(GOLDEN, "g2_voc.npz"))
+    z, spx, im_idx, suppix = g2_inputs(g)
+    S, C = int(g['S']), int(g['C'])
+    tr = fake_trainer('cuda:0')
+    for tag, method, ncls in (('plain', 'active_joint_multi_lossdecomp', C), ('strip', 'active_joint_multi_predignore_lossdecomp', C - 1)):
+        args = selector_args(val_batch_size=int(g['batch_size']), nseg=S, num_classes=ncls, method=method)
+        sel = my_bvsb.RegionSelector(args)
+        s = sel.calculate_scores_tensor(tr, FakePool(z, spx, im_idx, suppix)).cpu().numpy()
+        assert np.allclose(s, g['bvsb_%s_scores_tensor' % tag], rtol=1e-4, atol=2e-6)
+        tuples = sel.calculate_scores(tr, FakePool(z, spx, im_idx, suppix))
+        _, si, sid = tuples_to_arrays(tuples, im_idx)
+        assert np.array_equal(sid, g['bvsb_%s_list_id' % tag]) and np.array_equal(si, g['bvsb_%s_list_img' % tag])
+    args = selector_args(val_batch_size=int(g['batch_size']), nseg=S, num_classes=C, cls_weight_coeff=12.0,
+                         method='active_joint_multi_lossdecomp')
+    sel = my_bvsb_predclsbal_pwr.RegionSelector(args)
+    scores, hist = sel.calculate_scores_tensor(tr, FakePool(z, spx, im_idx, suppix), want_hist=True)
+    assert np.array_equal(hist.cpu().numpy(), g['pwr_region_ntop1'])
+    assert np.allclose(scores.cpu().numpy(), g['pwr_scores_tensor'], rtol=RTOL, atol=1e-9)
+
+
+def test_backend_refuses_cpu_device():
+    _need_gpu()
+    from mulactseg_amd import _lib
+    from mulactseg_amd.active_selection.engine import HipBackend
+    with pytest.raises(_lib.MulActSegHipError):
+        HipBackend('cpu')
