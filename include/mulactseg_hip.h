@@ -176,6 +176,25 @@ int mas_budget_walk(const uint64_t* sorted_keys, int64_t n, const uint8_t* regio
  * scratch2: 2 x uint32 of caller-owned device scratch. */
 int mas_minmax_normalize(float* scores, int64_t n, uint32_t* scratch2, void* stream);
 
+/* =============================================================================================
+ * mIoU counters
+ * ============================================================================================= */
+
+/* counts layout (uint64, caller-zeroed, accumulated across calls):
+ *   [0,C) seen, [C,2C) correct, [2C,3C) positive  over pixels with target != ignore_label
+ *   [3C] [3C+1] [3C+2]  seen / correct / positive of the "undefined" class (IoUIgnore).
+ * outputs      int64 [n]: predicted labels for the C classes (MeanIoU._after_step, utils/miou.py:23-38)
+ * outputs_all  int64 [n] or NULL: predictions including the extra class, value C = "undefined"
+ *              (IoUIgnore._after_step, utils/miou_evalignore.py:20-32). */
+int mas_iou_counts(const int64_t* outputs, const int64_t* outputs_all, const int64_t* targets, int64_t n,
+                   int num_classes, int64_t ignore_label, uint64_t* counts /* [3C+3] */, void* stream);
+
+/* Fused form for the evaluation loop (trainer/active_joint_multi_predignore.py:196-203): one read of
+ * logits [B,channels,H,W] f32 (channels = num_classes or num_classes+1) yields argmax over the first
+ * num_classes channels, argmax over all channels and every counter above; first maximum wins. */
+int mas_logits_iou_counts(const float* z, const int64_t* targets, int B, int channels, int H, int W, int num_classes,
+                          int64_t ignore_label, uint64_t* counts /* [3C+3] */, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

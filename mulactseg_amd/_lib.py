@@ -30,6 +30,8 @@ SIGNATURES = {
     "mas_sort_keys_desc": (_i, [_vp, _i64, _vp, _vp, _c.c_size_t, _vp]),
     "mas_budget_walk": (_i, [_vp, _i64, _vp, _vp, _i, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _c.c_size_t, _vp]),
     "mas_minmax_normalize": (_i, [_vp, _i64, _vp, _vp]),
+    "mas_iou_counts": (_i, [_vp, _vp, _vp, _i64, _i, _i64, _vp, _vp]),
+    "mas_logits_iou_counts": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i64, _vp, _vp]),
     "mas_target_bits": (_i, [_vp, _i64, _i, _i, _vp, _vp]),
     "mas_partial_loss_fwd": (_i, [_vp, _vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _f, _i, _vp, _vp, _vp]),
     "mas_group_finalize": (_i, [_vp, _i64, _vp, _vp]),

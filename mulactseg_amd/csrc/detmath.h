@@ -46,14 +46,16 @@ MAS_HD float mas_u2f(uint32_t u) {
 /* 2^n for n in [-126, 127] */
 MAS_HD float mas_pow2i(int n) { return mas_u2f((uint32_t)(n + 127) << 23); }
 
-/* exp(x), f32, ~1 ulp.  x < -104 -> 0 ; x > 88.72 -> +inf. */
+/* exp(x), f32, ~1 ulp.  x < -104 -> 0 ; x > 88.72 -> +inf ; NaN -> NaN.
+ * Branch-free on purpose (64-lane waves: a divergent early return costs more than the selects). */
 MAS_HD float mas_expf(float x) {
-    if (!(x >= -104.0f)) return (x != x) ? x : 0.0f;
-    if (x > 88.72f) return mas_u2f(0x7f800000u);
+    float xc = (x < -104.0f) ? -104.0f : x;
+    xc = (xc > 88.72f) ? 88.72f : xc;
+    xc = (x != x) ? 0.0f : xc;
     /* n = round-to-nearest-even(x * log2(e)) via the 1.5*2^23 magic constant */
-    float t = mas_fmaf(x, 1.44269504088896341f, 12582912.0f);
+    float t = mas_fmaf(xc, 1.44269504088896341f, 12582912.0f);
     float n = t - 12582912.0f;
-    float r = mas_fmaf(n, -0.693359375f, x);
+    float r = mas_fmaf(n, -0.693359375f, xc);
     r = mas_fmaf(n, 2.12194440e-4f, r);
     float p = 1.9875691500e-4f;
     p = mas_fmaf(p, r, 1.3981999507e-3f);
@@ -64,7 +66,10 @@ MAS_HD float mas_expf(float x) {
     float y = mas_fmaf(p, r * r, r) + 1.0f;
     int ni = (int)n;
     int h = ni / 2;               /* two exact power-of-two scalings: single final rounding */
-    return (y * mas_pow2i(h)) * mas_pow2i(ni - h);
+    float res = (y * mas_pow2i(h)) * mas_pow2i(ni - h);
+    res = (x < -104.0f) ? 0.0f : res;
+    res = (x > 88.72f) ? mas_u2f(0x7f800000u) : res;
+    return (x != x) ? x : res;
 }
 
 /* log(x) for finite x > 0, f32, ~1 ulp. */
@@ -102,18 +107,24 @@ MAS_HD float mas_logf(float x) {
 }
 
 /* Unsigned fixed point: floor(v * 2^FRAC) for finite v in [0, 2^(63-FRAC)); exact (no rounding other
- * than the floor).  Written with integer shifts on the f32 bit pattern so that host and device agree
- * without relying on float->int64 conversion sequences. */
+ * than the floor); negative, zero and subnormal inputs give 0.  Written with integer shifts on the f32
+ * bit pattern (branch-free) so that host and device agree without relying on float->int64 conversion
+ * sequences. */
 MAS_HD uint64_t mas_fix(float v, int frac) {
-    uint32_t b = mas_f2u(v);
-    if (b >> 31) return 0;                   /* negative / -0 -> 0 */
-    int e = (int)(b >> 23);
-    if (e == 0) return 0;                    /* zero or subnormal: below 2^-126 */
-    uint64_t m = (uint64_t)((b & 0x007fffffu) | 0x00800000u);
-    int sh = e - 150 + frac;                 /* value = m * 2^(e-150) */
-    if (sh >= 0) return (sh > 39) ? ~(uint64_t)0 : (m << sh);
-    return (sh < -24) ? 0 : (m >> (-sh));
+    const uint32_t b = mas_f2u(v);
+    const int e = (int)((b >> 23) & 0xffu);
+    const uint64_t m = (uint64_t)((b & 0x007fffffu) | 0x00800000u);
+    const int sh = e - 150 + frac;                 /* value = m * 2^(e-150) */
+    const int l = sh < 0 ? 0 : (sh > 39 ? 39 : sh);
+    const int r = sh < 0 ? (-sh > 63 ? 63 : -sh) : 0;
+    uint64_t q = (m << l) >> r;
+    q = (sh > 39) ? ~(uint64_t)0 : q;              /* saturate (never reached by the accumulators below) */
+    return ((b >> 31) | (uint32_t)(e == 0)) ? (uint64_t)0 : q;
 }
+
+/* floor(p * 2^31) for p in [0, 2): one multiply and one truncating conversion (same value as
+ * mas_fix(p, 31) on that domain). */
+MAS_HD uint32_t mas_fix31(float p) { return (uint32_t)(p * 2147483648.0f); }
 
 #define MAS_SCORE_FRAC 40   /* per-region sum of weighted BvSB: v in (0, 1.0000001], <= 2^23 px/region */
 #define MAS_PROB_FRAC  31   /* per-image class-probability sums: p in [0, 1.0000001], <= 2^32 px/image */

@@ -62,7 +62,7 @@ __global__ __launch_bounds__(kThreads) void k_class_prob_sum(const float* __rest
             if (ok[k]) {
 #pragma unroll
                 for (int c = 0; c < CT; ++c)
-                    if (EXACT || c < C) acc[c] += mas_fix(v[k][c], MAS_PROB_FRAC);
+                    if (EXACT || c < C) acc[c] += mas_fix31(v[k][c]);
             }
         }
     }

@@ -7,3 +7,25 @@ The reference's ~45 dataset variants, PIL augmentation and on-disk formats are o
 """
 from .region_active_dataset import RegionActiveDataset  # noqa: F401
 from .utils import DataProvider, collate_fn  # noqa: F401
+
+
+_DATASET_FACTORY = None
+
+
+def register_dataset_factory(fn):
+    """Plug a dataset constructor ``fn(args, name, data_root, datalist, imageset) -> Dataset`` in.
+
+    The reference's dataset classes (``dataloader/region_*.py``, ``dataloader/dataset.py``) and their
+    on-disk formats are outside the hot path; the trainers only need
+    objects that yield ``{'images' f32[3,H,W], 'labels' ...}`` (+ ``'spx'``, ``'spmask'`` for stage 1)."""
+    global _DATASET_FACTORY
+    _DATASET_FACTORY = fn
+
+
+def get_dataset(args, name, data_root, datalist, imageset):
+    """Reference ``dataloader/__init__.py:get_dataset`` entry point, backed by the registered factory."""
+    if _DATASET_FACTORY is None:
+        raise NotImplementedError(
+            "no dataset factory registered: call mulactseg_amd.dataloader.register_dataset_factory(fn); the "
+            "reference's Cityscapes/VOC file readers are out of scope for the hot path")
+    return _DATASET_FACTORY(args, name, data_root, datalist, imageset)

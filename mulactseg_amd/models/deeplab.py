@@ -1,0 +1,227 @@
+"""DeepLabv3+ with the weight-normalised (cosine) classifier over a deep-stem ResNet, OS 16.
+
+Architecture and parameter names follow the reference so that checkpoints interchange:
+  backbone   ``models/segmentation/backbone/resnet.py:119-232`` (deep stem 3x(3x3), Bottleneck x [3,4,6,3],
+             layer4 dilated for output stride 16, ``modeling.py:11-16``), wrapped like
+             ``IntermediateLayerGetter`` (``utils.py:45-100``): returns layer1 ('low_level') and layer4 ('out');
+  head       ``DeepLabHeadV3PlusWN`` (``deeplabv3.py:85-137``): low-level 1x1 -> 48, ASPP (1x1 | three atrous
+             separable 3x3, d = 6/12/18 | image pooling) -> 1x1 256 + Dropout(0.1), bilinear x4, concat 304 ->
+             two atrous-separable 3x3 256, then cosine similarity with the class proxies;
+  wrapper    ``_SimpleSegmentationModel`` (``utils.py:6-42``): bilinear upsample to the input size.
+``convert_to_separable_conv`` (``deeplabv3.py:249-261``) semantics are built in: every k > 1 conv of the HEAD
+is depthwise(k, dilation, no bias) followed by pointwise 1x1 (no bias), with nothing in between.
+
+This file is the plain PyTorch (MIOpen / hipBLASLt) form of the model; the HIP fast paths for the ASPP
+depthwise triple (K7) and the cosine head + upsample (K8) plug in underneath where available.
+"""
+from collections import OrderedDict
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+
+# ------------------------------------------------------------------------------------------------
+# backbone
+# ------------------------------------------------------------------------------------------------
+class Bottleneck(nn.Module):
+    expansion = 4
+
+    def __init__(self, inplanes, planes, stride=1, dilation=1, downsample=None):
+        super().__init__()
+        self.conv1 = nn.Conv2d(inplanes, planes, 1, bias=False)
+        self.bn1 = nn.BatchNorm2d(planes)
+        self.conv2 = nn.Conv2d(planes, planes, 3, stride=stride, padding=dilation, dilation=dilation, bias=False)
+        self.bn2 = nn.BatchNorm2d(planes)
+        self.conv3 = nn.Conv2d(planes, planes * self.expansion, 1, bias=False)
+        self.bn3 = nn.BatchNorm2d(planes * self.expansion)
+        self.relu = nn.ReLU(inplace=True)
+        self.downsample = downsample
+        self.stride = stride
+
+    def forward(self, x):
+        y = self.relu(self.bn1(self.conv1(x)))
+        y = self.relu(self.bn2(self.conv2(y)))
+        y = self.bn3(self.conv3(y))
+        if self.downsample is not None:
+            x = self.downsample(x)
+        y += x
+        return self.relu(y)
+
+
+class DeepStemResNetTrunk(nn.Module):
+    """conv1 (3 convs) / bn1 / relu / maxpool / layer1..layer4; returns {'low_level', 'out'}."""
+
+    def __init__(self, layers=(3, 4, 6, 3), stem_width=64, output_stride=16):
+        super().__init__()
+        if output_stride == 16:
+            dilate = (False, False, True)
+        elif output_stride == 8:
+            dilate = (False, True, True)
+        else:
+            raise ValueError("output_stride must be 8 or 16")
+        w = stem_width
+        self.conv1 = nn.Sequential(
+            nn.Conv2d(3, w, 3, stride=2, padding=1, bias=False), nn.BatchNorm2d(w), nn.ReLU(inplace=True),
+            nn.Conv2d(w, w, 3, stride=1, padding=1, bias=False), nn.BatchNorm2d(w), nn.ReLU(inplace=True),
+            nn.Conv2d(w, 2 * w, 3, stride=1, padding=1, bias=False))
+        self.bn1 = nn.BatchNorm2d(2 * w)
+        self.relu = nn.ReLU(inplace=True)
+        self.maxpool = nn.MaxPool2d(kernel_size=3, stride=2, padding=1)
+        self._inplanes, self._dilation = 2 * w, 1
+        self.layer1 = self._stage(64, layers[0], 1, False)
+        self.layer2 = self._stage(128, layers[1], 2, dilate[0])
+        self.layer3 = self._stage(256, layers[2], 2, dilate[1])
+        self.layer4 = self._stage(512, layers[3], 2, dilate[2])
+        for m in self.modules():
+            if isinstance(m, nn.Conv2d):
+                nn.init.kaiming_normal_(m.weight, mode='fan_out', nonlinearity='relu')
+            elif isinstance(m, nn.BatchNorm2d):
+                nn.init.constant_(m.weight, 1)
+                nn.init.constant_(m.bias, 0)
+
+    def _stage(self, planes, blocks, stride, dilate):
+        prev = self._dilation
+        if dilate:
+            self._dilation *= stride
+            stride = 1
+        down = None
+        if stride != 1 or self._inplanes != planes * Bottleneck.expansion:
+            down = nn.Sequential(nn.Conv2d(self._inplanes, planes * Bottleneck.expansion, 1, stride=stride, bias=False),
+                                 nn.BatchNorm2d(planes * Bottleneck.expansion))
+        mods = [Bottleneck(self._inplanes, planes, stride, prev, down)]
+        self._inplanes = planes * Bottleneck.expansion
+        mods += [Bottleneck(self._inplanes, planes, 1, self._dilation) for _ in range(1, blocks)]
+        return nn.Sequential(*mods)
+
+    def forward(self, x):
+        x = self.maxpool(self.relu(self.bn1(self.conv1(x))))
+        low = self.layer1(x)
+        out = self.layer4(self.layer3(self.layer2(low)))
+        return OrderedDict(low_level=low, out=out)
+
+
+# ------------------------------------------------------------------------------------------------
+# head
+# ------------------------------------------------------------------------------------------------
+class AtrousSeparableConvolution(nn.Module):
+    """depthwise kxk (dilated) -> pointwise 1x1, both bias-free, nothing in between
+    (``deeplabv3.py:168-192`` as instantiated by ``convert_to_separable_conv``)."""
+
+    def __init__(self, in_channels, out_channels, kernel_size, padding, dilation):
+        super().__init__()
+        self.body = nn.Sequential(
+            nn.Conv2d(in_channels, in_channels, kernel_size, padding=padding, dilation=dilation, bias=False, groups=in_channels),
+            nn.Conv2d(in_channels, out_channels, 1, bias=False))
+
+    def forward(self, x):
+        return self.body(x)
+
+
+def _conv3x3(cin, cout, dilation, separable):
+    if separable:
+        return AtrousSeparableConvolution(cin, cout, 3, padding=dilation, dilation=dilation)
+    return nn.Conv2d(cin, cout, 3, padding=dilation, dilation=dilation, bias=False)
+
+
+class _ASPPPooling(nn.Sequential):
+    def __init__(self, cin, cout):
+        super().__init__(nn.AdaptiveAvgPool2d(1), nn.Conv2d(cin, cout, 1, bias=False), nn.BatchNorm2d(cout), nn.ReLU(inplace=True))
+
+    def forward(self, x):
+        size = x.shape[-2:]
+        return F.interpolate(super().forward(x), size=size, mode='bilinear', align_corners=False)
+
+
+class ASPP(nn.Module):
+    def __init__(self, cin, rates, separable):
+        super().__init__()
+        cout = 256
+        branches = [nn.Sequential(nn.Conv2d(cin, cout, 1, bias=False), nn.BatchNorm2d(cout), nn.ReLU(inplace=True))]
+        for r in rates:
+            branches.append(nn.Sequential(_conv3x3(cin, cout, r, separable), nn.BatchNorm2d(cout), nn.ReLU(inplace=True)))
+        branches.append(_ASPPPooling(cin, cout))
+        self.convs = nn.ModuleList(branches)
+        self.project = nn.Sequential(nn.Conv2d(5 * cout, cout, 1, bias=False), nn.BatchNorm2d(cout), nn.ReLU(inplace=True),
+                                     nn.Dropout(0.1))
+
+    def forward(self, x):
+        return self.project(torch.cat([conv(x) for conv in self.convs], dim=1))
+
+
+class DeepLabHeadV3PlusWN(nn.Module):
+    def __init__(self, in_channels, low_level_channels, num_classes, aspp_dilate, separable):
+        super().__init__()
+        self.project = nn.Sequential(nn.Conv2d(low_level_channels, 48, 1, bias=False), nn.BatchNorm2d(48), nn.ReLU(inplace=True))
+        self.aspp = ASPP(in_channels, aspp_dilate, separable)
+        self.classifier = nn.Sequential(
+            _conv3x3(304, 256, 1, separable), nn.BatchNorm2d(256), nn.ReLU(inplace=True),
+            _conv3x3(256, 256, 1, separable), nn.BatchNorm2d(256), nn.ReLU(inplace=True))
+        self.final = nn.Conv2d(256, num_classes, 1, bias=False)
+        self.proxy = self.final.weight          # the same Parameter under two names (deeplabv3.py:88-89)
+        self.return_feat = False
+        for m in self.modules():
+            if isinstance(m, nn.Conv2d):
+                nn.init.kaiming_normal_(m.weight)
+            elif isinstance(m, nn.BatchNorm2d):
+                nn.init.constant_(m.weight, 1)
+                nn.init.constant_(m.bias, 0)
+
+    def point_feature(self, feature):
+        low = self.project(feature['low_level'])
+        x = self.aspp(feature['out'])
+        x = F.interpolate(x, size=low.shape[2:], mode='bilinear', align_corners=False)
+        return self.classifier(torch.cat([low, x], dim=1))
+
+    def forward(self, feature):
+        feat = F.normalize(self.point_feature(feature))          # over channels, eps 1e-12
+        out = F.conv2d(feat, F.normalize(self.proxy, dim=1))     # cosine similarity in [-1, 1]
+        return (feat, out) if self.return_feat else out
+
+
+class DeepLabV3PlusWN(nn.Module):
+    def __init__(self, backbone, classifier):
+        super().__init__()
+        self.backbone = backbone
+        self.classifier = classifier
+        self.return_feat = False
+
+    def set_return_feat(self):
+        self.return_feat = True
+        self.classifier.return_feat = True
+
+    def unset_return_feat(self):
+        self.return_feat = False
+        self.classifier.return_feat = False
+
+    def quarter_logits(self, x):
+        """Cosine logits at 1/4 resolution (before the final bilinear upsample)."""
+        keep = self.classifier.return_feat
+        self.classifier.return_feat = False
+        try:
+            return self.classifier(self.backbone(x))
+        finally:
+            self.classifier.return_feat = keep
+
+    def forward(self, x):
+        size = x.shape[-2:]
+        y = self.classifier(self.backbone(x))
+        return F.interpolate(y, size=size, mode='bilinear', align_corners=False)
+
+    def feat_forward(self, x):
+        size = x.shape[-2:]
+        keep = self.classifier.return_feat
+        self.classifier.return_feat = True
+        try:
+            feat, prob = self.classifier(self.backbone(x))
+        finally:
+            self.classifier.return_feat = keep
+        return (F.interpolate(feat, size=size, mode='bilinear', align_corners=False),
+                F.interpolate(prob, size=size, mode='bilinear', align_corners=False))
+
+
+def build_deeplabv3pluswn(num_classes, output_stride=16, layers=(3, 4, 6, 3), separable=True):
+    rates = (12, 24, 36) if output_stride == 8 else (6, 12, 18)
+    backbone = DeepStemResNetTrunk(layers, 64, output_stride)
+    head = DeepLabHeadV3PlusWN(2048, 256, num_classes, rates, separable)
+    return DeepLabV3PlusWN(backbone, head)

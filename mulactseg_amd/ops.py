@@ -116,9 +116,11 @@ def _mask_u8(mask):
     return _need(mask, "spmasks", torch.uint8)
 
 
-def partial_loss_fwd(z, spx, mask, bits, invT, flags):
+def partial_loss_fwd(z, spx, mask, bits, invT, flags, reduce_acc=None):
     """Forward scan + group finalize + loss values.  Returns (losses f32[3], acc i64[8], gmax i64[N,S,C])
-    -- all on the device, no host synchronisation."""
+    -- all on the device, no host synchronisation.  ``reduce_acc(acc)`` (optional) runs between the scans
+    and the division: data-parallel training all-reduces the integer sums / counts there so that the
+    normalisers 1 + n are global over the batch, as on one GPU."""
     _need(z, "inputs", torch.float32)
     _need(spx, "superpixels")
     mask = _mask_u8(mask)
@@ -140,6 +142,8 @@ def partial_loss_fwd(z, spx, mask, bits, invT, flags):
                                             acc.data_ptr(), st), "mas_partial_loss_fwd")
         if gmax is not None:
             _lib.check(lib.mas_group_finalize(gmax.data_ptr(), gmax.numel(), acc.data_ptr(), st), "mas_group_finalize")
+        if reduce_acc is not None:
+            reduce_acc(acc)
         _lib.check(lib.mas_loss_values(acc.data_ptr(), flags, losses.data_ptr(), st), "mas_loss_values")
     return losses, acc, gmax
 
@@ -240,3 +244,39 @@ def minmax_normalize_(scores):
         _lib.check(_lib.load().mas_minmax_normalize(scores.data_ptr(), scores.numel(), scratch.data_ptr(), _stream(scores)),
                    "mas_minmax_normalize")
     return scores
+
+
+# ------------------------------------------------------------------------------------------------
+# mIoU counters
+# ------------------------------------------------------------------------------------------------
+def iou_counts(outputs, outputs_all, targets, num_classes, ignore_label, counts=None):
+    """Accumulate seen/correct/positive (+ the 3 "undefined"-class counters) into ``counts`` int64[3C+3].
+    Reference: utils/miou.py:23-38, utils/miou_evalignore.py:20-32."""
+    _need(targets, "targets", torch.int64)
+    if outputs is not None:
+        _need(outputs, "outputs", torch.int64)
+    if outputs_all is not None:
+        _need(outputs_all, "outputs_all", torch.int64)
+    if counts is None:
+        counts = torch.zeros(3 * num_classes + 3, dtype=torch.int64, device=targets.device)
+    with torch.cuda.device(targets.device):
+        _lib.check(_lib.load().mas_iou_counts(outputs.data_ptr() if outputs is not None else None,
+                                              outputs_all.data_ptr() if outputs_all is not None else None,
+                                              targets.data_ptr(), targets.numel(), num_classes, int(ignore_label),
+                                              counts.data_ptr(), _stream(targets)), "mas_iou_counts")
+    return counts
+
+
+def logits_iou_counts(z, targets, num_classes, ignore_label, counts=None):
+    """Fused argmax + counters from logits [B,channels,H,W] (channels = num_classes or num_classes+1)."""
+    _need(z, "logits", torch.float32)
+    _need(targets, "targets", torch.int64)
+    B, CH, H, W = z.shape
+    if tuple(targets.shape) != (B, H, W):
+        raise ValueError("targets %s do not match logits %s" % (tuple(targets.shape), tuple(z.shape)))
+    if counts is None:
+        counts = torch.zeros(3 * num_classes + 3, dtype=torch.int64, device=z.device)
+    with torch.cuda.device(z.device):
+        _lib.check(_lib.load().mas_logits_iou_counts(z.data_ptr(), targets.data_ptr(), B, CH, H, W, num_classes,
+                                                     int(ignore_label), counts.data_ptr(), _stream(z)), "mas_logits_iou_counts")
+    return counts

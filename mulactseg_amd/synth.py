@@ -99,3 +99,27 @@ def train_crop(seed, H, W, S, frac_selected=0.09, pad_frac=0.12):
     selected = rs.uniform(size=S + 1) < frac_selected
     selected[S] = False
     return ids, selected[ids]
+
+
+def synthetic_state_dict(shapes, seed=0):
+    """Deterministic weights from (key name, shape): lets two implementations of the same architecture be
+    loaded with identical parameters without storing 107 MB.  ``shapes``: dict key -> tuple.
+    Conv / linear weights ~ N(0, 2/fan_in), BN weight in [0.8, 1.2], bias / running_mean small,
+    running_var in [0.6, 1.4], counters 0."""
+    import zlib
+    out = {}
+    for key in sorted(shapes):
+        shape = tuple(shapes[key])
+        rs = np.random.RandomState((zlib.crc32(key.encode()) ^ (seed * 2654435761)) & 0x7fffffff)
+        if key.endswith('num_batches_tracked'):
+            out[key] = np.zeros(shape, dtype=np.int64)
+        elif key.endswith('running_var'):
+            out[key] = rs.uniform(0.6, 1.4, size=shape).astype(np.float32)
+        elif key.endswith('running_mean') or key.endswith('.bias'):
+            out[key] = (0.05 * rs.standard_normal(size=shape)).astype(np.float32)
+        elif len(shape) == 1:
+            out[key] = rs.uniform(0.8, 1.2, size=shape).astype(np.float32)
+        else:
+            fan_in = int(np.prod(shape[1:]))
+            out[key] = (np.sqrt(2.0 / fan_in) * rs.standard_normal(size=shape)).astype(np.float32)
+    return out

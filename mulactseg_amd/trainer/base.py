@@ -1,0 +1,178 @@
+"""Base trainer -- reference ``trainer/base.py:21-294``.
+
+Differences that are design, not omissions:
+* one process per GPU: ``device = cuda:LOCAL_RANK`` (the reference hard-codes ``cuda:0``); under
+  ``torch.distributed`` the net is wrapped for gradient all-reduce (RCCL) and evaluation counters are
+  all-reduced as integers;
+* evaluation uses the fused arg-max + IoU-counter kernel (``utils.miou.LogitsIoU``): one read of the
+  logits, no int64 label maps, no per-class host synchronisation;
+* ``wandb`` / pandas summary tables are optional (``args.wandb`` is used when present).
+"""
+import os
+
+import numpy as np
+import torch
+import torch.optim as optim
+
+from ..dataloader.utils import DataProvider
+from ..models import get_model
+from ..utils.common import AverageMeter
+from ..utils.loss import GroupMultiLabelCE, JointMultiLoss, MultiChoiceCE, MyCrossEntropyLoss
+from ..utils.miou import LogitsIoU
+from ..utils.scheduler import PolyLR
+
+
+def _dist():
+    import torch.distributed as dist
+    return dist if dist.is_available() and dist.is_initialized() else None
+
+
+class BaseTrainer(object):
+    predicts_ignore = False          # True when the model emits num_classes + 1 channels
+
+    def __init__(self, args, logger):
+        self.args = args
+        self.logger = logger
+        self.model_save_dir = args.model_save_dir
+        self.best_iou = 0
+        self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+        if not torch.cuda.is_available():
+            raise RuntimeError("the MI355X trainer needs a ROCm device (the reference hard-codes cuda:0, trainer/base.py:27)")
+        self.device = torch.device('cuda', self.local_rank)
+        torch.cuda.set_device(self.device)
+        self.am = AverageMeter()
+
+        self.num_classes = args.num_classes
+        self.net = self.get_al_model()
+        self.net.to(self.device)
+        self.ddp = None
+        d = _dist()
+        if d is not None and d.get_world_size() > 1:
+            self.ddp = torch.nn.parallel.DistributedDataParallel(
+                self.net, device_ids=[self.local_rank], bucket_cap_mb=getattr(args, 'ddp_bucket_mb', 16),
+                gradient_as_bucket_view=True)
+
+        self.get_optim(my_lr=args.train_lr)
+        total_itrs = args.finetune_itrs if hasattr(args, "finetune_itrs") else args.total_itrs
+        if args.scheduler == 'poly':
+            self.scheduler = PolyLR(self.optimizer, total_itrs, power=args.power, min_lr=args.min_lr)
+        elif args.scheduler != 'none':
+            raise NotImplementedError
+        self.get_criterion()
+
+    # -- construction hooks (overridden by the plugins) -------------------------------------------
+    def get_al_model(self):
+        a = self.args
+        return get_model(model=a.model, num_classes=self.num_classes, output_stride=a.output_stride,
+                         separable_conv=a.separable_conv,
+                         pretrained_backbone=getattr(a, 'pretrained_backbone', True))
+
+    def get_optim(self, my_lr):
+        groups = [{'params': self.net.backbone.parameters(), 'lr': my_lr},
+                  {'params': self.net.classifier.parameters(), 'lr': self.args.cls_lr_scale * my_lr}]
+        if self.args.optimizer == 'adamw':
+            self.optimizer = optim.AdamW(params=groups, lr=my_lr, weight_decay=self.args.weight_decay)
+        elif self.args.optimizer == 'sgd':
+            self.optimizer = optim.SGD(params=groups, lr=my_lr, momentum=0.9, weight_decay=self.args.weight_decay)
+        else:
+            raise NotImplementedError
+
+    def get_criterion(self):
+        """The in-scope ``--loss_type`` values of ``trainer/base.py:73-112`` (the production trainers
+        override this; the reference's own 'joint_multi_loss' branch cannot be constructed, Appendix D)."""
+        a = self.args
+        if a.loss_type == 'cross_entropy':
+            self.loss_fun = MyCrossEntropyLoss(ignore_index=a.ignore_idx, reduction='mean', temperature=a.ce_temp)
+        elif a.loss_type == 'multi_choice_ce':
+            self.loss_fun = MultiChoiceCE(num_class=self.num_classes, temperature=a.multi_ce_temp)
+        elif a.loss_type == 'group_multi_label_ce':
+            self.loss_fun = GroupMultiLabelCE(args=a, num_class=self.num_classes, num_superpixel=a.nseg, temperature=a.group_ce_temp)
+        elif a.loss_type == 'joint_multi_loss':
+            self.loss_fun = JointMultiLoss(
+                GroupMultiLabelCE(args=a, num_class=self.num_classes, num_superpixel=a.nseg, temperature=a.group_ce_temp),
+                MultiChoiceCE(num_class=self.num_classes, temperature=a.multi_ce_temp))
+        else:
+            raise NotImplementedError("loss_type %r is outside the hot path" % a.loss_type)
+
+    # -- loaders ------------------------------------------------------------------------------------
+    def get_trainloader(self, dataset):
+        return DataProvider(dataset=dataset, batch_size=self.args.train_batch_size, shuffle=True,
+                            num_workers=self.args.num_workers, pin_memory=True, drop_last=True)
+
+    def get_valloader(self, dataset):
+        return DataProvider(dataset=dataset, batch_size=self.args.val_batch_size, shuffle=False,
+                            num_workers=self.args.val_num_workers, pin_memory=True, drop_last=False)
+
+    def train(self):
+        raise NotImplementedError
+
+    def train_impl(self, total_itrs, val_period):
+        raise NotImplementedError
+
+    def forward_train(self, images):
+        return (self.ddp or self.net)(images)
+
+    # -- evaluation ---------------------------------------------------------------------------------
+    def inference(self, loader, prefix=''):
+        """mIoU over a loader -- ``trainer/base.py:139-175`` / ``active_joint_multi_predignore.py:175-215``."""
+        meter = LogitsIoU(self.num_classes, self.args.ignore_idx)
+        meter._before_epoch()
+        self.net.eval()
+        with torch.no_grad():
+            for _ in range(len(loader)):
+                batch = next(loader)
+                images = batch['images'].to(self.device, dtype=torch.float32)
+                labels = batch['labels'].to(self.device, dtype=torch.long)
+                meter.step(self.net(images).detach(), labels)
+        meter.all_reduce()
+        ious = meter.ious()
+        miou = np.mean(ious)
+        cells = ['%.2f' % miou] + ['%.2f' % v for v in ious]
+        if self.predicts_ignore:
+            cells.append('%.2f' % meter.ignore_iou())
+        table = ','.join(cells)
+        print("\n[AL {}-round]: {}\n{}".format(getattr(self, 'selection_iter', 0), prefix, table), flush=True)
+        return miou, table
+
+    def _wandb_log(self, payload, step):
+        log = getattr(getattr(self.args, 'wandb', None), 'log', None)
+        if log is not None:
+            log(payload, step=step)
+
+    def validate(self, trainiter=None, prefix=''):
+        miou, table = self.inference(loader=self.val_dataset_loader, prefix='validation')
+        self.logger.info('[Validation Result]')
+        self.logger.info('%s' % table)
+        if self.best_iou < miou:
+            self.best_iou = miou
+            self.save_checkpoint()
+        self.logger.info('Current val miou is %.3f %%, while the best val miou is %.3f %%' % (miou, self.best_iou))
+        step = trainiter + int(self.args.finetune_itrs) * (self.selection_iter - 1)
+        self._wandb_log({'{}val-miou'.format(prefix): miou, '{}val-best-miou'.format(prefix): self.best_iou,
+                         '{}selection_iter'.format(prefix): self.selection_iter}, step + 1)
+        return table
+
+    def eval(self, selection_iter):
+        miou, table = self.inference(loader=self.eval_dataset_loader, prefix='evaluation')
+        self.logger.info('[Evaluation Result]')
+        self.logger.info('%s' % table)
+        self.logger.info('Current eval miou is %.3f %%' % miou)
+        self._wandb_log({'eval-miou': miou, 'selection_iter': selection_iter}, int(self.args.finetune_itrs) * selection_iter)
+        tab = getattr(self.args, 'wandb_iou_table', None)
+        if tab is not None:
+            tab.loc[0, 'round_v_miou'] = "{}{:.2f},".format(tab.loc[0]['round_v_miou'], miou)
+            tab.loc[0, "round-{}".format(selection_iter)] = table
+        return table
+
+    # -- checkpoints (``trainer/base.py:281-294``) -----------------------------------------------------
+    def save_checkpoint(self):
+        d = _dist()
+        if d is None or d.get_rank() == 0:
+            torch.save({'model_state_dict': self.net.state_dict(), 'opt_state_dict': self.optimizer.state_dict()},
+                       self.checkpoint_file)
+
+    def load_checkpoint(self, fname, load_optimizer=False):
+        checkpoint = torch.load(fname, map_location=self.device)
+        self.net.load_state_dict(checkpoint['model_state_dict'])
+        if load_optimizer is True:
+            self.optimizer.load_state_dict(checkpoint['opt_state_dict'])

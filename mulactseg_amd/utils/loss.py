@@ -33,11 +33,11 @@ class _PartialLossFn(torch.autograd.Function):
     table; backward is one scan writing dz.  No host synchronisation in either direction."""
 
     @staticmethod
-    def forward(ctx, inputs, bits, superpixels, spmasks, invT, flags):
+    def forward(ctx, inputs, bits, superpixels, spmasks, invT, flags, sync):
         z = inputs.contiguous()
         spx = superpixels.contiguous()
         msk = spmasks.contiguous()
-        losses, acc, gmax = ops.partial_loss_fwd(z, spx, msk, bits, invT, flags)
+        losses, acc, gmax = ops.partial_loss_fwd(z, spx, msk, bits, invT, flags, _all_reduce_sum if sync else None)
         ctx.save_for_backward(z, spx, msk, bits, acc, gmax if gmax is not None else acc)
         ctx.has_gmax = gmax is not None
         ctx.invT, ctx.flags = invT, flags
@@ -49,15 +49,23 @@ class _PartialLossFn(torch.autograd.Function):
         z, spx, msk, bits, acc, gmax = ctx.saved_tensors
         grad_out = torch.stack([g_ce, g_mc, g_group]).to(torch.float32).contiguous()
         dz = ops.partial_loss_bwd(z, spx, msk, bits, gmax if ctx.has_gmax else None, acc, grad_out, ctx.invT, ctx.flags)
-        return dz, None, None, None, None, None
+        return dz, None, None, None, None, None, None
 
 
-def _run(inputs, targets, superpixels, spmasks, temp, flags, drop_last_column):
+def _all_reduce_sum(acc):
+    """Sum the fixed-point loss sums and pixel counts over the data-parallel ranks (RCCL all-reduce of 8
+    int64 words): integer addition, so the result does not depend on the number of GPUs."""
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        dist.all_reduce(acc, op=dist.ReduceOp.SUM)
+
+
+def _run(inputs, targets, superpixels, spmasks, temp, flags, drop_last_column, sync=False):
     if targets.dtype != torch.uint8:
         targets = targets.to(torch.uint8)
     cols = targets.shape[-1]
     bits = ops.target_bits(targets.contiguous(), cols - 1 if drop_last_column else cols)
-    return _PartialLossFn.apply(inputs, bits, superpixels, spmasks, ops.inv_temperature(temp), flags)
+    return _PartialLossFn.apply(inputs, bits, superpixels, spmasks, ops.inv_temperature(temp), flags, sync)
 
 
 class MyCrossEntropyLoss(nn.CrossEntropyLoss):
@@ -163,8 +171,13 @@ class FusedPartialLabelLoss(nn.Module):
     ``GroupMultiLabelCE_onlymulti`` + ``OnehotCEMultihotChoice`` would
     (``trainer/active_joint_multi_predignore_lossdecomp.py:102-103``), reading the logits once."""
 
-    def __init__(self, num_superpixel, group_temperature=1.0, multi_temperature=1.0, only_multi=True, decomp=True):
+    def __init__(self, num_superpixel, group_temperature=1.0, multi_temperature=1.0, only_multi=True, decomp=True,
+                 sync_normalisers=True):
         super().__init__()
+        # under torch.distributed: all-reduce (sum, n) before the division so that the objective equals the
+        # single-GPU objective over the global batch; multiply the loss by world_size before backward()
+        # when gradients are then AVERAGED over ranks (DistributedDataParallel does).
+        self.sync_normalisers = sync_normalisers
         if group_temperature != multi_temperature:
             raise ValueError("the fused scan shares one softmax: group_ce_temp must equal multi_ce_temp "
                              "(both 0.1 in the reference scripts)")
@@ -174,5 +187,6 @@ class FusedPartialLabelLoss(nn.Module):
             | (_lib.LOSS_DECOMP if decomp else 0)
 
     def forward(self, inputs, targets, superpixels, spmasks):
-        ce, mc, group, self.last_acc = _run(inputs, targets, superpixels, spmasks, self.temp, self.flags, False)
+        ce, mc, group, self.last_acc = _run(inputs, targets, superpixels, spmasks, self.temp, self.flags, False,
+                                            sync=self.sync_normalisers)
         return group, ce, mc

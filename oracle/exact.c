@@ -52,7 +52,7 @@ void exact_class_prob_sum(const float* z, int B, int C, int H, int W, float invT
     for (b = 0; b < B; ++b)
         for (i = 0; i < HW; ++i) {
             softmax_row(z + (size_t)b * C * HW + i, HW, C, invT, p);
-            for (c = 0; c < C; ++c) prob_sum[(size_t)b * C + c] += mas_fix(p[c], MAS_PROB_FRAC);
+            for (c = 0; c < C; ++c) prob_sum[(size_t)b * C + c] += mas_fix31(p[c]);
         }
 }
 

@@ -267,6 +267,35 @@ def gen_g3():
     print("g3:", {k: float(v) for k, v in out.items() if k.endswith(('loss0', 'loss1', '_loss'))})
 
 
+def gen_g4():
+    """Model parity (row a-10): the reference's deeplabv3pluswn_resnet50deepstem + convert_to_separable_conv
+    (models/__init__.py:46-49) with weights derived from the key names, eval mode."""
+    from models.segmentation.modeling import deeplabv3pluswn_resnet50deepstem
+    from models.segmentation import convert_to_separable_conv
+    net = deeplabv3pluswn_resnet50deepstem(num_classes=20, output_stride=16, pretrained_backbone=False)
+    convert_to_separable_conv(net.classifier)
+    shapes = {k: tuple(v.shape) for k, v in net.state_dict().items()}
+    sd = synth.synthetic_state_dict(shapes, seed=4)
+    net.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+    net.eval()
+    x = torch.from_numpy(np.random.RandomState(44).standard_normal(size=(1, 3, 129, 161)).astype(np.float32))
+    with torch.no_grad():
+        feats = net.backbone(x)
+        quarter = net.classifier(feats)
+        full = net(x)
+        net.set_return_feat()                       # eval_within_multihot-style use (utils.py:13-15,28-34)
+        feat_up, prob_up = net.feat_forward(x)
+    keys = sorted(shapes)
+    np.savez_compressed(os.path.join(OUT, "g4_model.npz"), seed=4, x_seed=44,
+                        keys=np.array(keys), shapes=np.array([str(shapes[k]) for k in keys]),
+                        low_level_mean=np.float64(feats['low_level'].double().mean()),
+                        out_mean=np.float64(feats['out'].double().mean()),
+                        quarter=quarter.numpy(), full_sub=full[:, :, ::3, ::3].numpy(),
+                        feat_up_sub=feat_up[:, ::16, ::5, ::5].numpy(), prob_up_sub=prob_up[:, :, ::3, ::3].numpy(),
+                        input_digest=digest(x.numpy()))
+    print("g4: quarter", tuple(quarter.shape), "full", tuple(full.shape), float(quarter.abs().max()))
+
+
 def gen_g5():
     from utils.miou import MeanIoU
     from utils.miou_evalignore import IoUIgnore
@@ -300,6 +329,7 @@ if __name__ == "__main__":
     gen_g1()
     gen_g2()
     gen_g3()
+    gen_g4()
     gen_g5()
     for f in sorted(os.listdir(OUT)):
         print(f, os.path.getsize(os.path.join(OUT, f)))

@@ -1,0 +1,68 @@
+"""Model parity (row a-10): our DeepLabv3+WN / ResNet50-deepstem against the executed reference
+(tests/golden/g4_model.npz): identical state-dict key names and shapes, cosine logits within 1e-4
+(north-star tolerance) in eval mode -- on CPU here and on the GPU (MIOpen) under -m gpu."""
+import hashlib
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from mulactseg_amd import synth
+from mulactseg_amd.models import get_model
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def _load():
+    g = np.load(os.path.join(GOLDEN, "g4_model.npz"))
+    net = get_model('deeplabv3pluswn_resnet50deepstem', 20, 16, True, pretrained_backbone=False)
+    shapes = {k: tuple(v.shape) for k, v in net.state_dict().items()}
+    assert sorted(shapes) == list(g['keys'])                                   # reference checkpoints load
+    assert [str(shapes[k]) for k in sorted(shapes)] == list(g['shapes'])
+    sd = synth.synthetic_state_dict(shapes, seed=int(g['seed']))
+    net.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=True)
+    net.eval()
+    x = np.random.RandomState(int(g['x_seed'])).standard_normal(size=(1, 3, 129, 161)).astype(np.float32)
+    h = hashlib.sha256(); h.update(x.tobytes())
+    assert np.frombuffer(h.digest()[:8], dtype=np.uint64)[0] == g['input_digest']
+    return g, net, torch.from_numpy(x)
+
+
+def _check(g, net, x, tol):
+    with torch.no_grad():
+        feats = net.backbone(x)
+        quarter = net.quarter_logits(x)
+        full = net(x)
+        net.set_return_feat()
+        feat_up, prob_up = net.feat_forward(x)
+        net.unset_return_feat()
+    for name, ref in (('low_level', float(g['low_level_mean'])), ('out', float(g['out_mean']))):
+        assert abs(float(feats[name].double().mean()) - ref) < 10 * tol * max(1.0, abs(ref))   # un-normalised features
+    assert np.max(np.abs(quarter.cpu().numpy() - g['quarter'])) < tol
+    assert np.max(np.abs(full[:, :, ::3, ::3].cpu().numpy() - g['full_sub'])) < tol
+    assert np.max(np.abs(prob_up[:, :, ::3, ::3].cpu().numpy() - g['prob_up_sub'])) < tol
+    assert np.max(np.abs(feat_up[:, ::16, ::5, ::5].cpu().numpy() - g['feat_up_sub'])) < tol
+    assert float(quarter.abs().max()) <= 1.0 + 1e-5                              # cosine similarity
+
+
+def test_model_matches_reference_cpu():
+    g, net, x = _load()
+    _check(g, net, x, 1e-5)
+    assert net.classifier.proxy is net.classifier.final.weight                  # one Parameter, two names
+    assert sum(p.numel() for p in net.parameters()) == 26806224
+
+
+@pytest.mark.gpu
+def test_model_matches_reference_gpu():
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    g, net, x = _load()
+    _check(g, net.cuda(), x.cuda(), 1e-4)
+
+
+def test_get_model_surface():
+    with pytest.raises(FileNotFoundError):
+        get_model('deeplabv3pluswn_resnet50deepstem', 20, 16, True)            # reference: ./checkpoint/resnet50_deepstem.pth
+    with pytest.raises(NotImplementedError):
+        get_model('deeplabv3_mobilenet', 20, 16, True)
