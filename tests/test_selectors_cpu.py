@@ -152,3 +152,24 @@ def test_product_package_never_imports_the_oracle():
                 text = open(os.path.join(dirpath, f)).read()
                 for needle in ('from oracle', 'import oracle', 'libexact', 'oracle/port', 'oracle.port'):
                     assert needle not in text, (f, needle)
+
+
+def test_reference_driver_imports_resolve_to_this_package():
+    """train_AL.py:29-33 does importlib.import_module("active_selection." + name) / ("trainer." + name)."""
+    import importlib
+    import subprocess
+    import sys
+    code = (
+        "import sys; sys.path.insert(0, %r)\n"
+        "import mulactseg_amd, importlib\n"
+        "mulactseg_amd.install_aliases()\n"
+        "m = importlib.import_module('active_selection.my_bvsb_predclsbal_pwr_banignore')\n"
+        "assert m.RegionSelector.__module__.startswith('mulactseg_amd.'), m\n"
+        "t = importlib.import_module('trainer.active_joint_multi_predignore_lossdecomp')\n"
+        "assert hasattr(t, 'ActiveTrainer')\n"
+        "from utils.loss import MultiChoiceCE, GroupMultiLabelCE, JointMultiLoss, MyCrossEntropyLoss\n"
+        "from models import get_model\n"
+        "from dataloader.utils import collate_fn, DataProvider\n"
+        "print('ok')\n" % os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True)
+    assert out.returncode == 0 and out.stdout.strip() == 'ok', out.stderr
