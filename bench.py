@@ -45,6 +45,9 @@ def parse():
                     help="superpixel id element type (the reference data layer yields int64)")
     ap.add_argument("--nbuf", type=int, default=3, help="distinct resident batches rotated through")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-train", action="store_true", help="skip the secondary train-iter measurement")
+    ap.add_argument("--train-steps", type=int, default=8)
+    ap.add_argument("--crop", type=int, default=768, help="training crop (reference: 768, transform.py:107)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU-baseline budget")
     return ap.parse_args()
 
@@ -90,6 +93,83 @@ def cpu_baseline(args, budget_s):
     return {"value": n * S / t1, "unit": "superpixels/s", "cores": cores, "kind": "port",
             "sample": "%d synthetic %dx%dx%d images, nseg %d, both passes + ban (oracle/port.py, torch %s CPU), %.1f s"
                       % (n, C, H, W, S, torch.__version__, t1)}
+
+
+def train_iter_bench(args, dev, world):
+    """Secondary metric "train-iter images/sec" (BASELINE.json configs[1]): stage-1 step on a
+    [4,20,crop,crop] batch.  (a) loss-only: fused partial-label losses fwd+bwd on resident logits;
+    (b) full iteration: DeepLabv3+WN/ResNet50-deepstem fwd + losses + bwd + AdamW (fp32, random init)."""
+    from mulactseg_amd import synth
+    from mulactseg_amd.models import get_model
+    from mulactseg_amd.utils.loss import FusedPartialLabelLoss
+    N, C, S, crop = 4, args.classes, args.nseg, args.crop
+    spx, msk = zip(*[synth.train_crop(50 + i, crop, crop, S, frac_selected=0.09) for i in range(N)])
+    spx = torch.from_numpy(np.stack(spx)).to(dev)
+    msk = torch.from_numpy(np.stack(msk)).to(dev)
+    tgt = torch.from_numpy(np.stack([synth.multi_hot_targets(70 + i, S, C) for i in range(N)])).to(dev)
+    crit = FusedPartialLabelLoss(S, 0.1, 0.1)
+    g = torch.Generator(device=dev)
+    g.manual_seed(5)
+    z = (0.35 * torch.randn((N, C, crop, crop), generator=g, device=dev)).requires_grad_(True)
+
+    def loss_step(logits):
+        group, ce, mc = crit(logits, tgt, spx, msk)
+        return 16.0 * ce + 8.0 * mc + 1.0 * group
+
+    for _ in range(3):
+        loss_step(z).backward()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(20):
+        z.grad = None
+        loss_step(z).backward()
+    torch.cuda.synchronize()
+    loss_ms = (time.perf_counter() - t0) / 20 * 1e3
+    loss_bytes = N * C * crop * crop * 4 * 3 + N * crop * crop * 9 * 2      # fwd read z, bwd read z + write dz, ids+mask twice
+
+    net = get_model('deeplabv3pluswn_resnet50deepstem', C, 16, True, pretrained_backbone=False).to(dev).train()
+    opt = torch.optim.AdamW([{'params': net.backbone.parameters(), 'lr': 2e-5},
+                             {'params': net.classifier.parameters(), 'lr': 2e-4}], lr=2e-5, weight_decay=1e-5)
+    images = torch.randn((N, 3, crop, crop), generator=g, device=dev)
+
+    def full_step():
+        opt.zero_grad(set_to_none=True)
+        loss_step(net(images)).backward()
+        opt.step()
+
+    for _ in range(2):
+        full_step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.train_steps):
+        full_step()
+    torch.cuda.synchronize()
+    it_ms = (time.perf_counter() - t0) / args.train_steps * 1e3
+    return {"metric": "train-iter images/sec", "value": N * world / (it_ms * 1e-3), "unit": "images/s", "ms_per_iter": it_ms,
+            "config": {"workload": "stage-1 step: DeepLabv3+WN/ResNet50-deepstem fwd+bwd (MIOpen fp32) + fused partial-label "
+                                   "losses (HIP) + AdamW", "batch": [N, 3, crop, crop], "logits": [N, C, crop, crop], "nseg": S,
+                       "selected_fraction": float(msk.float().mean())},
+            "loss_only": {"ms_fwd_bwd": loss_ms, "algorithmic_GBs": loss_bytes / (loss_ms * 1e-3) / 1e9,
+                          "bytes": loss_bytes, "note": "includes ~8 small launches and the autograd glue"}}
+
+
+def pmc_traffic(kernel, default_shape):
+    """HBM bytes per launch of `kernel` from the latest committed rocprofv3 --pmc summary
+    (profiles/r*/..pmc_traffic.json, produced by profiles/summarize.py from separate FETCH_SIZE / WRITE_SIZE
+    passes of this same command, gfx950 FETCH_SIZE x2 correction applied).  None when the bench shape is not the
+    profiled default shape or no summary is present: PMC counters cannot be read from inside this process."""
+    if not default_shape:
+        return None
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "*pmc_traffic.json")))
+    for f in reversed(files):
+        try:
+            k = json.load(open(f))["kernels"].get(kernel)
+            if k:
+                return k["hbm_bytes_per_launch"]
+        except Exception:
+            continue
+    return None
 
 
 def main():
@@ -166,11 +246,13 @@ def main():
                    "images_per_step": B, "logits": [B, C, H, W], "nseg": S, "id_dtype": args.id_dtype,
                    "temperature": 0.1, "sharding": "pool images across ranks"},
         "roofline": {"bound": "hbm", "kernel": "k_bvsb_region_accum", "achieved": ach, "peak": HBM_PEAK_GBS,
-                     "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": None,
+                     "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+                     "traffic": pmc_traffic("k_bvsb_region_accum", (B, C, H, W, S, args.id_dtype) == (4, 20, 1024, 2048, 2048, "int64")),
                      "bytes_per_launch": k3_bytes, "avg_launch_ms": k3_ms},
         "kernels": {"k_class_prob_sum": {"avg_launch_ms": k2_ms, "achieved_GBs": k2_bytes / (k2_ms * 1e-3) / 1e9,
                                          "bytes_per_launch": k2_bytes}},
     }
+    out["train_iter"] = None if args.no_train else train_iter_bench(args, dev, world)
     if rank == 0:
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(args, args.cpu_seconds)
