@@ -41,7 +41,7 @@ extern "C" {
 
 /* fixed-point fractional bits of the accumulators (see detmath.h) */
 #define MAS_SCORE_FRAC_BITS 40
-#define MAS_PROB_FRAC_BITS 31
+#define MAS_PROB_FRAC_BITS 23
 #define MAS_LOSS_FRAC_BITS 32
 
 int mas_abi_version(void);
@@ -51,7 +51,7 @@ const char* mas_error_string(int code);
  * K2  class-prior pass.  Replaces, per batch,
  *       preds_prob = softmax(preds / ce_temp, dim=1); cum += mean(preds_prob, dim=(0,2,3))
  *     active_selection/my_bvsb_predclsbal_pwr_banignore.py:41-42 (VOC twin ..._pwr.py:41-42).
- * Adds, for every image b and class c, sum_p floor(softmax(z_p * invT)_c * 2^31) into
+ * Adds, for every image b and class c, sum_p round(softmax(z_p * invT)_c * 2^23) into
  * prob_sum[b*C + c]  (caller zeroes prob_sum; the host turns the integer sums into the reference's
  * mean-of-batch-means and the class weight (coeff*cum+1)^-2).
  * --------------------------------------------------------------------------------------------- */
@@ -194,6 +194,28 @@ int mas_iou_counts(const int64_t* outputs, const int64_t* outputs_all, const int
  * num_classes channels, argmax over all channels and every counter above; first maximum wins. */
 int mas_logits_iou_counts(const float* z, const int64_t* targets, int B, int channels, int H, int W, int num_classes,
                           int64_t ignore_label, uint64_t* counts /* [3C+3] */, void* stream);
+
+/* =============================================================================================
+ * Single-pass acquisition scan (one read of the logits, one model forward per pool image)
+ * ============================================================================================= */
+
+/* Fuses mas_class_prob_sum and mas_bvsb_region_accum: the class weight depends only on the pixel's arg-max
+ * class, so it factors out of the region sum.  Adds into
+ *   prob_sum [B,C]      as mas_class_prob_sum,
+ *   class_sum[B,S,C]    fixed-point (40 fractional bits) sum of the UNWEIGHTED margins of the pixels of region s
+ *                       whose arg-max class is c,
+ *   hist     [B,S,C]    pixel counts (as mas_bvsb_region_accum).
+ * The caller zeroes all three.  Replaces both loops of my_bvsb_predclsbal_pwr_banignore.py:35-72. */
+int mas_single_pass_accum(const float* z, const void* spx, int spx_dtype, int B, int C, int H, int W, int S, float invT,
+                          uint64_t* prob_sum, uint64_t* class_sum, uint32_t* hist, void* stream);
+
+/* score[r] = floor(((sum_c class_sum[r,c] * w31[c]) >> 31) / n_r) * 2^-40, w31[c] = floor(cls_weight[c] * 2^31)
+ * (exact integer arithmetic); dominant class, ban and optional outputs as mas_region_finalize.
+ * With w31[c] = 2^31 for all c the scores equal those of mas_bvsb_region_accum(cls_w = NULL) + mas_region_finalize
+ * bit for bit. */
+int mas_region_finalize_weighted(const uint64_t* class_sum, const uint32_t* hist, int64_t n_regions, int C,
+                                 const uint32_t* w31 /* [C] */, int ban_class, float* score, int32_t* dominant,
+                                 uint32_t* count, int64_t* hist_i64, void* stream);
 
 #ifdef __cplusplus
 }

@@ -11,7 +11,7 @@ LIB_PATH = os.path.join(_HERE, "libmulactseg_hip.so")
 
 ID_I64, ID_I32, ID_U16 = 0, 1, 2
 MAX_CLASSES = 32
-SCORE_FRAC, PROB_FRAC, LOSS_FRAC = 40, 31, 32
+SCORE_FRAC, PROB_FRAC, LOSS_FRAC = 40, 23, 32
 LOSS_CE, LOSS_GROUP, LOSS_GROUP_ONLY_MULTI, LOSS_DECOMP = 1, 2, 4, 8
 ACC_WORDS = 8
 
@@ -32,6 +32,8 @@ SIGNATURES = {
     "mas_minmax_normalize": (_i, [_vp, _i64, _vp, _vp]),
     "mas_iou_counts": (_i, [_vp, _vp, _vp, _i64, _i, _i64, _vp, _vp]),
     "mas_logits_iou_counts": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i64, _vp, _vp]),
+    "mas_single_pass_accum": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _f, _vp, _vp, _vp, _vp]),
+    "mas_region_finalize_weighted": (_i, [_vp, _vp, _i64, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp]),
     "mas_target_bits": (_i, [_vp, _i64, _i, _i, _vp, _vp]),
     "mas_partial_loss_fwd": (_i, [_vp, _vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _f, _i, _vp, _vp, _vp]),
     "mas_group_finalize": (_i, [_vp, _i64, _vp, _vp]),

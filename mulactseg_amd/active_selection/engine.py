@@ -79,7 +79,7 @@ def gather_rows(local, plan):
 def class_weight_from_sums(prob_sum, hw, batch_of, n_batches, coeff):
     """Reference: ``cum = sum_b mean_b / len(loader)``; ``cls_weight = (coeff*cum + 1)**-2``
     (``my_bvsb_predclsbal_pwr_banignore.py:42,45,47``), evaluated in f64 from the integer per-image
-    sums (31 fractional bits) and rounded once to f32.  Same operation order as
+    sums (23 fractional bits) and rounded once to f32.  Same operation order as
     ``oracle/exact.c:exact_class_weight`` (bit-identical)."""
     prob_sum = np.ascontiguousarray(prob_sum).view(np.uint64)
     n_img, C = prob_sum.shape
@@ -91,7 +91,7 @@ def class_weight_from_sums(prob_sum, hw, batch_of, n_batches, coeff):
             n = int(sel.sum())
             if n:
                 s = np.uint64(prob_sum[sel, c].sum(dtype=np.uint64))
-                acc = acc + (np.float64(s) / np.float64(2147483648.0)) / (np.float64(n) * np.float64(hw))
+                acc = acc + (np.float64(s) / np.float64(8388608.0)) / (np.float64(n) * np.float64(hw))
         cum[c] = acc / np.float64(n_batches)
     t = np.float64(coeff) * cum + np.float64(1.0)
     return cum, (np.float64(1.0) / (t * t)).astype(np.float32)
@@ -124,6 +124,14 @@ class HipBackend:
     def finalize(self, score_sum, hist, ban_class, want_hist_i64=False):
         return self.ops.region_finalize(score_sum, hist, ban_class, want_hist_i64)
 
+    def single_pass(self, logits, spx, S, invT, prob_sum, class_sum, hist):
+        self.ops.single_pass_accum(logits, spx, S, invT, prob_sum=prob_sum, class_sum=class_sum, hist=hist)
+
+    def finalize_weighted(self, class_sum, hist, cls_w, ban_class, want_hist_i64=False):
+        w = np.ones(hist.shape[-1], dtype=np.float32) if cls_w is None else cls_w.detach().cpu().numpy()
+        w31 = torch.from_numpy(self.ops.weights_to_fixed31(w).view(np.int32)).to(hist.device)
+        return self.ops.region_finalize_weighted(class_sum, hist, w31, ban_class, want_hist_i64)
+
     def minmax_normalize_(self, scores):
         return self.ops.minmax_normalize_(scores)
 
@@ -153,17 +161,22 @@ class AcquisitionRound:
         scores = rnd.scores(ban_class)               # exchange 2 -> [n_img, S] on every rank
     """
 
-    def __init__(self, n_img, n_channels, n_superpixels, batch_size, temperature, backend, rank=None, world=None):
+    def __init__(self, n_img, n_channels, n_superpixels, batch_size, temperature, backend, rank=None, world=None,
+                 single_pass=False):
         r, w = current_rank_world()
         self.plan = ShardPlan(n_img, batch_size, r if rank is None else rank, w if world is None else world)
         self.C, self.S = n_channels, n_superpixels
         self.backend = backend
         self.invT = backend.inv_temperature(temperature)
+        self.single_pass = single_pass
         dev = backend.device
         nl = max(self.plan.n_local, 1)
         self.prob_sum = torch.zeros((nl, n_channels), dtype=torch.int64, device=dev)
-        self.score_sum = torch.zeros((nl, n_superpixels), dtype=torch.int64, device=dev)
         self.hist = torch.zeros((nl, n_superpixels, n_channels), dtype=torch.int32, device=dev)
+        if single_pass:     # per (region, arg-max class) sums of the unweighted margin: 327 KB per Cityscapes image
+            self.class_sum = torch.zeros((nl, n_superpixels, n_channels), dtype=torch.int64, device=dev)
+        else:
+            self.score_sum = torch.zeros((nl, n_superpixels), dtype=torch.int64, device=dev)
         self.hw = None
 
     def _rows(self, row0, logits):
@@ -196,6 +209,26 @@ class AcquisitionRound:
     def add_regions(self, row0, logits, spx, cls_w):
         r = self._rows(row0, logits)
         self.backend.region_accum(logits.contiguous(), spx.contiguous(), cls_w, self.S, self.invT, self.score_sum[r], self.hist[r])
+
+    def add_single_pass(self, row0, logits, spx):
+        """One scan per batch: class-probability sums + per (region, class) margin sums + histogram."""
+        r = self._rows(row0, logits)
+        self.backend.single_pass(logits.contiguous(), spx.contiguous(), self.S, self.invT, self.prob_sum[r],
+                                 self.class_sum[r], self.hist[r])
+
+    def scores_single_pass(self, cls_w, ban_class=-1, want_hist=False):
+        """Weighted region means from the single-pass accumulators (cls_w None -> unweighted)."""
+        n = self.plan.n_local
+        if n == 0:
+            dev = self.backend.device
+            score = torch.zeros((0, self.S), dtype=torch.float32, device=dev)
+            h64 = torch.zeros((0, self.S, self.C), dtype=torch.int64, device=dev)
+        else:
+            score, dom, cnt, h64 = self.backend.finalize_weighted(self.class_sum[:n], self.hist[:n], cls_w, ban_class, want_hist)
+        full = gather_rows(score, self.plan)                                      # exchange 2
+        if want_hist:
+            return full, gather_rows(h64, self.plan)
+        return full
 
     def scores(self, ban_class=-1, want_hist=False):
         n = self.plan.n_local

@@ -1,9 +1,14 @@
 """BvSB + pixel-wise class balancing ("PixBal", the proposed acquisition of Hwang et al.) --
 reference ``active_selection/my_bvsb_predclsbal_pwr.py`` (VOC form: C = num_classes, no ban).
 
-Pass 1 estimates the predicted class prior (K2, ``k_class_prob_sum``), the host turns the integer
-sums into ``cls_weight = (coeff*prior + 1)**-2``; pass 2 averages ``bvsb * cls_weight[top1]`` per
-superpixel and histograms the arg-max class (K1+K3, ``k_bvsb_region_accum``).
+Default (``single_pass``): ONE scan and ONE model forward per pool image (``k_single_pass``): the class
+weight depends only on the pixel's arg-max class, so it factors out of the region sum; the scan keeps per
+(region, class) sums of the unweighted margin and the weights are applied in exact integer arithmetic once
+the pool's class prior is known.  ``args.two_pass_scoring = True`` selects the reference's own structure:
+pass 1 estimates the predicted class prior (K2, ``k_class_prob_sum``), the host turns the integer sums into
+``cls_weight = (coeff*prior + 1)**-2``; pass 2 averages ``bvsb * cls_weight[top1]`` per superpixel and
+histograms the arg-max class (K1+K3, ``k_bvsb_region_accum``).  The two forms agree to ~1e-7 relative (the
+per-pixel f32 rounding of ``bvsb * w`` is the only difference) and give the same integers.
 """
 import torch
 
@@ -22,6 +27,17 @@ class RegionSelector(my_bvsb.RegionSelector):
         backend = self._backend(trainer)
         n_img = len(pool_set.im_idx)
         C = self.num_class + self.extra_channels
+        ban = C - 1 if self.ban_ignore else -1                                      # (:79-84)
+        if not getattr(self.args, 'two_pass_scoring', False):
+            rnd = AcquisitionRound(n_img, C, self.num_superpixels, self.batch_size, self.args.ce_temp, backend,
+                                   single_pass=True)
+            for row, preds, spx in self._iterate(trainer, pool_set, rnd):           # the only pass
+                self._check_channels(preds, C)
+                rnd.add_single_pass(row, preds, spx)
+            cls_w = rnd.class_weights(self.args.cls_weight_coeff)
+            self.cumulated_pred_prob, self.cls_weight = rnd.cum, cls_w
+            self._round = rnd
+            return rnd.scores_single_pass(cls_w, ban_class=ban, want_hist=want_hist)
         rnd = AcquisitionRound(n_img, C, self.num_superpixels, self.batch_size, self.args.ce_temp, backend)
         for row, preds, _ in self._iterate(trainer, pool_set, rnd):                 # pass 1 (:35-43)
             self._check_channels(preds, C)
@@ -30,7 +46,6 @@ class RegionSelector(my_bvsb.RegionSelector):
         self.cumulated_pred_prob, self.cls_weight = rnd.cum, cls_w
         for row, preds, spx in self._iterate(trainer, pool_set, rnd):               # pass 2 (:49-72)
             rnd.add_regions(row, preds, spx, cls_w)
-        ban = C - 1 if self.ban_ignore else -1                                      # (:79-84)
         self._round = rnd
         return rnd.scores(ban_class=ban, want_hist=want_hist)
 

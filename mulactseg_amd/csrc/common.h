@@ -31,29 +31,181 @@ __device__ __forceinline__ int mas_load_id(const IdT* p, size_t i) {
 
 // Per-pixel softmax(z * invT) over CT register-resident channels; `C` live channels (C == CT when EXACT).
 // Operation order is normative (mirrored by oracle/exact.c:softmax_row):
-//   x_c = z_c*invT ; m = max x ; e_c = exp(x_c - m) ; sum = ((e_0+e_1)+e_2)... ; p_c = e_c * (1/sum)
+//   m = max_c z_c ; M = m*invT ; e_c = exp_np(fma(z_c, invT, -M)) ; sum = ((e_0+e_1)+e_2)... ; rinv = 1/sum
+// On return x[c] = e_c (un-normalised) and the function value is rinv; p_c = e_c * rinv.
 template <int CT, bool EXACT>
-__device__ __forceinline__ void mas_softmax_regs(float (&x)[CT], int C, float invT) {
+__device__ __forceinline__ float mas_softmax_regs(float (&x)[CT], int C, float invT) {
     const int Cn = EXACT ? CT : C;
-    float m = x[0] * invT;
+    float m = x[0];
 #pragma unroll
-    for (int c = 0; c < CT; ++c) {
-        if (EXACT || c < Cn) {
-            x[c] = x[c] * invT;
-            m = (x[c] > m) ? x[c] : m;
-        }
-    }
+    for (int c = 1; c < CT; ++c)
+        if (EXACT || c < Cn) m = (x[c] > m) ? x[c] : m;
+    const float negM = -(m * invT);
     float sum = 0.0f;
 #pragma unroll
     for (int c = 0; c < CT; ++c) {
         if (EXACT || c < Cn) {
-            x[c] = mas_expf(x[c] - m);
+            x[c] = mas_expf_np(mas_fmaf(x[c], invT, negM));
             sum = (c == 0) ? x[c] : (sum + x[c]);
         }
     }
-    const float rinv = 1.0f / sum;
+    return 1.0f / sum;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Packed (2 pixels per lane-op) form of the same arithmetic: v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32
+// evaluate both halves with IEEE semantics, so every element is bit-identical to the scalar functions of
+// detmath.h -- the oracle keeps using the scalar form.
+// ------------------------------------------------------------------------------------------------
+typedef float mas_v2f __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ mas_v2f mas_pk_fma(mas_v2f a, mas_v2f b, mas_v2f c) { return __builtin_elementwise_fma(a, b, c); }
+__device__ __forceinline__ mas_v2f mas_splat(float v) { return (mas_v2f){v, v}; }
+
+// single v_max_f32 (no canonicalising pre-ops); operands are never NaN here
+__device__ __forceinline__ float mas_vmax(float a, float b) {
+    float r;
+    asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+
+// mas_expf_np on two values
+__device__ __forceinline__ mas_v2f mas_expf_np2(mas_v2f x) {
+    const mas_v2f xc = {mas_vmax(x.x, -86.0f), mas_vmax(x.y, -86.0f)};
+    const mas_v2f magic = mas_splat(12582912.0f);
+    const mas_v2f t = mas_pk_fma(xc, mas_splat(1.44269504088896341f), magic);
+    const mas_v2f n = t - magic;
+    mas_v2f r = mas_pk_fma(n, mas_splat(-0.693359375f), xc);
+    r = mas_pk_fma(n, mas_splat(2.12194440e-4f), r);
+    mas_v2f p = mas_splat(1.9875691500e-4f);
+    p = mas_pk_fma(p, r, mas_splat(1.3981999507e-3f));
+    p = mas_pk_fma(p, r, mas_splat(8.3334519073e-3f));
+    p = mas_pk_fma(p, r, mas_splat(4.1665795894e-2f));
+    p = mas_pk_fma(p, r, mas_splat(1.6666665459e-1f));
+    p = mas_pk_fma(p, r, mas_splat(5.0000001201e-1f));
+    const mas_v2f y = mas_pk_fma(p, r * r, r) + mas_splat(1.0f);
+    return (mas_v2f){mas_u2f(mas_f2u(y.x) + (mas_f2u(t.x) << 23)), mas_u2f(mas_f2u(y.y) + (mas_f2u(t.y) << 23))};
+}
+
+// softmax of two pixels at once: x[c] = {z_c(pixel a), z_c(pixel b)} in, e_c (un-normalised) out; returns rinv.
+// KNOWN_MAX: the caller already holds the maxima of the raw logits (from its top-2 scan).
+template <int CT, bool EXACT, bool KNOWN_MAX = false>
+__device__ __forceinline__ mas_v2f mas_softmax_pair(mas_v2f (&x)[CT], int C, float invT, mas_v2f zmax = (mas_v2f){0.f, 0.f}) {
+    const int Cn = EXACT ? CT : C;
+    const mas_v2f it = mas_splat(invT);
+    if (!KNOWN_MAX) {
+        float m0 = x[0].x, m1 = x[0].y;
+#pragma unroll
+        for (int c = 1; c < CT; ++c) {
+            if (EXACT || c < Cn) {
+                m0 = mas_vmax(m0, x[c].x);
+                m1 = mas_vmax(m1, x[c].y);
+            }
+        }
+        zmax = (mas_v2f){m0, m1};
+    }
+    const mas_v2f negM = -(zmax * it);
+    mas_v2f sum = mas_splat(0.0f);
 #pragma unroll
     for (int c = 0; c < CT; ++c) {
-        if (EXACT || c < Cn) x[c] = x[c] * rinv;
+        if (EXACT || c < Cn) {
+            x[c] = mas_expf_np2(mas_pk_fma(x[c], it, negM));
+            sum = (c == 0) ? x[c] : (sum + x[c]);
+        }
     }
+    return (mas_v2f){1.0f / sum.x, 1.0f / sum.y};
+}
+
+// Two independent pairs at once, written interleaved: a single exp chain is ~17 DEPENDENT packed instructions and
+// the compiler does not interleave chains on its own, so one wave would stall on every instruction.  Same
+// arithmetic per element as mas_expf_np2.
+__device__ __forceinline__ void mas_expf_np2x2(mas_v2f xa, mas_v2f xb, mas_v2f& ea, mas_v2f& eb) {
+    const mas_v2f ca = {mas_vmax(xa.x, -86.0f), mas_vmax(xa.y, -86.0f)};
+    const mas_v2f cb = {mas_vmax(xb.x, -86.0f), mas_vmax(xb.y, -86.0f)};
+    const mas_v2f magic = mas_splat(12582912.0f);
+    const mas_v2f ta = mas_pk_fma(ca, mas_splat(1.44269504088896341f), magic);
+    const mas_v2f tb = mas_pk_fma(cb, mas_splat(1.44269504088896341f), magic);
+    const mas_v2f na = ta - magic;
+    const mas_v2f nb = tb - magic;
+    mas_v2f ra = mas_pk_fma(na, mas_splat(-0.693359375f), ca);
+    mas_v2f rb = mas_pk_fma(nb, mas_splat(-0.693359375f), cb);
+    ra = mas_pk_fma(na, mas_splat(2.12194440e-4f), ra);
+    rb = mas_pk_fma(nb, mas_splat(2.12194440e-4f), rb);
+    mas_v2f pa = mas_pk_fma(mas_splat(1.9875691500e-4f), ra, mas_splat(1.3981999507e-3f));
+    mas_v2f pb = mas_pk_fma(mas_splat(1.9875691500e-4f), rb, mas_splat(1.3981999507e-3f));
+    const mas_v2f qa = ra * ra;
+    const mas_v2f qb = rb * rb;
+    pa = mas_pk_fma(pa, ra, mas_splat(8.3334519073e-3f));
+    pb = mas_pk_fma(pb, rb, mas_splat(8.3334519073e-3f));
+    pa = mas_pk_fma(pa, ra, mas_splat(4.1665795894e-2f));
+    pb = mas_pk_fma(pb, rb, mas_splat(4.1665795894e-2f));
+    pa = mas_pk_fma(pa, ra, mas_splat(1.6666665459e-1f));
+    pb = mas_pk_fma(pb, rb, mas_splat(1.6666665459e-1f));
+    pa = mas_pk_fma(pa, ra, mas_splat(5.0000001201e-1f));
+    pb = mas_pk_fma(pb, rb, mas_splat(5.0000001201e-1f));
+    const mas_v2f ya = mas_pk_fma(pa, qa, ra) + mas_splat(1.0f);
+    const mas_v2f yb = mas_pk_fma(pb, qb, rb) + mas_splat(1.0f);
+    ea = (mas_v2f){mas_u2f(mas_f2u(ya.x) + (mas_f2u(ta.x) << 23)), mas_u2f(mas_f2u(ya.y) + (mas_f2u(ta.y) << 23))};
+    eb = (mas_v2f){mas_u2f(mas_f2u(yb.x) + (mas_f2u(tb.x) << 23)), mas_u2f(mas_f2u(yb.y) + (mas_f2u(tb.y) << 23))};
+}
+
+// softmax of FOUR pixels (two pairs) at once; xa/xb hold raw logits in, e_c out; returns (rinv_a, rinv_b).
+template <int CT, bool EXACT, bool KNOWN_MAX = false>
+__device__ __forceinline__ void mas_softmax_quad(mas_v2f (&xa)[CT], mas_v2f (&xb)[CT], int C, float invT, mas_v2f& rinv_a,
+                                                 mas_v2f& rinv_b, mas_v2f zmax_a = (mas_v2f){0.f, 0.f},
+                                                 mas_v2f zmax_b = (mas_v2f){0.f, 0.f}) {
+    const int Cn = EXACT ? CT : C;
+    const mas_v2f it = mas_splat(invT);
+    if (!KNOWN_MAX) {
+        float m0 = xa[0].x, m1 = xa[0].y, m2 = xb[0].x, m3 = xb[0].y;
+#pragma unroll
+        for (int c = 1; c < CT; ++c) {
+            if (EXACT || c < Cn) {
+                m0 = mas_vmax(m0, xa[c].x);
+                m1 = mas_vmax(m1, xa[c].y);
+                m2 = mas_vmax(m2, xb[c].x);
+                m3 = mas_vmax(m3, xb[c].y);
+            }
+        }
+        zmax_a = (mas_v2f){m0, m1};
+        zmax_b = (mas_v2f){m2, m3};
+    }
+    const mas_v2f negMa = -(zmax_a * it), negMb = -(zmax_b * it);
+    mas_v2f sa = mas_splat(0.0f), sb = mas_splat(0.0f);
+#pragma unroll
+    for (int c = 0; c < CT; ++c) {
+        if (EXACT || c < Cn) {
+            mas_expf_np2x2(mas_pk_fma(xa[c], it, negMa), mas_pk_fma(xb[c], it, negMb), xa[c], xb[c]);
+            sa = (c == 0) ? xa[c] : (sa + xa[c]);
+            sb = (c == 0) ? xb[c] : (sb + xb[c]);
+        }
+    }
+    rinv_a = (mas_v2f){1.0f / sa.x, 1.0f / sa.y};
+    rinv_b = (mas_v2f){1.0f / sb.x, 1.0f / sb.y};
+}
+
+// ------------------------------------------------------------------------------------------------
+// Wave-level segmented reduction over RUNS of equal keys in lane order (superpixel ids come in runs along a
+// row).  After the call, the lane for which the function returns true is the last lane of its run and holds the
+// run's total in (val, cnt); all other lanes must not use their values.  This turns a 64-way same-address LDS
+// atomic (serialised by the LDS unit) into one atomic per run.  6 Hillis-Steele steps on ds_bpermute shuffles.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ bool mas_wave_run_reduce(int key, mas_u64& val, unsigned& cnt) {
+    const int lane = threadIdx.x & (MAS_WAVE - 1);
+    const int prev = __shfl_up(key, 1, MAS_WAVE);
+    const bool head = (lane == 0) || (prev != key);
+    int f = head ? 1 : 0;
+#pragma unroll
+    for (int off = 1; off < MAS_WAVE; off <<= 1) {
+        const mas_u64 ov = __shfl_up(val, off, MAS_WAVE);
+        const unsigned oc = __shfl_up(cnt, off, MAS_WAVE);
+        const int of = __shfl_up(f, off, MAS_WAVE);
+        if (lane >= off && !f) {
+            val += ov;
+            cnt += oc;
+            f = of;
+        }
+    }
+    const int next_head = __shfl_down(head ? 1 : 0, 1, MAS_WAVE);
+    return (lane == MAS_WAVE - 1) || (next_head != 0);
 }

@@ -65,11 +65,35 @@ MAS_HD float mas_expf(float x) {
     p = mas_fmaf(p, r, 5.0000001201e-1f);
     float y = mas_fmaf(p, r * r, r) + 1.0f;
     int ni = (int)n;
-    int h = ni / 2;               /* two exact power-of-two scalings: single final rounding */
-    float res = (y * mas_pow2i(h)) * mas_pow2i(ni - h);
+    /* scale by 2^ni with ONE rounding: the first factor keeps the product normal (exact), the second
+     * factor is 1 unless the result is subnormal (ni < -125) or ni = 128 */
+    int h = ni < -125 ? -125 : (ni > 127 ? 127 : ni);
+    float res = mas_u2f(mas_f2u(y) + ((uint32_t)h << 23)) * mas_pow2i(ni - h);
     res = (x < -104.0f) ? 0.0f : res;
     res = (x > 88.72f) ? mas_u2f(0x7f800000u) : res;
     return (x != x) ? x : res;
+}
+
+/* exp(max(x, -86)) for finite x <= 0 -- the softmax argument after max-subtraction.  Same values as
+ * mas_expf on [-86, 0]; below -86 it saturates at exp(-86) ~ 4.5e-38, which keeps every result a NORMAL
+ * float (the 2^n scaling is a single exponent add) and is invisible to every accumulator: such a
+ * probability is < 2^-100 of the row sum, contributes 0 after mas_probq, and cannot change a row sum >= ~1. */
+MAS_HD float mas_expf_np(float x) {
+    float xc = (x < -86.0f) ? -86.0f : x;
+    float t = mas_fmaf(xc, 1.44269504088896341f, 12582912.0f);
+    float n = t - 12582912.0f;
+    float r = mas_fmaf(n, -0.693359375f, xc);
+    r = mas_fmaf(n, 2.12194440e-4f, r);
+    float p = 1.9875691500e-4f;
+    p = mas_fmaf(p, r, 1.3981999507e-3f);
+    p = mas_fmaf(p, r, 8.3334519073e-3f);
+    p = mas_fmaf(p, r, 4.1665795894e-2f);
+    p = mas_fmaf(p, r, 1.6666665459e-1f);
+    p = mas_fmaf(p, r, 5.0000001201e-1f);
+    float y = mas_fmaf(p, r * r, r) + 1.0f;
+    /* y * 2^n, exact (n >= -124, y in [0.7, 1.42]).  The bit pattern of t = 1.5*2^23 + n carries n mod 512 in its
+     * low 9 bits, so (bits(t) << 23) IS (n << 23) mod 2^32: one shift-add, no float->int conversion. */
+    return mas_u2f(mas_f2u(y) + (mas_f2u(t) << 23));
 }
 
 /* log(x) for finite x > 0, f32, ~1 ulp. */
@@ -122,12 +146,17 @@ MAS_HD uint64_t mas_fix(float v, int frac) {
     return ((b >> 31) | (uint32_t)(e == 0)) ? (uint64_t)0 : q;
 }
 
-/* floor(p * 2^31) for p in [0, 2): one multiply and one truncating conversion (same value as
- * mas_fix(p, 31) on that domain). */
-MAS_HD uint32_t mas_fix31(float p) { return (uint32_t)(p * 2147483648.0f); }
+/* Class-probability quantum of the class-prior pass: round-to-nearest-even of p * 2^23 with p = e * rinv never
+ * materialised: t = fma(e, R, 2^23) with R = rinv * 2^23 (exact scaling) lands in [2^23, 2^24] where floats are
+ * integers, so q = bits(t) - bits(2^23).  One fma; the constant can be subtracted once per accumulator.  23
+ * fractional bits keep a per-thread 32-bit accumulator exact over 511 pixels, the rounding is unbiased, and the
+ * quantisation error of the pool-wide class prior (~1e-9) is two orders below the f32 rounding of the
+ * reference's own mean. */
+#define MAS_PROBQ_BIAS 0x4B000000u
+MAS_HD uint32_t mas_probq(float e, float R) { return mas_f2u(mas_fmaf(e, R, 8388608.0f)) - MAS_PROBQ_BIAS; }
 
 #define MAS_SCORE_FRAC 40   /* per-region sum of weighted BvSB: v in (0, 1.0000001], <= 2^23 px/region */
-#define MAS_PROB_FRAC  31   /* per-image class-probability sums: p in [0, 1.0000001], <= 2^32 px/image */
+#define MAS_PROB_FRAC  23   /* per-image class-probability sums (mas_probq quanta), <= 2^40 px/image */
 #define MAS_LOSS_FRAC  32   /* loss sums: l in [0, 18.5], <= 2^27 selected px / batch */
 
 /* mean = floor(sum / count) * 2^-FRAC rounded once to f32 (count > 0) */
@@ -144,7 +173,24 @@ MAS_HD float mas_fixed_mean(uint64_t sum, uint64_t count, int frac) {
  *   here:      exp(z2*invT - z1*invT) + 1e-8           (same quantity, softmax denominator cancels) */
 MAS_HD float mas_bvsb(float z1, float z2, float invT) {
     float d = (z2 * invT) - (z1 * invT);
-    return mas_expf(d) + 1e-8f;
+    return mas_expf_np(d) + 1e-8f;     /* d <= 0; below -86 the exp term is far below ulp(1e-8) either way */
 }
+
+/* (a * w) accumulated into a 128-bit unsigned (hi:lo) -- the single-pass scorer's weighted region sum
+ * sum_c class_sum[c] * W31[c] needs up to 93 bits. */
+MAS_HD void mas_mac_u64_u32(uint64_t a, uint32_t w, uint64_t* hi, uint64_t* lo) {
+    const uint64_t p0 = (a & 0xffffffffu) * (uint64_t)w;     /* < 2^64 */
+    const uint64_t p1 = (a >> 32) * (uint64_t)w;             /* < 2^64, weight 2^32 */
+    uint64_t l = *lo + p0;
+    uint64_t h = *hi + (l < p0 ? 1u : 0u);
+    const uint64_t p1lo = p1 << 32;
+    l += p1lo;
+    h += (l < p1lo ? 1u : 0u) + (p1 >> 32);
+    *lo = l;
+    *hi = h;
+}
+
+/* (hi:lo) >> 31 as u64 (callers guarantee the result fits) */
+MAS_HD uint64_t mas_shr31_u128(uint64_t hi, uint64_t lo) { return (hi << 33) | (lo >> 31); }
 
 #endif /* MULACTSEG_DETMATH_H */

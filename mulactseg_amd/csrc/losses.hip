@@ -122,7 +122,11 @@ __global__ __launch_bounds__(kThreads) void k_partial_loss_fwd(const float* __re
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             if (!m[k]) continue;
-            mas_softmax_regs<CT, EXACT>(v[k], C, invT);
+            {
+                const float rinv = mas_softmax_regs<CT, EXACT>(v[k], C, invT);
+#pragma unroll
+                for (int c = 0; c < CT; ++c) v[k][c] = v[k][c] * rinv;
+            }
             const unsigned Y = bb[id[k]];
             const int nb = __popc(Y);
             if (nb == 0) { n_empty += 1; continue; }
@@ -302,7 +306,11 @@ __global__ __launch_bounds__(kThreads) void k_partial_loss_bwd(const float* __re
                     for (int c = 0; c < CT; ++c) v[k][c] = 0.0f;
                     continue;
                 }
-                mas_softmax_regs<CT, EXACT>(v[k], C, invT);
+                {
+                    const float rinv = mas_softmax_regs<CT, EXACT>(v[k], C, invT);
+#pragma unroll
+                    for (int c = 0; c < CT; ++c) v[k][c] = v[k][c] * rinv;
+                }
                 float coef = 0.0f, pos = 0.0f;
                 if (do_ce) {
 #pragma unroll

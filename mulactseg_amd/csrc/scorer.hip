@@ -28,13 +28,19 @@ __global__ __launch_bounds__(kThreads) void k_class_prob_sum(const float* __rest
     const int b = blockIdx.x / blocks_per_image;
     const int j = blockIdx.x - b * blocks_per_image;
     const float* zb = z + (size_t)b * C * HW;
-    mas_u64 acc[CT];
+    // per-thread 32-bit accumulators of mas_probq quanta (<= 2^23 each): exact for up to 511 pixels per thread,
+    // which the launcher guarantees by its choice of blocks_per_image.  The quanta are accumulated as raw bit
+    // patterns of fma(e, R, 2^23); the constant MAS_PROBQ_BIAS is subtracted once per accumulator at the end
+    // (modulo 2^32), so the inner loop is one packed fma and one 3-operand add per class and pixel pair.
+    unsigned acc[CT];
 #pragma unroll
     for (int c = 0; c < CT; ++c) acc[c] = 0;
+    unsigned n_quanta = 0;
 
     const int chunk_px = kThreads * 4;
     for (int p0 = j * chunk_px; p0 < HW; p0 += blocks_per_image * chunk_px) {
-        float v[4][CT];
+        // 4 pixels per lane as two PAIRS: packed f32 math evaluates both pixels of a pair per instruction
+        mas_v2f v[2][CT];
         bool ok[4];
         if (VEC) {
             const int p = p0 + threadIdx.x * 4;
@@ -44,28 +50,46 @@ __global__ __launch_bounds__(kThreads) void k_class_prob_sum(const float* __rest
 #pragma unroll
             for (int c = 0; c < CT; ++c) {
                 float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
-                if ((EXACT || c < C) && in) t = *reinterpret_cast<const float4*>(zb + (size_t)c * HW + p);
-                v[0][c] = t.x; v[1][c] = t.y; v[2][c] = t.z; v[3][c] = t.w;
+                const float* zc = zb + (size_t)c * HW;       // wave-uniform base, 32-bit lane offset
+                if ((EXACT || c < C) && in) t = *reinterpret_cast<const float4*>(zc + (unsigned)p);
+                v[0][c] = (mas_v2f){t.x, t.y};
+                v[1][c] = (mas_v2f){t.z, t.w};
             }
         } else {
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const int p = p0 + k * kThreads + threadIdx.x;
-                ok[k] = p < HW;
+            for (int k = 0; k < 4; ++k) ok[k] = (p0 + k * kThreads + (int)threadIdx.x) < HW;
 #pragma unroll
-                for (int c = 0; c < CT; ++c) v[k][c] = ((EXACT || c < C) && ok[k]) ? zb[(size_t)c * HW + p] : 0.f;
+            for (int c = 0; c < CT; ++c) {
+                float s[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const int p = p0 + k * kThreads + threadIdx.x;
+                    s[k] = ((EXACT || c < C) && ok[k]) ? zb[(size_t)c * HW + p] : 0.f;
+                }
+                v[0][c] = (mas_v2f){s[0], s[1]};
+                v[1][c] = (mas_v2f){s[2], s[3]};
             }
         }
+        {
+            mas_v2f Ra, Rb;
+            mas_softmax_quad<CT, EXACT>(v[0], v[1], C, invT, Ra, Rb);
+            Ra = Ra * mas_splat(8388608.0f);
+            Rb = Rb * mas_splat(8388608.0f);
+            Ra = (mas_v2f){ok[0] ? Ra.x : 0.0f, ok[1] ? Ra.y : 0.0f};     // pixels past the end add exactly 0
+            Rb = (mas_v2f){ok[2] ? Rb.x : 0.0f, ok[3] ? Rb.y : 0.0f};
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            mas_softmax_regs<CT, EXACT>(v[k], C, invT);
-            if (ok[k]) {
-#pragma unroll
-                for (int c = 0; c < CT; ++c)
-                    if (EXACT || c < C) acc[c] += mas_fix31(v[k][c]);
+            for (int c = 0; c < CT; ++c) {
+                if (EXACT || c < C) {
+                    const mas_v2f ta = mas_pk_fma(v[0][c], Ra, mas_splat(8388608.0f));      // mas_probq + bias
+                    const mas_v2f tb = mas_pk_fma(v[1][c], Rb, mas_splat(8388608.0f));
+                    acc[c] += (mas_f2u(ta.x) + mas_f2u(ta.y)) + (mas_f2u(tb.x) + mas_f2u(tb.y));
+                }
             }
         }
+        n_quanta += 4;
     }
+#pragma unroll
+    for (int c = 0; c < CT; ++c) acc[c] -= n_quanta * MAS_PROBQ_BIAS;
 
     // wave reduction (64 lanes), then 4 waves through LDS, then one atomic per class
     __shared__ mas_u64 s_part[kThreads / MAS_WAVE][CT];
@@ -155,6 +179,13 @@ __global__ __launch_bounds__(kThreads) void k_bvsb_region_accum(const float* __r
 #pragma unroll
         for (int k = 0; k < 4; ++k) { b1[k] = -__builtin_inff(); b2[k] = -__builtin_inff(); a1[k] = 0; }
         const size_t row = (size_t)y * W;
+        // ids first, so that their latency overlaps the logit loads
+        int id[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            id[k] = ok[k] ? mas_load_id(sb, row + xs[k]) : -1;
+            if (id[k] >= S) id[k] = -1;
+        }
 #pragma unroll
         for (int c = 0; c < CT; ++c) {
             if (EXACT || c < C) {
@@ -176,12 +207,6 @@ __global__ __launch_bounds__(kThreads) void k_bvsb_region_accum(const float* __r
                     b1[k] = g1 ? v[k] : b1[k];
                 }
             }
-        }
-        int id[4];
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            id[k] = ok[k] ? mas_load_id(sb, row + xs[k]) : -1;
-            if (id[k] >= S) id[k] = -1;
         }
         mas_u64 q[4];
 #pragma unroll
@@ -306,6 +331,8 @@ int launch_prob_sum(const float* z, int B, int C, int HW, float invT, mas_u64* p
     const int chunk_px = kThreads * 4;
     int bpi = 2048 / B;
     const int max_bpi = (HW + chunk_px - 1) / chunk_px;
+    const int min_bpi = (max_bpi + 59) / 60;      // <= 60 iterations x 4 px per thread: 32-bit accumulators stay exact
+    if (bpi < min_bpi) bpi = min_bpi;
     if (bpi > max_bpi) bpi = max_bpi;
     if (bpi < 1) bpi = 1;
     const bool vec = (HW % 4 == 0) && (((uintptr_t)z & 15) == 0);

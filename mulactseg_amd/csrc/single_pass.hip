@@ -1,0 +1,304 @@
+// single_pass.hip -- the MI355X-first form of the acquisition scan: ONE read of the logits per pool image.
+//
+// The reference needs two passes over the pool (two model forwards per image) because the class weight
+// cls_weight[top1] multiplies every pixel's BvSB margin and depends on the class prior of the WHOLE pool
+// (active_selection/my_bvsb_predclsbal_pwr_banignore.py:35-47 then :49-72).  But the weight only depends on the
+// pixel's arg-max class, so it factors out of the region sum:
+//
+//     sum_{p in s} bvsb_p * w[top1_p]  =  sum_c  w_c * ( sum_{p in s, top1_p = c} bvsb_p )
+//
+// k_single_pass accumulates, in one scan, (a) the per-image class-probability sums (K2), (b) per (region, class)
+// the fixed-point sum of the UNWEIGHTED margins and (c) the arg-max-class histogram (K3).  After the pool has been
+// seen once, k_region_finalize_weighted applies the weights in exact integer arithmetic
+// (sum_c class_sum[s,c] * floor(w_c * 2^31), 128-bit accumulate), divides by the pixel count and applies the ban.
+// With w = 1 the result is bit-identical to the two-pass kernels; with weights it differs from them only by the
+// per-pixel rounding of bvsb*w (~1e-9 relative).  HBM traffic per image: logits + ids once (176 MB instead of 344 MB)
+// and, end to end, ONE model forward per pool image instead of two.
+#include "common.h"
+
+namespace {
+
+constexpr int kThreads = 256;
+constexpr int kTileW = 256;     // 64 lanes x 4 px (16-B loads; two packed pixel pairs per lane)
+constexpr int kTileH = 16;      // 4 waves x 4 row iterations
+constexpr int kLogSlots = 7;
+constexpr int kSlots = 1 << kLogSlots;
+
+__device__ __forceinline__ int table_slot(int* keys, int id) {
+    unsigned h = ((unsigned)id * 2654435769u) >> (32 - kLogSlots);
+    for (int probe = 0; probe < kSlots; ++probe) {
+        int k = __hip_atomic_load(&keys[h], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (k == id) return (int)h;
+        if (k == -1) {
+            int old = atomicCAS(&keys[h], -1, id);
+            if (old == -1 || old == id) return (int)h;
+        }
+        h = (h + 1) & (kSlots - 1);
+    }
+    return -1;
+}
+
+template <int CT, bool EXACT, typename IdT, bool VEC>
+__global__ __launch_bounds__(kThreads) void k_single_pass(const float* __restrict__ z, const IdT* __restrict__ spx, int C, int H,
+                                                           int W, int S, float invT, int tiles_x, int tiles_y,
+                                                           mas_u64* __restrict__ prob_sum, mas_u64* __restrict__ class_sum,
+                                                           unsigned* __restrict__ hist) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    mas_u64* t_sum = reinterpret_cast<mas_u64*>(smem);                                        // [kSlots * C]
+    mas_u64* s_part = reinterpret_cast<mas_u64*>(smem + sizeof(mas_u64) * kSlots * C);         // [4][CT]
+    unsigned* t_hist = reinterpret_cast<unsigned*>(smem + sizeof(mas_u64) * (kSlots * C + 4 * CT));   // [kSlots * C]
+    int* t_keys = reinterpret_cast<int*>(smem + sizeof(mas_u64) * (kSlots * C + 4 * CT) + sizeof(unsigned) * kSlots * C);
+
+    for (int i = threadIdx.x; i < kSlots; i += kThreads) t_keys[i] = -1;
+    for (int i = threadIdx.x; i < kSlots * C; i += kThreads) { t_sum[i] = 0; t_hist[i] = 0; }
+    __syncthreads();
+
+    int bid = blockIdx.x;
+    const int tx = bid % tiles_x; bid /= tiles_x;
+    const int ty = bid % tiles_y;
+    const int b = bid / tiles_y;
+    const int HW = H * W;
+    const float* zb = z + (size_t)b * C * HW;
+    const IdT* sb = spx + (size_t)b * HW;
+    mas_u64* gsum = class_sum + (size_t)b * S * C;
+    unsigned* ghist = hist + (size_t)b * S * C;
+    const int lane = threadIdx.x & (MAS_WAVE - 1);
+    const int wave = threadIdx.x / MAS_WAVE;
+
+    unsigned acc[CT];       // mas_probq quanta (raw bit patterns, bias removed at the end): 16 px per thread per tile
+#pragma unroll
+    for (int c = 0; c < CT; ++c) acc[c] = 0;
+    unsigned n_quanta = 0;
+
+    for (int it = 0; it < kTileH / 4; ++it) {
+        const int y = ty * kTileH + it * 4 + wave;
+        if (y >= H) break;
+        const size_t row = (size_t)y * W;
+        int xs[4];
+        bool ok[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            xs[k] = tx * kTileW + (VEC ? (lane * 4 + k) : (k * MAS_WAVE + lane));
+            ok[k] = xs[k] < W;
+        }
+        // ids first: their HBM latency must overlap the logit loads, not sit exposed behind the softmax
+        int id[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            id[k] = ok[k] ? mas_load_id(sb, row + xs[k]) : -1;
+            if (id[k] >= S) id[k] = -1;
+        }
+        // pixel k lives in pair k>>1, half k&1
+        mas_v2f v[2][CT];
+        float b1[4], b2[4];
+        int a1[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { b1[k] = -__builtin_inff(); b2[k] = -__builtin_inff(); a1[k] = 0; }
+#pragma unroll
+        for (int c = 0; c < CT; ++c) {
+            if (EXACT || c < C) {
+                float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
+                const float* zc = zb + (size_t)c * HW;       // wave-uniform base, 32-bit lane offset
+                if (VEC) {
+                    if (ok[0]) t = *reinterpret_cast<const float4*>(zc + (unsigned)(row + xs[0]));
+                } else {
+                    if (ok[0]) t.x = zc[row + xs[0]];
+                    if (ok[1]) t.y = zc[row + xs[1]];
+                    if (ok[2]) t.z = zc[row + xs[2]];
+                    if (ok[3]) t.w = zc[row + xs[3]];
+                }
+                v[0][c] = (mas_v2f){t.x, t.y};
+                v[1][c] = (mas_v2f){t.z, t.w};
+                const float q[4] = {t.x, t.y, t.z, t.w};
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    // same update as "if (v > b1) {b2 = b1; b1 = v; a1 = c} else if (v > b2) b2 = v"
+                    const bool g1 = q[k] > b1[k];
+                    const bool g2 = q[k] > b2[k];
+                    b2[k] = g1 ? b1[k] : (g2 ? q[k] : b2[k]);
+                    a1[k] = g1 ? c : a1[k];
+                    b1[k] = g1 ? q[k] : b1[k];
+                }
+            } else {
+                v[0][c] = mas_splat(0.f);
+                v[1][c] = mas_splat(0.f);
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);     // keep the phases apart: interleaving them doubles the live registers
+        // class-probability quanta (K2 arithmetic); the maximum is already known from the top-2 scan
+        {
+            mas_v2f Ra, Rb;
+            mas_softmax_quad<CT, EXACT, true>(v[0], v[1], C, invT, Ra, Rb, (mas_v2f){b1[0], b1[1]}, (mas_v2f){b1[2], b1[3]});
+            Ra = Ra * mas_splat(8388608.0f);
+            Rb = Rb * mas_splat(8388608.0f);
+            Ra = (mas_v2f){ok[0] ? Ra.x : 0.0f, ok[1] ? Ra.y : 0.0f};
+            Rb = (mas_v2f){ok[2] ? Rb.x : 0.0f, ok[3] ? Rb.y : 0.0f};
+#pragma unroll
+            for (int c = 0; c < CT; ++c) {
+                if (EXACT || c < C) {
+                    const mas_v2f ta = mas_pk_fma(v[0][c], Ra, mas_splat(8388608.0f));      // mas_probq + bias
+                    const mas_v2f tb = mas_pk_fma(v[1][c], Rb, mas_splat(8388608.0f));
+                    acc[c] += (mas_f2u(ta.x) + mas_f2u(ta.y)) + (mas_f2u(tb.x) + mas_f2u(tb.y));
+                }
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        n_quanta += 4;
+        // region accumulation of the unweighted margin, keyed by (superpixel, arg-max class)
+        mas_u64 q[4];
+        int key[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            q[k] = mas_fix(mas_bvsb(b1[k], b2[k], invT), MAS_SCORE_FRAC);
+            key[k] = id[k] < 0 ? -1 : id[k] * MAS_MAX_CLASSES + a1[k];
+        }
+        const bool same = (key[0] == key[1]) && (key[1] == key[2]) && (key[2] == key[3]);
+        if (same) {
+            if (key[0] >= 0) {
+                const int s = table_slot(t_keys, id[0]);
+                const mas_u64 qs = (q[0] + q[1]) + (q[2] + q[3]);
+                if (s >= 0) {
+                    atomicAdd(&t_sum[s * C + a1[0]], qs);
+                    atomicAdd(&t_hist[s * C + a1[0]], 4u);
+                } else {
+                    atomicAdd(&gsum[(size_t)id[0] * C + a1[0]], qs);
+                    atomicAdd(&ghist[(size_t)id[0] * C + a1[0]], 4u);
+                }
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                if (key[k] < 0) continue;
+                const int s = table_slot(t_keys, id[k]);
+                if (s >= 0) {
+                    atomicAdd(&t_sum[s * C + a1[k]], q[k]);
+                    atomicAdd(&t_hist[s * C + a1[k]], 1u);
+                } else {
+                    atomicAdd(&gsum[(size_t)id[k] * C + a1[k]], q[k]);
+                    atomicAdd(&ghist[(size_t)id[k] * C + a1[k]], 1u);
+                }
+            }
+        }
+    }
+
+    // class sums: wave shuffle reduction, 4 waves through LDS, one atomic per class per workgroup
+#pragma unroll
+    for (int c = 0; c < CT; ++c) {
+        mas_u64 a = acc[c] - n_quanta * MAS_PROBQ_BIAS;
+#pragma unroll
+        for (int off = MAS_WAVE / 2; off > 0; off >>= 1) a += __shfl_down(a, off, MAS_WAVE);
+        if (lane == 0) s_part[wave * CT + c] = a;
+    }
+    __syncthreads();
+    if (threadIdx.x < CT && (EXACT || (int)threadIdx.x < C)) {
+        mas_u64 a = 0;
+#pragma unroll
+        for (int w = 0; w < kThreads / MAS_WAVE; ++w) a += s_part[w * CT + threadIdx.x];
+        if (a) atomicAdd(&prob_sum[(size_t)b * C + threadIdx.x], a);
+    }
+    for (int i = threadIdx.x; i < kSlots * C; i += kThreads) {
+        const unsigned n = t_hist[i];
+        if (n) {
+            const int s = i / C;
+            const size_t g = (size_t)t_keys[s] * C + (i - s * C);
+            atomicAdd(&ghist[g], n);
+            atomicAdd(&gsum[g], t_sum[i]);
+        }
+    }
+}
+
+// score[r] = floor( (sum_c class_sum[r,c] * W31[c]) >> 31  /  n_r ) * 2^-40 ; dominant class; ban
+__global__ __launch_bounds__(kThreads) void k_region_finalize_weighted(const mas_u64* __restrict__ class_sum,
+                                                                        const unsigned* __restrict__ hist, long long n_regions,
+                                                                        int C, const unsigned* __restrict__ w31, int ban_class,
+                                                                        float* __restrict__ score, int* __restrict__ dominant,
+                                                                        unsigned* __restrict__ count,
+                                                                        long long* __restrict__ hist_i64) {
+    const long long r = (long long)blockIdx.x * kThreads + threadIdx.x;
+    if (r >= n_regions) return;
+    const unsigned* h = hist + r * C;
+    const mas_u64* cs = class_sum + r * C;
+    unsigned long long n = 0;
+    unsigned best = 0;
+    int arg = 0;
+    uint64_t hi = 0, lo = 0;
+    for (int c = 0; c < C; ++c) {
+        const unsigned v = h[c];
+        n += v;
+        if (v > best) { best = v; arg = c; }
+        if (v) mas_mac_u64_u32((uint64_t)cs[c], w31[c], &hi, &lo);
+        if (hist_i64) hist_i64[r * C + c] = (long long)v;
+    }
+    float s = 0.0f;
+    if (n) s = mas_fixed_mean(mas_shr31_u128(hi, lo), n, MAS_SCORE_FRAC);
+    if (ban_class >= 0 && arg == ban_class) s = 0.0f;
+    score[r] = s;
+    if (dominant) dominant[r] = arg;
+    if (count) count[r] = (unsigned)n;
+}
+
+inline size_t smem_bytes(int C, int CT) {
+    return sizeof(mas_u64) * ((size_t)kSlots * C + 4 * CT) + sizeof(unsigned) * (size_t)kSlots * C + sizeof(int) * kSlots;
+}
+
+template <int CT, bool EXACT, typename IdT>
+int launch(const float* z, const void* spx, int B, int C, int H, int W, int S, float invT, mas_u64* prob_sum, mas_u64* class_sum,
+           unsigned* hist, hipStream_t st) {
+    const int tiles_x = (W + kTileW - 1) / kTileW;
+    const int tiles_y = (H + kTileH - 1) / kTileH;
+    const long long nblk = (long long)B * tiles_x * tiles_y;
+    if (nblk <= 0 || nblk > 0x7fffffffLL) return MAS_ERR_SHAPE;
+    const bool vec = (W % 4 == 0) && (((uintptr_t)z & 15) == 0);
+    const size_t smem = smem_bytes(C, CT);
+    const IdT* ids = static_cast<const IdT*>(spx);
+    if (vec)
+        hipLaunchKernelGGL((k_single_pass<CT, EXACT, IdT, true>), dim3((unsigned)nblk), dim3(kThreads), smem, st, z, ids, C, H, W, S,
+                           invT, tiles_x, tiles_y, prob_sum, class_sum, hist);
+    else
+        hipLaunchKernelGGL((k_single_pass<CT, EXACT, IdT, false>), dim3((unsigned)nblk), dim3(kThreads), smem, st, z, ids, C, H, W, S,
+                           invT, tiles_x, tiles_y, prob_sum, class_sum, hist);
+    return mas_launch_status();
+}
+
+template <int CT, bool EXACT>
+int dispatch_ids(const float* z, const void* spx, int spx_dtype, int B, int C, int H, int W, int S, float invT, mas_u64* prob_sum,
+                 mas_u64* class_sum, unsigned* hist, hipStream_t st) {
+    switch (spx_dtype) {
+        case MAS_ID_I64: return launch<CT, EXACT, long long>(z, spx, B, C, H, W, S, invT, prob_sum, class_sum, hist, st);
+        case MAS_ID_I32: return launch<CT, EXACT, int>(z, spx, B, C, H, W, S, invT, prob_sum, class_sum, hist, st);
+        case MAS_ID_U16: return launch<CT, EXACT, unsigned short>(z, spx, B, C, H, W, S, invT, prob_sum, class_sum, hist, st);
+        default: return MAS_ERR_DTYPE;
+    }
+}
+
+}  // namespace
+
+extern "C" int mas_single_pass_accum(const float* z, const void* spx, int spx_dtype, int B, int C, int H, int W, int S, float invT,
+                                     uint64_t* prob_sum, uint64_t* class_sum, uint32_t* hist, void* stream) {
+    if (!z || !spx || !prob_sum || !class_sum || !hist) return MAS_ERR_NULL;
+    if (B <= 0 || H <= 0 || W <= 0 || S <= 0 || (long long)H * W > (1LL << 23)) return MAS_ERR_SHAPE;
+    if (C < 2 || C > MAS_MAX_CLASSES) return MAS_ERR_CLASSES;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    mas_u64* ps = reinterpret_cast<mas_u64*>(prob_sum);
+    mas_u64* cs = reinterpret_cast<mas_u64*>(class_sum);
+    switch (C) {
+        case 19: return dispatch_ids<19, true>(z, spx, spx_dtype, B, C, H, W, S, invT, ps, cs, hist, st);
+        case 20: return dispatch_ids<20, true>(z, spx, spx_dtype, B, C, H, W, S, invT, ps, cs, hist, st);
+        case 21: return dispatch_ids<21, true>(z, spx, spx_dtype, B, C, H, W, S, invT, ps, cs, hist, st);
+        default: return dispatch_ids<MAS_MAX_CLASSES, false>(z, spx, spx_dtype, B, C, H, W, S, invT, ps, cs, hist, st);
+    }
+}
+
+extern "C" int mas_region_finalize_weighted(const uint64_t* class_sum, const uint32_t* hist, int64_t n_regions, int C,
+                                            const uint32_t* w31, int ban_class, float* score, int32_t* dominant, uint32_t* count,
+                                            int64_t* hist_i64, void* stream) {
+    if (!class_sum || !hist || !w31 || !score) return MAS_ERR_NULL;
+    if (n_regions <= 0) return MAS_ERR_SHAPE;
+    if (C < 1 || C > MAS_MAX_CLASSES) return MAS_ERR_CLASSES;
+    const long long nblk = (n_regions + kThreads - 1) / kThreads;
+    if (nblk > 0x7fffffffLL) return MAS_ERR_SHAPE;
+    hipLaunchKernelGGL(k_region_finalize_weighted, dim3((unsigned)nblk), dim3(kThreads), 0, static_cast<hipStream_t>(stream),
+                       reinterpret_cast<const mas_u64*>(class_sum), hist, (long long)n_regions, C, w31, ban_class, score, dominant,
+                       count, reinterpret_cast<long long*>(hist_i64));
+    return mas_launch_status();
+}

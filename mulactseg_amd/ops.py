@@ -280,3 +280,54 @@ def logits_iou_counts(z, targets, num_classes, ignore_label, counts=None):
         _lib.check(_lib.load().mas_logits_iou_counts(z.data_ptr(), targets.data_ptr(), B, CH, H, W, num_classes,
                                                      int(ignore_label), counts.data_ptr(), _stream(z)), "mas_logits_iou_counts")
     return counts
+
+
+# ------------------------------------------------------------------------------------------------
+# single-pass acquisition scan
+# ------------------------------------------------------------------------------------------------
+def weights_to_fixed31(cls_w):
+    """floor(w * 2^31) as int32-viewed uint32 (host, exact): the integer class weights of the single-pass
+    finalize.  ``cls_w``: float32 numpy array or None (-> all ones)."""
+    w = np.asarray(cls_w, dtype=np.float32).astype(np.float64)
+    return np.floor(w * 2147483648.0).astype(np.uint32)
+
+
+def single_pass_accum(z, spx, S, invT, prob_sum=None, class_sum=None, hist=None):
+    """One scan: (prob_sum [B,C] i64, class_sum [B,S,C] i64, hist [B,S,C] i32), all accumulated into."""
+    _need(z, "z", torch.float32)
+    _need(spx, "spx")
+    B, C, H, W = z.shape
+    if tuple(spx.shape) != (B, H, W):
+        raise ValueError("spx shape %s does not match logits %s" % (tuple(spx.shape), tuple(z.shape)))
+    dev = z.device
+    if prob_sum is None:
+        prob_sum = torch.zeros((B, C), dtype=torch.int64, device=dev)
+    if class_sum is None:
+        class_sum = torch.zeros((B, S, C), dtype=torch.int64, device=dev)
+    if hist is None:
+        hist = torch.zeros((B, S, C), dtype=torch.int32, device=dev)
+    with torch.cuda.device(dev):
+        _lib.check(_lib.load().mas_single_pass_accum(z.data_ptr(), spx.data_ptr(), _id_code(spx), B, C, H, W, S, invT,
+                                                     prob_sum.data_ptr(), class_sum.data_ptr(), hist.data_ptr(), _stream(z)),
+                   "mas_single_pass_accum")
+    return prob_sum, class_sum, hist
+
+
+def region_finalize_weighted(class_sum, hist, w31, ban_class=-1, want_hist_i64=False):
+    """Weighted mean per region from the single-pass accumulators.  ``w31``: int32 tensor [C] holding uint32 bits."""
+    _need(class_sum, "class_sum", torch.int64)
+    _need(hist, "hist", torch.int32)
+    _need(w31, "w31", torch.int32)
+    C = hist.shape[-1]
+    shape = hist.shape[:-1]
+    n = hist.numel() // C
+    dev = hist.device
+    score = torch.empty(shape, dtype=torch.float32, device=dev)
+    dom = torch.empty(shape, dtype=torch.int32, device=dev)
+    cnt = torch.empty(shape, dtype=torch.int32, device=dev)
+    h64 = torch.empty(hist.shape, dtype=torch.int64, device=dev) if want_hist_i64 else None
+    with torch.cuda.device(dev):
+        _lib.check(_lib.load().mas_region_finalize_weighted(
+            class_sum.data_ptr(), hist.data_ptr(), n, C, w31.data_ptr(), ban_class, score.data_ptr(), dom.data_ptr(),
+            cnt.data_ptr(), h64.data_ptr() if h64 is not None else None, _stream(hist)), "mas_region_finalize_weighted")
+    return score, dom, cnt, h64

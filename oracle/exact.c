@@ -24,21 +24,20 @@
 
 #define MAXC 64
 
-/* softmax(z * invT) of one pixel; operation order as in csrc/common.h:mas_softmax_regs */
-static void softmax_row(const float* z, size_t stride, int C, float invT, float* p) {
-    float m = z[0] * invT;
+/* softmax(z * invT) of one pixel; operation order as in csrc/common.h:mas_softmax_regs.
+ * On return e[c] are the un-normalised exponentials; the function value is rinv = 1/sum (p_c = e_c * rinv). */
+static float softmax_row(const float* z, size_t stride, int C, float invT, float* e) {
+    float m = z[0];
     int c;
-    for (c = 0; c < C; ++c) {
-        p[c] = z[(size_t)c * stride] * invT;
-        if (p[c] > m) m = p[c];
-    }
+    for (c = 1; c < C; ++c)
+        if (z[(size_t)c * stride] > m) m = z[(size_t)c * stride];
+    const float negM = -(m * invT);
     float sum = 0.0f;
     for (c = 0; c < C; ++c) {
-        p[c] = mas_expf(p[c] - m);
-        sum = (c == 0) ? p[c] : (sum + p[c]);
+        e[c] = mas_expf_np(mas_fmaf(z[(size_t)c * stride], invT, negM));
+        sum = (c == 0) ? e[c] : (sum + e[c]);
     }
-    const float rinv = 1.0f / sum;
-    for (c = 0; c < C; ++c) p[c] = p[c] * rinv;
+    return 1.0f / sum;
 }
 
 /* K2: per-image fixed-point sums of softmax(z/T) -- the integer form of
@@ -51,8 +50,8 @@ void exact_class_prob_sum(const float* z, int B, int C, int H, int W, float invT
     size_t i;
     for (b = 0; b < B; ++b)
         for (i = 0; i < HW; ++i) {
-            softmax_row(z + (size_t)b * C * HW + i, HW, C, invT, p);
-            for (c = 0; c < C; ++c) prob_sum[(size_t)b * C + c] += mas_fix31(p[c]);
+            const float R = softmax_row(z + (size_t)b * C * HW + i, HW, C, invT, p) * 8388608.0f;
+            for (c = 0; c < C; ++c) prob_sum[(size_t)b * C + c] += mas_probq(p[c], R);
         }
 }
 
@@ -69,7 +68,7 @@ void exact_class_weight(const uint64_t* prob_sum, int n_img, int C, int64_t HW, 
             int64_t n = 0;
             for (i = 0; i < n_img; ++i)
                 if (batch_of[i] == b) { s += prob_sum[(size_t)i * C + c]; n += 1; }
-            if (n) acc += ((double)s / 2147483648.0) / ((double)n * (double)HW);
+            if (n) acc += ((double)s / 8388608.0) / ((double)n * (double)HW);
         }
         cum[c] = acc / (double)n_batches;
         const double t = coeff * cum[c] + 1.0;
@@ -129,11 +128,16 @@ void exact_region_finalize(const uint64_t* score_sum, const uint32_t* hist, int6
 
 /* elementwise probes of the arithmetic spec, for tests/test_detmath.py */
 void exact_expf_array(const float* x, float* y, int64_t n) { int64_t i; for (i = 0; i < n; ++i) y[i] = mas_expf(x[i]); }
+void exact_expf_np_array(const float* x, float* y, int64_t n) { int64_t i; for (i = 0; i < n; ++i) y[i] = mas_expf_np(x[i]); }
 void exact_logf_array(const float* x, float* y, int64_t n) { int64_t i; for (i = 0; i < n; ++i) y[i] = mas_logf(x[i]); }
 void exact_fix_array(const float* x, int frac, uint64_t* y, int64_t n) { int64_t i; for (i = 0; i < n; ++i) y[i] = mas_fix(x[i], frac); }
 void exact_softmax_rows(const float* z, int64_t n, int C, float invT, float* p) {
     int64_t i;
-    for (i = 0; i < n; ++i) softmax_row(z + i * C, 1, C, invT, p + i * C);
+    for (i = 0; i < n; ++i) {
+        const float rinv = softmax_row(z + i * C, 1, C, invT, p + i * C);
+        int c;
+        for (c = 0; c < C; ++c) p[i * C + c] = p[i * C + c] * rinv;
+    }
 }
 
 /* =============================================================================================
@@ -178,7 +182,10 @@ void exact_partial_loss_fwd(const float* z, const int64_t* spx, const uint8_t* m
             const uint32_t Y = bits[(size_t)n * S + id];
             const int nb = popcount32(Y);
             if (nb == 0) { acc[ACC_N_EMPTY] += 1; continue; }
-            softmax_row(z + (size_t)n * C * HW + i, HW, C, invT, p);
+            {
+                const float rinv = softmax_row(z + (size_t)n * C * HW + i, HW, C, invT, p);
+                for (c = 0; c < C; ++c) p[c] = p[c] * rinv;
+            }
             if (flags & LOSS_CE) {
                 float pos = 0.0f;
                 for (c = 0; c < C; ++c)
@@ -262,7 +269,10 @@ void exact_partial_loss_bwd(const float* z, const int64_t* spx, const uint8_t* m
             const uint32_t Y = bits[(size_t)n * S + id];
             const int nb = popcount32(Y);
             if (nb == 0) continue;
-            softmax_row(z + (size_t)n * C * HW + i, HW, C, invT, p);
+            {
+                const float rinv = softmax_row(z + (size_t)n * C * HW + i, HW, C, invT, p);
+                for (c = 0; c < C; ++c) p[c] = p[c] * rinv;
+            }
             float coef = 0.0f, pos = 0.0f;
             if (flags & LOSS_CE) {
                 for (c = 0; c < C; ++c)
@@ -295,4 +305,60 @@ void exact_partial_loss_bwd(const float* z, const int64_t* spx, const uint8_t* m
                 dz[((size_t)n * C + c) * HW + i] = d;
             }
         }
+}
+
+/* =============================================================================================
+ * Single-pass acquisition scan (csrc/single_pass.hip)
+ * ============================================================================================= */
+
+/* One scan producing the class-probability quanta of exact_class_prob_sum, and per (region, arg-max class) the
+ * fixed-point sum of the UNWEIGHTED margins plus the pixel counts (the weight of
+ * my_bvsb_predclsbal_pwr_banignore.py:59-61 depends only on the arg-max class and factors out of the region sum). */
+void exact_single_pass_accum(const float* z, const int64_t* spx, int B, int C, int H, int W, int S, float invT,
+                             uint64_t* prob_sum, uint64_t* class_sum, uint32_t* hist) {
+    const size_t HW = (size_t)H * W;
+    float e[MAXC];
+    int b, c;
+    size_t i;
+    for (b = 0; b < B; ++b)
+        for (i = 0; i < HW; ++i) {
+            const float* zp = z + (size_t)b * C * HW + i;
+            const float R = softmax_row(zp, HW, C, invT, e) * 8388608.0f;
+            for (c = 0; c < C; ++c) prob_sum[(size_t)b * C + c] += mas_probq(e[c], R);
+            const int64_t id = spx[(size_t)b * HW + i];
+            if (id < 0 || id >= S) continue;
+            float b1 = -INFINITY, b2 = -INFINITY;
+            int a1 = 0;
+            for (c = 0; c < C; ++c) {
+                const float v = zp[(size_t)c * HW];
+                if (v > b1) { b2 = b1; b1 = v; a1 = c; }
+                else if (v > b2) b2 = v;
+            }
+            class_sum[((size_t)b * S + id) * C + a1] += mas_fix(mas_bvsb(b1, b2, invT), MAS_SCORE_FRAC);
+            hist[((size_t)b * S + id) * C + a1] += 1u;
+        }
+}
+
+/* score = floor(((sum_c class_sum[c] * w31[c]) >> 31) / n) * 2^-40, w31 = floor(w * 2^31); dominant class; ban. */
+void exact_region_finalize_weighted(const uint64_t* class_sum, const uint32_t* hist, int64_t n_regions, int C,
+                                    const uint32_t* w31, int ban_class, float* score, int32_t* dominant, uint32_t* count) {
+    int64_t r;
+    int c;
+    for (r = 0; r < n_regions; ++r) {
+        uint64_t n = 0, hi = 0, lo = 0;
+        uint32_t best = 0;
+        int arg = 0;
+        for (c = 0; c < C; ++c) {
+            const uint32_t v = hist[r * C + c];
+            n += v;
+            if (v > best) { best = v; arg = c; }
+            if (v) mas_mac_u64_u32(class_sum[r * C + c], w31[c], &hi, &lo);
+        }
+        float s = 0.0f;
+        if (n) s = mas_fixed_mean(mas_shr31_u128(hi, lo), n, MAS_SCORE_FRAC);
+        if (ban_class >= 0 && arg == ban_class) s = 0.0f;
+        score[r] = s;
+        if (dominant) dominant[r] = arg;
+        if (count) count[r] = (uint32_t)n;
+    }
 }

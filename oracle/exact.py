@@ -89,6 +89,13 @@ def expf(x):
     return y
 
 
+def expf_np(x):
+    x = _c(x, np.float32)
+    y = np.empty_like(x)
+    lib().exact_expf_np_array(_p(x), _p(y), ctypes.c_int64(x.size))
+    return y
+
+
 def logf(x):
     x = _c(x, np.float32)
     y = np.empty_like(x)
@@ -162,3 +169,36 @@ def partial_loss_bwd(z, spx, mask, bits, gmax, acc, grad_out, invT, flags):
     lib().exact_partial_loss_bwd(_p(z), _p(spx), _p(mask), _p(bits), _p(gmax), _p(scale), N, C, H, W, S,
                                  ctypes.c_float(invT), flags, _p(dz))
     return scale, dz
+
+
+# ------------------------------------------------------------------------------------------------
+# single-pass acquisition scan
+# ------------------------------------------------------------------------------------------------
+def single_pass_accum(z, spx, S, invT):
+    z = _c(z, np.float32)
+    spx = _c(spx, np.int64)
+    B, C, H, W = z.shape
+    ps = np.zeros((B, C), dtype=np.uint64)
+    cs = np.zeros((B, S, C), dtype=np.uint64)
+    hist = np.zeros((B, S, C), dtype=np.uint32)
+    lib().exact_single_pass_accum(_p(z), _p(spx), B, C, H, W, S, ctypes.c_float(invT), _p(ps), _p(cs), _p(hist))
+    return ps, cs, hist
+
+
+def weights_to_fixed31(cls_w):
+    return np.floor(np.asarray(cls_w, dtype=np.float32).astype(np.float64) * 2147483648.0).astype(np.uint32)
+
+
+def region_finalize_weighted(class_sum, hist, w31, ban_class):
+    class_sum = _c(class_sum, np.uint64)
+    hist = _c(hist, np.uint32)
+    w31 = _c(w31, np.uint32)
+    C = hist.shape[-1]
+    shape = hist.shape[:-1]
+    n = int(np.prod(shape))
+    score = np.zeros(shape, dtype=np.float32)
+    dom = np.zeros(shape, dtype=np.int32)
+    cnt = np.zeros(shape, dtype=np.uint32)
+    lib().exact_region_finalize_weighted(_p(class_sum), _p(hist), ctypes.c_int64(n), C, _p(w31), ban_class,
+                                         _p(score), _p(dom), _p(cnt))
+    return score, dom, cnt

@@ -33,6 +33,19 @@ class OracleBackend:
         h64 = hist.to(torch.int64) if want_hist_i64 else None
         return torch.from_numpy(score), torch.from_numpy(dom), torch.from_numpy(cnt.view(np.int32)), h64
 
+    def single_pass(self, logits, spx, S, invT, prob_sum, class_sum, hist):
+        ps, cs, h = exact.single_pass_accum(logits.numpy(), spx.numpy(), S, np.float32(invT))
+        prob_sum += torch.from_numpy(ps.view(np.int64))
+        class_sum += torch.from_numpy(cs.view(np.int64))
+        hist += torch.from_numpy(h.view(np.int32))
+
+    def finalize_weighted(self, class_sum, hist, cls_w, ban_class, want_hist_i64=False):
+        w = np.ones(hist.shape[-1], dtype=np.float32) if cls_w is None else cls_w.numpy()
+        score, dom, cnt = exact.region_finalize_weighted(class_sum.numpy().view(np.uint64), hist.numpy().view(np.uint32),
+                                                         exact.weights_to_fixed31(w), ban_class)
+        h64 = hist.to(torch.int64) if want_hist_i64 else None
+        return torch.from_numpy(score), torch.from_numpy(dom), torch.from_numpy(cnt.view(np.int32)), h64
+
     def minmax_normalize_(self, scores):
         u = scores.numpy()
         mn = u[u != 0].min()

@@ -72,8 +72,8 @@ def test_class_prob_sum_bit_exact(B, C, H, W, S):
     e = exact.class_prob_sum(z, np.float32(invT))
     g = ops.class_prob_sum(torch.from_numpy(z).cuda(), invT)
     assert np.array_equal(g.cpu().numpy().view(np.uint64), e)
-    # probabilities sum to one: the integer sums add up to about HW * 2^31 per image
-    tot = g.cpu().numpy().view(np.uint64).sum(axis=1).astype(np.float64) / 2.0 ** 31 / (H * W)
+    # probabilities sum to one: the integer sums add up to about HW * 2^23 per image
+    tot = g.cpu().numpy().view(np.uint64).sum(axis=1).astype(np.float64) / 2.0 ** 23 / (H * W)
     assert np.all(np.abs(tot - 1.0) < 1e-5)
 
 
@@ -111,3 +111,57 @@ def test_cpu_tensor_is_refused():
     from mulactseg_amd import _lib
     with pytest.raises(_lib.MulActSegHipError):
         ops.class_prob_sum(torch.zeros(1, 20, 4, 4), 10.0)
+
+
+@pytest.mark.parametrize("B,C,H,W,S", CASES)
+def test_single_pass_bit_exact_and_consistent_with_two_pass(B, C, H, W, S):
+    """k_single_pass == oracle bit for bit; its class sums equal the K2 kernel's, its per-class margin sums add up
+    to the K3 kernel's unweighted region sums, and with unit weights the finalize equals the two-pass finalize."""
+    ops = _gpu()
+    from oracle import exact
+    z, spx = _case(400 + C + W, B, C, H, W, S)
+    invT = ops.inv_temperature(0.1)
+    eps_, ecs, eh = exact.single_pass_accum(z, spx, S, np.float32(invT))
+    zt = torch.from_numpy(z).cuda()
+    for dtype in (torch.int64, torch.int32, torch.int16):
+        st = torch.from_numpy(spx).to(dtype).cuda()
+        ps, cs, hh = ops.single_pass_accum(zt, st, S, invT)
+        assert np.array_equal(ps.cpu().numpy().view(np.uint64), eps_), dtype
+        assert np.array_equal(cs.cpu().numpy().view(np.uint64), ecs), dtype
+        assert np.array_equal(hh.cpu().numpy().view(np.uint32), eh), dtype
+    assert torch.equal(ps, ops.class_prob_sum(zt, invT))
+    ss, h2 = ops.bvsb_region_accum(zt, st, None, S, invT)
+    assert torch.equal(h2, hh) and torch.equal(cs.sum(dim=2), ss)
+    w = (np.random.RandomState(9).uniform(0.2, 1.0, size=C)).astype(np.float32)
+    for weights in (np.ones(C, dtype=np.float32), w):
+        w31 = ops.weights_to_fixed31(weights)
+        score, dom, cnt, h64 = ops.region_finalize_weighted(cs, hh, torch.from_numpy(w31.view(np.int32)).cuda(), C - 1, True)
+        escore, edom, ecnt = exact.region_finalize_weighted(ecs, eh, w31, C - 1)
+        assert np.array_equal(score.cpu().numpy(), escore) and np.array_equal(dom.cpu().numpy(), edom)
+        assert np.array_equal(cnt.cpu().numpy().view(np.uint32), ecnt)
+    one = torch.from_numpy(ops.weights_to_fixed31(np.ones(C, dtype=np.float32)).view(np.int32)).cuda()
+    s1 = ops.region_finalize_weighted(cs, hh, one, -1)[0]
+    s2 = ops.region_finalize(ss, h2, -1)[0]
+    assert torch.equal(s1, s2)
+
+
+def test_single_pass_full_resolution_properties():
+    """Size-independent checks at the bench shape [4,20,1024,2048], S=2048: every pixel lands in exactly one
+    (region, class) bin, class-probability quanta sum to one per pixel, and a second accumulation doubles everything
+    (integer accumulators: exact linearity)."""
+    ops = _gpu()
+    B, C, H, W, S = 4, 20, 1024, 2048, 2048
+    g = torch.Generator(device='cuda'); g.manual_seed(3)
+    z = 0.4 * torch.randn((B, C, H, W), generator=g, device='cuda')
+    spx = torch.from_numpy(np.stack([synth.superpixel_map(70 + i, H, W, S) for i in range(B)])).cuda()
+    invT = ops.inv_temperature(0.1)
+    ps, cs, hh = ops.single_pass_accum(z, spx, S, invT)
+    assert int(hh.sum()) == B * H * W
+    tot = ps.sum(dim=1).double() / 2.0 ** 23 / (H * W)
+    assert float((tot - 1).abs().max()) < 1e-6
+    ps2, cs2, hh2 = ops.single_pass_accum(z, spx, S, invT, prob_sum=ps.clone(), class_sum=cs.clone(), hist=hh.clone())
+    assert torch.equal(ps2, 2 * ps) and torch.equal(cs2, 2 * cs) and torch.equal(hh2, 2 * hh)
+    # permuting the images permutes the outputs (no cross-image leakage)
+    perm = torch.tensor([2, 0, 3, 1], device='cuda')
+    ps3, cs3, hh3 = ops.single_pass_accum(z[perm].contiguous(), spx[perm].contiguous(), S, invT)
+    assert torch.equal(ps3, ps[perm]) and torch.equal(cs3, cs[perm]) and torch.equal(hh3, hh[perm])

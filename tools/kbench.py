@@ -1,0 +1,70 @@
+#!/usr/bin/env python
+"""Developer micro-benchmark: time individual scorer / loss kernels on resident synthetic tensors.
+   python tools/kbench.py [k2] [k3] [loss] [--ids int16]"""
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from bench import make_batch  # noqa: E402
+from mulactseg_amd import ops  # noqa: E402
+
+
+def timeit(fn, n=30, warm=5):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(n)]
+    for a, b in evs:
+        a.record(); fn(); b.record()
+    torch.cuda.synchronize()
+    t = sorted(a.elapsed_time(b) for a, b in evs)
+    return t[len(t) // 2] * 1e3, t[0] * 1e3
+
+
+def main():
+    which = [a for a in sys.argv[1:] if not a.startswith('--')] or ['k2', 'k3']
+    ids = 'int64'
+    if '--ids' in sys.argv:
+        ids = sys.argv[sys.argv.index('--ids') + 1]
+    dev = torch.device('cuda:0')
+    B, C, H, W, S = 4, 20, 1024, 2048, 2048
+    bufs = [make_batch(11 + i, B, C, H, W, S, ids, dev) for i in range(3)]
+    invT = ops.inv_temperature(0.1)
+    w = torch.linspace(0.3, 1.0, C, device=dev)
+    it = [0]
+    if 'k2' in which:
+        out = torch.zeros((B, C), dtype=torch.int64, device=dev)
+        def f():
+            it[0] += 1
+            ops.class_prob_sum(bufs[it[0] % 3][0], invT, out=out)
+        med, mn = timeit(f)
+        print("k2  median %.1f us  min %.1f us  -> %.2f TB/s" % (med, mn, B * C * H * W * 4 / med / 1e6))
+    if 'k3' in which:
+        ss = torch.zeros((B, S), dtype=torch.int64, device=dev)
+        hh = torch.zeros((B, S, C), dtype=torch.int32, device=dev)
+        idb = {'int64': 8, 'int32': 4, 'int16': 2}[ids]
+        def f():
+            it[0] += 1
+            z, spx = bufs[it[0] % 3]
+            ops.bvsb_region_accum(z, spx, w, S, invT, score_sum=ss, hist=hh)
+        med, mn = timeit(f)
+        print("k3  median %.1f us  min %.1f us  -> %.2f TB/s (%s ids)" % (med, mn, B * (C * H * W * 4 + H * W * idb) / med / 1e6, ids))
+    if 'fused' in which and hasattr(ops, 'single_pass_accum'):
+        ps = torch.zeros((B, C), dtype=torch.int64, device=dev)
+        s2 = torch.zeros((B, S, C), dtype=torch.int64, device=dev)
+        hh = torch.zeros((B, S, C), dtype=torch.int32, device=dev)
+        idb = {'int64': 8, 'int32': 4, 'int16': 2}[ids]
+        def f():
+            it[0] += 1
+            z, spx = bufs[it[0] % 3]
+            ops.single_pass_accum(z, spx, S, invT, prob_sum=ps, class_sum=s2, hist=hh)
+        med, mn = timeit(f)
+        print("fused median %.1f us  min %.1f us  -> %.2f TB/s (%s ids)" % (med, mn, B * (C * H * W * 4 + H * W * idb) / med / 1e6, ids))
+
+
+if __name__ == "__main__":
+    main()
