@@ -171,6 +171,15 @@ int mas_budget_walk(const uint64_t* sorted_keys, int64_t n, const uint8_t* regio
                     int S, int64_t budget, int64_t max_out, int64_t* n_selected,
                     int32_t* sel_img, int32_t* sel_id, float* sel_score, void* workspace, size_t ws_bytes, void* stream);
 
+/* score[r] <- (dominant[r] == ban_class ? 0 : score[r]) * (cls_w ? cls_w[dominant[r]] : 1), in place.
+ * The post-normalisation ban and the region-level class balancing of
+ * active_selection/my_bvsb_banignore.py:58-61 and my_bvsb_clsbal_v2_banignore.py:60-74 (ban_class < 0: no ban). */
+int mas_region_reweight(float* score, const int32_t* dominant, int64_t n, int ban_class, const float* cls_w /* [C] or NULL */,
+                        void* stream);
+
+/* counts[c] += number of regions whose dominant class is c (my_bvsb_clsbal_v2.py:65-66: est_label_dist). */
+int mas_dominant_hist(const int32_t* dominant, int64_t n, int C, uint64_t* counts /* [C] */, void* stream);
+
 /* In-place min-max normalisation of the plain BvSB selector (active_selection/my_bvsb.py:79-81):
  *   u <- (u - min(u[u != 0])) / max(u - min(u[u != 0]))     over all n region scores.
  * scratch2: 2 x uint32 of caller-owned device scratch. */

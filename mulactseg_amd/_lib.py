@@ -29,6 +29,8 @@ SIGNATURES = {
     "mas_select_workspace_bytes": (_c.c_size_t, [_i64]),
     "mas_sort_keys_desc": (_i, [_vp, _i64, _vp, _vp, _c.c_size_t, _vp]),
     "mas_budget_walk": (_i, [_vp, _i64, _vp, _vp, _i, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _c.c_size_t, _vp]),
+    "mas_region_reweight": (_i, [_vp, _vp, _i64, _i, _vp, _vp]),
+    "mas_dominant_hist": (_i, [_vp, _i64, _i, _vp, _vp]),
     "mas_minmax_normalize": (_i, [_vp, _i64, _vp, _vp]),
     "mas_iou_counts": (_i, [_vp, _vp, _vp, _i64, _i, _i64, _vp, _vp]),
     "mas_logits_iou_counts": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i64, _vp, _vp]),

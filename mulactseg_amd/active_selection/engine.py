@@ -135,6 +135,12 @@ class HipBackend:
     def minmax_normalize_(self, scores):
         return self.ops.minmax_normalize_(scores)
 
+    def region_reweight_(self, scores, dominant, ban_class, cls_w):
+        return self.ops.region_reweight_(scores, dominant, ban_class, cls_w)
+
+    def dominant_hist(self, dominant, C):
+        return self.ops.dominant_hist(dominant, C)
+
     def select(self, scores, valid, img_rank, img_of_rank, region_cost, budget, max_out):
         keys = self.ops.region_keys(scores, valid, img_rank)
         skeys = self.ops.sort_keys_desc(keys)
@@ -230,15 +236,18 @@ class AcquisitionRound:
             return full, gather_rows(h64, self.plan)
         return full
 
-    def scores(self, ban_class=-1, want_hist=False):
+    def scores(self, ban_class=-1, want_hist=False, want_dominant=False):
         n = self.plan.n_local
         if n == 0:      # more ranks than reference batches: this rank only takes part in the exchanges
             dev = self.backend.device
             score = torch.zeros((0, self.S), dtype=torch.float32, device=dev)
+            dom = torch.zeros((0, self.S), dtype=torch.int32, device=dev)
             h64 = torch.zeros((0, self.S, self.C), dtype=torch.int64, device=dev)
         else:
             score, dom, cnt, h64 = self.backend.finalize(self.score_sum[:n], self.hist[:n], ban_class, want_hist)
         full = gather_rows(score, self.plan)                                      # exchange 2
+        if want_dominant:
+            return full, gather_rows(dom, self.plan)
         if want_hist:
             return full, gather_rows(h64, self.plan)
         return full

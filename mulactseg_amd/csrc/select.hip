@@ -109,6 +109,32 @@ __global__ __launch_bounds__(kThreads) void k_walk_emit(const mas_u64* __restric
 
 __global__ void k_set_u64(unsigned long long* p, unsigned long long v) { *p = v; }
 
+// score[r] <- (dominant[r] == ban_class ? 0 : score[r]) * (cls_w ? cls_w[dominant[r]] : 1)
+__global__ __launch_bounds__(kThreads) void k_region_reweight(float* __restrict__ score, const int* __restrict__ dominant,
+                                                               long long n, int ban_class, const float* __restrict__ cls_w) {
+    const long long i = (long long)blockIdx.x * kThreads + threadIdx.x;
+    if (i >= n) return;
+    const int d = dominant[i];
+    float s = score[i];
+    if (d == ban_class) s = 0.0f;
+    if (cls_w) s = cls_w[d] * s;
+    score[i] = s;
+}
+
+// counts[c] += #regions with dominant class c (LDS histogram, one 64-bit atomic per class per block)
+__global__ __launch_bounds__(kThreads) void k_dominant_hist(const int* __restrict__ dominant, long long n, int C,
+                                                             mas_u64* __restrict__ counts) {
+    __shared__ unsigned s_cnt[MAS_MAX_CLASSES];
+    if (threadIdx.x < MAS_MAX_CLASSES) s_cnt[threadIdx.x] = 0;
+    __syncthreads();
+    for (long long i = (long long)blockIdx.x * kThreads + threadIdx.x; i < n; i += (long long)gridDim.x * kThreads) {
+        const int d = dominant[i];
+        if (d >= 0 && d < C) atomicAdd(&s_cnt[d], 1u);
+    }
+    __syncthreads();
+    if ((int)threadIdx.x < C && s_cnt[threadIdx.x]) atomicAdd(&counts[threadIdx.x], (mas_u64)s_cnt[threadIdx.x]);
+}
+
 // min over the non-zero entries and max over all entries, as order-preserving bit patterns
 __global__ __launch_bounds__(kThreads) void k_minmax_nonzero(const float* __restrict__ u, long long n, unsigned* __restrict__ mm) {
     unsigned lo = 0xffffffffu, hi = 0u;
@@ -228,5 +254,25 @@ extern "C" int mas_minmax_normalize(float* scores, int64_t n, uint32_t* scratch2
     hipLaunchKernelGGL(k_minmax_init, dim3(1), dim3(1), 0, st, scratch2);
     hipLaunchKernelGGL(k_minmax_nonzero, dim3((unsigned)(nblk > 1024 ? 1024 : nblk)), dim3(kThreads), 0, st, scores, (long long)n, scratch2);
     hipLaunchKernelGGL(k_minmax_apply, dim3((unsigned)nblk), dim3(kThreads), 0, st, scores, (long long)n, scratch2);
+    return mas_launch_status();
+}
+
+extern "C" int mas_region_reweight(float* score, const int32_t* dominant, int64_t n, int ban_class, const float* cls_w, void* stream) {
+    if (!score || !dominant) return MAS_ERR_NULL;
+    if (n <= 0) return MAS_ERR_SHAPE;
+    const long long nblk = (n + kThreads - 1) / kThreads;
+    hipLaunchKernelGGL(k_region_reweight, dim3((unsigned)nblk), dim3(kThreads), 0, static_cast<hipStream_t>(stream), score, dominant,
+                       (long long)n, ban_class, cls_w);
+    return mas_launch_status();
+}
+
+extern "C" int mas_dominant_hist(const int32_t* dominant, int64_t n, int C, uint64_t* counts, void* stream) {
+    if (!dominant || !counts) return MAS_ERR_NULL;
+    if (n <= 0) return MAS_ERR_SHAPE;
+    if (C < 1 || C > MAS_MAX_CLASSES) return MAS_ERR_CLASSES;
+    long long nblk = (n + kThreads - 1) / kThreads;
+    if (nblk > 1024) nblk = 1024;
+    hipLaunchKernelGGL(k_dominant_hist, dim3((unsigned)nblk), dim3(kThreads), 0, static_cast<hipStream_t>(stream), dominant,
+                       (long long)n, C, reinterpret_cast<mas_u64*>(counts));
     return mas_launch_status();
 }

@@ -331,3 +331,27 @@ def region_finalize_weighted(class_sum, hist, w31, ban_class=-1, want_hist_i64=F
             class_sum.data_ptr(), hist.data_ptr(), n, C, w31.data_ptr(), ban_class, score.data_ptr(), dom.data_ptr(),
             cnt.data_ptr(), h64.data_ptr() if h64 is not None else None, _stream(hist)), "mas_region_finalize_weighted")
     return score, dom, cnt, h64
+
+
+def region_reweight_(scores, dominant, ban_class=-1, cls_w=None):
+    """In place: zero the regions whose dominant class is ``ban_class`` and multiply by ``cls_w[dominant]``
+    (my_bvsb_banignore.py:58-61, my_bvsb_clsbal_v2_banignore.py:60-74)."""
+    _need(scores, "scores", torch.float32)
+    _need(dominant, "dominant", torch.int32)
+    if cls_w is not None:
+        _need(cls_w, "cls_w", torch.float32)
+    with torch.cuda.device(scores.device):
+        _lib.check(_lib.load().mas_region_reweight(scores.data_ptr(), dominant.data_ptr(), scores.numel(), ban_class,
+                                                   cls_w.data_ptr() if cls_w is not None else None, _stream(scores)),
+                   "mas_region_reweight")
+    return scores
+
+
+def dominant_hist(dominant, C):
+    """int64[C]: number of regions per dominant class."""
+    _need(dominant, "dominant", torch.int32)
+    counts = torch.zeros(C, dtype=torch.int64, device=dominant.device)
+    with torch.cuda.device(dominant.device):
+        _lib.check(_lib.load().mas_dominant_hist(dominant.data_ptr(), dominant.numel(), C, counts.data_ptr(), _stream(dominant)),
+                   "mas_dominant_hist")
+    return counts

@@ -195,6 +195,35 @@ def gen_g2():
     print("g2: ok")
 
 
+def gen_g7():
+    """Remaining selectors: my_bvsb_banignore, my_bvsb_clsbal_v2, my_bvsb_clsbal_v2_banignore."""
+    from active_selection import my_bvsb_banignore, my_bvsb_clsbal_v2, my_bvsb_clsbal_v2_banignore
+    trainer = types.SimpleNamespace(net=torch.nn.Identity(), device='cpu')
+    out = {}
+    for tag, mod, C, ncls, method, seed in (
+            ('banignore', my_bvsb_banignore, 20, 19, 'active_joint_multi_predignore_lossdecomp', 51),
+            ('clsbal_banignore', my_bvsb_clsbal_v2_banignore, 20, 19, 'active_joint_multi_predignore_lossdecomp', 52),
+            ('clsbal', my_bvsb_clsbal_v2, 21, 21, 'active_joint_multi_lossdecomp', 53)):
+        n_img, H, W, S, bs = 3, 40, 56, 48, 2
+        z, spx, im_idx, suppix = pool_inputs(seed, n_img, C, H, W, S, n_removed=4)
+        if C == 20:
+            z[0, C - 1, :14, :20] += 1.5
+        args = types.SimpleNamespace(val_batch_size=bs, val_num_workers=0, nseg=S, active_method='x', num_classes=ncls,
+                                     ce_temp=0.1, cls_weight_coeff=6.0, method=method, save_scores=False)
+        pool = FakePool(torch.from_numpy(z), torch.from_numpy(spx), [list(k) for k in im_idx],
+                        {k: list(v) for k, v in suppix.items()})
+        with CaptureLocals('calculate_scores', mod.__name__.split('.')[-1] + '.py') as cap:
+            scores = mod.RegionSelector(args).calculate_scores(trainer, pool)
+        sc, si, sid = tuples_to_arrays(scores, im_idx)
+        out.update({tag + '_seed': seed, tag + '_C': C, tag + '_ncls': ncls, tag + '_digest': digest(z, spx),
+                    tag + '_scores_tensor': cap.locals['scores_tensor'].numpy(),
+                    tag + '_list_score': sc, tag + '_list_img': si, tag + '_list_id': sid})
+        if 'cls_weight' in cap.locals:
+            out[tag + '_cls_weight'] = cap.locals['cls_weight'].numpy()
+    np.savez_compressed(os.path.join(OUT, "g7_selectors.npz"), n_img=3, H=40, W=56, S=48, batch_size=2, **out)
+    print("g7: ok")
+
+
 def loss_inputs(seed, N, C, H, W, S):
     z = synth.logits(seed, N, C, H, W)
     spx, msk = [], []
@@ -331,5 +360,6 @@ if __name__ == "__main__":
     gen_g3()
     gen_g4()
     gen_g5()
+    gen_g7()
     for f in sorted(os.listdir(OUT)):
         print(f, os.path.getsize(os.path.join(OUT, f)))

@@ -193,6 +193,32 @@ def bvsb_scores(logits, spx, batch_size, temperature, num_superpixels, strip_las
     return u.view(-1, num_superpixels)
 
 
+def bvsb_variant_scores(logits, spx, batch_size, temperature, num_superpixels, ban_ignore, class_balance):
+    """The remaining BvSB selectors: unweighted region means over ALL channels, min-max normalisation, then
+    optionally the ban of "undefined"-dominated regions (``my_bvsb_banignore.py:52-61``) and the region-level
+    class balancing ``exp(-share of regions with that dominant class)`` (``my_bvsb_clsbal_v2[_banignore].py:60-74``)."""
+    N, C = logits.shape[:2]
+    rb, rh = [], []
+    for a, b in _batches(N, batch_size):
+        r, h = region_scores_batch(logits[a:b], spx[a:b], temperature, None, num_superpixels, C)
+        rb.append(r)
+        rh.append(h)
+    u = torch.cat(rb).view(-1)
+    hist = torch.cat(rh).view(-1, C)
+    u = u - u[u != 0].min()
+    u = u / u.max()
+    dominant = hist.argmax(dim=1)
+    if ban_ignore:
+        u[dominant == C - 1] = 0
+    w = None
+    if class_balance:
+        oh = F.one_hot(dominant, num_classes=C)
+        dist = oh.sum(dim=0) / oh.sum()
+        w = torch.exp(-dist)
+        u = w[dominant] * u
+    return u.view(-1, num_superpixels), w
+
+
 def score_list(im_idx, suppix, scores):
     """``gen_score_list_from_tensor`` -- ``my_bvsb.py:29-48``: (score, "img,lbl,spx", id) for every id
     still listed in ``suppix[spx_path]``, images in ``im_idx`` order."""

@@ -53,6 +53,16 @@ class OracleBackend:
         u /= u.max()
         return scores
 
+    def region_reweight_(self, scores, dominant, ban_class, cls_w):
+        s, d = scores.numpy(), dominant.numpy()
+        s[d == ban_class] = 0
+        if cls_w is not None:
+            s *= cls_w.numpy()[d]
+        return scores
+
+    def dominant_hist(self, dominant, C):
+        return torch.from_numpy(np.bincount(dominant.numpy().ravel(), minlength=C).astype(np.int64))
+
     def select(self, scores, valid, img_rank, img_of_rank, region_cost, budget, max_out):
         # reference semantics: Python tuple sort with the rank standing in for the path string
         s, v = scores.numpy(), valid.numpy()

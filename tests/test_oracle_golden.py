@@ -216,3 +216,27 @@ def test_g5_miou_port_matches_reference():
     assert ious[7] == 100
     assert np.mean(ious) == g['miou']
     assert np.array_equal(ign, g['ign'])
+
+
+G7 = (('banignore', True, False), ('clsbal_banignore', True, True), ('clsbal', False, True))
+
+
+def g7_inputs(g, tag):
+    z, spx, im_idx, suppix = pool_inputs(int(g[tag + '_seed']), int(g['n_img']), int(g[tag + '_C']), int(g['H']), int(g['W']),
+                                         int(g['S']), 4)
+    if int(g[tag + '_C']) == 20:
+        z[0, 19, :14, :20] += 1.5
+    assert digest(z, spx) == g[tag + '_digest']
+    return z, spx, im_idx, suppix
+
+
+@pytest.mark.parametrize("tag,ban,bal", G7, ids=[t[0] for t in G7])
+def test_g7_remaining_selectors_port_matches_reference(tag, ban, bal):
+    g = np.load(os.path.join(GOLDEN, "g7_selectors.npz"))
+    z, spx, im_idx, suppix = g7_inputs(g, tag)
+    s, w = port.bvsb_variant_scores(torch.from_numpy(z), torch.from_numpy(spx), int(g['batch_size']), 0.1, int(g['S']), ban, bal)
+    assert np.array_equal(s.numpy(), g[tag + '_scores_tensor'])
+    if bal:
+        assert np.array_equal(w.numpy(), g[tag + '_cls_weight'])
+    sc, si, sid = tuples_to_arrays(port.score_list(im_idx, suppix, s), im_idx)
+    assert np.array_equal(sc, g[tag + '_list_score']) and np.array_equal(sid, g[tag + '_list_id'])

@@ -194,3 +194,24 @@ def test_single_pass_and_two_pass_agree():
     assert np.array_equal(a == 0, b == 0)
     assert np.max(np.abs(a[b > 0] / b[b > 0] - 1)) < 2e-7
     assert np.array_equal(np.argsort(-a.ravel(), kind='stable'), np.argsort(-b.ravel(), kind='stable'))
+
+
+@pytest.mark.parametrize("tag,modname,method", [
+    ('banignore', 'my_bvsb_banignore', 'active_joint_multi_predignore_lossdecomp'),
+    ('clsbal_banignore', 'my_bvsb_clsbal_v2_banignore', 'active_joint_multi_predignore_lossdecomp'),
+    ('clsbal', 'my_bvsb_clsbal_v2', 'active_joint_multi_lossdecomp')])
+def test_remaining_selectors_match_reference_g7(tag, modname, method):
+    from test_oracle_golden import g7_inputs
+    g = np.load(os.path.join(GOLDEN, "g7_selectors.npz"))
+    z, spx, im_idx, suppix = g7_inputs(g, tag)
+    args = selector_args(val_batch_size=int(g['batch_size']), nseg=int(g['S']), num_classes=int(g[tag + '_ncls']), method=method)
+    sel = _selector(modname, args)
+    s = sel.calculate_scores_tensor(fake_trainer(), FakePool(z, spx, im_idx, suppix)).numpy()
+    ref = g[tag + '_scores_tensor']
+    assert np.array_equal(s == 0, ref == 0)
+    assert np.allclose(s, ref, rtol=1e-4, atol=2e-6)
+    if tag != 'banignore':
+        assert np.allclose(sel.cls_weight.numpy(), g[tag + '_cls_weight'], rtol=2e-7)
+    tuples = sel.calculate_scores(fake_trainer(), FakePool(z, spx, im_idx, suppix))
+    sc, si, sid = tuples_to_arrays(tuples, im_idx)
+    assert np.array_equal(si, g[tag + '_list_img']) and np.array_equal(sid, g[tag + '_list_id'])

@@ -89,3 +89,24 @@ def test_backend_refuses_cpu_device():
     from mulactseg_amd.active_selection.engine import HipBackend
     with pytest.raises(_lib.MulActSegHipError):
         HipBackend('cpu')
+
+
+@pytest.mark.parametrize("tag,modname,method", [
+    ('banignore', 'my_bvsb_banignore', 'active_joint_multi_predignore_lossdecomp'),
+    ('clsbal_banignore', 'my_bvsb_clsbal_v2_banignore', 'active_joint_multi_predignore_lossdecomp'),
+    ('clsbal', 'my_bvsb_clsbal_v2', 'active_joint_multi_lossdecomp')])
+def test_remaining_selectors_on_gpu_match_reference(tag, modname, method):
+    _need_gpu()
+    import importlib
+    from test_oracle_golden import g7_inputs
+    g = np.load(os.path.join(GOLDEN, "g7_selectors.npz"))
+    z, spx, im_idx, suppix = g7_inputs(g, tag)
+    args = selector_args(val_batch_size=int(g['batch_size']), nseg=int(g['S']), num_classes=int(g[tag + '_ncls']), method=method)
+    sel = importlib.import_module("mulactseg_amd.active_selection." + modname).RegionSelector(args)
+    s = sel.calculate_scores_tensor(fake_trainer('cuda:0'), FakePool(z, spx, im_idx, suppix)).cpu().numpy()
+    ref = g[tag + '_scores_tensor']
+    assert np.array_equal(s == 0, ref == 0)
+    assert np.allclose(s, ref, rtol=1e-4, atol=2e-6)
+    tuples = sel.calculate_scores(fake_trainer('cuda:0'), FakePool(z, spx, im_idx, suppix))
+    _, si, sid = tuples_to_arrays(tuples, im_idx)
+    assert np.array_equal(si, g[tag + '_list_img']) and np.array_equal(sid, g[tag + '_list_id'])
