@@ -226,6 +226,36 @@ int mas_region_finalize_weighted(const uint64_t* class_sum, const uint32_t* hist
                                  const uint32_t* w31 /* [C] */, int ban_class, float* score, int32_t* dominant,
                                  uint32_t* count, int64_t* hist_i64, void* stream);
 
+/* =============================================================================================
+ * K9  stage-2 cosine pseudo labels with one-ring propagation
+ * (trainer/eval_save_cosplbl_prop.py:121-314, ..._includeonehot.py); one image per call.
+ * feat [Ch,fh,fw] is the L2-normalised feature map of feat_forward BEFORE its bilinear upsampling (fh x fw may
+ * equal H x W); every kernel interpolates to pixel (y,x) of the H x W grid on the fly (align_corners=False).
+ * Prototypes are listed in (superpixel, class) order: proto_start [S+1] prefix offsets, proto_cls [n], proto_pix [n]
+ * (arg-max pixels taken from the gmax table of mas_partial_loss_fwd run with invT = 1 and the group flags).
+ * ============================================================================================= */
+
+/* P [n_proto, Ch] = features at the prototype pixels (:197-199). */
+int mas_stage2_gather_protos(const float* feat, int Ch, int fh, int fw, int H, int W, const int32_t* proto_pix, int n_proto,
+                             float* P, void* stream);
+
+/* For every selected pixel whose superpixel owns prototypes: nn_proto = index of the most similar prototype of that
+ * superpixel (first maximum), nn_sim = that similarity; -1 / 0 elsewhere (:203-232). */
+int mas_stage2_assign(const float* feat, int Ch, int fh, int fw, int H, int W, const int64_t* spx, const uint8_t* mask, int S,
+                      const int32_t* proto_start, const float* P, int32_t* nn_proto /* [H*W] */, float* nn_sim /* [H*W] */,
+                      void* stream);
+
+/* adj [S, ceil(S/32)] (caller-zeroed bit matrix): bit g of row t set iff superpixel g owns prototypes and some pixel
+ * of g lies in the 3x3 neighbourhood of a pixel of t -- the binary_dilation + unique of :259-266, for all superpixels. */
+int mas_stage2_adjacency(const int64_t* spx, int H, int W, int S, const int32_t* proto_start, uint32_t* adj, void* stream);
+
+/* out [H*W] int64: 255, overwritten in ascending id order by every adjacent valid superpixel whose prototypes accept
+ * the pixel (some similarity above that prototype's threshold thr[j]; label = class of the most similar prototype),
+ * finally by the pixel's own nearest prototype (:272-311). */
+int mas_stage2_propagate(const float* feat, int Ch, int fh, int fw, int H, int W, const int64_t* spx, int S, const uint32_t* adj,
+                         const int32_t* proto_start, const int32_t* proto_cls, const float* P, const float* thr,
+                         const int32_t* nn_proto, int64_t* out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -36,6 +36,10 @@ SIGNATURES = {
     "mas_logits_iou_counts": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i64, _vp, _vp]),
     "mas_single_pass_accum": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _f, _vp, _vp, _vp, _vp]),
     "mas_region_finalize_weighted": (_i, [_vp, _vp, _i64, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp]),
+    "mas_stage2_gather_protos": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _i, _vp, _vp]),
+    "mas_stage2_assign": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp]),
+    "mas_stage2_adjacency": (_i, [_vp, _i, _i, _i, _vp, _vp, _vp]),
+    "mas_stage2_propagate": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "mas_target_bits": (_i, [_vp, _i64, _i, _i, _vp, _vp]),
     "mas_partial_loss_fwd": (_i, [_vp, _vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _f, _i, _vp, _vp, _vp]),
     "mas_group_finalize": (_i, [_vp, _i64, _vp, _vp]),

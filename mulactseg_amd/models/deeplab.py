@@ -208,6 +208,19 @@ class DeepLabV3PlusWN(nn.Module):
         y = self.classifier(self.backbone(x))
         return F.interpolate(y, size=size, mode='bilinear', align_corners=False)
 
+    def feat_forward_lowres(self, x):
+        """(L2-normalised point features at 1/4 resolution [N,256,H/4,W/4], logits upsampled to the input size):
+        what the stage-2 pseudo-label kernels consume -- they interpolate the features per pixel instead of
+        materialising feat_forward's 256-channel full-resolution tensor (2.1 GB per Cityscapes image)."""
+        size = x.shape[-2:]
+        keep = self.classifier.return_feat
+        self.classifier.return_feat = True
+        try:
+            feat, prob = self.classifier(self.backbone(x))
+        finally:
+            self.classifier.return_feat = keep
+        return feat, F.interpolate(prob, size=size, mode='bilinear', align_corners=False)
+
     def feat_forward(self, x):
         size = x.shape[-2:]
         keep = self.classifier.return_feat

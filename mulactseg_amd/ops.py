@@ -355,3 +355,71 @@ def dominant_hist(dominant, C):
         _lib.check(_lib.load().mas_dominant_hist(dominant.data_ptr(), dominant.numel(), C, counts.data_ptr(), _stream(dominant)),
                    "mas_dominant_hist")
     return counts
+
+
+# ------------------------------------------------------------------------------------------------
+# K9: stage-2 cosine pseudo labels
+# ------------------------------------------------------------------------------------------------
+def stage2_pseudo_labels(feats, logits, targets, spmasks, superpixels, include_onehot=True):
+    """Pseudo-label maps int64 [N,H,W] (255 = none) -- trainer/eval_save_cosplbl_prop[_includeonehot].py:121-314.
+
+    feats [N,Ch,fh,fw]: the L2-normalised point features of ``feat_forward`` BEFORE the bilinear upsampling (full
+    resolution is accepted too); logits [N,C,H,W]; targets u8 [N,S,C]; spmasks bool [N,H,W]; superpixels int64.
+    The small index bookkeeping (prototype list, per-prototype medians) uses torch ops on the device; feature
+    interpolation, similarities, adjacency and propagation are HIP kernels."""
+    _need(feats, "feats", torch.float32)
+    _need(logits, "logits", torch.float32)
+    _need(superpixels, "superpixels", torch.int64)
+    mask = _mask_u8(spmasks)
+    if targets.dtype != torch.uint8:
+        targets = targets.to(torch.uint8)
+    N, C, H, W = logits.shape
+    Ch, fh, fw = feats.shape[1:]
+    S = targets.shape[1]
+    dev = logits.device
+    lib = _lib.load()
+    bits = target_bits(targets.contiguous())
+    flags = _lib.LOSS_GROUP | (0 if include_onehot else _lib.LOSS_GROUP_ONLY_MULTI)
+    out = torch.full((N, H, W), 255, dtype=torch.int64, device=dev)
+    words = (S + 31) // 32
+    with torch.cuda.device(dev):
+        st = _stream(logits)
+        for i in range(N):
+            _, _, gmax = partial_loss_fwd(logits[i:i + 1], superpixels[i:i + 1], mask[i:i + 1], bits[i:i + 1], 1.0, flags)
+            g = gmax[0]
+            nz = (g != 0).nonzero()                              # ordered by (superpixel, class)
+            n_proto = nz.shape[0]
+            if n_proto == 0:
+                continue
+            proto_s, proto_c = nz[:, 0], nz[:, 1]
+            proto_pix = (0xffffffff - (g[proto_s, proto_c] & 0xffffffff)).to(torch.int32)
+            counts = torch.bincount(proto_s, minlength=S)
+            p_start = torch.zeros(S + 1, dtype=torch.int32, device=dev)
+            p_start[1:] = torch.cumsum(counts, 0).to(torch.int32)
+            p_cls = proto_c.to(torch.int32).contiguous()
+            P = torch.empty((n_proto, Ch), dtype=torch.float32, device=dev)
+            f, sp, mk = feats[i], superpixels[i], mask[i]
+            _lib.check(lib.mas_stage2_gather_protos(f.data_ptr(), Ch, fh, fw, H, W, proto_pix.data_ptr(), n_proto, P.data_ptr(), st),
+                       "mas_stage2_gather_protos")
+            nn = torch.empty(H * W, dtype=torch.int32, device=dev)
+            nn_sim = torch.empty(H * W, dtype=torch.float32, device=dev)
+            _lib.check(lib.mas_stage2_assign(f.data_ptr(), Ch, fh, fw, H, W, sp.data_ptr(), mk.data_ptr(), S, p_start.data_ptr(),
+                                             P.data_ptr(), nn.data_ptr(), nn_sim.data_ptr(), st), "mas_stage2_assign")
+            # per-prototype lower median of the assigned similarities (1.0 when a prototype attracts no pixel)
+            sel = (nn >= 0).nonzero().squeeze(1)
+            thr = torch.ones(n_proto, dtype=torch.float32, device=dev)
+            if sel.numel():
+                pid, sim = nn[sel].long(), nn_sim[sel]
+                order = torch.argsort(sim, stable=True)
+                order = order[torch.argsort(pid[order], stable=True)]            # sorted by (prototype, similarity)
+                pid_s, sim_s = pid[order], sim[order]
+                cnt = torch.bincount(pid_s, minlength=n_proto)
+                first = torch.cumsum(cnt, 0) - cnt
+                has = cnt > 0
+                thr[has] = sim_s[(first + (cnt - 1) // 2)[has]]
+            adj = torch.zeros((S, words), dtype=torch.int32, device=dev)
+            _lib.check(lib.mas_stage2_adjacency(sp.data_ptr(), H, W, S, p_start.data_ptr(), adj.data_ptr(), st), "mas_stage2_adjacency")
+            _lib.check(lib.mas_stage2_propagate(f.data_ptr(), Ch, fh, fw, H, W, sp.data_ptr(), S, adj.data_ptr(), p_start.data_ptr(),
+                                                p_cls.data_ptr(), P.data_ptr(), thr.data_ptr(), nn.data_ptr(), out[i].data_ptr(), st),
+                       "mas_stage2_propagate")
+    return out

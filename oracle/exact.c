@@ -362,3 +362,124 @@ void exact_region_finalize_weighted(const uint64_t* class_sum, const uint32_t* h
         if (count) count[r] = (uint32_t)n;
     }
 }
+
+/* =============================================================================================
+ * Stage-2 cosine pseudo labels with one-ring propagation (csrc/stage2.hip)
+ * trainer/eval_save_cosplbl_prop.py:121-314 and ..._includeonehot.py
+ * ============================================================================================= */
+
+/* feature k of output pixel (y, x): the feature map is [Ch, fh, fw]; when (fh, fw) != (H, W) it is upsampled
+ * bilinearly with align_corners=False exactly as F.interpolate does in feat_forward (models/segmentation/utils.py:28-34):
+ * src = scale*(dst+0.5)-0.5 clamped at 0, lambda = src - floor(src), value = l0h*(l0w*v00 + l1w*v01) + l1h*(l0w*v10 + l1w*v11). */
+static float stage2_feat(const float* f, int k, int fh, int fw, int H, int W, int y, int x) {
+    const float* p = f + (size_t)k * fh * fw;
+    if (fh == H && fw == W) return p[(size_t)y * W + x];
+    const float sh = (float)fh / (float)H, sw = (float)fw / (float)W;
+    float sy = sh * ((float)y + 0.5f) - 0.5f; if (sy < 0.0f) sy = 0.0f;
+    float sx = sw * ((float)x + 0.5f) - 0.5f; if (sx < 0.0f) sx = 0.0f;
+    const int y0 = (int)sy, x0 = (int)sx;
+    const int y1 = y0 + (y0 < fh - 1 ? 1 : 0), x1 = x0 + (x0 < fw - 1 ? 1 : 0);
+    const float l1h = sy - (float)y0, l0h = 1.0f - l1h, l1w = sx - (float)x0, l0w = 1.0f - l1w;
+    return l0h * (l0w * p[(size_t)y0 * fw + x0] + l1w * p[(size_t)y0 * fw + x1]) +
+           l1h * (l0w * p[(size_t)y1 * fw + x0] + l1w * p[(size_t)y1 * fw + x1]);
+}
+
+static int cmp_float(const void* a, const void* b) {
+    const float x = *(const float*)a, y = *(const float*)b;
+    return (x > y) - (x < y);
+}
+
+/* One image.  gmax [S,C] comes from exact_partial_loss_fwd(flags = GROUP [| ONLY_MULTI], invT = 1): packed
+ * (softmax prob bits << 32 | ~arg pixel).  out [H*W] int32, 255 = no label.  Returns the number of prototypes. */
+int exact_stage2_plbl(const float* feat, int Ch, int fh, int fw, int H, int W, const int64_t* spx, const uint8_t* mask,
+                      const uint64_t* gmax, int S, int C, int32_t* out) {
+    const size_t HW = (size_t)H * W;
+    int s, c, j, k;
+    size_t i;
+    /* prototypes ordered by (superpixel, class) */
+    int n_proto = 0;
+    for (s = 0; s < S; ++s) for (c = 0; c < C; ++c) if (gmax[(size_t)s * C + c]) n_proto++;
+    int* p_start = (int*)calloc(S + 1, sizeof(int));
+    int* p_cls = (int*)malloc(sizeof(int) * (n_proto + 1));
+    float* P = (float*)malloc(sizeof(float) * (size_t)(n_proto + 1) * Ch);
+    j = 0;
+    for (s = 0; s < S; ++s) {
+        p_start[s] = j;
+        for (c = 0; c < C; ++c) {
+            const uint64_t w = gmax[(size_t)s * C + c];
+            if (!w) continue;
+            const uint32_t pix = 0xffffffffu - (uint32_t)w;
+            for (k = 0; k < Ch; ++k) P[(size_t)j * Ch + k] = stage2_feat(feat, k, fh, fw, H, W, (int)(pix / W), (int)(pix % W));
+            p_cls[j++] = c;
+        }
+    }
+    p_start[S] = j;
+    /* nearest prototype of the own superpixel for every valid pixel */
+    int32_t* nn = (int32_t*)malloc(sizeof(int32_t) * HW);
+    float* nn_sim = (float*)malloc(sizeof(float) * HW);
+    float* fx = (float*)malloc(sizeof(float) * Ch);
+    for (i = 0; i < HW; ++i) {
+        nn[i] = -1;
+        out[i] = 255;
+        if (!mask[i]) continue;
+        const int64_t id = spx[i];
+        if (id < 0 || id >= S || p_start[id + 1] == p_start[id]) continue;
+        for (k = 0; k < Ch; ++k) fx[k] = stage2_feat(feat, k, fh, fw, H, W, (int)(i / W), (int)(i % W));
+        float best = 0.0f;
+        for (j = p_start[id]; j < p_start[id + 1]; ++j) {
+            float acc = 0.0f;
+            for (k = 0; k < Ch; ++k) acc = mas_fmaf(P[(size_t)j * Ch + k], fx[k], acc);
+            if (nn[i] < 0 || acc > best) { best = acc; nn[i] = j; }       /* first maximum wins */
+        }
+        nn_sim[i] = best;
+    }
+    /* per prototype: lower median of the similarities of its pixels, 1.0 when it has none */
+    float* thr = (float*)malloc(sizeof(float) * (n_proto + 1));
+    float* buf = (float*)malloc(sizeof(float) * HW);
+    for (j = 0; j < n_proto; ++j) {
+        size_t n = 0;
+        for (i = 0; i < HW; ++i) if (nn[i] == j) buf[n++] = nn_sim[i];
+        if (n) { qsort(buf, n, sizeof(float), cmp_float); thr[j] = buf[(n - 1) / 2]; }
+        else thr[j] = 1.0f;
+    }
+    /* ring[t] = valid superpixels within Chebyshev distance 1 of a pixel of t (3x3 dilation, symmetric) */
+    const int words = (S + 31) / 32;
+    uint32_t* adj = (uint32_t*)calloc((size_t)S * words, sizeof(uint32_t));
+    for (i = 0; i < HW; ++i) {
+        const int64_t t = spx[i];
+        if (t < 0 || t >= S) continue;
+        const int y = (int)(i / W), x = (int)(i % W);
+        int dy, dx;
+        for (dy = -1; dy <= 1; ++dy) for (dx = -1; dx <= 1; ++dx) {
+            const int yy = y + dy, xx = x + dx;
+            if (yy < 0 || yy >= H || xx < 0 || xx >= W) continue;
+            const int64_t g = spx[(size_t)yy * W + xx];
+            if (g < 0 || g >= S || p_start[g + 1] == p_start[g]) continue;
+            adj[(size_t)t * words + (g >> 5)] |= 1u << (g & 31);
+        }
+    }
+    /* propagation in ascending superpixel id: the last valid neighbour that accepts the pixel wins */
+    for (i = 0; i < HW; ++i) {
+        const int64_t t = spx[i];
+        int label = 255, have = 0;
+        if (t >= 0 && t < S) {
+            for (s = 0; s < S; ++s) {
+                if (!((adj[(size_t)t * words + (s >> 5)] >> (s & 31)) & 1u)) continue;
+                if (!have) { for (k = 0; k < Ch; ++k) fx[k] = stage2_feat(feat, k, fh, fw, H, W, (int)(i / W), (int)(i % W)); have = 1; }
+                float best = 0.0f;
+                int arg = -1, ok = 0;
+                for (j = p_start[s]; j < p_start[s + 1]; ++j) {
+                    float acc = 0.0f;
+                    for (k = 0; k < Ch; ++k) acc = mas_fmaf(P[(size_t)j * Ch + k], fx[k], acc);
+                    if (arg < 0 || acc > best) { best = acc; arg = j; }
+                    if (thr[j] < acc) ok = 1;
+                }
+                if (ok) label = p_cls[arg];
+            }
+        }
+        if (nn[i] >= 0) label = p_cls[nn[i]];
+        out[i] = label;
+    }
+    free(p_start); free(p_cls); free(P); free(nn); free(nn_sim); free(fx); free(thr); free(buf); free(adj);
+    return n_proto;
+}

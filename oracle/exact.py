@@ -202,3 +202,25 @@ def region_finalize_weighted(class_sum, hist, w31, ban_class):
     lib().exact_region_finalize_weighted(_p(class_sum), _p(hist), ctypes.c_int64(n), C, _p(w31), ban_class,
                                          _p(score), _p(dom), _p(cnt))
     return score, dom, cnt
+
+
+# ------------------------------------------------------------------------------------------------
+# stage-2 cosine pseudo labels
+# ------------------------------------------------------------------------------------------------
+def stage2_pseudo_labels(feats, logits, targets, spmasks, superpixels, include_onehot, out_hw=None):
+    """feats [N,Ch,fh,fw] (full or lower resolution), logits [N,C,H,W] -> int32 [N,H,W] (255 = none)."""
+    feats = _c(feats, np.float32)
+    logits = _c(logits, np.float32)
+    spx = _c(superpixels, np.int64)
+    mask = _c(spmasks, np.uint8)
+    N, C, H, W = logits.shape
+    Ch, fh, fw = feats.shape[1:]
+    S = targets.shape[1]
+    bits = target_bits(targets)
+    flags = LOSS_GROUP | (0 if include_onehot else LOSS_GROUP_ONLY_MULTI)
+    out = np.zeros((N, H, W), dtype=np.int32)
+    for i in range(N):
+        _, gmax, _ = partial_loss_fwd(logits[i:i + 1], spx[i:i + 1], mask[i:i + 1], bits[i:i + 1], np.float32(1.0), flags)
+        g = _c(gmax[0], np.uint64)
+        lib().exact_stage2_plbl(_p(feats[i]), Ch, fh, fw, H, W, _p(spx[i]), _p(mask[i]), _p(g), S, C, _p(out[i]))
+    return out

@@ -224,6 +224,46 @@ def gen_g7():
     print("g7: ok")
 
 
+def stage2_inputs(seed, N, C, Ch, H, W, S):
+    """Stage-2 inputs: L2-normalised features [N,Ch,H,W] (as feat_forward yields them before upsampling), logits,
+    multi-hot targets, superpixel map, selected mask (a few whole superpixels, one-hot and multi-hot)."""
+    rs = np.random.RandomState(seed)
+    cm = np.stack([synth.class_map(seed * 3 + i, H, W, C, blob=10) for i in range(N)])
+    proto = rs.standard_normal((C, Ch)).astype(np.float32)
+    feats = proto[cm].transpose(0, 3, 1, 2) + 0.6 * rs.standard_normal((N, Ch, H, W)).astype(np.float32)
+    feats = (feats / np.linalg.norm(feats, axis=1, keepdims=True)).astype(np.float32)
+    z = synth.logits(seed + 1, N, C, H, W)
+    spx = np.stack([synth.superpixel_map(seed * 5 + i, H, W, S) for i in range(N)])
+    tgt = np.stack([synth.multi_hot_targets(seed * 7 + i, S, C, p_counts=(0.5, 0.3, 0.15, 0.05)) for i in range(N)])
+    msk = np.zeros((N, H, W), dtype=bool)
+    for i in range(N):
+        chosen = rs.choice(S, size=max(3, S // 6), replace=False)
+        msk[i] = np.isin(spx[i], chosen)
+    msk[N - 1] = False                       # an image with nothing selected
+    labels = rs.randint(0, C - 1, size=(N, H, W)).astype(np.int64)
+    return feats, z, tgt, spx, msk, labels
+
+
+def gen_g6():
+    """Stage-2 cosine pseudo-label propagation (row a-13): trainer/eval_save_cosplbl_prop.py:121-314 and the
+    production variant ..._includeonehot (valid = every selected pixel)."""
+    import importlib
+    torch.Tensor.cuda = lambda self, *a, **k: self          # the reference hard-codes .cuda() at :266
+    seed, N, C, Ch, H, W, S = 61, 3, 20, 16, 40, 56, 36
+    feats, z, tgt, spx, msk, labels = stage2_inputs(seed, N, C, Ch, H, W, S)
+    out = dict(seed=seed, N=N, C=C, Ch=Ch, H=H, W=W, S=S, input_digest=digest(feats, z, tgt, spx, msk))
+    for tag, modname in (('multi', 'trainer.eval_save_cosplbl_prop'), ('all', 'trainer.eval_save_cosplbl_prop_includeonehot')):
+        T = importlib.import_module(modname).ActiveTrainer
+        tr = T.__new__(T)
+        tr.args = types.SimpleNamespace(nseg=S, cosprop_threshold_method='median')
+        tr.kernel = np.ones((3, 3), np.uint8)
+        plbl = tr.pseudo_label_generation(torch.from_numpy(labels), torch.from_numpy(feats), torch.from_numpy(z),
+                                          torch.from_numpy(tgt), torch.from_numpy(msk), torch.from_numpy(spx))
+        out['plbl_' + tag] = plbl.numpy().astype(np.int16)
+        print("g6 %s: labelled %d of %d pixels" % (tag, int((plbl != 255).sum()), plbl.numel()))
+    np.savez_compressed(os.path.join(OUT, "g6_stage2.npz"), **out)
+
+
 def loss_inputs(seed, N, C, H, W, S):
     z = synth.logits(seed, N, C, H, W)
     spx, msk = [], []
@@ -360,6 +400,7 @@ if __name__ == "__main__":
     gen_g3()
     gen_g4()
     gen_g5()
+    gen_g6()
     gen_g7()
     for f in sorted(os.listdir(OUT)):
         print(f, os.path.getsize(os.path.join(OUT, f)))

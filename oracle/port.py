@@ -374,3 +374,76 @@ def ignore_iou_counts(outputs, targets, num_classes, ignore_label):
     correct = torch.sum((targets == ignore_label) & (outputs == num_classes)).item()
     positive = torch.sum(outputs == num_classes).item()
     return seen, correct, positive
+
+
+# ----------------------------------------------------------------------------------------------
+# stage-2: cosine pseudo-label generation with one-ring propagation (K9)
+# ----------------------------------------------------------------------------------------------
+def cosine_pseudo_labels(feats, logits, targets, spmasks, superpixels, nseg, include_onehot, threshold_method='median'):
+    """Pseudo labels from class prototypes inside and one superpixel ring around the labelled regions.
+
+    Follows ``trainer/eval_save_cosplbl_prop.py:121-314`` (``include_onehot=False``: only superpixels with more than
+    one target bit) and ``..._includeonehot.py`` (every selected pixel).  Per image:
+      1. p = softmax(logits) (no temperature, :140); valid pixels = selected (and multi-hot) pixels;
+      2. for every valid superpixel s and class c in Y_s the PROTOTYPE is the feature of the valid pixel of s with
+         the largest p_c (``scatter_max``, first index on ties) (:173-199);
+      3. every valid pixel takes the class of the most similar prototype of ITS OWN superpixel (:203-232, :310-311);
+      4. per prototype the similarity threshold is the (lower) median of the similarities of the pixels assigned to
+         it, 1.0 if none (:234-257);
+      5. each valid superpixel, in ascending id order, labels the pixels of its 3x3-dilation neighbours (itself
+         included) with the class of their most similar prototype wherever some prototype's similarity exceeds that
+         prototype's threshold; later superpixels overwrite earlier ones (:259-306); step 3 is written last.
+    Returns int64 [N,H,W], 255 = no pseudo label."""
+    from scipy import ndimage
+    N, C, H, W = logits.shape
+    Ch = feats.shape[1]
+    out = torch.full((N, H * W), 255, dtype=torch.long)
+    is_multi = 1 < targets.sum(dim=2)
+    for i in range(N):
+        p = F.softmax(logits[i:i + 1], dim=1)[0].permute(1, 2, 0).reshape(-1, C)
+        fe = feats[i].permute(1, 2, 0).reshape(-1, Ch)
+        sp = superpixels[i].reshape(-1)
+        valid = spmasks[i].reshape(-1).clone()
+        if not torch.any(valid):
+            continue
+        if not include_onehot:
+            valid = valid & is_multi[i][sp.clamp(max=nseg - 1)]
+            if not torch.any(valid):
+                continue
+        vpix = valid.nonzero().squeeze(1)
+        vsp = sp[vpix]
+        vp, vf = p[vpix], fe[vpix]
+        _, arg = segment_max(vp, vsp, nseg)                       # [nseg, C] indices into the valid list
+        sp_valid = arg[:, 0] < vp.shape[0]
+        sp_ids = sp_valid.nonzero().squeeze(1)                     # ascending superpixel ids
+        tg = targets[i][sp_valid]
+        proto_g, proto_c = tg.nonzero(as_tuple=True)               # ordered by (superpixel, class)
+        proto_v = arg[sp_valid][proto_g, proto_c]
+        protos = vf[proto_v]
+        sim = torch.mm(protos, vf.T)                               # [n_proto, n_valid]
+        best_sim, best_proto = segment_max(sim, proto_g, int(proto_g.max()) + 1)   # per group, per valid pixel
+        to_group = torch.full((nseg,), -1, dtype=torch.long)
+        to_group[sp_ids] = torch.arange(sp_ids.shape[0])
+        vgroup = to_group[vsp]
+        cols = torch.arange(vgroup.shape[0])
+        nn_proto = best_proto.T[cols, vgroup]
+        nn_sim = best_sim.T[cols, vgroup]
+        # thresholds per prototype
+        thr = torch.ones(protos.shape[0])
+        for k in range(protos.shape[0]):
+            sel = nn_sim[nn_proto == k]
+            if sel.numel():
+                thr[k] = torch.median(sel) if threshold_method == 'median' else torch.min(sel)
+        # one-ring propagation, ascending superpixel id, later overwrites earlier
+        spmap = superpixels[i].numpy()
+        for g, s in enumerate(sp_ids.tolist()):
+            ring = np.unique(spmap[ndimage.binary_dilation(spmap == s, structure=np.ones((3, 3), np.uint8))])
+            around = torch.from_numpy(np.isin(spmap, ring).reshape(-1))
+            mine = proto_g == g
+            s_around = torch.mm(protos[mine], fe[around].T)        # [n_mine, n_around]
+            label = proto_c[mine][s_around.argmax(dim=0)]
+            ok = torch.any(thr[mine][:, None] < s_around, dim=0)
+            pix = around.nonzero().squeeze(1)
+            out[i, pix[ok]] = label[ok]
+        out[i, vpix] = proto_c[nn_proto]
+    return out.reshape(N, H, W)

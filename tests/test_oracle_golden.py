@@ -240,3 +240,38 @@ def test_g7_remaining_selectors_port_matches_reference(tag, ban, bal):
         assert np.array_equal(w.numpy(), g[tag + '_cls_weight'])
     sc, si, sid = tuples_to_arrays(port.score_list(im_idx, suppix, s), im_idx)
     assert np.array_equal(sc, g[tag + '_list_score']) and np.array_equal(sid, g[tag + '_list_id'])
+
+
+def stage2_inputs(seed, N, C, Ch, H, W, S):
+    rs = np.random.RandomState(seed)
+    cm = np.stack([synth.class_map(seed * 3 + i, H, W, C, blob=10) for i in range(N)])
+    proto = rs.standard_normal((C, Ch)).astype(np.float32)
+    feats = proto[cm].transpose(0, 3, 1, 2) + 0.6 * rs.standard_normal((N, Ch, H, W)).astype(np.float32)
+    feats = (feats / np.linalg.norm(feats, axis=1, keepdims=True)).astype(np.float32)
+    z = synth.logits(seed + 1, N, C, H, W)
+    spx = np.stack([synth.superpixel_map(seed * 5 + i, H, W, S) for i in range(N)])
+    tgt = np.stack([synth.multi_hot_targets(seed * 7 + i, S, C, p_counts=(0.5, 0.3, 0.15, 0.05)) for i in range(N)])
+    msk = np.zeros((N, H, W), dtype=bool)
+    for i in range(N):
+        chosen = rs.choice(S, size=max(3, S // 6), replace=False)
+        msk[i] = np.isin(spx[i], chosen)
+    msk[N - 1] = False
+    labels = rs.randint(0, C - 1, size=(N, H, W)).astype(np.int64)
+    return feats, z, tgt, spx, msk, labels
+
+
+def g6_inputs(g):
+    feats, z, tgt, spx, msk, labels = stage2_inputs(int(g['seed']), int(g['N']), int(g['C']), int(g['Ch']), int(g['H']),
+                                                    int(g['W']), int(g['S']))
+    assert digest(feats, z, tgt, spx, msk) == g['input_digest']
+    return feats, z, tgt, spx, msk
+
+
+@pytest.mark.parametrize("tag,include", [('multi', False), ('all', True)])
+def test_g6_stage2_port_matches_reference(tag, include):
+    g = np.load(os.path.join(GOLDEN, "g6_stage2.npz"))
+    feats, z, tgt, spx, msk = g6_inputs(g)
+    out = port.cosine_pseudo_labels(torch.from_numpy(feats), torch.from_numpy(z), torch.from_numpy(tgt), torch.from_numpy(msk),
+                                    torch.from_numpy(spx), int(g['S']), include)
+    assert np.array_equal(out.numpy().astype(np.int16), g['plbl_' + tag])
+    assert int((out[-1] != 255).sum()) == 0              # nothing selected -> nothing labelled

@@ -1,0 +1,69 @@
+"""K9 stage-2 pseudo labels on the GPU: labels identical to the executed reference (g6) and to the C oracle, on
+full-resolution features and on quarter-resolution features interpolated in-kernel."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from test_oracle_golden import GOLDEN, g6_inputs, stage2_inputs
+
+pytestmark = pytest.mark.gpu
+
+
+def _gpu():
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from mulactseg_amd import ops
+    return ops
+
+
+def _run(ops, feats, z, tgt, msk, spx, include):
+    c = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
+    return ops.stage2_pseudo_labels(c(feats), c(z), c(tgt), c(msk), c(spx), include).cpu().numpy()
+
+
+@pytest.mark.parametrize("tag,include", [('multi', False), ('all', True)])
+def test_matches_executed_reference_and_oracle(tag, include):
+    ops = _gpu()
+    from oracle import exact
+    g = np.load(os.path.join(GOLDEN, "g6_stage2.npz"))
+    feats, z, tgt, spx, msk = g6_inputs(g)
+    out = _run(ops, feats, z, tgt, msk, spx, include)
+    assert np.array_equal(out.astype(np.int16), g['plbl_' + tag])                 # index output: bit-exact vs reference
+    assert np.array_equal(out, exact.stage2_pseudo_labels(feats, z, tgt, msk, spx, include))
+
+
+@pytest.mark.parametrize("include", [False, True])
+def test_quarter_resolution_features_interpolated_in_kernel(include):
+    """Production form: 256-channel quarter-resolution features; the oracle interpolates with the same arithmetic, and
+    feeding the kernels a torch-upsampled full-resolution tensor gives the same labels except where the two
+    interpolation roundings decide a near-tie (none on this input)."""
+    ops = _gpu()
+    from oracle import exact
+    N, C, Ch, H, W, S = 2, 20, 32, 64, 96, 48
+    feats_full, z, tgt, spx, msk, _ = stage2_inputs(71, N, C, Ch, H, W, S)
+    q = torch.nn.functional.avg_pool2d(torch.from_numpy(feats_full), 4)
+    q = torch.nn.functional.normalize(q).numpy()                                    # [N,Ch,H/4,W/4], L2-normalised
+    out = _run(ops, q, z, tgt, msk, spx, include)
+    assert np.array_equal(out, exact.stage2_pseudo_labels(q, z, tgt, msk, spx, include))
+    up = torch.nn.functional.interpolate(torch.from_numpy(q), size=(H, W), mode='bilinear', align_corners=False).numpy()
+    out_up = _run(ops, up, z, tgt, msk, spx, include)
+    assert (out != out_up).mean() < 1e-3
+    assert (out != 255).sum() > 0 and (out[-1] != 255).sum() == 0
+
+
+def test_labels_only_inside_one_ring_of_selected_superpixels():
+    """Size-independent property at Cityscapes-like scale (nseg 2048): every labelled pixel belongs to a selected
+    superpixel or to a superpixel touching one; selected pixels are always labelled with one of their target classes."""
+    ops = _gpu()
+    from scipy import ndimage
+    N, C, Ch, H, W, S = 1, 20, 64, 256, 512, 512
+    feats, z, tgt, spx, msk, _ = stage2_inputs(73, N + 1, C, Ch, H, W, S)
+    feats, z, tgt, spx, msk = feats[:1], z[:1], tgt[:1], spx[:1], msk[:1]
+    out = _run(ops, feats, z, tgt, msk, spx, True)[0]
+    sel_ids = np.unique(spx[0][msk[0]])
+    ring = np.unique(spx[0][ndimage.binary_dilation(np.isin(spx[0], sel_ids), structure=np.ones((3, 3)))])
+    assert np.all(np.isin(spx[0][out != 255], ring))
+    assert np.all(out[msk[0]] != 255)
+    assert np.all(tgt[0][spx[0][msk[0]], out[msk[0]]] == 1)

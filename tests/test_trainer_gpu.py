@@ -127,3 +127,56 @@ def test_imagenet_checkpoint_loads_without_classifier():
     torch.save({'model_state_dict': src.state_dict()}, fname)
     tr.load_checkpoint(fname)
     assert torch.equal(tr.net.backbone.conv1[0].weight.cpu(), src.backbone.conv1[0].weight)
+
+
+class SynthLabelled(torch.utils.data.Dataset):
+    """What the stage-2 loader yields per labelled image: image, GT labels, spx, spmask, multi-hot target, fnames."""
+
+    def __init__(self, n):
+        self.im_idx = [["img/%03d.png" % i, "gt/lbl_%03d.png" % i, "spx/%03d.pkl" % i] for i in reversed(range(n))]
+
+    def __len__(self):
+        return len(self.im_idx)
+
+    def __getitem__(self, i):
+        k = int(self.im_idx[i][0][4:7])
+        rs = np.random.RandomState(500 + k)
+        spx = synth.superpixel_map(600 + k, H, W, S)
+        sel = rs.choice(S, size=8, replace=False)
+        lab = rs.randint(0, N_CLS, size=(H, W)).astype(np.int64)
+        return {'images': torch.from_numpy(rs.standard_normal((3, H, W)).astype(np.float32)), 'labels': torch.from_numpy(lab),
+                'spx': torch.from_numpy(spx), 'spmask': torch.from_numpy(np.isin(spx, sel)),
+                'target': torch.from_numpy(synth.multi_hot_targets(700 + k, S, N_CLS + 1)), 'fnames': self.im_idx[i]}
+
+
+def test_stage2_generator_plugin_writes_pseudo_labels():
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from PIL import Image
+    from mulactseg_amd import dataloader, ops
+    from mulactseg_amd.trainer import eval_save_cosplbl_prop_includeonehot as T
+    tmp = tempfile.mkdtemp()
+    a = _args(tmp)
+    a.val_batch_size = 1
+    a.init_checkpoint = os.path.join(tmp, 'checkpoint02.tar')
+    a.plbl_type = None
+    dataloader.register_dataset_factory(lambda *x, **k: SynthVal())
+    torch.manual_seed(0)
+    tr = T.ActiveTrainer(a, logging.getLogger("test"), 2)
+    labelled = SynthLabelled(3)
+    active = types.SimpleNamespace(trg_label_dataset=labelled, selection_iter=2)
+    table = tr.eval(active, 2)
+    assert len(table.split(',')) == 1 + N_CLS + 1
+    out_dir = os.path.join(tmp, 'plbl_gen', 'round_02')
+    files = sorted(os.listdir(out_dir))
+    assert files == ['lbl_000.png', 'lbl_001.png', 'lbl_002.png']          # eval sorts im_idx (eval_within_multihot.py:34)
+    # the PNG equals the kernel output on the same features
+    item = labelled[[k[1] for k in labelled.im_idx].index('gt/lbl_001.png')]
+    tr.net.eval()
+    with torch.no_grad():
+        feats, logits = tr.net.feat_forward_lowres(item['images'][None].cuda())
+        want = ops.stage2_pseudo_labels(feats.contiguous(), logits.contiguous(), item['target'][None].cuda(),
+                                        item['spmask'][None].cuda(), item['spx'][None].cuda(), True)[0].cpu().numpy()
+    got = np.array(Image.open(os.path.join(out_dir, 'lbl_001.png')))
+    assert got.dtype == np.uint8 and np.array_equal(got, want.astype(np.uint8))
+    assert np.all(got[item['spmask'].numpy()] != 255)
