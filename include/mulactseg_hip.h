@@ -256,6 +256,20 @@ int mas_stage2_propagate(const float* feat, int Ch, int fh, int fw, int H, int W
                          const int32_t* proto_start, const int32_t* proto_cls, const float* P, const float* thr,
                          const int32_t* nn_proto, int64_t* out, void* stream);
 
+/* =============================================================================================
+ * K7  ASPP: the three dilated depthwise 3x3 convolutions from one read of the feature map
+ * (models/segmentation/deeplabv3.py:168-201,216-245 after convert_to_separable_conv :249-261; dilations 6/12/18 at
+ * output stride 16).  x, y_d, dy_d, dx are [N,C,H,W] f32 contiguous; w_d, dw_d are [C,1,3,3]; zero padding = dilation,
+ * stride 1, no bias.  The pointwise 1x1 convolutions that follow stay GEMMs (MFMA).
+ * ============================================================================================= */
+int mas_aspp_dw3_fwd(const float* x, const float* w0, const float* w1, const float* w2, int N, int C, int H, int W,
+                     int d0, int d1, int d2, float* y0, float* y1, float* y2, void* stream);
+int mas_aspp_dw3_bwd_x(const float* dy0, const float* dy1, const float* dy2, const float* w0, const float* w1, const float* w2,
+                       int N, int C, int H, int W, int d0, int d1, int d2, float* dx, void* stream);
+/* deterministic (fixed reduction order): one workgroup per channel */
+int mas_aspp_dw3_bwd_w(const float* x, const float* dy0, const float* dy1, const float* dy2, int N, int C, int H, int W,
+                       int d0, int d1, int d2, float* dw0, float* dw1, float* dw2, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -145,8 +145,28 @@ class ASPP(nn.Module):
         self.project = nn.Sequential(nn.Conv2d(5 * cout, cout, 1, bias=False), nn.BatchNorm2d(cout), nn.ReLU(inplace=True),
                                      nn.Dropout(0.1))
 
+    def _fused_depthwise(self, x):
+        """K7: the three dilated depthwise convolutions from ONE read of x (csrc/aspp.hip) when the branches are
+        separable and x lives on the GPU; parameters and state-dict layout are untouched."""
+        seps = [self.convs[i][0] for i in (1, 2, 3)]
+        if not (x.is_cuda and x.dtype == torch.float32 and all(isinstance(m, AtrousSeparableConvolution) for m in seps)):
+            return None
+        dws = [m.body[0] for m in seps]
+        if any(d.kernel_size != (3, 3) or d.stride != (1, 1) or d.padding != d.dilation or d.groups != x.shape[1] for d in dws):
+            return None
+        from .. import ops
+        return ops.aspp_depthwise3(x, dws[0].weight, dws[1].weight, dws[2].weight, [d.dilation[0] for d in dws])
+
     def forward(self, x):
-        return self.project(torch.cat([conv(x) for conv in self.convs], dim=1))
+        fused = self._fused_depthwise(x)
+        if fused is None:                          # CPU reference form (parity tests), or a non-separable head
+            return self.project(torch.cat([conv(x) for conv in self.convs], dim=1))
+        outs = [self.convs[0](x)]
+        for i, y in zip((1, 2, 3), fused):
+            branch = self.convs[i]
+            outs.append(branch[2](branch[1](branch[0].body[1](y))))      # pointwise 1x1 -> BN -> ReLU
+        outs.append(self.convs[4](x))
+        return self.project(torch.cat(outs, dim=1))
 
 
 class DeepLabHeadV3PlusWN(nn.Module):

@@ -423,3 +423,53 @@ def stage2_pseudo_labels(feats, logits, targets, spmasks, superpixels, include_o
                                                 p_cls.data_ptr(), P.data_ptr(), thr.data_ptr(), nn.data_ptr(), out[i].data_ptr(), st),
                        "mas_stage2_propagate")
     return out
+
+
+# ------------------------------------------------------------------------------------------------
+# K7: ASPP depthwise triple
+# ------------------------------------------------------------------------------------------------
+class _AsppDepthwise3(torch.autograd.Function):
+    """(y6, y12, y18) = three dilated depthwise 3x3 convolutions of the same map, one read of x
+    (models/segmentation/deeplabv3.py:174-177 x 3 branches)."""
+
+    @staticmethod
+    def forward(ctx, x, w0, w1, w2, d0, d1, d2):
+        x = x.contiguous()
+        w0, w1, w2 = w0.contiguous(), w1.contiguous(), w2.contiguous()
+        N, C, H, W = x.shape
+        ys = [torch.empty_like(x) for _ in range(3)]
+        with torch.cuda.device(x.device):
+            _lib.check(_lib.load().mas_aspp_dw3_fwd(x.data_ptr(), w0.data_ptr(), w1.data_ptr(), w2.data_ptr(), N, C, H, W, d0, d1, d2,
+                                                    ys[0].data_ptr(), ys[1].data_ptr(), ys[2].data_ptr(), _stream(x)), "mas_aspp_dw3_fwd")
+        ctx.save_for_backward(x, w0, w1, w2)
+        ctx.dil = (d0, d1, d2)
+        return tuple(ys)
+
+    @staticmethod
+    def backward(ctx, g0, g1, g2):
+        x, w0, w1, w2 = ctx.saved_tensors
+        d0, d1, d2 = ctx.dil
+        N, C, H, W = x.shape
+        g0, g1, g2 = g0.contiguous(), g1.contiguous(), g2.contiguous()
+        lib = _lib.load()
+        dx = dws = None
+        with torch.cuda.device(x.device):
+            st = _stream(x)
+            if ctx.needs_input_grad[0]:
+                dx = torch.empty_like(x)
+                _lib.check(lib.mas_aspp_dw3_bwd_x(g0.data_ptr(), g1.data_ptr(), g2.data_ptr(), w0.data_ptr(), w1.data_ptr(), w2.data_ptr(),
+                                                  N, C, H, W, d0, d1, d2, dx.data_ptr(), st), "mas_aspp_dw3_bwd_x")
+            if any(ctx.needs_input_grad[1:4]):
+                dws = [torch.empty_like(w0), torch.empty_like(w1), torch.empty_like(w2)]
+                _lib.check(lib.mas_aspp_dw3_bwd_w(x.data_ptr(), g0.data_ptr(), g1.data_ptr(), g2.data_ptr(), N, C, H, W, d0, d1, d2,
+                                                  dws[0].data_ptr(), dws[1].data_ptr(), dws[2].data_ptr(), st), "mas_aspp_dw3_bwd_w")
+        dws = dws or [None, None, None]
+        return dx, dws[0], dws[1], dws[2], None, None, None
+
+
+def aspp_depthwise3(x, w0, w1, w2, dilations):
+    _need(x, "x", torch.float32)
+    for w in (w0, w1, w2):
+        if tuple(w.shape) != (x.shape[1], 1, 3, 3):
+            raise ValueError("depthwise weights must be [C,1,3,3]")
+    return _AsppDepthwise3.apply(x, w0, w1, w2, int(dilations[0]), int(dilations[1]), int(dilations[2]))
