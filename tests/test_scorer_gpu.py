@@ -165,3 +165,41 @@ def test_single_pass_full_resolution_properties():
     perm = torch.tensor([2, 0, 3, 1], device='cuda')
     ps3, cs3, hh3 = ops.single_pass_accum(z[perm].contiguous(), spx[perm].contiguous(), S, invT)
     assert torch.equal(ps3, ps[perm]) and torch.equal(cs3, cs[perm]) and torch.equal(hh3, hh[perm])
+
+
+def test_table_overflow_falls_back_to_global_atomics():
+    """Adversarial id maps: every pixel of a tile carries a different superpixel id (far more ids than LDS table slots),
+    plus a map with a single id -- both paths (LDS table, direct global atomics) must give the oracle's bits."""
+    ops = _gpu()
+    from oracle import exact
+    B, C, H, W = 1, 20, 32, 512
+    S = H * W
+    z = synth.logits(9, B, C, H, W)
+    invT = ops.inv_temperature(0.1)
+    rs = np.random.RandomState(1)
+    for spx in (rs.permutation(S).reshape(B, H, W).astype(np.int64), np.zeros((B, H, W), dtype=np.int64),
+                rs.randint(0, 300, size=(B, H, W)).astype(np.int64)):
+        zt, st = torch.from_numpy(z).cuda(), torch.from_numpy(spx).cuda()
+        es, eh = exact.bvsb_region_accum(z, spx, None, S, np.float32(invT))
+        gs, gh = ops.bvsb_region_accum(zt, st, None, S, invT)
+        assert np.array_equal(gs.cpu().numpy().view(np.uint64), es) and np.array_equal(gh.cpu().numpy().view(np.uint32), eh)
+        eps_, ecs, eh2 = exact.single_pass_accum(z, spx, S, np.float32(invT))
+        ps, cs, hh = ops.single_pass_accum(zt, st, S, invT)
+        assert np.array_equal(ps.cpu().numpy().view(np.uint64), eps_)
+        assert np.array_equal(cs.cpu().numpy().view(np.uint64), ecs) and np.array_equal(hh.cpu().numpy().view(np.uint32), eh2)
+
+
+def test_extreme_logits_stay_finite_and_exact():
+    """Large-magnitude logits (|z|/T up to 500): the clamped exp keeps every probability finite; bits still match."""
+    ops = _gpu()
+    from oracle import exact
+    B, C, H, W, S = 1, 20, 16, 256, 8
+    z, spx = _case(77, B, C, H, W, S)
+    z = (z * 30.0).astype(np.float32)
+    invT = ops.inv_temperature(0.1)
+    zt, st = torch.from_numpy(z).cuda(), torch.from_numpy(spx).cuda()
+    eps_, ecs, eh = exact.single_pass_accum(z, spx, S, np.float32(invT))
+    ps, cs, hh = ops.single_pass_accum(zt, st, S, invT)
+    assert np.array_equal(ps.cpu().numpy().view(np.uint64), eps_) and np.array_equal(cs.cpu().numpy().view(np.uint64), ecs)
+    tot = ps.cpu().numpy().view(np.uint64).sum(axis=1).astype(np.float64) / 2.0 ** 23 / (H * W)
+    assert np.all(np.abs(tot - 1.0) < 1e-5)
