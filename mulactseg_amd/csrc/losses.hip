@@ -20,7 +20,7 @@ namespace {
 
 constexpr int kThreads = 256;
 constexpr int kTileW = 256;
-constexpr int kTileH = 16;
+constexpr int kTileH = 4;
 constexpr int kLogSlots = 6;
 constexpr int kSlots = 1 << kLogSlots;
 
@@ -55,6 +55,65 @@ __global__ __launch_bounds__(kThreads) void k_target_bits(const unsigned char* _
     bits[r] = b;
 }
 
+// Selected pixels are sparse (a few % of a crop, whole superpixels at a time).  Both scans therefore run in two phases
+// per 16x256 tile: (1) every lane looks at the mask bytes of its pixels and the selected ones are COMPACTED into an LDS
+// queue (wave ballot + one LDS counter add per wave); (2) the queue is processed densely, one selected pixel per lane, so
+// the softmax / log arithmetic runs with all 64 lanes busy instead of whole waves executing it for a handful of lanes.
+// Only the logits of selected pixels are ever loaded.  Sums are integers and the group table is a max, so the
+// (non-deterministic) queue order cannot change any result.
+constexpr int kTilePx = kTileW * kTileH;
+
+__device__ __forceinline__ void queue_push(bool sel, unsigned short off, unsigned short* queue, int* qcount) {
+    const unsigned long long bal = __ballot(sel);
+    if (bal == 0) return;
+    const int lane = threadIdx.x & (MAS_WAVE - 1);
+    int base = 0;
+    if (lane == 0) base = atomicAdd(qcount, (int)__popcll(bal));
+    base = __shfl(base, 0, MAS_WAVE);
+    if (sel) queue[base + (int)__popcll(bal & ((1ull << lane) - 1ull))] = off;
+}
+
+// phase 1 of both scans: compact the selected pixels of this tile; BWD additionally zero-fills dz for the whole tile
+template <int CT, bool EXACT, bool VEC, bool BWD>
+__device__ __forceinline__ void tile_compact(const unsigned char* __restrict__ mb, int C, int H, int W, int HW, int tx, int ty,
+                                             unsigned short* queue, int* qcount, float* __restrict__ db) {
+    const int lane = threadIdx.x & (MAS_WAVE - 1);
+    const int wave = threadIdx.x / MAS_WAVE;
+    for (int it = 0; it < kTileH / 4; ++it) {
+        const int ry = it * 4 + wave;
+        const int y = ty * kTileH + ry;
+        if (y >= H) break;
+        const size_t row = (size_t)y * W;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int rx = VEC ? (lane * 4 + k) : (k * MAS_WAVE + lane);
+            const int x = tx * kTileW + rx;
+            const bool sel = (x < W) && (mb[row + (x < W ? x : 0)] != 0);
+            queue_push(sel, (unsigned short)((ry << 8) | rx), queue, qcount);
+        }
+        if (BWD) {
+            if (VEC) {
+                const int x = tx * kTileW + lane * 4;
+                if (x < W) {
+#pragma unroll
+                    for (int c = 0; c < CT; ++c)
+                        if (EXACT || c < C) *reinterpret_cast<float4*>(db + (size_t)c * HW + row + x) = make_float4(0.f, 0.f, 0.f, 0.f);
+                }
+            } else {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const int x = tx * kTileW + k * MAS_WAVE + lane;
+                    if (x < W) {
+#pragma unroll
+                        for (int c = 0; c < CT; ++c)
+                            if (EXACT || c < C) db[(size_t)c * HW + row + x] = 0.0f;
+                    }
+                }
+            }
+        }
+    }
+}
+
 template <int CT, bool EXACT, typename IdT, bool VEC>
 __global__ __launch_bounds__(kThreads) void k_partial_loss_fwd(const float* __restrict__ z, const IdT* __restrict__ spx,
                                                                 const unsigned char* __restrict__ mask,
@@ -65,15 +124,18 @@ __global__ __launch_bounds__(kThreads) void k_partial_loss_fwd(const float* __re
     mas_u64* t_max = reinterpret_cast<mas_u64*>(smem);                       // [kSlots * C]
     int* t_keys = reinterpret_cast<int*>(smem + sizeof(mas_u64) * kSlots * C);  // [kSlots]
     mas_u64* s_red = reinterpret_cast<mas_u64*>(smem + sizeof(mas_u64) * kSlots * C + sizeof(int) * kSlots);  // [4][5]
+    int* qcount = reinterpret_cast<int*>(s_red + 4 * 5);
+    unsigned short* queue = reinterpret_cast<unsigned short*>(qcount + 2);     // [kTilePx]
 
     const bool do_ce = flags & MAS_LOSS_CE;
     const bool do_group = flags & MAS_LOSS_GROUP;
     const bool only_multi = flags & MAS_LOSS_GROUP_ONLY_MULTI;
+    if (threadIdx.x == 0) *qcount = 0;
     if (do_group) {
         for (int i = threadIdx.x; i < kSlots; i += kThreads) t_keys[i] = -1;
         for (int i = threadIdx.x; i < kSlots * C; i += kThreads) t_max[i] = 0;
-        __syncthreads();
     }
+    __syncthreads();
 
     int bid = blockIdx.x;
     const int tx = bid % tiles_x; bid /= tiles_x;
@@ -88,67 +150,45 @@ __global__ __launch_bounds__(kThreads) void k_partial_loss_fwd(const float* __re
     const int lane = threadIdx.x & (MAS_WAVE - 1);
     const int wave = threadIdx.x / MAS_WAVE;
 
+    tile_compact<CT, EXACT, VEC, false>(mb, C, H, W, HW, tx, ty, queue, qcount, nullptr);
+    __syncthreads();
+    const int nq = *qcount;
+
     mas_u64 sum_ce = 0, sum_mc = 0;
     unsigned n_ce = 0, n_mc = 0, n_empty = 0;
-
-    for (int it = 0; it < kTileH / 4; ++it) {
-        const int y = ty * kTileH + it * 4 + wave;
-        if (y >= H) break;
-        const size_t row = (size_t)y * W;
-        int xs[4], id[4];
-        bool m[4];
-        bool any = false;
+    for (int i = threadIdx.x; i < nq; i += kThreads) {
+        const unsigned off = queue[i];
+        const size_t pix = (size_t)(ty * kTileH + (int)(off >> 8)) * W + (tx * kTileW + (int)(off & 255u));
+        const int id = mas_load_id(sb, pix);
+        if (id < 0 || id >= S) continue;
+        float v[CT];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            xs[k] = tx * kTileW + (VEC ? (lane * 4 + k) : (k * MAS_WAVE + lane));
-            m[k] = (xs[k] < W) && (mb[row + (xs[k] < W ? xs[k] : 0)] != 0);
-            id[k] = m[k] ? mas_load_id(sb, row + xs[k]) : -1;
-            if (id[k] < 0 || id[k] >= S) m[k] = false;
-            any |= m[k];
+        for (int c = 0; c < CT; ++c) v[c] = (EXACT || c < C) ? zb[(size_t)c * HW + pix] : 0.f;
+        const unsigned Y = bb[id];
+        const int nb = __popc(Y);
+        if (nb == 0) { n_empty += 1; continue; }
+        {
+            const float rinv = mas_softmax_regs<CT, EXACT>(v, C, invT);
+#pragma unroll
+            for (int c = 0; c < CT; ++c) v[c] = v[c] * rinv;
         }
-        if (!__any(any)) continue;       // wave-uniform: nothing selected here, no logit traffic at all
-        float v[4][CT];
+        if (do_ce) {
+            float pos = 0.0f;
 #pragma unroll
-        for (int c = 0; c < CT; ++c) {
-            if (VEC) {
-                float4 q = make_float4(0.f, 0.f, 0.f, 0.f);
-                if ((EXACT || c < C) && any) q = *reinterpret_cast<const float4*>(zb + (size_t)c * HW + row + xs[0]);
-                v[0][c] = q.x; v[1][c] = q.y; v[2][c] = q.z; v[3][c] = q.w;
-            } else {
-#pragma unroll
-                for (int k = 0; k < 4; ++k) v[k][c] = ((EXACT || c < C) && m[k]) ? zb[(size_t)c * HW + row + xs[k]] : 0.f;
-            }
+            for (int c = 0; c < CT; ++c)
+                if (EXACT || c < C) pos = ((Y >> c) & 1u) ? (pos + v[c]) : pos;
+            const float l = -mas_logf(pos + 1e-8f);
+            const mas_u64 q = mas_fix(l, MAS_LOSS_FRAC);
+            if (nb == 1) { sum_ce += q; n_ce += 1; } else { sum_mc += q; n_mc += 1; }
         }
+        if (do_group && (!only_multi || nb > 1)) {
+            const int s = table_slot(t_keys, id);
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            if (!m[k]) continue;
-            {
-                const float rinv = mas_softmax_regs<CT, EXACT>(v[k], C, invT);
-#pragma unroll
-                for (int c = 0; c < CT; ++c) v[k][c] = v[k][c] * rinv;
-            }
-            const unsigned Y = bb[id[k]];
-            const int nb = __popc(Y);
-            if (nb == 0) { n_empty += 1; continue; }
-            if (do_ce) {
-                float pos = 0.0f;
-#pragma unroll
-                for (int c = 0; c < CT; ++c)
-                    if (EXACT || c < C) pos = ((Y >> c) & 1u) ? (pos + v[k][c]) : pos;
-                const float l = -mas_logf(pos + 1e-8f);
-                const mas_u64 q = mas_fix(l, MAS_LOSS_FRAC);
-                if (nb == 1) { sum_ce += q; n_ce += 1; } else { sum_mc += q; n_mc += 1; }
-            }
-            if (do_group && (!only_multi || nb > 1)) {
-                const unsigned pix = (unsigned)(row + xs[k]);
-                const int s = table_slot(t_keys, id[k]);
-#pragma unroll
-                for (int c = 0; c < CT; ++c) {
-                    if ((EXACT || c < C) && ((Y >> c) & 1u)) {
-                        const mas_u64 w = pack_max(v[k][c], pix);
-                        if (s >= 0) atomicMax(&t_max[s * C + c], w);
-                        else atomicMax(&gm[(size_t)id[k] * C + c], w);
-                    }
+            for (int c = 0; c < CT; ++c) {
+                if ((EXACT || c < C) && ((Y >> c) & 1u)) {
+                    const mas_u64 w = pack_max(v[c], (unsigned)pix);
+                    if (s >= 0) atomicMax(&t_max[s * C + c], w);
+                    else atomicMax(&gm[(size_t)id * C + c], w);
                 }
             }
         }
@@ -249,9 +289,13 @@ __global__ __launch_bounds__(kThreads) void k_partial_loss_bwd(const float* __re
                                                                 const float* __restrict__ scale, int C, int H, int W, int S,
                                                                 float invT, int flags, int tiles_x, int tiles_y,
                                                                 float* __restrict__ dz) {
+    __shared__ int qcount[2];
+    __shared__ unsigned short queue[kTilePx];
     const bool do_ce = flags & MAS_LOSS_CE;
     const bool do_group = flags & MAS_LOSS_GROUP;
     const bool only_multi = flags & MAS_LOSS_GROUP_ONLY_MULTI;
+    if (threadIdx.x == 0) qcount[0] = 0;
+    __syncthreads();
     int bid = blockIdx.x;
     const int tx = bid % tiles_x; bid /= tiles_x;
     const int ty = bid % tiles_y;
@@ -263,116 +307,77 @@ __global__ __launch_bounds__(kThreads) void k_partial_loss_bwd(const float* __re
     const unsigned char* mb = mask + (size_t)n * HW;
     const unsigned* bb = bits + (size_t)n * S;
     const mas_u64* gm = gmax + (size_t)n * S * C;
-    const int lane = threadIdx.x & (MAS_WAVE - 1);
-    const int wave = threadIdx.x / MAS_WAVE;
     const float a_ce = scale[0] * invT, a_mc = scale[1] * invT, g6 = scale[2] * invT;
 
-    for (int it = 0; it < kTileH / 4; ++it) {
-        const int y = ty * kTileH + it * 4 + wave;
-        if (y >= H) break;
-        const size_t row = (size_t)y * W;
-        int xs[4], id[4];
-        bool ok[4], m[4];
-        bool any = false;
+    // phase 1: dz = 0 over the whole tile (streaming 16-B stores) while the selected pixels are compacted
+    tile_compact<CT, EXACT, VEC, true>(mb, C, H, W, HW, tx, ty, queue, qcount, db);
+    __syncthreads();        // (waits for this workgroup's zero stores: the gradients below overwrite some of them)
+    const int nq = qcount[0];
+
+    // phase 2: gradients of the selected pixels, one pixel per lane
+    for (int i = threadIdx.x; i < nq; i += kThreads) {
+        const unsigned off = queue[i];
+        const size_t pix = (size_t)(ty * kTileH + (int)(off >> 8)) * W + (tx * kTileW + (int)(off & 255u));
+        const int id = mas_load_id(sb, pix);
+        if (id < 0 || id >= S) continue;
+        const unsigned Y = bb[id];
+        const int nb = __popc(Y);
+        if (nb == 0) continue;
+        float v[CT];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            xs[k] = tx * kTileW + (VEC ? (lane * 4 + k) : (k * MAS_WAVE + lane));
-            ok[k] = xs[k] < W;
-            m[k] = ok[k] && (mb[row + (ok[k] ? xs[k] : 0)] != 0);
-            id[k] = m[k] ? mas_load_id(sb, row + xs[k]) : -1;
-            if (id[k] < 0 || id[k] >= S) m[k] = false;
-            any |= m[k];
+        for (int c = 0; c < CT; ++c) v[c] = (EXACT || c < C) ? zb[(size_t)c * HW + pix] : 0.f;
+        {
+            const float rinv = mas_softmax_regs<CT, EXACT>(v, C, invT);
+#pragma unroll
+            for (int c = 0; c < CT; ++c) v[c] = v[c] * rinv;
         }
-        float v[4][CT];
-        if (__any(any)) {
+        float coef = 0.0f, pos = 0.0f;
+        if (do_ce) {
+#pragma unroll
+            for (int c = 0; c < CT; ++c)
+                if (EXACT || c < C) pos = ((Y >> c) & 1u) ? (pos + v[c]) : pos;
+            coef = ((nb == 1) ? a_ce : a_mc) * (1.0f / (pos + 1e-8f));
+        }
+        // group loss: classes of Y whose arg-max pixel is this pixel
+        unsigned A = 0;
+        float u = 0.0f;
+        float t[CT];
+#pragma unroll
+        for (int c = 0; c < CT; ++c) t[c] = 0.0f;
+        if (do_group && (!only_multi || nb > 1)) {
+            const unsigned key = 0xffffffffu - (unsigned)pix;
 #pragma unroll
             for (int c = 0; c < CT; ++c) {
-                if (VEC) {
-                    float4 q = make_float4(0.f, 0.f, 0.f, 0.f);
-                    if ((EXACT || c < C) && any) q = *reinterpret_cast<const float4*>(zb + (size_t)c * HW + row + xs[0]);
-                    v[0][c] = q.x; v[1][c] = q.y; v[2][c] = q.z; v[3][c] = q.w;
-                } else {
-#pragma unroll
-                    for (int k = 0; k < 4; ++k) v[k][c] = ((EXACT || c < C) && m[k]) ? zb[(size_t)c * HW + row + xs[k]] : 0.f;
-                }
-            }
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                unsigned Y = 0;
-                int nb = 0;
-                if (m[k]) { Y = bb[id[k]]; nb = __popc(Y); }
-                if (!m[k] || nb == 0) {
-#pragma unroll
-                    for (int c = 0; c < CT; ++c) v[k][c] = 0.0f;
-                    continue;
-                }
-                {
-                    const float rinv = mas_softmax_regs<CT, EXACT>(v[k], C, invT);
-#pragma unroll
-                    for (int c = 0; c < CT; ++c) v[k][c] = v[k][c] * rinv;
-                }
-                float coef = 0.0f, pos = 0.0f;
-                if (do_ce) {
-#pragma unroll
-                    for (int c = 0; c < CT; ++c)
-                        if (EXACT || c < C) pos = ((Y >> c) & 1u) ? (pos + v[k][c]) : pos;
-                    coef = ((nb == 1) ? a_ce : a_mc) * (1.0f / (pos + 1e-8f));
-                }
-                // group loss: classes of Y whose arg-max pixel is this pixel
-                unsigned A = 0;
-                float u = 0.0f;
-                float t[CT];
-                if (do_group && (!only_multi || nb > 1)) {
-                    const unsigned key = 0xffffffffu - (unsigned)(row + xs[k]);
-#pragma unroll
-                    for (int c = 0; c < CT; ++c) {
-                        t[c] = 0.0f;
-                        if ((EXACT || c < C) && ((Y >> c) & 1u)) {
-                            const mas_u64 w = gm[(size_t)id[k] * C + c];
-                            if ((unsigned)w == key && (unsigned)(w >> 32) != 0u) {
-                                A |= 1u << c;
-                                t[c] = -(g6 / (v[k][c] + 1e-8f));
-                                u = u + t[c] * v[k][c];
-                            }
-                        }
-                    }
-                }
-#pragma unroll
-                for (int c = 0; c < CT; ++c) {
-                    if (EXACT || c < C) {
-                        const float p = v[k][c];
-                        const float yj = ((Y >> c) & 1u) ? 1.0f : 0.0f;
-                        float d = coef * (p * (pos - yj));
-                        if (A) {
-                            if ((A >> c) & 1u) d = d + t[c] * p;
-                            d = d - p * u;
-                        }
-                        v[k][c] = d;
+                if ((EXACT || c < C) && ((Y >> c) & 1u)) {
+                    const mas_u64 w = gm[(size_t)id * C + c];
+                    if ((unsigned)w == key && (unsigned)(w >> 32) != 0u) {
+                        A |= 1u << c;
+                        t[c] = -(g6 / (v[c] + 1e-8f));
+                        u = u + t[c] * v[c];
                     }
                 }
             }
-        } else {
-#pragma unroll
-            for (int k = 0; k < 4; ++k)
-#pragma unroll
-                for (int c = 0; c < CT; ++c) v[k][c] = 0.0f;
         }
 #pragma unroll
         for (int c = 0; c < CT; ++c) {
             if (EXACT || c < C) {
-                if (VEC) {
-                    if (ok[0]) *reinterpret_cast<float4*>(db + (size_t)c * HW + row + xs[0]) = make_float4(v[0][c], v[1][c], v[2][c], v[3][c]);
-                } else {
-#pragma unroll
-                    for (int k = 0; k < 4; ++k)
-                        if (ok[k]) db[(size_t)c * HW + row + xs[k]] = v[k][c];
+                const float p = v[c];
+                const float yj = ((Y >> c) & 1u) ? 1.0f : 0.0f;
+                float d = coef * (p * (pos - yj));
+                if (A) {
+                    if ((A >> c) & 1u) d = d + t[c] * p;
+                    d = d - p * u;
                 }
+                db[(size_t)c * HW + pix] = d;
             }
         }
     }
 }
 
-inline size_t fwd_smem_bytes(int C) { return sizeof(mas_u64) * kSlots * (size_t)C + sizeof(int) * kSlots + sizeof(mas_u64) * 4 * 5; }
+inline size_t fwd_smem_bytes(int C) {
+    return sizeof(mas_u64) * kSlots * (size_t)C + sizeof(int) * kSlots + sizeof(mas_u64) * 4 * 5 + sizeof(int) * 2 +
+           sizeof(unsigned short) * kTilePx;
+}
 
 struct LossArgs {
     const float* z; const void* spx; const unsigned char* mask; const unsigned* bits;

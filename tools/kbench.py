@@ -64,6 +64,30 @@ def main():
             ops.single_pass_accum(z, spx, S, invT, prob_sum=ps, class_sum=s2, hist=hh)
         med, mn = timeit(f)
         print("fused median %.1f us  min %.1f us  -> %.2f TB/s (%s ids)" % (med, mn, B * (C * H * W * 4 + H * W * idb) / med / 1e6, ids))
+    if 'loss' in which:
+        from mulactseg_amd import synth, _lib
+        N, crop, Sx = 4, 768, 2048
+        frac = 0.09
+        if '--frac' in sys.argv:
+            frac = float(sys.argv[sys.argv.index('--frac') + 1])
+        spx, msk = zip(*[synth.train_crop(50 + i, crop, crop, Sx, frac_selected=frac) for i in range(N)])
+        spx = torch.from_numpy(np.stack(spx)).to(dev)
+        msk = torch.from_numpy(np.stack(msk)).to(dev)
+        tgt = torch.from_numpy(np.stack([synth.multi_hot_targets(70 + i, Sx, C) for i in range(N)])).to(dev)
+        bits = ops.target_bits(tgt)
+        zz = 0.35 * torch.randn((N, C, crop, crop), device=dev)
+        flags = _lib.LOSS_CE | _lib.LOSS_GROUP | _lib.LOSS_GROUP_ONLY_MULTI | _lib.LOSS_DECOMP
+        go = torch.ones(3, device=dev)
+        keep = {}
+        def ffwd():
+            keep['r'] = ops.partial_loss_fwd(zz, spx, msk, bits, invT, flags)
+        med, mn = timeit(ffwd)
+        print("loss fwd (scan+finalize+values) median %.1f us min %.1f us; selected %.3f" % (med, mn, float(msk.float().mean())))
+        losses, acc, gmax = keep['r']
+        def fbwd():
+            ops.partial_loss_bwd(zz, spx, msk, bits, gmax, acc, go, invT, flags)
+        med, mn = timeit(fbwd)
+        print("loss bwd (scales+scan) median %.1f us min %.1f us -> dz write %.2f TB/s" % (med, mn, zz.numel() * 4 / med / 1e6))
 
 
 if __name__ == "__main__":
