@@ -14,6 +14,7 @@
 // With w = 1 the result is bit-identical to the two-pass kernels; with weights it differs from them only by the
 // per-pixel rounding of bvsb*w (~1e-9 relative).  HBM traffic per image: logits + ids once (176 MB instead of 344 MB)
 // and, end to end, ONE model forward per pool image instead of two.
+#include <cstdlib>
 #include "common.h"
 
 namespace {
@@ -207,6 +208,249 @@ __global__ __launch_bounds__(kThreads) void k_single_pass(const float* __restric
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Ring variant (wide, tall images): the same arithmetic, but every wave keeps the NEXT row's loads in flight while it
+// computes the current one.  Bandwidth on this part is (bytes in flight) / (round-trip time) and only the VGPR file is
+// big enough to hold ~300 KB/CU of outstanding loads, so the kernel runs at 2 waves/SIMD with two
+// 84-register row buffers per wave; the class-probability accumulators move to LDS (fire-and-forget ds_add, one
+// private word per thread and class) to pay for the second buffer.  A workgroup streams a 256 x 64 px column strip:
+// the four waves take interleaved rows, 16 rows each, so the pipeline is filled once per 16 rows.
+// ------------------------------------------------------------------------------------------------
+constexpr int kRingTileH = 64;
+constexpr int kRingRows = kRingTileH / 4;      // rows per wave
+
+// raw superpixel ids of four consecutive pixels, loaded with 16-B (8-B for u16) vector loads; every loaded register
+// is consumed by get() -- a dead half would let the allocator recycle a register that still has a load in flight,
+// which costs a vmcnt(0) in the middle of the pipeline
+template <typename IdT> struct IdQuad;
+template <> struct IdQuad<long long> {
+    int4 a, b;
+    __device__ __forceinline__ void load(const long long* p) {
+        a = *reinterpret_cast<const int4*>(p);
+        b = *reinterpret_cast<const int4*>(p + 2);
+    }
+    __device__ __forceinline__ void get(int (&id)[4]) const {     // ids outside int32 are invalid (-1)
+        id[0] = a.y == 0 ? a.x : -1;
+        id[1] = a.w == 0 ? a.z : -1;
+        id[2] = b.y == 0 ? b.x : -1;
+        id[3] = b.w == 0 ? b.z : -1;
+    }
+};
+template <> struct IdQuad<int> {
+    int4 a;
+    __device__ __forceinline__ void load(const int* p) { a = *reinterpret_cast<const int4*>(p); }
+    __device__ __forceinline__ void get(int (&id)[4]) const { id[0] = a.x; id[1] = a.y; id[2] = a.z; id[3] = a.w; }
+};
+template <> struct IdQuad<unsigned short> {
+    uint2 a;
+    __device__ __forceinline__ void load(const unsigned short* p) { a = *reinterpret_cast<const uint2*>(p); }
+    __device__ __forceinline__ void get(int (&id)[4]) const {
+        id[0] = (int)(a.x & 0xffffu); id[1] = (int)(a.x >> 16); id[2] = (int)(a.y & 0xffffu); id[3] = (int)(a.y >> 16);
+    }
+};
+
+template <int CT, typename IdT>
+struct RowRegs {
+    float4 t[CT];
+    IdQuad<IdT> ids;
+};
+
+template <int CT, bool EXACT, typename IdT>
+__device__ __forceinline__ void ring_issue(RowRegs<CT, IdT>& r, const float* __restrict__ zb, const IdT* __restrict__ sb, int C,
+                                           int HW, unsigned off) {
+    r.ids.load(sb + off);
+#pragma unroll
+    for (int c = 0; c < CT; ++c) {
+        if (EXACT || c < C) r.t[c] = *reinterpret_cast<const float4*>(zb + (size_t)c * HW + off);
+        else r.t[c] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+}
+
+// LDS adds carry workgroup scope, the global fallbacks agent scope: with the same scope on both the compiler
+// if-converts "LDS slot or global" into a pointer select and ONE flat_atomic, and a pending FLAT operation forces
+// s_waitcnt vmcnt(0) -- which would drain the prefetched row in the middle of the pipeline.
+template <typename T>
+__device__ __forceinline__ void lds_add(T* p, T v) {
+    (void)__hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+
+template <int CT, bool EXACT, typename IdT>
+__device__ __forceinline__ void ring_consume(RowRegs<CT, IdT>& r, bool ok, int C, int S, float invT, unsigned* s_acc, int* t_keys,
+                                             mas_u64* t_sum, unsigned* t_hist, mas_u64* __restrict__ gsum,
+                                             unsigned* __restrict__ ghist, int& last_id, int& last_slot) {
+    mas_v2f v[2][CT];
+    float b1[4], b2[4];
+    int a1[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { b1[k] = -__builtin_inff(); b2[k] = -__builtin_inff(); a1[k] = 0; }
+#pragma unroll
+    for (int c = 0; c < CT; ++c) {
+        if (EXACT || c < C) {
+            const float4 t = r.t[c];
+            v[0][c] = (mas_v2f){t.x, t.y};
+            v[1][c] = (mas_v2f){t.z, t.w};
+            const float q[4] = {t.x, t.y, t.z, t.w};
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                // with b1 >= b2:  b2' = median(b1, b2, q),  b1' = max(b1, q) = median(b1, q, FLT_MAX): two v_med3_f32
+                // (the same values as the compare/select form for finite logits; ties keep the lowest class index).
+                // FLT_MAX rather than +inf: the compiler folds median(.., +inf) into v_max_f32 and then has to
+                // canonicalise every loaded logit first (one more instruction per element)
+                const bool g1 = q[k] > b1[k];
+                b2[k] = __builtin_amdgcn_fmed3f(b1[k], b2[k], q[k]);
+                a1[k] = g1 ? c : a1[k];
+                b1[k] = __builtin_amdgcn_fmed3f(b1[k], q[k], 3.402823466e+38f);
+            }
+        } else {
+            v[0][c] = mas_splat(0.f);
+            v[1][c] = mas_splat(0.f);
+        }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    {
+        mas_v2f Ra, Rb;
+        mas_softmax_quad<CT, EXACT, true>(v[0], v[1], C, invT, Ra, Rb, (mas_v2f){b1[0], b1[1]}, (mas_v2f){b1[2], b1[3]});
+        Ra = Ra * mas_splat(8388608.0f);
+        Rb = Rb * mas_splat(8388608.0f);
+        Ra = ok ? Ra : mas_splat(0.0f);
+        Rb = ok ? Rb : mas_splat(0.0f);
+#pragma unroll
+        for (int c = 0; c < CT; ++c) {
+            if (EXACT || c < C) {
+                const mas_v2f ta = mas_pk_fma(v[0][c], Ra, mas_splat(8388608.0f));
+                const mas_v2f tb = mas_pk_fma(v[1][c], Rb, mas_splat(8388608.0f));
+                lds_add(&s_acc[c * kThreads + threadIdx.x], (mas_f2u(ta.x) + mas_f2u(ta.y)) + (mas_f2u(tb.x) + mas_f2u(tb.y)));
+            }
+        }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    mas_u64 q[4];
+    int key[4], id[4];
+    r.ids.get(id);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        id[k] = (ok && id[k] >= 0 && id[k] < S) ? id[k] : -1;
+        q[k] = mas_fix(mas_bvsb(b1[k], b2[k], invT), MAS_SCORE_FRAC);
+        key[k] = id[k] < 0 ? -1 : id[k] * MAS_MAX_CLASSES + a1[k];
+    }
+    const bool same = (key[0] == key[1]) && (key[1] == key[2]) && (key[2] == key[3]);
+    if (same) {
+        if (key[0] >= 0) {
+            // a lane walks down a column: most of the time it is still inside the superpixel of its previous row
+            if (id[0] != last_id) {
+                last_slot = table_slot(t_keys, id[0]);
+                last_id = id[0];
+            }
+            const int s = last_slot;
+            const mas_u64 qs = (q[0] + q[1]) + (q[2] + q[3]);
+            if (s >= 0) {
+                lds_add(&t_sum[s * C + a1[0]], qs);
+                lds_add(&t_hist[s * C + a1[0]], 4u);
+            } else {
+                atomicAdd(&gsum[(size_t)id[0] * C + a1[0]], qs);
+                atomicAdd(&ghist[(size_t)id[0] * C + a1[0]], 4u);
+            }
+        }
+    } else {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            if (key[k] < 0) continue;
+            const int s = table_slot(t_keys, id[k]);
+            if (s >= 0) {
+                lds_add(&t_sum[s * C + a1[k]], q[k]);
+                lds_add(&t_hist[s * C + a1[k]], 1u);
+            } else {
+                atomicAdd(&gsum[(size_t)id[k] * C + a1[k]], q[k]);
+                atomicAdd(&ghist[(size_t)id[k] * C + a1[k]], 1u);
+            }
+        }
+    }
+}
+
+template <int CT, bool EXACT, typename IdT>
+__global__ __launch_bounds__(kThreads, 2) void k_single_pass_ring(const float* __restrict__ z, const IdT* __restrict__ spx, int C,
+                                                                   int H, int W, int S, float invT, int tiles_x, int tiles_y,
+                                                                   mas_u64* __restrict__ prob_sum,
+                                                                   mas_u64* __restrict__ class_sum, unsigned* __restrict__ hist) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    mas_u64* t_sum = reinterpret_cast<mas_u64*>(smem);                                        // [kSlots * C]
+    mas_u64* s_part = reinterpret_cast<mas_u64*>(smem + sizeof(mas_u64) * kSlots * C);         // [4][CT]
+    unsigned* t_hist = reinterpret_cast<unsigned*>(smem + sizeof(mas_u64) * (kSlots * C + 4 * CT));   // [kSlots * C]
+    int* t_keys = reinterpret_cast<int*>(smem + sizeof(mas_u64) * (kSlots * C + 4 * CT) + sizeof(unsigned) * kSlots * C);
+    unsigned* s_acc = reinterpret_cast<unsigned*>(t_keys + kSlots);                            // [CT][kThreads]
+
+    for (int i = threadIdx.x; i < kSlots; i += kThreads) t_keys[i] = -1;
+    for (int i = threadIdx.x; i < kSlots * C; i += kThreads) { t_sum[i] = 0; t_hist[i] = 0; }
+#pragma unroll
+    for (int c = 0; c < CT; ++c) s_acc[c * kThreads + threadIdx.x] = 0;
+    __syncthreads();
+
+    int bid = blockIdx.x;
+    const int tx = bid % tiles_x; bid /= tiles_x;
+    const int ty = bid % tiles_y;
+    const int b = bid / tiles_y;
+    const int HW = H * W;
+    const float* zb = z + (size_t)b * C * HW;
+    const IdT* sb = spx + (size_t)b * HW;
+    mas_u64* gsum = class_sum + (size_t)b * S * C;
+    unsigned* ghist = hist + (size_t)b * S * C;
+    const int lane = threadIdx.x & (MAS_WAVE - 1);
+    const int wave = threadIdx.x / MAS_WAVE;
+
+    const int x0 = tx * kTileW + lane * 4;
+    const bool okx = x0 < W;                 // W % 4 == 0: all four pixels in or out
+    const unsigned xc = okx ? (unsigned)x0 : 0u;
+    const int ybase = ty * kRingTileH + wave;
+    // out-of-range rows / columns load a valid address (row H-1 / column 0) and are masked in ring_consume
+    auto off_of = [&](int it) -> unsigned {
+        int y = ybase + it * 4;
+        y = y < H ? y : H - 1;
+        return (unsigned)y * (unsigned)W + xc;
+    };
+    auto ok_of = [&](int it) -> bool { return okx && (ybase + it * 4 < H); };
+
+    RowRegs<CT, IdT> A, B;
+    int last_id = -2, last_slot = -1;
+    ring_issue<CT, EXACT, IdT>(A, zb, sb, C, HW, off_of(0));
+#pragma unroll 1
+    for (int it = 0; it < kRingRows; it += 2) {
+        ring_issue<CT, EXACT, IdT>(B, zb, sb, C, HW, off_of(it + 1));
+        __builtin_amdgcn_sched_barrier(0);
+        ring_consume<CT, EXACT, IdT>(A, ok_of(it), C, S, invT, s_acc, t_keys, t_sum, t_hist, gsum, ghist, last_id, last_slot);
+        __builtin_amdgcn_sched_barrier(0);
+        // the last trip re-reads its own second row (an L2 hit, never consumed): the wait counts stay static
+        ring_issue<CT, EXACT, IdT>(A, zb, sb, C, HW, off_of(it + 2 < kRingRows ? it + 2 : kRingRows - 1));
+        __builtin_amdgcn_sched_barrier(0);
+        ring_consume<CT, EXACT, IdT>(B, ok_of(it + 1), C, S, invT, s_acc, t_keys, t_sum, t_hist, gsum, ghist, last_id, last_slot);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+
+    __syncthreads();
+#pragma unroll
+    for (int c = 0; c < CT; ++c) {
+        mas_u64 a = s_acc[c * kThreads + threadIdx.x] - (unsigned)(kRingRows * 4) * MAS_PROBQ_BIAS;
+#pragma unroll
+        for (int off = MAS_WAVE / 2; off > 0; off >>= 1) a += __shfl_down(a, off, MAS_WAVE);
+        if (lane == 0) s_part[wave * CT + c] = a;
+    }
+    __syncthreads();
+    if (threadIdx.x < CT && (EXACT || (int)threadIdx.x < C)) {
+        mas_u64 a = 0;
+#pragma unroll
+        for (int w = 0; w < kThreads / MAS_WAVE; ++w) a += s_part[w * CT + threadIdx.x];
+        if (a) atomicAdd(&prob_sum[(size_t)b * C + threadIdx.x], a);
+    }
+    for (int i = threadIdx.x; i < kSlots * C; i += kThreads) {
+        const unsigned n = t_hist[i];
+        if (n) {
+            const int s = i / C;
+            const size_t g = (size_t)t_keys[s] * C + (i - s * C);
+            atomicAdd(&ghist[g], n);
+            atomicAdd(&gsum[g], t_sum[i]);
+        }
+    }
+}
+
 // score[r] = floor( (sum_c class_sum[r,c] * W31[c]) >> 31  /  n_r ) * 2^-40 ; dominant class; ban
 __global__ __launch_bounds__(kThreads) void k_region_finalize_weighted(const mas_u64* __restrict__ class_sum,
                                                                         const unsigned* __restrict__ hist, long long n_regions,
@@ -237,6 +481,11 @@ __global__ __launch_bounds__(kThreads) void k_region_finalize_weighted(const mas
     if (count) count[r] = (unsigned)n;
 }
 
+inline bool mas_ring_enabled() {
+    static const bool on = [] { const char* e = getenv("MAS_SINGLE_PASS_RING"); return !(e && e[0] == '0'); }();
+    return on;
+}
+
 inline size_t smem_bytes(int C, int CT) {
     return sizeof(mas_u64) * ((size_t)kSlots * C + 4 * CT) + sizeof(unsigned) * (size_t)kSlots * C + sizeof(int) * kSlots;
 }
@@ -251,6 +500,14 @@ int launch(const float* z, const void* spx, int B, int C, int H, int W, int S, f
     const bool vec = (W % 4 == 0) && (((uintptr_t)z & 15) == 0);
     const size_t smem = smem_bytes(C, CT);
     const IdT* ids = static_cast<const IdT*>(spx);
+    if (vec && H >= kRingTileH && (((uintptr_t)spx & 15) == 0) && mas_ring_enabled()) {
+        const int rtiles_y = (H + kRingTileH - 1) / kRingTileH;
+        const long long rblk = (long long)B * tiles_x * rtiles_y;
+        hipLaunchKernelGGL((k_single_pass_ring<CT, EXACT, IdT>), dim3((unsigned)rblk), dim3(kThreads),
+                           smem + sizeof(unsigned) * CT * kThreads, st, z, ids, C, H, W, S, invT, tiles_x, rtiles_y, prob_sum,
+                           class_sum, hist);
+        return mas_launch_status();
+    }
     if (vec)
         hipLaunchKernelGGL((k_single_pass<CT, EXACT, IdT, true>), dim3((unsigned)nblk), dim3(kThreads), smem, st, z, ids, C, H, W, S,
                            invT, tiles_x, tiles_y, prob_sum, class_sum, hist);

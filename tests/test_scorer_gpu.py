@@ -33,6 +33,10 @@ CASES = [
     (1, 19, 40, 260, 32),       # stripped channel count, ragged tile edge
     (2, 7, 24, 36, 16),         # generic (runtime-C) instantiation
     (1, 20, 256, 1024, 2048),   # Cityscapes-like density of regions
+    (2, 20, 100, 516, 200),     # ring kernel (H >= 64): ragged last strip (36 rows) and a 4-px-wide last tile column
+    (1, 19, 130, 260, 64),      # ring kernel, 19 channels, three strips
+    (1, 21, 70, 128, 40),       # ring kernel narrower than a tile
+    (2, 7, 96, 36, 16),         # ring kernel, generic (runtime-C) instantiation
 ]
 
 
@@ -172,7 +176,12 @@ def test_table_overflow_falls_back_to_global_atomics():
     plus a map with a single id -- both paths (LDS table, direct global atomics) must give the oracle's bits."""
     ops = _gpu()
     from oracle import exact
-    B, C, H, W = 1, 20, 32, 512
+    _table_overflow_case(ops, exact, 32)
+    _table_overflow_case(ops, exact, 64)        # tall enough for the ring kernel
+
+
+def _table_overflow_case(ops, exact, H):
+    B, C, W = 1, 20, 512
     S = H * W
     z = synth.logits(9, B, C, H, W)
     invT = ops.inv_temperature(0.1)

@@ -13,7 +13,7 @@ from bench import make_batch  # noqa: E402
 from mulactseg_amd import ops  # noqa: E402
 
 
-def timeit(fn, n=30, warm=5):
+def timeit(fn, n=int(os.environ.get("KBENCH_N", "30")), warm=5):
     for _ in range(warm):
         fn()
     torch.cuda.synchronize()
@@ -33,6 +33,10 @@ def main():
     dev = torch.device('cuda:0')
     B, C, H, W, S = 4, 20, 1024, 2048, 2048
     bufs = [make_batch(11 + i, B, C, H, W, S, ids, dev) for i in range(3)]
+    if '--noids' in sys.argv:      # ablation: every id invalid -> no table lookups / LDS atomics in the scan kernels
+        bufs = [(z, torch.full_like(spx, -1)) for z, spx in bufs]
+    if '--oneid' in sys.argv:      # ablation: a single region -> every lane takes the 4-equal-keys path, same slot
+        bufs = [(z, torch.zeros_like(spx)) for z, spx in bufs]
     invT = ops.inv_temperature(0.1)
     w = torch.linspace(0.3, 1.0, C, device=dev)
     it = [0]
