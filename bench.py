@@ -38,8 +38,8 @@ HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6.3 
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--batch", type=int, default=4, help="pool images per step (reference val_batch_size)")
     ap.add_argument("--height", type=int, default=1024)
     ap.add_argument("--width", type=int, default=2048)
@@ -47,6 +47,7 @@ def parse():
     ap.add_argument("--nseg", type=int, default=2048)
     ap.add_argument("--id-dtype", default="int64", choices=["int64", "int32", "int16"],
                     help="superpixel id element type (the reference data layer yields int64)")
+    ap.add_argument("--ramp", type=int, default=100, help="untimed launches before the warm-up steps (GPU clock ramp)")
     ap.add_argument("--nbuf", type=int, default=3, help="distinct resident batches rotated through")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-train", action="store_true", help="skip the secondary train-iter measurement")
@@ -234,6 +235,12 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
+    # untimed clock ramp: the first ~50 launches after an idle period run ~20 % slower than the steady state (power
+    # management), whatever --warmup the caller passes; the scan is re-run on the warm-up slots, results discarded
+    for k in range(args.ramp):
+        z, spx = bufs[k % args.nbuf]
+        ops.single_pass_accum(z, spx, S, invT, prob_sum=prob[0], class_sum=csum[0], hist=hist[0])
+    prob[0].zero_(); csum[0].zero_(); hist[0].zero_()
     for i in range(args.warmup):
         step(i)
     if args.warmup:
@@ -258,7 +265,7 @@ def main():
     ach = sp_bytes / (sp_ms * 1e-3) / 1e9
 
     # reference-structured two-pass kernels on the same buffers (secondary; not part of `value`)
-    def time_kernel(fn, n=10):
+    def time_kernel(fn, n=100):
         for _ in range(2):
             fn()
         torch.cuda.synchronize()

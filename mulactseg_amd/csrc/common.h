@@ -184,6 +184,29 @@ __device__ __forceinline__ void mas_softmax_quad(mas_v2f (&xa)[CT], mas_v2f (&xb
     rinv_b = (mas_v2f){1.0f / sb.x, 1.0f / sb.y};
 }
 
+// BvSB margins of four pixels (mas_bvsb element-wise: exp_np(z2*invT - z1*invT) + 1e-8) on packed pairs, and their
+// fixed-point quanta.  mas_fix_unit(v) == mas_fix(v, MAS_SCORE_FRAC) for 0 < v < 2 (a margin lies in [1e-8, 1 + 1e-8]):
+// the shift count is e - 110 in [-27, 17], so one 64-bit left shift or one 32-bit right shift suffices.
+__device__ __forceinline__ void mas_bvsb_quad(const float (&b1)[4], const float (&b2)[4], float invT, float (&out)[4]) {
+    const mas_v2f it = mas_splat(invT);
+    const mas_v2f da = ((mas_v2f){b2[0], b2[1]} * it) - ((mas_v2f){b1[0], b1[1]} * it);
+    const mas_v2f db = ((mas_v2f){b2[2], b2[3]} * it) - ((mas_v2f){b1[2], b1[3]} * it);
+    mas_v2f ea, eb;
+    mas_expf_np2x2(da, db, ea, eb);
+    ea = ea + mas_splat(1e-8f);
+    eb = eb + mas_splat(1e-8f);
+    out[0] = ea.x; out[1] = ea.y; out[2] = eb.x; out[3] = eb.y;
+}
+
+__device__ __forceinline__ mas_u64 mas_fix_unit(float v) {
+    const unsigned b = mas_f2u(v);
+    const int sh = (int)(b >> 23) - (150 - MAS_SCORE_FRAC);      // sign bit is 0
+    const unsigned m = (b & 0x007fffffu) | 0x00800000u;
+    const mas_u64 up = (mas_u64)m << (sh & 31);
+    const unsigned dn = m >> ((-sh) & 31);
+    return sh >= 0 ? up : (mas_u64)dn;
+}
+
 // ------------------------------------------------------------------------------------------------
 // Wave-level segmented reduction over RUNS of equal keys in lane order (superpixel ids come in runs along a
 // row).  After the call, the lane for which the function returns true is the last lane of its run and holds the

@@ -39,6 +39,14 @@ __device__ __forceinline__ int table_slot(int* keys, int id) {
     return -1;
 }
 
+// LDS adds carry workgroup scope, the global fallbacks agent scope: with the same scope on both the compiler
+// if-converts "LDS slot or global" into a pointer select and ONE flat_atomic, and a pending FLAT operation forces
+// s_waitcnt vmcnt(0) -- which would drain the prefetched row in the middle of the pipeline.
+template <typename T>
+__device__ __forceinline__ void lds_add(T* p, T v) {
+    (void)__hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+
 template <int CT, bool EXACT, typename IdT, bool VEC>
 __global__ __launch_bounds__(kThreads) void k_single_pass(const float* __restrict__ z, const IdT* __restrict__ spx, int C, int H,
                                                            int W, int S, float invT, int tiles_x, int tiles_y,
@@ -113,12 +121,11 @@ __global__ __launch_bounds__(kThreads) void k_single_pass(const float* __restric
                 const float q[4] = {t.x, t.y, t.z, t.w};
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
-                    // same update as "if (v > b1) {b2 = b1; b1 = v; a1 = c} else if (v > b2) b2 = v"
+                    // same update as "if (v > b1) {b2 = b1; b1 = v; a1 = c} else if (v > b2) b2 = v", as two medians (see ring_consume)
                     const bool g1 = q[k] > b1[k];
-                    const bool g2 = q[k] > b2[k];
-                    b2[k] = g1 ? b1[k] : (g2 ? q[k] : b2[k]);
+                    b2[k] = __builtin_amdgcn_fmed3f(b1[k], b2[k], q[k]);
                     a1[k] = g1 ? c : a1[k];
-                    b1[k] = g1 ? q[k] : b1[k];
+                    b1[k] = __builtin_amdgcn_fmed3f(b1[k], q[k], 3.402823466e+38f);
                 }
             } else {
                 v[0][c] = mas_splat(0.f);
@@ -148,9 +155,11 @@ __global__ __launch_bounds__(kThreads) void k_single_pass(const float* __restric
         // region accumulation of the unweighted margin, keyed by (superpixel, arg-max class)
         mas_u64 q[4];
         int key[4];
+        float margin[4];
+        mas_bvsb_quad(b1, b2, invT, margin);
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-            q[k] = mas_fix(mas_bvsb(b1[k], b2[k], invT), MAS_SCORE_FRAC);
+            q[k] = mas_fix_unit(margin[k]);
             key[k] = id[k] < 0 ? -1 : id[k] * MAS_MAX_CLASSES + a1[k];
         }
         const bool same = (key[0] == key[1]) && (key[1] == key[2]) && (key[2] == key[3]);
@@ -159,8 +168,8 @@ __global__ __launch_bounds__(kThreads) void k_single_pass(const float* __restric
                 const int s = table_slot(t_keys, id[0]);
                 const mas_u64 qs = (q[0] + q[1]) + (q[2] + q[3]);
                 if (s >= 0) {
-                    atomicAdd(&t_sum[s * C + a1[0]], qs);
-                    atomicAdd(&t_hist[s * C + a1[0]], 4u);
+                    lds_add(&t_sum[s * C + a1[0]], qs);
+                    lds_add(&t_hist[s * C + a1[0]], 4u);
                 } else {
                     atomicAdd(&gsum[(size_t)id[0] * C + a1[0]], qs);
                     atomicAdd(&ghist[(size_t)id[0] * C + a1[0]], 4u);
@@ -172,8 +181,8 @@ __global__ __launch_bounds__(kThreads) void k_single_pass(const float* __restric
                 if (key[k] < 0) continue;
                 const int s = table_slot(t_keys, id[k]);
                 if (s >= 0) {
-                    atomicAdd(&t_sum[s * C + a1[k]], q[k]);
-                    atomicAdd(&t_hist[s * C + a1[k]], 1u);
+                    lds_add(&t_sum[s * C + a1[k]], q[k]);
+                    lds_add(&t_hist[s * C + a1[k]], 1u);
                 } else {
                     atomicAdd(&gsum[(size_t)id[k] * C + a1[k]], q[k]);
                     atomicAdd(&ghist[(size_t)id[k] * C + a1[k]], 1u);
@@ -266,14 +275,6 @@ __device__ __forceinline__ void ring_issue(RowRegs<CT, IdT>& r, const float* __r
     }
 }
 
-// LDS adds carry workgroup scope, the global fallbacks agent scope: with the same scope on both the compiler
-// if-converts "LDS slot or global" into a pointer select and ONE flat_atomic, and a pending FLAT operation forces
-// s_waitcnt vmcnt(0) -- which would drain the prefetched row in the middle of the pipeline.
-template <typename T>
-__device__ __forceinline__ void lds_add(T* p, T v) {
-    (void)__hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-}
-
 template <int CT, bool EXACT, typename IdT>
 __device__ __forceinline__ void ring_consume(RowRegs<CT, IdT>& r, bool ok, int C, int S, float invT, unsigned* s_acc, int* t_keys,
                                              mas_u64* t_sum, unsigned* t_hist, mas_u64* __restrict__ gsum,
@@ -326,11 +327,13 @@ __device__ __forceinline__ void ring_consume(RowRegs<CT, IdT>& r, bool ok, int C
     __builtin_amdgcn_sched_barrier(0);
     mas_u64 q[4];
     int key[4], id[4];
+    float margin[4];
     r.ids.get(id);
+    mas_bvsb_quad(b1, b2, invT, margin);
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
         id[k] = (ok && id[k] >= 0 && id[k] < S) ? id[k] : -1;
-        q[k] = mas_fix(mas_bvsb(b1[k], b2[k], invT), MAS_SCORE_FRAC);
+        q[k] = mas_fix_unit(margin[k]);
         key[k] = id[k] < 0 ? -1 : id[k] * MAS_MAX_CLASSES + a1[k];
     }
     const bool same = (key[0] == key[1]) && (key[1] == key[2]) && (key[2] == key[3]);
@@ -500,7 +503,8 @@ int launch(const float* z, const void* spx, int B, int C, int H, int W, int S, f
     const bool vec = (W % 4 == 0) && (((uintptr_t)z & 15) == 0);
     const size_t smem = smem_bytes(C, CT);
     const IdT* ids = static_cast<const IdT*>(spx);
-    if (vec && H >= kRingTileH && (((uintptr_t)spx & 15) == 0) && mas_ring_enabled()) {
+    // (two row buffers of the generic 32-channel instantiation do not fit 256 VGPRs: it keeps the one-row kernel)
+    if constexpr (EXACT) if (vec && H >= kRingTileH && (((uintptr_t)spx & 15) == 0) && mas_ring_enabled()) {
         const int rtiles_y = (H + kRingTileH - 1) / kRingTileH;
         const long long rblk = (long long)B * tiles_x * rtiles_y;
         hipLaunchKernelGGL((k_single_pass_ring<CT, EXACT, IdT>), dim3((unsigned)rblk), dim3(kThreads),
