@@ -270,6 +270,15 @@ int mas_aspp_dw3_bwd_x(const float* dy0, const float* dy1, const float* dy2, con
 int mas_aspp_dw3_bwd_w(const float* x, const float* dy0, const float* dy1, const float* dy2, int N, int C, int H, int W,
                        int d0, int d1, int d2, float* dw0, float* dw1, float* dw2, void* stream);
 
+/* Single depthwise 3x3, stride 1, padding = dilation, no bias: y[n,c] = w[c] (*) x[n,c].  Replaces the depthwise half
+ * of AtrousSeparableConvolution (models/segmentation/deeplabv3.py:168-192) in the decoder (classifier.classifier.0/3:
+ * 304 and 256 channels), forward / data gradient / weight gradient.  (16 + 2d) * (W + 2d) * 4 bytes must fit 64 KB.
+ * bwd_w: `partial` is caller-owned scratch of N*C*9 floats; the reduction order is fixed (deterministic). */
+int mas_depthwise3x3_fwd(const float* x, const float* w, int N, int C, int H, int W, int dilation, float* y, void* stream);
+int mas_depthwise3x3_bwd_x(const float* dy, const float* w, int N, int C, int H, int W, int dilation, float* dx, void* stream);
+int mas_depthwise3x3_bwd_w(const float* x, const float* dy, int N, int C, int H, int W, int dilation, float* partial, float* dw,
+                           void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -43,6 +43,9 @@ SIGNATURES = {
     "mas_aspp_dw3_fwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp]),
     "mas_aspp_dw3_bwd_x": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp]),
     "mas_aspp_dw3_bwd_w": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp]),
+    "mas_depthwise3x3_fwd": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp, _vp]),
+    "mas_depthwise3x3_bwd_x": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp, _vp]),
+    "mas_depthwise3x3_bwd_w": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp]),
     "mas_target_bits": (_i, [_vp, _i64, _i, _i, _vp, _vp]),
     "mas_partial_loss_fwd": (_i, [_vp, _vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _f, _i, _vp, _vp, _vp]),
     "mas_group_finalize": (_i, [_vp, _i64, _vp, _vp]),

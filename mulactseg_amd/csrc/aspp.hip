@@ -129,6 +129,87 @@ __global__ __launch_bounds__(kThreads) void k_dw3_bwd_w(const float* __restrict_
     }
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// Single depthwise 3x3 (stride 1, padding = dilation): the decoder's two separable convolutions
+// (models/segmentation/deeplabv3.py:107-112 after convert_to_separable_conv; 304 and 256 channels at 192x192), for which
+// MIOpen falls back to its "naive" fp32 kernels (0.48 ms forward, 0.8 ms backward each).  A workgroup stages a
+// zero-padded (16 + 2d) x (W + 2d) strip of one (n, c) plane in LDS; the inner loop has no bounds checks.
+// FLIP = data gradient (correlation with the flipped kernel).
+// ------------------------------------------------------------------------------------------------
+constexpr int kStripH = 16;
+
+template <bool FLIP>
+__global__ __launch_bounds__(kThreads) void k_dw_strip(const float* __restrict__ x, const float* __restrict__ w, int C, int H, int W, int d,
+                                                        int strips, float* __restrict__ y) {
+    extern __shared__ float s_tile[];
+    const int strip = blockIdx.x % strips;
+    const int nc = blockIdx.x / strips;
+    const int c = nc % C;
+    const size_t plane = (size_t)nc * H * W;
+    const int y0 = strip * kStripH;
+    const int TW = W + 2 * d, TH = kStripH + 2 * d;
+    for (int i = threadIdx.x; i < TH * TW; i += kThreads) {
+        const int ty = i / TW, tx = i - ty * TW;
+        const int gy = y0 + ty - d, gx = tx - d;
+        s_tile[i] = (gy >= 0 && gy < H && gx >= 0 && gx < W) ? x[plane + (size_t)gy * W + gx] : 0.0f;
+    }
+    float k[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) k[t] = w[c * 9 + (FLIP ? 8 - t : t)];
+    __syncthreads();
+    const int rows = (H - y0) < kStripH ? (H - y0) : kStripH;
+    for (int i = threadIdx.x; i < rows * W; i += kThreads) {
+        const int py = i / W, px = i - py * W;
+        float acc = 0.f;
+#pragma unroll
+        for (int a = 0; a < 3; ++a)
+#pragma unroll
+            for (int b = 0; b < 3; ++b) acc = mas_fmaf(k[a * 3 + b], s_tile[(py + a * d) * TW + px + b * d], acc);
+        y[plane + (size_t)(y0 + py) * W + px] = acc;
+    }
+}
+
+// dw[c,a,b] = sum_{n,i,j} dy[n,c,i,j] * x[n,c, i+(a-1)d, j+(b-1)d]; one workgroup per (channel, image), nine sums per
+// thread, fixed-order wave/workgroup reduction into part[n,c,9]; k_dw_wsum adds the images in index order.
+__global__ __launch_bounds__(kThreads) void k_dw_bwd_w(const float* __restrict__ x, const float* __restrict__ g, int C, int H, int W, int d,
+                                                        float* __restrict__ part) {
+    __shared__ float s_red[kThreads / MAS_WAVE][9];
+    const size_t plane = (size_t)blockIdx.x * H * W;           // blockIdx.x = n*C + c
+    const float* xp = x + plane;
+    float acc[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) acc[t] = 0.f;
+    for (int i = threadIdx.x; i < H * W; i += kThreads) {
+        const int py = i / W, px = i - py * W;
+        const float v = g[plane + i];
+#pragma unroll
+        for (int a = 0; a < 3; ++a)
+#pragma unroll
+            for (int b = 0; b < 3; ++b) acc[a * 3 + b] = mas_fmaf(v, tap(xp, H, W, py + (a - 1) * d, px + (b - 1) * d), acc[a * 3 + b]);
+    }
+    const int lane = threadIdx.x & (MAS_WAVE - 1), wave = threadIdx.x / MAS_WAVE;
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+        float v = acc[t];
+#pragma unroll
+        for (int off = MAS_WAVE / 2; off > 0; off >>= 1) v += __shfl_down(v, off, MAS_WAVE);
+        if (lane == 0) s_red[wave][t] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x < 9)
+        part[(size_t)blockIdx.x * 9 + threadIdx.x] =
+            ((s_red[0][threadIdx.x] + s_red[1][threadIdx.x]) + s_red[2][threadIdx.x]) + s_red[3][threadIdx.x];
+}
+
+__global__ __launch_bounds__(kThreads) void k_dw_wsum(const float* __restrict__ part, int N, int C9, float* __restrict__ dw) {
+    const int i = blockIdx.x * kThreads + threadIdx.x;
+    if (i >= C9) return;
+    float v = 0.f;
+    for (int n = 0; n < N; ++n) v += part[(size_t)n * C9 + i];
+    dw[i] = v;
+}
+
 int check(int N, int C, int H, int W, int d0, int d1, int d2) {
     if (N <= 0 || C <= 0 || H <= 0 || W <= 0 || (long long)N * C > 0x7fffffffLL || (long long)H * W > (1 << 24)) return MAS_ERR_SHAPE;
     if (d0 <= 0 || d1 <= 0 || d2 <= 0) return MAS_ERR_RANGE;
@@ -168,5 +249,37 @@ extern "C" int mas_aspp_dw3_bwd_w(const float* x, const float* g0, const float* 
     if (int e = check(N, C, H, W, d0, d1, d2)) return e;
     hipLaunchKernelGGL(k_dw3_bwd_w, dim3((unsigned)C), dim3(kThreads), 0, static_cast<hipStream_t>(stream), x, g0, g1, g2, N, C, H, W, d0,
                        d1, d2, dw0, dw1, dw2);
+    return mas_launch_status();
+}
+
+static int dw_launch(bool flip, const float* x, const float* w, int N, int C, int H, int W, int d, float* y, void* stream) {
+    if (!x || !w || !y) return MAS_ERR_NULL;
+    if (int e = check(N, C, H, W, d, d, d)) return e;
+    const int strips = (H + kStripH - 1) / kStripH;
+    const size_t smem = sizeof(float) * (size_t)(kStripH + 2 * d) * (W + 2 * d);
+    if (smem > 64 * 1024 || (long long)N * C * strips > 0x7fffffffLL) return MAS_ERR_SHAPE;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (flip)
+        hipLaunchKernelGGL((k_dw_strip<true>), dim3((unsigned)(N * C * strips)), dim3(kThreads), smem, st, x, w, C, H, W, d, strips, y);
+    else
+        hipLaunchKernelGGL((k_dw_strip<false>), dim3((unsigned)(N * C * strips)), dim3(kThreads), smem, st, x, w, C, H, W, d, strips, y);
+    return mas_launch_status();
+}
+
+extern "C" int mas_depthwise3x3_fwd(const float* x, const float* w, int N, int C, int H, int W, int dilation, float* y, void* stream) {
+    return dw_launch(false, x, w, N, C, H, W, dilation, y, stream);
+}
+
+extern "C" int mas_depthwise3x3_bwd_x(const float* dy, const float* w, int N, int C, int H, int W, int dilation, float* dx, void* stream) {
+    return dw_launch(true, dy, w, N, C, H, W, dilation, dx, stream);
+}
+
+extern "C" int mas_depthwise3x3_bwd_w(const float* x, const float* dy, int N, int C, int H, int W, int dilation, float* partial,
+                                      float* dw, void* stream) {
+    if (!x || !dy || !partial || !dw) return MAS_ERR_NULL;
+    if (int e = check(N, C, H, W, dilation, dilation, dilation)) return e;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    hipLaunchKernelGGL(k_dw_bwd_w, dim3((unsigned)(N * C)), dim3(kThreads), 0, st, x, dy, C, H, W, dilation, partial);
+    hipLaunchKernelGGL(k_dw_wsum, dim3((unsigned)((C * 9 + kThreads - 1) / kThreads)), dim3(kThreads), 0, st, partial, N, C * 9, dw);
     return mas_launch_status();
 }

@@ -115,6 +115,11 @@ class AtrousSeparableConvolution(nn.Module):
             nn.Conv2d(in_channels, out_channels, 1, bias=False))
 
     def forward(self, x):
+        dw = self.body[0]
+        if x.is_cuda and dw.kernel_size == (3, 3) and dw.stride == (1, 1) and dw.padding == dw.dilation and dw.groups == x.shape[1]:
+            from .. import ops          # HIP depthwise (csrc/aspp.hip); MIOpen only has a naive fp32 kernel for it
+            if ops.depthwise3x3_supported(x, dw.dilation[0]):
+                return self.body[1](ops.depthwise3x3(x, dw.weight, dw.dilation[0]))
         return self.body(x)
 
 

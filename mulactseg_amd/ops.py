@@ -473,3 +473,50 @@ def aspp_depthwise3(x, w0, w1, w2, dilations):
         if tuple(w.shape) != (x.shape[1], 1, 3, 3):
             raise ValueError("depthwise weights must be [C,1,3,3]")
     return _AsppDepthwise3.apply(x, w0, w1, w2, int(dilations[0]), int(dilations[1]), int(dilations[2]))
+
+
+class _Depthwise3x3(torch.autograd.Function):
+    """y = depthwise 3x3 (stride 1, padding = dilation, no bias) of x (models/segmentation/deeplabv3.py:174-177)."""
+
+    @staticmethod
+    def forward(ctx, x, w, d):
+        x, w = x.contiguous(), w.contiguous()
+        N, C, H, W = x.shape
+        y = torch.empty_like(x)
+        with torch.cuda.device(x.device):
+            _lib.check(_lib.load().mas_depthwise3x3_fwd(x.data_ptr(), w.data_ptr(), N, C, H, W, d, y.data_ptr(), _stream(x)),
+                       "mas_depthwise3x3_fwd")
+        ctx.save_for_backward(x, w)
+        ctx.dil = d
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        x, w = ctx.saved_tensors
+        d = ctx.dil
+        N, C, H, W = x.shape
+        g = g.contiguous()
+        lib = _lib.load()
+        dx = dw = None
+        with torch.cuda.device(x.device):
+            st = _stream(x)
+            if ctx.needs_input_grad[0]:
+                dx = torch.empty_like(x)
+                _lib.check(lib.mas_depthwise3x3_bwd_x(g.data_ptr(), w.data_ptr(), N, C, H, W, d, dx.data_ptr(), st), "mas_depthwise3x3_bwd_x")
+            if ctx.needs_input_grad[1]:
+                dw = torch.empty_like(w)
+                part = torch.empty((N, C, 9), dtype=torch.float32, device=x.device)
+                _lib.check(lib.mas_depthwise3x3_bwd_w(x.data_ptr(), g.data_ptr(), N, C, H, W, d, part.data_ptr(), dw.data_ptr(), st),
+                           "mas_depthwise3x3_bwd_w")
+        return dx, dw, None
+
+
+def depthwise3x3_supported(x, dilation):
+    return x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and (16 + 2 * dilation) * (x.shape[3] + 2 * dilation) * 4 <= 64 * 1024
+
+
+def depthwise3x3(x, w, dilation):
+    _need(x, "x", torch.float32)
+    if tuple(w.shape) != (x.shape[1], 1, 3, 3):
+        raise ValueError("depthwise weight must be [C,1,3,3]")
+    return _Depthwise3x3.apply(x, w, int(dilation))

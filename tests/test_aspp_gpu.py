@@ -43,6 +43,41 @@ def test_depthwise_triple_matches_conv2d(N, C, H, W):
     assert all(torch.equal(a, w.grad) for a, w in zip(first, ws))
 
 
+@pytest.mark.parametrize("N,C,H,W,d", [(2, 48, 48, 48, 1), (4, 38, 192, 192, 1), (1, 16, 37, 53, 1), (2, 8, 20, 300, 2), (1, 4, 16, 16, 6)])
+def test_single_depthwise_matches_conv2d(N, C, H, W, d):
+    """Decoder depthwise 3x3 (mas_depthwise3x3_*) against float64 conv2d: forward, dx, dw; dw deterministic."""
+    _need()
+    from mulactseg_amd import ops
+    g = torch.Generator(device='cuda'); g.manual_seed(7 * N + C + d)
+    x = torch.randn((N, C, H, W), generator=g, device='cuda', requires_grad=True)
+    w = torch.randn((C, 1, 3, 3), generator=g, device='cuda', requires_grad=True)
+    assert ops.depthwise3x3_supported(x, d)
+    y = ops.depthwise3x3(x, w, d)
+    xr = x.detach().double().cpu().requires_grad_(True)
+    wr = w.detach().double().cpu().requires_grad_(True)
+    yr = F.conv2d(xr, wr, padding=d, dilation=d, groups=C)
+    assert float((y.double().cpu() - yr).abs().max()) < 1e-5 * max(1.0, float(yr.abs().max()))
+    go = torch.randn(y.shape, generator=g, device='cuda')
+    y.backward(go)
+    yr.backward(go.double().cpu())
+    assert float((x.grad.double().cpu() - xr.grad).abs().max()) < 1e-5 * max(1.0, float(xr.grad.abs().max()))
+    assert float((w.grad.double().cpu() - wr.grad).abs().max()) < 2e-4 * max(1.0, float(wr.grad.abs().max()))
+    first = w.grad.clone()
+    w.grad = None; x.grad = None
+    ops.depthwise3x3(x, w, d).backward(go)
+    assert torch.equal(first, w.grad)
+
+
+def test_separable_conv_module_takes_the_hip_path():
+    _need()
+    from mulactseg_amd.models.deeplab import AtrousSeparableConvolution
+    m = AtrousSeparableConvolution(24, 16, 3, padding=1, dilation=1).cuda()
+    x = torch.randn(2, 24, 40, 56, device='cuda')
+    ref = m.body(x)
+    out = m(x)
+    assert float((out - ref).abs().max()) < 1e-4 * max(1.0, float(ref.abs().max()))
+
+
 def test_model_uses_fused_aspp_and_keeps_parity():
     """The G4 model golden (executed reference) still holds with the K7 path active on the GPU."""
     _need()
