@@ -52,6 +52,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-train", action="store_true", help="skip the secondary train-iter measurement")
     ap.add_argument("--train-steps", type=int, default=8)
+    ap.add_argument("--acq-steps", type=int, default=4, help="steps of the secondary model-forward + scan measurement")
     ap.add_argument("--crop", type=int, default=768, help="training crop (reference: 768, transform.py:107)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU-baseline budget")
     return ap.parse_args()
@@ -165,6 +166,42 @@ def train_iter_bench(args, dev, world):
                        "selected_fraction": float(msk.float().mean())},
             "loss_only": {"ms_fwd_bwd": loss_ms, "algorithmic_GBs": loss_bytes / (loss_ms * 1e-3) / 1e9,
                           "bytes": loss_bytes, "note": "includes ~8 small launches and the autograd glue"}}
+
+
+def acquisition_with_model_bench(args, dev, world):
+    """the acquisition metric "also with the model forwards".  One step = eval-mode forward of
+    DeepLabv3+WN/ResNet50-deepstem (fp32, random init) on a [B,3,H,W] pool batch + the single-pass scan of its logits.
+    The reference structure needs two forwards per image (class prior, then scores); the single-pass scan needs one."""
+    from mulactseg_amd import ops
+    from mulactseg_amd.models import get_model
+    B, C, H, W, S = args.batch, args.classes, args.height, args.width, args.nseg
+    net = get_model('deeplabv3pluswn_resnet50deepstem', C, 16, True, pretrained_backbone=False).to(dev).eval()
+    g = torch.Generator(device=dev)
+    g.manual_seed(9)
+    images = torch.randn((B, 3, H, W), generator=g, device=dev)
+    _, spx = make_batch(4242, B, C, H, W, S, args.id_dtype, dev)
+    invT = ops.inv_temperature(0.1)
+    prob = torch.zeros((B, C), dtype=torch.int64, device=dev)
+    csum = torch.zeros((B, S, C), dtype=torch.int64, device=dev)
+    hist = torch.zeros((B, S, C), dtype=torch.int32, device=dev)
+
+    def step():
+        with torch.no_grad():
+            z = net(images)
+        ops.single_pass_accum(z.contiguous(), spx, S, invT, prob_sum=prob, class_sum=csum, hist=hist)
+
+    for _ in range(2):
+        step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.acq_steps):
+        step()
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) / args.acq_steps * 1e3
+    return {"metric": "superpixels scored/sec incl. model forward", "value": B * S * world / (ms * 1e-3), "unit": "superpixels/s",
+            "ms_per_batch": ms, "forwards_per_image": 1,
+            "config": {"workload": "eval forward (MIOpen fp32) of [%d,3,%d,%d] + single-pass scan; the reference structure runs the "
+                                   "forward twice per pool image" % (B, H, W)}}
 
 
 def pmc_traffic(kernel, default_shape):
@@ -303,6 +340,7 @@ def main():
                      "superpixels_per_s": B * S * world / ((k2_ms + k3_ms) * 1e-3)},
     }
     out["train_iter"] = None if args.no_train else train_iter_bench(args, dev, world)
+    out["acquisition_with_model"] = None if args.no_train else acquisition_with_model_bench(args, dev, world)
     if rank == 0:
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(args, args.cpu_seconds)

@@ -29,3 +29,14 @@ def get_dataset(args, name, data_root, datalist, imageset):
             "no dataset factory registered: call mulactseg_amd.dataloader.register_dataset_factory(fn); the "
             "reference's Cityscapes/VOC file readers are out of scope for the hot path")
     return _DATASET_FACTORY(args, name, data_root, datalist, imageset)
+
+
+def get_slide_dataset(name, data_root, datalist, total_itrs=None, imageset='train'):
+    """Reference ``dataloader/__init__.py:80-110``: the evaluation set at full resolution (Cityscapes resized to
+    1024x2048, VOC 513 centre crop), no region annotations; the registered factory is asked for imageset
+    ``'eval_slide'`` with ``args=None``."""
+    assert imageset == "eval"
+    assert name in ["cityscapes", "voc"]
+    if _DATASET_FACTORY is None:
+        raise NotImplementedError("no dataset factory registered: call mulactseg_amd.dataloader.register_dataset_factory(fn)")
+    return _DATASET_FACTORY(None, name, data_root, datalist, 'eval_slide')

@@ -123,3 +123,25 @@ def synthetic_state_dict(shapes, seed=0):
             fan_in = int(np.prod(shape[1:]))
             out[key] = (np.sqrt(2.0 / fan_in) * rs.standard_normal(size=shape)).astype(np.float32)
     return out
+
+
+def tiny_window_net(seed, num_channels, feat_dim=256):
+    """A two-convolution stand-in for the segmentation net (``net(x)`` -> scores, ``net.feat_forward(x)`` -> (features,
+    scores)) whose 3x3 zero-padded convolutions make every output depend on where the window border lies: used to pin
+    the sliding-window evaluators (tests/golden/g8) without the cost of a DeepLab forward per window."""
+    import torch
+
+    class _Net(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            rs = np.random.RandomState(seed)
+            self.wf = torch.nn.Parameter(torch.from_numpy(rs.standard_normal((feat_dim, 3, 3, 3)).astype(np.float32) * 0.2), False)
+            self.ws = torch.nn.Parameter(torch.from_numpy(rs.standard_normal((num_channels, 3, 3, 3)).astype(np.float32) * 0.2), False)
+
+        def feat_forward(self, x):
+            return torch.nn.functional.conv2d(x, self.wf, padding=1), torch.nn.functional.conv2d(x, self.ws, padding=1)
+
+        def forward(self, x):
+            return torch.nn.functional.conv2d(x, self.ws, padding=1)
+
+    return _Net().eval()

@@ -391,6 +391,29 @@ def gen_g5():
     print("g5: miou", np.mean(ious))
 
 
+def gen_g8():
+    """Sliding-window evaluators (BASELINE config 4, "sliding"): utils/sliding_evaluator.py and
+    utils/sliding_evaluator_plbl.py on their working branch (image larger than the crop), with a two-convolution
+    stand-in network.  Cases: both dims > crop with clamped last windows; one dim smaller than the crop (padding)."""
+    torch.Tensor.cuda = lambda self, *a, **k: self
+    from utils.sliding_evaluator import SlidingEval as RefScores
+    from utils.sliding_evaluator_plbl import SlidingEval as RefBoth
+    out = {}
+    for tag, seed, C, cls_n, H, W, crop in (('a', 81, 20, 19, 50, 77, 32), ('b', 82, 20, 20, 23, 61, 30), ('c', 83, 21, 21, 64, 64, 32)):
+        net = synth.tiny_window_net(seed, C, feat_dim=256)
+        img = torch.from_numpy(np.random.RandomState(seed + 100).standard_normal((1, 3, H, W)).astype(np.float32))
+        with torch.no_grad():
+            scores = RefScores(model=net, crop_size=crop, stride_rate=2 / 3, device='cpu', class_number=cls_n)(img)
+            feats, scores2 = RefBoth(model=net, crop_size=crop, stride_rate=2 / 3, device='cpu', class_number=cls_n)(img)
+        assert np.array_equal(scores, scores2)
+        out[tag + '_cfg'] = np.array([seed, C, cls_n, H, W, crop])
+        out[tag + '_scores'] = scores.astype(np.float32)
+        out[tag + '_feats_sub'] = feats[::8, ::2, ::3].astype(np.float32)
+        out[tag + '_feats_sum'] = np.float64(feats.sum())
+        print("g8", tag, scores.shape, feats.shape, float(np.abs(scores).max()))
+    np.savez_compressed(os.path.join(OUT, "g8_sliding.npz"), **out)
+
+
 if __name__ == "__main__":
     refshim.install()
     os.makedirs(OUT, exist_ok=True)
@@ -402,5 +425,6 @@ if __name__ == "__main__":
     gen_g5()
     gen_g6()
     gen_g7()
+    gen_g8()
     for f in sorted(os.listdir(OUT)):
         print(f, os.path.getsize(os.path.join(OUT, f)))

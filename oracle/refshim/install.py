@@ -15,6 +15,9 @@ small stand-ins into ``sys.modules`` *before* the reference modules are imported
   for the keys the scorer uses) and a ``DataProvider`` placeholder (``trainer/base.py:11``)
 * ``wandb``             -> empty module
 * ``skimage`` (+ ``.morphology.binary_dilation`` = scipy's, ``.segmentation.mark_boundaries``)
+* ``cv2``               -> ``copyMakeBorder`` (constant border = ``numpy.pad``) and ``resize`` restricted to the
+  identity case (same size in and out), the only one ``utils/sliding_evaluator*.py`` reaches on its working branch;
+  ``collections.Iterable`` (removed in Python 3.10, used at ``sliding_evaluator.py:51``) is aliased to ``collections.abc``
 
 No reference source is copied; the reference is imported from where it lies.
 """
@@ -76,6 +79,22 @@ def install():
             return ndimage.binary_dilation(image, structure=st)
     except Exception:  # pragma: no cover
         binary_dilation = None
+    import collections
+    import collections.abc
+    import numpy as _np
+    if not hasattr(collections, "Iterable"):
+        collections.Iterable = collections.abc.Iterable
+
+    def copyMakeBorder(img, top, bottom, left, right, border_mode, value=0):
+        assert border_mode == 0
+        pad = [(int(top), int(bottom)), (int(left), int(right))] + [(0, 0)] * (img.ndim - 2)
+        return _np.pad(img, pad, mode="constant", constant_values=value)
+
+    def resize(arr, dsize, interpolation=1):
+        assert (arr.shape[1], arr.shape[0]) == tuple(dsize), "cv2 stand-in: only the identity resize is restated"
+        return arr
+    _module("cv2", copyMakeBorder=copyMakeBorder, resize=resize, BORDER_CONSTANT=0, INTER_LINEAR=1)
+
     sk = _module("skimage")
     sk.__path__ = []
     sk.morphology = _module("skimage.morphology", binary_dilation=binary_dilation)

@@ -67,3 +67,29 @@ def test_labels_only_inside_one_ring_of_selected_superpixels():
     assert np.all(np.isin(spx[0][out != 255], ring))
     assert np.all(out[msk[0]] != 255)
     assert np.all(tgt[0][spx[0][msk[0]], out[msk[0]]] == 1)
+
+
+def test_sliding_window_ensemble_trainer():
+    """trainer/eval_save_cosplbl_prop_includeonehot_slide: window-ensemble features (summed at full resolution on the
+    device, re-normalised) through K9 == the C oracle fed the very same feature / score arrays."""
+    ops = _gpu()
+    from oracle import exact
+    from mulactseg_amd import synth
+    from mulactseg_amd.trainer import eval_save_cosplbl_prop_includeonehot_slide as mod
+    N, C, Ch, H, W, S = 1, 20, 256, 50, 77, 30
+    _, _, tgt, spx, msk, labels = [a[0:1] for a in stage2_inputs(91, 2, C, 8, H, W, S)]     # (the last image has an empty mask)
+    assert msk.any()
+    tr = object.__new__(mod.ActiveTrainer)
+    tr.net = synth.tiny_window_net(92, C, feat_dim=Ch).cuda()
+    tr.device = torch.device('cuda')
+    tr.num_classes = C - 1
+    tr.crop_size, tr.stride_rate = 32, 2 / 3
+    img = torch.from_numpy(np.random.RandomState(93).standard_normal((1, 3, H, W)).astype(np.float32)).cuda()
+    c = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
+    out = tr.pseudo_labels(img, c(labels), c(tgt), c(msk), c(spx)).cpu().numpy()
+    feats, scores = tr.evaluator(img)
+    assert tuple(feats.shape) == (Ch, H, W) and tuple(scores.shape) == (C, H, W)
+    fn = torch.nn.functional.normalize(feats[None], dim=1, p=2).cpu().numpy()
+    ref = exact.stage2_pseudo_labels(fn, scores[None].cpu().numpy(), tgt, msk, spx, True)
+    assert np.array_equal(out, ref)
+    assert (out != 255).any()
