@@ -36,6 +36,7 @@ extern "C" {
 #define MAS_ID_I64 0   /* torch.long, what the reference data layer yields (ext_transforms.py:406) */
 #define MAS_ID_I32 1
 #define MAS_ID_U16 2   /* compact resident pool maps (S <= 65535) */
+#define MAS_MAP_U8 3   /* label maps of mas_train_augment only */
 
 #define MAS_MAX_CLASSES 32
 
@@ -278,6 +279,21 @@ int mas_depthwise3x3_fwd(const float* x, const float* w, int N, int C, int H, in
 int mas_depthwise3x3_bwd_x(const float* dy, const float* w, int N, int C, int H, int W, int dilation, float* dx, void* stream);
 int mas_depthwise3x3_bwd_w(const float* x, const float* dy, int N, int C, int H, int W, int dilation, float* partial, float* dw,
                            void* stream);
+
+/* Training-time geometry of ONE sample on the device: dataloader/transform.py:105-113 = ExtRandomScale (Pillow BILINEAR
+ * for the picture, NEAREST for up to two label / superpixel maps; ext_transforms.py:172-192), pad-if-needed + random crop
+ * (:443-520), horizontal flip (:323-341), to-tensor + normalise (:384-437).  `mean`, `std` (3 floats) and `fill` (3
+ * bytes) are HOST pointers, everything else device memory.
+ * img u8 [H,W,3]; scaled size th x tw; hbounds[tw,2] / hk[tw,hks] and vbounds[th,2] / vk[th,vks]: Pillow's
+ * (first tap, tap count) and 22-bit fixed-point weights of the horizontal / vertical pass; xidx[tw], yidx[th]: source
+ * index of the nearest-neighbour resize; gap_*: padding on each side; (crop_i, crop_j): crop origin in the padded
+ * image; out_img f32 [3,out_h,out_w]; maps: MAS_ID_* / MAS_MAP_U8 in, int64 (or uint8 when out*_u8) out,
+ * pad value outside the scaled image.  map pointers may be NULL. */
+int mas_train_augment(const uint8_t* img, int H, int W, int th, int tw, const int32_t* hbounds, const int32_t* hk, int hks,
+                      const int32_t* vbounds, const int32_t* vk, int vks, const int32_t* xidx, const int32_t* yidx, int gap_y,
+                      int gap_x, int crop_i, int crop_j, int flip, int out_h, int out_w, const float* mean, const float* std,
+                      const uint8_t* fill, const void* map0, int map0_dtype, int64_t pad0, void* out_map0, int out0_u8,
+                      const void* map1, int map1_dtype, int64_t pad1, void* out_map1, int out1_u8, float* out_img, void* stream);
 
 #ifdef __cplusplus
 }

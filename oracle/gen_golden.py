@@ -414,6 +414,48 @@ def gen_g8():
     np.savez_compressed(os.path.join(OUT, "g8_sliding.npz"), **out)
 
 
+def gen_g9():
+    """Training-time geometry with REAL Pillow calls in the reference's order
+    (dataloader/transform.py:105-113, ext_transforms.py:172-192, 443-520, 323-341, 384-437): resize (BILINEAR / NEAREST),
+    ImageOps.expand padding, crop, horizontal flip, to-tensor, normalise.  torchvision's functional ops on PIL images
+    are thin wrappers over exactly these calls."""
+    import random
+    from PIL import Image, ImageOps
+    from oracle import augment
+    mean, std = [0.485, 0.456, 0.406], [0.229, 0.224, 0.225]
+    out = {}
+    cases = []
+    for k, (seed, H, W, crop, nseg) in enumerate(((1, 40, 64, (32, 32), 50), (2, 40, 64, (32, 32), 50), (3, 33, 47, (40, 40), 30),
+                                                 (4, 40, 64, (32, 32), 50), (5, 24, 48, (24, 48), 20), (6, 61, 37, (32, 32), 64))):
+        rs = np.random.RandomState(900 + seed)
+        img = rs.randint(0, 256, size=(H, W, 3)).astype(np.uint8)
+        lbl = rs.randint(0, 19, size=(H, W)).astype(np.uint8)
+        spx = rs.randint(0, nseg, size=(H, W)).astype(np.int32)
+        rng = random.Random(seed)
+        p = augment.draw_params(rng, H, W, crop, scale_range=(1.0, 1.0) if seed == 5 else (0.5, 2.0))
+        pim = Image.fromarray(img).resize((p['tw'], p['th']), Image.BILINEAR)
+        plb = Image.fromarray(lbl).resize((p['tw'], p['th']), Image.NEAREST)
+        psp = Image.fromarray(spx).convert('I').resize((p['tw'], p['th']), Image.NEAREST)
+        for gap, border in ((p['gap_y'], lambda g: (0, g, 0, g)), (p['gap_x'], lambda g: (g, 0, g, 0))):
+            if gap:
+                pim = ImageOps.expand(pim, border=border(gap), fill=(124, 116, 104))
+                plb = ImageOps.expand(plb, border=border(gap), fill=255)
+                psp = ImageOps.expand(psp, border=border(gap), fill=nseg)
+        box = (p['j'], p['i'], p['j'] + crop[1], p['i'] + crop[0])
+        pim, plb, psp = pim.crop(box), plb.crop(box), psp.crop(box)
+        if p['flip']:
+            pim, plb, psp = [im.transpose(Image.FLIP_LEFT_RIGHT) for im in (pim, plb, psp)]
+        t = torch.from_numpy(np.array(pim, dtype=np.uint8).transpose(2, 0, 1).copy()).to(torch.float32).div(255)
+        t = t.sub(torch.tensor(mean)[:, None, None]).div(torch.tensor(std)[:, None, None])
+        out['img_%d' % k] = t.numpy()
+        out['lbl_%d' % k] = np.array(plb, dtype=np.uint8)
+        out['spx_%d' % k] = np.array(psp, dtype=np.int64)
+        cases.append([seed, H, W, crop[0], crop[1], nseg, p['th'], p['tw'], p['gap_y'], p['gap_x'], p['i'], p['j'], int(p['flip'])])
+        print("g9", cases[-1])
+    out['cases'] = np.array(cases)
+    np.savez_compressed(os.path.join(OUT, "g9_augment.npz"), **out)
+
+
 if __name__ == "__main__":
     refshim.install()
     os.makedirs(OUT, exist_ok=True)
@@ -426,5 +468,6 @@ if __name__ == "__main__":
     gen_g6()
     gen_g7()
     gen_g8()
+    gen_g9()
     for f in sorted(os.listdir(OUT)):
         print(f, os.path.getsize(os.path.join(OUT, f)))

@@ -1,0 +1,87 @@
+"""mas_train_augment (csrc/augment.hip) == the numpy oracle == Pillow goldens, bit for bit (floats included)."""
+import os
+import random
+
+import numpy as np
+import pytest
+import torch
+
+from test_augment_cpu import GOLD, MEAN, STD, case_inputs
+
+pytestmark = pytest.mark.gpu
+
+
+def _gpu():
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from mulactseg_amd.dataloader import device_transforms
+    return device_transforms
+
+
+def test_goldens_bit_exact():
+    dt = _gpu()
+    g = np.load(GOLD)
+    for k, row in enumerate(g['cases']):
+        seed, H, W, crop, nseg, img, lbl, spx = case_inputs(row)
+        aug = dt.DeviceTrainAugment(size=crop, scale_range=(1.0, 1.0) if seed == 5 else (0.5, 2.0), pad_values=[255, nseg],
+                                    rng=random.Random(seed))
+        t, (l2, s2) = aug(torch.from_numpy(img).cuda(), [torch.from_numpy(lbl).cuda(), torch.from_numpy(spx).cuda()])
+        assert np.array_equal(t.cpu().numpy(), g['img_%d' % k])
+        assert l2.dtype == torch.uint8 and np.array_equal(l2.cpu().numpy(), g['lbl_%d' % k])
+        assert s2.dtype == torch.int64 and np.array_equal(s2.cpu().numpy(), g['spx_%d' % k])
+
+
+@pytest.mark.parametrize("seed,H,W,crop", [(11, 256, 512, (192, 192)), (12, 256, 512, (192, 192)), (13, 130, 75, (96, 128)),
+                                           (14, 1024, 2048, (768, 768))])
+def test_matches_oracle_on_larger_shapes(seed, H, W, crop):
+    dt = _gpu()
+    from oracle import augment
+    rs = np.random.RandomState(seed)
+    img = rs.randint(0, 256, size=(H, W, 3)).astype(np.uint8)
+    spx = rs.randint(0, 2048, size=(H, W)).astype(np.int64)
+    lbl = rs.randint(0, 20, size=(H, W)).astype(np.uint8)
+    p = dt.draw_params(random.Random(seed), H, W, crop)
+    aug = dt.DeviceTrainAugment(size=crop, pad_values=[255, 2048], keep_u8=False)
+    t, (l2, s2) = aug(torch.from_numpy(img).cuda(), [torch.from_numpy(lbl).cuda(), torch.from_numpy(spx).cuda()], params=p)
+    te, (le, se) = augment.train_augment(img, [lbl, spx], [255, 2048], p, crop, MEAN, STD)
+    assert np.array_equal(t.cpu().numpy(), te)
+    assert np.array_equal(l2.cpu().numpy(), le) and np.array_equal(s2.cpu().numpy(), se)
+
+
+def test_rejects_host_tensors():
+    dt = _gpu()
+    with pytest.raises(ValueError):
+        dt.DeviceTrainAugment()(torch.zeros((8, 8, 3), dtype=torch.uint8), [])
+
+
+def test_resident_region_dataset_samples():
+    """dataloader/resident.py: sample dictionary of the reference's region dataset from resident tensors; the mask is
+    np.isin(spx, selected ids) and the pad id is never selected; pool items are the normalised full picture."""
+    _gpu()
+    import types
+    from mulactseg_amd.dataloader.resident import ResidentRegionDataset
+    rs = np.random.RandomState(5)
+    nseg, n = 40, 3
+    pics = [torch.from_numpy(rs.randint(0, 256, size=(96, 160, 3)).astype(np.uint8)).cuda() for _ in range(n)]
+    spxs = [torch.from_numpy(rs.randint(0, nseg, size=(96, 160)).astype(np.int16)).cuda() for _ in range(n)]
+    mh = torch.from_numpy(rs.randint(0, 2, size=(n, nseg, 20)).astype(np.uint8)).cuda()
+    names = [("img%d.png" % i, "lbl%d.png" % i, "spx%d.pkl" % i) for i in range(n)]
+    args = types.SimpleNamespace(nseg=nseg, ignore_idx=255)
+    region = {"spx0.pkl": [1, 5, 7], "spx2.pkl": [0, 39]}
+    ds = ResidentRegionDataset(args, pics, spxs, mh, names, split='active-label', region_dict=region, rng=random.Random(3))
+    ds.transform.size = (64, 64)
+    assert len(ds) == 2 and ds.im_idx[1] == names[2]
+    for idx in range(2):
+        s = ds[idx]
+        assert tuple(s['images'].shape) == (3, 64, 64) and s['images'].dtype == torch.float32
+        assert s['spx'].dtype == torch.int64 and tuple(s['spmask'].shape) == (64, 64)
+        sel = region[s['fnames'][2]]
+        assert np.array_equal(s['spmask'].cpu().numpy(), np.isin(s['spx'].cpu().numpy(), sel))
+        assert not bool(s['spmask'][s['spx'] == nseg].any())
+        assert torch.equal(s['labels'], mh[ds.names[s['fnames'][2]]])
+    pool = ResidentRegionDataset(args, pics, spxs, mh, names, split='active-ulabel')
+    item = pool[1]
+    ref = pics[1].cpu().numpy().transpose(2, 0, 1).astype(np.float32) / np.float32(255)       # true division, as to_tensor on the CPU
+    ref = (ref - np.asarray(MEAN, np.float32)[:, None, None]) / np.asarray(STD, np.float32)[:, None, None]
+    assert np.array_equal(item['images'].cpu().numpy(), ref) and torch.equal(item['spx'], spxs[1].long())
+    assert sorted(pool.suppix["spx1.pkl"]) == list(range(nseg))

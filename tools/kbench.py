@@ -92,6 +92,36 @@ def main():
             ops.partial_loss_bwd(zz, spx, msk, bits, gmax, acc, go, invT, flags)
         med, mn = timeit(fbwd)
         print("loss bwd (scales+scan) median %.1f us min %.1f us -> dz write %.2f TB/s" % (med, mn, zz.numel() * 4 / med / 1e6))
+    if 'augment' in which:
+        import random
+        from mulactseg_amd.dataloader import device_transforms as dtm
+        rs = np.random.RandomState(0)
+        Hh, Ww = 1024, 2048
+        img = torch.from_numpy(rs.randint(0, 256, size=(Hh, Ww, 3)).astype(np.uint8)).to(dev)
+        lbl = torch.from_numpy(rs.randint(0, 20, size=(Hh, Ww)).astype(np.uint8)).to(dev)
+        spx = torch.from_numpy(rs.randint(0, 2048, size=(Hh, Ww)).astype(np.int16)).to(dev)
+        aug = dtm.DeviceTrainAugment(rng=random.Random(0))
+        t0 = time.perf_counter()
+        for _ in range(50):
+            aug(img, [lbl, spx])
+        torch.cuda.synchronize()
+        print("augment 1024x2048 -> 768x768 (picture + 2 maps): %.3f ms per sample wall (host tables + H2D + kernel)" % ((time.perf_counter() - t0) / 50 * 1e3))
+        med, mn = timeit(lambda: aug(img, [lbl, spx], params=dtm.draw_params(random.Random(1), Hh, Ww, (768, 768))))
+        print("augment fixed params: event median %.1f us" % med)
+        try:
+            from PIL import Image
+            pim, plb, psp = Image.fromarray(img.cpu().numpy()), Image.fromarray(lbl.cpu().numpy()), Image.fromarray(spx.cpu().numpy().astype(np.int32)).convert('I')
+            rng = random.Random(0)
+            t0 = time.perf_counter()
+            for _ in range(10):
+                p = dtm.draw_params(rng, Hh, Ww, (768, 768))
+                a = pim.resize((p['tw'], p['th']), Image.BILINEAR); b = plb.resize((p['tw'], p['th']), Image.NEAREST); c = psp.resize((p['tw'], p['th']), Image.NEAREST)
+                box = (max(p['j'] - p['gap_x'], 0), max(p['i'] - p['gap_y'], 0), min(p['j'] - p['gap_x'] + 768, p['tw']), min(p['i'] - p['gap_y'] + 768, p['th']))
+                t = torch.from_numpy(np.array(a.crop(box), dtype=np.uint8).transpose(2, 0, 1).copy()).float().div(255)
+                np.array(b.crop(box)); np.array(c.crop(box), dtype=np.int64)
+            print("Pillow on one host core (resize + crop + to-tensor, no pad/flip): %.1f ms per sample" % ((time.perf_counter() - t0) / 10 * 1e3))
+        except ImportError:
+            pass
 
 
 if __name__ == "__main__":
