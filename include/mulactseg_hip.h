@@ -295,6 +295,12 @@ int mas_train_augment(const uint8_t* img, int H, int W, int th, int tw, const in
                       const uint8_t* fill, const void* map0, int map0_dtype, int64_t pad0, void* out_map0, int out0_u8,
                       const void* map1, int map1_dtype, int64_t pad1, void* out_map1, int out1_u8, float* out_img, void* stream);
 
+/* K8 (part): F.interpolate(mode='bilinear', align_corners=False) of x [NC,Hi,Wi] -> y [NC,Ho,Wo]
+ * (models/segmentation/utils.py:25, deeplabv3.py:116) and its backward as a deterministic gather (no atomics).
+ * bwd requires Wo <= 6 * Wi. */
+int mas_upsample_bilinear_fwd(const float* x, int64_t NC, int Hi, int Wi, int Ho, int Wo, float* y, void* stream);
+int mas_upsample_bilinear_bwd(const float* gy, int64_t NC, int Hi, int Wi, int Ho, int Wo, float* gx, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

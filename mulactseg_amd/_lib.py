@@ -45,6 +45,8 @@ SIGNATURES = {
     "mas_aspp_dw3_bwd_w": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp]),
     "mas_train_augment": (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _i, _vp, _vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp,
                                _vp, _i, _i64, _vp, _i, _vp, _i, _i64, _vp, _i, _vp, _vp]),
+    "mas_upsample_bilinear_fwd": (_i, [_vp, _i64, _i, _i, _i, _i, _vp, _vp]),
+    "mas_upsample_bilinear_bwd": (_i, [_vp, _i64, _i, _i, _i, _i, _vp, _vp]),
     "mas_depthwise3x3_fwd": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp, _vp]),
     "mas_depthwise3x3_bwd_x": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp, _vp]),
     "mas_depthwise3x3_bwd_w": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp]),

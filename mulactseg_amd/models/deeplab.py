@@ -129,13 +129,24 @@ def _conv3x3(cin, cout, dilation, separable):
     return nn.Conv2d(cin, cout, 3, padding=dilation, dilation=dilation, bias=False)
 
 
+def _upsample(x, size):
+    """F.interpolate(bilinear, align_corners=False); on the GPU the HIP kernels of csrc/upsample.hip (same index and
+    weight arithmetic, deterministic gather backward instead of ATen's atomic scatter)."""
+    if x.is_cuda:
+        from .. import ops
+        if ops.upsample_bilinear_supported(x, size):
+            return ops.upsample_bilinear(x, size)
+    return F.interpolate(x, size=size, mode='bilinear', align_corners=False)
+
+
 class _ASPPPooling(nn.Sequential):
     def __init__(self, cin, cout):
         super().__init__(nn.AdaptiveAvgPool2d(1), nn.Conv2d(cin, cout, 1, bias=False), nn.BatchNorm2d(cout), nn.ReLU(inplace=True))
 
     def forward(self, x):
-        size = x.shape[-2:]
-        return F.interpolate(super().forward(x), size=size, mode='bilinear', align_corners=False)
+        # bilinear upsampling of a 1x1 map is a broadcast (F.interpolate differs from it by the rounding of l0*v + l1*v);
+        # ATen's backward for it is 2 304 atomic adds into ONE element per channel: 1.1 ms per step
+        return super().forward(x).expand(-1, -1, x.shape[-2], x.shape[-1])
 
 
 class ASPP(nn.Module):
@@ -195,7 +206,7 @@ class DeepLabHeadV3PlusWN(nn.Module):
     def point_feature(self, feature):
         low = self.project(feature['low_level'])
         x = self.aspp(feature['out'])
-        x = F.interpolate(x, size=low.shape[2:], mode='bilinear', align_corners=False)
+        x = _upsample(x, low.shape[2:])
         return self.classifier(torch.cat([low, x], dim=1))
 
     def forward(self, feature):
@@ -231,7 +242,7 @@ class DeepLabV3PlusWN(nn.Module):
     def forward(self, x):
         size = x.shape[-2:]
         y = self.classifier(self.backbone(x))
-        return F.interpolate(y, size=size, mode='bilinear', align_corners=False)
+        return _upsample(y, size)
 
     def feat_forward_lowres(self, x):
         """(L2-normalised point features at 1/4 resolution [N,256,H/4,W/4], logits upsampled to the input size):
@@ -244,7 +255,7 @@ class DeepLabV3PlusWN(nn.Module):
             feat, prob = self.classifier(self.backbone(x))
         finally:
             self.classifier.return_feat = keep
-        return feat, F.interpolate(prob, size=size, mode='bilinear', align_corners=False)
+        return feat, _upsample(prob, size)
 
     def feat_forward(self, x):
         size = x.shape[-2:]
@@ -254,8 +265,7 @@ class DeepLabV3PlusWN(nn.Module):
             feat, prob = self.classifier(self.backbone(x))
         finally:
             self.classifier.return_feat = keep
-        return (F.interpolate(feat, size=size, mode='bilinear', align_corners=False),
-                F.interpolate(prob, size=size, mode='bilinear', align_corners=False))
+        return _upsample(feat, size), _upsample(prob, size)
 
 
 def build_deeplabv3pluswn(num_classes, output_stride=16, layers=(3, 4, 6, 3), separable=True):

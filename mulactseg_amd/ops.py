@@ -520,3 +520,38 @@ def depthwise3x3(x, w, dilation):
     if tuple(w.shape) != (x.shape[1], 1, 3, 3):
         raise ValueError("depthwise weight must be [C,1,3,3]")
     return _Depthwise3x3.apply(x, w, int(dilation))
+
+
+class _UpsampleBilinear(torch.autograd.Function):
+    """F.interpolate(x, size, mode='bilinear', align_corners=False) with a deterministic gather backward."""
+
+    @staticmethod
+    def forward(ctx, x, Ho, Wo):
+        x = x.contiguous()
+        N, C, Hi, Wi = x.shape
+        y = torch.empty((N, C, Ho, Wo), dtype=torch.float32, device=x.device)
+        with torch.cuda.device(x.device):
+            _lib.check(_lib.load().mas_upsample_bilinear_fwd(x.data_ptr(), N * C, Hi, Wi, Ho, Wo, y.data_ptr(), _stream(x)),
+                       "mas_upsample_bilinear_fwd")
+        ctx.shape = (N, C, Hi, Wi, Ho, Wo)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        N, C, Hi, Wi, Ho, Wo = ctx.shape
+        g = g.contiguous()
+        gx = torch.empty((N, C, Hi, Wi), dtype=torch.float32, device=g.device)
+        with torch.cuda.device(g.device):
+            _lib.check(_lib.load().mas_upsample_bilinear_bwd(g.data_ptr(), N * C, Hi, Wi, Ho, Wo, gx.data_ptr(), _stream(g)),
+                       "mas_upsample_bilinear_bwd")
+        return gx, None, None
+
+
+def upsample_bilinear_supported(x, size):
+    return (x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and int(size[1]) <= 6 * x.shape[3] and int(size[0]) >= x.shape[2]
+            and int(size[1]) >= x.shape[3] and x.shape[0] * x.shape[1] <= 65535 and int(size[0]) <= 65535)
+
+
+def upsample_bilinear(x, size):
+    _need(x, "x", torch.float32)
+    return _UpsampleBilinear.apply(x, int(size[0]), int(size[1]))
