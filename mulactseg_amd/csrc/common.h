@@ -184,6 +184,14 @@ __device__ __forceinline__ void mas_softmax_quad(mas_v2f (&xa)[CT], mas_v2f (&xb
     rinv_b = (mas_v2f){1.0f / sb.x, 1.0f / sb.y};
 }
 
+// LDS adds carry workgroup scope, the global fallbacks agent scope: with the same scope on both the compiler
+// if-converts "LDS slot or global" into a pointer select and ONE flat_atomic, and a pending FLAT operation forces
+// s_waitcnt vmcnt(0) -- which would drain the prefetched row in the middle of the pipeline.
+template <typename T>
+__device__ __forceinline__ void lds_add(T* p, T v) {
+    (void)__hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+
 // BvSB margins of four pixels (mas_bvsb element-wise: exp_np(z2*invT - z1*invT) + 1e-8) on packed pairs, and their
 // fixed-point quanta.  mas_fix_unit(v) == mas_fix(v, MAS_SCORE_FRAC) for 0 < v < 2 (a margin lies in [1e-8, 1 + 1e-8]):
 // the shift count is e - 110 in [-27, 17], so one 64-bit left shift or one 32-bit right shift suffices.

@@ -200,18 +200,20 @@ __global__ __launch_bounds__(kThreads) void k_bvsb_region_accum(const float* __r
                 }
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
+                    // top-2 as two medians (single_pass.hip:ring_consume): same values, ties keep the lowest class
                     const bool g1 = v[k] > b1[k];
-                    const bool g2 = v[k] > b2[k];
-                    b2[k] = g1 ? b1[k] : (g2 ? v[k] : b2[k]);
+                    b2[k] = __builtin_amdgcn_fmed3f(b1[k], b2[k], v[k]);
                     a1[k] = g1 ? c : a1[k];
-                    b1[k] = g1 ? v[k] : b1[k];
+                    b1[k] = __builtin_amdgcn_fmed3f(b1[k], v[k], 3.402823466e+38f);
                 }
             }
         }
         mas_u64 q[4];
+        float margin[4];
+        mas_bvsb_quad(b1, b2, invT, margin);
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-            float v = mas_bvsb(b1[k], b2[k], invT);
+            float v = margin[k];
             if (cls_w) v = v * s_w[a1[k]];
             q[k] = mas_fix(v, MAS_SCORE_FRAC);
         }
@@ -222,11 +224,11 @@ __global__ __launch_bounds__(kThreads) void k_bvsb_region_accum(const float* __r
                 const int s = table_slot(t.keys, id[0]);
                 const bool same_a = (a1[0] == a1[1]) && (a1[1] == a1[2]) && (a1[2] == a1[3]);
                 if (s >= 0) {
-                    atomicAdd(&t.sum[s], qs);
-                    if (same_a) atomicAdd(&t.hist[s * C + a1[0]], 4u);
+                    lds_add(&t.sum[s], qs);
+                    if (same_a) lds_add(&t.hist[s * C + a1[0]], 4u);
                     else {
 #pragma unroll
-                        for (int k = 0; k < 4; ++k) atomicAdd(&t.hist[s * C + a1[k]], 1u);
+                        for (int k = 0; k < 4; ++k) lds_add(&t.hist[s * C + a1[k]], 1u);
                     }
                 } else {
                     atomicAdd(&gsum[id[0]], qs);
@@ -240,8 +242,8 @@ __global__ __launch_bounds__(kThreads) void k_bvsb_region_accum(const float* __r
                 if (id[k] < 0) continue;
                 const int s = table_slot(t.keys, id[k]);
                 if (s >= 0) {
-                    atomicAdd(&t.sum[s], q[k]);
-                    atomicAdd(&t.hist[s * C + a1[k]], 1u);
+                    lds_add(&t.sum[s], q[k]);
+                    lds_add(&t.hist[s * C + a1[k]], 1u);
                 } else {
                     atomicAdd(&gsum[id[k]], q[k]);
                     atomicAdd(&ghist[(size_t)id[k] * C + a1[k]], 1u);

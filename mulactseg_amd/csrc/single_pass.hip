@@ -39,14 +39,6 @@ __device__ __forceinline__ int table_slot(int* keys, int id) {
     return -1;
 }
 
-// LDS adds carry workgroup scope, the global fallbacks agent scope: with the same scope on both the compiler
-// if-converts "LDS slot or global" into a pointer select and ONE flat_atomic, and a pending FLAT operation forces
-// s_waitcnt vmcnt(0) -- which would drain the prefetched row in the middle of the pipeline.
-template <typename T>
-__device__ __forceinline__ void lds_add(T* p, T v) {
-    (void)__hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-}
-
 template <int CT, bool EXACT, typename IdT, bool VEC>
 __global__ __launch_bounds__(kThreads) void k_single_pass(const float* __restrict__ z, const IdT* __restrict__ spx, int C, int H,
                                                            int W, int S, float invT, int tiles_x, int tiles_y,
