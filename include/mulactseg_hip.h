@@ -301,6 +301,24 @@ int mas_train_augment(const uint8_t* img, int H, int W, int th, int tw, const in
 int mas_upsample_bilinear_fwd(const float* x, int64_t NC, int Hi, int Wi, int Ho, int Wo, float* y, void* stream);
 int mas_upsample_bilinear_bwd(const float* gy, int64_t NC, int Hi, int Wi, int Ho, int Wo, float* gx, void* stream);
 
+/* BatchNorm2d fused with the following ReLU and residual add (models/segmentation/backbone/resnet.py:143-160 Bottleneck,
+ * the conv -> bn -> relu triples of the stem / ASPP / decoder, deeplabv3.py:93-110,216-245).  x, y, residual: [N,C,HW]
+ * f32 NCHW; gamma / beta may be NULL (affine=False).  Deterministic reductions (fixed order, double).
+ * train_fwd: batch statistics (biased variance for the normalisation, unbiased for running_var, momentum update as
+ * torch.nn.BatchNorm2d; running_* / num_batches_tracked may be NULL), y = relu?((x-mean)*invstd*gamma+beta+residual);
+ * saves mean / invstd [C] for the backward.  workspace: mas_bn_workspace_bytes(N, C, HW) bytes of device memory.
+ * train_bwd: dx, dresidual (= masked dy; may be NULL), dgamma, dbeta (may be NULL); `y` is the forward output (ReLU mask).
+ * eval_fwd: the same map with the running statistics. */
+int64_t mas_bn_workspace_bytes(int N, int C, int HW);
+int mas_bn_act_train_fwd(const float* x, const float* gamma, const float* beta, const float* residual, int N, int C, int HW, float eps,
+                         float momentum, int relu, float* running_mean, float* running_var, int64_t* num_batches_tracked,
+                         float* save_mean, float* save_invstd, void* workspace, float* y, void* stream);
+int mas_bn_act_eval_fwd(const float* x, const float* gamma, const float* beta, const float* running_mean, const float* running_var,
+                        const float* residual, int N, int C, int HW, float eps, int relu, float* y, void* stream);
+int mas_bn_act_train_bwd(const float* dy, const float* x, const float* y, const float* gamma, const float* save_mean,
+                         const float* save_invstd, int N, int C, int HW, int relu, void* workspace, float* dx, float* dresidual,
+                         float* dgamma, float* dbeta, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

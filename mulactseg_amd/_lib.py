@@ -47,6 +47,10 @@ SIGNATURES = {
                                _vp, _i, _i64, _vp, _i, _vp, _i, _i64, _vp, _i, _vp, _vp]),
     "mas_upsample_bilinear_fwd": (_i, [_vp, _i64, _i, _i, _i, _i, _vp, _vp]),
     "mas_upsample_bilinear_bwd": (_i, [_vp, _i64, _i, _i, _i, _i, _vp, _vp]),
+    "mas_bn_workspace_bytes": (_i64, [_i, _i, _i]),
+    "mas_bn_act_train_fwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _f, _f, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "mas_bn_act_eval_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _f, _i, _vp, _vp]),
+    "mas_bn_act_train_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
     "mas_depthwise3x3_fwd": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp, _vp]),
     "mas_depthwise3x3_bwd_x": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp, _vp]),
     "mas_depthwise3x3_bwd_w": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp]),

@@ -21,6 +21,34 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 
+def _bn_act(bn, x, relu=True, residual=None):
+    """relu(bn(x) + residual): on the GPU one fused pass (csrc/bn.hip) instead of BatchNorm, add and ReLU kernels."""
+    if x.is_cuda:
+        from .. import ops
+        if ops.bn_act_supported(bn, x, residual):
+            return ops.bn_act(bn, x, relu, residual)
+    y = bn(x)
+    if residual is not None:
+        y = y + residual
+    return F.relu(y) if relu else y
+
+
+def _run(seq, x):
+    """nn.Sequential forward with every (BatchNorm2d, ReLU) pair fused; other modules run as they are."""
+    mods = list(seq)
+    i = 0
+    while i < len(mods):
+        m = mods[i]
+        if isinstance(m, nn.BatchNorm2d):
+            relu = i + 1 < len(mods) and isinstance(mods[i + 1], nn.ReLU)
+            x = _bn_act(m, x, relu)
+            i += 2 if relu else 1
+        else:
+            x = m(x)
+            i += 1
+    return x
+
+
 # ------------------------------------------------------------------------------------------------
 # backbone
 # ------------------------------------------------------------------------------------------------
@@ -40,13 +68,11 @@ class Bottleneck(nn.Module):
         self.stride = stride
 
     def forward(self, x):
-        y = self.relu(self.bn1(self.conv1(x)))
-        y = self.relu(self.bn2(self.conv2(y)))
-        y = self.bn3(self.conv3(y))
+        y = _bn_act(self.bn1, self.conv1(x))
+        y = _bn_act(self.bn2, self.conv2(y))
         if self.downsample is not None:
-            x = self.downsample(x)
-        y += x
-        return self.relu(y)
+            x = _run(self.downsample, x)
+        return _bn_act(self.bn3, self.conv3(y), True, x)
 
 
 class DeepStemResNetTrunk(nn.Module):
@@ -95,7 +121,7 @@ class DeepStemResNetTrunk(nn.Module):
         return nn.Sequential(*mods)
 
     def forward(self, x):
-        x = self.maxpool(self.relu(self.bn1(self.conv1(x))))
+        x = self.maxpool(_bn_act(self.bn1, _run(self.conv1, x)))
         low = self.layer1(x)
         out = self.layer4(self.layer3(self.layer2(low)))
         return OrderedDict(low_level=low, out=out)
@@ -146,7 +172,7 @@ class _ASPPPooling(nn.Sequential):
     def forward(self, x):
         # bilinear upsampling of a 1x1 map is a broadcast (F.interpolate differs from it by the rounding of l0*v + l1*v);
         # ATen's backward for it is 2 304 atomic adds into ONE element per channel: 1.1 ms per step
-        return super().forward(x).expand(-1, -1, x.shape[-2], x.shape[-1])
+        return _run(self, x).expand(-1, -1, x.shape[-2], x.shape[-1])
 
 
 class ASPP(nn.Module):
@@ -177,12 +203,12 @@ class ASPP(nn.Module):
         fused = self._fused_depthwise(x)
         if fused is None:                          # CPU reference form (parity tests), or a non-separable head
             return self.project(torch.cat([conv(x) for conv in self.convs], dim=1))
-        outs = [self.convs[0](x)]
+        outs = [_run(self.convs[0], x)]
         for i, y in zip((1, 2, 3), fused):
             branch = self.convs[i]
-            outs.append(branch[2](branch[1](branch[0].body[1](y))))      # pointwise 1x1 -> BN -> ReLU
+            outs.append(_bn_act(branch[1], branch[0].body[1](y)))           # pointwise 1x1 -> BN + ReLU
         outs.append(self.convs[4](x))
-        return self.project(torch.cat(outs, dim=1))
+        return _run(self.project, torch.cat(outs, dim=1))
 
 
 class DeepLabHeadV3PlusWN(nn.Module):
@@ -204,10 +230,10 @@ class DeepLabHeadV3PlusWN(nn.Module):
                 nn.init.constant_(m.bias, 0)
 
     def point_feature(self, feature):
-        low = self.project(feature['low_level'])
+        low = _run(self.project, feature['low_level'])
         x = self.aspp(feature['out'])
         x = _upsample(x, low.shape[2:])
-        return self.classifier(torch.cat([low, x], dim=1))
+        return _run(self.classifier, torch.cat([low, x], dim=1))
 
     def forward(self, feature):
         feat = F.normalize(self.point_feature(feature))          # over channels, eps 1e-12

@@ -555,3 +555,87 @@ def upsample_bilinear_supported(x, size):
 def upsample_bilinear(x, size):
     _need(x, "x", torch.float32)
     return _UpsampleBilinear.apply(x, int(size[0]), int(size[1]))
+
+
+# ------------------------------------------------------------------------------------------------
+# BatchNorm2d + ReLU + residual add, fused (csrc/bn.hip)
+# ------------------------------------------------------------------------------------------------
+def _opt(t):
+    return t.data_ptr() if t is not None else None
+
+
+class _BNActTrain(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, weight, bias, residual, running_mean, running_var, num_batches_tracked, eps, momentum, relu):
+        x = x.contiguous()
+        N, C, H, W = x.shape
+        HW = H * W
+        dev = x.device
+        res = residual.contiguous() if residual is not None else None
+        lib = _lib.load()
+        ws = torch.empty(int(lib.mas_bn_workspace_bytes(N, C, HW)), dtype=torch.uint8, device=dev)
+        mean = torch.empty(C, dtype=torch.float32, device=dev)
+        invstd = torch.empty(C, dtype=torch.float32, device=dev)
+        y = torch.empty_like(x)
+        with torch.cuda.device(dev):
+            _lib.check(lib.mas_bn_act_train_fwd(x.data_ptr(), _opt(weight), _opt(bias), _opt(res), N, C, HW, float(eps), float(momentum),
+                                                int(relu), _opt(running_mean), _opt(running_var), _opt(num_batches_tracked),
+                                                mean.data_ptr(), invstd.data_ptr(), ws.data_ptr(), y.data_ptr(), _stream(x)),
+                       "mas_bn_act_train_fwd")
+        ctx.save_for_backward(x, y, weight, mean, invstd)
+        ctx.relu = bool(relu)
+        ctx.has_res = residual is not None
+        ctx.mark_non_differentiable(*[t for t in (running_mean, running_var, num_batches_tracked) if t is not None])
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, y, weight, mean, invstd = ctx.saved_tensors
+        N, C, H, W = x.shape
+        HW = H * W
+        dev = x.device
+        dy = dy.contiguous()
+        lib = _lib.load()
+        ws = torch.empty(int(lib.mas_bn_workspace_bytes(N, C, HW)), dtype=torch.uint8, device=dev)
+        dx = torch.empty_like(x)
+        dres = torch.empty_like(x) if (ctx.has_res and ctx.needs_input_grad[3]) else None
+        dg = torch.empty(C, dtype=torch.float32, device=dev) if (weight is not None and ctx.needs_input_grad[1]) else None
+        db = torch.empty(C, dtype=torch.float32, device=dev) if ctx.needs_input_grad[2] else None
+        with torch.cuda.device(dev):
+            _lib.check(lib.mas_bn_act_train_bwd(dy.data_ptr(), x.data_ptr(), y.data_ptr(), _opt(weight), mean.data_ptr(), invstd.data_ptr(),
+                                                N, C, HW, int(ctx.relu), ws.data_ptr(), dx.data_ptr(), _opt(dres), _opt(dg), _opt(db),
+                                                _stream(x)), "mas_bn_act_train_bwd")
+        if ctx.has_res and dres is None and ctx.needs_input_grad[3]:
+            dres = dy
+        return dx, dg, db, dres, None, None, None, None, None, None
+
+
+def bn_act_supported(bn, x, residual=None):
+    """Fused path: f32 NCHW GPU tensors; training mode (batch statistics) or inference without autograd.  A frozen
+    BatchNorm (eval mode with gradients flowing through it) stays on the PyTorch ops."""
+    if not (x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and x.shape[0] <= 65535 and x.shape[1] <= 65535):
+        return False
+    if residual is not None and (residual.shape != x.shape or residual.dtype != torch.float32):
+        return False
+    if bn.training:
+        return bn.momentum is not None and x.shape[0] * x.shape[2] * x.shape[3] > 1
+    if not bn.track_running_stats:
+        return False
+    return not (torch.is_grad_enabled() and (x.requires_grad or (residual is not None and residual.requires_grad)))
+
+
+def bn_act(bn, x, relu=True, residual=None):
+    """relu?(bn(x) + residual) for a ``torch.nn.BatchNorm2d`` module ``bn`` (parameters, running statistics and
+    ``num_batches_tracked`` are the module's own and are updated as PyTorch updates them)."""
+    if bn.training:
+        rm, rv, nbt = (bn.running_mean, bn.running_var, bn.num_batches_tracked) if bn.track_running_stats else (None, None, None)
+        return _BNActTrain.apply(x, bn.weight, bn.bias, residual, rm, rv, nbt, bn.eps, bn.momentum, relu)
+    x = x.contiguous()
+    N, C, H, W = x.shape
+    res = residual.contiguous() if residual is not None else None
+    y = torch.empty_like(x)
+    with torch.cuda.device(x.device):
+        _lib.check(_lib.load().mas_bn_act_eval_fwd(x.data_ptr(), _opt(bn.weight), _opt(bn.bias), bn.running_mean.data_ptr(),
+                                                   bn.running_var.data_ptr(), _opt(res), N, C, H * W, float(bn.eps), int(relu), y.data_ptr(),
+                                                   _stream(x)), "mas_bn_act_eval_fwd")
+    return y

@@ -1,0 +1,127 @@
+"""csrc/bn.hip (BatchNorm2d + ReLU + residual add, fused) against torch.nn.BatchNorm2d on the CPU in float64:
+forward, running statistics, all gradients, inference mode, determinism; model-level parity and a training step."""
+import copy
+
+import numpy as np
+import pytest
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+CASES = [(4, 8, 24, 32, True, True), (2, 16, 7, 9, True, False), (4, 64, 1, 1, True, False), (3, 5, 33, 37, False, True),
+         (2, 12, 96, 96, True, True), (1, 3, 5, 4, False, False)]
+
+
+def _gpu():
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from mulactseg_amd import ops
+    return ops
+
+
+def _ref(bn64, x, res, relu):
+    y = bn64(x)
+    if res is not None:
+        y = y + res
+    return F.relu(y) if relu else y
+
+
+@pytest.mark.parametrize("N,C,H,W,relu,with_res", CASES)
+def test_training_forward_backward_and_running_stats(N, C, H, W, relu, with_res):
+    ops = _gpu()
+    g = torch.Generator().manual_seed(N * 1000 + C * 10 + H)
+    x = torch.randn((N, C, H, W), generator=g) * 2 + 0.5
+    res = torch.randn((N, C, H, W), generator=g) if with_res else None
+    go = torch.randn((N, C, H, W), generator=g)
+    bn = nn.BatchNorm2d(C, momentum=0.1)
+    with torch.no_grad():
+        bn.weight.copy_(torch.rand(C, generator=g) + 0.5)
+        bn.bias.copy_(torch.randn(C, generator=g) * 0.3)
+        bn.running_mean.copy_(torch.randn(C, generator=g) * 0.1)
+        bn.running_var.copy_(torch.rand(C, generator=g) + 0.5)
+    ref_bn = copy.deepcopy(bn).double().train()
+    dev_bn = copy.deepcopy(bn).cuda().train()
+    xr = x.double().requires_grad_(True)
+    rr = res.double().requires_grad_(True) if with_res else None
+    yr = _ref(ref_bn, xr, rr, relu)
+    yr.backward(go.double())
+    xd = x.cuda().requires_grad_(True)
+    rd = res.cuda().requires_grad_(True) if with_res else None
+    assert ops.bn_act_supported(dev_bn, xd, rd)
+    yd = ops.bn_act(dev_bn, xd, relu, rd)
+    yd.backward(go.cuda())
+    tol = lambda ref: 2e-5 * max(1.0, float(ref.abs().max()))
+    assert float((yd.detach().double().cpu() - yr.detach()).abs().max()) < tol(yr.detach())
+    assert float((xd.grad.double().cpu() - xr.grad).abs().max()) < 5 * tol(xr.grad)
+    if with_res:
+        assert float((rd.grad.double().cpu() - rr.grad).abs().max()) < tol(rr.grad)
+    assert float((dev_bn.weight.grad.double().cpu() - ref_bn.weight.grad).abs().max()) < 20 * tol(ref_bn.weight.grad)
+    assert float((dev_bn.bias.grad.double().cpu() - ref_bn.bias.grad).abs().max()) < 20 * tol(ref_bn.bias.grad)
+    assert float((dev_bn.running_mean.double().cpu() - ref_bn.running_mean).abs().max()) < 1e-6
+    assert float((dev_bn.running_var.double().cpu() - ref_bn.running_var).abs().max()) < 1e-5
+    assert int(dev_bn.num_batches_tracked) == 1
+    # determinism: a second identical forward/backward gives the same bits
+    dev2 = copy.deepcopy(bn).cuda().train()
+    x2 = x.cuda().requires_grad_(True)
+    r2 = res.cuda().requires_grad_(True) if with_res else None
+    y2 = ops.bn_act(dev2, x2, relu, r2)
+    y2.backward(go.cuda())
+    assert torch.equal(y2, yd) and torch.equal(x2.grad, xd.grad) and torch.equal(dev2.weight.grad, dev_bn.weight.grad)
+
+
+@pytest.mark.parametrize("N,C,H,W,relu,with_res", CASES[:4])
+def test_inference_uses_running_statistics(N, C, H, W, relu, with_res):
+    ops = _gpu()
+    g = torch.Generator().manual_seed(C)
+    x = torch.randn((N, C, H, W), generator=g)
+    res = torch.randn((N, C, H, W), generator=g) if with_res else None
+    bn = nn.BatchNorm2d(C)
+    with torch.no_grad():
+        bn.weight.copy_(torch.rand(C, generator=g) + 0.5)
+        bn.bias.copy_(torch.randn(C, generator=g))
+        bn.running_mean.copy_(torch.randn(C, generator=g))
+        bn.running_var.copy_(torch.rand(C, generator=g) + 0.2)
+    bn.eval()
+    with torch.no_grad():
+        ref = _ref(copy.deepcopy(bn).double(), x.double(), res.double() if with_res else None, relu)
+        dev = copy.deepcopy(bn).cuda()
+        assert ops.bn_act_supported(dev, x.cuda(), res.cuda() if with_res else None)
+        y = ops.bn_act(dev, x.cuda(), relu, res.cuda() if with_res else None)
+    assert float((y.double().cpu() - ref).abs().max()) < 2e-6 * max(1.0, float(ref.abs().max()))
+    # a frozen BatchNorm inside a training graph is left to PyTorch
+    assert not ops.bn_act_supported(dev, x.cuda().requires_grad_(True))
+
+
+def test_model_training_step_matches_unfused_modules():
+    """One SGD step of a Bottleneck stack with the fused path vs the same modules run op by op."""
+    ops = _gpu()
+    from mulactseg_amd.models import deeplab
+    torch.manual_seed(0)
+    blk = deeplab.Bottleneck(32, 8, downsample=None).cuda().train()
+    ref = copy.deepcopy(blk)
+    x = torch.randn(4, 32, 20, 24, device='cuda')
+
+    def unfused(m, t):
+        y = F.relu(m.bn1(m.conv1(t)))
+        y = F.relu(m.bn2(m.conv2(y)))
+        return F.relu(m.bn3(m.conv3(y)) + t)
+
+    xa, xb = x.clone().requires_grad_(True), x.clone().requires_grad_(True)
+    ya, yb = blk(xa), unfused(ref, xb)
+    assert float((ya - yb).detach().abs().max()) < 1e-4
+    ya.square().mean().backward()
+    yb.square().mean().backward()
+    assert float((xa.grad - xb.grad).abs().max()) < 1e-5 * max(1.0, float(xb.grad.abs().max()))
+    for (n, p), (_, q) in zip(blk.named_parameters(), ref.named_parameters()):
+        assert float((p.grad - q.grad).abs().max()) < 2e-4 * max(1.0, float(q.grad.abs().max())), n
+    for (n, b), (_, c) in zip(blk.named_buffers(), ref.named_buffers()):
+        assert float((b.double() - c.double()).abs().max()) < 1e-5, n
+
+
+def test_model_golden_parity_with_fused_bn():
+    _gpu()
+    from test_model import _check, _load
+    g, net, x = _load()
+    _check(g, net.cuda(), x.cuda(), 1e-4)
