@@ -204,6 +204,49 @@ def acquisition_with_model_bench(args, dev, world):
                                    "forward twice per pool image" % (B, H, W)}}
 
 
+def stage2_bench(args, dev):
+    """BASELINE.json config 4: stage-2 pseudo-label generation for one 1024x2048 image -- (a) whole-image forward
+    (quarter-resolution features, interpolated inside the K9 kernels), (b) the sliding-window ensemble (crop 800,
+    stride 2/3: 8 windows, features summed at full resolution on the device).  15 % of the regions are selected."""
+    import torch.nn.functional as F
+    from mulactseg_amd import ops, synth
+    from mulactseg_amd.models import get_model
+    from mulactseg_amd.utils.sliding_evaluator_plbl import SlidingEval
+    C, H, W, S = args.classes, args.height, args.width, args.nseg
+    net = get_model('deeplabv3pluswn_resnet50deepstem', C, 16, True, pretrained_backbone=False).to(dev).eval()
+    g = torch.Generator(device=dev)
+    g.manual_seed(21)
+    image = torch.randn((1, 3, H, W), generator=g, device=dev)
+    spx = torch.from_numpy(synth.superpixel_map(77, H, W, S))[None].to(dev)
+    tgt = torch.from_numpy(synth.multi_hot_targets(78, S, C))[None].to(dev)
+    chosen = torch.from_numpy(np.random.RandomState(79).choice(S, size=int(0.15 * S), replace=False)).to(dev)
+    lut = torch.zeros(S, dtype=torch.bool, device=dev)
+    lut[chosen] = True
+    msk = lut[spx]
+    evaluator = SlidingEval(net, 800, 2 / 3, class_number=C)
+
+    def whole():
+        with torch.no_grad():
+            feats, out = net.feat_forward_lowres(image)
+            return ops.stage2_pseudo_labels(feats.contiguous(), out.contiguous(), tgt, msk, spx, True)
+
+    def sliding():
+        with torch.no_grad():
+            feats, out = evaluator(image)
+            return ops.stage2_pseudo_labels(F.normalize(feats[None], dim=1, p=2), out[None].contiguous(), tgt, msk, spx, True)
+
+    res = {}
+    for name, fn in (("whole_image", whole), ("sliding_800", sliding)):
+        fn()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(3):
+            lab = fn()
+        torch.cuda.synchronize()
+        res[name] = {"ms_per_image": (time.perf_counter() - t0) / 3 * 1e3, "labelled_fraction": float((lab != 255).float().mean())}
+    return {"metric": "stage-2 pseudo-label generation, ms per 1024x2048 image (model forward + K9 kernels)", **res}
+
+
 def pmc_traffic(kernel, default_shape):
     """HBM bytes per launch of `kernel` from the latest committed rocprofv3 --pmc summary
     (profiles/r*/..pmc_traffic.json, produced by profiles/summarize.py from separate FETCH_SIZE / WRITE_SIZE
@@ -341,6 +384,7 @@ def main():
     }
     out["train_iter"] = None if args.no_train else train_iter_bench(args, dev, world)
     out["acquisition_with_model"] = None if args.no_train else acquisition_with_model_bench(args, dev, world)
+    out["stage2"] = None if (args.no_train or rank != 0) else stage2_bench(args, dev)
     if rank == 0:
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(args, args.cpu_seconds)
