@@ -69,56 +69,10 @@ __device__ __forceinline__ float mas_vmax(float a, float b) {
     return r;
 }
 
-// mas_expf_np on two values
-__device__ __forceinline__ mas_v2f mas_expf_np2(mas_v2f x) {
-    const mas_v2f xc = {mas_vmax(x.x, -86.0f), mas_vmax(x.y, -86.0f)};
-    const mas_v2f magic = mas_splat(12582912.0f);
-    const mas_v2f t = mas_pk_fma(xc, mas_splat(1.44269504088896341f), magic);
-    const mas_v2f n = t - magic;
-    mas_v2f r = mas_pk_fma(n, mas_splat(-0.693359375f), xc);
-    r = mas_pk_fma(n, mas_splat(2.12194440e-4f), r);
-    mas_v2f p = mas_splat(1.9875691500e-4f);
-    p = mas_pk_fma(p, r, mas_splat(1.3981999507e-3f));
-    p = mas_pk_fma(p, r, mas_splat(8.3334519073e-3f));
-    p = mas_pk_fma(p, r, mas_splat(4.1665795894e-2f));
-    p = mas_pk_fma(p, r, mas_splat(1.6666665459e-1f));
-    p = mas_pk_fma(p, r, mas_splat(5.0000001201e-1f));
-    const mas_v2f y = mas_pk_fma(p, r * r, r) + mas_splat(1.0f);
-    return (mas_v2f){mas_u2f(mas_f2u(y.x) + (mas_f2u(t.x) << 23)), mas_u2f(mas_f2u(y.y) + (mas_f2u(t.y) << 23))};
-}
-
-// softmax of two pixels at once: x[c] = {z_c(pixel a), z_c(pixel b)} in, e_c (un-normalised) out; returns rinv.
-// KNOWN_MAX: the caller already holds the maxima of the raw logits (from its top-2 scan).
-template <int CT, bool EXACT, bool KNOWN_MAX = false>
-__device__ __forceinline__ mas_v2f mas_softmax_pair(mas_v2f (&x)[CT], int C, float invT, mas_v2f zmax = (mas_v2f){0.f, 0.f}) {
-    const int Cn = EXACT ? CT : C;
-    const mas_v2f it = mas_splat(invT);
-    if (!KNOWN_MAX) {
-        float m0 = x[0].x, m1 = x[0].y;
-#pragma unroll
-        for (int c = 1; c < CT; ++c) {
-            if (EXACT || c < Cn) {
-                m0 = mas_vmax(m0, x[c].x);
-                m1 = mas_vmax(m1, x[c].y);
-            }
-        }
-        zmax = (mas_v2f){m0, m1};
-    }
-    const mas_v2f negM = -(zmax * it);
-    mas_v2f sum = mas_splat(0.0f);
-#pragma unroll
-    for (int c = 0; c < CT; ++c) {
-        if (EXACT || c < Cn) {
-            x[c] = mas_expf_np2(mas_pk_fma(x[c], it, negM));
-            sum = (c == 0) ? x[c] : (sum + x[c]);
-        }
-    }
-    return (mas_v2f){1.0f / sum.x, 1.0f / sum.y};
-}
-
 // Two independent pairs at once, written interleaved: a single exp chain is ~17 DEPENDENT packed instructions and
 // the compiler does not interleave chains on its own, so one wave would stall on every instruction.  Same
-// arithmetic per element as mas_expf_np2.
+// arithmetic per element as the scalar mas_expf_np of detmath.h (clamp, magic-number rint, Cody-Waite, degree-5
+// polynomial, integer exponent add).
 __device__ __forceinline__ void mas_expf_np2x2(mas_v2f xa, mas_v2f xb, mas_v2f& ea, mas_v2f& eb) {
     const mas_v2f ca = {mas_vmax(xa.x, -86.0f), mas_vmax(xa.y, -86.0f)};
     const mas_v2f cb = {mas_vmax(xb.x, -86.0f), mas_vmax(xb.y, -86.0f)};
@@ -213,30 +167,4 @@ __device__ __forceinline__ mas_u64 mas_fix_unit(float v) {
     const mas_u64 up = (mas_u64)m << (sh & 31);
     const unsigned dn = m >> ((-sh) & 31);
     return sh >= 0 ? up : (mas_u64)dn;
-}
-
-// ------------------------------------------------------------------------------------------------
-// Wave-level segmented reduction over RUNS of equal keys in lane order (superpixel ids come in runs along a
-// row).  After the call, the lane for which the function returns true is the last lane of its run and holds the
-// run's total in (val, cnt); all other lanes must not use their values.  This turns a 64-way same-address LDS
-// atomic (serialised by the LDS unit) into one atomic per run.  6 Hillis-Steele steps on ds_bpermute shuffles.
-// ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ bool mas_wave_run_reduce(int key, mas_u64& val, unsigned& cnt) {
-    const int lane = threadIdx.x & (MAS_WAVE - 1);
-    const int prev = __shfl_up(key, 1, MAS_WAVE);
-    const bool head = (lane == 0) || (prev != key);
-    int f = head ? 1 : 0;
-#pragma unroll
-    for (int off = 1; off < MAS_WAVE; off <<= 1) {
-        const mas_u64 ov = __shfl_up(val, off, MAS_WAVE);
-        const unsigned oc = __shfl_up(cnt, off, MAS_WAVE);
-        const int of = __shfl_up(f, off, MAS_WAVE);
-        if (lane >= off && !f) {
-            val += ov;
-            cnt += oc;
-            f = of;
-        }
-    }
-    const int next_head = __shfl_down(head ? 1 : 0, 1, MAS_WAVE);
-    return (lane == MAS_WAVE - 1) || (next_head != 0);
 }
