@@ -110,3 +110,33 @@ def test_remaining_selectors_on_gpu_match_reference(tag, modname, method):
     tuples = sel.calculate_scores(fake_trainer('cuda:0'), FakePool(z, spx, im_idx, suppix))
     _, si, sid = tuples_to_arrays(tuples, im_idx)
     assert np.array_equal(si, g[tag + '_list_img']) and np.array_equal(sid, g[tag + '_list_id'])
+
+
+def test_pixbal_selector_under_an_initialised_rccl_group():
+    """The sharded code path (ShardPlan, all-gather of class sums and scores over RCCL, 'nccl' backend) with a process
+    group of one rank on the real device: same bits as the non-distributed run.  (N > 1 is covered under gloo in
+    tests/test_distributed_cpu.py; this checks that the collectives accept the engine's device tensors.)"""
+    _need_gpu()
+    import torch.distributed as dist
+    from mulactseg_amd.active_selection import my_bvsb_predclsbal_pwr_banignore as banignore
+    g = np.load(os.path.join(GOLDEN, "g1_pixbal_city.npz"))
+    z, spx, im_idx, suppix = g1_inputs(g)
+    tmp = tempfile.mkdtemp()
+    args = selector_args(val_batch_size=int(g['batch_size']), nseg=int(g['S']), model_save_dir=tmp, active_method='pixbal')
+    base = banignore.RegionSelector(args)
+    s0, h0 = base.calculate_scores_tensor(fake_trainer('cuda:0', tmp), FakePool(z, spx, im_idx, suppix), want_hist=True)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    dist.init_process_group("nccl", init_method="tcp://127.0.0.1:29613", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        sel = banignore.RegionSelector(args)
+        s1, h1 = sel.calculate_scores_tensor(fake_trainer('cuda:0', tmp), FakePool(z, spx, im_idx, suppix), want_hist=True)
+        assert torch.equal(s0, s1) and torch.equal(h0, h1)
+        assert np.array_equal(base.cls_weight.cpu().numpy(), sel.cls_weight.cpu().numpy())
+        for two_pass in (True,):
+            args2 = selector_args(val_batch_size=int(g['batch_size']), nseg=int(g['S']), model_save_dir=tmp, active_method='pixbal',
+                                  two_pass_scoring=two_pass)
+            s2, _ = banignore.RegionSelector(args2).calculate_scores_tensor(fake_trainer('cuda:0', tmp), FakePool(z, spx, im_idx, suppix),
+                                                                            want_hist=True)
+            assert np.allclose(s2.cpu().numpy(), s1.cpu().numpy(), rtol=1e-6, atol=1e-9)
+    finally:
+        dist.destroy_process_group()
