@@ -11,6 +11,7 @@ from .base import BaseTrainer
 
 class ActiveTrainer(BaseTrainer):
     predicts_ignore = True
+    extra_channels = 1          # the "undefined" channel of the Cityscapes models; 0 in the VOC twin (..._voc.py:21)
 
     def __init__(self, args, logger, selection_iter):
         self.selection_iter = selection_iter
@@ -18,7 +19,7 @@ class ActiveTrainer(BaseTrainer):
 
     def get_al_model(self):
         a = self.args
-        return get_model(model=a.model, num_classes=self.num_classes + 1, output_stride=a.output_stride,
+        return get_model(model=a.model, num_classes=self.num_classes + self.extra_channels, output_stride=a.output_stride,
                          separable_conv=a.separable_conv, pretrained_backbone=getattr(a, 'pretrained_backbone', True))
 
     def eval(self, active_set, selection_iter):

@@ -64,3 +64,15 @@ def test_slide_trainers_importable():
     for name in ("eval_slide", "active_slide", "eval_save_cosplbl_prop_includeonehot_slide"):
         m = importlib.import_module("mulactseg_amd.trainer." + name)
         assert hasattr(m, "ActiveTrainer")
+
+
+def test_voc_variants_importable_and_parser_defaults():
+    import importlib
+    for name in ("base_voc", "active_voc", "eval_within_multihot_voc", "eval_save_cosplbl_prop_includeonehot_voc"):
+        assert importlib.import_module("mulactseg_amd.trainer." + name)
+    from mulactseg_amd.trainer import eval_within_multihot, eval_within_multihot_voc, eval_save_cosplbl_prop_includeonehot_voc as voc
+    assert eval_within_multihot.ActiveTrainer.extra_channels == 1 and eval_within_multihot_voc.ActiveTrainer.extra_channels == 0
+    assert voc.ActiveTrainer.extra_channels == 0 and voc.ActiveTrainer.include_onehot
+    from mulactseg_amd.utils import common_voc
+    a = common_voc.get_parser().parse_args([])
+    assert a.num_classes == 21 and a.nseg == 32 and a.method == 'active_voc'
