@@ -11,8 +11,10 @@ Architecture and parameter names follow the reference so that checkpoints interc
 ``convert_to_separable_conv`` (``deeplabv3.py:249-261``) semantics are built in: every k > 1 conv of the HEAD
 is depthwise(k, dilation, no bias) followed by pointwise 1x1 (no bias), with nothing in between.
 
-This file is the plain PyTorch (MIOpen / hipBLASLt) form of the model; the HIP fast paths for the ASPP
-depthwise triple (K7) and the cosine head + upsample (K8) plug in underneath where available.
+Convolutions and GEMMs run on MIOpen / hipBLASLt (MFMA).  On the GPU the memory-bound layers around them take the
+HIP kernels of this package: BatchNorm + ReLU + residual add (csrc/bn.hip), every depthwise 3x3 (csrc/aspp.hip; the
+three ASPP dilations from one read of the feature map), the bilinear upsamplings (csrc/upsample.hip).  On the CPU the
+same modules run as plain PyTorch ops (parity tests against the executed reference, tests/test_model.py).
 """
 from collections import OrderedDict
 
