@@ -17,9 +17,12 @@ class ActiveTrainer(active.ActiveTrainer):
         return 0 if torch.isnan(loss) else loss
 
     def check_loss_sanity(self, loss):
-        if loss == 0:
+        """Reference semantics (``active_joint_multi.py:31-37``): a zero loss (no selected pixel in the batch) skips
+        the step, NaN raises.  One device->host read instead of the reference's two."""
+        v = float(loss)
+        if v == 0:
             return False
-        if torch.isnan(loss):
+        if v != v:
             raise ValueError("NaN loss")
         return True
 
@@ -37,9 +40,14 @@ class ActiveTrainer(active.ActiveTrainer):
             self.scheduler.step()
 
     def update_average_meter(self, values):
-        for key, value in values.items():
-            if self.check_loss_sanity(value):
-                self.am.add({key: value.detach().cpu().item()})
+        """All meters from ONE device->host transfer (the reference syncs twice per value)."""
+        keys = list(values)
+        host = torch.stack([values[k].detach().float().reshape(()) for k in keys]).cpu().tolist()
+        for key, v in zip(keys, host):
+            if v != v:
+                raise ValueError("NaN loss")
+            if v != 0:
+                self.am.add({key: v})
 
     def _batch(self):
         batch = next(self.train_dataset_loader)
