@@ -19,7 +19,7 @@ class ActiveTrainer(active.ActiveTrainer):
     def check_loss_sanity(self, loss):
         """Reference semantics (``active_joint_multi.py:31-37``): a zero loss (no selected pixel in the batch) skips
         the step, NaN raises.  One device->host read instead of the reference's two."""
-        v = float(loss)
+        v = float(loss.detach())
         if v == 0:
             return False
         if v != v:
