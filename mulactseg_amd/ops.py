@@ -585,7 +585,6 @@ class _BNActTrain(torch.autograd.Function):
         ctx.save_for_backward(x, y, weight, mean, invstd)
         ctx.relu = bool(relu)
         ctx.has_res = residual is not None
-        ctx.mark_non_differentiable(*[t for t in (running_mean, running_var, num_batches_tracked) if t is not None])
         return y
 
     @staticmethod
