@@ -212,3 +212,37 @@ def test_extreme_logits_stay_finite_and_exact():
     assert np.array_equal(ps.cpu().numpy().view(np.uint64), eps_) and np.array_equal(cs.cpu().numpy().view(np.uint64), ecs)
     tot = ps.cpu().numpy().view(np.uint64).sum(axis=1).astype(np.float64) / 2.0 ** 23 / (H * W)
     assert np.all(np.abs(tot - 1.0) < 1e-5)
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_randomised_shapes_and_dirty_ids(seed):
+    """Random shapes around the kernel-selection boundaries (ring kernel for W % 4 == 0 and H >= 64, one-row kernel
+    otherwise; 19/20/21 or runtime channel counts), random noise ids, ids outside [0, S) and negative ids:
+    all three scan kernels equal the C oracle bit for bit."""
+    ops = _gpu()
+    from oracle import exact
+    rs = np.random.RandomState(1000 + seed)
+    B = int(rs.randint(1, 3))
+    C = int(rs.choice([19, 20, 21, 5, 32]))
+    H = int(rs.choice([rs.randint(3, 64), rs.randint(64, 150)]))
+    W = int(rs.choice([4 * rs.randint(1, 150), rs.randint(5, 300)]))
+    S = int(rs.randint(2, 400))
+    z = (rs.standard_normal((B, C, H, W)) * rs.choice([0.3, 1.0, 3.0])).astype(np.float32)
+    spx = np.stack([synth.superpixel_map(seed * 7 + i, H, W, S) for i in range(B)]).astype(np.int64)
+    dirty = rs.uniform(size=spx.shape)
+    spx[dirty < 0.03] = -1                   # invalid: skipped
+    spx[(dirty >= 0.03) & (dirty < 0.06)] = S + int(rs.randint(0, 5))
+    spx[(dirty >= 0.06) & (dirty < 0.15)] = rs.randint(0, S, size=int(((dirty >= 0.06) & (dirty < 0.15)).sum()))
+    invT = ops.inv_temperature(float(rs.choice([0.1, 1.0])))
+    w = rs.uniform(0.2, 1.0, size=C).astype(np.float32)
+    zt, st = torch.from_numpy(z).cuda(), torch.from_numpy(spx).cuda()
+    eps_, ecs, eh = exact.single_pass_accum(z, spx, S, np.float32(invT))
+    for dtype in (torch.int64, torch.int32):
+        ps, cs, hh = ops.single_pass_accum(zt, st.to(dtype), S, invT)
+        assert np.array_equal(ps.cpu().numpy().view(np.uint64), eps_), (B, C, H, W, S, dtype)
+        assert np.array_equal(cs.cpu().numpy().view(np.uint64), ecs), (B, C, H, W, S, dtype)
+        assert np.array_equal(hh.cpu().numpy().view(np.uint32), eh), (B, C, H, W, S, dtype)
+    es, eh3 = exact.bvsb_region_accum(z, spx, w, S, np.float32(invT))
+    gs, gh = ops.bvsb_region_accum(zt, st, torch.from_numpy(w).cuda(), S, invT)
+    assert np.array_equal(gs.cpu().numpy().view(np.uint64), es) and np.array_equal(gh.cpu().numpy().view(np.uint32), eh3)
+    assert np.array_equal(ops.class_prob_sum(zt, invT).cpu().numpy().view(np.uint64), eps_)
