@@ -319,6 +319,14 @@ int mas_bn_act_train_bwd(const float* dy, const float* x, const float* y, const 
                          const float* save_invstd, int N, int C, int HW, int relu, void* workspace, float* dx, float* dresidual,
                          float* dgamma, float* dbeta, void* stream);
 
+/* K8: cosine classifier of DeepLabHeadV3PlusWN (models/segmentation/deeplabv3.py:121-124):
+ * logits[n,k,p] = <feat[n,:,p], proxy_hat[k,:]> / max(|feat[n,:,p]|, eps) for unit-norm proxies proxy_hat [K,Ch]
+ * (K in {19, 20, 21}); inv_norm [N,HW] is saved for the backward.  bwd: dfeat only (the proxy gradient is a GEMM). */
+int mas_cosine_head_fwd(const float* feat, const float* proxy_hat, int N, int Ch, int K, int HW, float eps, float* logits,
+                        float* inv_norm, void* stream);
+int mas_cosine_head_bwd(const float* feat, const float* proxy_hat, const float* logits, const float* inv_norm, const float* dlogits,
+                        int N, int Ch, int K, int HW, float* dfeat, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -51,6 +51,8 @@ SIGNATURES = {
     "mas_bn_act_train_fwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _f, _f, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "mas_bn_act_eval_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _f, _i, _vp, _vp]),
     "mas_bn_act_train_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "mas_cosine_head_fwd": (_i, [_vp, _vp, _i, _i, _i, _i, _f, _vp, _vp, _vp]),
+    "mas_cosine_head_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp]),
     "mas_depthwise3x3_fwd": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp, _vp]),
     "mas_depthwise3x3_bwd_x": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp, _vp]),
     "mas_depthwise3x3_bwd_w": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp]),

@@ -238,7 +238,13 @@ class DeepLabHeadV3PlusWN(nn.Module):
         return _run(self.classifier, torch.cat([low, x], dim=1))
 
     def forward(self, feature):
-        feat = F.normalize(self.point_feature(feature))          # over channels, eps 1e-12
+        pf = self.point_feature(feature)
+        if pf.is_cuda:
+            from .. import ops
+            if ops.cosine_head_supported(pf, self.proxy):
+                out = ops.cosine_head(pf, self.proxy)            # K8: one pass over the features (csrc/head.hip)
+                return (F.normalize(pf), out) if self.return_feat else out
+        feat = F.normalize(pf)                                   # over channels, eps 1e-12
         out = F.conv2d(feat, F.normalize(self.proxy, dim=1))     # cosine similarity in [-1, 1]
         return (feat, out) if self.return_feat else out
 

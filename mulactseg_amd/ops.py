@@ -638,3 +638,51 @@ def bn_act(bn, x, relu=True, residual=None):
                                                    bn.running_var.data_ptr(), _opt(res), N, C, H * W, float(bn.eps), int(relu), y.data_ptr(),
                                                    _stream(x)), "mas_bn_act_eval_fwd")
     return y
+
+
+# ------------------------------------------------------------------------------------------------
+# K8: cosine classifier (csrc/head.hip)
+# ------------------------------------------------------------------------------------------------
+class _CosineHead(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, feat, proxy_hat):
+        feat, proxy_hat = feat.contiguous(), proxy_hat.contiguous()
+        N, Ch, H, W = feat.shape
+        K = proxy_hat.shape[0]
+        logits = torch.empty((N, K, H, W), dtype=torch.float32, device=feat.device)
+        inv = torch.empty((N, H, W), dtype=torch.float32, device=feat.device)
+        with torch.cuda.device(feat.device):
+            _lib.check(_lib.load().mas_cosine_head_fwd(feat.data_ptr(), proxy_hat.data_ptr(), N, Ch, K, H * W, 1e-12, logits.data_ptr(),
+                                                       inv.data_ptr(), _stream(feat)), "mas_cosine_head_fwd")
+        ctx.save_for_backward(feat, proxy_hat, logits, inv)
+        return logits
+
+    @staticmethod
+    def backward(ctx, g):
+        feat, proxy_hat, logits, inv = ctx.saved_tensors
+        N, Ch, H, W = feat.shape
+        K = proxy_hat.shape[0]
+        g = g.contiguous()
+        dfeat = dph = None
+        if ctx.needs_input_grad[0]:
+            dfeat = torch.empty_like(feat)
+            with torch.cuda.device(feat.device):
+                _lib.check(_lib.load().mas_cosine_head_bwd(feat.data_ptr(), proxy_hat.data_ptr(), logits.data_ptr(), inv.data_ptr(),
+                                                           g.data_ptr(), N, Ch, K, H * W, dfeat.data_ptr(), _stream(feat)),
+                           "mas_cosine_head_bwd")
+        if ctx.needs_input_grad[1]:
+            gs = (g * inv[:, None]).reshape(N, K, H * W)                       # small: [N,K,HW]
+            dph = torch.bmm(gs, feat.reshape(N, Ch, H * W).transpose(1, 2)).sum(0)      # [K,Ch] = sum_n gs_n @ f_n^T  (hipBLASLt)
+        return dfeat, dph
+
+
+def cosine_head_supported(feat, proxy):
+    return (feat.is_cuda and feat.dtype == torch.float32 and feat.dim() == 4 and proxy.dim() == 4 and proxy.shape[2:] == (1, 1)
+            and proxy.shape[0] in (19, 20, 21) and proxy.shape[1] == feat.shape[1] and feat.shape[0] <= 65535)
+
+
+def cosine_head(feat, proxy):
+    """logits = conv2d(normalize(feat), normalize(proxy)) (deeplabv3.py:121-124); proxy [K,Ch,1,1] raw weights (their
+    normalisation over dim 1 stays a PyTorch op on the [K,Ch] tensor, so its gradient is autograd's)."""
+    phat = torch.nn.functional.normalize(proxy, dim=1).reshape(proxy.shape[0], proxy.shape[1])
+    return _CosineHead.apply(feat, phat)
