@@ -274,9 +274,23 @@ __global__ __launch_bounds__(kThreads) void k_region_finalize(const mas_u64* __r
                                                                int C, int ban_class, float* __restrict__ score,
                                                                int* __restrict__ dominant, unsigned* __restrict__ count,
                                                                long long* __restrict__ hist_i64) {
-    const long long r = (long long)blockIdx.x * kThreads + threadIdx.x;
-    if (r >= n_regions) return;
-    const unsigned* h = hist + r * C;
+    // rows of C histogram words are staged through LDS with flat coalesced loads (see k_region_finalize_weighted)
+    extern __shared__ __attribute__((aligned(16))) unsigned char fin_smem[];
+    unsigned* s_hist = reinterpret_cast<unsigned*>(fin_smem);
+    const int CP = C | 1;
+    const long long r0 = (long long)blockIdx.x * kThreads;
+    const long long rows = (n_regions - r0) < kThreads ? (n_regions - r0) : kThreads;
+    const long long words = rows * C;
+    for (long long i = threadIdx.x; i < words; i += kThreads) {
+        const int row = (int)(i / C), col = (int)(i - (long long)row * C);
+        const unsigned hv = hist[r0 * C + i];
+        s_hist[row * CP + col] = hv;
+        if (hist_i64) hist_i64[r0 * C + i] = (long long)hv;
+    }
+    __syncthreads();
+    if ((long long)threadIdx.x >= rows) return;
+    const long long r = r0 + threadIdx.x;
+    const unsigned* h = s_hist + threadIdx.x * CP;
     unsigned long long n = 0;
     unsigned best = 0;
     int arg = 0;
@@ -284,7 +298,6 @@ __global__ __launch_bounds__(kThreads) void k_region_finalize(const mas_u64* __r
         const unsigned v = h[c];
         n += v;
         if (v > best) { best = v; arg = c; }     // strict: first maximum wins, empty region -> class 0
-        if (hist_i64) hist_i64[r * C + c] = (long long)v;
     }
     float s = 0.0f;
     if (n) s = mas_fixed_mean(score_sum[r], n, MAS_SCORE_FRAC);
@@ -386,7 +399,8 @@ extern "C" int mas_region_finalize(const uint64_t* score_sum, const uint32_t* hi
     if (C < 1 || C > MAS_MAX_CLASSES) return MAS_ERR_CLASSES;
     const long long nblk = (n_regions + kThreads - 1) / kThreads;
     if (nblk > 0x7fffffffLL) return MAS_ERR_SHAPE;
-    hipLaunchKernelGGL(k_region_finalize, dim3((unsigned)nblk), dim3(kThreads), 0, static_cast<hipStream_t>(stream),
+    hipLaunchKernelGGL(k_region_finalize, dim3((unsigned)nblk), dim3(kThreads), sizeof(unsigned) * (size_t)kThreads * (C | 1),
+                       static_cast<hipStream_t>(stream),
                        reinterpret_cast<const mas_u64*>(score_sum), hist, (long long)n_regions, C, ban_class, score, dominant,
                        count, reinterpret_cast<long long*>(hist_i64));
     return mas_launch_status();

@@ -453,10 +453,27 @@ __global__ __launch_bounds__(kThreads) void k_region_finalize_weighted(const mas
                                                                         float* __restrict__ score, int* __restrict__ dominant,
                                                                         unsigned* __restrict__ count,
                                                                         long long* __restrict__ hist_i64) {
-    const long long r = (long long)blockIdx.x * kThreads + threadIdx.x;
-    if (r >= n_regions) return;
-    const unsigned* h = hist + r * C;
-    const mas_u64* cs = class_sum + r * C;
+    // a thread owns a region, but rows of C words are not coalescable per thread: the workgroup's 256 rows are staged
+    // through LDS with flat, fully coalesced loads (row stride padded to an odd word count: conflict-free per-thread reads)
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int CP = C | 1;
+    mas_u64* s_sum = reinterpret_cast<mas_u64*>(smem);                          // [kThreads][CP]
+    unsigned* s_hist = reinterpret_cast<unsigned*>(s_sum + (size_t)kThreads * CP);   // [kThreads][CP]
+    const long long r0 = (long long)blockIdx.x * kThreads;
+    const long long rows = (n_regions - r0) < kThreads ? (n_regions - r0) : kThreads;
+    const long long words = rows * C;
+    for (long long i = threadIdx.x; i < words; i += kThreads) {
+        const int row = (int)(i / C), col = (int)(i - (long long)row * C);
+        const unsigned hv = hist[r0 * C + i];
+        s_sum[row * CP + col] = class_sum[r0 * C + i];
+        s_hist[row * CP + col] = hv;
+        if (hist_i64) hist_i64[r0 * C + i] = (long long)hv;
+    }
+    __syncthreads();
+    if ((long long)threadIdx.x >= rows) return;
+    const long long r = r0 + threadIdx.x;
+    const unsigned* h = s_hist + threadIdx.x * CP;
+    const mas_u64* cs = s_sum + threadIdx.x * CP;
     unsigned long long n = 0;
     unsigned best = 0;
     int arg = 0;
@@ -466,12 +483,11 @@ __global__ __launch_bounds__(kThreads) void k_region_finalize_weighted(const mas
         n += v;
         if (v > best) { best = v; arg = c; }
         if (v) mas_mac_u64_u32((uint64_t)cs[c], w31[c], &hi, &lo);
-        if (hist_i64) hist_i64[r * C + c] = (long long)v;
     }
-    float s = 0.0f;
-    if (n) s = mas_fixed_mean(mas_shr31_u128(hi, lo), n, MAS_SCORE_FRAC);
-    if (ban_class >= 0 && arg == ban_class) s = 0.0f;
-    score[r] = s;
+    float sc = 0.0f;
+    if (n) sc = mas_fixed_mean(mas_shr31_u128(hi, lo), n, MAS_SCORE_FRAC);
+    if (ban_class >= 0 && arg == ban_class) sc = 0.0f;
+    score[r] = sc;
     if (dominant) dominant[r] = arg;
     if (count) count[r] = (unsigned)n;
 }
@@ -550,7 +566,8 @@ extern "C" int mas_region_finalize_weighted(const uint64_t* class_sum, const uin
     if (C < 1 || C > MAS_MAX_CLASSES) return MAS_ERR_CLASSES;
     const long long nblk = (n_regions + kThreads - 1) / kThreads;
     if (nblk > 0x7fffffffLL) return MAS_ERR_SHAPE;
-    hipLaunchKernelGGL(k_region_finalize_weighted, dim3((unsigned)nblk), dim3(kThreads), 0, static_cast<hipStream_t>(stream),
+    const size_t smem = (sizeof(mas_u64) + sizeof(unsigned)) * (size_t)kThreads * (C | 1);
+    hipLaunchKernelGGL(k_region_finalize_weighted, dim3((unsigned)nblk), dim3(kThreads), smem, static_cast<hipStream_t>(stream),
                        reinterpret_cast<const mas_u64*>(class_sum), hist, (long long)n_regions, C, w31, ban_class, score, dominant,
                        count, reinterpret_cast<long long*>(hist_i64));
     return mas_launch_status();
