@@ -122,6 +122,27 @@ def main():
             print("Pillow on one host core (resize + crop + to-tensor, no pad/flip): %.1f ms per sample" % ((time.perf_counter() - t0) / 10 * 1e3))
         except ImportError:
             pass
+    if 'k4' in which:
+        n_img, Sx = 2975, 2048                                   # the whole Cityscapes pool
+        g = torch.Generator(device=dev); g.manual_seed(1)
+        csum = torch.randint(0, 1 << 44, (n_img, Sx, C), generator=g, device=dev, dtype=torch.int64)
+        hh = torch.randint(0, 200, (n_img, Sx, C), generator=g, device=dev, dtype=torch.int32)
+        w31 = torch.from_numpy(ops.weights_to_fixed31(np.linspace(0.3, 1.0, C).astype(np.float32)).view(np.int32)).to(dev)
+        rank_t = torch.arange(n_img, dtype=torch.int32, device=dev)
+        cost = torch.randint(1, 4, (n_img * Sx,), generator=g, device=dev, dtype=torch.int32).to(torch.uint8)
+        st = {}
+        def fin():
+            st['score'] = ops.region_finalize_weighted(csum, hh, w31, C - 1)[0]
+        def keys():
+            st['keys'] = ops.region_keys(st['score'], None, rank_t)
+        def sort():
+            st['sorted'] = ops.sort_keys_desc(st['keys'])
+        def walk():
+            st['sel'] = ops.budget_walk(st['sorted'], cost, rank_t, Sx, 100000, 100001)
+        for name, fn in (("finalize_weighted", fin), ("region_keys", keys), ("sort_keys_desc", sort), ("budget_walk", walk)):
+            med, mn = timeit(fn, n=10, warm=2)
+            print("K4 %-18s median %8.1f us  (6.09 M regions)" % (name, med))
+        print("selected", int(st['sel'][0].item()))
 
 
 if __name__ == "__main__":
