@@ -35,6 +35,9 @@ if ROOT not in sys.path:
 HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6.3 TB/s is achievable
 
 
+EVENT_EVERY = 4       # HIP-event pairs around every 4th scan launch of the timed region
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -297,9 +300,12 @@ def main():
 
     def step(i):
         z, spx = bufs[i % args.nbuf]
-        ev[i][0].record()
+        timed = (i % EVENT_EVERY) == 0        # an event pair costs ~2 barrier packets between launches: sample every 4th step
+        if timed:
+            ev[i][0].record()
         ops.single_pass_accum(z, spx, S, invT, prob_sum=prob[i], class_sum=csum[i], hist=hist[i])
-        ev[i][1].record()
+        if timed:
+            ev[i][1].record()
 
     def finish(lo, hi):
         """Weighted means + ban for every region scored in steps [lo, hi), then ordering + budget walk."""
@@ -341,7 +347,8 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
-    sp_ms = float(np.mean([a.elapsed_time(b) for a, b in ev[args.warmup:]]))
+    sampled = [ev[i] for i in range(args.warmup, n_total) if i % EVENT_EVERY == 0] or [ev[n_total - 1]]
+    sp_ms = float(np.mean([a.elapsed_time(b) for a, b in sampled]))
     id_bytes = {"int64": 8, "int32": 4, "int16": 2}[args.id_dtype]
     # algorithmic bytes of one k_single_pass launch: logits + ids read once, (prob + class sums + hist) written once
     sp_bytes = B * (C * H * W * 4 + H * W * id_bytes + S * C * (8 + 4) + C * 8)
