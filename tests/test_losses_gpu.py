@@ -173,3 +173,42 @@ def test_gradient_only_on_selected_pixels_and_linear_in_upstream():
     assert np.all(msk.reshape(N, -1)[nz[:, 0], pix])
     assert np.all(spx.reshape(N, -1)[nz[:, 0], pix] == nz[:, 1])
     assert int(a[6]) == len(nz)
+
+
+def test_full_training_batch_properties():
+    """BASELINE configs[1] shape [4,20,768,768], S = 2048: one image bit-exact against the C oracle; over the batch the
+    integer accumulators are additive over images, the gradient is zero outside the selection, and permuting the
+    images permutes dz (no cross-image leakage); selected fractions 0 %, ~9 % and 100 % in the same batch."""
+    ops = _gpu()
+    from oracle import exact
+    N, C, H, W, S = 4, 20, 768, 768, 2048
+    flags = FLAG_SETS['production']
+    z, tgt, spx, msk = _inputs(777, N, C, H, W, S, frac=0.09)
+    msk[1] = False                                   # nothing selected
+    msk[2] = spx[2] < S                              # everything but the pad id selected
+    invT = ops.inv_temperature(0.1)
+    zt, st, mt = torch.from_numpy(z).cuda(), torch.from_numpy(spx).cuda(), torch.from_numpy(msk).cuda()
+    bits = ops.target_bits(torch.from_numpy(tgt).cuda())
+    losses, acc, gmax = ops.partial_loss_fwd(zt, st, mt, bits, invT, flags)
+    go = torch.tensor([16.0, 8.0, 1.0], device='cuda')
+    dz = ops.partial_loss_bwd(zt, st, mt, bits, gmax, acc, go, invT, flags)
+    assert bool(torch.isfinite(dz).all()) and float(dz[1].abs().max()) == 0.0
+    assert float((dz * (~mt)[:, None]).abs().max()) == 0.0
+    # additivity of the integer sums / counts over images
+    tot = torch.zeros_like(acc)
+    for i in range(N):
+        _, a_i, g_i = ops.partial_loss_fwd(zt[i:i + 1], st[i:i + 1], mt[i:i + 1], bits[i:i + 1], invT, flags)
+        tot += a_i
+        assert torch.equal(g_i[0], gmax[i])
+    assert torch.equal(tot, acc)
+    # image 0 against the oracle, bit for bit (forward tables and sums)
+    ebits = exact.target_bits(tgt[:1])
+    eacc, egmax, _ = exact.partial_loss_fwd(z[:1], spx[:1], msk[:1], ebits, np.float32(invT), flags)
+    _, a0, g0 = ops.partial_loss_fwd(zt[:1], st[:1], mt[:1], bits[:1], invT, flags)
+    assert np.array_equal(a0.cpu().numpy().view(np.uint64), eacc) and np.array_equal(g0.cpu().numpy().view(np.uint64), egmax)
+    # permutation
+    perm = torch.tensor([3, 0, 2, 1], device='cuda')
+    l2, acc2, gmax2 = ops.partial_loss_fwd(zt[perm].contiguous(), st[perm].contiguous(), mt[perm].contiguous(), bits[perm].contiguous(), invT, flags)
+    assert torch.equal(acc2, acc) and torch.equal(l2, losses)
+    dz2 = ops.partial_loss_bwd(zt[perm].contiguous(), st[perm].contiguous(), mt[perm].contiguous(), bits[perm].contiguous(), gmax2, acc2, go, invT, flags)
+    assert torch.equal(dz2, dz[perm])
