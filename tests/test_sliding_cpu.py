@@ -68,7 +68,8 @@ def test_slide_trainers_importable():
 
 def test_voc_variants_importable_and_parser_defaults():
     import importlib
-    for name in ("base_voc", "active_voc", "eval_within_multihot_voc", "eval_save_cosplbl_prop_includeonehot_voc"):
+    for name in ("base_voc", "active_voc", "eval_within_multihot_voc", "eval_save_cosplbl_prop_includeonehot_voc",
+                 "eval_save_cosplbl_prop_includeonehot_voc_ms"):
         assert importlib.import_module("mulactseg_amd.trainer." + name)
     from mulactseg_amd.trainer import eval_within_multihot, eval_within_multihot_voc, eval_save_cosplbl_prop_includeonehot_voc as voc
     assert eval_within_multihot.ActiveTrainer.extra_channels == 1 and eval_within_multihot_voc.ActiveTrainer.extra_channels == 0
@@ -76,3 +77,28 @@ def test_voc_variants_importable_and_parser_defaults():
     from mulactseg_amd.utils import common_voc
     a = common_voc.get_parser().parse_args([])
     assert a.num_classes == 21 and a.nseg == 32 and a.method == 'active_voc'
+
+
+def test_voc_multiscale_ensemble_averages_scales_and_flips():
+    """The ensemble of eval_save_cosplbl_prop_includeonehot_voc_ms on CPU tensors with the stand-in net: flipping the
+    second half back and averaging equals the explicit computation."""
+    import torch.nn.functional as F
+    from mulactseg_amd.trainer import eval_save_cosplbl_prop_includeonehot_voc_ms as mod
+    net = synth.tiny_window_net(3, 21, feat_dim=16)
+    tr = object.__new__(mod.ActiveTrainer)
+    tr.net, tr.device = net, torch.device('cpu')
+    g = torch.Generator().manual_seed(0)
+    base = torch.randn(3, 20, 28, generator=g)
+    imgs = [F.interpolate(base[None], size=s, mode='bilinear', align_corners=False)[0] for s in ((10, 14), (20, 28), (30, 42))]
+    lst = imgs + [im.flip(-1) for im in imgs]
+    with torch.no_grad():
+        feats, outs = tr.ensemble(lst, (20, 28))
+        acc_f = acc_o = 0
+        for k, im in enumerate(lst):
+            f, o = net.feat_forward(im[None])
+            if k >= 3:
+                f, o = f.flip(-1), o.flip(-1)
+            acc_f = acc_f + F.interpolate(f, size=(20, 28), mode='bilinear', align_corners=False)
+            acc_o = acc_o + F.interpolate(o, size=(20, 28), mode='bilinear', align_corners=False)
+    assert torch.allclose(outs, acc_o / 6, atol=1e-6) and torch.allclose(feats, F.normalize(acc_f / 6, dim=1), atol=1e-6)
+    assert torch.allclose(feats.norm(dim=1), torch.ones(1, 20, 28), atol=1e-5)
