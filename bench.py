@@ -300,7 +300,7 @@ def main():
 
     def step(i):
         z, spx = bufs[i % args.nbuf]
-        timed = (i % EVENT_EVERY) == 0        # an event pair costs ~2 barrier packets between launches: sample every 4th step
+        timed = i >= args.warmup and (i - args.warmup) % EVENT_EVERY == 0     # an event pair costs ~2 barrier packets: sample
         if timed:
             ev[i][0].record()
         ops.single_pass_accum(z, spx, S, invT, prob_sum=prob[i], class_sum=csum[i], hist=hist[i])
@@ -347,7 +347,7 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
-    sampled = [ev[i] for i in range(args.warmup, n_total) if i % EVENT_EVERY == 0] or [ev[n_total - 1]]
+    sampled = [ev[i] for i in range(args.warmup, n_total) if (i - args.warmup) % EVENT_EVERY == 0]
     sp_ms = float(np.mean([a.elapsed_time(b) for a, b in sampled]))
     id_bytes = {"int64": 8, "int32": 4, "int16": 2}[args.id_dtype]
     # algorithmic bytes of one k_single_pass launch: logits + ids read once, (prob + class sums + hist) written once

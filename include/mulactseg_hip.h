@@ -327,6 +327,12 @@ int mas_cosine_head_fwd(const float* feat, const float* proxy_hat, int N, int Ch
 int mas_cosine_head_bwd(const float* feat, const float* proxy_hat, const float* logits, const float* inv_norm, const float* dlogits,
                         int N, int Ch, int K, int HW, float* dfeat, void* stream);
 
+/* MaxPool2d(kernel 3, stride 2, padding 1) of x [NC,H,W] (models/segmentation/backbone/resnet.py:171,206):
+ * y [NC,Ho,Wo] with Ho = (H - 1) / 2 + 1, and a one-byte arg-max offset (0..8 inside the window, first maximum) per
+ * output; bwd: dx [NC,H,W] gathered from dy through `arg` in a fixed order (no atomics). */
+int mas_maxpool3s2_fwd(const float* x, int64_t NC, int H, int W, float* y, uint8_t* arg, void* stream);
+int mas_maxpool3s2_bwd(const float* dy, const uint8_t* arg, int64_t NC, int H, int W, float* dx, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -123,7 +123,12 @@ class DeepStemResNetTrunk(nn.Module):
         return nn.Sequential(*mods)
 
     def forward(self, x):
-        x = self.maxpool(_bn_act(self.bn1, _run(self.conv1, x)))
+        x = _bn_act(self.bn1, _run(self.conv1, x))
+        if x.is_cuda:
+            from .. import ops
+            x = ops.maxpool3s2(x) if ops.maxpool3s2_supported(self.maxpool, x) else self.maxpool(x)
+        else:
+            x = self.maxpool(x)
         low = self.layer1(x)
         out = self.layer4(self.layer3(self.layer2(low)))
         return OrderedDict(low_level=low, out=out)

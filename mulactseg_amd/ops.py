@@ -686,3 +686,44 @@ def cosine_head(feat, proxy):
     normalisation over dim 1 stays a PyTorch op on the [K,Ch] tensor, so its gradient is autograd's)."""
     phat = torch.nn.functional.normalize(proxy, dim=1).reshape(proxy.shape[0], proxy.shape[1])
     return _CosineHead.apply(feat, phat)
+
+
+# ------------------------------------------------------------------------------------------------
+# stem max-pool (csrc/pool.hip)
+# ------------------------------------------------------------------------------------------------
+class _MaxPool3s2(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        x = x.contiguous()
+        N, C, H, W = x.shape
+        Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+        y = torch.empty((N, C, Ho, Wo), dtype=torch.float32, device=x.device)
+        arg = torch.empty((N, C, Ho, Wo), dtype=torch.uint8, device=x.device)
+        with torch.cuda.device(x.device):
+            _lib.check(_lib.load().mas_maxpool3s2_fwd(x.data_ptr(), N * C, H, W, y.data_ptr(), arg.data_ptr(), _stream(x)), "mas_maxpool3s2_fwd")
+        ctx.save_for_backward(arg)
+        ctx.shape = (N, C, H, W)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        (arg,) = ctx.saved_tensors
+        N, C, H, W = ctx.shape
+        g = g.contiguous()
+        dx = torch.empty((N, C, H, W), dtype=torch.float32, device=g.device)
+        with torch.cuda.device(g.device):
+            _lib.check(_lib.load().mas_maxpool3s2_bwd(g.data_ptr(), arg.data_ptr(), N * C, H, W, dx.data_ptr(), _stream(g)), "mas_maxpool3s2_bwd")
+        return dx
+
+
+def maxpool3s2_supported(pool, x):
+    def two(v):
+        return (v, v) if isinstance(v, int) else tuple(v)
+    return (x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and x.shape[0] * x.shape[1] <= 65535 and x.shape[2] <= 65535
+            and two(pool.kernel_size) == (3, 3) and two(pool.stride) == (2, 2) and two(pool.padding) == (1, 1)
+            and two(pool.dilation) == (1, 1) and not pool.ceil_mode and not pool.return_indices)
+
+
+def maxpool3s2(x):
+    _need(x, "x", torch.float32)
+    return _MaxPool3s2.apply(x)
