@@ -7,6 +7,7 @@
 // backward repeats that (threshold_backward, grad accumulation).  Fused:
 //   forward   k_bn_partial  (sum, sum of squares per (n, c, chunk), double)  ->  k_bn_stats (mean, invstd, running stats,
 //             num_batches_tracked)  ->  k_bn_apply  y = relu((x - mean) * invstd * gamma + beta + residual)
+//             (+ a ReLU mask of one byte per four outputs, so that the backward does not have to re-read y)
 //   backward  k_bn_bwd_partial (sum g, sum g * xhat with g = dy * [y > 0])  ->  k_bn_bwd_stats (dgamma, dbeta, means)
 //             ->  k_bn_bwd_apply  dx = gamma * invstd * (g - mean(g) - xhat * mean(g * xhat)),  dres = g
 //   inference k_bn_apply with the running statistics.
@@ -75,7 +76,8 @@ __global__ __launch_bounds__(kThreads) void k_bn_stats(const double2* __restrict
 template <bool FROM_VAR>
 __global__ __launch_bounds__(kThreads) void k_bn_apply(const float* __restrict__ x, const float* __restrict__ gamma, const float* __restrict__ beta,
                                                         const float* __restrict__ stat1, const float* __restrict__ stat2, float eps,
-                                                        const float* __restrict__ res, int C, int HW, int relu, float* __restrict__ y) {
+                                                        const float* __restrict__ res, int C, int HW, int relu, float* __restrict__ y,
+                                                        unsigned char* __restrict__ mask) {
     const int c = blockIdx.y % C;
     const float mu = stat1[c];
     const float is = FROM_VAR ? 1.0f / sqrtf(stat2[c] + eps) : stat2[c];
@@ -91,7 +93,10 @@ __global__ __launch_bounds__(kThreads) void k_bn_apply(const float* __restrict__
     if ((HW & 3) == 0) {
         const float4 v = *reinterpret_cast<const float4*>(x + base + i);
         const float4 r = res ? *reinterpret_cast<const float4*>(res + base + i) : make_float4(0.f, 0.f, 0.f, 0.f);
-        *reinterpret_cast<float4*>(y + base + i) = make_float4(f(v.x, r.x), f(v.y, r.y), f(v.z, r.z), f(v.w, r.w));
+        const float4 o = make_float4(f(v.x, r.x), f(v.y, r.y), f(v.z, r.z), f(v.w, r.w));
+        *reinterpret_cast<float4*>(y + base + i) = o;
+        // ReLU mask for the backward pass: one byte per four elements (1/16 of the bytes of y)
+        if (mask) mask[(base + i) >> 2] = (unsigned char)((o.x > 0.f) | ((o.y > 0.f) << 1) | ((o.z > 0.f) << 2) | ((o.w > 0.f) << 3));
     } else {
         for (int k = 0; k < 4 && i + k < HW; ++k) y[base + i + k] = f(x[base + i + k], res ? res[base + i + k] : 0.0f);
     }
@@ -99,8 +104,9 @@ __global__ __launch_bounds__(kThreads) void k_bn_apply(const float* __restrict__
 
 // part[(c * N + n) * chunks + chunk] = (sum g, sum g * xhat),  g = dy * [y > 0] (relu) or dy
 __global__ __launch_bounds__(kThreads) void k_bn_bwd_partial(const float* __restrict__ dy, const float* __restrict__ x, const float* __restrict__ y,
-                                                              const float* __restrict__ mean, const float* __restrict__ invstd, int C, int HW,
-                                                              int chunks, int relu, double2* __restrict__ part) {
+                                                              const unsigned char* __restrict__ mask, const float* __restrict__ mean,
+                                                              const float* __restrict__ invstd, int C, int HW, int chunks, int relu,
+                                                              double2* __restrict__ part) {
     __shared__ double s_red[kThreads / MAS_WAVE];
     const int chunk = blockIdx.x, n = blockIdx.y, c = blockIdx.z;
     const size_t base = ((size_t)n * C + c) * HW;
@@ -116,7 +122,13 @@ __global__ __launch_bounds__(kThreads) void k_bn_bwd_partial(const float* __rest
         for (int i = lo + threadIdx.x * 4; i < hi; i += kThreads * 4) {
             const float4 g = *reinterpret_cast<const float4*>(dy + base + i);
             const float4 xv = *reinterpret_cast<const float4*>(x + base + i);
-            const float4 yv = relu ? *reinterpret_cast<const float4*>(y + base + i) : make_float4(1.f, 1.f, 1.f, 1.f);
+            float4 yv = make_float4(1.f, 1.f, 1.f, 1.f);
+            if (relu && mask) {
+                const unsigned m = mask[(base + i) >> 2];
+                yv = make_float4((float)(m & 1u), (float)((m >> 1) & 1u), (float)((m >> 2) & 1u), (float)((m >> 3) & 1u));
+            } else if (relu) {
+                yv = *reinterpret_cast<const float4*>(y + base + i);
+            }
             acc(g.x, xv.x, yv.x); acc(g.y, xv.y, yv.y); acc(g.z, xv.z, yv.z); acc(g.w, xv.w, yv.w);
         }
     } else {
@@ -140,7 +152,8 @@ __global__ __launch_bounds__(kThreads) void k_bn_bwd_stats(const double2* __rest
 }
 
 __global__ __launch_bounds__(kThreads) void k_bn_bwd_apply(const float* __restrict__ dy, const float* __restrict__ x, const float* __restrict__ y,
-                                                            const float* __restrict__ gamma, const float* __restrict__ mean,
+                                                            const unsigned char* __restrict__ mask, const float* __restrict__ gamma,
+                                                            const float* __restrict__ mean,
                                                             const float* __restrict__ invstd, const float2* __restrict__ coef, int C, int HW,
                                                             int relu, float* __restrict__ dx, float* __restrict__ dres) {
     const int c = blockIdx.y % C;
@@ -158,7 +171,13 @@ __global__ __launch_bounds__(kThreads) void k_bn_bwd_apply(const float* __restri
     if ((HW & 3) == 0) {
         const float4 g = *reinterpret_cast<const float4*>(dy + base + i);
         const float4 xv = *reinterpret_cast<const float4*>(x + base + i);
-        const float4 yv = relu ? *reinterpret_cast<const float4*>(y + base + i) : make_float4(1.f, 1.f, 1.f, 1.f);
+        float4 yv = make_float4(1.f, 1.f, 1.f, 1.f);
+        if (relu && mask) {
+            const unsigned mk = mask[(base + i) >> 2];
+            yv = make_float4((float)(mk & 1u), (float)((mk >> 1) & 1u), (float)((mk >> 2) & 1u), (float)((mk >> 3) & 1u));
+        } else if (relu) {
+            yv = *reinterpret_cast<const float4*>(y + base + i);
+        }
         float4 r, o;
         o.x = f(g.x, xv.x, yv.x, r.x); o.y = f(g.y, xv.y, yv.y, r.y); o.z = f(g.z, xv.z, yv.z, r.z); o.w = f(g.w, xv.w, yv.w, r.w);
         *reinterpret_cast<float4*>(dx + base + i) = o;
@@ -188,7 +207,7 @@ extern "C" int64_t mas_bn_workspace_bytes(int N, int C, int HW) {
 extern "C" int mas_bn_act_train_fwd(const float* x, const float* gamma, const float* beta, const float* residual, int N, int C, int HW,
                                     float eps, float momentum, int relu, float* running_mean, float* running_var,
                                     int64_t* num_batches_tracked, float* save_mean, float* save_invstd, void* workspace, float* y,
-                                    void* stream) {
+                                    uint8_t* relu_mask, void* stream) {
     if (!x || !save_mean || !save_invstd || !workspace || !y) return MAS_ERR_NULL;
     if ((running_mean == nullptr) != (running_var == nullptr)) return MAS_ERR_NULL;
     if (int e = check(N, C, HW)) return e;
@@ -200,7 +219,7 @@ extern "C" int mas_bn_act_train_fwd(const float* x, const float* gamma, const fl
                        (double)N * (double)HW, eps, momentum, save_mean, save_invstd, running_mean, running_var,
                        reinterpret_cast<long long*>(num_batches_tracked));
     hipLaunchKernelGGL((k_bn_apply<false>), apply_grid(N, C, HW), dim3(kThreads), 0, st, x, gamma, beta, save_mean, save_invstd, eps, residual, C,
-                       HW, relu, y);
+                       HW, relu, y, (relu && (HW & 3) == 0) ? relu_mask : nullptr);
     return mas_launch_status();
 }
 
@@ -210,25 +229,26 @@ extern "C" int mas_bn_act_eval_fwd(const float* x, const float* gamma, const flo
     if (!x || !running_mean || !running_var || !y) return MAS_ERR_NULL;
     if (int e = check(N, C, HW)) return e;
     hipLaunchKernelGGL((k_bn_apply<true>), apply_grid(N, C, HW), dim3(kThreads), 0, static_cast<hipStream_t>(stream), x, gamma, beta,
-                       running_mean, running_var, eps, residual, C, HW, relu, y);
+                       running_mean, running_var, eps, residual, C, HW, relu, y, nullptr);
     return mas_launch_status();
 }
 
-extern "C" int mas_bn_act_train_bwd(const float* dy, const float* x, const float* y, const float* gamma, const float* save_mean,
-                                    const float* save_invstd, int N, int C, int HW, int relu, void* workspace, float* dx, float* dresidual,
-                                    float* dgamma, float* dbeta, void* stream) {
+extern "C" int mas_bn_act_train_bwd(const float* dy, const float* x, const float* y, const uint8_t* relu_mask, const float* gamma,
+                                    const float* save_mean, const float* save_invstd, int N, int C, int HW, int relu, void* workspace,
+                                    float* dx, float* dresidual, float* dgamma, float* dbeta, void* stream) {
     if (!dy || !x || !save_mean || !save_invstd || !workspace || !dx) return MAS_ERR_NULL;
-    if (relu && !y) return MAS_ERR_NULL;
+    if ((HW & 3) != 0) relu_mask = nullptr;
+    if (relu && !y && !relu_mask) return MAS_ERR_NULL;
     if (int e = check(N, C, HW)) return e;
     hipStream_t st = static_cast<hipStream_t>(stream);
     const int chunks = chunks_of(HW);
     double2* part = static_cast<double2*>(workspace);
     float2* coef = reinterpret_cast<float2*>(part + (size_t)C * N * chunks);
-    hipLaunchKernelGGL(k_bn_bwd_partial, dim3((unsigned)chunks, (unsigned)N, (unsigned)C), dim3(kThreads), 0, st, dy, x, y, save_mean, save_invstd,
-                       C, HW, chunks, relu, part);
+    hipLaunchKernelGGL(k_bn_bwd_partial, dim3((unsigned)chunks, (unsigned)N, (unsigned)C), dim3(kThreads), 0, st, dy, x, y, relu_mask, save_mean,
+                       save_invstd, C, HW, chunks, relu, part);
     hipLaunchKernelGGL(k_bn_bwd_stats, dim3((unsigned)((C + kThreads - 1) / kThreads)), dim3(kThreads), 0, st, part, C, N * chunks,
                        (double)N * (double)HW, dgamma, dbeta, coef);
-    hipLaunchKernelGGL(k_bn_bwd_apply, apply_grid(N, C, HW), dim3(kThreads), 0, st, dy, x, y, gamma, save_mean, save_invstd, coef, C, HW, relu,
-                       dx, dresidual);
+    hipLaunchKernelGGL(k_bn_bwd_apply, apply_grid(N, C, HW), dim3(kThreads), 0, st, dy, x, y, relu_mask, gamma, save_mean, save_invstd, coef, C, HW,
+                       relu, dx, dresidual);
     return mas_launch_status();
 }

@@ -577,19 +577,21 @@ class _BNActTrain(torch.autograd.Function):
         mean = torch.empty(C, dtype=torch.float32, device=dev)
         invstd = torch.empty(C, dtype=torch.float32, device=dev)
         y = torch.empty_like(x)
+        # ReLU mask, one byte per four outputs: the backward then reads 1/16 of the bytes of y
+        mask = torch.empty(N * C * HW // 4, dtype=torch.uint8, device=dev) if (relu and HW % 4 == 0) else None
         with torch.cuda.device(dev):
             _lib.check(lib.mas_bn_act_train_fwd(x.data_ptr(), _opt(weight), _opt(bias), _opt(res), N, C, HW, float(eps), float(momentum),
                                                 int(relu), _opt(running_mean), _opt(running_var), _opt(num_batches_tracked),
-                                                mean.data_ptr(), invstd.data_ptr(), ws.data_ptr(), y.data_ptr(), _stream(x)),
+                                                mean.data_ptr(), invstd.data_ptr(), ws.data_ptr(), y.data_ptr(), _opt(mask), _stream(x)),
                        "mas_bn_act_train_fwd")
-        ctx.save_for_backward(x, y, weight, mean, invstd)
+        ctx.save_for_backward(x, y if mask is None else None, weight, mean, invstd, mask)
         ctx.relu = bool(relu)
         ctx.has_res = residual is not None
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        x, y, weight, mean, invstd = ctx.saved_tensors
+        x, y, weight, mean, invstd, mask = ctx.saved_tensors
         N, C, H, W = x.shape
         HW = H * W
         dev = x.device
@@ -601,7 +603,7 @@ class _BNActTrain(torch.autograd.Function):
         dg = torch.empty(C, dtype=torch.float32, device=dev) if (weight is not None and ctx.needs_input_grad[1]) else None
         db = torch.empty(C, dtype=torch.float32, device=dev) if ctx.needs_input_grad[2] else None
         with torch.cuda.device(dev):
-            _lib.check(lib.mas_bn_act_train_bwd(dy.data_ptr(), x.data_ptr(), y.data_ptr(), _opt(weight), mean.data_ptr(), invstd.data_ptr(),
+            _lib.check(lib.mas_bn_act_train_bwd(dy.data_ptr(), x.data_ptr(), _opt(y), _opt(mask), _opt(weight), mean.data_ptr(), invstd.data_ptr(),
                                                 N, C, HW, int(ctx.relu), ws.data_ptr(), dx.data_ptr(), _opt(dres), _opt(dg), _opt(db),
                                                 _stream(x)), "mas_bn_act_train_bwd")
         if ctx.has_res and dres is None and ctx.needs_input_grad[3]:
