@@ -147,7 +147,7 @@ def train_iter_bench(args, dev, world):
 
     net = get_model('deeplabv3pluswn_resnet50deepstem', C, 16, True, pretrained_backbone=False).to(dev).train()
     opt = torch.optim.AdamW([{'params': net.backbone.parameters(), 'lr': 2e-5},
-                             {'params': net.classifier.parameters(), 'lr': 2e-4}], lr=2e-5, weight_decay=1e-5)
+                             {'params': net.classifier.parameters(), 'lr': 2e-4}], lr=2e-5, weight_decay=1e-5, fused=True)
     if world > 1 or torch.distributed.is_initialized():       # data parallel as the trainers run it: gradients all-reduced over RCCL
         net = torch.nn.parallel.DistributedDataParallel(net, device_ids=[dev.index], output_device=dev.index)
     images = torch.randn((N, 3, crop, crop), generator=g, device=dev)

@@ -68,10 +68,12 @@ class BaseTrainer(object):
                          pretrained_backbone=getattr(a, 'pretrained_backbone', True))
 
     def get_optim(self, my_lr):
-        groups = [{'params': self.net.backbone.parameters(), 'lr': my_lr},
-                  {'params': self.net.classifier.parameters(), 'lr': self.args.cls_lr_scale * my_lr}]
+        groups = [{'params': list(self.net.backbone.parameters()), 'lr': my_lr},
+                  {'params': list(self.net.classifier.parameters()), 'lr': self.args.cls_lr_scale * my_lr}]
         if self.args.optimizer == 'adamw':
-            self.optimizer = optim.AdamW(params=groups, lr=my_lr, weight_decay=self.args.weight_decay)
+            # same update rule as the reference's optim.AdamW (trainer/base.py:64-66); on the GPU the single-kernel form
+            on_gpu = any(p.is_cuda for g in groups for p in g['params'])
+            self.optimizer = optim.AdamW(params=groups, lr=my_lr, weight_decay=self.args.weight_decay, fused=on_gpu)
         elif self.args.optimizer == 'sgd':
             self.optimizer = optim.SGD(params=groups, lr=my_lr, momentum=0.9, weight_decay=self.args.weight_decay)
         else:

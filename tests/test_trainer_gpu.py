@@ -78,6 +78,9 @@ def test_production_trainer_step_matches_reference_loss():
     tmp = tempfile.mkdtemp()
     tr, active = _trainer(tmp)
     assert tr.net.classifier.final.weight.shape[0] == N_CLS + 1            # predignore: one extra channel
+    in_opt = {id(p) for g in tr.optimizer.param_groups for p in g['params']}
+    assert in_opt == {id(p) for p in tr.net.parameters()}                  # every parameter is optimised, once
+    assert tr.optimizer.param_groups[1]['lr'] == 10 * tr.optimizer.param_groups[0]['lr']      # head x10 (base.py:64-66)
     # reference value of the first step's loss: same batch, same dropout seed, losses restated on CPU
     tr.train_dataset_loader = tr.get_trainloader(active.get_trainset())
     torch.manual_seed(123)
