@@ -111,6 +111,96 @@ __global__ __launch_bounds__(kThreads) void k_class_prob_sum(const float* __rest
     }
 }
 
+// Ring form of K2 (16-B aligned planes): as in single_pass.hip every wave keeps the NEXT chunk's 20 loads in flight while
+// it runs the softmax of the current one (two 80-register buffers, 2 waves/SIMD).  Same arithmetic, same integer sums.
+template <int CT, bool EXACT>
+__device__ __forceinline__ void k2_issue(float4 (&t)[CT], const float* __restrict__ zb, int C, int HW, unsigned off) {
+#pragma unroll
+    for (int c = 0; c < CT; ++c) {
+        if (EXACT || c < C) t[c] = *reinterpret_cast<const float4*>(zb + (size_t)c * HW + off);
+        else t[c] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+}
+
+template <int CT, bool EXACT>
+__device__ __forceinline__ void k2_consume(float4 (&t)[CT], bool ok, int C, float invT, unsigned (&acc)[CT]) {
+    mas_v2f v[2][CT];
+#pragma unroll
+    for (int c = 0; c < CT; ++c) {
+        v[0][c] = (mas_v2f){t[c].x, t[c].y};
+        v[1][c] = (mas_v2f){t[c].z, t[c].w};
+    }
+    mas_v2f Ra, Rb;
+    mas_softmax_quad<CT, EXACT>(v[0], v[1], C, invT, Ra, Rb);
+    Ra = Ra * mas_splat(8388608.0f);
+    Rb = Rb * mas_splat(8388608.0f);
+    Ra = ok ? Ra : mas_splat(0.0f);               // chunks past the end add exactly the bias (removed below)
+    Rb = ok ? Rb : mas_splat(0.0f);
+#pragma unroll
+    for (int c = 0; c < CT; ++c) {
+        if (EXACT || c < C) {
+            const mas_v2f ta = mas_pk_fma(v[0][c], Ra, mas_splat(8388608.0f));
+            const mas_v2f tb = mas_pk_fma(v[1][c], Rb, mas_splat(8388608.0f));
+            acc[c] += (mas_f2u(ta.x) + mas_f2u(ta.y)) + (mas_f2u(tb.x) + mas_f2u(tb.y));
+        }
+    }
+}
+
+template <int CT, bool EXACT>
+__global__ __launch_bounds__(kThreads, 2) void k_class_prob_sum_ring(const float* __restrict__ z, int C, int HW, float invT,
+                                                                      mas_u64* __restrict__ prob_sum, int blocks_per_image, int iters) {
+    const int b = blockIdx.x / blocks_per_image;
+    const int j = blockIdx.x - b * blocks_per_image;
+    const float* zb = z + (size_t)b * C * HW;
+    unsigned acc[CT];
+#pragma unroll
+    for (int c = 0; c < CT; ++c) acc[c] = 0;
+    const int chunk_px = kThreads * 4;
+    // chunk `it` of this workgroup starts at pixel (j + it * blocks_per_image) * chunk_px; out-of-range chunks re-read the
+    // last valid float4 of the plane (a valid address) and are masked
+    auto off_of = [&](int it) -> unsigned {
+        const long long p = ((long long)j + (long long)it * blocks_per_image) * chunk_px + threadIdx.x * 4;
+        return (unsigned)(p < HW ? p : HW - 4);
+    };
+    auto ok_of = [&](int it) -> bool {
+        return ((long long)j + (long long)it * blocks_per_image) * chunk_px + threadIdx.x * 4 < HW;
+    };
+    float4 A[CT], Bf[CT];
+    k2_issue<CT, EXACT>(A, zb, C, HW, off_of(0));
+#pragma unroll 1
+    for (int it = 0; it < iters; it += 2) {
+        k2_issue<CT, EXACT>(Bf, zb, C, HW, off_of(it + 1));
+        __builtin_amdgcn_sched_barrier(0);
+        k2_consume<CT, EXACT>(A, ok_of(it), C, invT, acc);
+        __builtin_amdgcn_sched_barrier(0);
+        k2_issue<CT, EXACT>(A, zb, C, HW, off_of(it + 2));
+        __builtin_amdgcn_sched_barrier(0);
+        k2_consume<CT, EXACT>(Bf, (it + 1 < iters) && ok_of(it + 1), C, invT, acc);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    const unsigned n_quanta = (unsigned)(((iters + 1) / 2) * 2) * 4u;
+#pragma unroll
+    for (int c = 0; c < CT; ++c) acc[c] -= n_quanta * MAS_PROBQ_BIAS;
+
+    __shared__ mas_u64 s_part[kThreads / MAS_WAVE][CT];
+    const int lane = threadIdx.x & (MAS_WAVE - 1);
+    const int wave = threadIdx.x / MAS_WAVE;
+#pragma unroll
+    for (int c = 0; c < CT; ++c) {
+        mas_u64 a = acc[c];
+#pragma unroll
+        for (int off = MAS_WAVE / 2; off > 0; off >>= 1) a += __shfl_down(a, off, MAS_WAVE);
+        if (lane == 0) s_part[wave][c] = a;
+    }
+    __syncthreads();
+    if (threadIdx.x < CT && (EXACT || (int)threadIdx.x < C)) {
+        mas_u64 a = 0;
+#pragma unroll
+        for (int w = 0; w < kThreads / MAS_WAVE; ++w) a += s_part[w][threadIdx.x];
+        if (a) atomicAdd(&prob_sum[(size_t)b * C + threadIdx.x], a);
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // K1 + K3
 // ------------------------------------------------------------------------------------------------
@@ -351,6 +441,16 @@ int launch_prob_sum(const float* z, int B, int C, int HW, float invT, mas_u64* p
     if (bpi > max_bpi) bpi = max_bpi;
     if (bpi < 1) bpi = 1;
     const bool vec = (HW % 4 == 0) && (((uintptr_t)z & 15) == 0);
+    if constexpr (EXACT) if (vec && HW >= 8 * chunk_px) {
+        // one round of workgroups at 2 waves/SIMD: 512 workgroups in all, <= 60 chunks each (32-bit accumulators stay exact)
+        int rbpi = 512 / B > 0 ? 512 / B : 1;
+        if (rbpi < min_bpi) rbpi = min_bpi;
+        if (rbpi > max_bpi) rbpi = max_bpi;
+        const int iters = (max_bpi + rbpi - 1) / rbpi;
+        hipLaunchKernelGGL((k_class_prob_sum_ring<CT, EXACT>), dim3((unsigned)(B * rbpi)), dim3(kThreads), 0, st, z, C, HW, invT, prob_sum,
+                           rbpi, iters);
+        return mas_launch_status();
+    }
     if (vec)
         hipLaunchKernelGGL((k_class_prob_sum<CT, EXACT, true>), dim3((unsigned)(B * bpi)), dim3(kThreads), 0, st, z, C, HW, invT,
                            prob_sum, bpi);
