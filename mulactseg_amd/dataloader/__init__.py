@@ -1,12 +1,12 @@
-"""Host-side data contract of the hot path (tensor shapes/dtypes and the active-set bookkeeping).
+"""Data layer of the hot path: the tensor contract (shapes / dtypes), the active-set bookkeeping and the device data path.
 
-The reference's ~45 dataset variants, PIL augmentation and on-disk formats are out of scope
-(SURVEY.md section 2.1 #6); what the plugins need from the data layer is kept:
-``collate_fn`` / ``DataProvider`` (``dataloader/utils.py``) and ``RegionActiveDataset``
-(``dataloader/region_active_dataset.py``).
+``collate_fn`` / ``DataProvider`` (``utils.py``), ``RegionActiveDataset`` (``region_active_dataset.py``), readers of the
+reference's on-disk formats (``formats.py``), the Pillow-exact device augmentation (``device_transforms.py``) and a region
+dataset + batch provider for pictures resident in HBM (``resident.py``, ``utils.ResidentProvider``).  The reference's ~45
+dataset variants and its image decoding are out of scope: plug a dataset in with ``register_dataset_factory``.
 """
 from .region_active_dataset import RegionActiveDataset  # noqa: F401
-from .utils import DataProvider, collate_fn  # noqa: F401
+from .utils import DataProvider, ResidentProvider, collate_fn  # noqa: F401
 
 
 _DATASET_FACTORY = None

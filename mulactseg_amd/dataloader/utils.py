@@ -51,3 +51,40 @@ class DataProvider:
             batch = next(self.dataiter)
         self.iteration += 1
         return batch
+
+
+class ResidentProvider:
+    """``DataProvider`` for datasets whose samples are produced ON the device (``dataloader/resident.py``): no worker
+    processes, no pinned staging -- batches are stacked device tensors.  Same endless-iterator surface
+    (``len``, ``next``, ``epoch``, ``iteration``); shuffling draws a fresh permutation per epoch from ``rng``
+    (a ``random.Random`` or the ``random`` module), as ``DataLoader(shuffle=True)`` does per epoch."""
+
+    def __init__(self, dataset, batch_size, drop_last=True, shuffle=True, rng=None):
+        import random as _random
+        self.dataset, self.batch_size, self.drop_last, self.shuffle = dataset, int(batch_size), drop_last, shuffle
+        self.rng = rng if rng is not None else _random
+        self.iteration = 0
+        self.epoch = 0
+        self._order, self._pos = [], 0
+        self._new_epoch()
+
+    def _new_epoch(self):
+        self._order = list(range(len(self.dataset)))
+        if self.shuffle:
+            self.rng.shuffle(self._order)
+        self._pos = 0
+
+    def __len__(self):
+        n = len(self.dataset)
+        return n // self.batch_size if self.drop_last else (n + self.batch_size - 1) // self.batch_size
+
+    def __next__(self):
+        if len(self) == 0:
+            raise StopIteration("dataset smaller than one batch")
+        if self._pos + (self.batch_size if self.drop_last else 1) > len(self._order):
+            self.epoch += 1
+            self._new_epoch()
+        idx = self._order[self._pos:self._pos + self.batch_size]
+        self._pos += len(idx)
+        self.iteration += 1
+        return collate_fn([self.dataset[i] for i in idx])

@@ -85,3 +85,28 @@ def test_resident_region_dataset_samples():
     ref = (ref - np.asarray(MEAN, np.float32)[:, None, None]) / np.asarray(STD, np.float32)[:, None, None]
     assert np.array_equal(item['images'].cpu().numpy(), ref) and torch.equal(item['spx'], spxs[1].long())
     assert sorted(pool.suppix["spx1.pkl"]) == list(range(nseg))
+
+
+def test_resident_provider_batches_forever():
+    _gpu()
+    import types
+    from mulactseg_amd.dataloader import ResidentProvider
+    from mulactseg_amd.dataloader.resident import ResidentRegionDataset
+    rs = np.random.RandomState(9)
+    nseg, n = 20, 5
+    pics = [torch.from_numpy(rs.randint(0, 256, size=(80, 96, 3)).astype(np.uint8)).cuda() for _ in range(n)]
+    spxs = [torch.from_numpy(rs.randint(0, nseg, size=(80, 96)).astype(np.int32)).cuda() for _ in range(n)]
+    mh = torch.from_numpy(rs.randint(0, 2, size=(n, nseg, 20)).astype(np.uint8)).cuda()
+    names = [("i%d" % i, "l%d" % i, "s%d" % i) for i in range(n)]
+    ds = ResidentRegionDataset(types.SimpleNamespace(nseg=nseg, ignore_idx=255), pics, spxs, mh, names, split='active-label',
+                               region_dict={"s%d" % i: [i, i + 1] for i in range(n)}, rng=random.Random(1))
+    ds.transform.size = (48, 48)
+    prov = ResidentProvider(ds, batch_size=2, drop_last=True, shuffle=True, rng=random.Random(2))
+    assert len(prov) == 2
+    seen = []
+    for _ in range(5):
+        b = next(prov)
+        assert tuple(b['images'].shape) == (2, 3, 48, 48) and b['images'].is_cuda and b['spmask'].dtype == torch.bool
+        assert tuple(b['labels'].shape) == (2, nseg, 20) and len(b['fnames']) == 2
+        seen += [f[2] for f in b['fnames']]
+    assert prov.epoch == 2 and prov.iteration == 5 and len(set(seen)) == n
