@@ -14,6 +14,10 @@
 // With w = 1 the result is bit-identical to the two-pass kernels; with weights it differs from them only by the
 // per-pixel rounding of bvsb*w (~1e-9 relative).  HBM traffic per image: logits + ids once (176 MB instead of 344 MB)
 // and, end to end, ONE model forward per pool image instead of two.
+//
+// Two kernels share the arithmetic: k_single_pass_ring (16-B aligned rows, H >= 64, C in {19, 20, 21}: the Cityscapes /
+// bench shapes) keeps the next row's loads in flight while it computes the current row; k_single_pass (any shape) waits
+// for a row, then computes it.  MAS_SINGLE_PASS_RING=0 in the environment forces the second one (A/B measurements).
 #include <cstdlib>
 #include "common.h"
 
