@@ -53,6 +53,8 @@ __global__ __launch_bounds__(kThreads) void k_maxpool3s2_fwd(const float* __rest
             for (int bcol = 0; bcol < 3; ++bcol) {
                 const int t = 2 * k + bcol;
                 // ATen: maxidx starts at the first valid element; "val > maxval || isnan(val)" moves it
+                // (kept as selects on purpose: with an if-block here and a dynamically indexed store loop below, hipcc 7.2
+                //  produced the right maxima but a stale `where`; tests/test_pool_gpu.py checks the gradients against PyTorch)
                 const bool upd = in[t] && (where[k] < 0 || v[t] > best[k] || v[t] != v[t]);
                 best[k] = upd ? v[t] : best[k];
                 where[k] = upd ? (a * 3 + bcol) : where[k];
