@@ -56,6 +56,7 @@ class ActiveTrainer(eval_save_cosplbl_prop_includeonehot_voc.ActiveTrainer):
                 plbl = self.inference_batch(batch)
                 meter._after_step({'outputs': plbl, 'targets': batch['labels'].to(self.device, dtype=torch.long)})
                 self.after_batch(batch, plbl)
+        meter.all_reduce(self.device)
         ious = meter._after_epoch()
         miou = float(np.mean(ious))
         table = ','.join(['%.2f' % miou] + ['%.2f' % v for v in ious])

@@ -25,6 +25,11 @@ class ActiveTrainer(BaseTrainer):
     def eval(self, active_set, selection_iter):
         eval_dataset = active_set.trg_label_dataset
         eval_dataset.im_idx = sorted(eval_dataset.im_idx)
+        # one process per GPU: every rank generates the pseudo labels of its share of the labelled pictures (round-robin;
+        # the PNGs are per-picture files) and the IoU counters are summed over the ranks
+        import torch.distributed as dist
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+            eval_dataset.im_idx = eval_dataset.im_idx[dist.get_rank()::dist.get_world_size()]
         self.eval_dataset_loader = DataProvider(dataset=eval_dataset, batch_size=self.args.val_batch_size, shuffle=False,
                                                 num_workers=getattr(self.args, 'val_num_workers', 8), pin_memory=True,
                                                 drop_last=False)
@@ -54,6 +59,7 @@ class ActiveTrainer(BaseTrainer):
                 plbl = self.pseudo_labels(images, labels, targets, spmasks, superpixels)
                 meter._after_step({'outputs': plbl, 'targets': labels})
                 self.after_batch(batch, plbl)
+        meter.all_reduce(self.device)
         ious = meter._after_epoch()
         miou = np.mean(ious)
         table = ','.join(['%.2f' % miou] + ['%.2f' % v for v in ious])

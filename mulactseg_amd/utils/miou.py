@@ -42,6 +42,16 @@ class MeanIoU:
             return np.zeros(3 * self.num_classes + 3, dtype=np.float64)
         return self._counts.cpu().numpy().astype(np.float64)
 
+    def all_reduce(self, device=None):
+        """Sum the integer counters over the ranks of an initialised process group (validation / stage-2 sets are
+        sharded by rank).  A rank that saw no batch contributes zeros (``device`` tells it where to allocate them)."""
+        import torch.distributed as dist
+        if dist.is_available() and dist.is_initialized():
+            if self._counts is None and device is not None:
+                self._ensure(device)
+            if self._counts is not None:
+                dist.all_reduce(self._counts)
+
     @property
     def total_seen(self):
         return self._host_counts()[:self.num_classes]
@@ -120,12 +130,6 @@ class LogitsIoU(MeanIoU):
     def step(self, logits, labels):
         ops.logits_iou_counts(logits.contiguous(), labels.contiguous(), self.num_classes, self.ignore_label,
                               self._ensure(logits.device))
-
-    def all_reduce(self):
-        """Sum the integer counters over ranks (sharded validation set)."""
-        import torch.distributed as dist
-        if dist.is_available() and dist.is_initialized() and self._counts is not None:
-            dist.all_reduce(self._counts)
 
     def ious(self):
         return self._after_epoch()

@@ -103,3 +103,25 @@ def test_shard_plan_covers_pool_in_whole_batches():
             seen += p.local_indices
             assert p.n_local <= p.per_rank_imgs
         assert seen == list(range(n_img))
+
+
+def _run_meter(rank, world, port, out_dir):
+    import torch.distributed as dist
+    from mulactseg_amd.utils.miou import MeanIoU
+    dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
+    try:
+        m = MeanIoU(3, 255)
+        m._before_epoch()
+        if rank == 0:                                   # rank 1 saw no batch at all
+            m._ensure(torch.device('cpu'))[:] = torch.arange(12)
+        m.all_reduce(torch.device('cpu'))
+        torch.save(m._counts.clone(), os.path.join(out_dir, "meter%d.pt" % rank))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_iou_counters_sum_over_ranks_even_when_a_rank_saw_nothing():
+    out = tempfile.mkdtemp()
+    mp.spawn(_run_meter, args=(2, _free_port(), out), nprocs=2, join=True)
+    a, b = torch.load(os.path.join(out, "meter0.pt")), torch.load(os.path.join(out, "meter1.pt"))
+    assert torch.equal(a, torch.arange(12)) and torch.equal(a, b)
