@@ -102,6 +102,10 @@ class BaseTrainer(object):
                             num_workers=self.args.num_workers, pin_memory=True, drop_last=True)
 
     def get_valloader(self, dataset):
+        # one process per GPU: every rank evaluates its round-robin share; inference() sums the IoU counters over ranks
+        import torch.distributed as dist
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+            dataset = torch.utils.data.Subset(dataset, range(dist.get_rank(), len(dataset), dist.get_world_size()))
         return DataProvider(dataset=dataset, batch_size=self.args.val_batch_size, shuffle=False,
                             num_workers=self.args.val_num_workers, pin_memory=True, drop_last=False)
 
@@ -126,7 +130,7 @@ class BaseTrainer(object):
                 images = batch['images'].to(self.device, dtype=torch.float32)
                 labels = batch['labels'].to(self.device, dtype=torch.long)
                 meter.step(self.net(images).detach(), labels)
-        meter.all_reduce()
+        meter.all_reduce(self.device)
         ious = meter.ious()
         miou = np.mean(ious)
         cells = ['%.2f' % miou] + ['%.2f' % v for v in ious]

@@ -26,7 +26,7 @@ class ActiveTrainer(active.ActiveTrainer):
                 for i in range(images.shape[0]):
                     scores = evaluator(images[i:i + 1])
                     helper.step(scores[None].contiguous(), labels[i:i + 1])
-        helper.all_reduce()
+        helper.all_reduce(self.device)
         ious = helper.ious()
         miou = float(np.mean(ious))
         table = ','.join(['%.2f' % miou] + ['%.2f' % v for v in ious])
