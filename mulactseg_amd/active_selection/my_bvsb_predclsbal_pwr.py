@@ -10,7 +10,6 @@ pass 1 estimates the predicted class prior (K2, ``k_class_prob_sum``), the host 
 histograms the arg-max class (K1+K3, ``k_bvsb_region_accum``).  The two forms agree to ~1e-7 relative (the
 per-pixel f32 rounding of ``bvsb * w`` is the only difference) and give the same integers.
 """
-import torch
 
 from . import my_bvsb
 from .engine import AcquisitionRound

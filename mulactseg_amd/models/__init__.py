@@ -3,12 +3,10 @@
 ``.classifier``, ``.forward``, ``.feat_forward``, ``.set_return_feat`` whose ``state_dict`` key names
 equal the reference's, so the authors' checkpoints load.  In scope: the production architecture
 ``deeplabv3pluswn_resnet50deepstem`` (and its ResNet-101 twin, same code)."""
-import os
-
 import torch
 import torch.nn as nn
 
-from .deeplab import DeepLabV3PlusWN, build_deeplabv3pluswn
+from .deeplab import DeepLabV3PlusWN, build_deeplabv3pluswn  # noqa: F401  (DeepLabV3PlusWN re-exported)
 
 _ARCHS = {
     'deeplabv3pluswn_resnet50deepstem': ((3, 4, 6, 3), './checkpoint/resnet50_deepstem.pth'),

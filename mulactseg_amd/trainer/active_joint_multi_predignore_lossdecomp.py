@@ -9,7 +9,6 @@ re-compute the softmax.  Under data parallelism the normalisers ``1 + n`` are gl
 (SURVEY.md section 5.8): the fixed-point sums and counts are all-reduced before the division so that
 N GPUs x batch 4 optimise exactly the single-GPU objective of batch 4N.
 """
-import torch
 
 from ..utils.loss import FusedPartialLabelLoss, GroupMultiLabelCE_onlymulti, OnehotCEMultihotChoice
 from . import active_joint_multi_predignore

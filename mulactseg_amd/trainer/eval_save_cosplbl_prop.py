@@ -6,8 +6,6 @@ walks the selected superpixels in Python with a CPU dilation each; here the quar
 into the K9 kernels (``ops.stage2_pseudo_labels``, ``csrc/stage2.hip``)."""
 import os
 
-import numpy as np
-import torch
 
 from .. import ops
 from . import eval_within_multihot

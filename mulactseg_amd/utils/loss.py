@@ -23,7 +23,6 @@ Inputs must be ROCm tensors; there is no CPU path (``_lib.MulActSegHipError`` ot
 """
 import torch
 import torch.nn as nn
-import torch.nn.functional as F
 
 from .. import _lib, ops
 

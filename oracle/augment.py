@@ -14,7 +14,6 @@ installed here: ``tests/golden/g9_augment.npz`` is produced by ``oracle/gen_gold
 Random draws follow the reference's order on Python's ``random`` module: ``uniform`` (scale), then ``randint`` twice
 (crop row, crop column; skipped when the padded image already has the crop size), then ``random`` (flip)."""
 import math
-import random
 
 import numpy as np
 

@@ -1,6 +1,5 @@
 """K7 (fused ASPP depthwise triple) against plain PyTorch fp32 conv2d of the same op: forward, input gradient and
 weight gradients within fp32 rounding; deterministic weight gradients; model-level parity unchanged."""
-import numpy as np
 import pytest
 import torch
 import torch.nn.functional as F

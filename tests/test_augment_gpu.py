@@ -1,5 +1,4 @@
 """mas_train_augment (csrc/augment.hip) == the numpy oracle == Pillow goldens, bit for bit (floats included)."""
-import os
 import random
 
 import numpy as np

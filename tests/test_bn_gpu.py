@@ -2,7 +2,6 @@
 forward, running statistics, all gradients, inference mode, determinism; model-level parity and a training step."""
 import copy
 
-import numpy as np
 import pytest
 import torch
 import torch.nn as nn

@@ -1,7 +1,6 @@
 """GPU parity: HIP scorer kernels (through the C ABI) vs the plain-C restatement (oracle/exact.c).
 Bit-exact on every output -- integer AND float -- because both sides evaluate the arithmetic of
 csrc/detmath.h and accumulate in fixed point."""
-import os
 
 import numpy as np
 import pytest

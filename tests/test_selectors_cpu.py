@@ -8,7 +8,6 @@ import types
 
 import numpy as np
 import pytest
-import torch
 
 from helpers import FakePool, OracleBackend, fake_trainer, selector_args
 from test_oracle_golden import GOLDEN, g1_inputs, g2_inputs, tuples_to_arrays

@@ -1,6 +1,5 @@
 """csrc/upsample.hip against F.interpolate(bilinear, align_corners=False) computed on the CPU (float32 forward within
 rounding; backward against the float64 adjoint), determinism of the backward, exact adjointness."""
-import numpy as np
 import pytest
 import torch
 import torch.nn.functional as F
