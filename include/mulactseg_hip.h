@@ -335,6 +335,13 @@ int mas_cosine_head_bwd(const float* feat, const float* proxy_hat, const float* 
 int mas_maxpool3s2_fwd(const float* x, int64_t NC, int H, int W, float* y, uint8_t* arg, void* stream);
 int mas_maxpool3s2_bwd(const float* dy, const uint8_t* arg, int64_t NC, int H, int W, float* dx, void* stream);
 
+/* 1x1 convolution y[n,m,p] = sum_k w[m,k] x[n,k,p] for the small-K layers (models/segmentation/backbone/resnet.py:129-160:
+ * conv1 / conv3 / downsample of layer1, the stem's neighbours), x [N,K,HW], y [N,M,HW], HW % 4 == 0, M % 32 == 0;
+ * `w_t` is the TRANSPOSED weight [K,M].  With scale / shift (both or neither) the inference BatchNorm
+ * (y * scale[m] + shift[m]), the residual add and the ReLU that follow the convolution are applied in the epilogue. */
+int mas_conv1x1_fwd(const float* x, const float* w_t, int N, int K, int M, int HW, const float* scale, const float* shift,
+                    const float* residual, int relu, float* y, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -70,7 +70,13 @@ class Bottleneck(nn.Module):
         self.stride = stride
 
     def forward(self, x):
-        y = _bn_act(self.bn1, self.conv1(x))
+        y = None
+        if x.is_cuda and not self.training:
+            from .. import ops
+            if ops.conv1x1_bn_act_supported(self.conv1, self.bn1, x):     # small-K 1x1 + BN + ReLU in one kernel (csrc/conv1x1.hip)
+                y = ops.conv1x1_bn_act(self.conv1, self.bn1, x, True)
+        if y is None:
+            y = _bn_act(self.bn1, self.conv1(x))
         y = _bn_act(self.bn2, self.conv2(y))
         if self.downsample is not None:
             x = _run(self.downsample, x)
