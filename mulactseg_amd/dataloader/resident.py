@@ -13,6 +13,7 @@ from .formats import selection_mask
 
 
 class ResidentRegionDataset(torch.utils.data.Dataset):
+    device_resident = True          # trainers batch it with ResidentProvider instead of a DataLoader with workers
     def __init__(self, args, pictures, superpixels, multi_hot_cls, names, split='active-label', region_dict=None, rng=None):
         """pictures: list of uint8 [H,W,3] device tensors; superpixels: list of integer [H,W] device tensors;
         multi_hot_cls: uint8 [n_img, nseg, num_classes + 1]; names: list of (img, lbl, spx) path strings (the keys of

@@ -98,6 +98,9 @@ class BaseTrainer(object):
 
     # -- loaders ------------------------------------------------------------------------------------
     def get_trainloader(self, dataset):
+        if getattr(dataset, 'device_resident', False):      # samples are produced on the device (dataloader/resident.py)
+            from ..dataloader.utils import ResidentProvider
+            return ResidentProvider(dataset, batch_size=self.args.train_batch_size, drop_last=True, shuffle=True)
         return DataProvider(dataset=dataset, batch_size=self.args.train_batch_size, shuffle=True,
                             num_workers=self.args.num_workers, pin_memory=True, drop_last=True)
 
@@ -106,6 +109,9 @@ class BaseTrainer(object):
         import torch.distributed as dist
         if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
             dataset = torch.utils.data.Subset(dataset, range(dist.get_rank(), len(dataset), dist.get_world_size()))
+        if getattr(getattr(dataset, 'dataset', dataset), 'device_resident', False):
+            from ..dataloader.utils import ResidentProvider
+            return ResidentProvider(dataset, batch_size=self.args.val_batch_size, drop_last=False, shuffle=False)
         return DataProvider(dataset=dataset, batch_size=self.args.val_batch_size, shuffle=False,
                             num_workers=self.args.val_num_workers, pin_memory=True, drop_last=False)
 

@@ -204,3 +204,31 @@ def test_two_round_active_learning_loop_on_synthetic_data():
               "my_bvsb_predclsbal_pwr_banignore_selection_01.pkl", "my_bvsb_predclsbal_pwr_banignore_selection_02.pkl"):
         assert os.path.exists(os.path.join(out, f)), f
     assert all(np.isfinite(h[2]) for h in hist)
+
+
+def test_production_trainer_on_the_resident_data_path():
+    """SURVEY 8f rank 4 end to end: pictures and superpixel maps resident in HBM, augmentation by mas_train_augment,
+    batches from ResidentProvider (no DataLoader workers), the production trainer trains on them."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    import random
+    from mulactseg_amd.dataloader import ResidentProvider
+    from mulactseg_amd.dataloader.resident import ResidentRegionDataset
+    tmp = tempfile.mkdtemp()
+    tr, _ = _trainer(tmp)
+    rs = np.random.RandomState(0)
+    n = 4
+    pics = [torch.from_numpy(rs.randint(0, 256, size=(2 * H, 2 * W, 3)).astype(np.uint8)).cuda() for _ in range(n)]
+    spxs = [torch.from_numpy(synth.superpixel_map(500 + i, 2 * H, 2 * W, S).astype(np.int16)).cuda() for i in range(n)]
+    mh = torch.from_numpy(np.stack([synth.multi_hot_targets(600 + i, S, N_CLS + 1) for i in range(n)])).cuda()
+    names = [("img%d" % i, "lbl%d" % i, "spx%d" % i) for i in range(n)]
+    ds = ResidentRegionDataset(tr.args, pics, spxs, mh, names, split='active-label',
+                               region_dict={"spx%d" % i: list(range(0, S, 3)) for i in range(n)}, rng=random.Random(5))
+    ds.transform.size = (H, W)
+    ds.selection_iter = 1
+    active = types.SimpleNamespace(selection_iter=1, get_trainset=lambda: ds)
+    before = [p.detach().clone() for p in tr.net.parameters()]
+    tr.train(active)
+    assert isinstance(tr.train_dataset_loader, ResidentProvider)
+    moved = sum(float((p.detach() - q).abs().sum()) for p, q in zip(tr.net.parameters(), before))
+    assert moved > 0 and np.isfinite(moved)
