@@ -100,12 +100,21 @@ def test_resident_provider_batches_forever():
     ds = ResidentRegionDataset(types.SimpleNamespace(nseg=nseg, ignore_idx=255), pics, spxs, mh, names, split='active-label',
                                region_dict={"s%d" % i: [i, i + 1] for i in range(n)}, rng=random.Random(1))
     ds.transform.size = (48, 48)
-    prov = ResidentProvider(ds, batch_size=2, drop_last=True, shuffle=True, rng=random.Random(2))
+    prov = ResidentProvider(ds, batch_size=2, drop_last=True, shuffle=True, rng=random.Random(2), prefetch=False)
     assert len(prov) == 2
-    seen = []
+    seen, batches = [], []
     for _ in range(5):
         b = next(prov)
         assert tuple(b['images'].shape) == (2, 3, 48, 48) and b['images'].is_cuda and b['spmask'].dtype == torch.bool
         assert tuple(b['labels'].shape) == (2, nseg, 20) and len(b['fnames']) == 2
         seen += [f[2] for f in b['fnames']]
+        batches.append(b)
     assert prov.epoch == 2 and prov.iteration == 5 and len(set(seen)) == n
+    # prefetching on a side stream yields exactly the same batches (same order of the random draws)
+    ds.transform.rng = random.Random(1)
+    pre = ResidentProvider(ds, batch_size=2, drop_last=True, shuffle=True, rng=random.Random(2), prefetch=True)
+    for b in batches:
+        c = next(pre)
+        assert c['fnames'] == b['fnames'] and torch.equal(c['images'], b['images']) and torch.equal(c['spx'], b['spx'])
+        assert torch.equal(c['spmask'], b['spmask'])
+    assert pre.epoch == 2 and pre.iteration == 5
