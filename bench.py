@@ -2,20 +2,24 @@
 """bench.py -- MulActSeg hot path on MI355X: superpixels scored/sec (+ train-iter images/sec).
 
 Contract (driver):  python bench.py --gpus N --steps K --warmup W
-  N > 1 is launched by the driver as `python -m torch.distributed.run --nproc-per-node N ... bench.py`,
-  one rank per GPU; the pool of unlabeled images is sharded across ranks (no data-path collective in
-  the scan; the two tiny exchanges of the acquisition round -- class sums, scores -- are RCCL
-  collectives inside the timed region).
+  N > 1 is launched by the driver as `python -m torch.distributed.run --nproc-per-node N ... bench.py`, one rank per GPU.
 
-Workload "acquisition-scan" (BASELINE.json metric "superpixels scored/sec"): one step = one reference
-batch (val_batch_size = 4 pool images, logits [4,20,1024,2048] f32 + superpixel ids, already resident
-in HBM) through the scorer hot path of the PixBal + ban-ignore selector
-(reference: active_selection/my_bvsb_predclsbal_pwr_banignore.py:35-84): class-prior sums, per-superpixel
-margin sums and arg-max-class histograms in ONE scan of the logits (k_single_pass, the product default);
-after the K timed steps the weighted means + ban of all scored regions (k_region_finalize_weighted) and their
-ordering + budgeted selection walk (K4, budget scaled to the scored share of the 2975-image pool) run once,
-inside the timed region.  value = steps * 4 * 2048 * n_gpus / seconds.
-The reference-structured two-pass kernels (K2, K1+K3) are timed separately and reported under "two_pass".
+Primary workload "acquisition-round" (BASELINE.json metric "superpixels scored/sec"; config 3's shapes).  One step = one
+reference batch (val_batch_size = 4 pool pictures: logits [4,20,1024,2048] f32 + superpixel ids, resident in HBM) through
+the single-pass scan of the PixBal + ban-ignore selector (class prior + per-region margin sums + arg-max histograms,
+reference active_selection/my_bvsb_predclsbal_pwr_banignore.py:35-72).  Every rank scans K batches of ITS shard (weak
+scaling: per-GPU work fixed); then, still inside the timed region, the round is finished exactly as the selector plugins
+finish it (`engine.AcquisitionRound` -- the product object, not a private loop):
+  exchange 1  all-gather of the per-picture class sums (RCCL)  ->  host f64 class weights (one D2H read)
+  weighted region means + ban (k_region_finalize_weighted) on the rank's rows
+  exchange 2  all-gather of the region scores (RCCL)
+  K4          64-bit keys, radix sort, fair-counting budget walk over ALL N*K*4*2048 regions, replicated on every rank.
+value = N * K * 4 * 2048 / seconds (max over ranks, barrier + synchronize on both sides).
+
+Secondary legs (same JSON line): the reference-structured two-pass kernels; "pool_round" -- the FIXED 2 975-picture x
+2 048-superpixel pool with a 100 000-click budget through RegionSelector.select_next_batch, sharded over the ranks (strong
+scaling), scan-only and with the model forward; "train_iter" / "train_iter_769" -- the stage-1 step at the reference's real
+768x768 crop and at BASELINE.json's literal 769x769; "acquisition_with_model"; "stage2"; "cpu_baseline" (rank 0, N = 1).
 
 Prints ONE JSON line on rank 0.
 """
@@ -23,7 +27,9 @@ import argparse
 import json
 import os
 import sys
+import tempfile
 import time
+import types
 
 import numpy as np
 import torch
@@ -33,9 +39,8 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6.3 TB/s is achievable
-
-
-EVENT_EVERY = 4       # HIP-event pairs around every 4th scan launch of the timed region
+EVENT_EVERY = 4            # HIP-event pairs around every 4th scan launch of the timed region
+POOL_IMAGES, POOL_CLICKS = 2975, 100000
 
 
 def parse():
@@ -53,79 +58,204 @@ def parse():
     ap.add_argument("--ramp", type=int, default=100, help="untimed launches before the warm-up steps (GPU clock ramp)")
     ap.add_argument("--nbuf", type=int, default=3, help="distinct resident batches rotated through")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-train", action="store_true", help="skip the secondary train-iter measurement")
+    ap.add_argument("--no-train", action="store_true", help="skip the model legs (train-iter, acquisition with model, stage 2)")
+    ap.add_argument("--no-pool", action="store_true", help="skip the fixed-pool (strong scaling) acquisition round")
     ap.add_argument("--train-steps", type=int, default=8)
     ap.add_argument("--acq-steps", type=int, default=8, help="steps of the secondary model-forward + scan measurement")
     ap.add_argument("--crop", type=int, default=768, help="training crop (reference: 768, transform.py:107)")
-    ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU-baseline budget")
+    ap.add_argument("--cpu-images", type=int, default=16, help="pictures of the CPU-baseline scorer sample")
+    ap.add_argument("--cpu-reps", type=int, default=1, help="repetitions per thread count (median reported)")
+    ap.add_argument("--cpu-loss-steps", type=int, default=2)
+    ap.add_argument("--cpu-full", action="store_true",
+                    help="SURVEY section 8(d) protocol: 32 pictures, median of 3, 10 loss steps (takes ~10 minutes)")
     return ap.parse_args()
 
 
 def make_batch(seed, B, C, H, W, S, id_dtype, device):
     """Synthetic Cityscapes-shaped batch generated on the device (plumbing): cosine-like logits with a
-    blocky class layout, jittered-grid superpixel map (mulactseg_amd.synth)."""
-    from mulactseg_amd import synth
+    blocky class layout, jittered-grid superpixel map (mulactseg_amd.synth_pool)."""
+    from mulactseg_amd.synth_pool import device_superpixel_maps
     g = torch.Generator(device=device)
     g.manual_seed(seed)
     z = 0.35 * torch.randn((B, C, H, W), generator=g, device=device, dtype=torch.float32)
     cm = torch.randint(0, C, (B, 1, H // 32 + 1, W // 32 + 1), generator=g, device=device)
     cm = cm.repeat_interleave(32, 2).repeat_interleave(32, 3)[:, :, :H, :W]
     z.scatter_add_(1, cm, torch.full_like(cm, 0.6, dtype=torch.float32))
-    spx = np.stack([synth.superpixel_map(seed * 131 + i, H, W, S) for i in range(B)])
-    return z.contiguous(), torch.from_numpy(spx).to(getattr(torch, id_dtype)).to(device)
+    spx = device_superpixel_maps([seed * 131 + i for i in range(B)], H, W, S, device, torch.int16)
+    return z.contiguous(), spx.to(getattr(torch, id_dtype)).contiguous()
 
 
-def cpu_baseline(args, budget_s):
-    """Reference CPU path ("port": oracle/port.py, the torch-CPU restatement pinned bit-exact to the
-    executed reference) on a bounded sample of the same workload, all host cores."""
-    from mulactseg_amd import synth
-    from oracle import port
-    cores = os.cpu_count() or 1
-    torch.set_num_threads(cores)
-    C, H, W, S = args.classes, args.height, args.width, args.nseg
+def _dist():
+    import torch.distributed as dist
+    return dist if dist.is_available() and dist.is_initialized() else None
 
-    def sample(n):
-        z = torch.from_numpy(synth.logits(7, n, C, H, W))
-        spx = torch.from_numpy(np.stack([synth.superpixel_map(900 + i, H, W, S) for i in range(n)]))
-        return z, spx
 
-    def run(z, spx):
-        """calculate_scores (both passes + ban) -> tuple list -> sorted(reverse=True) -> budget walk, as the reference does"""
-        n = z.shape[0]
-        r = port.pixbal_scores(z, spx, args.batch, 0.1, 6.0, S, ban_ignore=True)
-        im_idx = [["img_%05d.png" % i, "lbl_%05d.png" % i, "spx_%05d.pkl" % i] for i in range(n)]
-        suppix = {k[2]: list(range(S)) for k in im_idx}
-        tuples = port.score_list(im_idx, suppix, r['scores'])
-        return port.select_regions(tuples, max(1, int(100000 * n / 2975)))
+def fence():
+    torch.cuda.synchronize()
+    d = _dist()
+    if d is not None and d.get_world_size() > 1:
+        d.barrier()
+        torch.cuda.synchronize()
 
-    z, spx = sample(1)
+
+def max_over_ranks(seconds, dev):
+    d = _dist()
+    if d is None or d.get_world_size() == 1:
+        return seconds
+    t = torch.tensor([seconds], dtype=torch.float64, device=dev)
+    d.all_reduce(t, op=d.ReduceOp.MAX)
+    return float(t.item())
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# primary leg
+# ------------------------------------------------------------------------------------------------------------------
+class ScanRound:
+    """K batches of this rank's shard through engine.AcquisitionRound, then the round's tail (two exchanges, host class
+    weights, weighted finalize + ban, replicated K4 with a fair-counting budget)."""
+
+    def __init__(self, args, dev, rank, world, backend, bufs, n_steps, cost_seed=5):
+        from mulactseg_amd.active_selection.engine import AcquisitionRound
+        B, C, S = args.batch, args.classes, args.nseg
+        self.args, self.bufs, self.n_steps, self.backend = args, bufs, n_steps, backend
+        self.n_img = world * n_steps * B
+        self.rnd = AcquisitionRound(self.n_img, C, S, B, 0.1, backend, rank=rank, world=world, single_pass=True)
+        assert self.rnd.plan.n_local == n_steps * B
+        g = torch.Generator(device=dev)
+        g.manual_seed(cost_seed)
+        # click cost per region under fair counting + or-labeling = number of classes under it (1..4), replicated
+        self.cost = (torch.rand((self.n_img, S), generator=g, device=dev) ** 3 * 4).to(torch.uint8).clamp_(0, 3) + 1
+        self.rank_t = torch.arange(self.n_img, dtype=torch.int32, device=dev)
+        self.budget = max(1, int(POOL_CLICKS * self.n_img / POOL_IMAGES))
+        self.events = []
+        self.tail_ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+
+    def scan(self, i, timed):
+        z, spx = self.bufs[i % len(self.bufs)]
+        if timed:
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+        self.rnd.add_single_pass(i * self.args.batch, z, spx)
+        if timed:
+            b.record()
+            self.events.append((a, b))
+
+    def tail(self):
+        C = self.args.classes
+        self.tail_ev[0].record()
+        cls_w = self.rnd.class_weights(6.0)                                    # exchange 1 + host f64
+        scores = self.rnd.scores_single_pass(cls_w, ban_class=C - 1)           # finalize + ban, exchange 2
+        n, simg, sid, ssc = self.backend.select(scores, None, self.rank_t, self.rank_t, self.cost, self.budget, self.budget + 1)
+        self.tail_ev[1].record()
+        self.scores = scores
+        self.selected = (simg, sid, ssc)
+        return n
+
+    def run(self, timed):
+        for i in range(self.n_steps):
+            self.scan(i, timed and i % EVENT_EVERY == 0)
+        return self.tail()
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# fixed-pool round (strong scaling) through the selector plugin
+# ------------------------------------------------------------------------------------------------------------------
+class ModelOnRotatingPictures(torch.nn.Module):
+    """trainer.net for the pool round WITH the model forward: picture indices in, logits of the real network out.  The
+    2 975 x 25 MB of pool pictures are rotated out of `nbuf` resident synthetic batches (the forward's cost does not
+    depend on the pixel values)."""
+
+    def __init__(self, net, B, H, W, dev, nbuf=2):
+        super().__init__()
+        self.net = net
+        g = torch.Generator(device=dev)
+        g.manual_seed(31)
+        self.pictures = torch.randn((nbuf, B, 3, H, W), generator=g, device=dev)
+        self.k = 0
+
+    def forward(self, indices):
+        self.k += 1
+        return self.net(self.pictures[self.k % self.pictures.shape[0]][:indices.shape[0]])
+
+
+def pool_round_bench(args, dev, rank, world, with_model):
+    """BASELINE.json config 3 at its real size: 2 975 pictures x 2 048 superpixels, 100 000 clicks (fair counting), through
+    RegionSelector.select_next_batch -- scan (+ model forward), two exchanges, host class weights, finalize + ban, K4 on
+    6.09 M keys, RegionActiveDataset bookkeeping.  The pool is sharded over the ranks: strong scaling."""
+    from mulactseg_amd.active_selection import my_bvsb_predclsbal_pwr_banignore as banignore
+    from mulactseg_amd.active_selection.engine import ShardPlan
+    from mulactseg_amd.dataloader import RegionActiveDataset
+    from mulactseg_amd.synth_pool import LogitSource, SyntheticLabels, SyntheticPool
+    B, C, H, W, S = args.batch, args.classes, args.height, args.width, args.nseg
+    plan = ShardPlan(POOL_IMAGES, B, rank, world)
+    pool = SyntheticPool(POOL_IMAGES, H, W, S, dev, shard=(plan.img_lo, plan.img_hi))
+    labels = SyntheticLabels(pool, C)
+    if with_model:
+        from mulactseg_amd.models import get_model
+        net = ModelOnRotatingPictures(get_model('deeplabv3pluswn_resnet50deepstem', C, 16, True, pretrained_backbone=False).to(dev).eval(),
+                                      B, H, W, dev)
+    else:
+        net = LogitSource(C, H, W, dev, nbuf=3)
+    tmp = tempfile.mkdtemp(prefix="mas_pool_r%d_" % rank)
+    a = types.SimpleNamespace(val_batch_size=B, val_num_workers=0, nseg=S, active_method='pixbal', num_classes=C - 1, ce_temp=0.1,
+                              cls_weight_coeff=6.0, method='active_joint_multi_predignore_lossdecomp', save_scores=False,
+                              fair_counting=True, or_labeling=True, model_save_dir=tmp, finetune_itrs=1,
+                              wandb=types.SimpleNamespace(log=lambda *x, **k: None))
+    marks = {}
+
+    class Timed(banignore.RegionSelector):
+        def calculate_scores_tensor(self, trainer, pool_set, want_hist=False):
+            out = super().calculate_scores_tensor(trainer, pool_set, want_hist)
+            torch.cuda.synchronize()
+            marks['scored'] = time.perf_counter()
+            return out
+
+    sel = Timed(a)
+    trainer = types.SimpleNamespace(net=net, device=dev, model_save_dir=tmp, selection_iter=1)
+    active = RegionActiveDataset(a, pool, labels)
+    active.selection_iter = 1
+    expand = active.expand_training_set
+
+    def timed_expand(*x, **k):
+        torch.cuda.synchronize()
+        marks['selected'] = time.perf_counter()
+        return expand(*x, **k)
+    active.expand_training_set = timed_expand
+    if with_model:                              # MIOpen's find runs on the first calls of a new shape
+        with torch.no_grad():
+            for _ in range(3):
+                net(torch.zeros(B))
+    fence()
     t0 = time.perf_counter()
-    run(z, spx)
-    t1 = time.perf_counter() - t0
-    n = int(max(1, min(16, budget_s // max(t1, 1e-3))))
-    if n > 1:
-        z, spx = sample(n)
-        t0 = time.perf_counter()
-        run(z, spx)
-        t1 = time.perf_counter() - t0
-    return {"value": n * S / t1, "unit": "superpixels/s", "cores": cores, "kind": "port",
-            "sample": "%d synthetic %dx%dx%d images, nseg %d: both passes + ban + tuple list + sort + budget walk "
-                      "(oracle/port.py, torch %s CPU, %d threads), %.1f s" % (n, C, H, W, S, torch.__version__, cores, t1)}
+    sel.select_next_batch(trainer, active, POOL_CLICKS)
+    fence()
+    t1 = time.perf_counter()
+    dt = max_over_ranks(t1 - t0, dev)
+    n_sel = sum(len(v) for v in labels.suppix.values())
+    return {"seconds": dt, "superpixels_per_s": POOL_IMAGES * S / dt, "regions_selected": n_sel,
+            "rank0_breakdown_s": {"scores (scan%s + exchanges + class weights + finalize)" % (" + model forward" if with_model else ""):
+                                  marks['scored'] - t0,
+                                  "valid mask + cost table + K4 (keys, radix sort, walk)": marks['selected'] - marks['scored'],
+                                  "RegionActiveDataset.expand_training_set + selection pickle (host)": t1 - marks['selected']},
+            "images_per_rank": plan.n_local}
 
 
-def train_iter_bench(args, dev, world):
+# ------------------------------------------------------------------------------------------------------------------
+# model legs
+# ------------------------------------------------------------------------------------------------------------------
+def train_iter_bench(args, dev, world, crop):
     """Secondary metric "train-iter images/sec" (BASELINE.json configs[1]): stage-1 step on a
     [4,20,crop,crop] batch.  (a) loss-only: fused partial-label losses fwd+bwd on resident logits;
     (b) full iteration: DeepLabv3+WN/ResNet50-deepstem fwd + losses + bwd + AdamW (fp32, random init)."""
     from mulactseg_amd import synth
-    from mulactseg_amd.models import get_model
+    from mulactseg_amd.models import deeplab, get_model
     from mulactseg_amd.utils.loss import FusedPartialLabelLoss
-    N, C, S, crop = 4, args.classes, args.nseg, args.crop
+    N, C, S = 4, args.classes, args.nseg
     spx, msk = zip(*[synth.train_crop(50 + i, crop, crop, S, frac_selected=0.09) for i in range(N)])
     spx = torch.from_numpy(np.stack(spx)).to(dev)
     msk = torch.from_numpy(np.stack(msk)).to(dev)
     tgt = torch.from_numpy(np.stack([synth.multi_hot_targets(70 + i, S, C) for i in range(N)])).to(dev)
-    crit = FusedPartialLabelLoss(S, 0.1, 0.1, sync_normalisers=world > 1 or torch.distributed.is_initialized())     # global 1 + n over the data-parallel batch
+    crit = FusedPartialLabelLoss(S, 0.1, 0.1, sync_normalisers=True)     # global 1 + n over the data-parallel batch
     g = torch.Generator(device=dev)
     g.manual_seed(5)
     z = (0.35 * torch.randn((N, C, crop, crop), generator=g, device=dev)).requires_grad_(True)
@@ -148,7 +278,7 @@ def train_iter_bench(args, dev, world):
     net = get_model('deeplabv3pluswn_resnet50deepstem', C, 16, True, pretrained_backbone=False).to(dev).train()
     opt = torch.optim.AdamW([{'params': net.backbone.parameters(), 'lr': 2e-5},
                              {'params': net.classifier.parameters(), 'lr': 2e-4}], lr=2e-5, weight_decay=1e-5, fused=True)
-    if world > 1 or torch.distributed.is_initialized():       # data parallel as the trainers run it: gradients all-reduced over RCCL
+    if _dist() is not None:       # data parallel as the trainers run it: gradients all-reduced over RCCL
         net = torch.nn.parallel.DistributedDataParallel(net, device_ids=[dev.index], output_device=dev.index)
     images = torch.randn((N, 3, crop, crop), generator=g, device=dev)
 
@@ -159,18 +289,23 @@ def train_iter_bench(args, dev, world):
 
     for _ in range(2):
         full_step()
-    torch.cuda.synchronize()
+    deeplab.path_report(reset=True)
+    full_step()
+    paths = deeplab.path_report(reset=True)
+    fence()
     t0 = time.perf_counter()
     for _ in range(args.train_steps):
         full_step()
-    torch.cuda.synchronize()
-    it_ms = (time.perf_counter() - t0) / args.train_steps * 1e3
+    fence()
+    it_ms = max_over_ranks(time.perf_counter() - t0, dev) / args.train_steps * 1e3
     return {"metric": "train-iter images/sec", "value": N * world / (it_ms * 1e-3), "unit": "images/s", "ms_per_iter": it_ms,
             "config": {"workload": "stage-1 step: DeepLabv3+WN/ResNet50-deepstem fwd+bwd (MIOpen fp32 + HIP memory-bound layers) + fused "
-                                   "partial-label losses (HIP) + AdamW" + ("; DistributedDataParallel over RCCL, global loss normalisers" if world > 1 else ""), "batch": [N, 3, crop, crop], "logits": [N, C, crop, crop], "nseg": S,
+                                   "partial-label losses (HIP) + AdamW" + ("; DistributedDataParallel over RCCL, global loss normalisers" if world > 1 else ""),
+                       "batch": [N, 3, crop, crop], "logits": [N, C, crop, crop], "nseg": S,
                        "selected_fraction": float(msk.float().mean())},
+            "layer_paths_per_step": paths,
             "loss_only": {"ms_fwd_bwd": loss_ms, "algorithmic_GBs": loss_bytes / (loss_ms * 1e-3) / 1e9,
-                          "bytes": loss_bytes, "note": "includes ~8 small launches and the autograd glue"}}
+                          "bytes": loss_bytes, "note": "includes the small launches around the two scans and the autograd glue"}}
 
 
 def acquisition_with_model_bench(args, dev, world):
@@ -178,7 +313,7 @@ def acquisition_with_model_bench(args, dev, world):
     DeepLabv3+WN/ResNet50-deepstem (fp32, random init) on a [B,3,H,W] pool batch + the single-pass scan of its logits.
     The reference structure needs two forwards per image (class prior, then scores); the single-pass scan needs one."""
     from mulactseg_amd import ops
-    from mulactseg_amd.models import get_model
+    from mulactseg_amd.models import deeplab, get_model
     B, C, H, W, S = args.batch, args.classes, args.height, args.width, args.nseg
     net = get_model('deeplabv3pluswn_resnet50deepstem', C, 16, True, pretrained_backbone=False).to(dev).eval()
     g = torch.Generator(device=dev)
@@ -197,6 +332,9 @@ def acquisition_with_model_bench(args, dev, world):
 
     for _ in range(4):              # MIOpen's find runs on the first calls of every new shape
         step()
+    deeplab.path_report(reset=True)
+    step()
+    paths = deeplab.path_report(reset=True)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.acq_steps):
@@ -204,9 +342,9 @@ def acquisition_with_model_bench(args, dev, world):
     torch.cuda.synchronize()
     ms = (time.perf_counter() - t0) / args.acq_steps * 1e3
     return {"metric": "superpixels scored/sec incl. model forward", "value": B * S * world / (ms * 1e-3), "unit": "superpixels/s",
-            "ms_per_batch": ms, "forwards_per_image": 1,
-            "config": {"workload": "eval forward (MIOpen fp32) of [%d,3,%d,%d] + single-pass scan; the reference structure runs the "
-                                   "forward twice per pool image" % (B, H, W)}}
+            "ms_per_batch": ms, "forwards_per_image": 1, "layer_paths_per_step": paths,
+            "config": {"workload": "eval forward (MIOpen fp32 + HIP layers) of [%d,3,%d,%d] + single-pass scan; the reference structure "
+                                   "runs the forward twice per pool image" % (B, H, W)}}
 
 
 def stage2_bench(args, dev):
@@ -252,23 +390,147 @@ def stage2_bench(args, dev):
     return {"metric": "stage-2 pseudo-label generation, ms per 1024x2048 image (model forward + K9 kernels)", **res}
 
 
+# ------------------------------------------------------------------------------------------------------------------
+# CPU baseline (rank 0, N = 1): oracle/port.py = the reference's op sequence in torch-CPU, pinned bit-exact to the
+# executed reference by tests/test_oracle_golden.py.  This is the ONLY place bench.py touches oracle/.
+# ------------------------------------------------------------------------------------------------------------------
+def numpy_select(scores, cost, budget):
+    """sorted(tuples, reverse=True) + budget walk on arrays (path rank = picture index): consumed (picture, id) pairs."""
+    n, s = scores.shape
+    img = np.repeat(np.arange(n), s)
+    rid = np.tile(np.arange(s), n)
+    order = np.lexsort((-rid, -img, -scores.reshape(-1).astype(np.float64)))
+    cum = np.cumsum(cost.reshape(-1)[order].astype(np.int64))
+    over = np.nonzero(cum > budget)[0]
+    m = len(order) if len(over) == 0 else int(over[0]) + 1
+    return img[order[:m]], rid[order[:m]]
+
+
+def cpu_baseline(args, dev, bufs, backend):
+    """the reference CPU path on the GPU box's host cores, on the SAME tensors the GPU leg scans (the
+    resident batches, copied to the host).  Scorer round (both passes + ban + tuple list + Python sort + budget walk) at
+    os.cpu_count() threads and at the reference's own default of 20 (utils/common.py:343), the partial-label losses
+    fwd+bwd on [4,20,768,768], and the model forward on one pool batch.  Bounded by --cpu-images / --cpu-reps; --cpu-full
+    runs the protocol's sizes (32 pictures, median of 3, 10 loss steps)."""
+    from mulactseg_amd import synth
+    from oracle import port
+    cores = os.cpu_count() or 1
+    B, C, H, W, S = args.batch, args.classes, args.height, args.width, args.nseg
+    n_img = 32 if args.cpu_full else max(B, args.cpu_images // B * B)
+    reps = 3 if args.cpu_full else args.cpu_reps
+    loss_steps = 10 if args.cpu_full else args.cpu_loss_steps
+    n_b = n_img // B
+    host = [(z.cpu(), spx.cpu().to(torch.int64)) for z, spx in bufs]                  # generated once on the device, copied
+    im_idx = [["img_%05d.png" % i, "lbl_%05d.png" % i, "spx_%05d.pkl" % i] for i in range(n_img)]
+    suppix = {k[2]: list(range(S)) for k in im_idx}
+    g = torch.Generator(device=dev)
+    g.manual_seed(5)
+    cost = ((torch.rand((n_img, S), generator=g, device=dev) ** 3 * 4).to(torch.uint8).clamp_(0, 3) + 1).cpu().numpy()
+    budget = max(1, int(POOL_CLICKS * n_img / POOL_IMAGES))
+    row = {','.join(k): i for i, k in enumerate(im_idx)}
+
+    def scorer_round():
+        """calculate_scores (pass 1, class weights, pass 2, ban) -> tuple list -> sorted(reverse=True) -> budget walk"""
+        means = [port.class_prior_batch(host[b % len(host)][0], 0.1) for b in range(n_b)]
+        _, w = port.class_weight(means, 6.0)
+        rb, rh = [], []
+        for b in range(n_b):
+            z, spx = host[b % len(host)]
+            r, h = port.region_scores_batch(z, spx, 0.1, w, S, C)
+            rb.append(r)
+            rh.append(h)
+        sc, _ = port.ban_ignore_dominant(torch.cat(rb).view(-1), torch.cat(rh).view(-1, C))
+        sc = sc.view(n_img, S)
+        tuples = port.score_list(im_idx, suppix, sc)
+        taken = port.select_regions(tuples, budget, lambda path, rid: int(cost[row[path], rid]))
+        return sc.numpy(), taken
+
+    def timed(threads):
+        torch.set_num_threads(threads)
+        ts = []
+        for _ in range(reps):
+            t0 = time.perf_counter()
+            out = scorer_round()
+            ts.append(time.perf_counter() - t0)
+        return float(np.median(ts)), ts, out
+
+    t_all, ts_all, (sc_cpu, taken) = timed(cores)
+    t_20, ts_20, _ = timed(min(20, cores))
+    best = min(t_all, t_20)
+
+    # the same pictures through the GPU round: selected sets compared (the reference's f32 order vs the fixed-point scan)
+    from mulactseg_amd.active_selection.engine import AcquisitionRound
+    rnd = AcquisitionRound(n_img, C, S, B, 0.1, backend, rank=0, world=1, single_pass=True)
+    for b in range(n_b):
+        z, spx = bufs[b % len(bufs)]
+        rnd.add_single_pass(b * B, z, spx)
+    sc_gpu = rnd.scores_single_pass(rnd.class_weights(6.0), ban_class=C - 1).cpu().numpy()
+    gi, gid = numpy_select(sc_gpu, cost, budget)
+    gpu_set = set(zip(gi.tolist(), gid.tolist()))
+    cpu_set = {(row[p], r) for _, p, r in taken}
+    nz = sc_cpu != 0
+    sel_cmp = {"selected_gpu": len(gpu_set), "selected_cpu": len(cpu_set), "symmetric_difference": len(gpu_set ^ cpu_set),
+               "max_rel_delta_score": float((np.abs(sc_gpu[nz] - sc_cpu[nz]) / sc_cpu[nz]).max()),
+               "same_zero_regions": bool(np.array_equal(nz, sc_gpu != 0))}
+
+    # losses: OnehotCEMultihotChoice + GroupMultiLabelCE_onlymulti fwd + bwd (utils/loss.py:81-141,535-588 subclasses)
+    torch.set_num_threads(cores)
+    N, crop = 4, 768
+    sp, mk = zip(*[synth.train_crop(50 + i, crop, crop, S, frac_selected=0.09) for i in range(N)])
+    sp, mk = torch.from_numpy(np.stack(sp)), torch.from_numpy(np.stack(mk))
+    tg = torch.from_numpy(np.stack([synth.multi_hot_targets(70 + i, S, C) for i in range(N)]))
+    zl = (0.35 * torch.randn((N, C, crop, crop), generator=torch.Generator().manual_seed(5))).requires_grad_(True)
+    lt = []
+    for _ in range(loss_steps):
+        zl.grad = None
+        t0 = time.perf_counter()
+        ce, mc = port.merged_positive_ce(zl, tg, sp, mk, 0.1, 'decomp')
+        gr = port.group_max_ce(zl, tg, sp, mk, S, 0.1, 'onlymulti')
+        (16.0 * ce + 8.0 * mc + gr).backward()
+        lt.append(time.perf_counter() - t0)
+
+    # model forward of one pool batch (same architecture in plain PyTorch ops on the host; parity pinned by G4)
+    from mulactseg_amd.models import get_model
+    net = get_model('deeplabv3pluswn_resnet50deepstem', C, 16, True, pretrained_backbone=False).eval()
+    x = torch.randn((B, 3, H, W), generator=torch.Generator().manual_seed(9))
+    with torch.no_grad():
+        t0 = time.perf_counter()
+        net(x)
+        t_model = time.perf_counter() - t0
+
+    per_img = best / n_img
+    return {"value": n_img * S / best, "unit": "superpixels/s", "cores": cores if t_all <= t_20 else min(20, cores), "kind": "port",
+            "sample": "%d pictures = %d of the GPU leg's resident [%d,%d,%d,%d] batches copied to the host; scorer round = both passes + ban + "
+                      "tuple list + Python sort + fair-counting budget walk (oracle/port.py, torch %s CPU); median of %d"
+                      % (n_img, n_b, B, C, H, W, torch.__version__, reps),
+            "scorer_seconds": {"threads_%d" % cores: t_all, "threads_%d" % min(20, cores): t_20, "runs": {"all": ts_all, "20": ts_20}},
+            "extrapolated_pool_round_s": {"scorer_only": per_img * POOL_IMAGES,
+                                          "with_two_model_forwards": (per_img + 2 * t_model / B) * POOL_IMAGES,
+                                          "note": "linear in the picture count: %.3f s per picture x 2 975 (the reference runs the model "
+                                                  "twice per picture, once per pass)" % per_img},
+            "selection_vs_gpu": sel_cmp,
+            "losses": {"seconds_per_step_fwd_bwd": float(np.median(lt)), "steps": loss_steps, "threads": cores,
+                       "shape": [N, C, crop, crop], "selected_fraction": float(mk.float().mean())},
+            "model_forward": {"seconds_per_batch": t_model, "batch": [B, 3, H, W], "threads": cores}}
+
+
 def pmc_traffic(kernel, default_shape):
-    """HBM bytes per launch of `kernel` from the latest committed rocprofv3 --pmc summary
+    """(HBM bytes per launch, source file) of `kernel` from the latest committed rocprofv3 --pmc summary
     (profiles/r*/..pmc_traffic.json, produced by profiles/summarize.py from separate FETCH_SIZE / WRITE_SIZE
-    passes of this same command, gfx950 FETCH_SIZE x2 correction applied).  None when the bench shape is not the
+    passes of this same command, gfx950 FETCH_SIZE x2 correction applied).  (None, None) when the bench shape is not the
     profiled default shape or no summary is present: PMC counters cannot be read from inside this process."""
     if not default_shape:
-        return None
+        return None, None
     import glob
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "*pmc_traffic.json")))
     for f in reversed(files):
         try:
             k = json.load(open(f))["kernels"].get(kernel)
             if k:
-                return k["hbm_bytes_per_launch"]
+                return k["hbm_bytes_per_launch"], os.path.relpath(f, ROOT)
         except Exception:
             continue
-    return None
+    return None, None
 
 
 def main():
@@ -286,69 +548,31 @@ def main():
     torch.cuda.set_device(dev)
 
     from mulactseg_amd import ops
+    from mulactseg_amd.active_selection.engine import HipBackend
+    backend = HipBackend(dev)
     B, C, H, W, S = args.batch, args.classes, args.height, args.width, args.nseg
     invT = ops.inv_temperature(0.1)
     bufs = [make_batch(1000 * rank + 17 * i + 1, B, C, H, W, S, args.id_dtype, dev) for i in range(args.nbuf)]
-    cls_w = torch.linspace(0.3, 1.0, C, device=dev)
-
-    n_total = args.steps + args.warmup
-    prob = torch.zeros((n_total, B, C), dtype=torch.int64, device=dev)
-    csum = torch.zeros((n_total, B, S, C), dtype=torch.int64, device=dev)
-    hist = torch.zeros((n_total, B, S, C), dtype=torch.int32, device=dev)
-    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(n_total)]
-    w31 = torch.from_numpy(ops.weights_to_fixed31(cls_w.cpu().numpy()).view(np.int32)).to(dev)
-
-    def step(i):
-        z, spx = bufs[i % args.nbuf]
-        timed = i >= args.warmup and (i - args.warmup) % EVENT_EVERY == 0     # an event pair costs ~2 barrier packets: sample
-        if timed:
-            ev[i][0].record()
-        ops.single_pass_accum(z, spx, S, invT, prob_sum=prob[i], class_sum=csum[i], hist=hist[i])
-        if timed:
-            ev[i][1].record()
-
-    def finish(lo, hi):
-        """Weighted means + ban for every region scored in steps [lo, hi), then ordering + budget walk."""
-        n_img = (hi - lo) * B
-        score = ops.region_finalize_weighted(csum[lo:hi].view(n_img, S, C), hist[lo:hi].view(n_img, S, C), w31, C - 1)[0]
-        rank_t = torch.arange(n_img, dtype=torch.int32, device=dev)
-        keys = ops.sort_keys_desc(ops.region_keys(score, None, rank_t))
-        budget = max(1, int(100000 * n_img / 2975))
-        nsel, simg, sid, ssc = ops.budget_walk(keys, None, rank_t, S, budget, budget + 1)
-        return int(nsel.item())
-
-    def fence():
-        torch.cuda.synchronize()
-        if world > 1:
-            import torch.distributed as dist
-            dist.barrier()
-            torch.cuda.synchronize()
 
     # untimed clock ramp: the first ~50 launches after an idle period run ~20 % slower than the steady state (power
-    # management), whatever --warmup the caller passes; the scan is re-run on the warm-up slots, results discarded
+    # management), whatever --warmup the caller passes
+    p0 = torch.zeros((B, C), dtype=torch.int64, device=dev)
+    c0 = torch.zeros((B, S, C), dtype=torch.int64, device=dev)
+    h0 = torch.zeros((B, S, C), dtype=torch.int32, device=dev)
     for k in range(args.ramp):
         z, spx = bufs[k % args.nbuf]
-        ops.single_pass_accum(z, spx, S, invT, prob_sum=prob[0], class_sum=csum[0], hist=hist[0])
-    prob[0].zero_(); csum[0].zero_(); hist[0].zero_()
-    for i in range(args.warmup):
-        step(i)
+        ops.single_pass_accum(z, spx, S, invT, prob_sum=p0, class_sum=c0, hist=h0)
     if args.warmup:
-        finish(0, args.warmup)
+        ScanRound(args, dev, rank, world, backend, bufs, args.warmup).run(False)
+    timed = ScanRound(args, dev, rank, world, backend, bufs, args.steps)
     fence()
     t0 = time.perf_counter()
-    for i in range(args.warmup, n_total):
-        step(i)
-    n_selected = finish(args.warmup, n_total)
+    n_selected = timed.run(True)
     fence()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        import torch.distributed as dist
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+    dt = max_over_ranks(time.perf_counter() - t0, dev)
 
-    sampled = [ev[i] for i in range(args.warmup, n_total) if (i - args.warmup) % EVENT_EVERY == 0]
-    sp_ms = float(np.mean([a.elapsed_time(b) for a, b in sampled]))
+    sp_ms = float(np.mean([a.elapsed_time(b) for a, b in timed.events]))
+    tail_ms = float(timed.tail_ev[0].elapsed_time(timed.tail_ev[1]))
     id_bytes = {"int64": 8, "int32": 4, "int16": 2}[args.id_dtype]
     # algorithmic bytes of one k_single_pass launch: logits + ids read once, (prob + class sums + hist) written once
     sp_bytes = B * (C * H * W * 4 + H * W * id_bytes + S * C * (8 + 4) + C * 8)
@@ -364,6 +588,7 @@ def main():
             a.record(); fn(k); b.record()
         torch.cuda.synchronize()
         return float(np.mean([a.elapsed_time(b) for a, b in es]))
+    cls_w = torch.linspace(0.3, 1.0, C, device=dev)
     p2 = torch.zeros((B, C), dtype=torch.int64, device=dev)
     s2 = torch.zeros((B, S), dtype=torch.int64, device=dev)
     h2 = torch.zeros((B, S, C), dtype=torch.int32, device=dev)
@@ -373,42 +598,62 @@ def main():
     k2_bytes = B * (C * H * W * 4)
     k3_bytes = B * (C * H * W * 4 + H * W * id_bytes + S * (8 + 4 * C))
     default_shape = (B, C, H, W, S, args.id_dtype) == (4, 20, 1024, 2048, 2048, "int64")
+    traffic, traffic_src = pmc_traffic("k_single_pass", default_shape)
+    traffic3, traffic3_src = pmc_traffic("k_bvsb_region_accum", default_shape)
     out = {
         "metric": "superpixels scored/sec", "value": args.steps * B * S * world / dt, "unit": "superpixels/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "config": {"workload": "acquisition-scan: PixBal+ban-ignore scorer on resident logits, Cityscapes pool shape; per step one "
-                               "single-pass scan (class prior + region sums + histograms); finalize + K4 selection once per run",
+        "config": {"workload": "acquisition-round: PixBal+ban-ignore scorer on resident logits, Cityscapes pool shape [%d,%d,%d,%d] per step; "
+                               "per rank K single-pass scans (class prior + region sums + histograms) of its shard, then exchange 1 "
+                               "(all-gather class sums) + host class weights + weighted finalize + ban + exchange 2 (all-gather scores) + "
+                               "replicated K4 (keys, radix sort, fair-counting budget walk) over all N*K*%d*%d regions"
+                               % (B, C, H, W, B, S),
                    "images_per_step": B, "logits": [B, C, H, W], "nseg": S, "id_dtype": args.id_dtype,
-                   "temperature": 0.1, "sharding": "pool images across ranks", "regions_selected": n_selected},
+                   "temperature": 0.1, "sharding": "pool images across ranks, whole reference batches (engine.ShardPlan)",
+                   "regions_scored": world * args.steps * B * S, "budget_clicks": timed.budget, "regions_selected": n_selected,
+                   "round_tail_ms": tail_ms},
         "roofline": {"bound": "hbm", "kernel": "k_single_pass", "achieved": ach, "peak": HBM_PEAK_GBS,
-                     "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": pmc_traffic("k_single_pass", default_shape),
+                     "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                      "bytes_per_launch": sp_bytes, "avg_launch_ms": sp_ms},
         "two_pass": {"k_class_prob_sum": {"avg_launch_ms": k2_ms, "achieved_GBs": k2_bytes / (k2_ms * 1e-3) / 1e9,
                                           "bytes_per_launch": k2_bytes},
                      "k_bvsb_region_accum": {"avg_launch_ms": k3_ms, "achieved_GBs": k3_bytes / (k3_ms * 1e-3) / 1e9,
                                              "frac_of_peak": k3_bytes / (k3_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                                             "bytes_per_launch": k3_bytes,
-                                             "traffic": pmc_traffic("k_bvsb_region_accum", default_shape)},
+                                             "bytes_per_launch": k3_bytes, "traffic": traffic3, "traffic_source": traffic3_src},
                      "superpixels_per_s": B * S * world / ((k2_ms + k3_ms) * 1e-3)},
     }
+
     def secondary(fn, *a):
         """Secondary legs never take the primary line down with them."""
         try:
             return fn(*a)
         except Exception as e:          # noqa: BLE001
-            return {"error": "%s: %s" % (type(e).__name__, str(e)[:200])}
-    out["train_iter"] = None if args.no_train else secondary(train_iter_bench, args, dev, world)
+            return {"error": "%s: %s" % (type(e).__name__, str(e)[:300])}
+    cpu_bufs = bufs if (rank == 0 and world == 1 and not args.no_cpu_baseline) else None
+    if cpu_bufs is None:
+        del bufs
+    del timed
+    torch.cuda.empty_cache()
+    if not args.no_pool:
+        out["pool_round"] = {"metric": "acquisition round over the fixed %d-picture x %d-superpixel pool, %d clicks, through "
+                                       "RegionSelector.select_next_batch; sharded over %d rank(s)" % (POOL_IMAGES, S, POOL_CLICKS, world),
+                             "scaling": "strong",
+                             "scan_only": secondary(pool_round_bench, args, dev, rank, world, False),
+                             "with_model_forward": None if args.no_train else secondary(pool_round_bench, args, dev, rank, world, True)}
+        torch.cuda.empty_cache()
+    out["train_iter"] = None if args.no_train else secondary(train_iter_bench, args, dev, world, args.crop)
+    out["train_iter_769"] = None if args.no_train else secondary(train_iter_bench, args, dev, world, 769)
     out["acquisition_with_model"] = None if args.no_train else secondary(acquisition_with_model_bench, args, dev, world)
     out["stage2"] = None if (args.no_train or rank != 0) else secondary(stage2_bench, args, dev)
     if rank == 0:
-        if not args.no_cpu_baseline and world == 1:
-            out["cpu_baseline"] = cpu_baseline(args, args.cpu_seconds)
-        else:
-            out["cpu_baseline"] = None
+        out["cpu_baseline"] = secondary(cpu_baseline, args, dev, cpu_bufs, backend) if cpu_bufs is not None else None
         print(json.dumps(out), flush=True)
-    if torch.distributed.is_available() and torch.distributed.is_initialized():
-        torch.distributed.destroy_process_group()
+    d = _dist()
+    if d is not None:
+        if world > 1:
+            d.barrier()
+        d.destroy_process_group()
 
 
 if __name__ == "__main__":

@@ -83,16 +83,16 @@ def class_weight_from_sums(prob_sum, hw, batch_of, n_batches, coeff):
     ``oracle/exact.c:exact_class_weight`` (bit-identical)."""
     prob_sum = np.ascontiguousarray(prob_sum).view(np.uint64)
     n_img, C = prob_sum.shape
-    cum = np.zeros(C, dtype=np.float64)
-    for c in range(C):
-        acc = np.float64(0.0)
-        for b in range(n_batches):
-            sel = batch_of == b
-            n = int(sel.sum())
-            if n:
-                s = np.uint64(prob_sum[sel, c].sum(dtype=np.uint64))
-                acc = acc + (np.float64(s) / np.float64(8388608.0)) / (np.float64(n) * np.float64(hw))
-        cum[c] = acc / np.float64(n_batches)
+    batch_of = np.asarray(batch_of)
+    # exact integer sums per reference batch, then the batch means added IN BATCH ORDER (np.cumsum is strictly
+    # sequential; np.sum is pairwise and would round differently from the oracle's loop)
+    sums = np.zeros((n_batches, C), dtype=np.uint64)
+    np.add.at(sums, batch_of, prob_sum)
+    n_in = np.bincount(batch_of, minlength=n_batches)[:n_batches]
+    live = n_in > 0
+    terms = (sums[live].astype(np.float64) / np.float64(8388608.0)) / (n_in[live].astype(np.float64) * np.float64(hw))[:, None]
+    acc = np.cumsum(terms, axis=0)[-1] if terms.shape[0] else np.zeros(C, dtype=np.float64)
+    cum = acc / np.float64(n_batches)
     t = np.float64(coeff) * cum + np.float64(1.0)
     return cum, (np.float64(1.0) / (t * t)).astype(np.float32)
 

@@ -64,6 +64,31 @@ def nearest_table(in_size, out_size):
     return np.minimum(xo.astype(np.int64), in_size - 1).astype(np.int32)
 
 
+class _PinnedRing:
+    """Page-locked staging slots for the per-sample coefficient tables: a copy from pageable memory blocks the host until
+    the stream's earlier work has drained, so a prefetching provider would serialise with its own augmentation kernels;
+    from a pinned slot the copy is only enqueued.  A slot is reused after the event recorded behind its copy."""
+
+    def __init__(self, slots=8):
+        self.bufs, self.events, self.k = [None] * slots, [None] * slots, 0
+
+    def upload(self, arr, device):
+        k, self.k = self.k, (self.k + 1) % len(self.bufs)
+        if self.events[k] is not None:
+            self.events[k].synchronize()
+        n = int(arr.size)
+        if self.bufs[k] is None or self.bufs[k].numel() < n:
+            self.bufs[k] = torch.empty(max(n, 1 << 15), dtype=torch.int32).pin_memory()
+        host = self.bufs[k][:n]
+        host.numpy()[:] = arr
+        dev = torch.empty(n, dtype=torch.int32, device=device)
+        dev.copy_(host, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream(device))
+        self.events[k] = ev
+        return dev
+
+
 def draw_params(rng, H, W, crop, scale_range=(0.5, 2.0), p_flip=0.5):
     """The reference's random draws, in its order (``ext_transforms.py:186-187, 470-474, 339``)."""
     scale = rng.uniform(scale_range[0], scale_range[1])
@@ -94,6 +119,7 @@ class DeviceTrainAugment:
         self.std = np.asarray(std, dtype=np.float32)
         self.rng = rng if rng is not None else _random
         self.keep_u8 = keep_u8
+        self._ring = _PinnedRing()
 
     def __call__(self, img, maps=(), params=None):
         if not (img.is_cuda and img.dtype == torch.uint8 and img.dim() == 3 and img.shape[2] == 3 and img.is_contiguous()):
@@ -112,7 +138,7 @@ class DeviceTrainAugment:
         xi, yi = nearest_table(W, tw), nearest_table(H, th)
         parts = [hb.ravel(), hk.ravel(), vb.ravel(), vk.ravel(), xi, yi]
         offs = np.cumsum([0] + [a.size for a in parts])
-        tab = torch.from_numpy(np.concatenate(parts)).to(img.device, non_blocking=True)       # one small H2D copy
+        tab = self._ring.upload(np.concatenate(parts).astype(np.int32, copy=False), img.device)   # one small pinned H2D copy
         ptr = [tab.data_ptr() + 4 * int(o) for o in offs[:-1]]
         ch, cw = self.size
         out = torch.empty((3, ch, cw), dtype=torch.float32, device=img.device)

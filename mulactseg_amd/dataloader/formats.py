@@ -102,11 +102,18 @@ def multi_hot_from_labels(target, superpixel, ids, nseg, num_classes, ignore=255
     return cls, size
 
 
+def selection_lut(selected_ids, nseg, device):
+    """bool [nseg + 1]: entry i true when id i is selected; the last entry (the crop pad id ``nseg``) is never set.
+    Built on the host and moved with one copy."""
+    lut = np.zeros(nseg + 1, dtype=np.bool_)
+    if len(selected_ids):
+        lut[np.asarray(list(selected_ids), dtype=np.int64)] = True
+    lut[nseg] = False
+    return torch.from_numpy(lut).to(device)
+
+
 def selection_mask(superpixel, selected_ids, nseg):
     """``np.isin(superpixel, selected ids)`` (``region_cityscapes_or_tensor.py:88-89``) as a table lookup that works on
     device tensors: ids outside [0, nseg) (the crop pad id ``nseg``) are never selected."""
-    lut = torch.zeros(nseg + 1, dtype=torch.bool, device=superpixel.device)
-    if len(selected_ids):
-        lut[torch.as_tensor(list(selected_ids), dtype=torch.long, device=superpixel.device)] = True
-    lut[nseg] = False
+    lut = selection_lut(selected_ids, nseg, superpixel.device)
     return lut[superpixel.clamp(min=0, max=nseg).long()] & (superpixel >= 0)

@@ -6,10 +6,11 @@ With 288 GB of HBM the decoded training set fits once (Cityscapes: 2 975 picture
 so a sample is produced by one kernel (``DeviceTrainAugment``) plus a table lookup for the selection mask; no worker
 processes, no host->device copy of float crops.  The sample dictionary and the ``im_idx`` / ``suppix`` bookkeeping are
 the reference's, so ``RegionActiveDataset`` and the trainers use it unchanged."""
+import numpy as np
 import torch
 
 from .device_transforms import DeviceTrainAugment
-from .formats import selection_mask
+from .formats import selection_lut
 
 
 class ResidentRegionDataset(torch.utils.data.Dataset):
@@ -26,7 +27,11 @@ class ResidentRegionDataset(torch.utils.data.Dataset):
         self.pictures, self.superpixels = list(pictures), list(superpixels)
         self.multi_hot_cls = multi_hot_cls
         self.names = {n[2]: k for k, n in enumerate(names)}
-        self.im_idx = [tuple(n) for n in names] if split == 'active-ulabel' else []
+        # rows of multi_hot_cls by label-file stem, as RegionActiveDataset looks them up (region_cityscapes_or_tensor.py:41-46)
+        self.id_to_index = {n[2].split('/')[-1].split('.')[0]: k for k, n in enumerate(names)}
+        # entries are LISTS like the reference's (region_cityscapes.py:75): expand_training_set compares them with
+        # ``joined.split(',')``, and a list never equals a tuple
+        self.im_idx = [list(n) for n in names] if split == 'active-ulabel' else []
         self.suppix = {}
         for n in names:
             ids = list(region_dict.get(n[2], [])) if region_dict is not None else []
@@ -35,7 +40,10 @@ class ResidentRegionDataset(torch.utils.data.Dataset):
             if ids:
                 self.suppix[n[2]] = ids
                 if split == 'active-label':
-                    self.im_idx.append(tuple(n))
+                    self.im_idx.append(list(n))
+        if split == 'active-ulabel':
+            self.isselected = np.zeros((len(names), args.nseg), dtype=np.uint8)     # region_active_dataset.py:55-56
+        self._lut = {}              # spx path -> (number of ids it was built from, bool [nseg + 1] on the device)
         self.transform = DeviceTrainAugment(size=(768, 768), scale_range=(0.5, 2.0), pad_values=[args.nseg], rng=rng)
         self.pool_transform = DeviceTrainAugment(scale_range=(1.0, 1.0), pad_values=[args.nseg])
 
@@ -44,6 +52,16 @@ class ResidentRegionDataset(torch.utils.data.Dataset):
 
     def _slot(self, spx_fname):
         return self.names[spx_fname]
+
+    def _selection_lut(self, spx_fname, device):
+        """bool [nseg + 1] table of the selected ids of one picture, kept on the device and rebuilt only when the id list
+        grew (expand_training_set appends; a pad id ``nseg`` is never selected) -- a sample then costs no H2D copy."""
+        ids = self.suppix.get(spx_fname, [])
+        hit = self._lut.get(spx_fname)
+        if hit is None or hit[0] != len(ids):
+            hit = (len(ids), selection_lut(ids, self.args.nseg, device))
+            self._lut[spx_fname] = hit
+        return hit[1]
 
     def __getpoolitem__(self, k):
         """Normalised full-size picture + untouched map (``region_cityscapes_or_tensor.py:47-52``)."""
@@ -61,6 +79,6 @@ class ResidentRegionDataset(torch.utils.data.Dataset):
         if self.split == 'active-ulabel':
             return self.__getpoolitem__(k)
         image, (superpixel,) = self.transform(self.pictures[k], [self.superpixels[k]])
-        sp_mask = selection_mask(superpixel, self.suppix.get(spx_fname, []), self.args.nseg)       # (:88-89)
+        sp_mask = self._selection_lut(spx_fname, superpixel.device)[superpixel.clamp(min=0, max=self.args.nseg)]     # (:88-89)
         return {'images': image, 'labels': self.multi_hot_cls[k], 'spx': superpixel, 'spmask': sp_mask,
                 'fnames': self.im_idx[index]}

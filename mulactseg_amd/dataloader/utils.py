@@ -29,14 +29,14 @@ class DataProvider:
     """Endless iterator over a DataLoader (epoch counter, restart on exhaustion) --
     ``dataloader/utils.py:28-62``."""
 
-    def __init__(self, dataset, batch_size, num_workers, drop_last, shuffle, pin_memory):
+    def __init__(self, dataset, batch_size, num_workers, drop_last, shuffle, pin_memory, generator=None):
         self.dataset = dataset
         self.iteration = 0
         self.epoch = 0
         self.batch_size, self.num_workers = batch_size, num_workers
         self.drop_last, self.shuffle, self.pin_memory = drop_last, shuffle, pin_memory
         self.dataloader = DataLoader(dataset, batch_size=batch_size, collate_fn=collate_fn, shuffle=shuffle,
-                                     num_workers=num_workers, drop_last=drop_last, pin_memory=pin_memory)
+                                     num_workers=num_workers, drop_last=drop_last, pin_memory=pin_memory, generator=generator)
         self.dataiter = iter(self.dataloader)
 
     def __len__(self):
@@ -66,7 +66,9 @@ class ResidentProvider:
     def __init__(self, dataset, batch_size, drop_last=True, shuffle=True, rng=None, prefetch=True):
         import random as _random
         self.dataset, self.batch_size, self.drop_last, self.shuffle = dataset, int(batch_size), drop_last, shuffle
-        self.rng = rng if rng is not None else _random
+        # a private generator by default: the batch prepared ahead (and possibly never consumed) must not advance the
+        # process-global ``random`` that ``my_random`` and expand_training_set's callers read
+        self.rng = rng if rng is not None else _random.Random(_random.getrandbits(64) if shuffle else 0)
         self.iteration = 0
         self.epoch = 0
         self._order, self._pos = [], 0

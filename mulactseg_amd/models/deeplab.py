@@ -23,12 +23,34 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 
+# Which implementation every fusable layer call took, per process: {("bn_act", "hip"): n, ("bn_act", "aten"): m, ...}.
+# On the GPU a layer falls back to the ATen / MIOpen op only when ops.*_supported() declines its shape or mode (e.g. a
+# frozen BatchNorm with gradients flowing through it); bench.py prints the table so a run shows what it measured.
+PATH_COUNTS = {}
+
+
+def _took(kind, path):
+    PATH_COUNTS[(kind, path)] = PATH_COUNTS.get((kind, path), 0) + 1
+
+
+def path_report(reset=False):
+    """{"bn_act": {"hip": n, "aten": m}, ...} since the last reset."""
+    out = {}
+    for (kind, path), n in sorted(PATH_COUNTS.items()):
+        out.setdefault(kind, {})[path] = n
+    if reset:
+        PATH_COUNTS.clear()
+    return out
+
+
 def _bn_act(bn, x, relu=True, residual=None):
     """relu(bn(x) + residual): on the GPU one fused pass (csrc/bn.hip) instead of BatchNorm, add and ReLU kernels."""
     if x.is_cuda:
         from .. import ops
         if ops.bn_act_supported(bn, x, residual):
+            _took("bn_act", "hip")
             return ops.bn_act(bn, x, relu, residual)
+    _took("bn_act", "aten")
     y = bn(x)
     if residual is not None:
         y = y + residual
@@ -74,6 +96,7 @@ class Bottleneck(nn.Module):
         if x.is_cuda and not self.training:
             from .. import ops
             if ops.conv1x1_bn_act_supported(self.conv1, self.bn1, x):     # small-K 1x1 + BN + ReLU in one kernel (csrc/conv1x1.hip)
+                _took("conv1x1_bn_act", "hip")
                 y = ops.conv1x1_bn_act(self.conv1, self.bn1, x, True)
         if y is None:
             y = _bn_act(self.bn1, self.conv1(x))
@@ -132,7 +155,9 @@ class DeepStemResNetTrunk(nn.Module):
         x = _bn_act(self.bn1, _run(self.conv1, x))
         if x.is_cuda:
             from .. import ops
-            x = ops.maxpool3s2(x) if ops.maxpool3s2_supported(self.maxpool, x) else self.maxpool(x)
+            hip = ops.maxpool3s2_supported(self.maxpool, x)
+            _took("maxpool", "hip" if hip else "aten")
+            x = ops.maxpool3s2(x) if hip else self.maxpool(x)
         else:
             x = self.maxpool(x)
         low = self.layer1(x)
@@ -158,7 +183,9 @@ class AtrousSeparableConvolution(nn.Module):
         if x.is_cuda and dw.kernel_size == (3, 3) and dw.stride == (1, 1) and dw.padding == dw.dilation and dw.groups == x.shape[1]:
             from .. import ops          # HIP depthwise (csrc/aspp.hip); MIOpen only has a naive fp32 kernel for it
             if ops.depthwise3x3_supported(x, dw.dilation[0]):
+                _took("depthwise3x3", "hip")
                 return self.body[1](ops.depthwise3x3(x, dw.weight, dw.dilation[0]))
+        _took("depthwise3x3", "miopen")
         return self.body(x)
 
 
@@ -174,7 +201,9 @@ def _upsample(x, size):
     if x.is_cuda:
         from .. import ops
         if ops.upsample_bilinear_supported(x, size):
+            _took("upsample", "hip")
             return ops.upsample_bilinear(x, size)
+    _took("upsample", "aten")
     return F.interpolate(x, size=size, mode='bilinear', align_corners=False)
 
 
@@ -210,6 +239,7 @@ class ASPP(nn.Module):
         if any(d.kernel_size != (3, 3) or d.stride != (1, 1) or d.padding != d.dilation or d.groups != x.shape[1] for d in dws):
             return None
         from .. import ops
+        _took("aspp_depthwise_triple", "hip")
         return ops.aspp_depthwise3(x, dws[0].weight, dws[1].weight, dws[2].weight, [d.dilation[0] for d in dws])
 
     def forward(self, x):
@@ -253,6 +283,7 @@ class DeepLabHeadV3PlusWN(nn.Module):
         if pf.is_cuda:
             from .. import ops
             if ops.cosine_head_supported(pf, self.proxy):
+                _took("cosine_head", "hip")
                 out = ops.cosine_head(pf, self.proxy)            # K8: one pass over the features (csrc/head.hip)
                 return (F.normalize(pf), out) if self.return_feat else out
         feat = F.normalize(pf)                                   # over channels, eps 1e-12

@@ -584,6 +584,11 @@ class _BNActTrain(torch.autograd.Function):
                                                 int(relu), _opt(running_mean), _opt(running_var), _opt(num_batches_tracked),
                                                 mean.data_ptr(), invstd.data_ptr(), ws.data_ptr(), y.data_ptr(), _opt(mask), _stream(x)),
                        "mas_bn_act_train_fwd")
+        # the kernel updated the running statistics through raw pointers: bump their version counters as an in-place
+        # torch op would, so caches keyed on (data_ptr, _version) -- _conv1x1_constants -- see the change
+        for buf in (running_mean, running_var, num_batches_tracked):
+            if buf is not None:
+                torch.autograd.graph.increment_version(buf)
         ctx.save_for_backward(x, y if mask is None else None, weight, mean, invstd, mask)
         ctx.relu = bool(relu)
         ctx.has_res = residual is not None

@@ -58,7 +58,11 @@ class ActiveTrainer(BaseTrainer):
             self.optimizer.zero_grad()
             preds = self.forward_train(images)
             loss = self.loss_fun(preds, labels)
-            ok = not bool(torch.isnan(loss))
+            bad = torch.isnan(loss.detach()).to(torch.int32)
+            if self.ddp is not None:            # the skip must be taken by every rank or by none (gradient all-reduce)
+                import torch.distributed as dist
+                dist.all_reduce(bad, op=dist.ReduceOp.MAX)
+            ok = not bool(bad)
             if ok:
                 loss.backward()
                 self.optimizer.step()

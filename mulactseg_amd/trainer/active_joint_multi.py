@@ -28,10 +28,11 @@ class ActiveTrainer(active.ActiveTrainer):
 
     def update(self, loss):
         if self.check_loss_sanity(loss):
-            # DDP averages gradients over ranks; the fused loss is already the GLOBAL-batch objective
-            # (normalisers all-reduced), so scale by the world size to get its exact gradient.
+            # DDP averages gradients over ranks; every partial-label loss module already returns the GLOBAL-batch
+            # objective (normalisers all-reduced, identical value on every rank -- so this branch is taken by all ranks
+            # or by none), hence scale by the world size to get its exact gradient.
             scale = 1
-            if self.ddp is not None and getattr(self, 'fused_loss', None) is not None:
+            if self.ddp is not None:
                 import torch.distributed as dist
                 scale = dist.get_world_size()
             (loss * scale if scale != 1 else loss).backward()

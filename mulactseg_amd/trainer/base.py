@@ -97,12 +97,27 @@ class BaseTrainer(object):
             raise NotImplementedError("loss_type %r is outside the hot path" % a.loss_type)
 
     # -- loaders ------------------------------------------------------------------------------------
+    def loader_seed(self):
+        """Seed of the training loader's PRIVATE generators: a function of (--seed, rank, AL round), so that data-parallel
+        ranks draw different batches and crops (N GPUs x batch 4 = one batch of 4N distinct samples) while the process-global
+        ``random`` / numpy / torch generators -- which ``my_random`` and the selectors read -- stay identical on all ranks."""
+        d = _dist()
+        rank = d.get_rank() if d is not None else 0
+        return (int(getattr(self.args, 'seed', 0)) * 1000003 + rank) * 1009 + int(getattr(self, 'selection_iter', 0))
+
     def get_trainloader(self, dataset):
+        import random
+        seed = self.loader_seed()
         if getattr(dataset, 'device_resident', False):      # samples are produced on the device (dataloader/resident.py)
             from ..dataloader.utils import ResidentProvider
-            return ResidentProvider(dataset, batch_size=self.args.train_batch_size, drop_last=True, shuffle=True)
+            if hasattr(getattr(dataset, 'transform', None), 'rng'):
+                dataset.transform.rng = random.Random(seed ^ 0x5bd1e995)           # crops / scales / flips
+            return ResidentProvider(dataset, batch_size=self.args.train_batch_size, drop_last=True, shuffle=True,
+                                    rng=random.Random(seed))
+        gen = torch.Generator()
+        gen.manual_seed(seed)               # epoch permutations and the workers' base seed (hence their `random` streams)
         return DataProvider(dataset=dataset, batch_size=self.args.train_batch_size, shuffle=True,
-                            num_workers=self.args.num_workers, pin_memory=True, drop_last=True)
+                            num_workers=self.args.num_workers, pin_memory=True, drop_last=True, generator=gen)
 
     def get_valloader(self, dataset):
         # one process per GPU: every rank evaluates its round-robin share; inference() sums the IoU counters over ranks

@@ -59,7 +59,11 @@ def _all_reduce_sum(acc):
         dist.all_reduce(acc, op=dist.ReduceOp.SUM)
 
 
-def _run(inputs, targets, superpixels, spmasks, temp, flags, drop_last_column, sync=False):
+def _run(inputs, targets, superpixels, spmasks, temp, flags, drop_last_column, sync=True):
+    """``sync``: under torch.distributed (world > 1) the integer sums and counts are all-reduced before the division, so
+    every rank holds the SAME loss value -- the loss over the global batch.  The reference's skip-on-zero / raise-on-NaN
+    decisions (``active_joint_multi.py:31-37``) are then global by construction: no rank can skip ``backward()`` while
+    its peers wait in the gradient all-reduce."""
     if targets.dtype != torch.uint8:
         targets = targets.to(torch.uint8)
     cols = targets.shape[-1]

@@ -39,7 +39,10 @@ FLAG_SETS = {
     'mc_predignore': 1,
     'group_predignore': 2,
 }
-SHAPES = [(2, 20, 64, 512, 128), (3, 20, 40, 44, 48), (2, 21, 33, 37, 150), (1, 7, 24, 36, 16), (2, 20, 192, 768, 512)]
+SHAPES = [(2, 20, 64, 512, 128), (3, 20, 40, 44, 48), (2, 21, 33, 37, 150), (1, 7, 24, 36, 16), (2, 20, 192, 768, 512),
+          # BASELINE.json's literal "769x769x19" crop (the reference's transform is NAMED 769 but crops 768, transform.py:91-114):
+          # odd row length -> rows are only 4-byte aligned, every scan takes its per-row alignment prologue
+          (1, 20, 769, 769, 2048), (1, 19, 769, 769, 2048)]
 
 
 @pytest.mark.parametrize("N,C,H,W,S", SHAPES)
@@ -206,9 +209,42 @@ def test_full_training_batch_properties():
     eacc, egmax, _ = exact.partial_loss_fwd(z[:1], spx[:1], msk[:1], ebits, np.float32(invT), flags)
     _, a0, g0 = ops.partial_loss_fwd(zt[:1], st[:1], mt[:1], bits[:1], invT, flags)
     assert np.array_equal(a0.cpu().numpy().view(np.uint64), eacc) and np.array_equal(g0.cpu().numpy().view(np.uint64), egmax)
+    # ... and image 0's gradient: the scales come from the batch-wide accumulators (normalisers 1 + n over the batch)
+    _, edz0 = exact.partial_loss_bwd(z[:1], spx[:1], msk[:1], ebits, egmax, acc.cpu().numpy().view(np.uint64),
+                                     np.array([16.0, 8.0, 1.0], dtype=np.float32), np.float32(invT), flags)
+    assert np.array_equal(dz[0].cpu().numpy(), edz0[0])
     # permutation
     perm = torch.tensor([3, 0, 2, 1], device='cuda')
     l2, acc2, gmax2 = ops.partial_loss_fwd(zt[perm].contiguous(), st[perm].contiguous(), mt[perm].contiguous(), bits[perm].contiguous(), invT, flags)
     assert torch.equal(acc2, acc) and torch.equal(l2, losses)
     dz2 = ops.partial_loss_bwd(zt[perm].contiguous(), st[perm].contiguous(), mt[perm].contiguous(), bits[perm].contiguous(), gmax2, acc2, go, invT, flags)
     assert torch.equal(dz2, dz[perm])
+
+
+def test_literal_769_crop_batch_properties():
+    """[4,20,769,769] (BASELINE.json metric shape): additivity over images, zero gradient off the selection, exact
+    power-of-two linearity, and image 3 bit-exact against the C oracle (forward tables, sums and dz)."""
+    ops = _gpu()
+    from oracle import exact
+    N, C, H, W, S = 4, 20, 769, 769, 2048
+    flags = FLAG_SETS['production']
+    z, tgt, spx, msk = _inputs(769, N, C, H, W, S, frac=0.09)
+    invT = ops.inv_temperature(0.1)
+    zt, st, mt = torch.from_numpy(z).cuda(), torch.from_numpy(spx).cuda(), torch.from_numpy(msk).cuda()
+    bits = ops.target_bits(torch.from_numpy(tgt).cuda())
+    losses, acc, gmax = ops.partial_loss_fwd(zt, st, mt, bits, invT, flags)
+    go = torch.tensor([16.0, 8.0, 1.0], device='cuda')
+    dz = ops.partial_loss_bwd(zt, st, mt, bits, gmax, acc, go, invT, flags)
+    assert float((dz * (~mt)[:, None]).abs().max()) == 0.0
+    assert torch.equal(ops.partial_loss_bwd(zt, st, mt, bits, gmax, acc, 4 * go, invT, flags), 4 * dz)
+    tot = torch.zeros_like(acc)
+    for i in range(N):
+        tot += ops.partial_loss_fwd(zt[i:i + 1], st[i:i + 1], mt[i:i + 1], bits[i:i + 1], invT, flags)[1]
+    assert torch.equal(tot, acc)
+    ebits = exact.target_bits(tgt[3:])
+    eacc, egmax, _ = exact.partial_loss_fwd(z[3:], spx[3:], msk[3:], ebits, np.float32(invT), flags)
+    _, a3, g3 = ops.partial_loss_fwd(zt[3:], st[3:], mt[3:], bits[3:], invT, flags)
+    assert np.array_equal(a3.cpu().numpy().view(np.uint64), eacc) and np.array_equal(g3.cpu().numpy().view(np.uint64), egmax)
+    _, edz = exact.partial_loss_bwd(z[3:], spx[3:], msk[3:], ebits, egmax, acc.cpu().numpy().view(np.uint64),
+                                    np.array([16.0, 8.0, 1.0], dtype=np.float32), np.float32(invT), flags)
+    assert np.array_equal(dz[3].cpu().numpy(), edz[0])

@@ -36,6 +36,8 @@ CASES = [
     (1, 19, 130, 260, 64),      # ring kernel, 19 channels, three strips
     (1, 21, 70, 128, 40),       # ring kernel narrower than a tile
     (2, 7, 96, 36, 16),         # ring kernel, generic (runtime-C) instantiation
+    (1, 19, 769, 769, 2048),    # BASELINE.json's literal "769x769x19": odd row length, rows only 4-byte aligned
+    (1, 20, 769, 769, 2048),    # the same crop with the "undefined" channel (what the predignore model emits)
 ]
 
 
