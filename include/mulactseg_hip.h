@@ -227,6 +227,16 @@ int mas_region_finalize_weighted(const uint64_t* class_sum, const uint32_t* hist
                                  const uint32_t* w31 /* [C] */, int ban_class, float* score, int32_t* dominant,
                                  uint32_t* count, int64_t* hist_i64, void* stream);
 
+/* Class weights of the PixBal selectors from the per-picture class-probability sums, on the device:
+ *   cum[c]   = (sum over reference batches b of mean_{pictures of b, pixels} p_c) / n_batches       (f64)
+ *   cls_w[c] = (float)(1 / (coeff * cum[c] + 1)^2),   w31[c] = floor(cls_w[c] * 2^31)  (w31 may be NULL)
+ * prob_sum [n_img, C] as mas_class_prob_sum / mas_single_pass_accum wrote it (23 fractional bits); batch b holds
+ * pictures [b*batch_size, min((b+1)*batch_size, n_img)); a batch without pictures contributes nothing but counts in
+ * n_batches.  Batch means are added in batch order.  Replaces my_bvsb_predclsbal_pwr_banignore.py:42,45,47
+ * (cumulated_pred_prob / len(loader); cls_weight = 1 / (coeff * cum + 1)^2) without a host round trip. */
+int mas_class_weight(const uint64_t* prob_sum, int n_img, int C, int64_t hw, int batch_size, int n_batches, double coeff,
+                     double* cum, float* cls_w, uint32_t* w31, void* stream);
+
 /* =============================================================================================
  * K9  stage-2 cosine pseudo labels with one-ring propagation
  * (trainer/eval_save_cosplbl_prop.py:121-314, ..._includeonehot.py); one image per call.

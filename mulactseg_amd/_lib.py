@@ -16,7 +16,7 @@ LOSS_CE, LOSS_GROUP, LOSS_GROUP_ONLY_MULTI, LOSS_DECOMP = 1, 2, 4, 8
 ACC_WORDS = 8
 
 _c = ctypes
-_vp, _i, _f, _i64 = _c.c_void_p, _c.c_int, _c.c_float, _c.c_int64
+_vp, _i, _f, _i64, _d = _c.c_void_p, _c.c_int, _c.c_float, _c.c_int64, _c.c_double
 
 # name -> (restype, argtypes); mirrors include/mulactseg_hip.h one to one
 SIGNATURES = {
@@ -35,6 +35,7 @@ SIGNATURES = {
     "mas_iou_counts": (_i, [_vp, _vp, _vp, _i64, _i, _i64, _vp, _vp]),
     "mas_logits_iou_counts": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i64, _vp, _vp]),
     "mas_single_pass_accum": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _f, _vp, _vp, _vp, _vp]),
+    "mas_class_weight": (_i, [_vp, _i, _i, _i64, _i, _i, _d, _vp, _vp, _vp, _vp]),
     "mas_region_finalize_weighted": (_i, [_vp, _vp, _i64, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp]),
     "mas_stage2_gather_protos": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _i, _vp, _vp]),
     "mas_stage2_assign": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp]),

@@ -60,7 +60,14 @@ class RegionSelector(object):
             return None
         label = active_set.trg_label_dataset
         rows = [label.id_to_index[key[2].split('/')[-1].split('.')[0]] for key in pool_set.im_idx]
+        table = getattr(active_set, 'click_cost_table', None)
+        if table is not None:                   # this package's RegionActiveDataset: popcounts computed once per run
+            return np.ascontiguousarray(table()[rows])
         return np.ascontiguousarray(np.asarray(label.multi_hot_cls)[rows].sum(axis=2).astype(np.uint8))
+
+    def _pool_valid(self, active_set, pool_set):
+        mask = getattr(active_set, 'pool_valid_mask', None)
+        return mask(self.num_superpixels) if mask is not None else self.valid_mask(pool_set)
 
     def select_next_batch(self, trainer, active_set, selection_count):
         pool_set = active_set.trg_pool_dataset
@@ -80,11 +87,11 @@ class RegionSelector(object):
         dev = scores_tensor.device
         cost = self._region_cost(active_set, pool_set)
         n, simg, sid, ssc = backend.select(
-            scores_tensor.contiguous(), torch.from_numpy(self.valid_mask(pool_set)).to(dev),
+            scores_tensor.contiguous(), torch.from_numpy(self._pool_valid(active_set, pool_set)).to(dev),
             torch.from_numpy(img_rank).to(dev), torch.from_numpy(img_of_rank).to(dev),
             None if cost is None else torch.from_numpy(cost).to(dev), int(selection_count),
             max_out=None if cost is not None and cost.min() == 0 else int(selection_count) + 1)
-        consumed = [(float(s), paths[int(i)], int(r)) for s, i, r in zip(ssc, simg, sid)]
+        consumed = [(s, paths[i], r) for s, i, r in zip(ssc.tolist(), simg.tolist(), sid.tolist())]
         active_set.expand_training_set(consumed, selection_count, self.active_method)
 
     def _backend(self, trainer):

@@ -8,7 +8,7 @@ and the (image rank, id) tie-break keys are identical for any number of GPUs.  T
 no collective; the round has exactly two tiny exchanges:
 
   1. after pass 1: all-gather of the per-image fixed-point class sums  [N_img, C] int64  (476 KB for
-     the Cityscapes pool) -> every rank derives the same class weights in f64 on the host;
+     the Cityscapes pool) -> every rank derives the same class weights in f64 (``k_class_weight``, on the device);
   2. after pass 2: all-gather of the per-image region scores [N_img, S] f32 (24 MB) -> every rank
      runs the same K4 ordering + budget walk (replicated, deterministic).
 
@@ -74,7 +74,7 @@ def gather_rows(local, plan):
 
 
 # ------------------------------------------------------------------------------------------------
-# host arithmetic between the passes
+# the class-weight arithmetic between the passes, restated for the host (tests, CPU stand-in backends)
 # ------------------------------------------------------------------------------------------------
 def class_weight_from_sums(prob_sum, hw, batch_of, n_batches, coeff):
     """Reference: ``cum = sum_b mean_b / len(loader)``; ``cls_weight = (coeff*cum + 1)**-2``
@@ -127,9 +127,18 @@ class HipBackend:
     def single_pass(self, logits, spx, S, invT, prob_sum, class_sum, hist):
         self.ops.single_pass_accum(logits, spx, S, invT, prob_sum=prob_sum, class_sum=class_sum, hist=hist)
 
+    def class_weight(self, prob_sum, hw, batch_size, n_batches, coeff):
+        """(cum f64 [C], cls_w f32 [C]) on the device from the gathered per-picture class sums; the integer form of the
+        weights rides along on the tensor so that ``finalize_weighted`` needs no conversion (and no host round trip)."""
+        cum, w, w31 = self.ops.class_weight(prob_sum.contiguous(), hw, batch_size, n_batches, coeff)
+        w._mas_w31 = w31
+        return cum, w
+
     def finalize_weighted(self, class_sum, hist, cls_w, ban_class, want_hist_i64=False):
-        w = np.ones(hist.shape[-1], dtype=np.float32) if cls_w is None else cls_w.detach().cpu().numpy()
-        w31 = torch.from_numpy(self.ops.weights_to_fixed31(w).view(np.int32)).to(hist.device)
+        w31 = None if cls_w is None else getattr(cls_w, '_mas_w31', None)
+        if w31 is None:     # weights that did not come from class_weight(): floor(w * 2^31) with exact device arithmetic
+            w = torch.ones(hist.shape[-1], dtype=torch.float32, device=hist.device) if cls_w is None else cls_w.detach().to(hist.device)
+            w31 = (w.double() * 2147483648.0).floor().to(torch.int64).view(torch.int32)[::2].contiguous()
         return self.ops.region_finalize_weighted(class_sum, hist, w31, ban_class, want_hist_i64)
 
     def minmax_normalize_(self, scores):
@@ -208,9 +217,14 @@ class AcquisitionRound:
             t = torch.tensor([hw or 0], dtype=torch.int64, device=allsum.device)
             d.all_reduce(t, op=d.ReduceOp.MAX)
             hw = int(t.item())
-        cum, w = class_weight_from_sums(allsum.cpu().numpy(), hw, self.plan.batch_of, self.plan.n_batches, coeff)
-        self.cum = cum
-        return torch.from_numpy(w).to(self.backend.device)
+        self._cum, w = self.backend.class_weight(allsum, hw, self.plan.batch_size, self.plan.n_batches, coeff)
+        return w
+
+    @property
+    def cum(self):
+        """f64 [C] numpy: the class prior ``cumulated_pred_prob / len(loader)`` of the last ``class_weights`` call."""
+        c = self._cum
+        return c.cpu().numpy() if torch.is_tensor(c) else c
 
     def add_regions(self, row0, logits, spx, cls_w):
         r = self._rows(row0, logits)

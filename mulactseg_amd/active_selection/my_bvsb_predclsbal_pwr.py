@@ -5,7 +5,7 @@ Default (``single_pass``): ONE scan and ONE model forward per pool image (``k_si
 weight depends only on the pixel's arg-max class, so it factors out of the region sum; the scan keeps per
 (region, class) sums of the unweighted margin and the weights are applied in exact integer arithmetic once
 the pool's class prior is known.  ``args.two_pass_scoring = True`` selects the reference's own structure:
-pass 1 estimates the predicted class prior (K2, ``k_class_prob_sum``), the host turns the integer sums into
+pass 1 estimates the predicted class prior (K2, ``k_class_prob_sum``), ``k_class_weight`` turns the gathered integer sums into
 ``cls_weight = (coeff*prior + 1)**-2``; pass 2 averages ``bvsb * cls_weight[top1]`` per superpixel and
 histograms the arg-max class (K1+K3, ``k_bvsb_region_accum``).  The two forms agree to ~1e-7 relative (the
 per-pixel f32 rounding of ``bvsb * w`` is the only difference) and give the same integers.
@@ -34,19 +34,22 @@ class RegionSelector(my_bvsb.RegionSelector):
                 self._check_channels(preds, C)
                 rnd.add_single_pass(row, preds, spx)
             cls_w = rnd.class_weights(self.args.cls_weight_coeff)
-            self.cumulated_pred_prob, self.cls_weight = rnd.cum, cls_w
-            self._round = rnd
+            self._round, self.cls_weight = rnd, cls_w
             return rnd.scores_single_pass(cls_w, ban_class=ban, want_hist=want_hist)
         rnd = AcquisitionRound(n_img, C, self.num_superpixels, self.batch_size, self.args.ce_temp, backend)
         for row, preds, _ in self._iterate(trainer, pool_set, rnd):                 # pass 1 (:35-43)
             self._check_channels(preds, C)
             rnd.add_prior(row, preds)
         cls_w = rnd.class_weights(self.args.cls_weight_coeff)                       # (:45-47)
-        self.cumulated_pred_prob, self.cls_weight = rnd.cum, cls_w
+        self._round, self.cls_weight = rnd, cls_w
         for row, preds, spx in self._iterate(trainer, pool_set, rnd):               # pass 2 (:49-72)
             rnd.add_regions(row, preds, spx, cls_w)
-        self._round = rnd
         return rnd.scores(ban_class=ban, want_hist=want_hist)
+
+    @property
+    def cumulated_pred_prob(self):
+        """Class prior of the last round (``cumulated_pred_prob / len(loader)``, :45), fetched from the device on demand."""
+        return self._round.cum
 
     @staticmethod
     def _check_channels(preds, C):

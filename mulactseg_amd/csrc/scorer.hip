@@ -505,3 +505,59 @@ extern "C" int mas_region_finalize(const uint64_t* score_sum, const uint32_t* hi
                        count, reinterpret_cast<long long*>(hist_i64));
     return mas_launch_status();
 }
+
+// ---------------------------------------------------------------------------------------------------------------
+// Class weights between the two halves of a round, on the device (no host round trip in the round's tail).
+// One workgroup per class.  The per-batch integer sums and their f64 terms are independent and computed by all
+// threads; the f64 accumulation over batches is strictly sequential IN BATCH ORDER (the reference adds per-batch
+// means in loader order, my_bvsb_predclsbal_pwr_banignore.py:42-45), done by thread 0 from LDS.  Every f64
+// operation is a single IEEE operation (no contraction, correctly rounded division), so the result equals
+// oracle/exact.c:exact_class_weight and engine.class_weight_from_sums bit for bit.
+// ---------------------------------------------------------------------------------------------------------------
+constexpr int kCwChunk = 1024;
+
+__global__ __launch_bounds__(kThreads) void k_class_weight(const mas_u64* __restrict__ prob_sum, int n_img, int C,
+                                                            long long hw, int batch_size, int n_batches, double coeff,
+                                                            double* __restrict__ cum, float* __restrict__ cls_w,
+                                                            unsigned* __restrict__ w31) {
+    __shared__ double s_term[kCwChunk];
+    const int c = blockIdx.x;
+    double acc = 0.0;
+    for (int b0 = 0; b0 < n_batches; b0 += kCwChunk) {
+        const int nb = (n_batches - b0) < kCwChunk ? (n_batches - b0) : kCwChunk;
+        for (int j = threadIdx.x; j < nb; j += kThreads) {
+            const long long i0 = (long long)(b0 + j) * batch_size;
+            long long i1 = i0 + batch_size;
+            if (i1 > n_img) i1 = n_img;
+            mas_u64 s = 0;
+            for (long long i = i0; i < i1; ++i) s += prob_sum[i * C + c];
+            const long long n = i1 - i0;
+            s_term[j] = n > 0 ? ((double)s / 8388608.0) / ((double)n * (double)hw) : -1.0;     // terms are >= 0; -1 marks "no image"
+        }
+        __syncthreads();
+        if (threadIdx.x == 0)
+            for (int j = 0; j < nb; ++j)
+                if (s_term[j] >= 0.0) acc += s_term[j];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        const double m = acc / (double)n_batches;
+        const double t = coeff * m + 1.0;
+        const float w = (float)(1.0 / (t * t));
+        cum[c] = m;
+        cls_w[c] = w;
+        if (w31) w31[c] = (unsigned)floor((double)w * 2147483648.0);
+    }
+}
+
+extern "C" int mas_class_weight(const uint64_t* prob_sum, int n_img, int C, int64_t hw, int batch_size, int n_batches,
+                                double coeff, double* cum, float* cls_w, uint32_t* w31, void* stream) {
+    if (!prob_sum || !cum || !cls_w) return MAS_ERR_NULL;
+    if (n_img <= 0 || hw <= 0 || batch_size <= 0 || n_batches <= 0) return MAS_ERR_SHAPE;
+    if ((long long)n_batches * batch_size < n_img) return MAS_ERR_RANGE;
+    if (C < 1 || C > MAS_MAX_CLASSES) return MAS_ERR_CLASSES;
+    hipLaunchKernelGGL(k_class_weight, dim3((unsigned)C), dim3(kThreads), 0, static_cast<hipStream_t>(stream),
+                       reinterpret_cast<const mas_u64*>(prob_sum), n_img, C, (long long)hw, batch_size, n_batches, coeff, cum,
+                       cls_w, w31);
+    return mas_launch_status();
+}

@@ -8,6 +8,8 @@ after the region that makes the click cost exceed the budget; the consumed prefi
 import os
 import pickle
 
+import numpy as np
+
 
 class RegionActiveDataset:
     def __init__(self, args, trg_pool_dataset, trg_label_dataset):
@@ -15,6 +17,9 @@ class RegionActiveDataset:
         self.selection_iter = 0
         self.trg_pool_dataset = trg_pool_dataset
         self.trg_label_dataset = trg_label_dataset
+        self._valid = None          # u8 [n_img_total, S] mirror of pool.suppix (see pool_valid_mask)
+        self._click_cost = None     # (multi_hot_cls it was computed from, u8 [n_img_total, S])
+        self._lists_replaced = False
 
     # -- cost of one region ---------------------------------------------------------------------
     def _fair(self):
@@ -31,37 +36,90 @@ class RegionActiveDataset:
             return int(self.trg_label_dataset.multi_hot_cls[self._image_index(spx_file_path), suppix_id].sum())
         return 1
 
+    def click_cost_table(self):
+        """u8 [n_img_total, S]: ``multi_hot_cls[i, s].sum()`` for every region (static over the rounds, computed once),
+        or None for unit cost."""
+        if not self._fair():
+            return None
+        mh = self.trg_label_dataset.multi_hot_cls
+        if self._click_cost is None or self._click_cost[0] is not mh:
+            if hasattr(mh, 'is_cuda'):          # a (device-resident) torch tensor
+                tab = mh.sum(dim=2).to(dtype=mh.dtype).cpu().numpy().astype(np.uint8)
+            else:
+                tab = np.asarray(mh).sum(axis=2, dtype=np.uint8)
+            self._click_cost = (mh, np.ascontiguousarray(tab))
+        return self._click_cost[1]
+
+    def pool_valid_mask(self, nseg):
+        """u8 [len(pool.im_idx), nseg] in ``pool.im_idx`` order: 1 where the id is still listed in ``pool.suppix``
+        (``active_selection/my_bvsb.py:41-46``).  The table is built once from the lists (or taken from the pool's
+        ``initial_valid_table()`` when it offers one), then kept in step by ``expand_training_set``;
+        ``load_datalist`` drops it."""
+        pool = self.trg_pool_dataset
+        if self._valid is None or self._valid.shape[1] != nseg:
+            init = getattr(pool, 'initial_valid_table', None)
+            tab = init() if (init is not None and not self._lists_replaced) else None
+            if tab is None:
+                n_total = len(self.trg_label_dataset.id_to_index)
+                tab = np.zeros((n_total, nseg), dtype=np.uint8)
+                for key in pool.im_idx:
+                    tab[self._image_index(key[2]), pool.suppix[key[2]]] = 1
+            self._valid = tab
+        rows = np.fromiter((self._image_index(key[2]) for key in pool.im_idx), dtype=np.intp, count=len(pool.im_idx))
+        return self._valid[rows]
+
     # -- selection ------------------------------------------------------------------------------
     def expand_training_set(self, sample_region, selection_count, selection_method):
-        """``sample_region``: sorted list of (score, "img,lbl,spx", suppix_id)."""
+        """``sample_region``: sorted list of (score, "img,lbl,spx", suppix_id).
+
+        Same end state as the reference loop (:31-73) -- order of ``label.im_idx``, order inside every ``suppix`` list,
+        ``isselected``, the pickled prefix -- but without its per-region linear scans: ``key not in label.im_idx`` (:38) is
+        answered by a set, the click cost by a table computed once, and ``pool.suppix[path].remove(id)`` (:46, O(S) each) is
+        deferred: the ids leaving a list are collected and every touched list is rewritten once, order preserved."""
         pool, label = self.trg_pool_dataset, self.trg_label_dataset
         cost = 0
         n_sup = 0
-        # ``key not in label.im_idx`` of the reference (:38) is a linear scan per region (2 975 list compares x 100 000
-        # regions per Cityscapes round); the set below answers the same question: an image is listed iff its key is.
         listed = {tuple(k) for k in label.im_idx}
+        cost_tab = self.click_cost_table()
+        has_sel = hasattr(pool, 'isselected')
+        leaving = {}            # spx path -> (key, image row, set of ids removed from the pool in this call)
         for idx, (_, joined, suppix_id) in enumerate(sample_region):
-            key = joined.split(",")
-            spx_path = key[2]
-            if tuple(key) not in listed:
-                listed.add(tuple(key))
-                label.im_idx.append(key)
-                label.suppix[spx_path] = [suppix_id]
-            else:
-                label.suppix[spx_path].append(suppix_id)
-            pool.suppix[spx_path].remove(suppix_id)
-            if len(pool.suppix[spx_path]) == 0:
-                pool.suppix.pop(spx_path)
-                pool.im_idx.remove(key)
-            if hasattr(pool, 'isselected'):
-                pool.isselected[self._image_index(spx_path), suppix_id] = 1
-            cost += self.region_cost(spx_path, suppix_id)
+            st = leaving.get(joined)
+            if st is None:
+                key = joined.split(",")
+                spx_path = key[2]
+                st = leaving[joined] = (key, self._image_index(spx_path), set(), set(pool.suppix[spx_path]))
+                if tuple(key) not in listed:
+                    listed.add(tuple(key))
+                    label.im_idx.append(key)
+                    label.suppix[spx_path] = []
+            key, row, gone, present = st
+            if suppix_id not in present:
+                raise ValueError("list.remove(x): x not in list")            # what pool.suppix[path].remove(id) raises (:46)
+            present.discard(suppix_id)
+            gone.add(suppix_id)
+            label.suppix[key[2]].append(suppix_id)
+            if has_sel:
+                pool.isselected[row, suppix_id] = 1
+            if self._valid is not None:
+                self._valid[row, suppix_id] = 0
+            cost += int(cost_tab[row, suppix_id]) if cost_tab is not None else 1
             n_sup += 1
             if cost > selection_count:
                 fname = '%s_selection_%02d.pkl' % (selection_method, self.selection_iter)
                 with open(os.path.join(self.args.model_save_dir, fname), "wb") as f:
                     pickle.dump(sample_region[:idx + 1], f)
                 break
+        emptied = set()
+        for key, row, gone, present in leaving.values():
+            spx_path = key[2]
+            if present:
+                pool.suppix[spx_path] = [i for i in pool.suppix[spx_path] if i not in gone]
+            else:
+                pool.suppix.pop(spx_path)
+                emptied.add(tuple(key))
+        if emptied:
+            pool.im_idx[:] = [k for k in pool.im_idx if tuple(k) not in emptied]
         log = getattr(getattr(self.args, 'wandb', None), 'log', None)
         if log is not None and n_sup:
             step = int(getattr(self.args, 'finetune_itrs', 0)) * (self.selection_iter - 1)
@@ -87,6 +145,7 @@ class RegionActiveDataset:
         self.trg_pool_dataset.im_idx = data['trg_pool_im_idx']
         self.trg_label_dataset.suppix = data['trg_label_suppix']
         self.trg_pool_dataset.suppix = data['trg_pool_suppix']
+        self._valid, self._lists_replaced = None, True
 
     def get_trainset(self):
         return self.trg_label_dataset

@@ -292,6 +292,22 @@ def weights_to_fixed31(cls_w):
     return np.floor(w * 2147483648.0).astype(np.uint32)
 
 
+def class_weight(prob_sum, hw, batch_size, n_batches, coeff):
+    """Device-side class weights from the per-picture class sums [n_img, C] int64 (``mas_class_weight``): returns
+    (cum f64 [C], cls_w f32 [C], w31 int32 [C] = floor(cls_w * 2^31) bits).  No host synchronisation."""
+    _need(prob_sum, "prob_sum", torch.int64)
+    n_img, C = prob_sum.shape
+    dev = prob_sum.device
+    cum = torch.empty(C, dtype=torch.float64, device=dev)
+    w = torch.empty(C, dtype=torch.float32, device=dev)
+    w31 = torch.empty(C, dtype=torch.int32, device=dev)
+    with torch.cuda.device(dev):
+        _lib.check(_lib.load().mas_class_weight(prob_sum.data_ptr(), n_img, C, int(hw), int(batch_size), int(n_batches),
+                                                float(coeff), cum.data_ptr(), w.data_ptr(), w31.data_ptr(), _stream(prob_sum)),
+                   "mas_class_weight")
+    return cum, w, w31
+
+
 def single_pass_accum(z, spx, S, invT, prob_sum=None, class_sum=None, hist=None):
     """One scan: (prob_sum [B,C] i64, class_sum [B,S,C] i64, hist [B,S,C] i32), all accumulated into."""
     _need(z, "z", torch.float32)

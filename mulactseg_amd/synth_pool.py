@@ -44,9 +44,17 @@ def device_superpixel_maps(seeds, H, W, S, device, dtype=torch.int16):
 class LogitSource(torch.nn.Module):
     """Stand-in for the segmentation net of an acquisition round: picture indices in, logits out."""
 
-    def __init__(self, C, H, W, device, nbuf=3, seed=1, alias=None):
+    def __init__(self, C, H, W, device, nbuf=3, seed=1, alias=None, window=None):
+        """``window = (batch_size, first_batch)``: zero-copy mode for timing runs -- the k-th call returns the contiguous
+        slice ``base[j : j + len(indices)]`` with ``j = (first_batch + k) % (nbuf - batch_size + 1)`` (picture ``i`` =
+        base ``(i // batch_size) % (nbuf - batch_size + 1) + i % batch_size``), sequenced on the host: the scan reads
+        resident logits, with no generator copy and no device->host read of the indices in between.  Calls must come in
+        pool order (``RegionSelector._iterate`` does)."""
         super().__init__()
         self.C, self.H, self.W, self.nbuf = C, H, W, nbuf
+        self.window, self._calls = window, 0
+        if window is not None and nbuf < window[0]:
+            raise ValueError("window mode needs nbuf >= batch_size")
         self.alias = dict(alias or {})
         g = torch.Generator(device=device)
         g.manual_seed(seed)
@@ -67,6 +75,11 @@ class LogitSource(torch.nn.Module):
             out.copy_(src)
 
     def forward(self, indices):
+        if self.window is not None:
+            bs, first = self.window
+            j = (first + self._calls) % (self.nbuf - bs + 1)
+            self._calls += 1
+            return self.base[j:j + indices.shape[0]]
         idx = [int(v) for v in indices.reshape(-1).tolist()]
         z = torch.empty((len(idx), self.C, self.H, self.W), dtype=torch.float32, device=self.base.device)
         for k, i in enumerate(idx):
@@ -99,15 +112,20 @@ class SyntheticPool(torch.utils.data.Dataset):
         self.suppix = {k[2]: list(range(S)) for k in self.im_idx}
         self._row = {k[2]: i for i, k in enumerate(self.im_idx)}
         self.isselected = np.zeros((n_img, S), dtype=np.uint8)
+        self._index = torch.arange(n_img, dtype=torch.int64, device=device)
 
     def __len__(self):
         return len(self.im_idx)
+
+    def initial_valid_table(self):
+        """u8 [n_img, S] of the freshly built pool (every id listed): spares RegionActiveDataset the walk over 6 M list entries."""
+        return np.ones((self.n_img, self.S), dtype=np.uint8)
 
     def __getitem__(self, k):
         i = self._row[self.im_idx[k][2]]
         if not self.lo <= i < self.hi:
             raise IndexError("picture %d is outside this rank's shard [%d, %d)" % (i, self.lo, self.hi))
-        return {'images': torch.tensor(i, dtype=torch.int64), 'spx': self.maps[i - self.lo]}
+        return {'images': self._index[i], 'spx': self.maps[i - self.lo]}
 
     def host_map(self, i):
         return self.maps[i - self.lo].cpu().numpy().view(np.uint16).astype(np.int64)

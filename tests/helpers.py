@@ -39,6 +39,12 @@ class OracleBackend:
         class_sum += torch.from_numpy(cs.view(np.int64))
         hist += torch.from_numpy(h.view(np.int32))
 
+    def class_weight(self, prob_sum, hw, batch_size, n_batches, coeff):
+        from mulactseg_amd.active_selection.engine import class_weight_from_sums
+        n_img = prob_sum.shape[0]
+        cum, w = class_weight_from_sums(prob_sum.numpy(), hw, np.arange(n_img) // batch_size, n_batches, coeff)
+        return cum, torch.from_numpy(w)
+
     def finalize_weighted(self, class_sum, hist, cls_w, ban_class, want_hist_i64=False):
         w = np.ones(hist.shape[-1], dtype=np.float32) if cls_w is None else cls_w.numpy()
         score, dom, cnt = exact.region_finalize_weighted(class_sum.numpy().view(np.uint64), hist.numpy().view(np.uint32),

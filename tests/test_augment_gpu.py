@@ -69,7 +69,7 @@ def test_resident_region_dataset_samples():
     region = {"spx0.pkl": [1, 5, 7], "spx2.pkl": [0, 39]}
     ds = ResidentRegionDataset(args, pics, spxs, mh, names, split='active-label', region_dict=region, rng=random.Random(3))
     ds.transform.size = (64, 64)
-    assert len(ds) == 2 and ds.im_idx[1] == names[2]
+    assert len(ds) == 2 and tuple(ds.im_idx[1]) == names[2]
     for idx in range(2):
         s = ds[idx]
         assert tuple(s['images'].shape) == (3, 64, 64) and s['images'].dtype == torch.float32

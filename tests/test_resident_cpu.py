@@ -53,3 +53,67 @@ def test_budget_is_the_click_cost_under_fair_counting(tmp_path):
     budget = int(costs[4])                                            # reached exactly by 5 regions -> one more is taken
     n = aset.expand_training_set(order, budget, 'x')
     assert n == int(np.searchsorted(costs, budget, side='right')) + 1
+
+
+def _reference_loop(pool, label, isselected, index_of, mh, sample_region, selection_count):
+    """The loop of the reference's RegionActiveDataset.expand_training_set (dataloader/region_active_dataset.py:31-73,
+    fair counting + or-labeling), statement by statement, on plain lists: the yardstick for the deferred-removal
+    implementation.  Returns the number of consumed regions."""
+    cost = 0
+    for idx, (_, joined, sid) in enumerate(sample_region):
+        key = joined.split(",")
+        spx = key[2]
+        if key not in label['im_idx']:
+            label['im_idx'].append(key)
+            label['suppix'][spx] = [sid]
+        else:
+            label['suppix'][spx].append(sid)
+        pool['suppix'][spx].remove(sid)
+        if len(pool['suppix'][spx]) == 0:
+            pool['suppix'].pop(spx)
+            pool['im_idx'].remove(key)
+        isselected[index_of(spx), sid] = 1
+        cost += int(mh[index_of(spx), sid].sum())
+        if cost > selection_count:
+            return idx + 1
+    return len(sample_region)
+
+
+def test_expand_training_set_equals_the_reference_loop_on_random_rounds(tmp_path):
+    """Three successive rounds of random orders (one of them emptying pictures, one stopped by the budget) leave the lists,
+    the id order inside every list, isselected, the valid table and the pickled prefix exactly as the reference loop does."""
+    import copy
+    import pickle
+    rs = np.random.RandomState(4)
+    args, names, mh, aset = _sets(tmp_path, n=6, nseg=24)
+    pool, label = aset.trg_pool_dataset, aset.trg_label_dataset
+    ref_pool = {'im_idx': copy.deepcopy(pool.im_idx), 'suppix': copy.deepcopy(pool.suppix)}
+    ref_label = {'im_idx': copy.deepcopy(label.im_idx), 'suppix': copy.deepcopy(label.suppix)}
+    ref_sel = np.zeros_like(pool.isselected)
+    index_of = lambda spx: label.id_to_index[spx.split('/')[-1].split('.')[0]]
+    assert np.array_equal(aset.pool_valid_mask(args.nseg).sum(1), [len(pool.suppix[k[2]]) for k in pool.im_idx])
+    for rnd, budget in enumerate([25, 10 ** 6, 40]):
+        aset.selection_iter = rnd + 1
+        cand = [(float(rs.rand()), ','.join(k), i) for k in pool.im_idx for i in pool.suppix[k[2]]]
+        cand.sort(reverse=True)
+        if rnd == 1:                                    # consume two whole pictures and a bit more, in score order
+            whole = {','.join(pool.im_idx[0]), ','.join(pool.im_idx[2])}
+            cand = [c for c in cand if c[1] in whole] + [c for c in cand if c[1] not in whole][:7]
+        n_ref = _reference_loop(ref_pool, ref_label, ref_sel, index_of, mh, cand, budget)
+        n = aset.expand_training_set(cand, budget, 'm')
+        assert n == n_ref
+        assert pool.im_idx == ref_pool['im_idx'] and pool.suppix == ref_pool['suppix']
+        assert list(pool.suppix) == list(ref_pool['suppix'])                   # dict order too (datalist pickle)
+        assert label.im_idx == ref_label['im_idx'] and label.suppix == ref_label['suppix']
+        assert np.array_equal(pool.isselected, ref_sel)
+        valid = aset.pool_valid_mask(args.nseg)
+        for k, key in enumerate(pool.im_idx):
+            assert sorted(np.nonzero(valid[k])[0].tolist()) == sorted(pool.suppix[key[2]])
+        if n < len(cand):
+            with open(tmp_path / ('m_selection_%02d.pkl' % (rnd + 1)), 'rb') as f:
+                assert pickle.load(f) == cand[:n]
+    # a region that is not in the pool any more raises as the reference does (list.remove -> ValueError; picture gone -> KeyError)
+    gone = ref_label['suppix'][ref_label['im_idx'][0][2]][0]
+    import pytest
+    with pytest.raises((ValueError, KeyError)):
+        aset.expand_training_set([(1.0, ','.join(ref_label['im_idx'][0]), gone)], 5, 'm')

@@ -247,3 +247,24 @@ def test_randomised_shapes_and_dirty_ids(seed):
     gs, gh = ops.bvsb_region_accum(zt, st, torch.from_numpy(w).cuda(), S, invT)
     assert np.array_equal(gs.cpu().numpy().view(np.uint64), es) and np.array_equal(gh.cpu().numpy().view(np.uint32), eh3)
     assert np.array_equal(ops.class_prob_sum(zt, invT).cpu().numpy().view(np.uint64), eps_)
+
+
+@pytest.mark.parametrize("n_img,batch,C,n_batches", [(7, 2, 20, 4), (2975, 4, 20, 744), (5000, 3, 21, 1667), (9, 4, 19, 5), (1, 1, 2, 1)])
+def test_class_weight_kernel_bit_exact(n_img, batch, C, n_batches):
+    """k_class_weight (device f64, batch means added in batch order) == oracle/exact.c:exact_class_weight bit for bit:
+    ragged last batch, more than one LDS chunk of batches (1 667 > 1 024), a trailing batch without pictures (9 pictures
+    in 5 batches of 4: the gather pad of engine.ShardPlan), and the integer form floor(w * 2^31)."""
+    from mulactseg_amd import ops
+    from oracle import exact
+    rs = np.random.RandomState(n_img)
+    hw = 1024 * 2048
+    ps = (rs.rand(n_img, C) * hw * 8388608.0 / C * 2).astype(np.uint64)
+    ps[0, 0] = 0
+    cum, w, w31 = ops.class_weight(torch.from_numpy(ps.view(np.int64)).cuda(), hw, batch, n_batches, 6.0)
+    ecum, ew = exact.class_weight(ps, hw, (np.arange(n_img) // batch).astype(np.int32), n_batches, 6.0)
+    assert np.array_equal(cum.cpu().numpy().view(np.uint64), ecum.view(np.uint64))
+    assert np.array_equal(w.cpu().numpy().view(np.uint32), ew.view(np.uint32))
+    assert np.array_equal(w31.cpu().numpy().view(np.uint32), exact.weights_to_fixed31(ew))
+    from mulactseg_amd.active_selection.engine import class_weight_from_sums
+    hcum, hw_ = class_weight_from_sums(ps.view(np.int64), hw, np.arange(n_img) // batch, n_batches, 6.0)
+    assert np.array_equal(hcum.view(np.uint64), ecum.view(np.uint64)) and np.array_equal(hw_, ew)
