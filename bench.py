@@ -569,6 +569,7 @@ def main():
     if args.warmup:
         ScanRound(args, dev, rank, world, backend, bufs, args.warmup).run(False)
     timed = ScanRound(args, dev, rank, world, backend, bufs, args.steps)
+    timed.rnd.hw = H * W
     timed.tail()            # untimed, on the still-empty accumulators: the timed round's buffers come out of torch's caching
     #                         allocator instead of hipMalloc (a long-lived trainer process is in that state from round 2 on)
     fence()
