@@ -352,6 +352,18 @@ int mas_maxpool3s2_bwd(const float* dy, const uint8_t* arg, int64_t NC, int H, i
 int mas_conv1x1_fwd(const float* x, const float* w_t, int N, int K, int M, int HW, const float* scale, const float* shift,
                     const float* residual, int relu, float* y, void* stream);
 
+/* Dense convolution on the f32 matrix cores (v_mfma_f32_32x32x2_f32; exact f32 products, k-ordered accumulation),
+ * NCHW: y[n,m,oy,ox] = sum_{c,r,s} w[m,c,r,s] * x[n,c, oy*stride + (r-1)*dil, ox*stride + (s-1)*dil]   (ksize 3, padding = dil)
+ *       y[n,m,oy,ox] = sum_c w[m,c] * x[n,c, oy*stride, ox*stride]                                     (ksize 1)
+ * with Ho = (H-1)/stride + 1.  `wt` is the re-arranged weight [Cin/CK][ksize*ksize][CK][Cout] with
+ * CK = mas_conv_chunk(ksize, Cin) (0 = unsupported channel count); Cout % 64 == 0.  With scale / shift (both or neither)
+ * the epilogue applies y*scale[m] + shift[m] (inference BatchNorm), then `residual` (NULL or [N,Cout,Ho,Wo]) is added
+ * and, if `relu`, max(.,0) taken -- the conv-bn-relu / conv-bn-add-relu triples of
+ * models/segmentation/backbone/resnet.py:143-160 and the 1x1 projections of deeplabv3.py:85-137,216-245 in one kernel. */
+int mas_conv_chunk(int ksize, int Cin);
+int mas_conv_fwd(const float* x, const float* wt, int N, int Cin, int H, int W, int Cout, int ksize, int stride, int dil,
+                 const float* scale, const float* shift, const float* residual, int relu, float* y, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,297 @@
+// conv_mfma.hip -- dense 2-D convolution (1x1 and 3x3; stride 1 / 2; any dilation) as an implicit GEMM on the f32 matrix
+// cores of gfx950 (v_mfma_f32_32x32x2_f32: exact f32, every product rounded once, accumulation in k order), NCHW in and
+// out, with the layers that follow a convolution in the network folded into the epilogue:
+//     y = relu?( conv(x, w) * scale[m] + shift[m] + residual )          (inference BatchNorm, residual add, ReLU)
+// Reference: the convolutions of models/segmentation/backbone/resnet.py:129-160 (Bottleneck: conv1x1 - bn - relu,
+// conv3x3 - bn - relu, conv1x1 - bn - (+identity) - relu), the deep stem (:163-171), the ASPP / decoder 1x1 projections
+// of models/segmentation/deeplabv3.py:85-137,216-245.
+//
+// GEMM view per picture:  Y[m, p] = sum_{tap, c} Wt[(tap, c), m] * X[c, pixel p shifted by tap]
+//   M = output channels (A operand, from a [chunk][tap][c][M] re-arranged weight so that a k-row is M-contiguous),
+//   N = output pixels   (B operand: a lane reads ITS pixel of an LDS-resident input patch, tap shifts are address offsets),
+//   K = taps * Cin, walked in chunks of CK input channels.
+// A workgroup (4 waves) owns BM channels x BN pixels (a TH x TW patch of one output plane); a wave owns 64 x (BN / WN)
+// of it as 32x32 MFMA tiles.  The two k values of one MFMA (lane halves) are the channels c, c + 1 of the same tap, so
+// per step the operand addresses of both halves differ by a constant and the step offset is wave-uniform.
+// Per chunk: global -> registers (issued before the MFMAs of the previous chunk), registers -> LDS after it (one LDS
+// buffer, two workgroups per CU overlap each other's staging), every input element is fetched once per workgroup and
+// reused for all taps and all BM channels.  Blocks that share an input patch (the M tiles of one pixel tile) sit on one
+// XCD so that the re-reads hit its L2.
+#include "common.h"
+
+namespace {
+constexpr int kThreads = 256;
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+struct ConvP {
+    const float* x;
+    const float* wt;
+    const float* scale;
+    const float* shift;
+    const float* res;
+    float* y;
+    int Cin, H, W, Cout, Ho, Wo, stride, dil, pad, relu;
+    int tw_log2, TH;                    // output tile: TH rows x (1 << tw_log2) columns, TH << tw_log2 == BN
+    int tiles_x, tiles_y, ptiles, mtiles;
+    int PH, PW, CS;                     // LDS input patch: rows, columns, channel stride (floats)
+};
+
+template <int TAPS, int CK, int BM, int BN, int NXMAX, bool VEC>
+__global__ __launch_bounds__(kThreads, 2) void k_conv_mfma(const ConvP p) {
+    constexpr int WM = BM / 64, WN = 4 / WM, TN = BN / WN / 32;
+    constexpr int KC = TAPS * CK;
+    constexpr int W4 = KC * BM / 4;
+    constexpr int NW = (W4 + kThreads - 1) / kThreads;
+    static_assert(BM == 64 || BM == 128, "BM");
+    static_assert(TN >= 1 && CK % 2 == 0, "tile");
+    extern __shared__ __attribute__((aligned(16))) float conv_smem[];
+    float* sW = conv_smem;                  // [KC][BM]
+    float* sX = conv_smem + KC * BM;        // [CK][CS]
+
+    const int tid = threadIdx.x;
+    const int bid = blockIdx.x;
+    const int xcd = bid & 7, slot = bid >> 3;
+    const int mt = slot % p.mtiles;
+    const int pt = (slot / p.mtiles) * 8 + xcd;
+    if (pt >= p.ptiles) return;
+    const int tpi = p.tiles_x * p.tiles_y;
+    const int n = pt / tpi;
+    const int trem = pt - n * tpi;
+    const int tyi = trem / p.tiles_x, txi = trem - tyi * p.tiles_x;
+    const int TW = 1 << p.tw_log2;
+    const int oy0 = tyi * p.TH, ox0 = txi * TW;
+    const int m0 = mt * BM;
+    const int HW = p.H * p.W;
+
+    // ---- staging descriptors (the same for every chunk; only the base pointers advance) -------------------------------
+    int goff[NXMAX], loff[NXMAX];
+    unsigned ok = 0, live = 0;
+    {
+        const int per_c = p.PH * p.PW;
+        const int total = VEC ? (CK * per_c) / 4 : CK * per_c;
+        const int iy0 = oy0 * p.stride - p.pad, ix0 = ox0 * p.stride - p.pad;
+#pragma unroll
+        for (int j = 0; j < NXMAX; ++j) {
+            const int e = (tid + j * kThreads) * (VEC ? 4 : 1);
+            goff[j] = 0;
+            loff[j] = 0;
+            if (e < (VEC ? total * 4 : total)) {
+                const int c = e / per_c, rem = e - c * per_c;
+                const int py = rem / p.PW, px = rem - py * p.PW;
+                const int iy = (TAPS == 1) ? (oy0 + py) * p.stride : iy0 + py;
+                const int ix = (TAPS == 1) ? (ox0 + px) * p.stride : ix0 + px;
+                live |= 1u << j;
+                loff[j] = c * p.CS + py * p.PW + px;
+                if (iy >= 0 && iy < p.H && ix >= 0 && ix < p.W) {
+                    ok |= 1u << j;
+                    goff[j] = c * HW + iy * p.W + ix;
+                }
+            }
+        }
+    }
+    int woff[NW];
+#pragma unroll
+    for (int j = 0; j < NW; ++j) {
+        int f = tid + j * kThreads;
+        if (f >= W4) f = W4 - 1;                        // clamped duplicate (same value written twice)
+        const int row = f / (BM / 4), col4 = f - row * (BM / 4);
+        woff[j] = row * p.Cout + col4 * 4;
+    }
+
+    // ---- MFMA operand addressing ---------------------------------------------------------------------------------------
+    const int wave = tid >> 6, lane = tid & 63, l31 = lane & 31, h = lane >> 5;
+    const int wm = wave / WN, wn = wave - wm * WN;
+    const int aBase = h * BM + wm * 64 + l31;
+    int bBase[TN];
+#pragma unroll
+    for (int tn = 0; tn < TN; ++tn) {
+        const int pl = wn * (BN / WN) + tn * 32 + l31;
+        const int ty = pl >> p.tw_log2, tx = pl & (TW - 1);
+        bBase[tn] = h * p.CS + ((TAPS == 1) ? ty * p.PW + tx : ty * p.stride * p.PW + tx * p.stride);
+    }
+    f32x16 acc[2][TN];
+#pragma unroll
+    for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+        for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[tm][tn][r] = 0.0f;
+
+    const float* xb = p.x + (size_t)n * p.Cin * HW;
+    const float* wb = p.wt + m0;
+    const int nchunks = p.Cin / CK;
+    float4 wr[NW];
+    float xr[NXMAX * (VEC ? 4 : 1)];
+
+    auto fetch = [&](int t) {
+        const float* xc = xb + (size_t)t * CK * HW;
+        const float* wc = wb + (size_t)t * KC * p.Cout;
+#pragma unroll
+        for (int j = 0; j < NW; ++j) wr[j] = *reinterpret_cast<const float4*>(wc + woff[j]);
+#pragma unroll
+        for (int j = 0; j < NXMAX; ++j) {
+            if (VEC) {
+                const float4 v = *reinterpret_cast<const float4*>(xc + goff[j]);
+                xr[4 * j] = v.x; xr[4 * j + 1] = v.y; xr[4 * j + 2] = v.z; xr[4 * j + 3] = v.w;
+            } else {
+                xr[j] = xc[goff[j]];
+            }
+        }
+    };
+    auto stage = [&]() {
+#pragma unroll
+        for (int j = 0; j < NW; ++j) {
+            int f = tid + j * kThreads;
+            if (f >= W4) f = W4 - 1;
+            *reinterpret_cast<float4*>(sW + 4 * f) = wr[j];
+        }
+#pragma unroll
+        for (int j = 0; j < NXMAX; ++j) {
+            if (live & (1u << j)) {
+                const bool v = ok & (1u << j);
+                if (VEC) {
+                    *reinterpret_cast<float4*>(sX + loff[j]) = v ? make_float4(xr[4 * j], xr[4 * j + 1], xr[4 * j + 2], xr[4 * j + 3])
+                                                                 : make_float4(0.f, 0.f, 0.f, 0.f);
+                } else {
+                    sX[loff[j]] = v ? xr[j] : 0.0f;
+                }
+            }
+        }
+    };
+
+    fetch(0);
+    for (int t = 0; t < nchunks; ++t) {
+        stage();
+        __syncthreads();
+        if (t + 1 < nchunks) fetch(t + 1);
+#pragma unroll
+        for (int tap = 0; tap < TAPS; ++tap) {
+            const int toff = (TAPS == 1) ? 0 : ((tap / 3) * p.PW + (tap % 3)) * p.dil;
+#pragma unroll
+            for (int cp = 0; cp < CK / 2; ++cp) {
+                const float* wrow = sW + (tap * CK + 2 * cp) * BM + aBase;
+                const float* xrow = sX + 2 * cp * p.CS + toff;
+                const float a0 = wrow[0], a1 = wrow[32];
+                float b[TN];
+#pragma unroll
+                for (int tn = 0; tn < TN; ++tn) b[tn] = xrow[bBase[tn]];
+#pragma unroll
+                for (int tn = 0; tn < TN; ++tn) {
+                    acc[0][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b[tn], acc[0][tn], 0, 0, 0);
+                    acc[1][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b[tn], acc[1][tn], 0, 0, 0);
+                }
+            }
+        }
+        __syncthreads();
+    }
+
+    // ---- epilogue: accumulator (row = (r & 3) + 8 (r >> 2) + 4 h, column = lane & 31) -> NCHW --------------------------
+    const int HWo = p.Ho * p.Wo;
+    float* yb = p.y + ((size_t)n * p.Cout + m0) * HWo;
+    const float* rb = p.res ? p.res + ((size_t)n * p.Cout + m0) * HWo : nullptr;
+#pragma unroll
+    for (int tn = 0; tn < TN; ++tn) {
+        const int pl = wn * (BN / WN) + tn * 32 + l31;
+        const int oy = oy0 + (pl >> p.tw_log2), ox = ox0 + (pl & (TW - 1));
+        const bool inside = oy < p.Ho && ox < p.Wo;
+        const int po = oy * p.Wo + ox;
+#pragma unroll
+        for (int tm = 0; tm < 2; ++tm) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = wm * 64 + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                float v = acc[tm][tn][r];
+                if (p.scale) v = mas_fmaf(v, p.scale[m0 + m], p.shift[m0 + m]);
+                if (inside) {
+                    if (rb) v += rb[(size_t)m * HWo + po];
+                    if (p.relu) v = v > 0.0f ? v : 0.0f;
+                    yb[(size_t)m * HWo + po] = v;
+                }
+            }
+        }
+    }
+}
+
+inline int ilog2(int v) {
+    int l = 0;
+    while ((1 << l) < v) ++l;
+    return l;
+}
+
+template <int TAPS, int CK, int BM, int BN, int NXMAX, bool VEC>
+int launch(ConvP p, int N, hipStream_t st) {
+    const int TW = 1 << p.tw_log2;
+    p.TH = BN / TW;
+    p.tiles_x = (p.Wo + TW - 1) / TW;
+    p.tiles_y = (p.Ho + p.TH - 1) / p.TH;
+    p.ptiles = N * p.tiles_x * p.tiles_y;
+    p.mtiles = p.Cout / BM;
+    if (TAPS == 1) {
+        p.PH = p.TH;
+        p.PW = TW;
+    } else {
+        p.PH = (p.TH - 1) * p.stride + 2 * p.dil + 1;
+        p.PW = (TW - 1) * p.stride + 2 * p.dil + 1;
+    }
+    p.CS = p.PH * p.PW;
+    if (VEC) p.CS = (p.CS + 3) & ~3;
+    const int per = CK * p.PH * p.PW;
+    if ((VEC ? per / 4 : per) > NXMAX * kThreads) return MAS_ERR_SHAPE;
+    const size_t smem = sizeof(float) * ((size_t)TAPS * CK * BM + (size_t)CK * p.CS);
+    if (smem > 64 * 1024) {
+        static bool once = false;       // > 64 KB of dynamic LDS needs the attribute (set once per instantiation)
+        if (!once) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv_mfma<TAPS, CK, BM, BN, NXMAX, VEC>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            once = true;
+        }
+    }
+    const long long nblk = 8LL * ((p.ptiles + 7) / 8) * p.mtiles;
+    if (nblk <= 0 || nblk > 0x7fffffffLL) return MAS_ERR_SHAPE;
+    hipLaunchKernelGGL((k_conv_mfma<TAPS, CK, BM, BN, NXMAX, VEC>), dim3((unsigned)nblk), dim3(kThreads), smem, st, p);
+    return mas_launch_status();
+}
+}  // namespace
+
+extern "C" int mas_conv_chunk(int ksize, int Cin) {
+    if (ksize == 3) return Cin % 8 == 0 ? 8 : 0;
+    if (ksize == 1) return Cin % 32 == 0 ? 32 : (Cin % 16 == 0 ? 16 : 0);
+    return 0;
+}
+
+extern "C" int mas_conv_fwd(const float* x, const float* wt, int N, int Cin, int H, int W, int Cout, int ksize, int stride, int dil,
+                            const float* scale, const float* shift, const float* residual, int relu, float* y, void* stream) {
+    if (!x || !wt || !y) return MAS_ERR_NULL;
+    if ((scale == nullptr) != (shift == nullptr)) return MAS_ERR_NULL;
+    if (N <= 0 || Cin <= 0 || H <= 0 || W <= 0 || Cout <= 0) return MAS_ERR_SHAPE;
+    if ((ksize != 1 && ksize != 3) || (stride != 1 && stride != 2) || dil < 1 || dil > 4) return MAS_ERR_RANGE;
+    if (ksize == 1 && dil != 1) return MAS_ERR_RANGE;
+    if (Cout % 64 != 0 || mas_conv_chunk(ksize, Cin) == 0) return MAS_ERR_SHAPE;
+    if ((long long)Cin * H * W > 0x7fffffffLL) return MAS_ERR_SHAPE;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    ConvP p;
+    p.x = x; p.wt = wt; p.scale = scale; p.shift = shift; p.res = residual; p.y = y;
+    p.Cin = Cin; p.H = H; p.W = W; p.Cout = Cout;
+    p.stride = stride; p.dil = dil; p.pad = ksize == 3 ? dil : 0; p.relu = relu;
+    p.Ho = (H - 1) / stride + 1;
+    p.Wo = (W - 1) / stride + 1;
+    const bool big_m = Cout % 128 == 0;
+    // tile width: 32 columns when the plane has them, 16 for the 48 / 49-wide planes of the deep layers
+    const int TW = p.Wo >= 32 ? 32 : 16;
+    p.tw_log2 = ilog2(TW);
+    if (ksize == 1) {
+        const bool vec = stride == 1 && (W % 4 == 0) && ((uintptr_t)x % 16 == 0);
+        const int ck = mas_conv_chunk(1, Cin);
+        if (ck == 32) {
+            if (big_m) return vec ? launch<1, 32, 128, 128, 4, true>(p, N, st) : launch<1, 32, 128, 128, 16, false>(p, N, st);
+            return vec ? launch<1, 32, 64, 128, 4, true>(p, N, st) : launch<1, 32, 64, 128, 16, false>(p, N, st);
+        }
+        if (big_m) return vec ? launch<1, 16, 128, 128, 2, true>(p, N, st) : launch<1, 16, 128, 128, 8, false>(p, N, st);
+        return vec ? launch<1, 16, 64, 128, 2, true>(p, N, st) : launch<1, 16, 64, 128, 8, false>(p, N, st);
+    }
+    if (stride == 2) {
+        if (dil != 1) return MAS_ERR_RANGE;
+        return big_m ? launch<9, 8, 128, 128, 20, false>(p, N, st) : launch<9, 8, 64, 128, 20, false>(p, N, st);
+    }
+    return big_m ? launch<9, 8, 128, 128, 12, false>(p, N, st) : launch<9, 8, 64, 128, 12, false>(p, N, st);
+}

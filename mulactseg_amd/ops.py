@@ -795,3 +795,74 @@ def conv1x1_bn_act(conv, bn, x, relu=True, residual=None):
         _lib.check(_lib.load().mas_conv1x1_fwd(x.data_ptr(), w_t.data_ptr(), N, K, M, H * W, scale.data_ptr(), shift.data_ptr(), _opt(res),
                                                int(relu), y.data_ptr(), _stream(x)), "mas_conv1x1_fwd")
     return y
+
+
+# ------------------------------------------------------------------------------------------------
+# dense convolutions on the f32 matrix cores (csrc/conv_mfma.hip)
+# ------------------------------------------------------------------------------------------------
+def conv_mfma_supported(conv, x):
+    """Shapes the implicit-GEMM MFMA kernel takes: 1x1 / 3x3, stride 1 or 2 (3x3 stride 2 only undilated), padding =
+    dilation for 3x3, no groups, no bias, Cout % 64 == 0, Cin % 8 (3x3) / % 16 (1x1) == 0, fp32 NCHW on the GPU."""
+    if not (x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and conv.groups == 1 and conv.bias is None):
+        return False
+    k, s, d, pd = conv.kernel_size, conv.stride, conv.dilation, conv.padding
+    if k[0] != k[1] or s[0] != s[1] or d[0] != d[1] or pd[0] != pd[1] or k[0] not in (1, 3) or s[0] not in (1, 2):
+        return False
+    if k[0] == 3 and (pd[0] != d[0] or d[0] > 2 or (s[0] == 2 and d[0] != 1)):
+        return False
+    if k[0] == 1 and (pd[0] != 0 or d[0] != 1):
+        return False
+    if conv.out_channels % 64 != 0 or x.shape[1] != conv.in_channels:
+        return False
+    return _lib.load().mas_conv_chunk(k[0], conv.in_channels) > 0 and conv.in_channels * x.shape[2] * x.shape[3] < 2 ** 31
+
+
+def _versions(tensors):
+    return tuple((t.data_ptr(), t._version) for t in tensors if t is not None)
+
+
+def _conv_packed_weight(conv):
+    """[Cin/CK][taps][CK][Cout] copy of the weight (k-rows contiguous over the output channels), cached on the module
+    until the parameter changes."""
+    key = _versions((conv.weight,))
+    cache = getattr(conv, '_mas_conv_pack', None)
+    if cache is None or cache[0] != key:
+        with torch.no_grad():
+            M, K, kh, kw = conv.weight.shape
+            ck = _lib.load().mas_conv_chunk(kh, K)
+            w = conv.weight.detach().permute(1, 2, 3, 0).reshape(K // ck, ck, kh * kw, M).permute(0, 2, 1, 3).contiguous()
+        cache = conv._mas_conv_pack = (key, w)
+    return cache[1]
+
+
+def _bn_fold(bn):
+    """(scale, shift) f32 [C] of an inference BatchNorm, cached on the module until a parameter or running statistic
+    changes (the training kernels bump the buffers' version counters, _BNActTrain.forward)."""
+    key = _versions((bn.weight, bn.bias, bn.running_mean, bn.running_var))
+    cache = getattr(bn, '_mas_fold', None)
+    if cache is None or cache[0] != key:
+        with torch.no_grad():
+            inv = torch.rsqrt(bn.running_var.double() + bn.eps)
+            g = bn.weight.double() if bn.weight is not None else torch.ones_like(inv)
+            b = bn.bias.double() if bn.bias is not None else torch.zeros_like(inv)
+            scale = g * inv
+            shift = b - bn.running_mean.double() * scale
+        cache = bn._mas_fold = (key, scale.float().contiguous(), shift.float().contiguous())
+    return cache[1], cache[2]
+
+
+def conv_mfma(conv, x, bn=None, relu=False, residual=None):
+    """relu?(bn(conv(x)) + residual) in one kernel; ``bn`` None -> the bare convolution (then residual / relu still apply)."""
+    x = x.contiguous()
+    N, K, H, W = x.shape
+    M = conv.out_channels
+    ks, s, d = conv.kernel_size[0], conv.stride[0], conv.dilation[0]
+    wt = _conv_packed_weight(conv)
+    scale, shift = _bn_fold(bn) if bn is not None else (None, None)
+    res = residual.contiguous() if residual is not None else None
+    Ho, Wo = (H - 1) // s + 1, (W - 1) // s + 1
+    y = torch.empty((N, M, Ho, Wo), dtype=torch.float32, device=x.device)
+    with torch.cuda.device(x.device):
+        _lib.check(_lib.load().mas_conv_fwd(x.data_ptr(), wt.data_ptr(), N, K, H, W, M, ks, s, d, _opt(scale), _opt(shift), _opt(res),
+                                            int(relu), y.data_ptr(), _stream(x)), "mas_conv_fwd")
+    return y
