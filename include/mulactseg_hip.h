@@ -355,8 +355,9 @@ int mas_conv1x1_fwd(const float* x, const float* w_t, int N, int K, int M, int H
 /* Dense convolution on the f32 matrix cores (v_mfma_f32_32x32x2_f32; exact f32 products, k-ordered accumulation),
  * NCHW: y[n,m,oy,ox] = sum_{c,r,s} w[m,c,r,s] * x[n,c, oy*stride + (r-1)*dil, ox*stride + (s-1)*dil]   (ksize 3, padding = dil)
  *       y[n,m,oy,ox] = sum_c w[m,c] * x[n,c, oy*stride, ox*stride]                                     (ksize 1)
- * with Ho = (H-1)/stride + 1.  `wt` is the re-arranged weight [Cin/CK][ksize*ksize][CK][Cout] with
- * CK = mas_conv_chunk(ksize, Cin) (0 = unsupported channel count); Cout % 64 == 0.  With scale / shift (both or neither)
+ * with Ho = (H-1)/stride + 1.  `wt` is the re-arranged weight [Cin/CK][KC/8][2][Cout][4], KC = ksize*ksize*CK,
+ * CK = mas_conv_chunk(ksize, Cin) (0 = unsupported channel count): element (chunk, q, h, m, j) is
+ * w[m, chunk*CK + 2*cp + h, tap] with k-step kk = 4*q + j, tap = kk / (CK/2), cp = kk % (CK/2); Cout % 64 == 0.  With scale / shift (both or neither)
  * the epilogue applies y*scale[m] + shift[m] (inference BatchNorm), then `residual` (NULL or [N,Cout,Ho,Wo]) is added
  * and, if `relu`, max(.,0) taken -- the conv-bn-relu / conv-bn-add-relu triples of
  * models/segmentation/backbone/resnet.py:143-160 and the 1x1 projections of deeplabv3.py:85-137,216-245 in one kernel. */

@@ -7,7 +7,8 @@
 // of models/segmentation/deeplabv3.py:85-137,216-245.
 //
 // GEMM view per picture:  Y[m, p] = sum_{tap, c} Wt[(tap, c), m] * X[c, pixel p shifted by tap]
-//   M = output channels (A operand, from a [chunk][tap][c][M] re-arranged weight so that a k-row is M-contiguous),
+//   M = output channels (A operand, from a re-arranged weight [chunk][k-step / 4][lane half][M][4 k-steps]: the four
+//       A values a lane needs for four consecutive MFMAs are one 16-byte LDS read),
 //   N = output pixels   (B operand: a lane reads ITS pixel of an LDS-resident input patch, tap shifts are address offsets),
 //   K = taps * Cin, walked in chunks of CK input channels.
 // A workgroup (4 waves) owns BM channels x BN pixels (a TH x TW patch of one output plane); a wave owns 64 x (BN / WN)
@@ -22,6 +23,7 @@
 namespace {
 constexpr int kThreads = 256;
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float v4f __attribute__((ext_vector_type(4)));      // a native vector (HIP's float4 is a struct: arrays of it stay in scratch)
 
 struct ConvP {
     const float* x;
@@ -36,17 +38,52 @@ struct ConvP {
     int PH, PW, CS;                     // LDS input patch: rows, columns, channel stride (floats)
 };
 
-template <int TAPS, int CK, int BM, int BN, int NXMAX, bool VEC>
+// global -> registers: the weight tile (NW float4 per thread) and the input patch (NXMAX elements or float4s per thread);
+// addresses outside the plane were redirected to offset 0 when the descriptors were built, so every load is unconditional
+template <int NW, int NXMAX, bool VEC>
+__device__ __forceinline__ void conv_fetch(const float* __restrict__ xc, const float* __restrict__ wc, const int (&woff)[NW],
+                                           const int (&goff)[NXMAX], v4f (&wr)[NW], v4f (&xr)[NXMAX]) {
+#pragma unroll
+    for (int j = 0; j < NW; ++j) wr[j] = *reinterpret_cast<const v4f*>(wc + woff[j]);
+#pragma unroll
+    for (int j = 0; j < NXMAX; ++j) {
+        if (VEC) xr[j] = *reinterpret_cast<const v4f*>(xc + goff[j]);
+        else xr[j].x = xc[goff[j]];
+    }
+}
+
+// registers -> LDS
+template <int NW, int NXMAX, bool VEC, int W4>
+__device__ __forceinline__ void conv_stage(float* __restrict__ sW, float* __restrict__ sX, int tid, const int (&loff)[NXMAX], unsigned live,
+                                           unsigned ok, const v4f (&wr)[NW], const v4f (&xr)[NXMAX]) {
+#pragma unroll
+    for (int j = 0; j < NW; ++j) {
+        int f = tid + j * kThreads;
+        if (f >= W4) f = W4 - 1;
+        *reinterpret_cast<v4f*>(sW + 4 * f) = wr[j];
+    }
+#pragma unroll
+    for (int j = 0; j < NXMAX; ++j) {
+        if (live & (1u << j)) {
+            const bool v = ok & (1u << j);
+            if (VEC) *reinterpret_cast<v4f*>(sX + loff[j]) = v ? xr[j] : (v4f){0.f, 0.f, 0.f, 0.f};
+            else sX[loff[j]] = v ? xr[j].x : 0.0f;
+        }
+    }
+}
+
+template <int TAPS, int CK, int BM, int BN, int NXMAX, bool VEC, bool RES>
 __global__ __launch_bounds__(kThreads, 2) void k_conv_mfma(const ConvP p) {
     constexpr int WM = BM / 64, WN = 4 / WM, TN = BN / WN / 32;
     constexpr int KC = TAPS * CK;
     constexpr int W4 = KC * BM / 4;
     constexpr int NW = (W4 + kThreads - 1) / kThreads;
     static_assert(BM == 64 || BM == 128, "BM");
-    static_assert(TN >= 1 && CK % 2 == 0, "tile");
+    static_assert(TN >= 1 && KC % 8 == 0, "tile");
     extern __shared__ __attribute__((aligned(16))) float conv_smem[];
-    float* sW = conv_smem;                  // [KC][BM]
-    float* sX = conv_smem + KC * BM;        // [CK][CS]
+    float* sW = conv_smem;                  // [KC / 8][2][BM][4]
+    float* sE = conv_smem + KC * BM;        // [2][BM]: epilogue scale, shift
+    float* sX = sE + 2 * BM;                // [CK][CS]
 
     const int tid = threadIdx.x;
     const int bid = blockIdx.x;
@@ -94,14 +131,14 @@ __global__ __launch_bounds__(kThreads, 2) void k_conv_mfma(const ConvP p) {
     for (int j = 0; j < NW; ++j) {
         int f = tid + j * kThreads;
         if (f >= W4) f = W4 - 1;                        // clamped duplicate (same value written twice)
-        const int row = f / (BM / 4), col4 = f - row * (BM / 4);
-        woff[j] = row * p.Cout + col4 * 4;
+        const int row = f / BM, m = f - row * BM;          // row = (k-step / 4) * 2 + lane half
+        woff[j] = (row * p.Cout + m) * 4;
     }
 
     // ---- MFMA operand addressing ---------------------------------------------------------------------------------------
     const int wave = tid >> 6, lane = tid & 63, l31 = lane & 31, h = lane >> 5;
     const int wm = wave / WN, wn = wave - wm * WN;
-    const int aBase = h * BM + wm * 64 + l31;
+    const int aBase = (h * BM + wm * 64 + l31) * 4;
     int bBase[TN];
 #pragma unroll
     for (int tn = 0; tn < TN; ++tn) {
@@ -118,67 +155,37 @@ __global__ __launch_bounds__(kThreads, 2) void k_conv_mfma(const ConvP p) {
             for (int r = 0; r < 16; ++r) acc[tm][tn][r] = 0.0f;
 
     const float* xb = p.x + (size_t)n * p.Cin * HW;
-    const float* wb = p.wt + m0;
+    const float* wb = p.wt + (size_t)m0 * 4;
     const int nchunks = p.Cin / CK;
-    float4 wr[NW];
-    float xr[NXMAX * (VEC ? 4 : 1)];
+    v4f wr[NW];
+    v4f xr[NXMAX];
 
-    auto fetch = [&](int t) {
-        const float* xc = xb + (size_t)t * CK * HW;
-        const float* wc = wb + (size_t)t * KC * p.Cout;
-#pragma unroll
-        for (int j = 0; j < NW; ++j) wr[j] = *reinterpret_cast<const float4*>(wc + woff[j]);
-#pragma unroll
-        for (int j = 0; j < NXMAX; ++j) {
-            if (VEC) {
-                const float4 v = *reinterpret_cast<const float4*>(xc + goff[j]);
-                xr[4 * j] = v.x; xr[4 * j + 1] = v.y; xr[4 * j + 2] = v.z; xr[4 * j + 3] = v.w;
-            } else {
-                xr[j] = xc[goff[j]];
-            }
-        }
-    };
-    auto stage = [&]() {
-#pragma unroll
-        for (int j = 0; j < NW; ++j) {
-            int f = tid + j * kThreads;
-            if (f >= W4) f = W4 - 1;
-            *reinterpret_cast<float4*>(sW + 4 * f) = wr[j];
-        }
-#pragma unroll
-        for (int j = 0; j < NXMAX; ++j) {
-            if (live & (1u << j)) {
-                const bool v = ok & (1u << j);
-                if (VEC) {
-                    *reinterpret_cast<float4*>(sX + loff[j]) = v ? make_float4(xr[4 * j], xr[4 * j + 1], xr[4 * j + 2], xr[4 * j + 3])
-                                                                 : make_float4(0.f, 0.f, 0.f, 0.f);
-                } else {
-                    sX[loff[j]] = v ? xr[j] : 0.0f;
-                }
-            }
-        }
-    };
-
-    fetch(0);
+    if (tid < BM) {
+        sE[tid] = p.scale ? p.scale[m0 + tid] : 1.0f;
+        sE[BM + tid] = p.scale ? p.shift[m0 + tid] : 0.0f;
+    }
+    conv_fetch<NW, NXMAX, VEC>(xb, wb, woff, goff, wr, xr);
     for (int t = 0; t < nchunks; ++t) {
-        stage();
+        conv_stage<NW, NXMAX, VEC, W4>(sW, sX, tid, loff, live, ok, wr, xr);
         __syncthreads();
-        if (t + 1 < nchunks) fetch(t + 1);
+        if (t + 1 < nchunks)
+            conv_fetch<NW, NXMAX, VEC>(xb + (size_t)(t + 1) * CK * HW, wb + (size_t)(t + 1) * KC * p.Cout, woff, goff, wr, xr);
 #pragma unroll
-        for (int tap = 0; tap < TAPS; ++tap) {
-            const int toff = (TAPS == 1) ? 0 : ((tap / 3) * p.PW + (tap % 3)) * p.dil;
+        for (int q = 0; q < KC / 8; ++q) {
+            const v4f a0 = *reinterpret_cast<const v4f*>(sW + q * 8 * BM + aBase);
+            const v4f a1 = *reinterpret_cast<const v4f*>(sW + q * 8 * BM + aBase + 128);
 #pragma unroll
-            for (int cp = 0; cp < CK / 2; ++cp) {
-                const float* wrow = sW + (tap * CK + 2 * cp) * BM + aBase;
+            for (int j = 0; j < 4; ++j) {
+                const int kk = 4 * q + j, tap = kk / (CK / 2), cp = kk - tap * (CK / 2);
+                const int toff = (TAPS == 1) ? 0 : ((tap / 3) * p.PW + (tap % 3)) * p.dil;
                 const float* xrow = sX + 2 * cp * p.CS + toff;
-                const float a0 = wrow[0], a1 = wrow[32];
                 float b[TN];
 #pragma unroll
                 for (int tn = 0; tn < TN; ++tn) b[tn] = xrow[bBase[tn]];
 #pragma unroll
                 for (int tn = 0; tn < TN; ++tn) {
-                    acc[0][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b[tn], acc[0][tn], 0, 0, 0);
-                    acc[1][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b[tn], acc[1][tn], 0, 0, 0);
+                    acc[0][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[j], b[tn], acc[0][tn], 0, 0, 0);
+                    acc[1][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[j], b[tn], acc[1][tn], 0, 0, 0);
                 }
             }
         }
@@ -186,27 +193,36 @@ __global__ __launch_bounds__(kThreads, 2) void k_conv_mfma(const ConvP p) {
     }
 
     // ---- epilogue: accumulator (row = (r & 3) + 8 (r >> 2) + 4 h, column = lane & 31) -> NCHW --------------------------
+    // Branch-free per element: scale / shift come from LDS (1 / 0 without a BatchNorm), the 16 residual values of a tile are
+    // loaded together (clamped address outside the plane), one predicate guards the 16 stores.
     const int HWo = p.Ho * p.Wo;
     float* yb = p.y + ((size_t)n * p.Cout + m0) * HWo;
-    const float* rb = p.res ? p.res + ((size_t)n * p.Cout + m0) * HWo : nullptr;
+    const float* rb = RES ? p.res + ((size_t)n * p.Cout + m0) * HWo : nullptr;
+    const float lo = p.relu ? 0.0f : -INFINITY;
 #pragma unroll
     for (int tn = 0; tn < TN; ++tn) {
         const int pl = wn * (BN / WN) + tn * 32 + l31;
         const int oy = oy0 + (pl >> p.tw_log2), ox = ox0 + (pl & (TW - 1));
         const bool inside = oy < p.Ho && ox < p.Wo;
-        const int po = oy * p.Wo + ox;
+        const int po = inside ? oy * p.Wo + ox : 0;
 #pragma unroll
         for (int tm = 0; tm < 2; ++tm) {
+            const int mb = wm * 64 + tm * 32 + 4 * h;
+            float rv[16], out[16];
+            if (RES) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) rv[r] = rb[(size_t)(mb + (r & 3) + 8 * (r >> 2)) * HWo + po];
+            }
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int m = wm * 64 + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-                float v = acc[tm][tn][r];
-                if (p.scale) v = mas_fmaf(v, p.scale[m0 + m], p.shift[m0 + m]);
-                if (inside) {
-                    if (rb) v += rb[(size_t)m * HWo + po];
-                    if (p.relu) v = v > 0.0f ? v : 0.0f;
-                    yb[(size_t)m * HWo + po] = v;
-                }
+                const int m = mb + (r & 3) + 8 * (r >> 2);
+                float v = mas_fmaf(acc[tm][tn][r], sE[m], sE[BM + m]);
+                if (RES) v += rv[r];
+                out[r] = v < lo ? lo : v;
+            }
+            if (inside) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) yb[(size_t)(mb + (r & 3) + 8 * (r >> 2)) * HWo + po] = out[r];
             }
         }
     }
@@ -218,8 +234,8 @@ inline int ilog2(int v) {
     return l;
 }
 
-template <int TAPS, int CK, int BM, int BN, int NXMAX, bool VEC>
-int launch(ConvP p, int N, hipStream_t st) {
+template <int TAPS, int CK, int BM, int BN, int NXMAX, bool VEC, bool RES>
+int launch_res(ConvP p, int N, hipStream_t st) {
     const int TW = 1 << p.tw_log2;
     p.TH = BN / TW;
     p.tiles_x = (p.Wo + TW - 1) / TW;
@@ -237,19 +253,17 @@ int launch(ConvP p, int N, hipStream_t st) {
     if (VEC) p.CS = (p.CS + 3) & ~3;
     const int per = CK * p.PH * p.PW;
     if ((VEC ? per / 4 : per) > NXMAX * kThreads) return MAS_ERR_SHAPE;
-    const size_t smem = sizeof(float) * ((size_t)TAPS * CK * BM + (size_t)CK * p.CS);
-    if (smem > 64 * 1024) {
-        static bool once = false;       // > 64 KB of dynamic LDS needs the attribute (set once per instantiation)
-        if (!once) {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv_mfma<TAPS, CK, BM, BN, NXMAX, VEC>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-            once = true;
-        }
-    }
+    const size_t smem = sizeof(float) * ((size_t)TAPS * CK * BM + 2 * BM + (size_t)CK * p.CS);
+    if (smem > 64 * 1024) return MAS_ERR_SHAPE;        // every supported geometry stays below the default dynamic-LDS limit
     const long long nblk = 8LL * ((p.ptiles + 7) / 8) * p.mtiles;
     if (nblk <= 0 || nblk > 0x7fffffffLL) return MAS_ERR_SHAPE;
-    hipLaunchKernelGGL((k_conv_mfma<TAPS, CK, BM, BN, NXMAX, VEC>), dim3((unsigned)nblk), dim3(kThreads), smem, st, p);
+    hipLaunchKernelGGL((k_conv_mfma<TAPS, CK, BM, BN, NXMAX, VEC, RES>), dim3((unsigned)nblk), dim3(kThreads), smem, st, p);
     return mas_launch_status();
+}
+
+template <int TAPS, int CK, int BM, int BN, int NXMAX, bool VEC>
+int launch(ConvP p, int N, hipStream_t st) {
+    return p.res ? launch_res<TAPS, CK, BM, BN, NXMAX, VEC, true>(p, N, st) : launch_res<TAPS, CK, BM, BN, NXMAX, VEC, false>(p, N, st);
 }
 }  // namespace
 
@@ -284,14 +298,15 @@ extern "C" int mas_conv_fwd(const float* x, const float* wt, int N, int Cin, int
         const int ck = mas_conv_chunk(1, Cin);
         if (ck == 32) {
             if (big_m) return vec ? launch<1, 32, 128, 128, 4, true>(p, N, st) : launch<1, 32, 128, 128, 16, false>(p, N, st);
-            return vec ? launch<1, 32, 64, 128, 4, true>(p, N, st) : launch<1, 32, 64, 128, 16, false>(p, N, st);
+            return vec ? launch<1, 32, 64, 256, 8, true>(p, N, st) : launch<1, 32, 64, 128, 16, false>(p, N, st);
         }
         if (big_m) return vec ? launch<1, 16, 128, 128, 2, true>(p, N, st) : launch<1, 16, 128, 128, 8, false>(p, N, st);
-        return vec ? launch<1, 16, 64, 128, 2, true>(p, N, st) : launch<1, 16, 64, 128, 8, false>(p, N, st);
+        return vec ? launch<1, 16, 64, 256, 4, true>(p, N, st) : launch<1, 16, 64, 128, 8, false>(p, N, st);
     }
     if (stride == 2) {
         if (dil != 1) return MAS_ERR_RANGE;
         return big_m ? launch<9, 8, 128, 128, 20, false>(p, N, st) : launch<9, 8, 64, 128, 20, false>(p, N, st);
     }
-    return big_m ? launch<9, 8, 128, 128, 12, false>(p, N, st) : launch<9, 8, 64, 128, 12, false>(p, N, st);
+    if (big_m) return launch<9, 8, 128, 128, 9, false>(p, N, st);
+    return dil == 1 ? launch<9, 8, 64, 256, 12, false>(p, N, st) : launch<9, 8, 64, 128, 12, false>(p, N, st);
 }

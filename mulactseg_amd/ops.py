@@ -822,15 +822,19 @@ def _versions(tensors):
 
 
 def _conv_packed_weight(conv):
-    """[Cin/CK][taps][CK][Cout] copy of the weight (k-rows contiguous over the output channels), cached on the module
-    until the parameter changes."""
+    """The weight as mas_conv_fwd reads it -- [Cin/CK][KC/8][2][Cout][4]: k-step kk = tap * (CK/2) + cp pairs the input
+    channels c = 2 cp + h (h = lane half of the MFMA), four consecutive k-steps of one (half, output channel) are
+    adjacent -- cached on the module until the parameter changes."""
     key = _versions((conv.weight,))
     cache = getattr(conv, '_mas_conv_pack', None)
     if cache is None or cache[0] != key:
         with torch.no_grad():
             M, K, kh, kw = conv.weight.shape
             ck = _lib.load().mas_conv_chunk(kh, K)
-            w = conv.weight.detach().permute(1, 2, 3, 0).reshape(K // ck, ck, kh * kw, M).permute(0, 2, 1, 3).contiguous()
+            taps = kh * kw
+            w = conv.weight.detach().reshape(M, K // ck, ck // 2, 2, taps)          # [m, chunk, cp, h, tap]
+            w = w.permute(1, 4, 2, 3, 0).reshape(K // ck, taps * ck // 2, 2, M)     # [chunk, kk = tap * ck/2 + cp, h, m]
+            w = w.reshape(K // ck, taps * ck // 8, 4, 2, M).permute(0, 1, 3, 4, 2).contiguous()     # [chunk, q, h, m, j]
         cache = conv._mas_conv_pack = (key, w)
     return cache[1]
 
