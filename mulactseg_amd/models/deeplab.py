@@ -57,13 +57,35 @@ def _bn_act(bn, x, relu=True, residual=None):
     return F.relu(y) if relu else y
 
 
+def _conv_bn_act(conv, bn, x, relu=True, residual=None):
+    """relu?(bn(conv(x)) + residual).  Inference on the GPU: ONE kernel on the f32 matrix cores with the BatchNorm, the
+    residual add and the ReLU in its epilogue (csrc/conv_mfma.hip) -- no separate normalisation pass over the activation.
+    Training (batch statistics, autograd) and unsupported geometries: MIOpen's convolution + the fused BatchNorm kernels."""
+    if x.is_cuda and not bn.training and bn.track_running_stats and not torch.is_grad_enabled():
+        from .. import ops
+        if x.shape[2] * x.shape[3] >= 256 and ops.conv_mfma_supported(conv, x):
+            _took("conv_bn_act", "hip_mfma")
+            return ops.conv_mfma(conv, x, bn, relu, residual)
+    _took("conv_bn_act", "miopen+bn")
+    return _bn_act(bn, conv(x), relu, residual)
+
+
 def _run(seq, x):
-    """nn.Sequential forward with every (BatchNorm2d, ReLU) pair fused; other modules run as they are."""
+    """nn.Sequential forward with every (Conv2d, BatchNorm2d[, ReLU]) triple and (BatchNorm2d, ReLU) pair fused; other
+    modules run as they are."""
     mods = list(seq)
     i = 0
     while i < len(mods):
         m = mods[i]
-        if isinstance(m, nn.BatchNorm2d):
+        if isinstance(m, nn.Conv2d) and i + 1 < len(mods) and isinstance(mods[i + 1], nn.BatchNorm2d):
+            relu = i + 2 < len(mods) and isinstance(mods[i + 2], nn.ReLU)
+            x = _conv_bn_act(m, mods[i + 1], x, relu)
+            i += 3 if relu else 2
+        elif hasattr(m, 'depthwise') and i + 1 < len(mods) and isinstance(mods[i + 1], nn.BatchNorm2d):
+            relu = i + 2 < len(mods) and isinstance(mods[i + 2], nn.ReLU)           # separable: depthwise, then pointwise + BN (+ ReLU) fused
+            x = _conv_bn_act(m.body[1], mods[i + 1], m.depthwise(x), relu)
+            i += 3 if relu else 2
+        elif isinstance(m, nn.BatchNorm2d):
             relu = i + 1 < len(mods) and isinstance(mods[i + 1], nn.ReLU)
             x = _bn_act(m, x, relu)
             i += 2 if relu else 1
@@ -99,11 +121,11 @@ class Bottleneck(nn.Module):
                 _took("conv1x1_bn_act", "hip")
                 y = ops.conv1x1_bn_act(self.conv1, self.bn1, x, True)
         if y is None:
-            y = _bn_act(self.bn1, self.conv1(x))
-        y = _bn_act(self.bn2, self.conv2(y))
+            y = _conv_bn_act(self.conv1, self.bn1, x)
+        y = _conv_bn_act(self.conv2, self.bn2, y)
         if self.downsample is not None:
             x = _run(self.downsample, x)
-        return _bn_act(self.bn3, self.conv3(y), True, x)
+        return _conv_bn_act(self.conv3, self.bn3, y, True, x)
 
 
 class DeepStemResNetTrunk(nn.Module):
@@ -152,7 +174,8 @@ class DeepStemResNetTrunk(nn.Module):
         return nn.Sequential(*mods)
 
     def forward(self, x):
-        x = _bn_act(self.bn1, _run(self.conv1, x))
+        stem = list(self.conv1)
+        x = _conv_bn_act(stem[-1], self.bn1, _run(stem[:-1], x))
         if x.is_cuda:
             from .. import ops
             hip = ops.maxpool3s2_supported(self.maxpool, x)
@@ -178,15 +201,18 @@ class AtrousSeparableConvolution(nn.Module):
             nn.Conv2d(in_channels, in_channels, kernel_size, padding=padding, dilation=dilation, bias=False, groups=in_channels),
             nn.Conv2d(in_channels, out_channels, 1, bias=False))
 
-    def forward(self, x):
+    def depthwise(self, x):
         dw = self.body[0]
         if x.is_cuda and dw.kernel_size == (3, 3) and dw.stride == (1, 1) and dw.padding == dw.dilation and dw.groups == x.shape[1]:
             from .. import ops          # HIP depthwise (csrc/aspp.hip); MIOpen only has a naive fp32 kernel for it
             if ops.depthwise3x3_supported(x, dw.dilation[0]):
                 _took("depthwise3x3", "hip")
-                return self.body[1](ops.depthwise3x3(x, dw.weight, dw.dilation[0]))
+                return ops.depthwise3x3(x, dw.weight, dw.dilation[0])
         _took("depthwise3x3", "miopen")
-        return self.body(x)
+        return dw(x)
+
+    def forward(self, x):
+        return self.body[1](self.depthwise(x))
 
 
 def _conv3x3(cin, cout, dilation, separable):
@@ -249,7 +275,7 @@ class ASPP(nn.Module):
         outs = [_run(self.convs[0], x)]
         for i, y in zip((1, 2, 3), fused):
             branch = self.convs[i]
-            outs.append(_bn_act(branch[1], branch[0].body[1](y)))           # pointwise 1x1 -> BN + ReLU
+            outs.append(_conv_bn_act(branch[0].body[1], branch[1], y))      # pointwise 1x1 -> BN + ReLU
         outs.append(self.convs[4](x))
         return _run(self.project, torch.cat(outs, dim=1))
 
