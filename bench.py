@@ -59,6 +59,7 @@ def parse():
     ap.add_argument("--nbuf", type=int, default=3, help="distinct resident batches rotated through")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-train", action="store_true", help="skip the model legs (train-iter, acquisition with model, stage 2)")
+    ap.add_argument("--no-trainleg", action="store_true", help="skip the train-iter and stage-2 legs but keep the acquisition leg with the model forward")
     ap.add_argument("--no-pool", action="store_true", help="skip the fixed-pool (strong scaling) acquisition round")
     ap.add_argument("--train-steps", type=int, default=8)
     ap.add_argument("--acq-steps", type=int, default=8, help="steps of the secondary model-forward + scan measurement")
@@ -649,10 +650,10 @@ def main():
                              "scan_only": secondary(pool_round_bench, args, dev, rank, world, False),
                              "with_model_forward": None if args.no_train else secondary(pool_round_bench, args, dev, rank, world, True)}
         torch.cuda.empty_cache()
-    out["train_iter"] = None if args.no_train else secondary(train_iter_bench, args, dev, world, args.crop)
-    out["train_iter_769"] = None if args.no_train else secondary(train_iter_bench, args, dev, world, 769)
+    out["train_iter"] = None if (args.no_train or args.no_trainleg) else secondary(train_iter_bench, args, dev, world, args.crop)
+    out["train_iter_769"] = None if (args.no_train or args.no_trainleg) else secondary(train_iter_bench, args, dev, world, 769)
     out["acquisition_with_model"] = None if args.no_train else secondary(acquisition_with_model_bench, args, dev, world)
-    out["stage2"] = None if (args.no_train or rank != 0) else secondary(stage2_bench, args, dev)
+    out["stage2"] = None if (args.no_train or args.no_trainleg or rank != 0) else secondary(stage2_bench, args, dev)
     if rank == 0:
         out["cpu_baseline"] = secondary(cpu_baseline, args, dev, cpu_bufs, backend) if cpu_bufs is not None else None
         print(json.dumps(out), flush=True)
