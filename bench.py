@@ -276,6 +276,30 @@ def train_iter_bench(args, dev, world, crop):
     loss_ms = (time.perf_counter() - t0) / 20 * 1e3
     loss_bytes = N * C * crop * crop * 4 * 3 + N * crop * crop * 9 * 2      # fwd read z, bwd read z + write dz, ids+mask twice
 
+    # the production form: quarter-resolution logits in, the x4 bilinear upsampling evaluated inside the scans (no [N,C,H,W]
+    # logit / gradient tensors); compared with upsample + loss + both backwards of the materialised path
+    from mulactseg_amd import ops
+    q = ((crop - 1) // 2) // 2 + 1
+    zq = (0.35 * torch.randn((N, C, q, q), generator=g, device=dev)).requires_grad_(True)
+
+    def lowres_step(logits_q):
+        group, ce, mc = crit.forward_lowres(logits_q, (crop, crop), tgt, spx, msk)
+        return 16.0 * ce + 8.0 * mc + 1.0 * group
+
+    def timed_loss(fn, leaf, n=20):
+        for _ in range(3):
+            leaf.grad = None
+            fn().backward()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(n):
+            leaf.grad = None
+            fn().backward()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / n * 1e3
+    low_ms = timed_loss(lambda: lowres_step(zq), zq)
+    mat_ms = timed_loss(lambda: loss_step(ops.upsample_bilinear(zq, (crop, crop))), zq)
+
     net = get_model('deeplabv3pluswn_resnet50deepstem', C, 16, True, pretrained_backbone=False).to(dev).train()
     opt = torch.optim.AdamW([{'params': net.backbone.parameters(), 'lr': 2e-5},
                              {'params': net.classifier.parameters(), 'lr': 2e-4}], lr=2e-5, weight_decay=1e-5, fused=True)
@@ -285,7 +309,7 @@ def train_iter_bench(args, dev, world, crop):
 
     def full_step():
         opt.zero_grad(set_to_none=True)
-        (loss_step(net(images)) * world).backward()
+        (lowres_step(net(images, lowres=True)) * world).backward()          # as the production trainer's train_impl does
         opt.step()
 
     for _ in range(2):
@@ -306,7 +330,11 @@ def train_iter_bench(args, dev, world, crop):
                        "selected_fraction": float(msk.float().mean())},
             "layer_paths_per_step": paths,
             "loss_only": {"ms_fwd_bwd": loss_ms, "algorithmic_GBs": loss_bytes / (loss_ms * 1e-3) / 1e9,
-                          "bytes": loss_bytes, "note": "includes the small launches around the two scans and the autograd glue"}}
+                          "bytes": loss_bytes, "note": "full-resolution logits as the leaf; includes the small launches around the two scans "
+                                                       "and the autograd glue"},
+            "loss_from_quarter_logits": {"ms_fwd_bwd_fused": low_ms, "ms_fwd_bwd_upsample_then_loss": mat_ms, "quarter_logits": [N, C, q, q],
+                                         "note": "leaf = the model's quarter-resolution logits: fused = bilinear x4 evaluated inside both scans "
+                                                 "(train_iter uses this); the other = upsample kernel + loss scans + dz + upsample backward"}}
 
 
 def acquisition_with_model_bench(args, dev, world):

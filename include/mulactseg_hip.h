@@ -143,6 +143,24 @@ int mas_partial_loss_bwd(const float* z, const void* spx, int spx_dtype, const u
                          const uint64_t* gmax, const float* scale /* [3] */,
                          int N, int C, int H, int W, int S, float invT, int flags, float* dz, void* stream);
 
+/* Quarter-resolution forms of the two scans.  The model emits cosine logits zq [N,C,h,w] and upsamples them x4 bilinearly to
+ * the crop (models/segmentation/utils.py:25, F.interpolate(..., mode='bilinear', align_corners=False)) before the losses read
+ * them.  These entry points take zq and evaluate that interpolation per selected pixel (operation order of
+ * mas_upsample_bilinear_fwd), so the forward sums / gmax equal those of mas_partial_loss_fwd on the materialised tensor bit
+ * for bit, and neither the [N,C,H,W] logits nor their gradient ever exist in memory.
+ * Backward: dzq_fix [N,C,h,w] int64, caller-zeroed; every selected pixel adds round_to_nearest_even(d * ly * lx * 2^44) for
+ * each of the four elements its class-c logit was interpolated from (integer atomics: order-independent, run-to-run
+ * identical); mas_fix_to_float(dzq_fix, n, 44, dzq) then yields the f32 gradient of zq. */
+int mas_partial_loss_fwd_lowres(const float* zq, int h, int w, const void* spx, int spx_dtype, const uint8_t* mask,
+                                const uint32_t* bits, int N, int C, int H, int W, int S, float invT, int flags,
+                                uint64_t* gmax /* [N,S,C] */, uint64_t* acc /* [8] */, void* stream);
+int mas_partial_loss_bwd_lowres(const float* zq, int h, int w, const void* spx, int spx_dtype, const uint8_t* mask,
+                                const uint32_t* bits, const uint64_t* gmax, const float* scale /* [3] */, int N, int C, int H, int W,
+                                int S, float invT, int flags, int64_t* dzq_fix /* [N,C,h,w] */, void* stream);
+#define MAS_GRAD_FRAC_BITS 44
+/* out[i] = (float)(fix[i] * 2^-frac_bits) */
+int mas_fix_to_float(const int64_t* fix, int64_t n, int frac_bits, float* out, void* stream);
+
 /* =============================================================================================
  * K4  ordering of the region scores and the budgeted selection walk
  * ============================================================================================= */

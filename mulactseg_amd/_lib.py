@@ -14,6 +14,7 @@ MAX_CLASSES = 32
 SCORE_FRAC, PROB_FRAC, LOSS_FRAC = 40, 23, 32
 LOSS_CE, LOSS_GROUP, LOSS_GROUP_ONLY_MULTI, LOSS_DECOMP = 1, 2, 4, 8
 ACC_WORDS = 8
+GRAD_FRAC = 44
 
 _c = ctypes
 _vp, _i, _f, _i64, _d = _c.c_void_p, _c.c_int, _c.c_float, _c.c_int64, _c.c_double
@@ -68,6 +69,9 @@ SIGNATURES = {
     "mas_loss_values": (_i, [_vp, _i, _vp, _vp]),
     "mas_loss_scales": (_i, [_vp, _vp, _i, _vp, _vp]),
     "mas_partial_loss_bwd": (_i, [_vp, _vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _i, _vp, _vp]),
+    "mas_partial_loss_fwd_lowres": (_i, [_vp, _i, _i, _vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _f, _i, _vp, _vp, _vp]),
+    "mas_partial_loss_bwd_lowres": (_i, [_vp, _i, _i, _vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _i, _vp, _vp]),
+    "mas_fix_to_float": (_i, [_vp, _i64, _i, _vp, _vp]),
 }
 
 _lib = None

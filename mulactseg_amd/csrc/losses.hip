@@ -55,6 +55,58 @@ __global__ __launch_bounds__(kThreads) void k_target_bits(const unsigned char* _
     bits[r] = b;
 }
 
+
+// ---- logits of one pixel -------------------------------------------------------------------------------------------
+// LOWRES: the kernels read the model's quarter-resolution logits zq [C,h,w] and evaluate the final
+// F.interpolate(bilinear, align_corners=False) of models/segmentation/utils.py:25 for the pixel in registers -- the
+// arithmetic of csrc/upsample.hip (ATen's area_pixel_compute_source_index), so the values equal those of the materialised
+// full-resolution tensor bit for bit; that tensor (189 MB per training batch) is then never written or read.
+struct LTap { int i0, i1; float l0, l1; };
+
+__device__ __forceinline__ LTap loss_tap(float scale, int o, int n_in) {
+    float s = scale * ((float)o + 0.5f) - 0.5f;
+    s = s < 0.0f ? 0.0f : s;
+    LTap t;
+    t.i0 = (int)s;
+    t.i1 = t.i0 + (t.i0 < n_in - 1 ? 1 : 0);
+    t.l1 = s - (float)t.i0;
+    t.l0 = 1.0f - t.l1;
+    return t;
+}
+
+struct LowRes { int h, w; float sh, sw; };
+
+template <int CT, bool EXACT, bool LOWRES>
+__device__ __forceinline__ void load_logits(const float* __restrict__ zb, int C, int HW, size_t pix, int y, int x, const LowRes& lr,
+                                            float (&v)[CT], LTap& ty, LTap& tx) {
+    if (LOWRES) {
+        ty = loss_tap(lr.sh, y, lr.h);
+        tx = loss_tap(lr.sw, x, lr.w);
+        const int hw = lr.h * lr.w;
+        const int o00 = ty.i0 * lr.w + tx.i0, o01 = ty.i0 * lr.w + tx.i1, o10 = ty.i1 * lr.w + tx.i0, o11 = ty.i1 * lr.w + tx.i1;
+#pragma unroll
+        for (int c = 0; c < CT; ++c) {
+            if (EXACT || c < C) {
+                const float* q = zb + (size_t)c * hw;
+                v[c] = ty.l0 * (tx.l0 * q[o00] + tx.l1 * q[o01]) + ty.l1 * (tx.l0 * q[o10] + tx.l1 * q[o11]);
+            } else {
+                v[c] = 0.f;
+            }
+        }
+    } else {
+#pragma unroll
+        for (int c = 0; c < CT; ++c) v[c] = (EXACT || c < C) ? zb[(size_t)c * HW + pix] : 0.f;
+    }
+}
+
+// signed fixed point (44 fractional bits) of one gradient contribution, round to nearest even; mirrored by oracle/exact.c
+#define MAS_GRAD_FRAC 44
+__device__ __forceinline__ long long grad_fix(float t) {
+    union { double d; mas_u64 u; } s;
+    s.u = (mas_u64)(1023 + MAS_GRAD_FRAC) << 52;
+    return __double2ll_rn((double)t * s.d);
+}
+
 // Selected pixels are sparse (a few % of a crop, whole superpixels at a time).  Both scans therefore run in two phases
 // per 16x256 tile: (1) every lane looks at the mask bytes of its pixels and the selected ones are COMPACTED into an LDS
 // queue (wave ballot + one LDS counter add per wave); (2) the queue is processed densely, one selected pixel per lane, so
@@ -114,12 +166,12 @@ __device__ __forceinline__ void tile_compact(const unsigned char* __restrict__ m
     }
 }
 
-template <int CT, bool EXACT, typename IdT, bool VEC>
+template <int CT, bool EXACT, typename IdT, bool VEC, bool LOWRES>
 __global__ __launch_bounds__(kThreads) void k_partial_loss_fwd(const float* __restrict__ z, const IdT* __restrict__ spx,
                                                                 const unsigned char* __restrict__ mask,
                                                                 const unsigned* __restrict__ bits, int C, int H, int W, int S,
                                                                 float invT, int flags, int tiles_x, int tiles_y,
-                                                                mas_u64* __restrict__ gmax, mas_u64* __restrict__ acc) {
+                                                                mas_u64* __restrict__ gmax, mas_u64* __restrict__ acc, const LowRes lr) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     mas_u64* t_max = reinterpret_cast<mas_u64*>(smem);                       // [kSlots * C]
     int* t_keys = reinterpret_cast<int*>(smem + sizeof(mas_u64) * kSlots * C);  // [kSlots]
@@ -142,7 +194,7 @@ __global__ __launch_bounds__(kThreads) void k_partial_loss_fwd(const float* __re
     const int ty = bid % tiles_y;
     const int n = bid / tiles_y;
     const int HW = H * W;
-    const float* zb = z + (size_t)n * C * HW;
+    const float* zb = z + (size_t)n * C * (LOWRES ? lr.h * lr.w : HW);
     const IdT* sb = spx + (size_t)n * HW;
     const unsigned char* mb = mask + (size_t)n * HW;
     const unsigned* bb = bits + (size_t)n * S;
@@ -158,12 +210,13 @@ __global__ __launch_bounds__(kThreads) void k_partial_loss_fwd(const float* __re
     unsigned n_ce = 0, n_mc = 0, n_empty = 0;
     for (int i = threadIdx.x; i < nq; i += kThreads) {
         const unsigned off = queue[i];
-        const size_t pix = (size_t)(ty * kTileH + (int)(off >> 8)) * W + (tx * kTileW + (int)(off & 255u));
+        const int py = ty * kTileH + (int)(off >> 8), px = tx * kTileW + (int)(off & 255u);
+        const size_t pix = (size_t)py * W + px;
         const int id = mas_load_id(sb, pix);
         if (id < 0 || id >= S) continue;
         float v[CT];
-#pragma unroll
-        for (int c = 0; c < CT; ++c) v[c] = (EXACT || c < C) ? zb[(size_t)c * HW + pix] : 0.f;
+        LTap t_y, t_x;
+        load_logits<CT, EXACT, LOWRES>(zb, C, HW, pix, py, px, lr, v, t_y, t_x);
         const unsigned Y = bb[id];
         const int nb = __popc(Y);
         if (nb == 0) { n_empty += 1; continue; }
@@ -281,14 +334,18 @@ __global__ void k_loss_scales(const mas_u64* __restrict__ acc, const float* __re
     scale[2] = grad_out[2] / (float)(acc[ACC_N_GROUP] + 1);
 }
 
-template <int CT, bool EXACT, typename IdT, bool VEC>
+// LOWRES: `dz` is the caller-zeroed int64 fixed-point accumulator dzq_fix [N,C,h,w] (MAS_GRAD_FRAC fractional bits): every
+// selected pixel adds (gradient of its class-c logit) * (bilinear weight) into the four quarter-resolution elements its
+// logits were interpolated from -- integer atomics, so the sums do not depend on the order; nothing is written at full
+// resolution.
+template <int CT, bool EXACT, typename IdT, bool VEC, bool LOWRES>
 __global__ __launch_bounds__(kThreads) void k_partial_loss_bwd(const float* __restrict__ z, const IdT* __restrict__ spx,
                                                                 const unsigned char* __restrict__ mask,
                                                                 const unsigned* __restrict__ bits,
                                                                 const mas_u64* __restrict__ gmax,
                                                                 const float* __restrict__ scale, int C, int H, int W, int S,
                                                                 float invT, int flags, int tiles_x, int tiles_y,
-                                                                float* __restrict__ dz) {
+                                                                float* __restrict__ dz, const LowRes lr) {
     __shared__ int qcount[2];
     __shared__ unsigned short queue[kTilePx];
     const bool do_ce = flags & MAS_LOSS_CE;
@@ -301,8 +358,10 @@ __global__ __launch_bounds__(kThreads) void k_partial_loss_bwd(const float* __re
     const int ty = bid % tiles_y;
     const int n = bid / tiles_y;
     const int HW = H * W;
-    const float* zb = z + (size_t)n * C * HW;
-    float* db = dz + (size_t)n * C * HW;
+    const int hw_in = LOWRES ? lr.h * lr.w : HW;
+    const float* zb = z + (size_t)n * C * hw_in;
+    float* db = LOWRES ? nullptr : dz + (size_t)n * C * HW;
+    mas_u64* qb = LOWRES ? reinterpret_cast<mas_u64*>(dz) + (size_t)n * C * hw_in : nullptr;
     const IdT* sb = spx + (size_t)n * HW;
     const unsigned char* mb = mask + (size_t)n * HW;
     const unsigned* bb = bits + (size_t)n * S;
@@ -310,22 +369,23 @@ __global__ __launch_bounds__(kThreads) void k_partial_loss_bwd(const float* __re
     const float a_ce = scale[0] * invT, a_mc = scale[1] * invT, g6 = scale[2] * invT;
 
     // phase 1: dz = 0 over the whole tile (streaming 16-B stores) while the selected pixels are compacted
-    tile_compact<CT, EXACT, VEC, true>(mb, C, H, W, HW, tx, ty, queue, qcount, db);
+    tile_compact<CT, EXACT, VEC, !LOWRES>(mb, C, H, W, HW, tx, ty, queue, qcount, db);
     __syncthreads();        // (waits for this workgroup's zero stores: the gradients below overwrite some of them)
     const int nq = qcount[0];
 
     // phase 2: gradients of the selected pixels, one pixel per lane
     for (int i = threadIdx.x; i < nq; i += kThreads) {
         const unsigned off = queue[i];
-        const size_t pix = (size_t)(ty * kTileH + (int)(off >> 8)) * W + (tx * kTileW + (int)(off & 255u));
+        const int py = ty * kTileH + (int)(off >> 8), px = tx * kTileW + (int)(off & 255u);
+        const size_t pix = (size_t)py * W + px;
         const int id = mas_load_id(sb, pix);
         if (id < 0 || id >= S) continue;
         const unsigned Y = bb[id];
         const int nb = __popc(Y);
         if (nb == 0) continue;
         float v[CT];
-#pragma unroll
-        for (int c = 0; c < CT; ++c) v[c] = (EXACT || c < C) ? zb[(size_t)c * HW + pix] : 0.f;
+        LTap t_y, t_x;
+        load_logits<CT, EXACT, LOWRES>(zb, C, HW, pix, py, px, lr, v, t_y, t_x);
         {
             const float rinv = mas_softmax_regs<CT, EXACT>(v, C, invT);
 #pragma unroll
@@ -368,7 +428,15 @@ __global__ __launch_bounds__(kThreads) void k_partial_loss_bwd(const float* __re
                     if ((A >> c) & 1u) d = d + t[c] * p;
                     d = d - p * u;
                 }
-                db[(size_t)c * HW + pix] = d;
+                if (LOWRES) {
+                    mas_u64* q = qb + (size_t)c * hw_in;
+                    atomicAdd(q + (t_y.i0 * lr.w + t_x.i0), (mas_u64)grad_fix(d * (t_y.l0 * t_x.l0)));
+                    atomicAdd(q + (t_y.i0 * lr.w + t_x.i1), (mas_u64)grad_fix(d * (t_y.l0 * t_x.l1)));
+                    atomicAdd(q + (t_y.i1 * lr.w + t_x.i0), (mas_u64)grad_fix(d * (t_y.l1 * t_x.l0)));
+                    atomicAdd(q + (t_y.i1 * lr.w + t_x.i1), (mas_u64)grad_fix(d * (t_y.l1 * t_x.l1)));
+                } else {
+                    db[(size_t)c * HW + pix] = d;
+                }
             }
         }
     }
@@ -383,6 +451,7 @@ struct LossArgs {
     const float* z; const void* spx; const unsigned char* mask; const unsigned* bits;
     int N, C, H, W, S; float invT; int flags;
     mas_u64* gmax; mas_u64* acc; const float* scale; float* dz;
+    int h = 0, w = 0;           // > 0: `z` is the quarter-resolution tensor [N,C,h,w] (LOWRES kernels)
 };
 
 template <int CT, bool EXACT, typename IdT>
@@ -392,24 +461,22 @@ int launch_loss(const LossArgs& a, bool backward, hipStream_t st) {
     const long long nblk = (long long)a.N * tiles_x * tiles_y;
     if (nblk <= 0 || nblk > 0x7fffffffLL) return MAS_ERR_SHAPE;
     const IdT* ids = static_cast<const IdT*>(a.spx);
-    const bool vec = (a.W % 4 == 0) && (((uintptr_t)a.z & 15) == 0) && (!backward || (((uintptr_t)a.dz & 15) == 0));
+    const bool low = a.h > 0;
+    const bool vec = (a.W % 4 == 0) && (low || ((((uintptr_t)a.z & 15) == 0) && (!backward || (((uintptr_t)a.dz & 15) == 0))));
     const dim3 grid((unsigned)nblk), block(kThreads);
-    if (!backward) {
-        const size_t smem = fwd_smem_bytes(a.C);
-        if (vec)
-            hipLaunchKernelGGL((k_partial_loss_fwd<CT, EXACT, IdT, true>), grid, block, smem, st, a.z, ids, a.mask, a.bits, a.C, a.H,
-                               a.W, a.S, a.invT, a.flags, tiles_x, tiles_y, a.gmax, a.acc);
-        else
-            hipLaunchKernelGGL((k_partial_loss_fwd<CT, EXACT, IdT, false>), grid, block, smem, st, a.z, ids, a.mask, a.bits, a.C, a.H,
-                               a.W, a.S, a.invT, a.flags, tiles_x, tiles_y, a.gmax, a.acc);
-    } else {
-        if (vec)
-            hipLaunchKernelGGL((k_partial_loss_bwd<CT, EXACT, IdT, true>), grid, block, 0, st, a.z, ids, a.mask, a.bits, a.gmax, a.scale,
-                               a.C, a.H, a.W, a.S, a.invT, a.flags, tiles_x, tiles_y, a.dz);
-        else
-            hipLaunchKernelGGL((k_partial_loss_bwd<CT, EXACT, IdT, false>), grid, block, 0, st, a.z, ids, a.mask, a.bits, a.gmax, a.scale,
-                               a.C, a.H, a.W, a.S, a.invT, a.flags, tiles_x, tiles_y, a.dz);
-    }
+    const LowRes lr{a.h, a.w, low ? (float)a.h / (float)a.H : 0.f, low ? (float)a.w / (float)a.W : 0.f};
+#define MAS_LAUNCH_LOSS(VECV, LOWV)                                                                                                     \
+    do {                                                                                                                                \
+        if (!backward)                                                                                                                  \
+            hipLaunchKernelGGL((k_partial_loss_fwd<CT, EXACT, IdT, VECV, LOWV>), grid, block, fwd_smem_bytes(a.C), st, a.z, ids, a.mask, \
+                               a.bits, a.C, a.H, a.W, a.S, a.invT, a.flags, tiles_x, tiles_y, a.gmax, a.acc, lr);                        \
+        else                                                                                                                            \
+            hipLaunchKernelGGL((k_partial_loss_bwd<CT, EXACT, IdT, VECV, LOWV>), grid, block, 0, st, a.z, ids, a.mask, a.bits, a.gmax,   \
+                               a.scale, a.C, a.H, a.W, a.S, a.invT, a.flags, tiles_x, tiles_y, a.dz, lr);                                \
+    } while (0)
+    if (low) { if (vec) MAS_LAUNCH_LOSS(true, true); else MAS_LAUNCH_LOSS(false, true); }
+    else { if (vec) MAS_LAUNCH_LOSS(true, false); else MAS_LAUNCH_LOSS(false, false); }
+#undef MAS_LAUNCH_LOSS
     return mas_launch_status();
 }
 
@@ -489,4 +556,46 @@ extern "C" int mas_partial_loss_bwd(const float* z, const void* spx, int spx_dty
     LossArgs a{z, spx, mask, bits, N, C, H, W, S, invT, flags,
                const_cast<mas_u64*>(reinterpret_cast<const mas_u64*>(gmax)), nullptr, scale, dz};
     return dispatch_loss(a, spx_dtype, true, static_cast<hipStream_t>(stream));
+}
+
+// ---- quarter-resolution forms: the x4 bilinear upsampling of the logits (models/segmentation/utils.py:25) is evaluated per
+// selected pixel inside the scans; forward results are bit-identical to mas_partial_loss_fwd on the materialised tensor.
+extern "C" int mas_partial_loss_fwd_lowres(const float* zq, int h, int w, const void* spx, int spx_dtype, const uint8_t* mask,
+                                           const uint32_t* bits, int N, int C, int H, int W, int S, float invT, int flags,
+                                           uint64_t* gmax, uint64_t* acc, void* stream) {
+    if (!zq || !spx || !mask || !bits || !acc) return MAS_ERR_NULL;
+    if ((flags & MAS_LOSS_GROUP) && !gmax) return MAS_ERR_NULL;
+    if (h <= 0 || w <= 0 || h > H || w > W) return MAS_ERR_SHAPE;
+    LossArgs a{zq, spx, mask, bits, N, C, H, W, S, invT, flags, reinterpret_cast<mas_u64*>(gmax),
+               reinterpret_cast<mas_u64*>(acc), nullptr, nullptr, h, w};
+    return dispatch_loss(a, spx_dtype, false, static_cast<hipStream_t>(stream));
+}
+
+extern "C" int mas_partial_loss_bwd_lowres(const float* zq, int h, int w, const void* spx, int spx_dtype, const uint8_t* mask,
+                                           const uint32_t* bits, const uint64_t* gmax, const float* scale, int N, int C, int H, int W,
+                                           int S, float invT, int flags, int64_t* dzq_fix, void* stream) {
+    if (!zq || !spx || !mask || !bits || !scale || !dzq_fix) return MAS_ERR_NULL;
+    if ((flags & MAS_LOSS_GROUP) && !gmax) return MAS_ERR_NULL;
+    if (h <= 0 || w <= 0 || h > H || w > W) return MAS_ERR_SHAPE;
+    LossArgs a{zq, spx, mask, bits, N, C, H, W, S, invT, flags, const_cast<mas_u64*>(reinterpret_cast<const mas_u64*>(gmax)), nullptr,
+               scale, reinterpret_cast<float*>(dzq_fix), h, w};
+    return dispatch_loss(a, spx_dtype, true, static_cast<hipStream_t>(stream));
+}
+
+namespace {
+__global__ __launch_bounds__(kThreads) void k_fix_to_float(const long long* __restrict__ fix, long long n, int frac, float* __restrict__ out) {
+    const long long i = (long long)blockIdx.x * kThreads + threadIdx.x;
+    if (i >= n) return;
+    union { double d; mas_u64 u; } s;
+    s.u = (mas_u64)(1023 - frac) << 52;
+    out[i] = (float)((double)fix[i] * s.d);
+}
+}  // namespace
+
+extern "C" int mas_fix_to_float(const int64_t* fix, int64_t n, int frac_bits, float* out, void* stream) {
+    if (!fix || !out) return MAS_ERR_NULL;
+    if (n <= 0 || frac_bits < 0 || frac_bits > 62) return MAS_ERR_SHAPE;
+    hipLaunchKernelGGL(k_fix_to_float, dim3((unsigned)((n + kThreads - 1) / kThreads)), dim3(kThreads), 0, static_cast<hipStream_t>(stream),
+                       reinterpret_cast<const long long*>(fix), (long long)n, frac_bits, out);
+    return mas_launch_status();
 }

@@ -341,9 +341,13 @@ class DeepLabV3PlusWN(nn.Module):
         finally:
             self.classifier.return_feat = keep
 
-    def forward(self, x):
+    def forward(self, x, lowres=False):
+        """Logits at the input size (``utils.py:25``).  ``lowres=True`` returns the quarter-resolution cosine logits the final
+        bilinear upsampling starts from -- for consumers that evaluate it themselves (``FusedPartialLabelLoss.forward_lowres``)."""
         size = x.shape[-2:]
         y = self.classifier(self.backbone(x))
+        if lowres:
+            return y[1] if isinstance(y, tuple) else y
         return _upsample(y, size)
 
     def feat_forward_lowres(self, x):

@@ -170,6 +170,60 @@ def partial_loss_bwd(z, spx, mask, bits, gmax, acc, grad_out, invT, flags):
 # ------------------------------------------------------------------------------------------------
 # K4: ordering + budgeted selection walk
 # ------------------------------------------------------------------------------------------------
+def partial_loss_fwd_lowres(zq, size, spx, mask, bits, invT, flags, reduce_acc=None):
+    """As ``partial_loss_fwd`` for the logits ``F.interpolate(zq, size, 'bilinear', align_corners=False)`` without
+    materialising them: ``zq`` [N,C,h,w] quarter-resolution logits, ``size`` = (H, W) of ids / masks."""
+    _need(zq, "inputs", torch.float32)
+    _need(spx, "superpixels")
+    mask = _mask_u8(mask)
+    _need(bits, "bits", torch.int32)
+    N, C, h, w = zq.shape
+    H, W = int(size[0]), int(size[1])
+    S = bits.shape[1]
+    if tuple(spx.shape) != (N, H, W) or tuple(mask.shape) != (N, H, W) or bits.shape[0] != N:
+        raise ValueError("shape mismatch between inputs %s at size %s, superpixels %s, spmasks %s, targets %s"
+                         % (tuple(zq.shape), (H, W), tuple(spx.shape), tuple(mask.shape), tuple(bits.shape)))
+    dev = zq.device
+    acc = torch.zeros(_lib.ACC_WORDS, dtype=torch.int64, device=dev)
+    gmax = torch.zeros((N, S, C), dtype=torch.int64, device=dev) if flags & _lib.LOSS_GROUP else None
+    losses = torch.empty(3, dtype=torch.float32, device=dev)
+    lib = _lib.load()
+    with torch.cuda.device(dev):
+        st = _stream(zq)
+        _lib.check(lib.mas_partial_loss_fwd_lowres(zq.data_ptr(), h, w, spx.data_ptr(), _id_code(spx), mask.data_ptr(), bits.data_ptr(),
+                                                   N, C, H, W, S, invT, flags, gmax.data_ptr() if gmax is not None else None,
+                                                   acc.data_ptr(), st), "mas_partial_loss_fwd_lowres")
+        if gmax is not None:
+            _lib.check(lib.mas_group_finalize(gmax.data_ptr(), gmax.numel(), acc.data_ptr(), st), "mas_group_finalize")
+        if reduce_acc is not None:
+            reduce_acc(acc)
+        _lib.check(lib.mas_loss_values(acc.data_ptr(), flags, losses.data_ptr(), st), "mas_loss_values")
+    return losses, acc, gmax
+
+
+def partial_loss_bwd_lowres(zq, size, spx, mask, bits, gmax, acc, grad_out, invT, flags, want_fix=False):
+    """Gradient of the losses with respect to the quarter-resolution logits: dzq [N,C,h,w] f32 (and the int64 fixed-point
+    sums it was rounded from when ``want_fix``)."""
+    mask = _mask_u8(mask)
+    _need(grad_out, "grad_out", torch.float32)
+    N, C, h, w = zq.shape
+    H, W = int(size[0]), int(size[1])
+    S = bits.shape[1]
+    dev = zq.device
+    scale = torch.empty(3, dtype=torch.float32, device=dev)
+    fix = torch.zeros((N, C, h, w), dtype=torch.int64, device=dev)
+    dzq = torch.empty_like(zq)
+    lib = _lib.load()
+    with torch.cuda.device(dev):
+        st = _stream(zq)
+        _lib.check(lib.mas_loss_scales(acc.data_ptr(), grad_out.data_ptr(), flags, scale.data_ptr(), st), "mas_loss_scales")
+        _lib.check(lib.mas_partial_loss_bwd_lowres(zq.data_ptr(), h, w, spx.data_ptr(), _id_code(spx), mask.data_ptr(), bits.data_ptr(),
+                                                   gmax.data_ptr() if gmax is not None else None, scale.data_ptr(), N, C, H, W, S,
+                                                   invT, flags, fix.data_ptr(), st), "mas_partial_loss_bwd_lowres")
+        _lib.check(lib.mas_fix_to_float(fix.data_ptr(), fix.numel(), _lib.GRAD_FRAC, dzq.data_ptr(), st), "mas_fix_to_float")
+    return (dzq, fix) if want_fix else dzq
+
+
 def path_ranks(paths):
     """Rank of every image's joined path string in ascending (Python ``str``) order -- the tie-break
     the reference's tuple sort applies after the score (``active_selection/base.py:37``).

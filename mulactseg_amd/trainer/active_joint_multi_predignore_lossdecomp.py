@@ -5,7 +5,8 @@
 
 The three losses come from ONE forward scan and ONE backward scan of the logits
 (``utils.loss.FusedPartialLabelLoss`` over ``csrc/losses.hip``) instead of two modules that each
-re-compute the softmax.  Under data parallelism the normalisers ``1 + n`` are global over the batch
+re-compute the softmax; by default (``args.lowres_loss``, True) the scans take the model's quarter-resolution logits and
+evaluate the final x4 bilinear upsampling (``models/segmentation/utils.py:25``) per selected pixel.  Under data parallelism the normalisers ``1 + n`` are global over the batch
 (SURVEY.md section 5.8): the fixed-point sums and counts are all-reduced before the division so that
 N GPUs x batch 4 optimise exactly the single-GPU objective of batch 4N.
 """
@@ -38,8 +39,13 @@ class ActiveTrainer(active_joint_multi_predignore.ActiveTrainer):
         for iteration in range(total_itrs):
             images, labels, superpixels, spmasks = self._batch()
             self.optimizer.zero_grad()
-            preds = self.forward_train(images)
-            group_loss, ce_loss, mc_loss = self.losses(preds, labels, superpixels, spmasks)
+            if self.fused_loss is not None and getattr(a, 'lowres_loss', True) and images.is_cuda:
+                # quarter-resolution logits in, upsampling inside the loss scans (no [N,C,H,W] logit / gradient tensors)
+                preds_q = self.forward_train(images, lowres=True)
+                group_loss, ce_loss, mc_loss = self.fused_loss.forward_lowres(preds_q, images.shape[-2:], labels, superpixels, spmasks)
+            else:
+                preds = self.forward_train(images)
+                group_loss, ce_loss, mc_loss = self.losses(preds, labels, superpixels, spmasks)
             loss = (a.coeff * ce_loss) + (a.coeff_mc * mc_loss) + (a.coeff_gm * group_loss)
             self.update(loss)
             self.update_average_meter({'train-loss': loss, 'ce-loss': ce_loss, 'pos-loss': mc_loss, 'group-loss': group_loss})

@@ -136,8 +136,8 @@ class BaseTrainer(object):
     def train_impl(self, total_itrs, val_period):
         raise NotImplementedError
 
-    def forward_train(self, images):
-        return (self.ddp or self.net)(images)
+    def forward_train(self, images, **kw):
+        return (self.ddp or self.net)(images, **kw)
 
     # -- evaluation ---------------------------------------------------------------------------------
     def inference(self, loader, prefix=''):

@@ -51,6 +51,32 @@ class _PartialLossFn(torch.autograd.Function):
         return dz, None, None, None, None, None, None
 
 
+class _PartialLossLowResFn(torch.autograd.Function):
+    """(ce, mc, group) = f(zq) with the x4 bilinear upsampling of the logits evaluated inside both scans: the
+    full-resolution logits and their gradient never exist (``csrc/losses.hip`` LOWRES kernels).  Forward values are
+    bit-identical to ``_PartialLossFn`` on ``F.interpolate(zq, size, 'bilinear')``; the gradient of ``zq`` is an
+    order-independent fixed-point sum (run-to-run identical)."""
+
+    @staticmethod
+    def forward(ctx, zq, size, bits, superpixels, spmasks, invT, flags, sync):
+        zq = zq.contiguous()
+        spx = superpixels.contiguous()
+        msk = spmasks.contiguous()
+        losses, acc, gmax = ops.partial_loss_fwd_lowres(zq, size, spx, msk, bits, invT, flags, _all_reduce_sum if sync else None)
+        ctx.save_for_backward(zq, spx, msk, bits, acc, gmax if gmax is not None else acc)
+        ctx.has_gmax = gmax is not None
+        ctx.invT, ctx.flags, ctx.size = invT, flags, (int(size[0]), int(size[1]))
+        ctx.mark_non_differentiable(acc)
+        return losses[0], losses[1], losses[2], acc
+
+    @staticmethod
+    def backward(ctx, g_ce, g_mc, g_group, _g_acc):
+        zq, spx, msk, bits, acc, gmax = ctx.saved_tensors
+        grad_out = torch.stack([g_ce, g_mc, g_group]).to(torch.float32).contiguous()
+        dzq = ops.partial_loss_bwd_lowres(zq, ctx.size, spx, msk, bits, gmax if ctx.has_gmax else None, acc, grad_out, ctx.invT, ctx.flags)
+        return dzq, None, None, None, None, None, None, None
+
+
 def _all_reduce_sum(acc):
     """Sum the fixed-point loss sums and pixel counts over the data-parallel ranks (RCCL all-reduce of 8
     int64 words): integer addition, so the result does not depend on the number of GPUs."""
@@ -192,4 +218,14 @@ class FusedPartialLabelLoss(nn.Module):
     def forward(self, inputs, targets, superpixels, spmasks):
         ce, mc, group, self.last_acc = _run(inputs, targets, superpixels, spmasks, self.temp, self.flags, False,
                                             sync=self.sync_normalisers)
+        return group, ce, mc
+
+    def forward_lowres(self, quarter_logits, size, targets, superpixels, spmasks):
+        """The same three losses from the model's quarter-resolution logits (``net(images, lowres=True)``): the final x4
+        bilinear upsampling (``models/segmentation/utils.py:25``) happens per selected pixel inside the scans."""
+        if targets.dtype != torch.uint8:
+            targets = targets.to(torch.uint8)
+        bits = ops.target_bits(targets.contiguous(), targets.shape[-1])
+        ce, mc, group, self.last_acc = _PartialLossLowResFn.apply(quarter_logits, tuple(size), bits, superpixels, spmasks,
+                                                                  ops.inv_temperature(self.temp), self.flags, self.sync_normalisers)
         return group, ce, mc

@@ -307,6 +307,79 @@ void exact_partial_loss_bwd(const float* z, const int64_t* spx, const uint8_t* m
         }
 }
 
+/* F.interpolate(x, size=(Ho, Wo), mode='bilinear', align_corners=False) of models/segmentation/utils.py:25, in the
+ * operation order of csrc/upsample.hip (ATen's area_pixel_compute_source_index; every product and sum rounded once). */
+static void bilinear_tap(float scale, int o, int n_in, int* i0, int* i1, float* l0, float* l1) {
+    float s = scale * ((float)o + 0.5f) - 0.5f;
+    s = s < 0.0f ? 0.0f : s;
+    *i0 = (int)s;
+    *i1 = *i0 + (*i0 < n_in - 1 ? 1 : 0);
+    *l1 = s - (float)*i0;
+    *l0 = 1.0f - *l1;
+}
+
+void exact_upsample_bilinear(const float* x, int64_t NC, int Hi, int Wi, int Ho, int Wo, float* y) {
+    const float sh = (float)Hi / (float)Ho, sw = (float)Wi / (float)Wo;
+    int64_t nc;
+    int oy, ox;
+    for (nc = 0; nc < NC; ++nc)
+        for (oy = 0; oy < Ho; ++oy) {
+            int y0, y1;
+            float ly0, ly1;
+            bilinear_tap(sh, oy, Hi, &y0, &y1, &ly0, &ly1);
+            const float* r0 = x + ((size_t)nc * Hi + y0) * Wi;
+            const float* r1 = x + ((size_t)nc * Hi + y1) * Wi;
+            for (ox = 0; ox < Wo; ++ox) {
+                int x0, x1;
+                float lx0, lx1;
+                bilinear_tap(sw, ox, Wi, &x0, &x1, &lx0, &lx1);
+                y[((size_t)nc * Ho + oy) * Wo + ox] = ly0 * (lx0 * r0[x0] + lx1 * r0[x1]) + ly1 * (lx0 * r1[x0] + lx1 * r1[x1]);
+            }
+        }
+}
+
+/* Backward of (bilinear x4 upsampling -> partial-label losses) with respect to the QUARTER-resolution logits zq [N,C,h,w]
+ * (mas_partial_loss_bwd_lowres): every full-resolution gradient d (exact_partial_loss_bwd on the interpolated logits) adds
+ * round_to_nearest_even(d * (ly * lx) * 2^44) into the four elements its logit was interpolated from -- integer sums, so the
+ * result does not depend on the order; dzq = (float)(sum * 2^-44). */
+void exact_partial_loss_bwd_lowres(const float* zq, int h, int w, const int64_t* spx, const uint8_t* mask, const uint32_t* bits,
+                                   const uint64_t* gmax, const float* scale, int N, int C, int H, int W, int S, float invT, int flags,
+                                   int64_t* dzq_fix, float* dzq) {
+    const size_t HW = (size_t)H * W, hw = (size_t)h * w;
+    float* z = (float*)malloc(sizeof(float) * (size_t)N * C * HW);
+    float* dz = (float*)malloc(sizeof(float) * (size_t)N * C * HW);
+    const float sh = (float)h / (float)H, sw = (float)w / (float)W;
+    int n, c, oy, ox;
+    size_t i;
+    exact_upsample_bilinear(zq, (int64_t)N * C, h, w, H, W, z);
+    exact_partial_loss_bwd(z, spx, mask, bits, gmax, scale, N, C, H, W, S, invT, flags, dz);
+    memset(dzq_fix, 0, sizeof(int64_t) * (size_t)N * C * hw);
+    for (n = 0; n < N; ++n)
+        for (c = 0; c < C; ++c) {
+            int64_t* q = dzq_fix + ((size_t)n * C + c) * hw;
+            const float* g = dz + ((size_t)n * C + c) * HW;
+            for (oy = 0; oy < H; ++oy) {
+                int y0, y1;
+                float ly0, ly1;
+                bilinear_tap(sh, oy, h, &y0, &y1, &ly0, &ly1);
+                for (ox = 0; ox < W; ++ox) {
+                    const float d = g[(size_t)oy * W + ox];
+                    int x0, x1;
+                    float lx0, lx1;
+                    if (d == 0.0f) continue;                 /* rounds to 0 quanta in any case */
+                    bilinear_tap(sw, ox, w, &x0, &x1, &lx0, &lx1);
+                    q[(size_t)y0 * w + x0] += (int64_t)llrint((double)(d * (ly0 * lx0)) * 17592186044416.0);
+                    q[(size_t)y0 * w + x1] += (int64_t)llrint((double)(d * (ly0 * lx1)) * 17592186044416.0);
+                    q[(size_t)y1 * w + x0] += (int64_t)llrint((double)(d * (ly1 * lx0)) * 17592186044416.0);
+                    q[(size_t)y1 * w + x1] += (int64_t)llrint((double)(d * (ly1 * lx1)) * 17592186044416.0);
+                }
+            }
+        }
+    for (i = 0; i < (size_t)N * C * hw; ++i) dzq[i] = (float)((double)dzq_fix[i] * (1.0 / 17592186044416.0));
+    free(z);
+    free(dz);
+}
+
 /* =============================================================================================
  * Single-pass acquisition scan (csrc/single_pass.hip)
  * ============================================================================================= */

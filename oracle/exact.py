@@ -171,6 +171,36 @@ def partial_loss_bwd(z, spx, mask, bits, gmax, acc, grad_out, invT, flags):
     return scale, dz
 
 
+def upsample_bilinear(x, Ho, Wo):
+    """[..., hi, wi] -> [..., Ho, Wo], F.interpolate(bilinear, align_corners=False) in the kernels' operation order."""
+    x = _c(x, np.float32)
+    hi, wi = x.shape[-2:]
+    nc = int(np.prod(x.shape[:-2]))
+    y = np.empty(x.shape[:-2] + (Ho, Wo), dtype=np.float32)
+    lib().exact_upsample_bilinear(_p(x), ctypes.c_int64(nc), hi, wi, Ho, Wo, _p(y))
+    return y
+
+
+def partial_loss_bwd_lowres(zq, H, W, spx, mask, bits, gmax, acc, grad_out, invT, flags):
+    """Returns (dzq_fix int64 [N,C,h,w], dzq f32): gradient of the losses w.r.t. the quarter-resolution logits."""
+    zq = _c(zq, np.float32)
+    spx = _c(spx, np.int64)
+    mask = _c(mask, np.uint8)
+    bits = _c(bits, np.uint32)
+    gmax = _c(gmax, np.uint64)
+    acc = _c(acc, np.uint64)
+    grad_out = _c(grad_out, np.float32)
+    N, C, h, w = zq.shape
+    S = bits.shape[1]
+    scale = np.zeros(3, dtype=np.float32)
+    lib().exact_loss_scales(_p(acc), _p(grad_out), flags, _p(scale))
+    fix = np.zeros(zq.shape, dtype=np.int64)
+    dzq = np.empty_like(zq)
+    lib().exact_partial_loss_bwd_lowres(_p(zq), h, w, _p(spx), _p(mask), _p(bits), _p(gmax), _p(scale), N, C, H, W, S,
+                                        ctypes.c_float(invT), flags, _p(fix), _p(dzq))
+    return fix, dzq
+
+
 # ------------------------------------------------------------------------------------------------
 # single-pass acquisition scan
 # ------------------------------------------------------------------------------------------------

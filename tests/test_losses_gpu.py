@@ -248,3 +248,77 @@ def test_literal_769_crop_batch_properties():
     _, edz = exact.partial_loss_bwd(z[3:], spx[3:], msk[3:], ebits, egmax, acc.cpu().numpy().view(np.uint64),
                                     np.array([16.0, 8.0, 1.0], dtype=np.float32), np.float32(invT), flags)
     assert np.array_equal(dz[3].cpu().numpy(), edz[0])
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# quarter-resolution forms: the x4 bilinear upsampling of the logits (models/segmentation/utils.py:25) inside the scans
+# ---------------------------------------------------------------------------------------------------------------------
+LOW_SHAPES = [(2, 20, 16, 48, 64, 192, 128), (1, 20, 13, 11, 52, 44, 48), (2, 21, 9, 10, 33, 37, 150), (1, 20, 48, 48, 192, 192, 512),
+              (1, 20, 193, 193, 769, 769, 2048)]
+
+
+@pytest.mark.parametrize("N,C,h,w,H,W,S", LOW_SHAPES)
+@pytest.mark.parametrize("fname", ['production', 'decomp', 'group_predignore'])
+def test_lowres_scans_equal_the_materialised_path_and_the_c_oracle(N, C, h, w, H, W, S, fname):
+    """Forward: sums, counts, arg-pixel table and losses are BIT-identical to the full-resolution scan of
+    upsample_bilinear(zq) (and the upsampling itself to oracle/exact.c).  Backward: the fixed-point gradient sums of zq equal
+    oracle/exact.c:exact_partial_loss_bwd_lowres bit for bit, and the f32 gradient agrees with the composed float path
+    (full-resolution dz gathered by the deterministic upsample backward) to rounding."""
+    ops = _gpu()
+    from oracle import exact
+    flags = FLAG_SETS[fname]
+    _, tgt, spx, msk = _inputs(900 + W + C, N, C, H, W, S)
+    zq = synth.logits(77 + h, N, C, h, w)
+    invT = ops.inv_temperature(0.1)
+    zqt, st, mt = torch.from_numpy(zq).cuda(), torch.from_numpy(spx).cuda(), torch.from_numpy(msk).cuda()
+    bits = ops.target_bits(torch.from_numpy(tgt).cuda())
+    zfull = ops.upsample_bilinear(zqt, (H, W))
+    assert np.array_equal(zfull.cpu().numpy(), exact.upsample_bilinear(zq, H, W))
+    l_full, a_full, g_full = ops.partial_loss_fwd(zfull, st, mt, bits, invT, flags)
+    l_low, a_low, g_low = ops.partial_loss_fwd_lowres(zqt, (H, W), st, mt, bits, invT, flags)
+    assert torch.equal(a_low, a_full) and torch.equal(l_low.view(torch.int32), l_full.view(torch.int32))
+    if g_full is not None:
+        assert torch.equal(g_low, g_full)
+    go = np.array([16.0, 8.0, 1.0], dtype=np.float32)
+    got = torch.from_numpy(go).cuda()
+    dzq, fix = ops.partial_loss_bwd_lowres(zqt, (H, W), st, mt, bits, g_low, a_low, got, invT, flags, want_fix=True)
+    egmax = np.zeros((N, S, C), dtype=np.uint64) if g_low is None else g_low.cpu().numpy().view(np.uint64)
+    efix, edzq = exact.partial_loss_bwd_lowres(zq, H, W, spx, msk, exact.target_bits(tgt), egmax, a_low.cpu().numpy().view(np.uint64),
+                                               go, np.float32(invT), flags)
+    assert np.array_equal(fix.cpu().numpy(), efix)
+    assert np.array_equal(dzq.cpu().numpy().view(np.uint32), edzq.view(np.uint32))
+    # composed float path: dz at full resolution, then the gather backward of the upsampling
+    dz = ops.partial_loss_bwd(zfull, st, mt, bits, g_full, a_full, got, invT, flags)
+    lib = __import__('mulactseg_amd._lib', fromlist=['x'])
+    ref = torch.empty_like(zqt)
+    lib.check(lib.load().mas_upsample_bilinear_bwd(dz.data_ptr(), N * C, h, w, H, W, ref.data_ptr(), torch.cuda.current_stream().cuda_stream), "bwd")
+    scale = float(ref.abs().max())
+    assert scale > 0 and float((dzq - ref).abs().max()) <= 2e-6 * scale
+    # run-to-run identical (integer atomics)
+    dzq2 = ops.partial_loss_bwd_lowres(zqt, (H, W), st, mt, bits, g_low, a_low, got, invT, flags)
+    assert torch.equal(dzq, dzq2)
+
+
+def test_fused_module_lowres_matches_interpolate_then_loss():
+    """FusedPartialLabelLoss.forward_lowres through autograd == F.interpolate + forward: same losses bit for bit, gradient of the
+    quarter-resolution logits within rounding (ATen's interpolate backward sums the same terms with float atomics)."""
+    _gpu()
+    import torch.nn.functional as F
+    from mulactseg_amd.utils.loss import FusedPartialLabelLoss
+    N, C, h, w, S = 2, 20, 24, 24, 256
+    H, W = 4 * h, 4 * w
+    _, tgt, spx, msk = _inputs(41, N, C, H, W, S)
+    crit = FusedPartialLabelLoss(S, 0.1, 0.1, sync_normalisers=False)
+    tg, sp, mk = torch.from_numpy(tgt).cuda(), torch.from_numpy(spx).cuda(), torch.from_numpy(msk).cuda()
+    zq1 = torch.from_numpy(synth.logits(5, N, C, h, w)).cuda().requires_grad_(True)
+    zq2 = zq1.detach().clone().requires_grad_(True)
+    g1, c1, m1 = crit.forward_lowres(zq1, (H, W), tg, sp, mk)
+    (16.0 * c1 + 8.0 * m1 + g1).backward()
+    from mulactseg_amd import ops
+    g2, c2, m2 = crit(ops.upsample_bilinear(zq2, (H, W)), tg, sp, mk)
+    (16.0 * c2 + 8.0 * m2 + g2).backward()
+    assert float(g1) == float(g2) and float(c1) == float(c2) and float(m1) == float(m2)
+    s = float(zq2.grad.abs().max())
+    assert s > 0 and float((zq1.grad - zq2.grad).abs().max()) <= 2e-6 * s
+    ref = F.interpolate(zq2.detach(), size=(H, W), mode='bilinear', align_corners=False)
+    assert float((ops.upsample_bilinear(zq2.detach(), (H, W)) - ref).abs().max()) <= 1e-6
