@@ -214,3 +214,44 @@ def test_remaining_selectors_match_reference_g7(tag, modname, method):
     tuples = sel.calculate_scores(fake_trainer(), FakePool(z, spx, im_idx, suppix))
     sc, si, sid = tuples_to_arrays(tuples, im_idx)
     assert np.array_equal(si, g[tag + '_list_img']) and np.array_equal(sid, g[tag + '_list_id'])
+
+
+def test_my_random_vectorised_selection_equals_the_tuple_sort(tmp_path):
+    """my_random.select_next_batch (numpy lexsort over the same random.random() draws) consumes exactly the regions the
+    reference path -- calculate_scores + sorted(reverse=True) + expand_training_set -- consumes, and leaves the global RNG
+    in the same state."""
+    import copy
+    import pickle
+    import random
+    import types
+    from mulactseg_amd.active_selection import base, my_random
+    from mulactseg_amd.dataloader import RegionActiveDataset
+    rs = np.random.RandomState(2)
+    n, S, C = 7, 23, 20
+    names = [["im/%02d.png" % i, "gt/%02d.png" % i, "sp/%02d.pkl" % i] for i in (3, 0, 6, 1, 5, 2, 4)]       # not in path order
+    mh = (rs.rand(n, S, C) < 0.15).astype(np.uint8)
+    mh[..., 1] = 1
+
+    def sets(tag):
+        d = tmp_path / tag
+        d.mkdir()
+        args = selector_args(nseg=S, model_save_dir=str(d), active_method='my_random')
+        pool = types.SimpleNamespace(im_idx=copy.deepcopy(names), suppix={k[2]: [i for i in range(S) if (i + j) % 5] for j, k in enumerate(names)},
+                                     isselected=np.zeros((n, S), np.uint8))
+        label = types.SimpleNamespace(im_idx=[], suppix={}, multi_hot_cls=mh, id_to_index={"%02d" % i: i for i in range(n)})
+        a = RegionActiveDataset(args, pool, label)
+        a.selection_iter = 1
+        return args, a
+
+    outs = []
+    for tag, cls in (("vec", my_random.RegionSelector), ("ref", None)):
+        args, aset = sets(tag)
+        random.seed(11)
+        sel = my_random.RegionSelector(args)
+        if cls is None:
+            base.RegionSelector.select_next_batch(sel, None, aset, 37)           # the generic tuple-sort path
+        else:
+            sel.select_next_batch(None, aset, 37)
+        with open(tmp_path / tag / 'my_random_selection_01.pkl', 'rb') as f:
+            outs.append((pickle.load(f), aset.trg_label_dataset.suppix, aset.trg_pool_dataset.suppix, random.random()))
+    assert outs[0] == outs[1] and len(outs[0][0]) > 5

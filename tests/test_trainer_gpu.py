@@ -232,3 +232,27 @@ def test_production_trainer_on_the_resident_data_path():
     assert isinstance(tr.train_dataset_loader, ResidentProvider)
     moved = sum(float((p.detach() - q).abs().sum()) for p, q in zip(tr.net.parameters(), before))
     assert moved > 0 and np.isfinite(moved)
+
+
+def test_five_round_loop_on_a_resident_pool_keeps_the_books(tmp_path):
+    """BASELINE.json config 5 in miniature (examples/al_rounds_pool_scale.py, the script that produces
+    profiles/r02/al_rounds_pool_scale.json at 2 975 x 2 048): five rounds on a resident pool; every round the labelled set grows by
+    exactly the consumed prefix, the pool shrinks by the same regions, the budget walk stops where the reference's does and
+    datalist_RR.pkl reloads -- the assertions live in the script and run at every size."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    import importlib.util
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("al_pool", os.path.join(root, "examples", "al_rounds_pool_scale.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    rep = mod.main(["--rounds", "5", "--images", "24", "--height", "128", "--width", "256", "--nseg", "64", "--budget", "150", "--iters", "4",
+                    "--crop", "96", "--val-images", "2", "--stage2-images", "2", "--out", str(tmp_path)])
+    rs = rep["rounds"]
+    assert [r["round"] for r in rs] == [1, 2, 3, 4, 5]
+    tot = [r["labelled_regions_total"] for r in rs]
+    assert all(b - a == r["regions_selected"] for a, b, r in zip([0] + tot, tot, rs))
+    assert all(r["clicks"] > 150 for r in rs) and all(np.isfinite(r["val_miou_synthetic"]) for r in rs)
+    assert rep["stage2_generation"]["pictures"] == 2
+    for k in range(1, 6):
+        assert os.path.exists(tmp_path / ("checkpoint%02d.tar" % k)) and os.path.exists(tmp_path / ("datalist_%02d.pkl" % k))
