@@ -38,6 +38,7 @@ N_CLS = 19
 
 class ResidentVal(torch.utils.data.Dataset):
     """Validation pictures and label maps resident on the device (synthetic)."""
+    device_resident = True
 
     def __init__(self, n, H, W, dev, seed=99):
         g = torch.Generator(device=dev)

@@ -19,7 +19,7 @@ class RegionActiveDataset:
         self.trg_label_dataset = trg_label_dataset
         self._valid = None          # u8 [n_img_total, S] mirror of pool.suppix (see pool_valid_mask)
         self._click_cost = None     # (multi_hot_cls it was computed from, u8 [n_img_total, S])
-        self._lists_replaced = False
+        self._initial_ok = True     # pool.initial_valid_table() describes the lists only until they change behind the table's back
 
     # -- cost of one region ---------------------------------------------------------------------
     def _fair(self):
@@ -58,7 +58,7 @@ class RegionActiveDataset:
         pool = self.trg_pool_dataset
         if self._valid is None or self._valid.shape[1] != nseg:
             init = getattr(pool, 'initial_valid_table', None)
-            tab = init() if (init is not None and not self._lists_replaced) else None
+            tab = init() if (init is not None and self._initial_ok) else None
             if tab is None:
                 n_total = len(self.trg_label_dataset.id_to_index)
                 tab = np.zeros((n_total, nseg), dtype=np.uint8)
@@ -83,6 +83,8 @@ class RegionActiveDataset:
         cost_tab = self.click_cost_table()
         has_sel = hasattr(pool, 'isselected')
         leaving = {}            # spx path -> (key, image row, set of ids removed from the pool in this call)
+        if self._valid is None:
+            self._initial_ok = False        # the lists change now without a table to mirror it: rebuild from the lists later
         for idx, (_, joined, suppix_id) in enumerate(sample_region):
             st = leaving.get(joined)
             if st is None:
@@ -145,7 +147,7 @@ class RegionActiveDataset:
         self.trg_pool_dataset.im_idx = data['trg_pool_im_idx']
         self.trg_label_dataset.suppix = data['trg_label_suppix']
         self.trg_pool_dataset.suppix = data['trg_pool_suppix']
-        self._valid, self._lists_replaced = None, True
+        self._valid, self._initial_ok = None, False
 
     def get_trainset(self):
         return self.trg_label_dataset

@@ -117,3 +117,18 @@ def test_expand_training_set_equals_the_reference_loop_on_random_rounds(tmp_path
     import pytest
     with pytest.raises((ValueError, KeyError)):
         aset.expand_training_set([(1.0, ','.join(ref_label['im_idx'][0]), gone)], 5, 'm')
+
+
+def test_valid_table_is_rebuilt_from_the_lists_when_a_round_ran_before_it_existed(tmp_path):
+    """A pool may offer initial_valid_table() (all ids listed when it was built); once expand_training_set has changed the lists
+    without a table to mirror it (a random first round), the table must come from the lists, not from the stale initial one."""
+    args, names, mh, aset = _sets(tmp_path, n=3, nseg=16)
+    pool = aset.trg_pool_dataset
+    pool.initial_valid_table = lambda: np.ones((3, 16), dtype=np.uint8)
+    aset.expand_training_set([(0.9, ','.join(names[1]), 3), (0.8, ','.join(names[2]), 5)], 10 ** 6, 'x')
+    valid = aset.pool_valid_mask(16)
+    for k, key in enumerate(pool.im_idx):
+        assert sorted(np.nonzero(valid[k])[0].tolist()) == sorted(pool.suppix[key[2]])
+    aset.expand_training_set([(0.7, ','.join(names[1]), 4)], 10 ** 6, 'x')          # now mirrored incrementally
+    valid = aset.pool_valid_mask(16)
+    assert valid[[k[2] for k in pool.im_idx].index(names[1][2]), 4] == 0
