@@ -109,3 +109,37 @@ def selector_args(**kw):
                 wandb=types.SimpleNamespace(log=lambda *a, **k: None))
     base.update(kw)
     return types.SimpleNamespace(**base)
+
+
+class OracleLossOps:
+    """CPU stand-in for the part of mulactseg_amd.ops the loss modules call (partial_loss_fwd / _bwd, target_bits,
+    inv_temperature), backed by oracle/exact.c -- lets the world-size-2 gloo tests drive FusedPartialLabelLoss's normaliser
+    all-reduce and autograd wiring without a GPU.  TEST INFRASTRUCTURE."""
+
+    @staticmethod
+    def inv_temperature(T):
+        return float(exact.inv_temperature(T))
+
+    @staticmethod
+    def target_bits(targets, cols_used=None):
+        return torch.from_numpy(exact.target_bits(targets.numpy(), cols_used).view(np.int32))
+
+    @staticmethod
+    def partial_loss_fwd(z, spx, mask, bits, invT, flags, reduce_acc=None):
+        import ctypes
+        acc, gmax, _ = exact.partial_loss_fwd(z.detach().numpy(), spx.numpy(), mask.numpy().astype(np.uint8), bits.numpy().view(np.uint32),
+                                              np.float32(invT), flags)
+        acc_t = torch.from_numpy(acc.view(np.int64).copy())
+        if reduce_acc is not None:
+            reduce_acc(acc_t)                            # the all-reduce of the integer sums and counts under test
+        accn = np.ascontiguousarray(acc_t.numpy().view(np.uint64))
+        losses = np.zeros(3, dtype=np.float32)
+        exact.lib().exact_loss_values(accn.ctypes.data_as(ctypes.c_void_p), flags, losses.ctypes.data_as(ctypes.c_void_p))
+        return torch.from_numpy(losses), acc_t, torch.from_numpy(gmax.view(np.int64))
+
+    @staticmethod
+    def partial_loss_bwd(z, spx, mask, bits, gmax, acc, grad_out, invT, flags):
+        g = np.zeros((z.shape[0], bits.shape[1], z.shape[1]), dtype=np.uint64) if gmax is None else gmax.numpy().view(np.uint64)
+        _, dz = exact.partial_loss_bwd(z.detach().numpy(), spx.numpy(), mask.numpy().astype(np.uint8), bits.numpy().view(np.uint32), g,
+                                       acc.numpy().view(np.uint64), grad_out.numpy(), np.float32(invT), flags)
+        return torch.from_numpy(dz)

@@ -125,3 +125,86 @@ def test_iou_counters_sum_over_ranks_even_when_a_rank_saw_nothing():
     mp.spawn(_run_meter, args=(2, _free_port(), out), nprocs=2, join=True)
     a, b = torch.load(os.path.join(out, "meter0.pt")), torch.load(os.path.join(out, "meter1.pt"))
     assert torch.equal(a, torch.arange(12)) and torch.equal(a, b)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# data-parallel training: global loss normalisers and decorrelated data order
+# ---------------------------------------------------------------------------------------------------------------------
+def _loss_inputs():
+    sys.path.insert(0, ROOT)
+    from mulactseg_amd import synth
+    N, C, H, W, S = 4, 20, 24, 32, 24
+    z = synth.logits(31, N, C, H, W)
+    sm = [synth.train_crop(40 + i, H, W, S, frac_selected=0.15 + 0.15 * i) for i in range(N)]     # very different counts per picture
+    spx, msk = np.stack([a for a, _ in sm]), np.stack([b for _, b in sm])
+    tgt = np.stack([synth.multi_hot_targets(60 + i, S, C) for i in range(N)])
+    return z, tgt, spx, msk, S
+
+
+def _run_loss(rank, world, port, out_dir):
+    sys.path.insert(0, HERE)
+    sys.path.insert(0, ROOT)
+    torch.set_num_threads(1)
+    if world > 1:
+        dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
+    try:
+        from helpers import OracleLossOps
+        from mulactseg_amd.utils import loss as loss_mod
+        loss_mod.ops = OracleLossOps                      # the scans come from oracle/exact.c; everything else is the product code
+        z, tgt, spx, msk, S = _loss_inputs()
+        per = z.shape[0] // world
+        sl = slice(rank * per, (rank + 1) * per)
+        zt = torch.from_numpy(z[sl].copy()).requires_grad_(True)
+        crit = loss_mod.FusedPartialLabelLoss(S, 0.1, 0.1, sync_normalisers=True)
+        group, ce, mc = crit(zt, torch.from_numpy(tgt[sl]), torch.from_numpy(spx[sl]), torch.from_numpy(msk[sl]))
+        loss = (16.0 * ce + 8.0 * mc + 1.0 * group) * world          # what the trainers do before DDP averages the gradients
+        loss.backward()
+        g = zt.grad.clone()
+        if world > 1:
+            # DistributedDataParallel averages parameter gradients over ranks; for the logits themselves that is dz / world
+            g = g / world
+        torch.save(dict(losses=torch.stack([group, ce, mc]).detach(), grad=g, acc=crit.last_acc.clone()),
+                   os.path.join(out_dir, "loss_w%d_r%d.pt" % (world, rank)))
+    finally:
+        if world > 1:
+            dist.barrier()
+            dist.destroy_process_group()
+
+
+def test_two_ranks_with_batch_two_optimise_the_single_rank_objective_of_batch_four():
+    """FusedPartialLabelLoss(sync_normalisers=True): the integer sums / counts are all-reduced before the division, so both ranks
+    hold the loss of the GLOBAL batch (bit-identical to one rank with all four pictures), and loss * world followed by DDP's
+    gradient averaging gives every picture exactly the single-rank gradient."""
+    out = tempfile.mkdtemp()
+    _run_loss(0, 1, 0, out)
+    single = torch.load(os.path.join(out, "loss_w1_r0.pt"))
+    mp.spawn(_run_loss, args=(2, _free_port(), out), nprocs=2, join=True)
+    parts = [torch.load(os.path.join(out, "loss_w2_r%d.pt" % r)) for r in range(2)]
+    for p in parts:
+        assert torch.equal(p['losses'].view(torch.int32), single['losses'].view(torch.int32))      # same bits on every rank
+        assert torch.equal(p['acc'], single['acc'])
+    grad = torch.cat([p['grad'] for p in parts])
+    assert torch.equal(grad.view(torch.int32), single['grad'].view(torch.int32))
+    assert float(single['losses'].abs().sum()) > 0 and float(single['grad'].abs().sum()) > 0
+
+
+def _run_seeds(rank, world, port, out_dir):
+    sys.path.insert(0, ROOT)
+    dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
+    try:
+        import random
+        from mulactseg_amd.trainer.base import BaseTrainer
+        t = types.SimpleNamespace(args=types.SimpleNamespace(seed=1), selection_iter=2)
+        seed = BaseTrainer.loader_seed(t)
+        random.seed(1)                                   # the process-global stream the selectors use stays identical
+        with open(os.path.join(out_dir, "seed%d.pkl" % rank), "wb") as f:
+            pickle.dump((seed, random.random()), f)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_data_order_seeds_differ_per_rank_while_the_global_stream_agrees():
+    out = tempfile.mkdtemp()
+    mp.spawn(_run_seeds, args=(2, _free_port(), out), nprocs=2, join=True)
+    (s0, g0), (s1, g1) = [pickle.load(open(os.path.join(out, "seed%d.pkl" % r), "rb")) for r in range(2)]
+    assert s0 != s1 and g0 == g1
