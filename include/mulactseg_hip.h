@@ -335,11 +335,13 @@ int mas_upsample_bilinear_bwd(const float* gy, int64_t NC, int Hi, int Wi, int H
  * train_fwd: batch statistics (biased variance for the normalisation, unbiased for running_var, momentum update as
  * torch.nn.BatchNorm2d; running_* / num_batches_tracked may be NULL), y = relu?((x-mean)*invstd*gamma+beta+residual);
  * saves mean / invstd [C] for the backward.  workspace: mas_bn_workspace_bytes(N, C, HW) bytes of device memory.
- * relu_mask (optional, N*C*HW/4 bytes, used when HW % 4 == 0): bit k of byte j tells whether output 4j+k is positive;
+ * relu_mask (optional, mas_bn_mask_bytes(N, C, HW) bytes): one byte per 16-byte-aligned group of four outputs of a plane
+ * ((HW + 3) / 4 + 1 groups per plane, whatever the plane's alignment), bit k = output k of the group is positive;
  * train_bwd: dx, dresidual (= masked dy; may be NULL), dgamma, dbeta (may be NULL); the ReLU mask comes from `relu_mask`
  * when given, else from the forward output `y`.
  * eval_fwd: the same map with the running statistics. */
 int64_t mas_bn_workspace_bytes(int N, int C, int HW);
+int64_t mas_bn_mask_bytes(int N, int C, int HW);
 int mas_bn_act_train_fwd(const float* x, const float* gamma, const float* beta, const float* residual, int N, int C, int HW, float eps,
                          float momentum, int relu, float* running_mean, float* running_var, int64_t* num_batches_tracked,
                          float* save_mean, float* save_invstd, void* workspace, float* y, uint8_t* relu_mask, void* stream);

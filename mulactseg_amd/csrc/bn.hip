@@ -12,7 +12,7 @@
 //             ->  k_bn_bwd_apply  dx = gamma * invstd * (g - mean(g) - xhat * mean(g * xhat)),  dres = g
 //   inference k_bn_apply with the running statistics.
 // All reductions run in a fixed order (per-chunk tree, then chunks in index order, in double): results do not depend on
-// the launch or on the run.  Layout NCHW; float4 paths when H*W is a multiple of 4.
+// the launch or on the run.  Layout NCHW; 16-byte accesses for planes of any length (aligned groups, see groups_of).
 #include "common.h"
 
 namespace {
@@ -29,21 +29,59 @@ __device__ __forceinline__ double block_sum(double v, double* s_red) {
     return ((s_red[0] + s_red[1]) + s_red[2]) + s_red[3];
 }
 
+// ---- 16-byte groups over planes of any length ----------------------------------------------------------------------
+// A plane (n, c) starts at element (n*C + c)*HW: with H*W odd (the 769 crop: 385^2, 193^2, 97^2, 49^2) three planes out of
+// four are not 16-byte aligned.  Every streaming kernel therefore walks ALIGNED groups of four floats: group g of a plane
+// covers the addresses [start + 4g, start + 4g + 4) with start = the plane's first element rounded down to 16 bytes; a
+// group that lies completely inside the plane is one float4 access, the (at most two) boundary groups of a plane are
+// handled element by element -- their other elements belong to the neighbouring planes, which other workgroups own.
+// `a` = misalignment of the plane in elements (0..3) taken from the real address, so tensors with a storage offset work
+// too; VEC is false when the tensors of a launch are not congruent modulo 16 bytes (then every group goes element-wise).
+struct Groups { const float* start; int a; int n; };
+
+__device__ __forceinline__ Groups groups_of(const float* plane, int HW) {
+    Groups g;
+    g.a = (int)((reinterpret_cast<uintptr_t>(plane) >> 2) & 3);
+    g.start = plane - g.a;
+    g.n = (g.a + HW + 3) >> 2;
+    return g;
+}
+__device__ __forceinline__ bool group_full(const Groups& g, int i, int HW) { return 4 * i >= g.a && 4 * i + 4 <= g.a + HW; }
+__device__ __forceinline__ bool elem_in(const Groups& g, int i, int k, int HW) { return 4 * i + k >= g.a && 4 * i + k < g.a + HW; }
+
+template <bool VEC>
+__device__ __forceinline__ float4 load_group(const float* t_start, const Groups& g, int i, int HW, float fill) {
+    if (VEC && group_full(g, i, HW)) return *reinterpret_cast<const float4*>(t_start + 4 * i);
+    float v[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) v[k] = elem_in(g, i, k, HW) ? t_start[4 * i + k] : fill;
+    return make_float4(v[0], v[1], v[2], v[3]);
+}
+template <bool VEC>
+__device__ __forceinline__ void store_group(float* t_start, const Groups& g, int i, int HW, float4 o) {
+    if (VEC && group_full(g, i, HW)) { *reinterpret_cast<float4*>(t_start + 4 * i) = o; return; }
+    const float v[4] = {o.x, o.y, o.z, o.w};
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+        if (elem_in(g, i, k, HW)) t_start[4 * i + k] = v[k];
+}
+__device__ __forceinline__ float4 mask_bits(unsigned m) {
+    return make_float4((float)(m & 1u), (float)((m >> 1) & 1u), (float)((m >> 2) & 1u), (float)((m >> 3) & 1u));
+}
+constexpr int kGroupsPerChunk = kChunk / 4;
+
 // grid (chunks, N, C): part[(c * N + n) * chunks + chunk] = (sum x, sum x^2)
+template <bool VEC>
 __global__ __launch_bounds__(kThreads) void k_bn_partial(const float* __restrict__ x, int C, int HW, int chunks, double2* __restrict__ part) {
     __shared__ double s_red[kThreads / MAS_WAVE];
     const int chunk = blockIdx.x, n = blockIdx.y, c = blockIdx.z;
-    const float* p = x + ((size_t)n * C + c) * HW;
-    const int lo = chunk * kChunk, hi = min(HW, lo + kChunk);
+    const Groups g = groups_of(x + ((size_t)n * C + c) * HW, HW);
+    const int lo = chunk * kGroupsPerChunk, hi = min(g.n, lo + kGroupsPerChunk);
     float s = 0.f, q = 0.f;
-    if ((HW & 3) == 0) {
-        for (int i = lo + threadIdx.x * 4; i < hi; i += kThreads * 4) {
-            const float4 v = *reinterpret_cast<const float4*>(p + i);
-            s += (v.x + v.y) + (v.z + v.w);
-            q += (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
-        }
-    } else {
-        for (int i = lo + threadIdx.x; i < hi; i += kThreads) { const float v = p[i]; s += v; q += v * v; }
+    for (int i = lo + threadIdx.x; i < hi; i += kThreads) {
+        const float4 v = load_group<VEC>(g.start, g, i, HW, 0.0f);
+        s += (v.x + v.y) + (v.z + v.w);
+        q += (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
     }
     const double S = block_sum((double)s, s_red);
     const double Q = block_sum((double)q, s_red);
@@ -72,67 +110,58 @@ __global__ __launch_bounds__(kThreads) void k_bn_stats(const double2* __restrict
     }
 }
 
-// grid (ceil(HW / (4 * 256)), N * C).  FROM_VAR: `stat2` holds the running variance (inference), else invstd.
-template <bool FROM_VAR>
+// grid (ceil(groups / 256), N * C), one aligned group per thread.  FROM_VAR: `stat2` holds the running variance (inference),
+// else invstd.  mask: one byte per group, mask_stride bytes per plane (bit k = output k of the group is positive).
+template <bool FROM_VAR, bool VEC>
 __global__ __launch_bounds__(kThreads) void k_bn_apply(const float* __restrict__ x, const float* __restrict__ gamma, const float* __restrict__ beta,
                                                         const float* __restrict__ stat1, const float* __restrict__ stat2, float eps,
                                                         const float* __restrict__ res, int C, int HW, int relu, float* __restrict__ y,
-                                                        unsigned char* __restrict__ mask) {
+                                                        unsigned char* __restrict__ mask, int mask_stride) {
     const int c = blockIdx.y % C;
     const float mu = stat1[c];
     const float is = FROM_VAR ? 1.0f / sqrtf(stat2[c] + eps) : stat2[c];
-    const float g = gamma ? gamma[c] : 1.0f, b = beta ? beta[c] : 0.0f;
+    const float gm = gamma ? gamma[c] : 1.0f, b = beta ? beta[c] : 0.0f;
     const size_t base = (size_t)blockIdx.y * HW;
-    const int i = (blockIdx.x * kThreads + threadIdx.x) * 4;
-    if (i >= HW) return;
+    const Groups g = groups_of(x + base, HW);
+    const int i = blockIdx.x * kThreads + threadIdx.x;
+    if (i >= g.n) return;
     auto f = [&](float v, float r) {
-        float t = ((v - mu) * is) * g + b;
+        float t = ((v - mu) * is) * gm + b;
         t = t + r;
         return (relu && !(t > 0.0f)) ? 0.0f : t;
     };
-    if ((HW & 3) == 0) {
-        const float4 v = *reinterpret_cast<const float4*>(x + base + i);
-        const float4 r = res ? *reinterpret_cast<const float4*>(res + base + i) : make_float4(0.f, 0.f, 0.f, 0.f);
-        const float4 o = make_float4(f(v.x, r.x), f(v.y, r.y), f(v.z, r.z), f(v.w, r.w));
-        *reinterpret_cast<float4*>(y + base + i) = o;
-        // ReLU mask for the backward pass: one byte per four elements (1/16 of the bytes of y)
-        if (mask) mask[(base + i) >> 2] = (unsigned char)((o.x > 0.f) | ((o.y > 0.f) << 1) | ((o.z > 0.f) << 2) | ((o.w > 0.f) << 3));
-    } else {
-        for (int k = 0; k < 4 && i + k < HW; ++k) y[base + i + k] = f(x[base + i + k], res ? res[base + i + k] : 0.0f);
-    }
+    const float4 v = load_group<VEC>(g.start, g, i, HW, 0.0f);
+    const float4 r = res ? load_group<VEC>(res + base - g.a, g, i, HW, 0.0f) : make_float4(0.f, 0.f, 0.f, 0.f);
+    const float4 o = make_float4(f(v.x, r.x), f(v.y, r.y), f(v.z, r.z), f(v.w, r.w));
+    store_group<VEC>(y + base - g.a, g, i, HW, o);
+    if (mask) mask[(size_t)blockIdx.y * mask_stride + i] = (unsigned char)((o.x > 0.f) | ((o.y > 0.f) << 1) | ((o.z > 0.f) << 2) | ((o.w > 0.f) << 3));
 }
 
 // part[(c * N + n) * chunks + chunk] = (sum g, sum g * xhat),  g = dy * [y > 0] (relu) or dy
+template <bool VEC>
 __global__ __launch_bounds__(kThreads) void k_bn_bwd_partial(const float* __restrict__ dy, const float* __restrict__ x, const float* __restrict__ y,
-                                                              const unsigned char* __restrict__ mask, const float* __restrict__ mean,
+                                                              const unsigned char* __restrict__ mask, int mask_stride, const float* __restrict__ mean,
                                                               const float* __restrict__ invstd, int C, int HW, int chunks, int relu,
                                                               double2* __restrict__ part) {
     __shared__ double s_red[kThreads / MAS_WAVE];
     const int chunk = blockIdx.x, n = blockIdx.y, c = blockIdx.z;
-    const size_t base = ((size_t)n * C + c) * HW;
+    const size_t plane = (size_t)n * C + c, base = plane * HW;
     const float mu = mean[c], is = invstd[c];
-    const int lo = chunk * kChunk, hi = min(HW, lo + kChunk);
+    const Groups g = groups_of(x + base, HW);
+    const int lo = chunk * kGroupsPerChunk, hi = min(g.n, lo + kGroupsPerChunk);
     float s = 0.f, q = 0.f;
-    auto acc = [&](float g, float xv, float yv) {
-        g = (relu && !(yv > 0.0f)) ? 0.0f : g;
-        s += g;
-        q += g * ((xv - mu) * is);
+    auto acc = [&](float gr, float xv, float yv) {
+        gr = (relu && !(yv > 0.0f)) ? 0.0f : gr;
+        s += gr;
+        q += gr * ((xv - mu) * is);
     };
-    if ((HW & 3) == 0) {
-        for (int i = lo + threadIdx.x * 4; i < hi; i += kThreads * 4) {
-            const float4 g = *reinterpret_cast<const float4*>(dy + base + i);
-            const float4 xv = *reinterpret_cast<const float4*>(x + base + i);
-            float4 yv = make_float4(1.f, 1.f, 1.f, 1.f);
-            if (relu && mask) {
-                const unsigned m = mask[(base + i) >> 2];
-                yv = make_float4((float)(m & 1u), (float)((m >> 1) & 1u), (float)((m >> 2) & 1u), (float)((m >> 3) & 1u));
-            } else if (relu) {
-                yv = *reinterpret_cast<const float4*>(y + base + i);
-            }
-            acc(g.x, xv.x, yv.x); acc(g.y, xv.y, yv.y); acc(g.z, xv.z, yv.z); acc(g.w, xv.w, yv.w);
-        }
-    } else {
-        for (int i = lo + threadIdx.x; i < hi; i += kThreads) acc(dy[base + i], x[base + i], relu ? y[base + i] : 1.0f);
+    for (int i = lo + threadIdx.x; i < hi; i += kThreads) {
+        const float4 gr = load_group<VEC>(dy + base - g.a, g, i, HW, 0.0f);         // elements of other planes: gradient 0, x = mean
+        const float4 xv = load_group<VEC>(g.start, g, i, HW, mu);
+        float4 yv = make_float4(1.f, 1.f, 1.f, 1.f);
+        if (relu && mask) yv = mask_bits(mask[plane * mask_stride + i]);
+        else if (relu) yv = load_group<VEC>(y + base - g.a, g, i, HW, 0.0f);
+        acc(gr.x, xv.x, yv.x); acc(gr.y, xv.y, yv.y); acc(gr.z, xv.z, yv.z); acc(gr.w, xv.w, yv.w);
     }
     const double S = block_sum((double)s, s_red);
     const double Q = block_sum((double)q, s_red);
@@ -151,8 +180,9 @@ __global__ __launch_bounds__(kThreads) void k_bn_bwd_stats(const double2* __rest
     coef[c] = make_float2((float)(S / count), (float)(Q / count));
 }
 
+template <bool VEC>
 __global__ __launch_bounds__(kThreads) void k_bn_bwd_apply(const float* __restrict__ dy, const float* __restrict__ x, const float* __restrict__ y,
-                                                            const unsigned char* __restrict__ mask, const float* __restrict__ gamma,
+                                                            const unsigned char* __restrict__ mask, int mask_stride, const float* __restrict__ gamma,
                                                             const float* __restrict__ mean,
                                                             const float* __restrict__ invstd, const float2* __restrict__ coef, int C, int HW,
                                                             int relu, float* __restrict__ dx, float* __restrict__ dres) {
@@ -161,43 +191,41 @@ __global__ __launch_bounds__(kThreads) void k_bn_bwd_apply(const float* __restri
     const float k = (gamma ? gamma[c] : 1.0f) * is;
     const float2 m = coef[c];
     const size_t base = (size_t)blockIdx.y * HW;
-    const int i = (blockIdx.x * kThreads + threadIdx.x) * 4;
-    if (i >= HW) return;
-    auto f = [&](float g, float xv, float yv, float& gout) {
-        g = (relu && !(yv > 0.0f)) ? 0.0f : g;
-        gout = g;
-        return k * ((g - m.x) - ((xv - mu) * is) * m.y);
+    const Groups g = groups_of(x + base, HW);
+    const int i = blockIdx.x * kThreads + threadIdx.x;
+    if (i >= g.n) return;
+    auto f = [&](float gr, float xv, float yv, float& gout) {
+        gr = (relu && !(yv > 0.0f)) ? 0.0f : gr;
+        gout = gr;
+        return k * ((gr - m.x) - ((xv - mu) * is) * m.y);
     };
-    if ((HW & 3) == 0) {
-        const float4 g = *reinterpret_cast<const float4*>(dy + base + i);
-        const float4 xv = *reinterpret_cast<const float4*>(x + base + i);
-        float4 yv = make_float4(1.f, 1.f, 1.f, 1.f);
-        if (relu && mask) {
-            const unsigned mk = mask[(base + i) >> 2];
-            yv = make_float4((float)(mk & 1u), (float)((mk >> 1) & 1u), (float)((mk >> 2) & 1u), (float)((mk >> 3) & 1u));
-        } else if (relu) {
-            yv = *reinterpret_cast<const float4*>(y + base + i);
-        }
-        float4 r, o;
-        o.x = f(g.x, xv.x, yv.x, r.x); o.y = f(g.y, xv.y, yv.y, r.y); o.z = f(g.z, xv.z, yv.z, r.z); o.w = f(g.w, xv.w, yv.w, r.w);
-        *reinterpret_cast<float4*>(dx + base + i) = o;
-        if (dres) *reinterpret_cast<float4*>(dres + base + i) = r;
-    } else {
-        for (int t = 0; t < 4 && i + t < HW; ++t) {
-            float r;
-            dx[base + i + t] = f(dy[base + i + t], x[base + i + t], relu ? y[base + i + t] : 1.0f, r);
-            if (dres) dres[base + i + t] = r;
-        }
-    }
+    const float4 gr = load_group<VEC>(dy + base - g.a, g, i, HW, 0.0f);
+    const float4 xv = load_group<VEC>(g.start, g, i, HW, 0.0f);
+    float4 yv = make_float4(1.f, 1.f, 1.f, 1.f);
+    if (relu && mask) yv = mask_bits(mask[(size_t)blockIdx.y * mask_stride + i]);
+    else if (relu) yv = load_group<VEC>(y + base - g.a, g, i, HW, 0.0f);
+    float4 r, o;
+    o.x = f(gr.x, xv.x, yv.x, r.x); o.y = f(gr.y, xv.y, yv.y, r.y); o.z = f(gr.z, xv.z, yv.z, r.z); o.w = f(gr.w, xv.w, yv.w, r.w);
+    store_group<VEC>(dx + base - g.a, g, i, HW, o);
+    if (dres) store_group<VEC>(dres + base - g.a, g, i, HW, r);
 }
 
 int check(int N, int C, int HW) {
     if (N <= 0 || C <= 0 || HW <= 0 || N > 65535 || C > 65535 || (long long)N * C > 0x7fffffffLL) return MAS_ERR_SHAPE;
     return 0;
 }
-inline int chunks_of(int HW) { return (HW + kChunk - 1) / kChunk; }
-inline dim3 apply_grid(int N, int C, int HW) { return dim3((unsigned)((HW + kThreads * 4 - 1) / (kThreads * 4)), (unsigned)(N * C)); }
+inline int max_groups(int HW) { return (HW + 3) / 4 + 1; }                    // aligned groups a plane can touch (any misalignment)
+inline int chunks_of(int HW) { return (max_groups(HW) + kGroupsPerChunk - 1) / kGroupsPerChunk; }
+inline dim3 apply_grid(int N, int C, int HW) { return dim3((unsigned)((max_groups(HW) + kThreads - 1) / kThreads), (unsigned)(N * C)); }
+// float4 accesses need every tensor of the launch at the same offset modulo 16 bytes (and 4-byte aligned)
+inline bool congruent(const void* a, const void* b) { return b == nullptr || (((uintptr_t)a ^ (uintptr_t)b) & 15) == 0; }
 }  // namespace
+
+/* bytes of the ReLU mask of mas_bn_act_train_fwd / _bwd: one byte per aligned 16-byte group, max_groups(HW) per plane */
+extern "C" int64_t mas_bn_mask_bytes(int N, int C, int HW) {
+    if (check(N, C, HW)) return -1;
+    return (int64_t)N * C * max_groups(HW);
+}
 
 extern "C" int64_t mas_bn_workspace_bytes(int N, int C, int HW) {
     if (check(N, C, HW)) return -1;
@@ -214,12 +242,17 @@ extern "C" int mas_bn_act_train_fwd(const float* x, const float* gamma, const fl
     hipStream_t st = static_cast<hipStream_t>(stream);
     const int chunks = chunks_of(HW);
     double2* part = static_cast<double2*>(workspace);
-    hipLaunchKernelGGL(k_bn_partial, dim3((unsigned)chunks, (unsigned)N, (unsigned)C), dim3(kThreads), 0, st, x, C, HW, chunks, part);
+    const bool vec = congruent(x, y) && congruent(x, residual) && ((uintptr_t)x & 3) == 0;
+    if (vec) hipLaunchKernelGGL(k_bn_partial<true>, dim3((unsigned)chunks, (unsigned)N, (unsigned)C), dim3(kThreads), 0, st, x, C, HW, chunks, part);
+    else hipLaunchKernelGGL(k_bn_partial<false>, dim3((unsigned)chunks, (unsigned)N, (unsigned)C), dim3(kThreads), 0, st, x, C, HW, chunks, part);
     hipLaunchKernelGGL(k_bn_stats, dim3((unsigned)((C + kThreads - 1) / kThreads)), dim3(kThreads), 0, st, part, C, N * chunks,
                        (double)N * (double)HW, eps, momentum, save_mean, save_invstd, running_mean, running_var,
                        reinterpret_cast<long long*>(num_batches_tracked));
-    hipLaunchKernelGGL((k_bn_apply<false>), apply_grid(N, C, HW), dim3(kThreads), 0, st, x, gamma, beta, save_mean, save_invstd, eps, residual, C,
-                       HW, relu, y, (relu && (HW & 3) == 0) ? relu_mask : nullptr);
+    unsigned char* mk = relu ? relu_mask : nullptr;
+    if (vec) hipLaunchKernelGGL((k_bn_apply<false, true>), apply_grid(N, C, HW), dim3(kThreads), 0, st, x, gamma, beta, save_mean, save_invstd, eps,
+                                residual, C, HW, relu, y, mk, max_groups(HW));
+    else hipLaunchKernelGGL((k_bn_apply<false, false>), apply_grid(N, C, HW), dim3(kThreads), 0, st, x, gamma, beta, save_mean, save_invstd, eps,
+                            residual, C, HW, relu, y, mk, max_groups(HW));
     return mas_launch_status();
 }
 
@@ -228,8 +261,11 @@ extern "C" int mas_bn_act_eval_fwd(const float* x, const float* gamma, const flo
                                    void* stream) {
     if (!x || !running_mean || !running_var || !y) return MAS_ERR_NULL;
     if (int e = check(N, C, HW)) return e;
-    hipLaunchKernelGGL((k_bn_apply<true>), apply_grid(N, C, HW), dim3(kThreads), 0, static_cast<hipStream_t>(stream), x, gamma, beta,
-                       running_mean, running_var, eps, residual, C, HW, relu, y, nullptr);
+    const bool vec = congruent(x, y) && congruent(x, residual) && ((uintptr_t)x & 3) == 0;
+    if (vec) hipLaunchKernelGGL((k_bn_apply<true, true>), apply_grid(N, C, HW), dim3(kThreads), 0, static_cast<hipStream_t>(stream), x, gamma, beta,
+                                running_mean, running_var, eps, residual, C, HW, relu, y, nullptr, 0);
+    else hipLaunchKernelGGL((k_bn_apply<true, false>), apply_grid(N, C, HW), dim3(kThreads), 0, static_cast<hipStream_t>(stream), x, gamma, beta,
+                            running_mean, running_var, eps, residual, C, HW, relu, y, nullptr, 0);
     return mas_launch_status();
 }
 
@@ -237,18 +273,23 @@ extern "C" int mas_bn_act_train_bwd(const float* dy, const float* x, const float
                                     const float* save_mean, const float* save_invstd, int N, int C, int HW, int relu, void* workspace,
                                     float* dx, float* dresidual, float* dgamma, float* dbeta, void* stream) {
     if (!dy || !x || !save_mean || !save_invstd || !workspace || !dx) return MAS_ERR_NULL;
-    if ((HW & 3) != 0) relu_mask = nullptr;
     if (relu && !y && !relu_mask) return MAS_ERR_NULL;
     if (int e = check(N, C, HW)) return e;
     hipStream_t st = static_cast<hipStream_t>(stream);
     const int chunks = chunks_of(HW);
     double2* part = static_cast<double2*>(workspace);
     float2* coef = reinterpret_cast<float2*>(part + (size_t)C * N * chunks);
-    hipLaunchKernelGGL(k_bn_bwd_partial, dim3((unsigned)chunks, (unsigned)N, (unsigned)C), dim3(kThreads), 0, st, dy, x, y, relu_mask, save_mean,
-                       save_invstd, C, HW, chunks, relu, part);
+    const bool vec = congruent(x, dy) && congruent(x, dx) && congruent(x, dresidual) && (relu_mask || congruent(x, y)) && ((uintptr_t)x & 3) == 0;
+    const int ms = max_groups(HW);
+    if (vec) hipLaunchKernelGGL(k_bn_bwd_partial<true>, dim3((unsigned)chunks, (unsigned)N, (unsigned)C), dim3(kThreads), 0, st, dy, x, y, relu_mask, ms,
+                                save_mean, save_invstd, C, HW, chunks, relu, part);
+    else hipLaunchKernelGGL(k_bn_bwd_partial<false>, dim3((unsigned)chunks, (unsigned)N, (unsigned)C), dim3(kThreads), 0, st, dy, x, y, relu_mask, ms,
+                            save_mean, save_invstd, C, HW, chunks, relu, part);
     hipLaunchKernelGGL(k_bn_bwd_stats, dim3((unsigned)((C + kThreads - 1) / kThreads)), dim3(kThreads), 0, st, part, C, N * chunks,
                        (double)N * (double)HW, dgamma, dbeta, coef);
-    hipLaunchKernelGGL(k_bn_bwd_apply, apply_grid(N, C, HW), dim3(kThreads), 0, st, dy, x, y, relu_mask, gamma, save_mean, save_invstd, coef, C, HW,
-                       relu, dx, dresidual);
+    if (vec) hipLaunchKernelGGL(k_bn_bwd_apply<true>, apply_grid(N, C, HW), dim3(kThreads), 0, st, dy, x, y, relu_mask, ms, gamma, save_mean,
+                                save_invstd, coef, C, HW, relu, dx, dresidual);
+    else hipLaunchKernelGGL(k_bn_bwd_apply<false>, apply_grid(N, C, HW), dim3(kThreads), 0, st, dy, x, y, relu_mask, ms, gamma, save_mean,
+                            save_invstd, coef, C, HW, relu, dx, dresidual);
     return mas_launch_status();
 }

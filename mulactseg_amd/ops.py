@@ -647,8 +647,8 @@ class _BNActTrain(torch.autograd.Function):
         mean = torch.empty(C, dtype=torch.float32, device=dev)
         invstd = torch.empty(C, dtype=torch.float32, device=dev)
         y = torch.empty_like(x)
-        # ReLU mask, one byte per four outputs: the backward then reads 1/16 of the bytes of y
-        mask = torch.empty(N * C * HW // 4, dtype=torch.uint8, device=dev) if (relu and HW % 4 == 0) else None
+        # ReLU mask, one byte per aligned group of four outputs: the backward then reads 1/16 of the bytes of y
+        mask = torch.empty(int(lib.mas_bn_mask_bytes(N, C, HW)), dtype=torch.uint8, device=dev) if relu else None
         with torch.cuda.device(dev):
             _lib.check(lib.mas_bn_act_train_fwd(x.data_ptr(), _opt(weight), _opt(bias), _opt(res), N, C, HW, float(eps), float(momentum),
                                                 int(relu), _opt(running_mean), _opt(running_var), _opt(num_batches_tracked),

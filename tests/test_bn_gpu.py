@@ -10,7 +10,9 @@ import torch.nn.functional as F
 pytestmark = pytest.mark.gpu
 
 CASES = [(4, 8, 24, 32, True, True), (2, 16, 7, 9, True, False), (4, 64, 1, 1, True, False), (3, 5, 33, 37, False, True),
-         (2, 12, 96, 96, True, True), (1, 3, 5, 4, False, False)]
+         (2, 12, 96, 96, True, True), (1, 3, 5, 4, False, False),
+         # odd planes longer than one reduction chunk (the 769 crop's 193 x 193): aligned-group path, three of four planes misaligned
+         (2, 6, 193, 193, True, True), (1, 5, 97, 97, True, False)]
 
 
 def _gpu():
@@ -124,3 +126,26 @@ def test_model_golden_parity_with_fused_bn():
     from test_model import _check, _load
     g, net, x = _load()
     _check(g, net.cuda(), x.cuda(), 1e-4)
+
+
+def test_tensors_with_a_storage_offset_take_the_element_path_and_agree():
+    """x / residual / upstream gradient that are contiguous views at an odd element offset (planes misaligned differently from the
+    freshly allocated outputs): the launch falls back to element-wise groups, same values as on aligned copies."""
+    ops = _gpu()
+    g = torch.Generator().manual_seed(7)
+    N, C, H, W = 2, 4, 9, 11
+    big = torch.randn((N * C * H * W + 3,), generator=g).cuda()
+    bigr = torch.randn((N * C * H * W + 1,), generator=g).cuda()
+    x_view = big[3:].view(N, C, H, W)
+    r_view = bigr[1:].view(N, C, H, W)
+    bn = nn.BatchNorm2d(C).cuda().train()
+    outs = []
+    for xs, rs in ((x_view, r_view), (x_view.clone(), r_view.clone())):
+        b = copy.deepcopy(bn)
+        xq = xs.detach().requires_grad_(True)
+        rq = rs.detach().requires_grad_(True)
+        y = ops.bn_act(b, xq, True, rq)
+        y.backward(torch.ones_like(y) * 0.5)
+        outs.append((y.detach(), xq.grad, rq.grad, b.weight.grad, b.running_var.clone()))
+    for a, c in zip(*outs):
+        assert torch.equal(a, c)
