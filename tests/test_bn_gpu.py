@@ -130,7 +130,7 @@ def test_model_golden_parity_with_fused_bn():
 
 def test_tensors_with_a_storage_offset_take_the_element_path_and_agree():
     """x / residual / upstream gradient that are contiguous views at an odd element offset (planes misaligned differently from the
-    freshly allocated outputs): the launch falls back to element-wise groups, same values as on aligned copies."""
+    freshly allocated outputs): the launch falls back to element-wise groups; values agree with those on aligned copies to rounding."""
     ops = _gpu()
     g = torch.Generator().manual_seed(7)
     N, C, H, W = 2, 4, 9, 11
@@ -147,5 +147,5 @@ def test_tensors_with_a_storage_offset_take_the_element_path_and_agree():
         y = ops.bn_act(b, xq, True, rq)
         y.backward(torch.ones_like(y) * 0.5)
         outs.append((y.detach(), xq.grad, rq.grad, b.weight.grad, b.running_var.clone()))
-    for a, c in zip(*outs):
-        assert torch.equal(a, c)
+    for a, c in zip(*outs):         # the partial sums are grouped by address, so the last bits may differ between the two alignments
+        assert float((a - c).abs().max()) <= 2e-6 * max(1.0, float(c.abs().max()))
