@@ -37,6 +37,51 @@ __global__ __launch_bounds__(kThreads) void k_cosine_fwd(const float* __restrict
     for (int k = 0; k < K; ++k) logits[(n * K + k) * HW + p] = dot[k] * inv;
 }
 
+// Four consecutive pixels per lane (one 16-B load per channel), packed-f32 accumulators (v_pk_fma_f32 evaluates both halves
+// with IEEE semantics: every pixel's sums are the same fma chain, in channel order, as in k_cosine_fwd), four channels of
+// loads in flight per trip.  The one-pixel form above spends its time waiting for a single 4-B load per 21 fmas
+// (1.3 TB/s at [4,256,256,512]); this one is bound by the 2 x (K + 1) packed fmas per channel.
+template <int K>
+__global__ __launch_bounds__(kThreads) void k_cosine_fwd4(const float* __restrict__ f, const float* __restrict__ phat, int Ch, int HW,
+                                                           float eps, float* __restrict__ logits, float* __restrict__ inv_norm) {
+    const int p = (blockIdx.x * kThreads + threadIdx.x) * 4;
+    const size_t n = blockIdx.y;
+    if (p >= HW) return;
+    const float* fp = f + n * Ch * HW + p;
+    mas_v2f ssa = mas_splat(0.f), ssb = mas_splat(0.f), da[K], db[K];
+#pragma unroll
+    for (int k = 0; k < K; ++k) { da[k] = mas_splat(0.f); db[k] = mas_splat(0.f); }
+    for (int c = 0; c < Ch; c += 4) {            // Ch % 4 == 0 (launcher)
+        float4 v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) v[u] = *reinterpret_cast<const float4*>(fp + (size_t)(c + u) * HW);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const mas_v2f va = {v[u].x, v[u].y}, vb = {v[u].z, v[u].w};
+            ssa = mas_pk_fma(va, va, ssa);
+            ssb = mas_pk_fma(vb, vb, ssb);
+#pragma unroll
+            for (int k = 0; k < K; ++k) {
+                const mas_v2f w = mas_splat(phat[k * Ch + c + u]);
+                da[k] = mas_pk_fma(va, w, da[k]);
+                db[k] = mas_pk_fma(vb, w, db[k]);
+            }
+        }
+    }
+    float inv[4];
+    const float ss[4] = {ssa.x, ssa.y, ssb.x, ssb.y};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        float nrm = sqrtf(ss[j]);
+        nrm = nrm < eps ? eps : nrm;
+        inv[j] = 1.0f / nrm;
+    }
+    *reinterpret_cast<float4*>(inv_norm + n * HW + p) = make_float4(inv[0], inv[1], inv[2], inv[3]);
+#pragma unroll
+    for (int k = 0; k < K; ++k)
+        *reinterpret_cast<float4*>(logits + (n * K + k) * HW + p) = make_float4(da[k].x * inv[0], da[k].y * inv[1], db[k].x * inv[2], db[k].y * inv[3]);
+}
+
 template <int K>
 __global__ __launch_bounds__(kThreads) void k_cosine_bwd(const float* __restrict__ f, const float* __restrict__ phat,
                                                           const float* __restrict__ logits, const float* __restrict__ inv_norm,
@@ -65,6 +110,11 @@ __global__ __launch_bounds__(kThreads) void k_cosine_bwd(const float* __restrict
 
 template <int K>
 int launch_fwd(const float* f, const float* phat, int N, int Ch, int HW, float eps, float* logits, float* inv_norm, hipStream_t st) {
+    if (HW % 4 == 0 && Ch % 4 == 0 && (((uintptr_t)f | (uintptr_t)logits | (uintptr_t)inv_norm) & 15) == 0) {
+        hipLaunchKernelGGL((k_cosine_fwd4<K>), dim3((unsigned)((HW / 4 + kThreads - 1) / kThreads), (unsigned)N), dim3(kThreads), 0, st, f, phat, Ch,
+                           HW, eps, logits, inv_norm);
+        return mas_launch_status();
+    }
     hipLaunchKernelGGL((k_cosine_fwd<K>), dim3((unsigned)((HW + kThreads - 1) / kThreads), (unsigned)N), dim3(kThreads), 0, st, f, phat, Ch, HW, eps,
                        logits, inv_norm);
     return mas_launch_status();

@@ -301,6 +301,17 @@ class DeepLabHeadV3PlusWN(nn.Module):
     def point_feature(self, feature):
         low = _run(self.project, feature['low_level'])
         x = self.aspp(feature['out'])
+        if x.is_cuda and not torch.is_grad_enabled():
+            from .. import ops
+            if ops.upsample_bilinear_supported(x, low.shape[2:]):
+                # inference: the upsampled ASPP output is written straight into its slice of the concatenation buffer
+                # (torch.cat re-reads and re-writes both inputs: 0.4 ms per pool batch)
+                _took("upsample", "hip")
+                N, cl = low.shape[0], low.shape[1]
+                buf = torch.empty((N, cl + x.shape[1], low.shape[2], low.shape[3]), dtype=low.dtype, device=low.device)
+                buf[:, :cl].copy_(low)
+                ops.upsample_bilinear_into(x.contiguous(), buf[:, cl:])
+                return _run(self.classifier, buf)
         x = _upsample(x, low.shape[2:])
         return _run(self.classifier, torch.cat([low, x], dim=1))
 

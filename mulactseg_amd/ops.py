@@ -627,6 +627,22 @@ def upsample_bilinear(x, size):
     return _UpsampleBilinear.apply(x, int(size[0]), int(size[1]))
 
 
+def upsample_bilinear_into(x, out):
+    """Inference only: write the upsampling of x [N,C,hi,wi] into ``out`` [N,C,Ho,Wo], a view whose per-picture [C,Ho,Wo]
+    blocks are contiguous (e.g. a channel slice of a concatenation buffer) -- one launch per picture, no copy afterwards."""
+    _need(x, "x", torch.float32)
+    N, C, Hi, Wi = x.shape
+    Ho, Wo = out.shape[2], out.shape[3]
+    if out.shape[0] != N or out.shape[1] != C or out.stride(3) != 1 or out.stride(2) != Wo or out.stride(1) != Ho * Wo:
+        raise ValueError("out must be [N,C,Ho,Wo] with contiguous per-picture blocks")
+    lib = _lib.load()
+    with torch.cuda.device(x.device):
+        for n in range(N):
+            _lib.check(lib.mas_upsample_bilinear_fwd(x[n].data_ptr(), C, Hi, Wi, Ho, Wo, out[n].data_ptr(), _stream(x)),
+                       "mas_upsample_bilinear_fwd")
+    return out
+
+
 # ------------------------------------------------------------------------------------------------
 # BatchNorm2d + ReLU + residual add, fused (csrc/bn.hip)
 # ------------------------------------------------------------------------------------------------

@@ -52,8 +52,10 @@ def main():
     for name, m in net.named_modules():
         if isinstance(m, nn.Conv2d):
             m.register_forward_hook(hook(name))
+    net.train()             # in eval mode most convolutions bypass Module.__call__ (fused MFMA path): collect the shapes in train mode
     with torch.no_grad():
         net(torch.randn(N, 3, H, W, device=dev))
+    net.eval()
     rows = []
     tot = collections.Counter()
     for (cin, cout, k, s, d, g, xs), names in shapes.items():
