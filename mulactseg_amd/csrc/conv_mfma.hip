@@ -164,12 +164,20 @@ __global__ __launch_bounds__(kThreads, 2) void k_conv_mfma(const ConvP p) {
         sE[tid] = p.scale ? p.scale[m0 + tid] : 1.0f;
         sE[BM + tid] = p.scale ? p.shift[m0 + tid] : 0.0f;
     }
-    conv_fetch<NW, NXMAX, VEC>(xb, wb, woff, goff, wr, xr);
-    for (int t = 0; t < nchunks; ++t) {
-        conv_stage<NW, NXMAX, VEC, W4>(sW, sX, tid, loff, live, ok, wr, xr);
-        __syncthreads();
-        if (t + 1 < nchunks)
-            conv_fetch<NW, NXMAX, VEC>(xb + (size_t)(t + 1) * CK * HW, wb + (size_t)(t + 1) * KC * p.Cout, woff, goff, wr, xr);
+    // epilogue geometry (needed early: the residual values are fetched while the last chunk's MFMAs run)
+    const int HWo = p.Ho * p.Wo;
+    int po[TN];
+    bool inside[TN];
+#pragma unroll
+    for (int tn = 0; tn < TN; ++tn) {
+        const int pl = wn * (BN / WN) + tn * 32 + l31;
+        const int oy = oy0 + (pl >> p.tw_log2), ox = ox0 + (pl & (TW - 1));
+        inside[tn] = oy < p.Ho && ox < p.Wo;
+        po[tn] = inside[tn] ? oy * p.Wo + ox : 0;
+    }
+    const float* rb = RES ? p.res + ((size_t)n * p.Cout + m0) * HWo : nullptr;
+
+    auto mfma_chunk = [&]() {
 #pragma unroll
         for (int q = 0; q < KC / 8; ++q) {
             const v4f a0 = *reinterpret_cast<const v4f*>(sW + q * 8 * BM + aBase);
@@ -189,29 +197,35 @@ __global__ __launch_bounds__(kThreads, 2) void k_conv_mfma(const ConvP p) {
                 }
             }
         }
+    };
+    conv_fetch<NW, NXMAX, VEC>(xb, wb, woff, goff, wr, xr);
+    for (int t = 0; t + 1 < nchunks; ++t) {
+        conv_stage<NW, NXMAX, VEC, W4>(sW, sX, tid, loff, live, ok, wr, xr);
+        __syncthreads();
+        conv_fetch<NW, NXMAX, VEC>(xb + (size_t)(t + 1) * CK * HW, wb + (size_t)(t + 1) * KC * p.Cout, woff, goff, wr, xr);
+        mfma_chunk();
         __syncthreads();
     }
+    // last chunk (peeled: nothing left to prefetch)
+    conv_stage<NW, NXMAX, VEC, W4>(sW, sX, tid, loff, live, ok, wr, xr);
+    __syncthreads();
+    mfma_chunk();
 
     // ---- epilogue: accumulator (row = (r & 3) + 8 (r >> 2) + 4 h, column = lane & 31) -> NCHW --------------------------
     // Branch-free per element: scale / shift come from LDS (1 / 0 without a BatchNorm), the 16 residual values of a tile are
-    // loaded together (clamped address outside the plane), one predicate guards the 16 stores.
-    const int HWo = p.Ho * p.Wo;
+    // loaded together (clamped address outside the plane; fetching all 64 behind the last chunk's MFMAs was measured: the
+    // registers it pins cost more than the latency it hides), one predicate guards the 16 stores of a tile.
     float* yb = p.y + ((size_t)n * p.Cout + m0) * HWo;
-    const float* rb = RES ? p.res + ((size_t)n * p.Cout + m0) * HWo : nullptr;
     const float lo = p.relu ? 0.0f : -INFINITY;
 #pragma unroll
     for (int tn = 0; tn < TN; ++tn) {
-        const int pl = wn * (BN / WN) + tn * 32 + l31;
-        const int oy = oy0 + (pl >> p.tw_log2), ox = ox0 + (pl & (TW - 1));
-        const bool inside = oy < p.Ho && ox < p.Wo;
-        const int po = inside ? oy * p.Wo + ox : 0;
 #pragma unroll
         for (int tm = 0; tm < 2; ++tm) {
             const int mb = wm * 64 + tm * 32 + 4 * h;
-            float rv[16], out[16];
+            float out[16], rv[16];
             if (RES) {
 #pragma unroll
-                for (int r = 0; r < 16; ++r) rv[r] = rb[(size_t)(mb + (r & 3) + 8 * (r >> 2)) * HWo + po];
+                for (int r = 0; r < 16; ++r) rv[r] = rb[(size_t)(mb + (r & 3) + 8 * (r >> 2)) * HWo + po[tn]];
             }
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
@@ -220,9 +234,9 @@ __global__ __launch_bounds__(kThreads, 2) void k_conv_mfma(const ConvP p) {
                 if (RES) v += rv[r];
                 out[r] = v < lo ? lo : v;
             }
-            if (inside) {
+            if (inside[tn]) {
 #pragma unroll
-                for (int r = 0; r < 16; ++r) yb[(size_t)(mb + (r & 3) + 8 * (r >> 2)) * HWo + po] = out[r];
+                for (int r = 0; r < 16; ++r) yb[(size_t)(mb + (r & 3) + 8 * (r >> 2)) * HWo + po[tn]] = out[r];
             }
         }
     }
