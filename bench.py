@@ -568,6 +568,11 @@ def pmc_traffic(kernel, default_shape):
 
 def main():
     args = parse()
+    # stdout carries exactly ONE line, the JSON: library banners (RCCL prints its version block to stdout when the first
+    # communicator is built) go to stderr for the whole run
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -684,7 +689,8 @@ def main():
     out["stage2"] = None if (args.no_train or args.no_trainleg or rank != 0) else secondary(stage2_bench, args, dev)
     if rank == 0:
         out["cpu_baseline"] = secondary(cpu_baseline, args, dev, cpu_bufs, backend) if cpu_bufs is not None else None
-        print(json.dumps(out), flush=True)
+        sys.stdout.flush()
+        os.write(json_fd, (json.dumps(out) + "\n").encode())
     d = _dist()
     if d is not None:
         if world > 1:
