@@ -170,6 +170,62 @@ __global__ __launch_bounds__(kThreads) void k_dw_strip(const float* __restrict__
     }
 }
 
+// Undilated form (the decoder's two separable convolutions, d = 1) without LDS: a lane owns four consecutive columns and walks
+// down kRowsPerLane output rows with a sliding window of three input rows in registers -- per output row ONE 16-byte load plus
+// the two neighbouring scalars (same cache lines), 36 fmas, one 16-byte store; no integer divisions, no barrier.  The
+// accumulation order per output is the strip kernel's (taps row-major), so both give the same bits.
+// grid: (ceil(W / 256), ceil(H / kRowsPerLane), N*C), block: one wave per 256 columns x 4 row groups... (64 x 4 threads).
+constexpr int kRowsPerLane = 16;
+
+template <bool FLIP>
+__global__ __launch_bounds__(kThreads) void k_dw_rows(const float* __restrict__ x, const float* __restrict__ w, int C, int H, int W,
+                                                       float* __restrict__ y) {
+    const int lane = threadIdx.x & (MAS_WAVE - 1), wave = threadIdx.x / MAS_WAVE;
+    const int x0 = (blockIdx.x * MAS_WAVE + lane) * 4;
+    const int ys = (blockIdx.y * (kThreads / MAS_WAVE) + wave) * kRowsPerLane;
+    if (x0 >= W || ys >= H) return;
+    const size_t nc = blockIdx.z;
+    const int c = (int)(nc % C);
+    const float* xp = x + nc * H * W;
+    float* yp = y + nc * H * W;
+    float k[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) k[t] = w[c * 9 + (FLIP ? 8 - t : t)];
+    // r[j][0..5] = input row (ys - 1 + row index), columns x0 - 1 .. x0 + 4 (zero outside the plane)
+    float r[3][6];
+    auto load_row = [&](int gy, float (&dst)[6]) {
+        if (gy >= 0 && gy < H) {
+            const float* p = xp + (size_t)gy * W + x0;
+            const float4 v = *reinterpret_cast<const float4*>(p);
+            dst[0] = x0 > 0 ? p[-1] : 0.0f;
+            dst[1] = v.x; dst[2] = v.y; dst[3] = v.z; dst[4] = v.w;
+            dst[5] = x0 + 4 < W ? p[4] : 0.0f;
+        } else {
+#pragma unroll
+            for (int j = 0; j < 6; ++j) dst[j] = 0.0f;
+        }
+    };
+    load_row(ys - 1, r[0]);
+    load_row(ys, r[1]);
+    const int ye = (ys + kRowsPerLane) < H ? (ys + kRowsPerLane) : H;
+    for (int gy = ys; gy < ye; ++gy) {
+        load_row(gy + 1, r[2]);
+        float o[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float acc = 0.f;
+#pragma unroll
+            for (int a = 0; a < 3; ++a)
+#pragma unroll
+                for (int b = 0; b < 3; ++b) acc = mas_fmaf(k[a * 3 + b], r[a][j + b], acc);
+            o[j] = acc;
+        }
+        *reinterpret_cast<float4*>(yp + (size_t)gy * W + x0) = make_float4(o[0], o[1], o[2], o[3]);
+#pragma unroll
+        for (int j = 0; j < 6; ++j) { r[0][j] = r[1][j]; r[1][j] = r[2][j]; }
+    }
+}
+
 // dw[c,a,b] = sum_{n,i,j} dy[n,c,i,j] * x[n,c, i+(a-1)d, j+(b-1)d]; one workgroup per (channel, image), nine sums per
 // thread, fixed-order wave/workgroup reduction into part[n,c,9]; k_dw_wsum adds the images in index order.
 __global__ __launch_bounds__(kThreads) void k_dw_bwd_w(const float* __restrict__ x, const float* __restrict__ g, int C, int H, int W, int d,
@@ -259,6 +315,13 @@ static int dw_launch(bool flip, const float* x, const float* w, int N, int C, in
     const size_t smem = sizeof(float) * (size_t)(kStripH + 2 * d) * (W + 2 * d);
     if (smem > 64 * 1024 || (long long)N * C * strips > 0x7fffffffLL) return MAS_ERR_SHAPE;
     hipStream_t st = static_cast<hipStream_t>(stream);
+    if (d == 1 && W % 4 == 0 && (((uintptr_t)x | (uintptr_t)y) & 15) == 0 && (long long)N * C <= 65535) {
+        const dim3 grid((unsigned)((W + 4 * MAS_WAVE - 1) / (4 * MAS_WAVE)),
+                        (unsigned)((H + kRowsPerLane * (kThreads / MAS_WAVE) - 1) / (kRowsPerLane * (kThreads / MAS_WAVE))), (unsigned)(N * C));
+        if (flip) hipLaunchKernelGGL((k_dw_rows<true>), grid, dim3(kThreads), 0, st, x, w, C, H, W, y);
+        else hipLaunchKernelGGL((k_dw_rows<false>), grid, dim3(kThreads), 0, st, x, w, C, H, W, y);
+        return mas_launch_status();
+    }
     if (flip)
         hipLaunchKernelGGL((k_dw_strip<true>), dim3((unsigned)(N * C * strips)), dim3(kThreads), smem, st, x, w, C, H, W, d, strips, y);
     else
