@@ -355,9 +355,11 @@ def acquisition_with_model_bench(args, dev, world):
     hist = torch.zeros((B, S, C), dtype=torch.int32, device=dev)
 
     def step():
+        # as the PixBal selectors run it: quarter-resolution logits out of the model, the final x4 bilinear upsampling
+        # (models/segmentation/utils.py:25) evaluated inside the scan -- bit-identical to scanning the upsampled tensor
         with torch.no_grad():
-            z = net(images)
-        ops.single_pass_accum(z.contiguous(), spx, S, invT, prob_sum=prob, class_sum=csum, hist=hist)
+            zq = net(images, lowres=True)
+        ops.single_pass_accum_lowres(zq.contiguous(), (H, W), spx, S, invT, prob_sum=prob, class_sum=csum, hist=hist)
 
     for _ in range(4):              # MIOpen's find runs on the first calls of every new shape
         step()
@@ -370,7 +372,26 @@ def acquisition_with_model_bench(args, dev, world):
         step()
     torch.cuda.synchronize()
     ms = (time.perf_counter() - t0) / args.acq_steps * 1e3
-    return {"metric": "superpixels scored/sec incl. model forward", "value": B * S * world / (ms * 1e-3), "unit": "superpixels/s",
+    # the two forms of the scan on the same quarter-resolution logits, kernel time by HIP events
+    with torch.no_grad():
+        zq = net(images, lowres=True).contiguous()
+
+        def ev(fn, n=20):
+            for _ in range(3):
+                fn()
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+            for _ in range(n):
+                fn()
+            b.record()
+            torch.cuda.synchronize()
+            return a.elapsed_time(b) / n
+        low_ms = ev(lambda: ops.single_pass_accum_lowres(zq, (H, W), spx, S, invT, prob_sum=prob, class_sum=csum, hist=hist))
+        mat_ms = ev(lambda: ops.single_pass_accum(ops.upsample_bilinear(zq, (H, W)), spx, S, invT, prob_sum=prob, class_sum=csum, hist=hist))
+    scan_forms = {"scan_from_quarter_logits_ms": low_ms, "upsample_then_scan_ms": mat_ms,
+                  "note": "k_single_pass<LOWRES> (interpolation in registers, VALU-bound: ~1 700 issue slots per 256-pixel row) vs "
+                          "k_upsample_fwd + k_single_pass_ring (671 MB written and re-read)"}
+    return {"metric": "superpixels scored/sec incl. model forward", "scan_forms": scan_forms, "value": B * S * world / (ms * 1e-3), "unit": "superpixels/s",
             "ms_per_batch": ms, "forwards_per_image": 1, "layer_paths_per_step": paths,
             "config": {"workload": "eval forward (MIOpen fp32 + HIP layers) of [%d,3,%d,%d] + single-pass scan; the reference structure "
                                    "runs the forward twice per pool image" % (B, H, W)}}

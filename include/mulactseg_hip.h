@@ -237,6 +237,14 @@ int mas_logits_iou_counts(const float* z, const int64_t* targets, int B, int cha
 int mas_single_pass_accum(const float* z, const void* spx, int spx_dtype, int B, int C, int H, int W, int S, float invT,
                           uint64_t* prob_sum, uint64_t* class_sum, uint32_t* hist, void* stream);
 
+/* K8 form of the scan: zq [B,C,h,w] are the model's QUARTER-resolution cosine logits; their x4 bilinear upsampling to H x W
+ * (models/segmentation/utils.py:25, F.interpolate(..., 'bilinear', align_corners=False)) is evaluated in registers, in the
+ * operation order of mas_upsample_bilinear_fwd, so prob_sum / class_sum / hist equal those of mas_single_pass_accum on the
+ * materialised tensor bit for bit -- without that tensor (671 MB per Cityscapes batch) or the pass that writes it.
+ * C in {19, 20, 21}; H / h and W / w >= ~3.8 (MAS_ERR_RANGE otherwise). */
+int mas_single_pass_accum_lowres(const float* zq, int h, int w, const void* spx, int spx_dtype, int B, int C, int H, int W, int S,
+                                 float invT, uint64_t* prob_sum, uint64_t* class_sum, uint32_t* hist, void* stream);
+
 /* score[r] = floor(((sum_c class_sum[r,c] * w31[c]) >> 31) / n_r) * 2^-40, w31[c] = floor(cls_weight[c] * 2^31)
  * (exact integer arithmetic); dominant class, ban and optional outputs as mas_region_finalize.
  * With w31[c] = 2^31 for all c the scores equal those of mas_bvsb_region_accum(cls_w = NULL) + mas_region_finalize

@@ -127,6 +127,9 @@ class HipBackend:
     def single_pass(self, logits, spx, S, invT, prob_sum, class_sum, hist):
         self.ops.single_pass_accum(logits, spx, S, invT, prob_sum=prob_sum, class_sum=class_sum, hist=hist)
 
+    def single_pass_lowres(self, zq, size, spx, S, invT, prob_sum, class_sum, hist):
+        self.ops.single_pass_accum_lowres(zq, size, spx, S, invT, prob_sum=prob_sum, class_sum=class_sum, hist=hist)
+
     def class_weight(self, prob_sum, hw, batch_size, n_batches, coeff):
         """(cum f64 [C], cls_w f32 [C]) on the device from the gathered per-picture class sums; the integer form of the
         weights rides along on the tensor so that ``finalize_weighted`` needs no conversion (and no host round trip)."""
@@ -235,6 +238,21 @@ class AcquisitionRound:
         r = self._rows(row0, logits)
         self.backend.single_pass(logits.contiguous(), spx.contiguous(), self.S, self.invT, self.prob_sum[r],
                                  self.class_sum[r], self.hist[r])
+
+    def add_single_pass_lowres(self, row0, zq, size, spx):
+        """As ``add_single_pass`` for the logits ``F.interpolate(zq, size, 'bilinear', align_corners=False)`` (the model's final
+        upsampling, ``models/segmentation/utils.py:25``) evaluated inside the scan: same accumulators, bit for bit."""
+        B = zq.shape[0]
+        if row0 < 0 or row0 + B > self.plan.n_local:
+            raise IndexError("batch rows [%d,%d) outside this rank's shard of %d images" % (row0, row0 + B, self.plan.n_local))
+        hw = int(size[0]) * int(size[1])
+        if self.hw is None:
+            self.hw = hw
+        elif self.hw != hw:
+            raise ValueError("all pool images of one round must share H*W (the class prior is a pixel mean)")
+        r = slice(row0, row0 + B)
+        self.backend.single_pass_lowres(zq.contiguous(), (int(size[0]), int(size[1])), spx.contiguous(), self.S, self.invT,
+                                        self.prob_sum[r], self.class_sum[r], self.hist[r])
 
     def scores_single_pass(self, cls_w, ban_class=-1, want_hist=False):
         """Weighted region means from the single-pass accumulators (cls_w None -> unweighted)."""

@@ -15,8 +15,10 @@ class RegionSelector(base.RegionSelector):
         super().__init__(args)
         self.temperature = args.ce_temp
 
-    def _iterate(self, trainer, pool_set, rnd):
-        """Yield (first local row, logits, spx) for this rank's reference batches, in loader order."""
+    def _iterate(self, trainer, pool_set, rnd, lowres=False):
+        """Yield (first local row, logits, spx) for this rank's reference batches, in loader order.  ``lowres``: the model's
+        quarter-resolution logits instead (a consumer that evaluates the final bilinear upsampling itself); the image size is
+        then ``spx.shape[-2:]``."""
         model = trainer.net
         model.eval()
         loader, _ = get_al_loader(trainer, pool_set, self.batch_size, self.num_workers, rnd.plan.local_indices)
@@ -25,7 +27,7 @@ class RegionSelector(base.RegionSelector):
             for batch in loader:
                 images = batch['images'].to(trainer.device, dtype=torch.float32)
                 spx = batch['spx'].to(trainer.device)
-                preds = model(images)
+                preds = model(images, lowres=True) if lowres else model(images)
                 yield row, preds, spx
                 row += images.shape[0]
 

@@ -30,9 +30,16 @@ class RegionSelector(my_bvsb.RegionSelector):
         if not getattr(self.args, 'two_pass_scoring', False):
             rnd = AcquisitionRound(n_img, C, self.num_superpixels, self.batch_size, self.args.ce_temp, backend,
                                    single_pass=True)
-            for row, preds, spx in self._iterate(trainer, pool_set, rnd):           # the only pass
+            # a model that can hand out its quarter-resolution logits (models/deeplab.py) is scanned from them: the final x4
+            # bilinear upsampling happens inside the scan (K8), bit-identical to scanning the upsampled tensor
+            low = (getattr(trainer.net, 'lowres_logits', False) and getattr(self.args, 'lowres_scan', True)
+                   and C in (19, 20, 21) and hasattr(backend, 'single_pass_lowres'))
+            for row, preds, spx in self._iterate(trainer, pool_set, rnd, lowres=low):   # the only pass
                 self._check_channels(preds, C)
-                rnd.add_single_pass(row, preds, spx)
+                if low:
+                    rnd.add_single_pass_lowres(row, preds, spx.shape[-2:], spx)
+                else:
+                    rnd.add_single_pass(row, preds, spx)
             cls_w = rnd.class_weights(self.args.cls_weight_coeff)
             self._round, self.cls_weight = rnd, cls_w
             return rnd.scores_single_pass(cls_w, ban_class=ban, want_hist=want_hist)

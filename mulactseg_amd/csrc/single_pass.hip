@@ -43,27 +43,60 @@ __device__ __forceinline__ int table_slot(int* keys, int id) {
     return -1;
 }
 
-template <int CT, bool EXACT, typename IdT, bool VEC>
+// LOWRES (K8): `z` is the model's QUARTER-resolution logit tensor [B,C,h,w]; the x4 bilinear upsampling of
+// models/segmentation/utils.py:25 is evaluated in registers from an LDS copy of the tile's low-resolution footprint
+// (edge-replicated, so the clamped second tap of ATen's index arithmetic is a plain "+1"), in the operation order of
+// csrc/upsample.hip -- every pixel's 20 logits, hence every output of the scan, equal those of the materialised tensor bit for
+// bit.  The [B,C,H,W] logits (671 MB per pool batch) and the upsampling pass are gone; the scan then has no HBM stream left
+// to wait for and is bound by its ~1 700 VALU issue slots per row of 256 pixels (9 packed operations per pixel pair and class
+// for the interpolation on top of the ~1 300 of the scan itself).
+struct LowSrc { int h, w; float sh, sw; };
+constexpr int kLowRows = 7, kLowCols = 68;       // footprint of a 16 x 256 tile for ratios >= 3.8 (checked by the launcher)
+
+__device__ __forceinline__ void low_tap(float scale, int o, int& i0, float& l0, float& l1) {
+    float s = scale * ((float)o + 0.5f) - 0.5f;
+    s = s < 0.0f ? 0.0f : s;
+    i0 = (int)s;
+    l1 = s - (float)i0;
+    l0 = 1.0f - l1;
+}
+
+template <int CT, bool EXACT, typename IdT, bool VEC, bool LOWRES = false>
 __global__ __launch_bounds__(kThreads) void k_single_pass(const float* __restrict__ z, const IdT* __restrict__ spx, int C, int H,
                                                            int W, int S, float invT, int tiles_x, int tiles_y,
                                                            mas_u64* __restrict__ prob_sum, mas_u64* __restrict__ class_sum,
-                                                           unsigned* __restrict__ hist) {
+                                                           unsigned* __restrict__ hist, const LowSrc lr = LowSrc{0, 0, 0.f, 0.f}) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     mas_u64* t_sum = reinterpret_cast<mas_u64*>(smem);                                        // [kSlots * C]
     mas_u64* s_part = reinterpret_cast<mas_u64*>(smem + sizeof(mas_u64) * kSlots * C);         // [4][CT]
     unsigned* t_hist = reinterpret_cast<unsigned*>(smem + sizeof(mas_u64) * (kSlots * C + 4 * CT));   // [kSlots * C]
     int* t_keys = reinterpret_cast<int*>(smem + sizeof(mas_u64) * (kSlots * C + 4 * CT) + sizeof(unsigned) * kSlots * C);
+    float* s_low = reinterpret_cast<float*>(t_keys + kSlots);                                     // LOWRES: [C][kLowRows][kLowCols]
 
     for (int i = threadIdx.x; i < kSlots; i += kThreads) t_keys[i] = -1;
     for (int i = threadIdx.x; i < kSlots * C; i += kThreads) { t_sum[i] = 0; t_hist[i] = 0; }
-    __syncthreads();
 
     int bid = blockIdx.x;
     const int tx = bid % tiles_x; bid /= tiles_x;
     const int ty = bid % tiles_y;
     const int b = bid / tiles_y;
     const int HW = H * W;
-    const float* zb = z + (size_t)b * C * HW;
+    const float* zb = z + (size_t)b * C * (LOWRES ? lr.h * lr.w : HW);
+    int low_r0 = 0, low_c0 = 0;
+    if (LOWRES) {
+        float u0, u1;
+        low_tap(lr.sh, ty * kTileH, low_r0, u0, u1);
+        low_tap(lr.sw, tx * kTileW, low_c0, u0, u1);
+        // one (class, row) line of the footprint per wave and trip: lanes run along the columns, edges replicated
+        const int lane_ = threadIdx.x & (MAS_WAVE - 1), wave_ = threadIdx.x / MAS_WAVE;
+        for (int cr = wave_; cr < C * kLowRows; cr += kThreads / MAS_WAVE) {
+            const int c = cr / kLowRows, r = cr - c * kLowRows;
+            const int gy = min(low_r0 + r, lr.h - 1);
+            const float* src = zb + ((size_t)c * lr.h + gy) * lr.w;
+            for (int x = lane_; x < kLowCols; x += MAS_WAVE) s_low[cr * kLowCols + x] = src[min(low_c0 + x, lr.w - 1)];
+        }
+    }
+    __syncthreads();
     const IdT* sb = spx + (size_t)b * HW;
     mas_u64* gsum = class_sum + (size_t)b * S * C;
     unsigned* ghist = hist + (size_t)b * S * C;
@@ -74,6 +107,21 @@ __global__ __launch_bounds__(kThreads) void k_single_pass(const float* __restric
 #pragma unroll
     for (int c = 0; c < CT; ++c) acc[c] = 0;
     unsigned n_quanta = 0;
+    // LOWRES: the column taps of this lane's four pixels are the same for every row of the tile
+    int lx[4];
+    mas_v2f l0xa = mas_splat(0.f), l1xa = mas_splat(0.f), l0xb = mas_splat(0.f), l1xb = mas_splat(0.f);
+    if (LOWRES) {
+        float a0[4], a1[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int xk = tx * kTileW + (VEC ? (lane * 4 + k) : (k * MAS_WAVE + lane));
+            int i0;
+            low_tap(lr.sw, xk < W ? xk : W - 1, i0, a0[k], a1[k]);
+            lx[k] = i0 - low_c0;
+        }
+        l0xa = (mas_v2f){a0[0], a0[1]}; l1xa = (mas_v2f){a1[0], a1[1]};
+        l0xb = (mas_v2f){a0[2], a0[3]}; l1xb = (mas_v2f){a1[2], a1[3]};
+    }
 
     for (int it = 0; it < kTileH / 4; ++it) {
         const int y = ty * kTileH + it * 4 + wave;
@@ -99,12 +147,32 @@ __global__ __launch_bounds__(kThreads) void k_single_pass(const float* __restric
         int a1[4];
 #pragma unroll
         for (int k = 0; k < 4; ++k) { b1[k] = -__builtin_inff(); b2[k] = -__builtin_inff(); a1[k] = 0; }
+        int ly = 0;
+        mas_v2f l0y = mas_splat(0.f), l1y = mas_splat(0.f);
+        if (LOWRES) {
+            float u0, u1;
+            low_tap(lr.sh, y, ly, u0, u1);
+            ly -= low_r0;
+            l0y = mas_splat(u0);
+            l1y = mas_splat(u1);
+        }
 #pragma unroll
         for (int c = 0; c < CT; ++c) {
             if (EXACT || c < C) {
                 float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
                 const float* zc = zb + (size_t)c * HW;       // wave-uniform base, 32-bit lane offset
-                if (VEC) {
+                if (LOWRES) {
+                    // y = l0y * (l0x * v00 + l1x * v01) + l1y * (l0x * v10 + l1x * v11), every product and sum rounded once
+                    const float* r0 = s_low + (c * kLowRows + ly) * kLowCols;
+                    const float* r1 = r0 + kLowCols;
+                    const mas_v2f v00a = {r0[lx[0]], r0[lx[1]]}, v01a = {r0[lx[0] + 1], r0[lx[1] + 1]};
+                    const mas_v2f v10a = {r1[lx[0]], r1[lx[1]]}, v11a = {r1[lx[0] + 1], r1[lx[1] + 1]};
+                    const mas_v2f v00b = {r0[lx[2]], r0[lx[3]]}, v01b = {r0[lx[2] + 1], r0[lx[3] + 1]};
+                    const mas_v2f v10b = {r1[lx[2]], r1[lx[3]]}, v11b = {r1[lx[2] + 1], r1[lx[3] + 1]};
+                    const mas_v2f oa = l0y * (l0xa * v00a + l1xa * v01a) + l1y * (l0xa * v10a + l1xa * v11a);
+                    const mas_v2f ob = l0y * (l0xb * v00b + l1xb * v01b) + l1y * (l0xb * v10b + l1xb * v11b);
+                    t = make_float4(ok[0] ? oa.x : 0.f, ok[1] ? oa.y : 0.f, ok[2] ? ob.x : 0.f, ok[3] ? ob.y : 0.f);
+                } else if (VEC) {
                     if (ok[0]) t = *reinterpret_cast<const float4*>(zc + (unsigned)(row + xs[0]));
                 } else {
                     if (ok[0]) t.x = zc[row + xs[0]];
@@ -533,6 +601,52 @@ int launch(const float* z, const void* spx, int B, int C, int H, int W, int S, f
     return mas_launch_status();
 }
 
+template <int CT, bool EXACT, typename IdT>
+int launch_low(const float* zq, int h, int w, const void* spx, int B, int C, int H, int W, int S, float invT, mas_u64* prob_sum,
+               mas_u64* class_sum, unsigned* hist, hipStream_t st) {
+    const int tiles_x = (W + kTileW - 1) / kTileW;
+    const int tiles_y = (H + kTileH - 1) / kTileH;
+    const long long nblk = (long long)B * tiles_x * tiles_y;
+    if (nblk <= 0 || nblk > 0x7fffffffLL) return MAS_ERR_SHAPE;
+    const LowSrc lr{h, w, (float)h / (float)H, (float)w / (float)W};
+    // the LDS footprint holds kLowRows x kLowCols low-resolution elements per class: enough for a 16 x 256 tile when the
+    // ratio is >= ~3.8 in both directions (the model's is 4, or 769 / 193)
+    if ((double)kTileH * h / H + 2.0 > kLowRows || (double)kTileW * w / W + 2.0 > kLowCols) return MAS_ERR_RANGE;
+    const size_t smem = smem_bytes(C, CT) + sizeof(float) * (size_t)C * kLowRows * kLowCols;
+    const bool vec = (W % 4 == 0);
+    const IdT* ids = static_cast<const IdT*>(spx);
+    static bool attr_vec = false, attr_scalar = false;          // > 64 KB of dynamic LDS needs the attribute, once per kernel
+    if (vec) {
+        if (!attr_vec) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_single_pass<CT, EXACT, IdT, true, true>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+            attr_vec = true;
+        }
+        hipLaunchKernelGGL((k_single_pass<CT, EXACT, IdT, true, true>), dim3((unsigned)nblk), dim3(kThreads), smem, st, zq, ids, C, H, W, S,
+                           invT, tiles_x, tiles_y, prob_sum, class_sum, hist, lr);
+    } else {
+        if (!attr_scalar) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_single_pass<CT, EXACT, IdT, false, true>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+            attr_scalar = true;
+        }
+        hipLaunchKernelGGL((k_single_pass<CT, EXACT, IdT, false, true>), dim3((unsigned)nblk), dim3(kThreads), smem, st, zq, ids, C, H, W, S,
+                           invT, tiles_x, tiles_y, prob_sum, class_sum, hist, lr);
+    }
+    return mas_launch_status();
+}
+
+template <int CT, bool EXACT>
+int dispatch_low_ids(const float* zq, int h, int w, const void* spx, int spx_dtype, int B, int C, int H, int W, int S, float invT,
+                     mas_u64* prob_sum, mas_u64* class_sum, unsigned* hist, hipStream_t st) {
+    switch (spx_dtype) {
+        case MAS_ID_I64: return launch_low<CT, EXACT, long long>(zq, h, w, spx, B, C, H, W, S, invT, prob_sum, class_sum, hist, st);
+        case MAS_ID_I32: return launch_low<CT, EXACT, int>(zq, h, w, spx, B, C, H, W, S, invT, prob_sum, class_sum, hist, st);
+        case MAS_ID_U16: return launch_low<CT, EXACT, unsigned short>(zq, h, w, spx, B, C, H, W, S, invT, prob_sum, class_sum, hist, st);
+        default: return MAS_ERR_DTYPE;
+    }
+}
+
 template <int CT, bool EXACT>
 int dispatch_ids(const float* z, const void* spx, int spx_dtype, int B, int C, int H, int W, int S, float invT, mas_u64* prob_sum,
                  mas_u64* class_sum, unsigned* hist, hipStream_t st) {
@@ -559,6 +673,21 @@ extern "C" int mas_single_pass_accum(const float* z, const void* spx, int spx_dt
         case 20: return dispatch_ids<20, true>(z, spx, spx_dtype, B, C, H, W, S, invT, ps, cs, hist, st);
         case 21: return dispatch_ids<21, true>(z, spx, spx_dtype, B, C, H, W, S, invT, ps, cs, hist, st);
         default: return dispatch_ids<MAS_MAX_CLASSES, false>(z, spx, spx_dtype, B, C, H, W, S, invT, ps, cs, hist, st);
+    }
+}
+
+extern "C" int mas_single_pass_accum_lowres(const float* zq, int h, int w, const void* spx, int spx_dtype, int B, int C, int H, int W, int S,
+                                            float invT, uint64_t* prob_sum, uint64_t* class_sum, uint32_t* hist, void* stream) {
+    if (!zq || !spx || !prob_sum || !class_sum || !hist) return MAS_ERR_NULL;
+    if (B <= 0 || H <= 0 || W <= 0 || S <= 0 || h <= 0 || w <= 0 || h > H || w > W || (long long)H * W > (1LL << 23)) return MAS_ERR_SHAPE;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    mas_u64* ps = reinterpret_cast<mas_u64*>(prob_sum);
+    mas_u64* cs = reinterpret_cast<mas_u64*>(class_sum);
+    switch (C) {                 // (the generic 32-channel footprint would not fit the LDS budget: the Cityscapes / VOC channel counts only)
+        case 19: return dispatch_low_ids<19, true>(zq, h, w, spx, spx_dtype, B, C, H, W, S, invT, ps, cs, hist, st);
+        case 20: return dispatch_low_ids<20, true>(zq, h, w, spx, spx_dtype, B, C, H, W, S, invT, ps, cs, hist, st);
+        case 21: return dispatch_low_ids<21, true>(zq, h, w, spx, spx_dtype, B, C, H, W, S, invT, ps, cs, hist, st);
+        default: return MAS_ERR_CLASSES;
     }
 }
 

@@ -329,6 +329,8 @@ class DeepLabHeadV3PlusWN(nn.Module):
 
 
 class DeepLabV3PlusWN(nn.Module):
+    lowres_logits = True        # forward(x, lowres=True) returns the quarter-resolution logits (selectors / losses upsample in-kernel)
+
     def __init__(self, backbone, classifier):
         super().__init__()
         self.backbone = backbone

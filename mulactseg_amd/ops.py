@@ -383,6 +383,29 @@ def single_pass_accum(z, spx, S, invT, prob_sum=None, class_sum=None, hist=None)
     return prob_sum, class_sum, hist
 
 
+def single_pass_accum_lowres(zq, size, spx, S, invT, prob_sum=None, class_sum=None, hist=None):
+    """``single_pass_accum`` of ``F.interpolate(zq, size, 'bilinear', align_corners=False)`` without materialising it: ``zq``
+    [B,C,h,w] quarter-resolution logits, ``spx`` [B,H,W]; same outputs, bit for bit."""
+    _need(zq, "zq", torch.float32)
+    _need(spx, "spx")
+    B, C, h, w = zq.shape
+    H, W = int(size[0]), int(size[1])
+    if tuple(spx.shape) != (B, H, W):
+        raise ValueError("spx shape %s does not match logits %s at size %s" % (tuple(spx.shape), tuple(zq.shape), (H, W)))
+    dev = zq.device
+    if prob_sum is None:
+        prob_sum = torch.zeros((B, C), dtype=torch.int64, device=dev)
+    if class_sum is None:
+        class_sum = torch.zeros((B, S, C), dtype=torch.int64, device=dev)
+    if hist is None:
+        hist = torch.zeros((B, S, C), dtype=torch.int32, device=dev)
+    with torch.cuda.device(dev):
+        _lib.check(_lib.load().mas_single_pass_accum_lowres(zq.data_ptr(), h, w, spx.data_ptr(), _id_code(spx), B, C, H, W, S, invT,
+                                                            prob_sum.data_ptr(), class_sum.data_ptr(), hist.data_ptr(), _stream(zq)),
+                   "mas_single_pass_accum_lowres")
+    return prob_sum, class_sum, hist
+
+
 def region_finalize_weighted(class_sum, hist, w31, ban_class=-1, want_hist_i64=False):
     """Weighted mean per region from the single-pass accumulators.  ``w31``: int32 tensor [C] holding uint32 bits."""
     _need(class_sum, "class_sum", torch.int64)

@@ -268,3 +268,37 @@ def test_class_weight_kernel_bit_exact(n_img, batch, C, n_batches):
     from mulactseg_amd.active_selection.engine import class_weight_from_sums
     hcum, hw_ = class_weight_from_sums(ps.view(np.int64), hw, np.arange(n_img) // batch, n_batches, 6.0)
     assert np.array_equal(hcum.view(np.uint64), ecum.view(np.uint64)) and np.array_equal(hw_, ew)
+
+
+@pytest.mark.parametrize("B,C,h,w,H,W,S,dt", [(2, 20, 16, 64, 64, 256, 64, 'int64'), (1, 20, 35, 130, 140, 520, 300, 'int32'),
+                                              (1, 19, 193, 193, 769, 769, 2048, 'int16'), (2, 21, 12, 9, 48, 33, 40, 'int64'),
+                                              (1, 20, 256, 512, 1024, 2048, 2048, 'int16')])
+def test_lowres_scan_equals_the_scan_of_the_upsampled_logits(B, C, h, w, H, W, S, dt):
+    """K8: mas_single_pass_accum_lowres(zq) == mas_single_pass_accum(upsample_bilinear(zq)) bit for bit (class-probability sums,
+    per-(region, class) margin sums, histograms) -- odd sizes, the 769 / 193 ratio, partial tiles, all id types; and against
+    oracle/exact.c on the C-upsampled tensor for the small cases."""
+    from mulactseg_amd import ops
+    zq = synth.logits(11 + h, B, C, h, w)
+    spx = np.stack([synth.superpixel_map(300 + i, H, W, S) for i in range(B)])
+    invT = ops.inv_temperature(0.1)
+    zt = torch.from_numpy(zq).cuda()
+    st = torch.from_numpy(spx).cuda().to(getattr(torch, dt))
+    full = ops.upsample_bilinear(zt, (H, W))
+    a = ops.single_pass_accum(full, st, S, invT)
+    b = ops.single_pass_accum_lowres(zt, (H, W), st, S, invT)
+    for x, y in zip(a, b):
+        assert torch.equal(x, y)
+    if H * W <= 520 * 140:
+        from oracle import exact
+        e = exact.single_pass_accum(exact.upsample_bilinear(zq, H, W), spx, S, np.float32(invT))
+        assert np.array_equal(b[0].cpu().numpy().view(np.uint64), e[0])
+        assert np.array_equal(b[1].cpu().numpy().view(np.uint64), e[1])
+        assert np.array_equal(b[2].cpu().numpy().view(np.uint32), e[2])
+
+
+def test_lowres_scan_refuses_ratios_it_has_no_footprint_for():
+    from mulactseg_amd import _lib, ops
+    zq = torch.zeros((1, 20, 32, 32), device='cuda')
+    spx = torch.zeros((1, 64, 64), dtype=torch.int64, device='cuda')
+    with pytest.raises(_lib.MulActSegHipError):
+        ops.single_pass_accum_lowres(zq, (64, 64), spx, 8, 10.0)
