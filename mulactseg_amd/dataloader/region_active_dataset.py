@@ -90,15 +90,17 @@ class RegionActiveDataset:
             if st is None:
                 key = joined.split(",")
                 spx_path = key[2]
-                st = leaving[joined] = (key, self._image_index(spx_path), set(), set(pool.suppix[spx_path]))
+                # membership of an id in the pool list: the valid table answers it when it exists, else a set of the list
+                st = leaving[joined] = (key, self._image_index(spx_path), set(), None if self._valid is not None else set(pool.suppix[spx_path]))
                 if tuple(key) not in listed:
                     listed.add(tuple(key))
                     label.im_idx.append(key)
                     label.suppix[spx_path] = []
             key, row, gone, present = st
-            if suppix_id not in present:
+            if (self._valid[row, suppix_id] == 0) if present is None else (suppix_id not in present):
                 raise ValueError("list.remove(x): x not in list")            # what pool.suppix[path].remove(id) raises (:46)
-            present.discard(suppix_id)
+            if present is not None:
+                present.discard(suppix_id)
             gone.add(suppix_id)
             label.suppix[key[2]].append(suppix_id)
             if has_sel:
@@ -115,8 +117,13 @@ class RegionActiveDataset:
         emptied = set()
         for key, row, gone, present in leaving.values():
             spx_path = key[2]
-            if present:
-                pool.suppix[spx_path] = [i for i in pool.suppix[spx_path] if i not in gone]
+            lst = pool.suppix[spx_path]
+            if len(gone) < len(lst):
+                if len(gone) <= 4:                      # a handful: list.remove keeps the order and runs at C speed
+                    for i in gone:
+                        lst.remove(i)
+                else:
+                    pool.suppix[spx_path] = [i for i in lst if i not in gone]
             else:
                 pool.suppix.pop(spx_path)
                 emptied.add(tuple(key))
