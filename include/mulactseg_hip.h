@@ -385,13 +385,20 @@ int mas_conv1x1_fwd(const float* x, const float* w_t, int N, int K, int M, int H
  *       y[n,m,oy,ox] = sum_c w[m,c] * x[n,c, oy*stride, ox*stride]                                     (ksize 1)
  * with Ho = (H-1)/stride + 1.  `wt` is the re-arranged weight [Cin/CK][KC/8][2][Cout][4], KC = ksize*ksize*CK,
  * CK = mas_conv_chunk(ksize, Cin) (0 = unsupported channel count): element (chunk, q, h, m, j) is
- * w[m, chunk*CK + 2*cp + h, tap] with k-step kk = 4*q + j, tap = kk / (CK/2), cp = kk % (CK/2); Cout % 64 == 0.  With scale / shift (both or neither)
+ * w[m, chunk*CK + 2*cp + h, tap] with k-step kk = 4*q + j, tap = kk / (CK/2), cp = kk % (CK/2); the M extent of `wt` is
+ * Cout rounded up to a multiple of 64 (zero rows), y / residual / scale / shift have Cout channels.  With scale / shift (both or neither)
  * the epilogue applies y*scale[m] + shift[m] (inference BatchNorm), then `residual` (NULL or [N,Cout,Ho,Wo]) is added
  * and, if `relu`, max(.,0) taken -- the conv-bn-relu / conv-bn-add-relu triples of
  * models/segmentation/backbone/resnet.py:143-160 and the 1x1 projections of deeplabv3.py:85-137,216-245 in one kernel. */
 int mas_conv_chunk(int ksize, int Cin);
 int mas_conv_fwd(const float* x, const float* wt, int N, int Cin, int H, int W, int Cout, int ksize, int stride, int dil,
                  const float* scale, const float* shift, const float* residual, int relu, float* y, void* stream);
+
+/* The first convolution of the deep stem (models/segmentation/backbone/resnet.py:163-171, conv1[0..2]): x [N,3,H,W] ->
+ * y [N,Cout,(H-1)/2+1,(W-1)/2+1], 3x3, stride 2, padding 1, w [Cout,3,3,3] as PyTorch stores it, optional inference BatchNorm
+ * (scale / shift, both or neither) and ReLU in the epilogue.  Cout % 16 == 0, W % 8 == 0, 16-byte aligned tensors. */
+int mas_stem_conv_fwd(const float* x, const float* w, int N, int H, int W, int Cout, const float* scale, const float* shift, int relu,
+                      float* y, void* stream);
 
 #ifdef __cplusplus
 }

@@ -60,6 +60,7 @@ SIGNATURES = {
     "mas_maxpool3s2_fwd": (_i, [_vp, _i64, _i, _i, _vp, _vp, _vp]),
     "mas_maxpool3s2_bwd": (_i, [_vp, _vp, _i64, _i, _i, _vp, _vp]),
     "mas_conv1x1_fwd": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _i, _vp, _vp]),
+    "mas_stem_conv_fwd": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _i, _vp, _vp]),
     "mas_conv_chunk": (_i, [_i, _i]),
     "mas_conv_fwd": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _i, _vp, _vp]),
     "mas_depthwise3x3_fwd": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp, _vp]),

@@ -32,7 +32,7 @@ struct ConvP {
     const float* shift;
     const float* res;
     float* y;
-    int Cin, H, W, Cout, Ho, Wo, stride, dil, pad, relu;
+    int Cin, H, W, Cout, CoutP, Ho, Wo, stride, dil, pad, relu;      // CoutP = Cout rounded up to 64: the M extent of the packed weight
     int tw_log2, TH;                    // output tile: TH rows x (1 << tw_log2) columns, TH << tw_log2 == BN
     int tiles_x, tiles_y, ptiles, mtiles;
     int PH, PW, CS;                     // LDS input patch: rows, columns, channel stride (floats)
@@ -72,7 +72,7 @@ __device__ __forceinline__ void conv_stage(float* __restrict__ sW, float* __rest
     }
 }
 
-template <int TAPS, int CK, int BM, int BN, int NXMAX, bool VEC, bool RES>
+template <int TAPS, int CK, int BM, int BN, int NXMAX, bool VEC, bool RES, bool MPAD>
 __global__ __launch_bounds__(kThreads, 2) void k_conv_mfma(const ConvP p) {
     constexpr int WM = BM / 64, WN = 4 / WM, TN = BN / WN / 32;
     constexpr int KC = TAPS * CK;
@@ -132,7 +132,7 @@ __global__ __launch_bounds__(kThreads, 2) void k_conv_mfma(const ConvP p) {
         int f = tid + j * kThreads;
         if (f >= W4) f = W4 - 1;                        // clamped duplicate (same value written twice)
         const int row = f / BM, m = f - row * BM;          // row = (k-step / 4) * 2 + lane half
-        woff[j] = (row * p.Cout + m) * 4;
+        woff[j] = (row * p.CoutP + m) * 4;
     }
 
     // ---- MFMA operand addressing ---------------------------------------------------------------------------------------
@@ -161,8 +161,9 @@ __global__ __launch_bounds__(kThreads, 2) void k_conv_mfma(const ConvP p) {
     v4f xr[NXMAX];
 
     if (tid < BM) {
-        sE[tid] = p.scale ? p.scale[m0 + tid] : 1.0f;
-        sE[BM + tid] = p.scale ? p.shift[m0 + tid] : 0.0f;
+        const bool real = !MPAD || m0 + tid < p.Cout;   // rows of the 64-padding carry zero weights and are never stored
+        sE[tid] = (p.scale && real) ? p.scale[m0 + tid] : 1.0f;
+        sE[BM + tid] = (p.scale && real) ? p.shift[m0 + tid] : 0.0f;
     }
     // epilogue geometry (needed early: the residual values are fetched while the last chunk's MFMAs run)
     const int HWo = p.Ho * p.Wo;
@@ -202,7 +203,7 @@ __global__ __launch_bounds__(kThreads, 2) void k_conv_mfma(const ConvP p) {
     for (int t = 0; t + 1 < nchunks; ++t) {
         conv_stage<NW, NXMAX, VEC, W4>(sW, sX, tid, loff, live, ok, wr, xr);
         __syncthreads();
-        conv_fetch<NW, NXMAX, VEC>(xb + (size_t)(t + 1) * CK * HW, wb + (size_t)(t + 1) * KC * p.Cout, woff, goff, wr, xr);
+        conv_fetch<NW, NXMAX, VEC>(xb + (size_t)(t + 1) * CK * HW, wb + (size_t)(t + 1) * KC * p.CoutP, woff, goff, wr, xr);
         mfma_chunk();
         __syncthreads();
     }
@@ -222,10 +223,14 @@ __global__ __launch_bounds__(kThreads, 2) void k_conv_mfma(const ConvP p) {
 #pragma unroll
         for (int tm = 0; tm < 2; ++tm) {
             const int mb = wm * 64 + tm * 32 + 4 * h;
+            const int mlim = MPAD ? p.Cout - m0 : (1 << 30);    // rows >= mlim are padding (MPAD: Cout % 64 != 0)
             float out[16], rv[16];
             if (RES) {
 #pragma unroll
-                for (int r = 0; r < 16; ++r) rv[r] = rb[(size_t)(mb + (r & 3) + 8 * (r >> 2)) * HWo + po[tn]];
+                for (int r = 0; r < 16; ++r) {
+                    const int m = mb + (r & 3) + 8 * (r >> 2);
+                    rv[r] = rb[(size_t)(m < mlim ? m : 0) * HWo + po[tn]];
+                }
             }
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
@@ -236,7 +241,10 @@ __global__ __launch_bounds__(kThreads, 2) void k_conv_mfma(const ConvP p) {
             }
             if (inside[tn]) {
 #pragma unroll
-                for (int r = 0; r < 16; ++r) yb[(size_t)(mb + (r & 3) + 8 * (r >> 2)) * HWo + po[tn]] = out[r];
+                for (int r = 0; r < 16; ++r) {
+                    const int m = mb + (r & 3) + 8 * (r >> 2);
+                    if (m < mlim) yb[(size_t)m * HWo + po[tn]] = out[r];
+                }
             }
         }
     }
@@ -248,14 +256,14 @@ inline int ilog2(int v) {
     return l;
 }
 
-template <int TAPS, int CK, int BM, int BN, int NXMAX, bool VEC, bool RES>
+template <int TAPS, int CK, int BM, int BN, int NXMAX, bool VEC, bool RES, bool MPAD>
 int launch_res(ConvP p, int N, hipStream_t st) {
     const int TW = 1 << p.tw_log2;
     p.TH = BN / TW;
     p.tiles_x = (p.Wo + TW - 1) / TW;
     p.tiles_y = (p.Ho + p.TH - 1) / p.TH;
     p.ptiles = N * p.tiles_x * p.tiles_y;
-    p.mtiles = p.Cout / BM;
+    p.mtiles = p.CoutP / BM;
     if (TAPS == 1) {
         p.PH = p.TH;
         p.PW = TW;
@@ -272,20 +280,25 @@ int launch_res(ConvP p, int N, hipStream_t st) {
     if (smem > 64 * 1024) {
         static bool once = false;                      // above the default dynamic-LDS limit: raise it once per instantiation
         if (!once) {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv_mfma<TAPS, CK, BM, BN, NXMAX, VEC, RES>),
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv_mfma<TAPS, CK, BM, BN, NXMAX, VEC, RES, MPAD>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
             once = true;
         }
     }
     const long long nblk = 8LL * ((p.ptiles + 7) / 8) * p.mtiles;
     if (nblk <= 0 || nblk > 0x7fffffffLL) return MAS_ERR_SHAPE;
-    hipLaunchKernelGGL((k_conv_mfma<TAPS, CK, BM, BN, NXMAX, VEC, RES>), dim3((unsigned)nblk), dim3(kThreads), smem, st, p);
+    hipLaunchKernelGGL((k_conv_mfma<TAPS, CK, BM, BN, NXMAX, VEC, RES, MPAD>), dim3((unsigned)nblk), dim3(kThreads), smem, st, p);
     return mas_launch_status();
 }
 
 template <int TAPS, int CK, int BM, int BN, int NXMAX, bool VEC>
 int launch(ConvP p, int N, hipStream_t st) {
-    return p.res ? launch_res<TAPS, CK, BM, BN, NXMAX, VEC, true>(p, N, st) : launch_res<TAPS, CK, BM, BN, NXMAX, VEC, false>(p, N, st);
+    if constexpr (BM == 64) {           // output-channel counts that are not a multiple of 64 always take a 64-row M tile
+        if (p.Cout % 64 != 0)
+            return p.res ? launch_res<TAPS, CK, BM, BN, NXMAX, VEC, true, true>(p, N, st) : launch_res<TAPS, CK, BM, BN, NXMAX, VEC, false, true>(p, N, st);
+    }
+    if (p.Cout % 64 != 0) return MAS_ERR_SHAPE;
+    return p.res ? launch_res<TAPS, CK, BM, BN, NXMAX, VEC, true, false>(p, N, st) : launch_res<TAPS, CK, BM, BN, NXMAX, VEC, false, false>(p, N, st);
 }
 }  // namespace
 
@@ -302,16 +315,16 @@ extern "C" int mas_conv_fwd(const float* x, const float* wt, int N, int Cin, int
     if (N <= 0 || Cin <= 0 || H <= 0 || W <= 0 || Cout <= 0) return MAS_ERR_SHAPE;
     if ((ksize != 1 && ksize != 3) || (stride != 1 && stride != 2) || dil < 1 || dil > 4) return MAS_ERR_RANGE;
     if (ksize == 1 && dil != 1) return MAS_ERR_RANGE;
-    if (Cout % 64 != 0 || mas_conv_chunk(ksize, Cin) == 0) return MAS_ERR_SHAPE;
+    if (mas_conv_chunk(ksize, Cin) == 0) return MAS_ERR_SHAPE;
     if ((long long)Cin * H * W > 0x7fffffffLL) return MAS_ERR_SHAPE;
     hipStream_t st = static_cast<hipStream_t>(stream);
     ConvP p;
     p.x = x; p.wt = wt; p.scale = scale; p.shift = shift; p.res = residual; p.y = y;
-    p.Cin = Cin; p.H = H; p.W = W; p.Cout = Cout;
+    p.Cin = Cin; p.H = H; p.W = W; p.Cout = Cout; p.CoutP = (Cout + 63) / 64 * 64;
     p.stride = stride; p.dil = dil; p.pad = ksize == 3 ? dil : 0; p.relu = relu;
     p.Ho = (H - 1) / stride + 1;
     p.Wo = (W - 1) / stride + 1;
-    const bool big_m = Cout % 128 == 0;
+    const bool big_m = p.CoutP % 128 == 0 && Cout % 64 == 0;
     // tile width: 32 columns when the plane has them, 16 for the 48 / 49-wide planes of the deep layers
     const int TW = p.Wo >= 32 ? 32 : 16;
     p.tw_log2 = ilog2(TW);

@@ -66,6 +66,17 @@ def _conv_bn_act(conv, bn, x, relu=True, residual=None):
         if x.shape[2] * x.shape[3] >= 256 and ops.conv_mfma_supported(conv, x):
             _took("conv_bn_act", "hip_mfma")
             return ops.conv_mfma(conv, x, bn, relu, residual)
+        if residual is None and ops.stem_conv_supported(conv, x):          # 3 -> 64, stride 2: output-bound, packed-f32 kernel
+            _took("conv_bn_act", "hip_stem")
+            return ops.stem_conv(conv, x, bn, relu)
+        if (residual is None and x.shape[2] * x.shape[3] == 1 and conv.kernel_size == (1, 1) and conv.groups == 1 and conv.bias is None
+                and x.dtype == torch.float32):
+            # a 1x1 convolution of a 1x1 map (the ASPP image-pooling branch) is a [N,K] x [K,M] product: rocBLAS, no MIOpen
+            # solver search for every new batch size
+            _took("conv_bn_act", "gemm")
+            scale, shift = ops._bn_fold(bn)
+            y = torch.addmm(shift, x.flatten(1), (conv.weight.flatten(1) * scale[:, None]).t())
+            return (F.relu(y) if relu else y)[:, :, None, None]
     _took("conv_bn_act", "miopen+bn")
     return _bn_act(bn, conv(x), relu, residual)
 

@@ -895,7 +895,7 @@ def conv1x1_bn_act(conv, bn, x, relu=True, residual=None):
 # ------------------------------------------------------------------------------------------------
 def conv_mfma_supported(conv, x):
     """Shapes the implicit-GEMM MFMA kernel takes: 1x1 / 3x3, stride 1 or 2 (3x3 stride 2 only undilated), padding =
-    dilation for 3x3, no groups, no bias, Cout % 64 == 0, Cin % 8 (3x3) / % 16 (1x1) == 0, fp32 NCHW on the GPU."""
+    dilation for 3x3, no groups, no bias, Cin % 8 (3x3) / % 16 (1x1) == 0 (any Cout: padded to 64 inside), fp32 NCHW on the GPU."""
     if not (x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and conv.groups == 1 and conv.bias is None):
         return False
     k, s, d, pd = conv.kernel_size, conv.stride, conv.dilation, conv.padding
@@ -905,7 +905,7 @@ def conv_mfma_supported(conv, x):
         return False
     if k[0] == 1 and (pd[0] != 0 or d[0] != 1):
         return False
-    if conv.out_channels % 64 != 0 or x.shape[1] != conv.in_channels:
+    if x.shape[1] != conv.in_channels:
         return False
     return _lib.load().mas_conv_chunk(k[0], conv.in_channels) > 0 and conv.in_channels * x.shape[2] * x.shape[3] < 2 ** 31
 
@@ -925,7 +925,11 @@ def _conv_packed_weight(conv):
             M, K, kh, kw = conv.weight.shape
             ck = _lib.load().mas_conv_chunk(kh, K)
             taps = kh * kw
-            w = conv.weight.detach().reshape(M, K // ck, ck // 2, 2, taps)          # [m, chunk, cp, h, tap]
+            w = conv.weight.detach()
+            if M % 64:                                              # output channels padded to 64 with zero rows (never stored)
+                w = torch.cat([w, w.new_zeros((64 - M % 64, K, kh, kw))], dim=0)
+                M = w.shape[0]
+            w = w.reshape(M, K // ck, ck // 2, 2, taps)                             # [m, chunk, cp, h, tap]
             w = w.permute(1, 4, 2, 3, 0).reshape(K // ck, taps * ck // 2, 2, M)     # [chunk, kk = tap * ck/2 + cp, h, m]
             w = w.reshape(K // ck, taps * ck // 8, 4, 2, M).permute(0, 1, 3, 4, 2).contiguous()     # [chunk, q, h, m, j]
         cache = conv._mas_conv_pack = (key, w)
@@ -962,4 +966,26 @@ def conv_mfma(conv, x, bn=None, relu=False, residual=None):
     with torch.cuda.device(x.device):
         _lib.check(_lib.load().mas_conv_fwd(x.data_ptr(), wt.data_ptr(), N, K, H, W, M, ks, s, d, _opt(scale), _opt(shift), _opt(res),
                                             int(relu), y.data_ptr(), _stream(x)), "mas_conv_fwd")
+    return y
+
+
+def stem_conv_supported(conv, x):
+    """The deep stem's first convolution (3 -> C, 3x3, stride 2, padding 1) on csrc/stem.hip: fp32 NCHW, W % 8 == 0."""
+    return (x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and x.shape[1] == 3 and conv.in_channels == 3
+            and conv.kernel_size == (3, 3) and conv.stride == (2, 2) and conv.padding == (1, 1) and conv.dilation == (1, 1)
+            and conv.groups == 1 and conv.bias is None and conv.out_channels % 16 == 0 and x.shape[3] % 8 == 0
+            and x.shape[0] * (conv.out_channels // 16) <= 65535)
+
+
+def stem_conv(conv, x, bn=None, relu=False):
+    """relu?(bn(conv(x))) for the stem's first convolution in one kernel (inference)."""
+    x = x.contiguous()
+    N, _, H, W = x.shape
+    M = conv.out_channels
+    scale, shift = _bn_fold(bn) if bn is not None else (None, None)
+    y = torch.empty((N, M, (H - 1) // 2 + 1, (W - 1) // 2 + 1), dtype=torch.float32, device=x.device)
+    w = conv.weight.detach().contiguous()
+    with torch.cuda.device(x.device):
+        _lib.check(_lib.load().mas_stem_conv_fwd(x.data_ptr(), w.data_ptr(), N, H, W, M, _opt(scale), _opt(shift), int(relu), y.data_ptr(),
+                                                 _stream(x)), "mas_stem_conv_fwd")
     return y

@@ -24,6 +24,8 @@ CASES = [
     (512, 512, 3, 1, 2, 1, 13, 24),      # layer4 conv2: dilation 2, 16-wide tiles
     (256, 256, 3, 1, 2, 1, 9, 40),       # dilation 2, 32-wide tiles
     (8, 64, 3, 1, 1, 1, 5, 7),           # one chunk, plane smaller than a tile
+    (256, 48, 1, 1, 1, 2, 20, 36),       # decoder low-level projection: Cout padded to 64 inside, 48 rows stored
+    (64, 200, 3, 1, 1, 1, 9, 33),        # Cout 200 -> 256: the last M tile is half padding
 ]
 
 
@@ -92,3 +94,23 @@ def test_packed_weight_cache_follows_the_parameter():
         conv.weight.mul_(2.0)
         b = ops.conv_mfma(conv, x)
     assert torch.allclose(b, 2 * a, rtol=1e-6, atol=1e-6)
+
+
+@pytest.mark.parametrize("N,H,W,Cout,relu", [(2, 64, 96, 64, True), (1, 37, 40, 64, True), (1, 1024, 2048, 64, True), (3, 16, 8, 32, False)])
+def test_stem_conv_matches_conv2d(N, H, W, Cout, relu):
+    """csrc/stem.hip (3 -> C, 3x3, stride 2, padding 1, BatchNorm + ReLU epilogue) against conv2d + BatchNorm in float64; odd
+    heights, the left / right / top / bottom borders, the full Cityscapes picture."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from mulactseg_amd import ops
+    torch.manual_seed(H + W)
+    conv = nn.Conv2d(3, Cout, 3, stride=2, padding=1, bias=False).cuda()
+    bn = nn.BatchNorm2d(Cout).cuda().eval()
+    with torch.no_grad():
+        bn.weight.uniform_(0.5, 1.5); bn.bias.normal_(); bn.running_mean.normal_(); bn.running_var.uniform_(0.5, 2.0)
+        x = torch.randn(N, 3, H, W, device='cuda')
+        assert ops.stem_conv_supported(conv, x)
+        y = ops.stem_conv(conv, x, bn, relu)
+        ref = _ref(x.double(), conv.double(), bn.double(), relu, None)
+    assert y.shape == ref.shape
+    assert float((y.double() - ref).abs().max()) <= 2e-5 * float(ref.abs().max())
