@@ -55,7 +55,7 @@ def parse():
     ap.add_argument("--nseg", type=int, default=2048)
     ap.add_argument("--id-dtype", default="int64", choices=["int64", "int32", "int16"],
                     help="superpixel id element type (the reference data layer yields int64)")
-    ap.add_argument("--ramp", type=int, default=100, help="untimed launches before the warm-up steps (GPU clock ramp)")
+    ap.add_argument("--ramp", type=int, default=500, help="untimed launches before the warm-up steps (GPU clock ramp: 100 launches leave the scan ~6 % slower than 400+, tools/ramp_probe.sh)")
     ap.add_argument("--nbuf", type=int, default=3, help="distinct resident batches rotated through")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-train", action="store_true", help="skip the model legs (train-iter, acquisition with model, stage 2)")
