@@ -66,3 +66,28 @@ def test_get_model_surface():
         get_model('deeplabv3pluswn_resnet50deepstem', 20, 16, True)            # reference: ./checkpoint/resnet50_deepstem.pth
     with pytest.raises(NotImplementedError):
         get_model('deeplabv3_mobilenet', 20, 16, True)
+
+
+@pytest.mark.gpu
+def test_inference_forward_runs_on_this_packages_kernels_and_matches_the_cpu_modules():
+    """Aligned picture size (the Cityscapes / crop sizes): every dense convolution of the eval forward takes a kernel of this
+    package (k_conv_mfma with the BatchNorm epilogue, k_stem_conv, k_conv1x1, a GEMM for the pooled 1x1) -- no MIOpen
+    convolution, no separate BatchNorm pass -- and the logits equal the plain PyTorch modules on the CPU to 1e-4."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from mulactseg_amd.models import deeplab
+    g, net, _ = _load()
+    x = torch.from_numpy(np.random.RandomState(5).standard_normal(size=(2, 3, 128, 256)).astype(np.float32))
+    with torch.no_grad():
+        ref_full = net(x)
+        ref_q = net(x, lowres=True)
+        dev = net.cuda()
+        deeplab.path_report(reset=True)
+        out_full = dev(x.cuda())
+        paths = deeplab.path_report(reset=True)
+        out_q = dev(x.cuda(), lowres=True)
+    assert 'miopen+bn' not in paths.get('conv_bn_act', {}), paths
+    assert paths['conv_bn_act'].get('hip_mfma', 0) >= 55 and paths['conv_bn_act'].get('hip_stem', 0) == 1
+    assert 'aten' not in paths.get('bn_act', {}) and 'aten' not in paths.get('upsample', {})
+    assert float((out_full.cpu() - ref_full).abs().max()) < 1e-4
+    assert float((out_q.cpu() - ref_q).abs().max()) < 1e-4
