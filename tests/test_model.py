@@ -77,7 +77,7 @@ def test_inference_forward_runs_on_this_packages_kernels_and_matches_the_cpu_mod
         pytest.skip("needs a GPU")
     from mulactseg_amd.models import deeplab
     g, net, _ = _load()
-    x = torch.from_numpy(np.random.RandomState(5).standard_normal(size=(2, 3, 128, 256)).astype(np.float32))
+    x = torch.from_numpy(np.random.RandomState(5).standard_normal(size=(1, 3, 256, 512)).astype(np.float32))
     with torch.no_grad():
         ref_full = net(x)
         ref_q = net(x, lowres=True)

@@ -32,7 +32,7 @@ if len(ends) >= 22:
     table(ends[4], ends[10], 6, "train step, crop 768: steady-state kernel breakdown (last 6 steps)", 'gpurun_out/c_train_768_steady.md')
     table(ends[15], ends[21], 6, "train step, crop 769: steady-state kernel breakdown (last 6 steps)", 'gpurun_out/d_train_769_steady.md')
 PY
-python profiles/steady.py gpurun_out/tr2/t_kernel_trace.csv k_single_pass 5 gpurun_out/e_pool_forward_steady.md "rocprofv3 --kernel-trace -- python bench.py --no-cpu-baseline --no-pool --steps 2 --warmup 1 --ramp 0 --train-steps 8 --acq-steps 8 (acquisition_with_model leg)" | head -30
+python profiles/steady.py gpurun_out/tr2/t_kernel_trace.csv k_cosine_fwd4 5 gpurun_out/e_pool_forward_steady.md "rocprofv3 --kernel-trace -- python bench.py --no-cpu-baseline --no-pool --steps 2 --warmup 1 --ramp 0 --train-steps 8 --acq-steps 8 (acquisition_with_model leg)" | head -30
 rm -rf gpurun_out/mf2 && rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F32 GRBM_GUI_ACTIVE --output-format csv -d gpurun_out/mf2 -o m -- python bench.py --no-cpu-baseline --no-pool --no-trainleg --steps 2 --warmup 1 --ramp 0 --acq-steps 4 > /dev/null 2>&1
 python - <<'PY'
 import csv, collections, sys
@@ -44,9 +44,9 @@ for r in cc:
     e = disp.setdefault(int(r['Dispatch_Id']), {'name': r['Kernel_Name']})
     e[r['Counter_Name']] = e.get(r['Counter_Name'], 0.0) + float(r['Counter_Value'])
 ids = sorted(disp)
-marks = [i for i in ids if 'k_single_pass' in disp[i]['name']]
-# the acquisition leg's scans come last: a forward + scan per step; keep the last 3 steps
-a, b = marks[-4], marks[-1]
+marks = [i for i in ids if 'k_cosine_fwd4' in disp[i]['name']]
+# one cosine-head launch per forward; the acquisition leg's forwards come last: keep 3 whole steps before the last head launch
+a, b = marks[-5], marks[-2]
 acc = collections.defaultdict(lambda: collections.defaultdict(float))
 for i in ids:
     if a < i <= b:
