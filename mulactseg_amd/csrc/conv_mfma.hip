@@ -324,10 +324,16 @@ extern "C" int mas_conv_fwd(const float* x, const float* wt, int N, int Cin, int
     p.stride = stride; p.dil = dil; p.pad = ksize == 3 ? dil : 0; p.relu = relu;
     p.Ho = (H - 1) / stride + 1;
     p.Wo = (W - 1) / stride + 1;
-    const bool big_m = p.CoutP % 128 == 0 && Cout % 64 == 0;
     // tile width: 32 columns when the plane has them, 16 for the 48 / 49-wide planes of the deep layers
     const int TW = p.Wo >= 32 ? 32 : 16;
     p.tw_log2 = ilog2(TW);
+    // Tile choice.  The chip holds 512 workgroups at a time (2 per CU); a launch with fewer than ~640 leaves matrix pipes idle for
+    // its whole duration, so small planes (crop-sized inputs, the deep layers) trade operand reuse for workgroups: 64-row M
+    // tiles instead of 128, 128-pixel tiles instead of 256.
+    const long long px128 = (long long)N * ((p.Ho + 128 / TW - 1) / (128 / TW)) * ((p.Wo + TW - 1) / TW);
+    const long long px256 = (long long)N * ((p.Ho + 256 / TW - 1) / (256 / TW)) * ((p.Wo + TW - 1) / TW);
+    const bool big_m = p.CoutP % 128 == 0 && Cout % 64 == 0 && px128 * (p.CoutP / 128) >= 640;
+    const bool wide_n = px256 * (p.CoutP / 64) >= 640;         // (for the 64-row tiles) 256-pixel tiles only when there are enough of them
     if (ksize == 1) {
         const bool vec = stride == 1 && (W % 4 == 0) && ((uintptr_t)x % 16 == 0);
         const int ck = mas_conv_chunk(1, Cin);
@@ -335,15 +341,17 @@ extern "C" int mas_conv_fwd(const float* x, const float* wt, int N, int Cin, int
         // channel pairs in order.  64-channel chunks, half the barriers per MFMA, were measured: 256 VGPRs, 3 % SLOWER.)
         if (ck == 32) {
             if (big_m) return vec ? launch<1, 32, 128, 128, 4, true>(p, N, st) : launch<1, 32, 128, 128, 16, false>(p, N, st);
-            return vec ? launch<1, 32, 64, 256, 8, true>(p, N, st) : launch<1, 32, 64, 128, 16, false>(p, N, st);
+            if (!vec) return launch<1, 32, 64, 128, 16, false>(p, N, st);
+            return wide_n ? launch<1, 32, 64, 256, 8, true>(p, N, st) : launch<1, 32, 64, 128, 4, true>(p, N, st);
         }
         if (big_m) return vec ? launch<1, 16, 128, 128, 2, true>(p, N, st) : launch<1, 16, 128, 128, 8, false>(p, N, st);
-        return vec ? launch<1, 16, 64, 256, 4, true>(p, N, st) : launch<1, 16, 64, 128, 8, false>(p, N, st);
+        if (!vec) return launch<1, 16, 64, 128, 8, false>(p, N, st);
+        return wide_n ? launch<1, 16, 64, 256, 4, true>(p, N, st) : launch<1, 16, 64, 128, 2, true>(p, N, st);
     }
     if (stride == 2) {
         if (dil != 1) return MAS_ERR_RANGE;
         return big_m ? launch<9, 8, 128, 128, 20, false>(p, N, st) : launch<9, 8, 64, 128, 20, false>(p, N, st);
     }
     if (big_m) return launch<9, 8, 128, 128, 9, false>(p, N, st);
-    return dil == 1 ? launch<9, 8, 64, 256, 12, false>(p, N, st) : launch<9, 8, 64, 128, 12, false>(p, N, st);
+    return (dil == 1 && wide_n) ? launch<9, 8, 64, 256, 12, false>(p, N, st) : launch<9, 8, 64, 128, 12, false>(p, N, st);
 }
