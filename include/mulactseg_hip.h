@@ -136,6 +136,15 @@ int mas_loss_values(const uint64_t* acc, int flags, float* losses /* [3] */, voi
  * training step needs no host synchronisation between forward and backward). */
 int mas_loss_scales(const uint64_t* acc, const float* grad_out /* [3] */, int flags, float* scale /* [3] */, void* stream);
 
+/* The trainer's objective and its chain rule in the same two launches (fewer, smaller kernels around the scans):
+ *   losses4 = (ce, mc, group, (w[0]*ce + w[1]*mc) + w[2]*group)      -- `coeff*ce + coeff_mc*mc + coeff_gm*group`,
+ *                                                                        trainer/active_joint_multi_predignore_lossdecomp.py:104
+ *   scale[k] = (grad_total * w[k]) / (1 + n_k)                        -- what mas_partial_loss_bwd[_lowres] multiplies in.
+ * weights, grad_total: device pointers (3 floats / 1 float). */
+int mas_loss_values_weighted(const uint64_t* acc, int flags, const float* weights /* [3] */, float* losses4 /* [4] */, void* stream);
+int mas_loss_scales_weighted(const uint64_t* acc, const float* grad_total /* [1] */, const float* weights /* [3] */, int flags,
+                             float* scale /* [3] */, void* stream);
+
 /* Backward scan: writes dz [N,C,H,W] completely (zeros outside the mask).  Autograd equivalent of the
  * reference losses; the group loss sends gradient only to the arg-max pixel of each (superpixel, class)
  * (torch_scatter scatter_max backward). */

@@ -74,6 +74,8 @@ SIGNATURES = {
     "mas_partial_loss_bwd": (_i, [_vp, _vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _i, _vp, _vp]),
     "mas_partial_loss_fwd_lowres": (_i, [_vp, _i, _i, _vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _f, _i, _vp, _vp, _vp]),
     "mas_partial_loss_bwd_lowres": (_i, [_vp, _i, _i, _vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _i, _vp, _vp]),
+    "mas_loss_values_weighted": (_i, [_vp, _i, _vp, _vp, _vp]),
+    "mas_loss_scales_weighted": (_i, [_vp, _vp, _vp, _i, _vp, _vp]),
     "mas_fix_to_float": (_i, [_vp, _i64, _i, _vp, _vp]),
 }
 

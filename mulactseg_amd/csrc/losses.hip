@@ -319,6 +319,42 @@ __global__ void k_loss_values(const mas_u64* __restrict__ acc, int flags, float*
     out[2] = loss_value(acc[ACC_SUM_GROUP], acc[ACC_N_GROUP]);
 }
 
+// The trainer's objective in the same launch: total = (w_ce * ce + w_mc * mc) + w_group * group, every product and sum rounded
+// once in f32 -- the operation order of `coeff * ce_loss + coeff_mc * mc_loss + coeff_gm * group_loss`
+// (trainer/active_joint_multi_predignore_lossdecomp.py:104), so the value equals the torch expression bit for bit.
+__global__ void k_loss_values_weighted(const mas_u64* __restrict__ acc, int flags, const float* __restrict__ w, float* __restrict__ out) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    float ce, mc;
+    if (flags & MAS_LOSS_DECOMP) {
+        ce = loss_value(acc[ACC_SUM_CE], acc[ACC_N_CE]);
+        mc = loss_value(acc[ACC_SUM_MC], acc[ACC_N_MC]);
+    } else {
+        ce = loss_value(acc[ACC_SUM_CE] + acc[ACC_SUM_MC], acc[ACC_N_CE] + acc[ACC_N_MC]);
+        mc = 0.0f;
+    }
+    const float gr = loss_value(acc[ACC_SUM_GROUP], acc[ACC_N_GROUP]);
+    out[0] = ce;
+    out[1] = mc;
+    out[2] = gr;
+    out[3] = (w[0] * ce + w[1] * mc) + w[2] * gr;
+}
+
+// scale_k = (dL/dtotal * w_k) / (1 + n_k): the chain rule through the weighted sum, in the order autograd applies it
+__global__ void k_loss_scales_weighted(const mas_u64* __restrict__ acc, const float* __restrict__ grad_total, const float* __restrict__ w,
+                                       int flags, float* __restrict__ scale) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    const float g = grad_total[0];
+    if (flags & MAS_LOSS_DECOMP) {
+        scale[0] = (g * w[0]) / (float)(acc[ACC_N_CE] + 1);
+        scale[1] = (g * w[1]) / (float)(acc[ACC_N_MC] + 1);
+    } else {
+        const float sc = (g * w[0]) / (float)(acc[ACC_N_CE] + acc[ACC_N_MC] + 1);
+        scale[0] = sc;
+        scale[1] = sc;
+    }
+    scale[2] = (g * w[2]) / (float)(acc[ACC_N_GROUP] + 1);
+}
+
 // scale_k = upstream_k / (1 + n_k)   (f32 division, correctly rounded)
 __global__ void k_loss_scales(const mas_u64* __restrict__ acc, const float* __restrict__ grad_out, int flags,
                               float* __restrict__ scale) {
@@ -567,6 +603,21 @@ extern "C" int mas_loss_values(const uint64_t* acc, int flags, float* losses, vo
     if (!acc || !losses) return MAS_ERR_NULL;
     hipLaunchKernelGGL(k_loss_values, dim3(1), dim3(64), 0, static_cast<hipStream_t>(stream),
                        reinterpret_cast<const mas_u64*>(acc), flags, losses);
+    return mas_launch_status();
+}
+
+extern "C" int mas_loss_values_weighted(const uint64_t* acc, int flags, const float* weights, float* losses4, void* stream) {
+    if (!acc || !weights || !losses4) return MAS_ERR_NULL;
+    hipLaunchKernelGGL(k_loss_values_weighted, dim3(1), dim3(64), 0, static_cast<hipStream_t>(stream), reinterpret_cast<const mas_u64*>(acc),
+                       flags, weights, losses4);
+    return mas_launch_status();
+}
+
+extern "C" int mas_loss_scales_weighted(const uint64_t* acc, const float* grad_total, const float* weights, int flags, float* scale,
+                                        void* stream) {
+    if (!acc || !grad_total || !weights || !scale) return MAS_ERR_NULL;
+    hipLaunchKernelGGL(k_loss_scales_weighted, dim3(1), dim3(64), 0, static_cast<hipStream_t>(stream), reinterpret_cast<const mas_u64*>(acc),
+                       grad_total, weights, flags, scale);
     return mas_launch_status();
 }
 

@@ -170,9 +170,10 @@ def partial_loss_bwd(z, spx, mask, bits, gmax, acc, grad_out, invT, flags):
 # ------------------------------------------------------------------------------------------------
 # K4: ordering + budgeted selection walk
 # ------------------------------------------------------------------------------------------------
-def partial_loss_fwd_lowres(zq, size, spx, mask, bits, invT, flags, reduce_acc=None):
+def partial_loss_fwd_lowres(zq, size, spx, mask, bits, invT, flags, reduce_acc=None, weights=None):
     """As ``partial_loss_fwd`` for the logits ``F.interpolate(zq, size, 'bilinear', align_corners=False)`` without
-    materialising them: ``zq`` [N,C,h,w] quarter-resolution logits, ``size`` = (H, W) of ids / masks."""
+    materialising them: ``zq`` [N,C,h,w] quarter-resolution logits, ``size`` = (H, W) of ids / masks.  ``weights`` (f32 [3]
+    device tensor: w_ce, w_mc, w_group): ``losses`` gets a fourth entry, the weighted objective (w_ce*ce + w_mc*mc) + w_group*group."""
     _need(zq, "inputs", torch.float32)
     _need(spx, "superpixels")
     mask = _mask_u8(mask)
@@ -184,9 +185,12 @@ def partial_loss_fwd_lowres(zq, size, spx, mask, bits, invT, flags, reduce_acc=N
         raise ValueError("shape mismatch between inputs %s at size %s, superpixels %s, spmasks %s, targets %s"
                          % (tuple(zq.shape), (H, W), tuple(spx.shape), tuple(mask.shape), tuple(bits.shape)))
     dev = zq.device
-    acc = torch.zeros(_lib.ACC_WORDS, dtype=torch.int64, device=dev)
-    gmax = torch.zeros((N, S, C), dtype=torch.int64, device=dev) if flags & _lib.LOSS_GROUP else None
-    losses = torch.empty(3, dtype=torch.float32, device=dev)
+    if flags & _lib.LOSS_GROUP:             # accumulators and the arg-pixel table from ONE zero-filled allocation (one memset)
+        buf = torch.zeros(_lib.ACC_WORDS + N * S * C, dtype=torch.int64, device=dev)
+        acc, gmax = buf[:_lib.ACC_WORDS], buf[_lib.ACC_WORDS:].view(N, S, C)
+    else:
+        acc, gmax = torch.zeros(_lib.ACC_WORDS, dtype=torch.int64, device=dev), None
+    losses = torch.empty(3 if weights is None else 4, dtype=torch.float32, device=dev)
     lib = _lib.load()
     with torch.cuda.device(dev):
         st = _stream(zq)
@@ -197,13 +201,18 @@ def partial_loss_fwd_lowres(zq, size, spx, mask, bits, invT, flags, reduce_acc=N
             _lib.check(lib.mas_group_finalize(gmax.data_ptr(), gmax.numel(), acc.data_ptr(), st), "mas_group_finalize")
         if reduce_acc is not None:
             reduce_acc(acc)
-        _lib.check(lib.mas_loss_values(acc.data_ptr(), flags, losses.data_ptr(), st), "mas_loss_values")
+        if weights is None:
+            _lib.check(lib.mas_loss_values(acc.data_ptr(), flags, losses.data_ptr(), st), "mas_loss_values")
+        else:
+            _need(weights, "weights", torch.float32)
+            _lib.check(lib.mas_loss_values_weighted(acc.data_ptr(), flags, weights.data_ptr(), losses.data_ptr(), st), "mas_loss_values_weighted")
     return losses, acc, gmax
 
 
-def partial_loss_bwd_lowres(zq, size, spx, mask, bits, gmax, acc, grad_out, invT, flags, want_fix=False):
+def partial_loss_bwd_lowres(zq, size, spx, mask, bits, gmax, acc, grad_out, invT, flags, want_fix=False, weights=None):
     """Gradient of the losses with respect to the quarter-resolution logits: dzq [N,C,h,w] f32 (and the int64 fixed-point
-    sums it was rounded from when ``want_fix``)."""
+    sums it was rounded from when ``want_fix``).  With ``weights`` [3], ``grad_out`` is the upstream gradient of the weighted
+    objective, a one-element tensor."""
     mask = _mask_u8(mask)
     _need(grad_out, "grad_out", torch.float32)
     N, C, h, w = zq.shape
@@ -216,7 +225,11 @@ def partial_loss_bwd_lowres(zq, size, spx, mask, bits, gmax, acc, grad_out, invT
     lib = _lib.load()
     with torch.cuda.device(dev):
         st = _stream(zq)
-        _lib.check(lib.mas_loss_scales(acc.data_ptr(), grad_out.data_ptr(), flags, scale.data_ptr(), st), "mas_loss_scales")
+        if weights is None:
+            _lib.check(lib.mas_loss_scales(acc.data_ptr(), grad_out.data_ptr(), flags, scale.data_ptr(), st), "mas_loss_scales")
+        else:               # grad_out is dL/d(total) [1]; the chain rule through the weighted sum happens in the kernel
+            _lib.check(lib.mas_loss_scales_weighted(acc.data_ptr(), grad_out.data_ptr(), weights.data_ptr(), flags, scale.data_ptr(), st),
+                       "mas_loss_scales_weighted")
         _lib.check(lib.mas_partial_loss_bwd_lowres(zq.data_ptr(), h, w, spx.data_ptr(), _id_code(spx), mask.data_ptr(), bits.data_ptr(),
                                                    gmax.data_ptr() if gmax is not None else None, scale.data_ptr(), N, C, H, W, S,
                                                    invT, flags, fix.data_ptr(), st), "mas_partial_loss_bwd_lowres")

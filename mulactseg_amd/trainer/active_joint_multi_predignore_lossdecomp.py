@@ -42,11 +42,12 @@ class ActiveTrainer(active_joint_multi_predignore.ActiveTrainer):
             if self.fused_loss is not None and getattr(a, 'lowres_loss', True) and images.is_cuda:
                 # quarter-resolution logits in, upsampling inside the loss scans (no [N,C,H,W] logit / gradient tensors)
                 preds_q = self.forward_train(images, lowres=True)
-                group_loss, ce_loss, mc_loss = self.fused_loss.forward_lowres(preds_q, images.shape[-2:], labels, superpixels, spmasks)
+                loss, group_loss, ce_loss, mc_loss = self.fused_loss.weighted_lowres(preds_q, images.shape[-2:], labels, superpixels, spmasks,
+                                                                                     a.coeff, a.coeff_mc, a.coeff_gm)
             else:
                 preds = self.forward_train(images)
                 group_loss, ce_loss, mc_loss = self.losses(preds, labels, superpixels, spmasks)
-            loss = (a.coeff * ce_loss) + (a.coeff_mc * mc_loss) + (a.coeff_gm * group_loss)
+                loss = (a.coeff * ce_loss) + (a.coeff_mc * mc_loss) + (a.coeff_gm * group_loss)
             self.update(loss)
             self.update_average_meter({'train-loss': loss, 'ce-loss': ce_loss, 'pos-loss': mc_loss, 'group-loss': group_loss})
             self.log_training(iteration, None, total_itrs)

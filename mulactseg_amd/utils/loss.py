@@ -77,6 +77,36 @@ class _PartialLossLowResFn(torch.autograd.Function):
         return dzq, None, None, None, None, None, None, None
 
 
+class _WeightedLowResLossFn(torch.autograd.Function):
+    """total, ce, mc, group = f(zq): the trainer's objective ``w_ce*ce + w_mc*mc + w_group*group`` as ONE differentiable
+    output (its value and its chain rule are computed in the kernels that turn sums into losses / upstream gradients into
+    scales), the three parts as detached values for logging.  Same scans as ``_PartialLossLowResFn``; about half the launches of
+    composing the parts with torch arithmetic."""
+
+    @staticmethod
+    def forward(ctx, zq, size, bits, superpixels, spmasks, invT, flags, sync, weights):
+        zq = zq.contiguous()
+        spx = superpixels.contiguous()
+        msk = spmasks.contiguous()
+        losses, acc, gmax = ops.partial_loss_fwd_lowres(zq, size, spx, msk, bits, invT, flags, _all_reduce_sum if sync else None,
+                                                        weights=weights)
+        ctx.save_for_backward(zq, spx, msk, bits, acc, gmax if gmax is not None else acc, weights)
+        ctx.has_gmax = gmax is not None
+        ctx.invT, ctx.flags, ctx.size = invT, flags, (int(size[0]), int(size[1]))
+        ctx.mark_non_differentiable(acc)
+        parts = losses.detach()
+        ctx.mark_non_differentiable(parts)
+        return losses[3], parts, acc
+
+    @staticmethod
+    def backward(ctx, g_total, _g_parts, _g_acc):
+        zq, spx, msk, bits, acc, gmax, weights = ctx.saved_tensors
+        g = g_total.reshape(1).to(torch.float32).contiguous()
+        dzq = ops.partial_loss_bwd_lowres(zq, ctx.size, spx, msk, bits, gmax if ctx.has_gmax else None, acc, g, ctx.invT, ctx.flags,
+                                          weights=weights)
+        return dzq, None, None, None, None, None, None, None, None
+
+
 def _all_reduce_sum(acc):
     """Sum the fixed-point loss sums and pixel counts over the data-parallel ranks (RCCL all-reduce of 8
     int64 words): integer addition, so the result does not depend on the number of GPUs."""
@@ -229,3 +259,17 @@ class FusedPartialLabelLoss(nn.Module):
         ce, mc, group, self.last_acc = _PartialLossLowResFn.apply(quarter_logits, tuple(size), bits, superpixels, spmasks,
                                                                   ops.inv_temperature(self.temp), self.flags, self.sync_normalisers)
         return group, ce, mc
+
+    def weighted_lowres(self, quarter_logits, size, targets, superpixels, spmasks, coeff, coeff_mc, coeff_gm):
+        """``(coeff * ce + coeff_mc * mc) + coeff_gm * group`` (``..._lossdecomp.py:104``) as one differentiable scalar, plus the
+        detached parts ``(group, ce, mc)`` for logging -- same value, bit for bit, as composing ``forward_lowres`` with torch
+        arithmetic, in half the kernel launches."""
+        if targets.dtype != torch.uint8:
+            targets = targets.to(torch.uint8)
+        bits = ops.target_bits(targets.contiguous(), targets.shape[-1])
+        key = (float(coeff), float(coeff_mc), float(coeff_gm), quarter_logits.device)
+        if getattr(self, '_w_key', None) != key:
+            self._w_key, self._w = key, torch.tensor(key[:3], dtype=torch.float32, device=quarter_logits.device)
+        total, parts, self.last_acc = _WeightedLowResLossFn.apply(quarter_logits, tuple(size), bits, superpixels, spmasks,
+                                                                  ops.inv_temperature(self.temp), self.flags, self.sync_normalisers, self._w)
+        return total, parts[2], parts[0], parts[1]

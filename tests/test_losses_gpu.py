@@ -322,3 +322,30 @@ def test_fused_module_lowres_matches_interpolate_then_loss():
     assert s > 0 and float((zq1.grad - zq2.grad).abs().max()) <= 2e-6 * s
     ref = F.interpolate(zq2.detach(), size=(H, W), mode='bilinear', align_corners=False)
     assert float((ops.upsample_bilinear(zq2.detach(), (H, W)) - ref).abs().max()) <= 1e-6
+
+
+def test_weighted_objective_equals_the_torch_composition():
+    """FusedPartialLabelLoss.weighted_lowres: total == (16*ce + 8*mc) + 1*group of forward_lowres bit for bit, the parts are the
+    same values, and the gradient of the quarter-resolution logits equals the one autograd derives through the torch arithmetic."""
+    _gpu()
+    from mulactseg_amd.utils.loss import FusedPartialLabelLoss
+    N, C, h, w, S = 2, 20, 24, 40, 256
+    H, W = 4 * h, 4 * w
+    _, tgt, spx, msk = _inputs(43, N, C, H, W, S)
+    crit = FusedPartialLabelLoss(S, 0.1, 0.1, sync_normalisers=False)
+    tg, sp, mk = torch.from_numpy(tgt).cuda(), torch.from_numpy(spx).cuda(), torch.from_numpy(msk).cuda()
+    z1 = torch.from_numpy(synth.logits(6, N, C, h, w)).cuda().requires_grad_(True)
+    z2 = z1.detach().clone().requires_grad_(True)
+    total, g1, c1, m1 = crit.weighted_lowres(z1, (H, W), tg, sp, mk, 16.0, 8.0, 1.0)
+    total.backward()
+    g2, c2, m2 = crit.forward_lowres(z2, (H, W), tg, sp, mk)
+    ref = (16.0 * c2) + (8.0 * m2) + (1.0 * g2)
+    ref.backward()
+    assert float(total) == float(ref) and float(g1) == float(g2) and float(c1) == float(c2) and float(m1) == float(m2)
+    assert not g1.requires_grad and total.requires_grad
+    assert torch.equal(z1.grad, z2.grad)
+    # an upstream factor (the data-parallel trainers multiply the loss by the world size)
+    z3 = z1.detach().clone().requires_grad_(True)
+    t3, _, _, _ = crit.weighted_lowres(z3, (H, W), tg, sp, mk, 16.0, 8.0, 1.0)
+    (t3 * 2.0).backward()
+    assert float((z3.grad - 2.0 * z1.grad).abs().max()) <= 1e-6 * float(z1.grad.abs().max())
