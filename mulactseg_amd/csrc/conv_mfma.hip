@@ -327,13 +327,13 @@ extern "C" int mas_conv_fwd(const float* x, const float* wt, int N, int Cin, int
     // tile width: 32 columns when the plane has them, 16 for the 48 / 49-wide planes of the deep layers
     const int TW = p.Wo >= 32 ? 32 : 16;
     p.tw_log2 = ilog2(TW);
-    // Tile choice.  The chip holds 512 workgroups at a time (2 per CU); a launch with fewer than ~640 leaves matrix pipes idle for
-    // its whole duration, so small planes (crop-sized inputs, the deep layers) trade operand reuse for workgroups: 64-row M
+    // Tile choice.  The chip holds 512 workgroups at a time (2 per CU); a launch with fewer than ~400 leaves matrix pipes idle for
+    // its whole duration (at exactly 512 = one full round the big tile still wins: measured), so small planes (crop-sized inputs, the deep layers) trade operand reuse for workgroups: 64-row M
     // tiles instead of 128, 128-pixel tiles instead of 256.
     const long long px128 = (long long)N * ((p.Ho + 128 / TW - 1) / (128 / TW)) * ((p.Wo + TW - 1) / TW);
     const long long px256 = (long long)N * ((p.Ho + 256 / TW - 1) / (256 / TW)) * ((p.Wo + TW - 1) / TW);
-    const bool big_m = p.CoutP % 128 == 0 && Cout % 64 == 0 && px128 * (p.CoutP / 128) >= 640;
-    const bool wide_n = px256 * (p.CoutP / 64) >= 640;         // (for the 64-row tiles) 256-pixel tiles only when there are enough of them
+    const bool big_m = p.CoutP % 128 == 0 && Cout % 64 == 0 && px128 * (p.CoutP / 128) >= 400;
+    const bool wide_n = px256 * (p.CoutP / 64) >= 400;         // (for the 64-row tiles) 256-pixel tiles only when there are enough of them
     if (ksize == 1) {
         const bool vec = stride == 1 && (W % 4 == 0) && ((uintptr_t)x % 16 == 0);
         const int ck = mas_conv_chunk(1, Cin);
