@@ -1,5 +1,5 @@
 import sys, time, torch
-sys.path.insert(0, '/root/repo')
+import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from mulactseg_amd.models import get_model
 def run(tag, cl, bench):
     torch.backends.cudnn.benchmark = bench
