@@ -114,3 +114,36 @@ def test_stem_conv_matches_conv2d(N, H, W, Cout, relu):
         ref = _ref(x.double(), conv.double(), bn.double(), relu, None)
     assert y.shape == ref.shape
     assert float((y.double() - ref).abs().max()) <= 2e-5 * float(ref.abs().max())
+
+
+@pytest.mark.parametrize("seed", range(24))
+def test_conv_mfma_randomised_geometries(seed):
+    """Random supported geometries (channel counts incl. non-multiples of 64 on the output side, odd planes, planes smaller than a
+    tile, every stride / dilation combination, all epilogues) against conv2d in float64: the kernel's address arithmetic --
+    partial tiles, halo clamps, the chunk walk, the 64-padding of the output channels -- has to hold everywhere
+    conv_mfma_supported says yes, not only on the network's own layers."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from mulactseg_amd import ops
+    rs = np.random.RandomState(1000 + seed)
+    k = int(rs.choice([1, 3]))
+    stride = int(rs.choice([1, 2]))
+    dil = 1 if (k == 1 or stride == 2) else int(rs.choice([1, 2]))
+    cin = int(rs.choice([8, 16, 24, 40, 64, 72, 128])) if k == 3 else int(rs.choice([16, 32, 48, 64, 96, 160]))
+    cout = int(rs.choice([16, 48, 64, 80, 128, 192, 200]))
+    N = int(rs.randint(1, 4))
+    H, W = int(rs.randint(3, 70)), int(rs.randint(3, 90))
+    torch.manual_seed(seed)
+    conv = nn.Conv2d(cin, cout, k, stride=stride, padding=dil if k == 3 else 0, dilation=dil, bias=False).cuda()
+    bn = nn.BatchNorm2d(cout).cuda().eval()
+    with torch.no_grad():
+        bn.weight.uniform_(0.5, 1.5); bn.bias.normal_(); bn.running_mean.normal_(); bn.running_var.uniform_(0.5, 2.0)
+        x = torch.randn(N, cin, H, W, device='cuda')
+        assert ops.conv_mfma_supported(conv, x), (cin, cout, k, stride, dil)
+        use_bn, use_res, relu = bool(rs.randint(2)), bool(rs.randint(2)), bool(rs.randint(2))
+        res = torch.randn_like(conv(x)) if use_res else None
+        ref = _ref(x.double(), conv.double(), bn.double() if use_bn else None, relu, res.double() if use_res else None)
+        conv.float(); bn.float()
+        y = ops.conv_mfma(conv, x, bn if use_bn else None, relu=relu, residual=res)
+    assert y.shape == ref.shape
+    assert float((y.double() - ref).abs().max()) <= 2e-5 * max(1.0, float(ref.abs().max())), (cin, cout, k, stride, dil, N, H, W)
