@@ -52,3 +52,4 @@ class ActiveTrainer(active_joint_multi_predignore.ActiveTrainer):
             self.update_average_meter({'train-loss': loss, 'ce-loss': ce_loss, 'pos-loss': mc_loss, 'group-loss': group_loss})
             self.log_training(iteration, None, total_itrs)
             self.log_validation(iteration, val_period)
+        self.flush_meters()
