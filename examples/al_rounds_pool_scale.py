@@ -176,6 +176,7 @@ def main(argv=None):
         trainer.train(active_set)
         r["training_s"] = clock() - t
         r["train_iterations"] = int(args.finetune_itrs)
+        # (training_s includes the validation pass and the checkpoint write that trainer.train() does at its last iteration)
         r["train_images_per_s"] = 4 * int(args.finetune_itrs) / r["training_s"]
         t = clock()
         trainer.load_checkpoint(os.path.join(args.model_save_dir, 'checkpoint%02d.tar' % selection_iter))
