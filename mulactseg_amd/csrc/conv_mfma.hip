@@ -218,33 +218,40 @@ __global__ __launch_bounds__(kThreads, 2) void k_conv_mfma(const ConvP p) {
     // registers it pins cost more than the latency it hides), one predicate guards the 16 stores of a tile.
     float* yb = p.y + ((size_t)n * p.Cout + m0) * HWo;
     const float lo = p.relu ? 0.0f : -INFINITY;
+    // the residual values of tile i + 1 are requested before tile i is finished (two 16-register sets): half of the memory round
+    // trips of the per-tile form are hidden, without pinning all 64 values (measured slower) 
+    constexpr int NT = 2 * TN;
+    float rv[2][16];
+    auto res_load = [&](int i, float (&dst)[16]) {
+        const int tn = i >> 1, tm = i & 1;
+        const int mb = wm * 64 + tm * 32 + 4 * h;
+        const int mlim = MPAD ? p.Cout - m0 : (1 << 30);
 #pragma unroll
-    for (int tn = 0; tn < TN; ++tn) {
+        for (int r = 0; r < 16; ++r) {
+            const int m = mb + (r & 3) + 8 * (r >> 2);
+            dst[r] = rb[(size_t)(m < mlim ? m : 0) * HWo + po[tn]];
+        }
+    };
+    if (RES) res_load(0, rv[0]);
 #pragma unroll
-        for (int tm = 0; tm < 2; ++tm) {
-            const int mb = wm * 64 + tm * 32 + 4 * h;
-            const int mlim = MPAD ? p.Cout - m0 : (1 << 30);    // rows >= mlim are padding (MPAD: Cout % 64 != 0)
-            float out[16], rv[16];
-            if (RES) {
+    for (int i = 0; i < NT; ++i) {
+        const int tn = i >> 1, tm = i & 1;
+        if (RES && i + 1 < NT) res_load(i + 1, rv[(i + 1) & 1]);
+        const int mb = wm * 64 + tm * 32 + 4 * h;
+        const int mlim = MPAD ? p.Cout - m0 : (1 << 30);    // rows >= mlim are padding (MPAD: Cout % 64 != 0)
+        float out[16];
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int m = mb + (r & 3) + 8 * (r >> 2);
-                    rv[r] = rb[(size_t)(m < mlim ? m : 0) * HWo + po[tn]];
-                }
-            }
+        for (int r = 0; r < 16; ++r) {
+            const int m = mb + (r & 3) + 8 * (r >> 2);
+            float v = mas_fmaf(acc[tm][tn][r], sE[m], sE[BM + m]);
+            if (RES) v += rv[i & 1][r];
+            out[r] = v < lo ? lo : v;
+        }
+        if (inside[tn]) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int m = mb + (r & 3) + 8 * (r >> 2);
-                float v = mas_fmaf(acc[tm][tn][r], sE[m], sE[BM + m]);
-                if (RES) v += rv[r];
-                out[r] = v < lo ? lo : v;
-            }
-            if (inside[tn]) {
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int m = mb + (r & 3) + 8 * (r >> 2);
-                    if (m < mlim) yb[(size_t)m * HWo + po[tn]] = out[r];
-                }
+                if (m < mlim) yb[(size_t)m * HWo + po[tn]] = out[r];
             }
         }
     }
