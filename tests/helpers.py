@@ -39,6 +39,10 @@ class OracleBackend:
         class_sum += torch.from_numpy(cs.view(np.int64))
         hist += torch.from_numpy(h.view(np.int32))
 
+    def single_pass_lowres(self, zq, size, spx, S, invT, prob_sum, class_sum, hist):
+        full = exact.upsample_bilinear(zq.numpy(), int(size[0]), int(size[1]))
+        self.single_pass(torch.from_numpy(full), spx, S, invT, prob_sum, class_sum, hist)
+
     def class_weight(self, prob_sum, hw, batch_size, n_batches, coeff):
         from mulactseg_amd.active_selection.engine import class_weight_from_sums
         n_img = prob_sum.shape[0]

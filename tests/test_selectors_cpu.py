@@ -255,3 +255,43 @@ def test_my_random_vectorised_selection_equals_the_tuple_sort(tmp_path):
         with open(tmp_path / tag / 'my_random_selection_01.pkl', 'rb') as f:
             outs.append((pickle.load(f), aset.trg_label_dataset.suppix, aset.trg_pool_dataset.suppix, random.random()))
     assert outs[0] == outs[1] and len(outs[0][0]) > 5
+
+
+def test_pixbal_selector_scans_quarter_resolution_logits_when_the_model_offers_them():
+    """A net with ``lowres_logits`` (models/deeplab.py) is asked for its quarter-resolution logits and the round goes through
+    ``add_single_pass_lowres``; the scores equal those of the same selector on a net that upsamples first (oracle backend)."""
+    import torch
+    import torch.nn.functional as F
+    from helpers import OracleBackend, fake_trainer
+    from mulactseg_amd.active_selection import my_bvsb_predclsbal_pwr_banignore as banignore
+    from mulactseg_amd import synth
+    from oracle import exact
+    n_img, C, h, w, S = 5, 20, 6, 10, 24
+    H, W = 4 * h, 4 * w
+    zq = synth.logits(91, n_img, C, h, w)
+    spx = np.stack([synth.superpixel_map(700 + i, H, W, S) for i in range(n_img)])
+    im_idx = [["i/%03d.png" % i, "l/%03d.png" % i, "s/%03d.pkl" % i] for i in range(n_img)]
+    suppix = {k[2]: list(range(S)) for k in im_idx}
+    calls = []
+
+    class LowNet(torch.nn.Module):
+        lowres_logits = True
+
+        def forward(self, x, lowres=False):
+            calls.append(lowres)
+            return x if lowres else torch.from_numpy(exact.upsample_bilinear(x.numpy(), H, W))
+
+    class FullNet(torch.nn.Module):
+        def forward(self, x):
+            return torch.from_numpy(exact.upsample_bilinear(x.numpy(), H, W))
+
+    out = []
+    for net in (LowNet(), FullNet()):
+        pool = FakePool(zq, spx, im_idx, suppix)
+        sel = banignore.RegionSelector(selector_args(val_batch_size=2, nseg=S))
+        sel.backend = OracleBackend()
+        tr = fake_trainer()
+        tr.net = net
+        out.append(sel.calculate_scores_tensor(tr, pool).numpy())
+    assert calls and all(calls)
+    assert np.array_equal(out[0], out[1]) and float(out[0].max()) > 0
