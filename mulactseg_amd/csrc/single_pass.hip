@@ -48,8 +48,7 @@ __device__ __forceinline__ int table_slot(int* keys, int id) {
 // (edge-replicated, so the clamped second tap of ATen's index arithmetic is a plain "+1"), in the operation order of
 // csrc/upsample.hip -- every pixel's 20 logits, hence every output of the scan, equal those of the materialised tensor bit for
 // bit.  The [B,C,H,W] logits (671 MB per pool batch) and the upsampling pass are gone; the scan then has no HBM stream left
-// to wait for and is bound by its ~1 700 VALU issue slots per row of 256 pixels (9 packed operations per pixel pair and class
-// for the interpolation on top of the ~1 300 of the scan itself).
+// to wait for: it is bound by its VALU work and the latency of its LDS reads (profiles/r02/k_scan_forms_pmc.md).
 struct LowSrc { int h, w; float sh, sw; };
 constexpr int kLowRows = 7, kLowCols = 68;       // footprint of a 16 x 256 tile for ratios >= 3.8 (checked by the launcher)
 
