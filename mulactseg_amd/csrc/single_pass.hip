@@ -155,22 +155,40 @@ __global__ __launch_bounds__(kThreads) void k_single_pass(const float* __restric
             l0y = mas_splat(u0);
             l1y = mas_splat(u1);
         }
+        if (LOWRES) {
+            // y = l0y * (l0x * v00 + l1x * v01) + l1y * (l0x * v10 + l1x * v11), every product and sum rounded once.  The 16 LDS
+            // reads of class c + 1 are issued before class c is combined (two register sets), so the combine never waits for its
+            // own reads.  Pixels beyond the picture (clamped column taps, finite values) are masked where it matters: their
+            // probability quanta through Ra / Rb = 0, their region key through id = -1.
+            float raw[2][16];
+            auto fetch16 = [&](int c, float (&d)[16]) {
+                const float* r0 = s_low + (c * kLowRows + ly) * kLowCols;
+                const float* r1 = r0 + kLowCols;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    d[4 * k] = r0[lx[k]]; d[4 * k + 1] = r0[lx[k] + 1]; d[4 * k + 2] = r1[lx[k]]; d[4 * k + 3] = r1[lx[k] + 1];
+                }
+            };
+            fetch16(0, raw[0]);
+#pragma unroll
+            for (int c = 0; c < CT; ++c) {
+                if (EXACT || c < C) {
+                    if (c + 1 < CT && (EXACT || c + 1 < C)) fetch16(c + 1, raw[(c + 1) & 1]);
+                    const float (&d)[16] = raw[c & 1];
+                    const mas_v2f v00a = {d[0], d[4]}, v01a = {d[1], d[5]}, v10a = {d[2], d[6]}, v11a = {d[3], d[7]};
+                    const mas_v2f v00b = {d[8], d[12]}, v01b = {d[9], d[13]}, v10b = {d[10], d[14]}, v11b = {d[11], d[15]};
+                    v[0][c] = l0y * (l0xa * v00a + l1xa * v01a) + l1y * (l0xa * v10a + l1xa * v11a);
+                    v[1][c] = l0y * (l0xb * v00b + l1xb * v01b) + l1y * (l0xb * v10b + l1xb * v11b);
+                }
+            }
+        }
 #pragma unroll
         for (int c = 0; c < CT; ++c) {
             if (EXACT || c < C) {
                 float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
                 const float* zc = zb + (size_t)c * HW;       // wave-uniform base, 32-bit lane offset
                 if (LOWRES) {
-                    // y = l0y * (l0x * v00 + l1x * v01) + l1y * (l0x * v10 + l1x * v11), every product and sum rounded once
-                    const float* r0 = s_low + (c * kLowRows + ly) * kLowCols;
-                    const float* r1 = r0 + kLowCols;
-                    const mas_v2f v00a = {r0[lx[0]], r0[lx[1]]}, v01a = {r0[lx[0] + 1], r0[lx[1] + 1]};
-                    const mas_v2f v10a = {r1[lx[0]], r1[lx[1]]}, v11a = {r1[lx[0] + 1], r1[lx[1] + 1]};
-                    const mas_v2f v00b = {r0[lx[2]], r0[lx[3]]}, v01b = {r0[lx[2] + 1], r0[lx[3] + 1]};
-                    const mas_v2f v10b = {r1[lx[2]], r1[lx[3]]}, v11b = {r1[lx[2] + 1], r1[lx[3] + 1]};
-                    const mas_v2f oa = l0y * (l0xa * v00a + l1xa * v01a) + l1y * (l0xa * v10a + l1xa * v11a);
-                    const mas_v2f ob = l0y * (l0xb * v00b + l1xb * v01b) + l1y * (l0xb * v10b + l1xb * v11b);
-                    t = make_float4(ok[0] ? oa.x : 0.f, ok[1] ? oa.y : 0.f, ok[2] ? ob.x : 0.f, ok[3] ? ob.y : 0.f);
+                    t = make_float4(v[0][c].x, v[0][c].y, v[1][c].x, v[1][c].y);          // interpolated before this loop
                 } else if (VEC) {
                     if (ok[0]) t = *reinterpret_cast<const float4*>(zc + (unsigned)(row + xs[0]));
                 } else {
