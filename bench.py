@@ -13,7 +13,8 @@ finish it (`engine.AcquisitionRound` -- the product object, not a private loop):
   exchange 1  all-gather of the per-picture class sums (RCCL)  ->  host f64 class weights (one D2H read)
   weighted region means + ban (k_region_finalize_weighted) on the rank's rows
   exchange 2  all-gather of the region scores (RCCL)
-  K4          64-bit keys, radix sort, fair-counting budget walk over ALL N*K*4*2048 regions, replicated on every rank.
+  K4          64-bit keys + radix sort of the rank's own regions, all-gather of the per-rank heads (budget + 1 keys each), merged
+              sort + fair-counting budget walk on every rank (engine.select_regions; one rank: keys, sort, walk over all regions).
 value = N * K * 4 * 2048 / seconds (max over ranks, barrier + synchronize on both sides).
 
 Secondary legs (same JSON line): the reference-structured two-pass kernels; "pool_round" -- the FIXED 2 975-picture x
@@ -146,7 +147,9 @@ class ScanRound:
         self.tail_ev[0].record()
         cls_w = self.rnd.class_weights(6.0)                                    # exchange 1 + host f64
         scores = self.rnd.scores_single_pass(cls_w, ban_class=C - 1)           # finalize + ban, exchange 2
-        n, simg, sid, ssc = self.backend.select(scores, None, self.rank_t, self.rank_t, self.cost, self.budget, self.budget + 1)
+        from mulactseg_amd.active_selection.engine import select_regions
+        n, simg, sid, ssc = select_regions(self.backend, self.rnd.plan, scores, None, self.rank_t, self.rank_t, self.cost, self.budget,
+                                           self.budget + 1)
         self.tail_ev[1].record()
         self.scores = scores
         self.selected = (simg, sid, ssc)

@@ -86,8 +86,11 @@ class RegionSelector(object):
         img_rank, img_of_rank = path_ranks(paths)
         dev = scores_tensor.device
         cost = self._region_cost(active_set, pool_set)
-        n, simg, sid, ssc = backend.select(
-            scores_tensor.contiguous(), torch.from_numpy(self._pool_valid(active_set, pool_set)).to(dev),
+        from .engine import ShardPlan, current_rank_world, select_regions
+        rank, world = current_rank_world()
+        plan = ShardPlan(len(pool_set.im_idx), self.batch_size, rank, world)        # the sharding the scores were computed under
+        n, simg, sid, ssc = select_regions(
+            backend, plan, scores_tensor.contiguous(), torch.from_numpy(self._pool_valid(active_set, pool_set)).to(dev),
             torch.from_numpy(img_rank).to(dev), torch.from_numpy(img_of_rank).to(dev),
             None if cost is None else torch.from_numpy(cost).to(dev), int(selection_count),
             max_out=None if cost is not None and cost.min() == 0 else int(selection_count) + 1)

@@ -160,9 +160,46 @@ class HipBackend:
         n = int(nsel.item())               # the round's single host synchronisation
         return n, simg[:n].cpu().numpy(), sid[:n].cpu().numpy(), ssc[:n].cpu().numpy()
 
+    def local_head(self, plan, scores, valid, img_rank, max_out):
+        """int64 [max_out]: the first ``max_out`` keys of the descending order of THIS rank's rows (zero-padded: key 0 = "no
+        region", sorts last and costs nothing)."""
+        lo, hi = plan.img_lo, plan.img_hi
+        head = torch.zeros(max_out, dtype=torch.int64, device=scores.device)
+        if hi > lo:
+            keys = self.ops.region_keys(scores[lo:hi].contiguous(), None if valid is None else valid[lo:hi].contiguous(),
+                                        img_rank[lo:hi].contiguous())
+            m = min(keys.numel(), max_out)
+            head[:m] = self.ops.sort_keys_desc(keys)[:m]
+        return head
+
+    def walk_heads(self, heads, region_cost, img_of_rank, S, budget, max_out):
+        """Merged ordering + budget walk over the concatenated per-rank heads."""
+        nsel, simg, sid, ssc = self.ops.budget_walk(self.ops.sort_keys_desc(heads), region_cost, img_of_rank, S, budget, max_out)
+        n = int(nsel.item())               # the round's single host synchronisation
+        return n, simg[:n].cpu().numpy(), sid[:n].cpu().numpy(), ssc[:n].cpu().numpy()
+
+    def select_sharded(self, plan, scores, valid, img_rank, img_of_rank, region_cost, budget, max_out):
+        """See ``select_regions``: local keys + local sort, all-gather of the per-rank heads (RCCL), merged sort + walk."""
+        head = self.local_head(plan, scores, valid, img_rank, max_out)
+        merged = torch.empty(plan.world * max_out, dtype=torch.int64, device=scores.device)
+        _dist().all_gather_into_tensor(merged, head)
+        return self.walk_heads(merged, region_cost, img_of_rank, scores.shape[1], budget, max_out)
+
 
 def default_backend(device):
     return HipBackend(device)
+
+
+def select_regions(backend, plan, scores, valid, img_rank, img_of_rank, region_cost, budget, max_out):
+    """K4 over the whole pool: the consumed prefix (n, picture indices, ids, scores) of the descending (score, path rank, id)
+    order under the click budget.  One rank: ``backend.select``.  Several ranks: every rank orders only ITS rows, the first
+    ``max_out`` keys of every rank are all-gathered and the merged candidates are ordered and walked on every rank -- the
+    prefix the budget consumes has at most ``max_out`` regions, so it lies inside the union of the per-rank heads and the
+    result equals the replicated ordering of all regions, at 1 / world of the sorting work.  (``max_out`` None -- a region may
+    cost nothing -- falls back to the replicated ordering.)"""
+    if plan.world > 1 and max_out is not None and _dist() is not None and hasattr(backend, 'select_sharded'):
+        return backend.select_sharded(plan, scores, valid, img_rank, img_of_rank, region_cost, budget, max_out)
+    return backend.select(scores, valid, img_rank, img_of_rank, region_cost, budget, max_out)
 
 
 # ------------------------------------------------------------------------------------------------

@@ -86,6 +86,24 @@ class OracleBackend:
                 np.array([t[2] for t in taken], dtype=np.int32), np.array([t[0] for t in taken], dtype=np.float32))
 
 
+    def select_sharded(self, plan, scores, valid, img_rank, img_of_rank, region_cost, budget, max_out):
+        """The sharded K4 of engine.select_regions restated on tuples: local head of max_out regions, all-gather, merged walk."""
+        import torch.distributed as dist
+        s, v = scores.numpy(), valid.numpy()
+        rank = img_rank.numpy()
+        local = sorted(((float(s[i, r]), int(rank[i]), r) for i in range(plan.img_lo, plan.img_hi) for r in range(s.shape[1]) if v[i, r]),
+                       reverse=True)[:max_out]
+        heads = [None] * plan.world
+        dist.all_gather_object(heads, local)
+        merged = sorted((t for h in heads for t in h), reverse=True)
+        inv = img_of_rank.numpy()
+        cost = None if region_cost is None else region_cost.numpy()
+        fn = None if cost is None else (lambda rk, rid: int(cost[inv[rk], rid]))
+        taken = port.select_regions(merged, budget, fn)
+        return (len(taken), np.array([inv[t[1]] for t in taken], dtype=np.int32),
+                np.array([t[2] for t in taken], dtype=np.int32), np.array([t[0] for t in taken], dtype=np.float32))
+
+
 class FakePool(torch.utils.data.Dataset):
     """Pool dataset whose 'images' ARE the logits (the fake trainer's net is the identity)."""
 

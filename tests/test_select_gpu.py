@@ -108,3 +108,30 @@ def test_minmax_normalize_matches_plain_bvsb_reference():
     ref = ref / ref.max()
     out = ops.minmax_normalize_(torch.from_numpy(u.copy()).cuda()).cpu().numpy()
     assert np.array_equal(out, ref)
+
+
+@pytest.mark.parametrize("world", [2, 3, 8])
+def test_sharded_ordering_of_per_rank_heads_equals_the_replicated_ordering(world):
+    """engine.select_regions on several ranks (HipBackend.local_head per rank + walk_heads on the gathered heads, here with the
+    ranks simulated one after the other on one GPU) consumes exactly the prefix backend.select consumes on all regions: ties
+    across ranks, invalid regions, a ragged last shard, fair-counting costs."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from mulactseg_amd.active_selection.engine import HipBackend, ShardPlan
+    dev = torch.device('cuda:0')
+    be = HipBackend(dev)
+    n_img, S, bs = 37, 96, 4
+    g = torch.Generator(device=dev).manual_seed(world)
+    scores = (torch.randint(0, 50, (n_img, S), generator=g, device=dev).float() / 50.0).contiguous()      # heavy ties
+    valid = (torch.rand((n_img, S), generator=g, device=dev) > 0.1).to(torch.uint8)
+    cost = (torch.randint(1, 5, (n_img, S), generator=g, device=dev)).to(torch.uint8)
+    perm = torch.randperm(n_img, generator=g, device=dev).to(torch.int32)                                   # path ranks != picture order
+    inv = torch.empty_like(perm)
+    inv[perm.long()] = torch.arange(n_img, dtype=torch.int32, device=dev)
+    budget = 400
+    want = be.select(scores, valid, perm, inv, cost, budget, budget + 1)
+    heads = torch.cat([be.local_head(ShardPlan(n_img, bs, r, world), scores, valid, perm, budget + 1) for r in range(world)])
+    got = be.walk_heads(heads, cost, inv, S, budget, budget + 1)
+    assert got[0] == want[0] and got[0] > 50
+    for a, b in zip(got[1:], want[1:]):
+        assert np.array_equal(a, b)
