@@ -392,8 +392,8 @@ def acquisition_with_model_bench(args, dev, world):
         low_ms = ev(lambda: ops.single_pass_accum_lowres(zq, (H, W), spx, S, invT, prob_sum=prob, class_sum=csum, hist=hist))
         mat_ms = ev(lambda: ops.single_pass_accum(ops.upsample_bilinear(zq, (H, W)), spx, S, invT, prob_sum=prob, class_sum=csum, hist=hist))
     scan_forms = {"scan_from_quarter_logits_ms": low_ms, "upsample_then_scan_ms": mat_ms,
-                  "note": "k_single_pass<LOWRES> (interpolation in registers, VALU-bound: ~1 700 issue slots per 256-pixel row) vs "
-                          "k_upsample_fwd + k_single_pass_ring (671 MB written and re-read)"}
+                  "note": "k_single_pass<LOWRES> (interpolation in registers; bound by VALU work and LDS-read latency, "
+                          "profiles/r02/k_scan_forms_pmc.md) vs k_upsample_fwd + k_single_pass_ring (671 MB written and re-read)"}
     return {"metric": "superpixels scored/sec incl. model forward", "scan_forms": scan_forms, "value": B * S * world / (ms * 1e-3), "unit": "superpixels/s",
             "ms_per_batch": ms, "forwards_per_image": 1, "layer_paths_per_step": paths,
             "config": {"workload": "eval forward (MIOpen fp32 + HIP layers) of [%d,3,%d,%d] + single-pass scan; the reference structure "
