@@ -53,51 +53,6 @@ __global__ __launch_bounds__(kThreads) void k_dw3_fwd(const float* __restrict__ 
     }
 }
 
-// Row form of k_dw3_fwd for planes whose width is a multiple of 64 (the 64 x 128 planes of the Cityscapes pool): the plane is
-// staged with zero columns on both sides, every wave owns whole rows -- so the vertical bounds of a tap row are a scalar branch
-// and the horizontal ones do not exist -- and a lane produces its pixels from plain LDS reads.  The tap order of every output
-// is k_dw3_fwd's, so both kernels give the same bits; this one issues ~60 instructions per pixel instead of ~220 (the generic
-// kernel spends its time on the four compares and the select of every one of its 27 taps).
-__global__ __launch_bounds__(kThreads) void k_dw3_fwd_rows(const float* __restrict__ x, const float* __restrict__ w0, const float* __restrict__ w1,
-                                                            const float* __restrict__ w2, int C, int H, int W, int d0, int d1, int d2, int pad,
-                                                            float* __restrict__ y0, float* __restrict__ y1, float* __restrict__ y2) {
-    extern __shared__ float s_plane[];
-    const size_t plane = (size_t)blockIdx.x * H * W;            // blockIdx.x = n*C + c
-    const int c = blockIdx.x % C;
-    const int PW = W + 2 * pad;
-    const float* src = x + plane;
-    for (int i = threadIdx.x; i < H * PW; i += kThreads) {
-        const int r = i / PW, cx = i - r * PW - pad;
-        s_plane[i] = (cx >= 0 && cx < W) ? src[r * W + cx] : 0.0f;
-    }
-    __syncthreads();
-    float k0[9], k1[9], k2[9];
-#pragma unroll
-    for (int t = 0; t < 9; ++t) { k0[t] = w0[c * 9 + t]; k1[t] = w1[c * 9 + t]; k2[t] = w2[c * 9 + t]; }
-    const int lane = threadIdx.x & (MAS_WAVE - 1), wave = threadIdx.x / MAS_WAVE;
-    const int segs = W / MAS_WAVE;                               // 64-pixel segments per row
-    for (int seg = wave; seg < H * segs; seg += kThreads / MAS_WAVE) {
-        const int py = seg / segs, px = (seg - py * segs) * MAS_WAVE + lane;        // py: wave-uniform
-        float a0 = 0.f, a1 = 0.f, a2 = 0.f;
-#pragma unroll
-        for (int a = 0; a < 3; ++a) {
-            const int r0 = py + (a - 1) * d0, r1 = py + (a - 1) * d1, r2 = py + (a - 1) * d2;
-            const bool in0 = r0 >= 0 && r0 < H, in1 = r1 >= 0 && r1 < H, in2 = r2 >= 0 && r2 < H;       // scalar
-#pragma unroll
-            for (int b = 0; b < 3; ++b) {
-                // rows outside the plane contribute exact zeros, as the zero padding does: fma(k, 0, acc) == acc
-                a0 = mas_fmaf(k0[a * 3 + b], in0 ? s_plane[r0 * PW + pad + px + (b - 1) * d0] : 0.0f, a0);
-                a1 = mas_fmaf(k1[a * 3 + b], in1 ? s_plane[r1 * PW + pad + px + (b - 1) * d1] : 0.0f, a1);
-                a2 = mas_fmaf(k2[a * 3 + b], in2 ? s_plane[r2 * PW + pad + px + (b - 1) * d2] : 0.0f, a2);
-            }
-        }
-        const size_t o = plane + (size_t)py * W + px;
-        y0[o] = a0;
-        y1[o] = a1;
-        y2[o] = a2;
-    }
-}
-
 template <bool USE_LDS>
 __global__ __launch_bounds__(kThreads) void k_dw3_bwd_x(const float* __restrict__ g0, const float* __restrict__ g1, const float* __restrict__ g2,
                                                          const float* __restrict__ w0, const float* __restrict__ w1, const float* __restrict__ w2,
@@ -324,12 +279,6 @@ extern "C" int mas_aspp_dw3_fwd(const float* x, const float* w0, const float* w1
     if (int e = check(N, C, H, W, d0, d1, d2)) return e;
     const size_t smem = sizeof(float) * (size_t)H * W;
     hipStream_t st = static_cast<hipStream_t>(stream);
-    const int pad = d0 > d1 ? (d0 > d2 ? d0 : d2) : (d1 > d2 ? d1 : d2);
-    const size_t smem_rows = sizeof(float) * (size_t)H * (W + 2 * pad);
-    if (W % MAS_WAVE == 0 && smem_rows <= 64 * 1024) {
-        hipLaunchKernelGGL(k_dw3_fwd_rows, dim3((unsigned)(N * C)), dim3(kThreads), smem_rows, st, x, w0, w1, w2, C, H, W, d0, d1, d2, pad, y0, y1, y2);
-        return mas_launch_status();
-    }
     if (smem <= 64 * 1024)
         hipLaunchKernelGGL((k_dw3_fwd<true>), dim3((unsigned)(N * C)), dim3(kThreads), smem, st, x, w0, w1, w2, C, H, W, d0, d1, d2, y0, y1, y2);
     else

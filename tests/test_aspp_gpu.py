@@ -12,7 +12,7 @@ def _need():
         pytest.skip("needs a GPU")
 
 
-@pytest.mark.parametrize("N,C,H,W", [(2, 64, 48, 48), (1, 32, 64, 128), (2, 16, 9, 13), (1, 8, 150, 130), (2, 4, 20, 64)])
+@pytest.mark.parametrize("N,C,H,W", [(2, 64, 48, 48), (1, 32, 64, 128), (2, 16, 9, 13), (1, 8, 150, 130)])
 def test_depthwise_triple_matches_conv2d(N, C, H, W):
     _need()
     from mulactseg_amd import ops
