@@ -2,7 +2,9 @@
 """bench.py -- MulActSeg hot path on MI355X: superpixels scored/sec (+ train-iter images/sec).
 
 Contract (driver):  python bench.py --gpus N --steps K --warmup W
-  N > 1 is launched by the driver as `python -m torch.distributed.run --nproc-per-node N ... bench.py`, one rank per GPU.
+  N > 1 is launched by the driver as `python -m torch.distributed.run --nproc-per-node N ... bench.py`, one rank per GPU;
+  run bare (`python bench.py --gpus N`, no WORLD_SIZE in the environment) the script starts those N ranks itself as child
+  processes and relays rank 0's line; a WORLD_SIZE that differs from --gpus is refused (exit 2).
 
 Primary workload "acquisition-round" (BASELINE.json metric "superpixels scored/sec"; config 3's shapes).  One step = one
 reference batch (val_batch_size = 4 pool pictures: logits [4,20,1024,2048] f32 + superpixel ids, resident in HBM) through
@@ -10,7 +12,7 @@ the single-pass scan of the PixBal + ban-ignore selector (class prior + per-regi
 reference active_selection/my_bvsb_predclsbal_pwr_banignore.py:35-72).  Every rank scans K batches of ITS shard (weak
 scaling: per-GPU work fixed); then, still inside the timed region, the round is finished exactly as the selector plugins
 finish it (`engine.AcquisitionRound` -- the product object, not a private loop):
-  exchange 1  all-gather of the per-picture class sums (RCCL)  ->  host f64 class weights (one D2H read)
+  exchange 1  all-gather of the per-picture class sums (RCCL)  ->  device f64 class weights (k_class_weight, no host round trip)
   weighted region means + ban (k_region_finalize_weighted) on the rank's rows
   exchange 2  all-gather of the region scores (RCCL)
   K4          64-bit keys + radix sort of the rank's own regions, all-gather of the per-rank heads (budget + 1 keys each), merged
@@ -65,11 +67,13 @@ def parse():
     ap.add_argument("--train-steps", type=int, default=8)
     ap.add_argument("--acq-steps", type=int, default=8, help="steps of the secondary model-forward + scan measurement")
     ap.add_argument("--crop", type=int, default=768, help="training crop (reference: 768, transform.py:107)")
-    ap.add_argument("--cpu-images", type=int, default=16, help="pictures of the CPU-baseline scorer sample")
-    ap.add_argument("--cpu-reps", type=int, default=1, help="repetitions per thread count (median reported)")
-    ap.add_argument("--cpu-loss-steps", type=int, default=2)
-    ap.add_argument("--cpu-full", action="store_true",
-                    help="SURVEY section 8(d) protocol: 32 pictures, median of 3, 10 loss steps (takes ~10 minutes)")
+    ap.add_argument("--cpu-images", type=int, default=32, help="pictures of the CPU-baseline scorer sample (SURVEY 8(d): >= 32)")
+    ap.add_argument("--cpu-reps", type=int, default=3, help="repetitions at the reference's 20 threads (median reported; 8(d): 3)")
+    ap.add_argument("--cpu-loss-steps", type=int, default=10, help="loss fwd+bwd steps on the host (8(d): 10)")
+    ap.add_argument("--cpu-allcore-images", type=int, default=8,
+                    help="pictures of the one extra scorer run at os.cpu_count() threads (torch-CPU is 4-6x slower at the box's 256 "
+                         "hardware threads than at 20; reported, never the baseline unless it wins)")
+    ap.add_argument("--cpu-full", action="store_true", help="kept for compatibility: the defaults are the 8(d) protocol now")
     return ap.parse_args()
 
 
@@ -113,8 +117,8 @@ def max_over_ranks(seconds, dev):
 # primary leg
 # ------------------------------------------------------------------------------------------------------------------
 class ScanRound:
-    """K batches of this rank's shard through engine.AcquisitionRound, then the round's tail (two exchanges, host class
-    weights, weighted finalize + ban, replicated K4 with a fair-counting budget)."""
+    """K batches of this rank's shard through engine.AcquisitionRound, then the round's tail (two exchanges, device class
+    weights (k_class_weight), weighted finalize + ban, sharded K4 with a fair-counting budget)."""
 
     def __init__(self, args, dev, rank, world, backend, bufs, n_steps, cost_seed=5):
         from mulactseg_amd.active_selection.engine import AcquisitionRound
@@ -145,7 +149,7 @@ class ScanRound:
     def tail(self):
         C = self.args.classes
         self.tail_ev[0].record()
-        cls_w = self.rnd.class_weights(6.0)                                    # exchange 1 + host f64
+        cls_w = self.rnd.class_weights(6.0)                                    # exchange 1 + k_class_weight (device f64)
         scores = self.rnd.scores_single_pass(cls_w, ban_class=C - 1)           # finalize + ban, exchange 2
         from mulactseg_amd.active_selection.engine import select_regions
         n, simg, sid, ssc = select_regions(self.backend, self.rnd.plan, scores, None, self.rank_t, self.rank_t, self.cost, self.budget,
@@ -184,7 +188,7 @@ class ModelOnRotatingPictures(torch.nn.Module):
 
 def pool_round_bench(args, dev, rank, world, with_model):
     """BASELINE.json config 3 at its real size: 2 975 pictures x 2 048 superpixels, 100 000 clicks (fair counting), through
-    RegionSelector.select_next_batch -- scan (+ model forward), two exchanges, host class weights, finalize + ban, K4 on
+    RegionSelector.select_next_batch -- scan (+ model forward), two exchanges, device class weights, finalize + ban, K4 on
     6.09 M keys, RegionActiveDataset bookkeeping.  The pool is sharded over the ranks: strong scaling."""
     from mulactseg_amd.active_selection import my_bvsb_predclsbal_pwr_banignore as banignore
     from mulactseg_amd.active_selection.engine import ShardPlan
@@ -396,8 +400,9 @@ def acquisition_with_model_bench(args, dev, world):
                           "profiles/r02/k_scan_forms_pmc.md) vs k_upsample_fwd + k_single_pass_ring (671 MB written and re-read)"}
     return {"metric": "superpixels scored/sec incl. model forward", "scan_forms": scan_forms, "value": B * S * world / (ms * 1e-3), "unit": "superpixels/s",
             "ms_per_batch": ms, "forwards_per_image": 1, "layer_paths_per_step": paths,
-            "config": {"workload": "eval forward (MIOpen fp32 + HIP layers) of [%d,3,%d,%d] + single-pass scan; the reference structure "
-                                   "runs the forward twice per pool image" % (B, H, W)}}
+            "config": {"workload": "eval forward (f32-MFMA convolutions with BatchNorm / residual / ReLU epilogues + HIP memory-bound layers, no "
+                                   "MIOpen kernel: see layer_paths_per_step) of [%d,3,%d,%d] + single-pass scan of the quarter-resolution "
+                                   "logits; the reference structure runs the forward twice per pool image" % (B, H, W)}}
 
 
 def stage2_bench(args, dev):
@@ -463,15 +468,15 @@ def cpu_baseline(args, dev, bufs, backend):
     """the reference CPU path on the GPU box's host cores, on the SAME tensors the GPU leg scans (the
     resident batches, copied to the host).  Scorer round (both passes + ban + tuple list + Python sort + budget walk) at
     os.cpu_count() threads and at the reference's own default of 20 (utils/common.py:343), the partial-label losses
-    fwd+bwd on [4,20,768,768], and the model forward on one pool batch.  Bounded by --cpu-images / --cpu-reps; --cpu-full
-    runs the protocol's sizes (32 pictures, median of 3, 10 loss steps)."""
+    fwd+bwd on [4,20,768,768], and the model forward on one pool batch.  Defaults = the protocol's sizes (32 pictures, median
+    of 3 at 20 threads, 10 loss steps: ~40 s); the run at every hardware thread is one repetition on --cpu-allcore-images."""
     from mulactseg_amd import synth
     from oracle import port
     cores = os.cpu_count() or 1
     B, C, H, W, S = args.batch, args.classes, args.height, args.width, args.nseg
-    n_img = 32 if args.cpu_full else max(B, args.cpu_images // B * B)
-    reps = 3 if args.cpu_full else args.cpu_reps
-    loss_steps = 10 if args.cpu_full else args.cpu_loss_steps
+    n_img = max(B, args.cpu_images // B * B)
+    reps = max(1, args.cpu_reps)
+    loss_steps = max(1, args.cpu_loss_steps)
     n_b = n_img // B
     host = [(z.cpu(), spx.cpu().to(torch.int64)) for z, spx in bufs]                  # generated once on the device, copied
     im_idx = [["img_%05d.png" % i, "lbl_%05d.png" % i, "spx_%05d.pkl" % i] for i in range(n_img)]
@@ -482,33 +487,42 @@ def cpu_baseline(args, dev, bufs, backend):
     budget = max(1, int(POOL_CLICKS * n_img / POOL_IMAGES))
     row = {','.join(k): i for i, k in enumerate(im_idx)}
 
-    def scorer_round():
+    def scorer_round(n_pictures=None):
         """calculate_scores (pass 1, class weights, pass 2, ban) -> tuple list -> sorted(reverse=True) -> budget walk"""
-        means = [port.class_prior_batch(host[b % len(host)][0], 0.1) for b in range(n_b)]
+        n_p = n_img if n_pictures is None else n_pictures
+        nb = n_p // B
+        means = [port.class_prior_batch(host[b % len(host)][0], 0.1) for b in range(nb)]
         _, w = port.class_weight(means, 6.0)
         rb, rh = [], []
-        for b in range(n_b):
+        for b in range(nb):
             z, spx = host[b % len(host)]
             r, h = port.region_scores_batch(z, spx, 0.1, w, S, C)
             rb.append(r)
             rh.append(h)
         sc, _ = port.ban_ignore_dominant(torch.cat(rb).view(-1), torch.cat(rh).view(-1, C))
-        sc = sc.view(n_img, S)
-        tuples = port.score_list(im_idx, suppix, sc)
-        taken = port.select_regions(tuples, budget, lambda path, rid: int(cost[row[path], rid]))
+        sc = sc.view(n_p, S)
+        tuples = port.score_list(im_idx[:n_p], suppix, sc)
+        taken = port.select_regions(tuples, max(1, int(POOL_CLICKS * n_p / POOL_IMAGES)), lambda path, rid: int(cost[row[path], rid]))
         return sc.numpy(), taken
 
-    def timed(threads):
+    def timed(threads, n_rep, n_pictures=None):
         torch.set_num_threads(threads)
         ts = []
-        for _ in range(reps):
+        for _ in range(n_rep):
             t0 = time.perf_counter()
-            out = scorer_round()
+            out = scorer_round(n_pictures)
             ts.append(time.perf_counter() - t0)
         return float(np.median(ts)), ts, out
 
-    t_all, ts_all, (sc_cpu, taken) = timed(cores)
-    t_20, ts_20, _ = timed(min(20, cores))
+    # the protocol's run: the reference's own default thread count (utils/common.py:343), n_img pictures, median of `reps`
+    t_20, ts_20, (sc_cpu, taken) = timed(min(20, cores), reps)
+    # one extra run at every hardware thread of the box on a smaller sample, scaled to n_img pictures for the comparison
+    n_all = max(B, min(n_img, args.cpu_allcore_images // B * B))
+    if cores > 20:
+        t_all_raw, ts_all, _ = timed(cores, 1, n_all)
+        t_all = t_all_raw * n_img / n_all
+    else:
+        t_all, ts_all = t_20, ts_20
     best = min(t_all, t_20)
 
     # the same pictures through the GPU round: selected sets compared (the reference's f32 order vs the fixed-point scan)
@@ -558,9 +572,11 @@ def cpu_baseline(args, dev, bufs, backend):
     per_img = best / n_img
     return {"value": n_img * S / best, "unit": "superpixels/s", "cores": cores if t_all <= t_20 else min(20, cores), "kind": "port",
             "sample": "%d pictures = %d of the GPU leg's resident [%d,%d,%d,%d] batches copied to the host; scorer round = both passes + ban + "
-                      "tuple list + Python sort + fair-counting budget walk (oracle/port.py, torch %s CPU); median of %d"
-                      % (n_img, n_b, B, C, H, W, torch.__version__, reps),
-            "scorer_seconds": {"threads_%d" % cores: t_all, "threads_%d" % min(20, cores): t_20, "runs": {"all": ts_all, "20": ts_20}},
+                      "tuple list + Python sort + fair-counting budget walk (oracle/port.py, torch %s CPU); median of %d at %d threads; "
+                      "+ %d loss steps and one model forward at the same thread count"
+                      % (n_img, n_b, B, C, H, W, torch.__version__, reps, min(20, cores), loss_steps),
+            "scorer_seconds": {"threads_%d" % min(20, cores): t_20, "threads_%d_scaled_from_%d_pictures" % (cores, n_all): t_all,
+                               "runs": {"20": ts_20, "all": ts_all}},
             "extrapolated_pool_round_s": {"scorer_only": per_img * POOL_IMAGES,
                                           "with_two_model_forwards": (per_img + 2 * t_model / B) * POOL_IMAGES,
                                           "note": "linear in the picture count: %.3f s per picture x 2 975 (the reference runs the model "
@@ -590,8 +606,37 @@ def pmc_traffic(kernel, default_shape):
     return None, None
 
 
+def rank_launch_command(n_gpus, argv, port):
+    """The command `python bench.py --gpus N` runs when no launcher is around it: one rank per GPU of this node over RCCL,
+    rendezvous on 127.0.0.1 (the container hostname may not resolve)."""
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n_gpus), "--master-addr", "127.0.0.1",
+            "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+
+
+def launch_ranks(args, argv):
+    """Parent of an N-rank run.  It never touches the GPU (the ranks are child processes; nothing is exec'ed from a process that
+    has initialised HIP) and relays rank 0's JSON line through the inherited stdout; its exit code is the launcher's."""
+    import socket
+    import subprocess
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return subprocess.call(rank_launch_command(args.gpus, argv, port), env=env)
+
+
 def main():
     args = parse()
+    if args.gpus < 1:
+        sys.stderr.write("bench.py: --gpus must be >= 1\n")
+        sys.exit(2)
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(args, sys.argv[1:]))
+    if int(os.environ.get("WORLD_SIZE", "1")) != args.gpus:
+        sys.stderr.write("bench.py: --gpus %d but the launcher started WORLD_SIZE=%s ranks; refusing to report a mislabelled run\n"
+                         % (args.gpus, os.environ.get("WORLD_SIZE", "1")))
+        sys.exit(2)
     # stdout carries exactly ONE line, the JSON: library banners (RCCL prints its version block to stdout when the first
     # communicator is built) go to stderr for the whole run
     sys.stdout.flush()
@@ -671,7 +716,7 @@ def main():
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": "acquisition-round: PixBal+ban-ignore scorer on resident logits, Cityscapes pool shape [%d,%d,%d,%d] per step; "
                                "per rank K single-pass scans (class prior + region sums + histograms) of its shard, then exchange 1 "
-                               "(all-gather class sums) + host class weights + weighted finalize + ban + exchange 2 (all-gather scores) + "
+                               "(all-gather class sums) + device class weights (k_class_weight) + weighted finalize + ban + exchange 2 (all-gather scores) + "
                                "replicated K4 (keys, radix sort, fair-counting budget walk) over all N*K*%d*%d regions"
                                % (B, C, H, W, B, S),
                    "images_per_step": B, "logits": [B, C, H, W], "nseg": S, "id_dtype": args.id_dtype,

@@ -403,6 +403,19 @@ int mas_conv_chunk(int ksize, int Cin);
 int mas_conv_fwd(const float* x, const float* wt, int N, int Cin, int H, int W, int Cout, int ksize, int stride, int dil,
                  const float* scale, const float* shift, const float* residual, int relu, float* y, void* stream);
 
+/* Weight gradient of a dense convolution on the f32 matrix cores (csrc/conv_wgrad.hip), NCHW operands as autograd holds them:
+ *   dw[m,c,r,s] = sum_{n,oy,ox} dy[n,m,oy,ox] * x[n,c, oy*stride + r*dil - pad, ox*stride + s*dil - pad],  pad = dil (ksize 3) / 0 (ksize 1)
+ * -- the backward of the nn.Conv2d modules of models/segmentation/backbone/resnet.py:129-171 and
+ * models/segmentation/deeplabv3.py:85-137,168-245 with respect to their weights (what loss.backward() of
+ * trainer/active_joint_multi_predignore_lossdecomp.py:83-116 runs through MIOpen in the reference).
+ * x [N,Cin,H,W], dy [N,Cout,Ho,Wo] with Ho = (H-1)/stride + 1, dw [Cout,Cin,ksize,ksize] (overwritten).  ksize 1 | 3, stride 1 | 2,
+ * dil 1 (ksize 1, stride 2), 1 | 2 | 4 (ksize 3, stride 1).  Any channel counts and plane sizes (16-byte loads when the
+ * planes allow them).  Split-K partial sums go through `workspace` (mas_conv_wgrad_workspace_bytes) and are added in a fixed
+ * order: run-to-run identical results. */
+size_t mas_conv_wgrad_workspace_bytes(int N, int Cin, int H, int W, int Cout, int ksize, int stride, int dil);
+int mas_conv_wgrad(const float* x, const float* dy, int N, int Cin, int H, int W, int Cout, int ksize, int stride, int dil,
+                   float* dw, void* workspace, size_t workspace_bytes, void* stream);
+
 /* The first convolution of the deep stem (models/segmentation/backbone/resnet.py:163-171, conv1[0..2]): x [N,3,H,W] ->
  * y [N,Cout,(H-1)/2+1,(W-1)/2+1], 3x3, stride 2, padding 1, w [Cout,3,3,3] as PyTorch stores it, optional inference BatchNorm
  * (scale / shift, both or neither) and ReLU in the epilogue.  Cout % 16 == 0, W % 8 == 0, 16-byte aligned tensors. */

@@ -1,0 +1,433 @@
+// conv_wgrad.hip -- weight gradient of the dense convolutions (1x1 / 3x3, stride 1 / 2, dilation 1 / 2 / 4) on the f32
+// matrix cores of gfx950 (v_mfma_f32_32x32x2_f32: exact f32 products, k-ordered accumulation), NCHW operands as autograd
+// hands them over -- no NHWC copies:
+//     dW[m, c, ky, kx] = sum_{n, oy, ox} dY[n, m, oy, ox] * X[n, c, oy*stride + ky*dil - pad, ox*stride + kx*dil - pad]
+// Reference: the backward of every nn.Conv2d of models/segmentation/backbone/resnet.py:129-171 and
+// models/segmentation/deeplabv3.py:85-137,168-245 as driven by trainer/active_joint_multi_predignore_lossdecomp.py:83-116
+// (loss.backward()).
+//
+// GEMM view:  M = output channels (A operand = dY), N = (tap, input channel) (B operand = X shifted by the tap), K = output
+// pixels of all pictures.  Both operands are pixel-contiguous in NCHW, i.e. K-contiguous: 16-byte global loads on both sides.
+//   * K is walked in chunks of KP pixels (a TH x TW patch of one output plane, or KP consecutive pixels for 1x1 / stride 1).
+//     Per chunk a workgroup stages dY[BM rows][KP] and the input patch X[BC channels][PH x PWL] that covers the pixels of the
+//     chunk under all nine taps -- every input element is fetched once per chunk and reused for all taps and all BM rows.
+//   * The two k values of one MFMA (lane halves) are pixels 8j + i and 8j + 4 + i, so the A operand of four consecutive
+//     MFMAs is ONE 16-byte LDS read; the B operand is the lane's channel at a tap-shifted pixel: per-lane base + immediate.
+//   * One workgroup = 8 waves = one CU (LDS 90-140 KB): waves w and w + 4 share a SIMD and own complementary halves of the
+//     n-tiles (taps 0..4 / 5..8), so every SIMD issues the same number of MFMAs; two LDS buffers, chunk t + 1 travels
+//     global -> registers while chunk t is multiplied, one barrier per chunk.  The kernel does not depend on a second
+//     resident workgroup to hide its staging, so a launch of k * 256 workgroups fills the chip evenly.
+//   * split K: the grid is (output tiles) x S pixel ranges; every workgroup writes its partial tile to a workspace
+//     [S][Cout][taps][Cin] and k_wgrad_reduce adds the S slices in a fixed order (run-to-run identical, no atomics) into
+//     dW[Cout][Cin][k][k].  Workgroups of one pixel range sit on one XCD (they stream the same chunks through its L2).
+#include <type_traits>
+
+#include "common.h"
+
+namespace {
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float v4f __attribute__((ext_vector_type(4)));
+constexpr int kWgThreads = 512;
+
+struct WgP {
+    const float* x;
+    const float* dy;
+    float* part;
+    int N, Cin, H, W, Cout, Ho, Wo;
+    int tiles_x, tiles_y, nch;          // K chunks: pictures x pixel tiles (PATCH) / pictures x ceil(HW / KP) (FLAT)
+    int mtiles, ctiles, S;
+};
+
+template <int TAPS, int WM, int CG, int TW, int KP, int STRIDE, int DIL, bool FLAT>
+struct WgGeom {
+    static constexpr int BM = 32 * WM, BC = 32 * CG, NT = TAPS * CG;
+    static constexpr int KH = (WM == 2 && !FLAT) ? 2 : 1;       // K halves inside the workgroup (8 waves = WM x 2 tile groups x KH)
+    static constexpr int TH = KP / TW;
+    static constexpr int PAD = TAPS == 9 ? DIL : 0;
+    static constexpr int PH = FLAT ? 1 : (TH - 1) * STRIDE + 1 + 2 * PAD;
+    static constexpr int PWL = FLAT ? KP + 4 : (((TW - 1) * STRIDE + 1 + 8) + 3) & ~3;     // patch row: 4 columns of halo on the left, >= 4 on the right
+    static constexpr int CS = FLAT ? KP + 4 : PH * PWL + 1;     // channel stride in LDS: odd -> 32 channels on 32 banks
+    static constexpr int RS = KP + 4;                           // dY row stride: 4 * odd -> conflict-free 16-byte reads
+    static constexpr int ASZ = BM * RS, BSZ = BC * CS;
+    static constexpr int NG = FLAT ? 8 / WM : 2;                // n-tile groups of the 8 waves
+    static constexpr int NT0 = (NT + NG - 1) / NG;              // n-tiles of a wave (the last group may own fewer)
+    static constexpr int RED = KH == 2 ? 4 * NT0 * 1024 : 0;    // floats of the K-half reduction in the epilogue
+    static constexpr int FLOATS = 2 * (ASZ + BSZ) > RED ? 2 * (ASZ + BSZ) : RED;
+    static constexpr size_t SMEM = sizeof(float) * FLOATS;
+};
+
+// FLAT (1x1, stride 1): 8 waves = WM m-tiles x NG n-groups, each wave NTW = NT / NG n-tiles of 32 input channels, both operands
+//                       read with ds_read_b128.
+// PATCH: 8 waves = WM m-tiles x 2 tile groups (x 2 K halves when WM == 2); B read per pixel with ds_read_b32.
+template <int TAPS, int WM, int CG, int TW, int KP, int STRIDE, int DIL, bool VEC, bool FLAT>
+__global__ __launch_bounds__(kWgThreads) void k_wgrad(const WgP p) {
+    using G = WgGeom<TAPS, WM, CG, TW, KP, STRIDE, DIL, FLAT>;
+    constexpr int BM = G::BM, BC = G::BC, NT = G::NT, KH = G::KH, PAD = G::PAD, PH = G::PH, PWL = G::PWL, CS = G::CS, RS = G::RS;
+    constexpr int ASZ = G::ASZ, BSZ = G::BSZ;
+    constexpr int NG = G::NG, NT0 = G::NT0;
+    constexpr int F4R = KP / 4;                             // float4 per dY row
+    constexpr int NA = (BM * F4R + kWgThreads - 1) / kWgThreads;
+    constexpr int F4C = FLAT ? F4R : PH * PWL / 4;          // float4 per staged input channel
+    constexpr int NB = (BC * F4C + kWgThreads - 1) / kWgThreads;
+    static_assert(KP % 8 == 0 && (FLAT || (KP % TW == 0 && TW % 8 == 0)), "chunk");
+    static_assert(KH == 1 || (KP / 2) % TW == 0, "K halves must split the chunk at a row boundary");
+    static_assert(NT % NG == 0 || !FLAT, "FLAT n-tiles must divide");
+    extern __shared__ __attribute__((aligned(16))) float wg_smem[];
+
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, l31 = lane & 31, h = lane >> 5;
+    const int mtw = wave % WM;
+    const int khw = KH == 2 ? (wave / WM) & 1 : 0;
+    const int tg = FLAT ? wave / WM : wave >> 2;            // PATCH: waves w and w + 4 (one SIMD) own complementary tile groups
+
+    // block -> (pixel range s, input-channel tile ct, output-channel tile mt); the tiles of one range share an XCD
+    const int tiles = p.mtiles * p.ctiles;
+    const int bid = blockIdx.x;
+    const int xcd = bid & 7, slot = bid >> 3;
+    const int s = (slot / tiles) * 8 + xcd;
+    if (s >= p.S) return;
+    const int tile = slot % tiles;
+    const int mt = tile % p.mtiles, ct = tile / p.mtiles;
+    const int m0 = mt * BM, c0 = ct * BC;
+    const int q0 = (int)((long long)s * p.nch / p.S), q1 = (int)((long long)(s + 1) * p.nch / p.S);
+    const int HW = p.H * p.W, HWo = p.Ho * p.Wo;
+
+    v4f ra[NA], rb[NB];
+
+    auto fetch = [&](int q) {
+        if (FLAT) {
+            const int cpi = (HW + KP - 1) / KP;
+            const int n = q / cpi, k0 = (q - n * cpi) * KP;
+            const float* dyb = p.dy + (size_t)n * p.Cout * HWo + k0;
+            const float* xb = p.x + (size_t)n * p.Cin * HW + k0;
+#pragma unroll
+            for (int j = 0; j < NA; ++j) {
+                const int f = tid + j * kWgThreads;
+                const int m = f / F4R, kp = (f % F4R) * 4;
+                const bool rowok = f < BM * F4R && m0 + m < p.Cout;
+                const float* src = dyb + (size_t)(m0 + m) * HWo + kp;
+                if (VEC) {
+                    ra[j] = (rowok && k0 + kp < HW) ? *reinterpret_cast<const v4f*>(src) : (v4f){0.f, 0.f, 0.f, 0.f};
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) ra[j][e] = (rowok && k0 + kp + e < HW) ? src[e] : 0.0f;
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < NB; ++j) {
+                const int f = tid + j * kWgThreads;
+                const int c = f / F4R, kp = (f % F4R) * 4;
+                const bool rowok = f < BC * F4R && c0 + c < p.Cin;
+                const float* src = xb + (size_t)(c0 + c) * HW + kp;
+                if (VEC) {
+                    rb[j] = (rowok && k0 + kp < HW) ? *reinterpret_cast<const v4f*>(src) : (v4f){0.f, 0.f, 0.f, 0.f};
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) rb[j][e] = (rowok && k0 + kp + e < HW) ? src[e] : 0.0f;
+                }
+            }
+        } else {
+            const int tpi = p.tiles_x * p.tiles_y;
+            const int n = q / tpi, r = q - n * tpi;
+            const int tyi = r / p.tiles_x, txi = r - tyi * p.tiles_x;
+            const int oy0 = tyi * G::TH, ox0 = txi * TW;
+            const int iy0 = oy0 * STRIDE - PAD, ix0 = ox0 * STRIDE - 4;
+            const float* dyb = p.dy + (size_t)n * p.Cout * HWo;
+            const float* xb = p.x + (size_t)n * p.Cin * HW;
+#pragma unroll
+            for (int j = 0; j < NA; ++j) {
+                const int f = tid + j * kWgThreads;
+                const int m = f / F4R, kp = (f % F4R) * 4;
+                const int oy = oy0 + kp / TW, ox = ox0 + kp % TW;
+                const bool rowok = f < BM * F4R && m0 + m < p.Cout && oy < p.Ho;
+                const float* src = dyb + (size_t)(m0 + m) * HWo + oy * p.Wo + ox;
+                if (VEC) {
+                    ra[j] = (rowok && ox < p.Wo) ? *reinterpret_cast<const v4f*>(src) : (v4f){0.f, 0.f, 0.f, 0.f};
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) ra[j][e] = (rowok && ox + e < p.Wo) ? src[e] : 0.0f;
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < NB; ++j) {
+                const int f = tid + j * kWgThreads;
+                const int c = f / F4C, rem = f % F4C;
+                const int row = rem / (PWL / 4), col = (rem % (PWL / 4)) * 4;
+                const int iy = iy0 + row, ix = ix0 + col;
+                const bool rowok = f < BC * F4C && c0 + c < p.Cin && (unsigned)iy < (unsigned)p.H;
+                const float* src = xb + (size_t)(c0 + c) * HW + iy * p.W + ix;
+                if (VEC) {
+                    rb[j] = (rowok && (unsigned)ix < (unsigned)p.W) ? *reinterpret_cast<const v4f*>(src) : (v4f){0.f, 0.f, 0.f, 0.f};
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) rb[j][e] = (rowok && (unsigned)(ix + e) < (unsigned)p.W) ? src[e] : 0.0f;
+                }
+            }
+        }
+    };
+
+    auto stage = [&](int buf) {
+        float* sA = wg_smem + buf * (ASZ + BSZ);
+        float* sB = sA + ASZ;
+#pragma unroll
+        for (int j = 0; j < NA; ++j) {
+            const int f = tid + j * kWgThreads;
+            if (f < BM * F4R) *reinterpret_cast<v4f*>(sA + (f / F4R) * RS + (f % F4R) * 4) = ra[j];
+        }
+#pragma unroll
+        for (int j = 0; j < NB; ++j) {
+            const int f = tid + j * kWgThreads;
+            if (FLAT) {
+                if (f < BC * F4R) *reinterpret_cast<v4f*>(sB + (f / F4R) * CS + (f % F4R) * 4) = rb[j];
+            } else if (f < BC * F4C) {
+                float* dst = sB + (f / F4C) * CS + (f % F4C) * 4;       // channel stride is odd: four 4-byte stores
+                dst[0] = rb[j][0]; dst[1] = rb[j][1]; dst[2] = rb[j][2]; dst[3] = rb[j][3];
+            }
+        }
+    };
+
+    f32x16 acc[NT0];
+#pragma unroll
+    for (int t = 0; t < NT0; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.0f;
+
+    // one chunk of MFMAs for the wave's n-tiles [T0, T0 + TN)
+    const int aoff = (mtw * 32 + l31) * RS + 4 * h + khw * (KP / 2);
+    const int boff = FLAT ? (tg * NT0 * 32 + l31) * CS + 4 * h : l31 * CS + 4 * h * STRIDE + khw * ((KP / 2) / TW) * STRIDE * PWL;
+    auto mfma_chunk = [&](int buf, auto T0c, auto TNc) {
+        constexpr int T0 = decltype(T0c)::value, TN = decltype(TNc)::value;
+        const float* sA = wg_smem + buf * (ASZ + BSZ);
+        const float* sB = sA + ASZ;
+#pragma unroll
+        for (int jl = 0; jl < KP / 8 / KH; ++jl) {
+            const v4f a = *reinterpret_cast<const v4f*>(sA + aoff + 8 * jl);
+            if constexpr (FLAT) {
+                v4f b[TN];
+#pragma unroll
+                for (int t = 0; t < TN; ++t) b[t] = *reinterpret_cast<const v4f*>(sB + boff + (T0 + t) * 32 * CS + 8 * jl);
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int t = 0; t < TN; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[t][i], acc[t], 0, 0, 0);
+            } else {
+                const int ty = (8 * jl) / TW, txb = (8 * jl) % TW;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    float b[TN];
+#pragma unroll
+                    for (int t = 0; t < TN; ++t) {
+                        const int cg = (T0 + t) / TAPS, tap = (T0 + t) % TAPS;
+                        const int ky = TAPS == 9 ? tap / 3 : 0, kx = TAPS == 9 ? tap % 3 : 0;
+                        b[t] = sB[boff + cg * 32 * CS + (ty * STRIDE + ky * DIL) * PWL + (txb + i) * STRIDE + kx * DIL - PAD + 4];
+                    }
+#pragma unroll
+                    for (int t = 0; t < TN; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[t], acc[t], 0, 0, 0);
+                }
+            }
+        }
+    };
+    auto mfma = [&](int buf) {
+        if constexpr (FLAT) {           // the wave's tile group is an address offset (boff)
+            mfma_chunk(buf, std::integral_constant<int, 0>{}, std::integral_constant<int, NT0>{});
+        } else {                        // tap subsets differ per group: two instruction streams, chosen per wave
+            if (tg == 0) mfma_chunk(buf, std::integral_constant<int, 0>{}, std::integral_constant<int, NT0>{});
+            else if constexpr (NT - NT0 > 0) mfma_chunk(buf, std::integral_constant<int, NT0>{}, std::integral_constant<int, NT - NT0>{});
+        }
+    };
+
+    int buf = 0;
+    fetch(q0);
+    stage(0);
+    __syncthreads();
+    for (int q = q0; q < q1; ++q) {
+        const bool more = q + 1 < q1;
+        if (more) fetch(q + 1);
+        mfma(buf);
+        if (more) stage(buf ^ 1);
+        __syncthreads();
+        buf ^= 1;
+    }
+
+    // ---- epilogue: K halves added through LDS, then the partial tile -> part[s][m][tap][c] ----------------------------------
+    if constexpr (KH == 2) {
+        float* red = wg_smem;                   // [4 waves][NT0][16][64]: all chunk reads are behind the last barrier
+        if (khw == 1) {
+#pragma unroll
+            for (int t = 0; t < NT0; ++t)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) red[(((wave & 1) + 2 * tg) * NT0 + t) * 1024 + r * 64 + lane] = acc[t][r];
+        }
+        __syncthreads();
+        if (khw == 1) return;
+#pragma unroll
+        for (int t = 0; t < NT0; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[t][r] += red[(((wave & 1) + 2 * tg) * NT0 + t) * 1024 + r * 64 + lane];
+    }
+    float* pb = p.part + (size_t)s * p.Cout * TAPS * p.Cin;
+    const int tbase = tg * NT0;
+#pragma unroll
+    for (int t = 0; t < NT0; ++t) {
+        const int tt = tbase + t;
+        if (tt < NT) {
+            const int cg = tt / TAPS, tap = tt % TAPS;
+            const int c = c0 + cg * 32 + l31;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + mtw * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                if (m < p.Cout && c < p.Cin) pb[((size_t)m * TAPS + tap) * p.Cin + c] = acc[t][r];
+            }
+        }
+    }
+}
+
+// dW[m][c][tap] = sum_s part[s][m][tap][c], slices added in order; threads walk the partial layout (coalesced reads)
+__global__ __launch_bounds__(256) void k_wgrad_reduce(const float* __restrict__ part, int S, int Cout, int Cin, int taps, float* __restrict__ dw) {
+    const size_t n = (size_t)Cout * taps * Cin;
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    float v = part[i];
+    for (int s = 1; s < S; ++s) v += part[(size_t)s * n + i];
+    const int c = (int)(i % Cin);
+    const size_t mt = i / Cin;
+    const int tap = (int)(mt % taps);
+    const size_t m = mt / taps;
+    dw[(m * Cin + c) * taps + tap] = v;
+}
+
+// S pixel ranges.  One workgroup fills a CU, so the launch should be k * 256 equal workgroups; every workgroup pays about one
+// chunk time of prologue / epilogue, and the S partial slices are written and re-read once (bounded by kPartCap).
+constexpr size_t kPartCap = (size_t)48 << 20;
+inline int wg_pick_split(int tiles, int nch, size_t slice_bytes) {
+    int best = 1;
+    double best_score = -1.0;
+    const int smax = nch < 1024 ? nch : 1024;
+    for (int S = 1; S <= smax; ++S) {
+        if (S > 1 && (size_t)S * slice_bytes > kPartCap) break;
+        const long long wg = (long long)tiles * S;
+        const long long rounds = (wg + 255) / 256;
+        const double fill = (double)wg / (double)(rounds * 256);
+        const double per = (double)nch / S;                     // chunks per workgroup
+        const double score = fill * per / (per + 1.5) - 2e-4 * S;
+        if (score > best_score) {
+            best_score = score;
+            best = S;
+        }
+    }
+    return best;
+}
+
+template <int TAPS, int WM, int CG, int TW, int KP, int STRIDE, int DIL, bool VEC, bool FLAT>
+int wg_launch(WgP p, hipStream_t st) {
+    using G = WgGeom<TAPS, WM, CG, TW, KP, STRIDE, DIL, FLAT>;
+    auto kern = &k_wgrad<TAPS, WM, CG, TW, KP, STRIDE, DIL, VEC, FLAT>;
+    static_assert(G::SMEM <= 160 * 1024, "LDS");
+    if (G::SMEM > 64 * 1024) {
+        static bool raised[64] = {};                    // per device: the attribute belongs to the device's copy of the code object
+        int dev = 0;
+        hipError_t e = hipGetDevice(&dev);
+        if (e != hipSuccess) return (int)e;
+        if (dev < 0 || dev >= 64 || !raised[dev]) {
+            e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::SMEM);
+            if (e != hipSuccess) return (int)e;
+            if (dev >= 0 && dev < 64) raised[dev] = true;
+        }
+    }
+    const long long nblk = 8LL * ((p.S + 7) / 8) * p.mtiles * p.ctiles;
+    if (nblk <= 0 || nblk > 0x7fffffffLL) return MAS_ERR_SHAPE;
+    hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(kWgThreads), G::SMEM, st, p);
+    return mas_launch_status();
+}
+
+struct WgShape {
+    int BM, BC, KP, TW, flat;
+};
+
+inline bool wg_shape(int Cout, int ksize, int stride, int dil, int Wo, WgShape* g) {
+    g->flat = ksize == 1 && stride == 1;
+    g->BM = Cout > 64 ? 128 : 64;
+    g->TW = Wo >= 32 && !(Wo % 32 != 0 && Wo % 16 == 0) ? 32 : 16;       // 48-wide planes: three exact 16-wide tiles
+    if (g->flat) {
+        g->BC = 128;
+        g->KP = 64;
+    } else if (stride == 2) {
+        g->BC = ksize == 3 ? 32 : 64;
+        g->KP = 32;
+        g->TW = 16;
+    } else {
+        g->BC = 32;
+        g->KP = 64;
+        if (dil == 4) g->TW = 16;
+    }
+    return true;
+}
+}  // namespace
+
+extern "C" size_t mas_conv_wgrad_workspace_bytes(int N, int Cin, int H, int W, int Cout, int ksize, int stride, int dil) {
+    (void)dil;
+    if (N <= 0 || Cin <= 0 || H <= 0 || W <= 0 || Cout <= 0 || (ksize != 1 && ksize != 3) || (stride != 1 && stride != 2)) return 0;
+    // the split count never exceeds what wg_pick_split's cap admits; one slice always fits
+    const size_t slice = sizeof(float) * (size_t)Cout * Cin * ksize * ksize;
+    size_t smax = kPartCap / slice;
+    if (smax < 1) smax = 1;
+    if (smax > 1024) smax = 1024;
+    return smax * slice;
+}
+
+extern "C" int mas_conv_wgrad(const float* x, const float* dy, int N, int Cin, int H, int W, int Cout, int ksize, int stride, int dil,
+                              float* dw, void* workspace, size_t workspace_bytes, void* stream) {
+    if (!x || !dy || !dw || !workspace) return MAS_ERR_NULL;
+    if (N <= 0 || Cin <= 0 || H <= 0 || W <= 0 || Cout <= 0) return MAS_ERR_SHAPE;
+    if ((ksize != 1 && ksize != 3) || (stride != 1 && stride != 2)) return MAS_ERR_RANGE;
+    if (ksize == 1 && dil != 1) return MAS_ERR_RANGE;
+    if (ksize == 3 && !(dil == 1 || (stride == 1 && (dil == 2 || dil == 4)))) return MAS_ERR_RANGE;
+    if ((long long)Cin * H * W > 0x7fffffffLL || (long long)Cout * H * W > 0x7fffffffLL) return MAS_ERR_SHAPE;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    WgP p;
+    p.x = x; p.dy = dy; p.part = static_cast<float*>(workspace);
+    p.N = N; p.Cin = Cin; p.H = H; p.W = W; p.Cout = Cout;
+    p.Ho = (H - 1) / stride + 1;
+    p.Wo = (W - 1) / stride + 1;
+    WgShape g;
+    wg_shape(Cout, ksize, stride, dil, p.Wo, &g);
+    const int taps = ksize * ksize;
+    p.mtiles = (Cout + g.BM - 1) / g.BM;
+    p.ctiles = (Cin + g.BC - 1) / g.BC;
+    if (g.flat) {
+        p.tiles_x = p.tiles_y = 0;
+        p.nch = N * ((H * W + g.KP - 1) / g.KP);
+    } else {
+        p.tiles_x = (p.Wo + g.TW - 1) / g.TW;
+        p.tiles_y = (p.Ho + g.KP / g.TW - 1) / (g.KP / g.TW);
+        p.nch = N * p.tiles_x * p.tiles_y;
+    }
+    const size_t slice = sizeof(float) * (size_t)Cout * Cin * taps;
+    p.S = wg_pick_split(p.mtiles * p.ctiles, p.nch, slice);
+    while (p.S > 1 && (size_t)p.S * slice > workspace_bytes) --p.S;
+    if ((size_t)p.S * slice > workspace_bytes) return MAS_ERR_WORKSPACE;
+    const bool al = ((uintptr_t)x % 16 == 0) && ((uintptr_t)dy % 16 == 0);
+    const bool vec = al && (g.flat ? (H * W) % 4 == 0 : (W % 4 == 0 && p.Wo % 4 == 0));
+    int rc = MAS_ERR_SHAPE;
+    const bool big = g.BM == 128;
+#define WG_GO(TAPS, CG, TW, KP, STRIDE, DIL, FLAT)                                                                            \
+    rc = big ? (vec ? wg_launch<TAPS, 4, CG, TW, KP, STRIDE, DIL, true, FLAT>(p, st) : wg_launch<TAPS, 4, CG, TW, KP, STRIDE, DIL, false, FLAT>(p, st)) \
+             : (vec ? wg_launch<TAPS, 2, CG, TW, KP, STRIDE, DIL, true, FLAT>(p, st) : wg_launch<TAPS, 2, CG, TW, KP, STRIDE, DIL, false, FLAT>(p, st))
+    if (g.flat) {
+        WG_GO(1, 4, 32, 64, 1, 1, true);
+    } else if (ksize == 1) {
+        WG_GO(1, 2, 16, 32, 2, 1, false);
+    } else if (stride == 2) {
+        WG_GO(9, 1, 16, 32, 2, 1, false);
+    } else if (dil == 1) {
+        if (g.TW == 32) { WG_GO(9, 1, 32, 64, 1, 1, false); } else { WG_GO(9, 1, 16, 64, 1, 1, false); }
+    } else if (dil == 2) {
+        if (g.TW == 32) { WG_GO(9, 1, 32, 64, 1, 2, false); } else { WG_GO(9, 1, 16, 64, 1, 2, false); }
+    } else {
+        WG_GO(9, 1, 16, 64, 1, 4, false);          // the 32-wide patch of dilation 4 does not fit two LDS buffers
+    }
+#undef WG_GO
+    if (rc != 0) return rc;
+    const size_t n = (size_t)Cout * taps * Cin;
+    hipLaunchKernelGGL(k_wgrad_reduce, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, p.part, p.S, Cout, Cin, taps, dw);
+    return mas_launch_status();
+}

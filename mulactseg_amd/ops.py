@@ -1002,3 +1002,110 @@ def stem_conv(conv, x, bn=None, relu=False):
         _lib.check(_lib.load().mas_stem_conv_fwd(x.data_ptr(), w.data_ptr(), N, H, W, M, _opt(scale), _opt(shift), int(relu), y.data_ptr(),
                                                  _stream(x)), "mas_stem_conv_fwd")
     return y
+
+
+# ------------------------------------------------------------------------------------------------
+# training-mode dense convolutions: forward, input gradient and weight gradient on the f32 matrix cores
+# (csrc/conv_mfma.hip, csrc/conv_wgrad.hip) -- no MIOpen, no NCHW <-> NHWC copies
+# ------------------------------------------------------------------------------------------------
+_WGRAD_WS = {}
+
+
+def _wgrad_workspace(dev, nbytes):
+    """One split-K workspace per device, grown on demand (the kernels of one stream run in order, so consecutive weight
+    gradients can share it)."""
+    ws = _WGRAD_WS.get(dev)
+    if ws is None or ws.numel() < nbytes:
+        ws = _WGRAD_WS[dev] = torch.empty(int(nbytes), dtype=torch.uint8, device=dev)
+    return ws
+
+
+def conv_wgrad(x, dy, ksize, stride, dil):
+    """dW [Cout,Cin,k,k] of y = conv2d(x, W, stride, padding = dil (k = 3) / 0 (k = 1), dilation) from x [N,Cin,H,W] and
+    dy [N,Cout,Ho,Wo] (mas_conv_wgrad: split-K over the pixels, fixed-order reduction)."""
+    _need(x, "x", torch.float32)
+    _need(dy, "dy", torch.float32)
+    N, Cin, H, W = x.shape
+    Cout = dy.shape[1]
+    Ho, Wo = (H - 1) // stride + 1, (W - 1) // stride + 1
+    if tuple(dy.shape) != (N, Cout, Ho, Wo):
+        raise ValueError("dy %s does not match x %s under stride %d" % (tuple(dy.shape), tuple(x.shape), stride))
+    lib = _lib.load()
+    nbytes = lib.mas_conv_wgrad_workspace_bytes(N, Cin, H, W, Cout, ksize, stride, dil)
+    if nbytes == 0:
+        raise ValueError("unsupported convolution geometry for mas_conv_wgrad")
+    ws = _wgrad_workspace(x.device, nbytes)
+    dw = torch.empty((Cout, Cin, ksize, ksize), dtype=torch.float32, device=x.device)
+    with torch.cuda.device(x.device):
+        _lib.check(lib.mas_conv_wgrad(x.data_ptr(), dy.data_ptr(), N, Cin, H, W, Cout, ksize, stride, dil, dw.data_ptr(),
+                                      ws.data_ptr(), ws.numel(), _stream(x)), "mas_conv_wgrad")
+    return dw
+
+
+def _pack_conv_weight(w):
+    """[M,K,kh,kw] -> the layout mas_conv_fwd reads (see _conv_packed_weight), M padded to 64 with zero rows."""
+    M, K, kh, kw = w.shape
+    ck = _lib.load().mas_conv_chunk(kh, K)
+    taps = kh * kw
+    if M % 64:
+        w = torch.cat([w, w.new_zeros((64 - M % 64, K, kh, kw))], dim=0)
+        M = w.shape[0]
+    w = w.reshape(M, K // ck, ck // 2, 2, taps)
+    w = w.permute(1, 4, 2, 3, 0).reshape(K // ck, taps * ck // 8, 4, 2, M).permute(0, 1, 3, 4, 2).contiguous()
+    return w
+
+
+def _conv_fwd_raw(x, wt, Cout, ksize, stride, dil):
+    N, K, H, W = x.shape
+    Ho, Wo = (H - 1) // stride + 1, (W - 1) // stride + 1
+    y = torch.empty((N, Cout, Ho, Wo), dtype=torch.float32, device=x.device)
+    with torch.cuda.device(x.device):
+        _lib.check(_lib.load().mas_conv_fwd(x.data_ptr(), wt.data_ptr(), N, K, H, W, Cout, ksize, stride, dil, None, None, None, 0,
+                                            y.data_ptr(), _stream(x)), "mas_conv_fwd")
+    return y
+
+
+class _ConvTrain(torch.autograd.Function):
+    """y = conv2d(x, w) with autograd: forward and input gradient on k_conv_mfma (the input gradient is the same kernel on
+    the transposed, tap-flipped weight), weight gradient on k_wgrad."""
+
+    @staticmethod
+    def forward(ctx, x, w, stride, dil):
+        x = x.contiguous()
+        ks = w.shape[2]
+        with torch.no_grad():
+            y = _conv_fwd_raw(x, _pack_conv_weight(w.detach()), w.shape[0], ks, stride, dil)
+        ctx.save_for_backward(x, w)
+        ctx.geom = (ks, stride, dil)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w = ctx.saved_tensors
+        ks, stride, dil = ctx.geom
+        dy = dy.contiguous()
+        dx = dw = None
+        if ctx.needs_input_grad[0]:
+            if stride == 1:
+                wt = _pack_conv_weight(w.detach().permute(1, 0, 2, 3).flip(2, 3))
+                dx = _conv_fwd_raw(dy, wt, w.shape[1], ks, 1, dil)
+            else:
+                pad = dil if ks == 3 else 0
+                dx = torch.ops.aten.convolution_backward(dy, x, w, None, (stride, stride), (pad, pad), (dil, dil), False, (0, 0), 1,
+                                                         (True, False, False))[0]
+        if ctx.needs_input_grad[1]:
+            dw = conv_wgrad(x, dy, ks, stride, dil)
+        return dx, dw, None, None
+
+
+def conv_train_supported(conv, x):
+    """Training-mode path of a dense convolution: the shapes conv_mfma_supported takes whose output-channel count also
+    works as the K extent of the input-gradient product (Cout % 8 for 3x3, % 16 for 1x1)."""
+    if not conv_mfma_supported(conv, x):
+        return False
+    k = conv.kernel_size[0]
+    return _lib.load().mas_conv_chunk(k, conv.out_channels) > 0 and x.shape[2] * x.shape[3] >= 64
+
+
+def conv_train(conv, x):
+    return _ConvTrain.apply(x, conv.weight, conv.stride[0], conv.dilation[0])
