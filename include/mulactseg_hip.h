@@ -413,6 +413,9 @@ int mas_conv_fwd(const float* x, const float* wt, int N, int Cin, int H, int W, 
  * planes allow them).  Split-K partial sums go through `workspace` (mas_conv_wgrad_workspace_bytes) and are added in a fixed
  * order: run-to-run identical results. */
 size_t mas_conv_wgrad_workspace_bytes(int N, int Cin, int H, int W, int Cout, int ksize, int stride, int dil);
+/* the launch plan of mas_conv_wgrad for a geometry (host only, for tools): out6 = {BM, BC, pixels per K chunk, K chunks, split S,
+ * workgroups} */
+int mas_conv_wgrad_plan(int N, int Cin, int H, int W, int Cout, int ksize, int stride, int dil, int* out6);
 int mas_conv_wgrad(const float* x, const float* dy, int N, int Cin, int H, int W, int Cout, int ksize, int stride, int dil,
                    float* dw, void* workspace, size_t workspace_bytes, void* stream);
 

@@ -64,6 +64,7 @@ SIGNATURES = {
     "mas_conv_chunk": (_i, [_i, _i]),
     "mas_conv_fwd": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _i, _vp, _vp]),
     "mas_conv_wgrad_workspace_bytes": (_c.c_size_t, [_i, _i, _i, _i, _i, _i, _i, _i]),
+    "mas_conv_wgrad_plan": (_i, [_i, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "mas_conv_wgrad": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _c.c_size_t, _vp]),
     "mas_depthwise3x3_fwd": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp, _vp]),
     "mas_depthwise3x3_bwd_x": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp, _vp]),

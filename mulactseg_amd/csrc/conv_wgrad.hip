@@ -79,14 +79,15 @@ __global__ __launch_bounds__(kWgThreads) void k_wgrad(const WgP p) {
     const int khw = KH == 2 ? (wave / WM) & 1 : 0;
     const int tg = FLAT ? wave / WM : wave >> 2;            // PATCH: waves w and w + 4 (one SIMD) own complementary tile groups
 
-    // block -> (pixel range s, input-channel tile ct, output-channel tile mt); the tiles of one range share an XCD
-    const int tiles = p.mtiles * p.ctiles;
+    // block -> unit (pixel range s, input-channel tile ct) x output-channel tile mt.  The mtiles workgroups of a unit stream
+    // the same input patches: a unit sits on ONE XCD (blocks b and b + 8 share an XCD), units are dealt round-robin over the 8.
+    const int units = p.S * p.ctiles;
     const int bid = blockIdx.x;
     const int xcd = bid & 7, slot = bid >> 3;
-    const int s = (slot / tiles) * 8 + xcd;
-    if (s >= p.S) return;
-    const int tile = slot % tiles;
-    const int mt = tile % p.mtiles, ct = tile / p.mtiles;
+    const int unit = (slot / p.mtiles) * 8 + xcd;
+    if (unit >= units) return;
+    const int mt = slot % p.mtiles;
+    const int ct = unit % p.ctiles, s = unit / p.ctiles;
     const int m0 = mt * BM, c0 = ct * BC;
     const int q0 = (int)((long long)s * p.nch / p.S), q1 = (int)((long long)(s + 1) * p.nch / p.S);
     const int HW = p.H * p.W, HWo = p.Ho * p.Wo;
@@ -194,12 +195,15 @@ __global__ __launch_bounds__(kWgThreads) void k_wgrad(const WgP p) {
     // one chunk of MFMAs for the wave's n-tiles [T0, T0 + TN)
     const int aoff = (mtw * 32 + l31) * RS + 4 * h + khw * (KP / 2);
     const int boff = FLAT ? (tg * NT0 * 32 + l31) * CS + 4 * h : l31 * CS + 4 * h * STRIDE + khw * ((KP / 2) / TW) * STRIDE * PWL;
-    auto mfma_chunk = [&](int buf, auto T0c, auto TNc) {
-        constexpr int T0 = decltype(T0c)::value, TN = decltype(TNc)::value;
+    constexpr int JN = KP / 8 / KH;                 // groups of four MFMA k-steps per chunk and wave
+    constexpr int JSPLIT = (3 * JN + 3) / 4;        // the next chunk is written to LDS after this many groups (its loads have had
+                                                    // 3/4 of a chunk to arrive; the other buffer's readers are behind the last barrier)
+    auto mfma_chunk = [&](int buf, auto T0c, auto TNc, auto JLc, auto JHc) {
+        constexpr int T0 = decltype(T0c)::value, TN = decltype(TNc)::value, jlo = decltype(JLc)::value, jhi = decltype(JHc)::value;
         const float* sA = wg_smem + buf * (ASZ + BSZ);
         const float* sB = sA + ASZ;
 #pragma unroll
-        for (int jl = 0; jl < KP / 8 / KH; ++jl) {
+        for (int jl = jlo; jl < jhi; ++jl) {
             const v4f a = *reinterpret_cast<const v4f*>(sA + aoff + 8 * jl);
             if constexpr (FLAT) {
                 v4f b[TN];
@@ -226,12 +230,12 @@ __global__ __launch_bounds__(kWgThreads) void k_wgrad(const WgP p) {
             }
         }
     };
-    auto mfma = [&](int buf) {
+    auto mfma = [&](int buf, auto jlo, auto jhi) {
         if constexpr (FLAT) {           // the wave's tile group is an address offset (boff)
-            mfma_chunk(buf, std::integral_constant<int, 0>{}, std::integral_constant<int, NT0>{});
+            mfma_chunk(buf, std::integral_constant<int, 0>{}, std::integral_constant<int, NT0>{}, jlo, jhi);
         } else {                        // tap subsets differ per group: two instruction streams, chosen per wave
-            if (tg == 0) mfma_chunk(buf, std::integral_constant<int, 0>{}, std::integral_constant<int, NT0>{});
-            else if constexpr (NT - NT0 > 0) mfma_chunk(buf, std::integral_constant<int, NT0>{}, std::integral_constant<int, NT - NT0>{});
+            if (tg == 0) mfma_chunk(buf, std::integral_constant<int, 0>{}, std::integral_constant<int, NT0>{}, jlo, jhi);
+            else if constexpr (NT - NT0 > 0) mfma_chunk(buf, std::integral_constant<int, NT0>{}, std::integral_constant<int, NT - NT0>{}, jlo, jhi);
         }
     };
 
@@ -242,8 +246,9 @@ __global__ __launch_bounds__(kWgThreads) void k_wgrad(const WgP p) {
     for (int q = q0; q < q1; ++q) {
         const bool more = q + 1 < q1;
         if (more) fetch(q + 1);
-        mfma(buf);
+        mfma(buf, std::integral_constant<int, 0>{}, std::integral_constant<int, JSPLIT>{});
         if (more) stage(buf ^ 1);
+        mfma(buf, std::integral_constant<int, JSPLIT>{}, std::integral_constant<int, JN>{});
         __syncthreads();
         buf ^= 1;
     }
@@ -333,7 +338,7 @@ int wg_launch(WgP p, hipStream_t st) {
             if (dev >= 0 && dev < 64) raised[dev] = true;
         }
     }
-    const long long nblk = 8LL * ((p.S + 7) / 8) * p.mtiles * p.ctiles;
+    const long long nblk = 8LL * (((long long)p.S * p.ctiles + 7) / 8) * p.mtiles;
     if (nblk <= 0 || nblk > 0x7fffffffLL) return MAS_ERR_SHAPE;
     hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(kWgThreads), G::SMEM, st, p);
     return mas_launch_status();
@@ -372,6 +377,19 @@ extern "C" size_t mas_conv_wgrad_workspace_bytes(int N, int Cin, int H, int W, i
     if (smax < 1) smax = 1;
     if (smax > 1024) smax = 1024;
     return smax * slice;
+}
+
+extern "C" int mas_conv_wgrad_plan(int N, int Cin, int H, int W, int Cout, int ksize, int stride, int dil, int* out6) {
+    if (!out6) return MAS_ERR_NULL;
+    if (N <= 0 || Cin <= 0 || H <= 0 || W <= 0 || Cout <= 0 || (ksize != 1 && ksize != 3) || (stride != 1 && stride != 2)) return MAS_ERR_SHAPE;
+    WgShape g;
+    const int Ho = (H - 1) / stride + 1, Wo = (W - 1) / stride + 1;
+    wg_shape(Cout, ksize, stride, dil, Wo, &g);
+    const int mtiles = (Cout + g.BM - 1) / g.BM, ctiles = (Cin + g.BC - 1) / g.BC;
+    const int nch = g.flat ? N * ((H * W + g.KP - 1) / g.KP) : N * ((Wo + g.TW - 1) / g.TW) * ((Ho + g.KP / g.TW - 1) / (g.KP / g.TW));
+    const int S = wg_pick_split(mtiles * ctiles, nch, sizeof(float) * (size_t)Cout * Cin * ksize * ksize);
+    out6[0] = g.BM; out6[1] = g.BC; out6[2] = g.KP; out6[3] = nch; out6[4] = S; out6[5] = mtiles * ctiles * S;
+    return 0;
 }
 
 extern "C" int mas_conv_wgrad(const float* x, const float* dy, int N, int Cin, int H, int W, int Cout, int ksize, int stride, int dil,

@@ -85,6 +85,10 @@ def main():
         ref = torch.ops.aten.convolution_backward(dy.double(), x.double(), w.double(), None, (s, s), pad, (d, d), False, (0, 0), 1,
                                                   (False, True, False))[1]
         err = float((dw.double() - ref).abs().max() / ref.abs().max())
+        import ctypes
+        plan = (ctypes.c_int * 6)()
+        from mulactseg_amd import _lib
+        _lib.load().mas_conv_wgrad_plan(xs[0], cin, xs[2], xs[3], cout, k, s, d, plan)
         n = len(names)
         for kk, v in t.items():
             tot[kk] += n * v
@@ -95,14 +99,14 @@ def main():
 
         def tf(us):
             return "%.0f" % (gflop / us * 1e3) if us and us > 0 else "-"
-        rows.append("| %d | %d | %d | %d | %d | %d | %dx%d | %.2f | %.0f / %s | %.0f / %s | %.0f / %s | %s / %s | %s / %s | %.1e | %s |" % (
+        rows.append("| %d | %d | %d | %d | %d | %d | %dx%d | %.2f | %.0f / %s | %.0f / %s | %.0f / %s | %s / %s | %s / %s | %.1e | S %d, %d wg x %d chunks | %s |" % (
             n, cin, cout, k, s, d, xs[2], xs[3], gflop, t["mi_f"], ("%.0f" % t["my_f"]) if "my_f" in t else "-",
             t["mi_d"], ("%.0f" % t["my_d"]) if "my_d" in t else "-", t["mi_w"], "%.0f" % t["my_w"],
-            tf(t["mi_d"]), tf(t.get("my_d")), tf(t["mi_w"]), tf(t["my_w"]), err, names[0]))
+            tf(t["mi_d"]), tf(t.get("my_d")), tf(t["mi_w"]), tf(t["my_w"]), err, plan[4], plan[5], plan[3] // max(1, plan[4]), names[0]))
     head = ["# dense convolutions of one training step, batch [%d,3,%d,%d] (tools/conv_train_table.py)" % (N, H, W), "",
             "us per call, MIOpen / this package; TF/s likewise; f32 MFMA peak %.1f TFLOP/s." % PEAK_TF, "",
-            "| x | Cin | Cout | k | s | d | plane | GFLOP | fwd us | dgrad us | wgrad us | dgrad TF/s | wgrad TF/s | wgrad rel err | first layer |",
-            "|---|---|---|---|---|---|---|---|---|---|---|---|---|---|---|"]
+            "| x | Cin | Cout | k | s | d | plane | GFLOP | fwd us | dgrad us | wgrad us | dgrad TF/s | wgrad TF/s | wgrad rel err | wgrad plan | first layer |",
+            "|---|---|---|---|---|---|---|---|---|---|---|---|---|---|---|---|"]
     foot = ["", "totals per step (us): forward MIOpen %.0f / mine (supported) %.0f; dgrad MIOpen %.0f / mine (stride 1) %.0f; wgrad MIOpen %.0f / mine %.0f;"
             % (tot["mi_f"], tot["my_f"], tot["mi_d"], tot["my_d"], tot["mi_w"], tot["my_w"]),
             "best-of per direction: fwd %.0f, dgrad %.0f, wgrad %.0f; floor per direction %.0f us; %.1f GFLOP per direction"
