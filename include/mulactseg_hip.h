@@ -403,6 +403,25 @@ int mas_conv_chunk(int ksize, int Cin);
 int mas_conv_fwd(const float* x, const float* wt, int N, int Cin, int H, int W, int Cout, int ksize, int stride, int dil,
                  const float* scale, const float* shift, const float* residual, int relu, float* y, void* stream);
 
+/* Forward and input gradient of a dense convolution in training, as a persistent stream-K implicit GEMM on the f32 matrix
+ * cores (csrc/conv_sk.hip); `w` is the weight as PyTorch stores it, [Cout][Cin][ksize][ksize] -- nothing is re-packed after an
+ * optimizer step.  The nn.Conv2d forward / backward-input of models/segmentation/backbone/resnet.py:129-171 and
+ * models/segmentation/deeplabv3.py:85-137,168-245 inside trainer/active_joint_multi_predignore_lossdecomp.py:83-116.
+ *   dgrad = 0:  y[n,m,oy,ox] = sum_{c,r,s} w[m,c,r,s] x[n,c, oy*stride + r*dil - pad, ox*stride + s*dil - pad]   x [N,Cin,H,W], y [N,Cout,Ho,Wo]
+ *   dgrad = 1:  y[n,c,iy,ix] = sum_{m,r,s} w[m,c,r,s] x[n,m, iy - r*dil + pad, ix - s*dil + pad]  (stride 1)       x [N,Cout,H,W], y [N,Cin,H,W]
+ * pad = dil (ksize 3) / 0 (ksize 1); ksize 1 | 3; stride 1 | 2 (stride 2: forward only, dil 1); dil <= 4 (ksize 3).  Epilogue as
+ * mas_conv_fwd: y*scale[m] + shift[m] (both or neither), + residual (same shape as y, may be NULL), ReLU if `relu`.
+ * One workgroup per CU; the (tile, K-chunk) iterations of the layer are dealt to the workgroups in equal runs, tiles that
+ * straddle two workgroups are combined through `workspace` (mas_conv_sk_workspace_bytes(), zero-filled ONCE by the caller, then
+ * owned by launches of ONE stream) in a fixed order: run-to-run identical results.  `epoch` must be non-zero and differ from the
+ * epoch of the previous launch on the same workspace.  mas_conv_sk_error copies the workspace's error word to the host
+ * (non-zero: a bounded wait for another workgroup gave up; results of that launch are invalid). */
+size_t mas_conv_sk_workspace_bytes(void);
+int mas_conv_sk(const float* x, const float* w, int N, int Cin, int H, int W, int Cout, int ksize, int stride, int dil, int dgrad,
+                const float* scale, const float* shift, const float* residual, int relu, float* y, void* workspace,
+                size_t workspace_bytes, unsigned epoch, void* stream);
+int mas_conv_sk_error(const void* workspace, unsigned* out_host);
+
 /* Weight gradient of a dense convolution on the f32 matrix cores (csrc/conv_wgrad.hip), NCHW operands as autograd holds them:
  *   dw[m,c,r,s] = sum_{n,oy,ox} dy[n,m,oy,ox] * x[n,c, oy*stride + r*dil - pad, ox*stride + s*dil - pad],  pad = dil (ksize 3) / 0 (ksize 1)
  * -- the backward of the nn.Conv2d modules of models/segmentation/backbone/resnet.py:129-171 and

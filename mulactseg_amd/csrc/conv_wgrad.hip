@@ -286,13 +286,23 @@ __global__ __launch_bounds__(kWgThreads) void k_wgrad(const WgP p) {
     }
 }
 
-// dW[m][c][tap] = sum_s part[s][m][tap][c], slices added in order; threads walk the partial layout (coalesced reads)
+// dW[m][c][tap] = sum_s part[s][m][tap][c]: threads walk the partial layout (coalesced reads), four loads in flight per thread;
+// the order of the additions is fixed: ((s = 0, 4, 8, ..) + (1, 5, ..)) + ((2, 6, ..) + (3, 7, ..))
 __global__ __launch_bounds__(256) void k_wgrad_reduce(const float* __restrict__ part, int S, int Cout, int Cin, int taps, float* __restrict__ dw) {
     const size_t n = (size_t)Cout * taps * Cin;
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
-    float v = part[i];
-    for (int s = 1; s < S; ++s) v += part[(size_t)s * n + i];
+    float v0 = 0.0f, v1 = 0.0f, v2 = 0.0f, v3 = 0.0f;
+    int s = 0;
+    for (; s + 4 <= S; s += 4) {
+        const float a = part[(size_t)s * n + i], b = part[(size_t)(s + 1) * n + i], c = part[(size_t)(s + 2) * n + i],
+                    d = part[(size_t)(s + 3) * n + i];
+        v0 += a; v1 += b; v2 += c; v3 += d;
+    }
+    if (s < S) v0 += part[(size_t)s * n + i];
+    if (s + 1 < S) v1 += part[(size_t)(s + 1) * n + i];
+    if (s + 2 < S) v2 += part[(size_t)(s + 2) * n + i];
+    const float v = (v0 + v1) + (v2 + v3);
     const int c = (int)(i % Cin);
     const size_t mt = i / Cin;
     const int tap = (int)(mt % taps);
@@ -302,10 +312,10 @@ __global__ __launch_bounds__(256) void k_wgrad_reduce(const float* __restrict__ 
 
 // S pixel ranges.  One workgroup fills a CU, so the launch should be k * 256 equal workgroups; every workgroup pays about one
 // chunk time of prologue / epilogue, and the S partial slices are written and re-read once (bounded by kPartCap).
-constexpr size_t kPartCap = (size_t)48 << 20;
-inline int wg_pick_split(int tiles, int nch, size_t slice_bytes) {
+constexpr size_t kPartCap = (size_t)64 << 20;
+inline int wg_pick_split(int tiles, int nch, size_t slice_bytes, double flop_per_chunk) {
     int best = 1;
-    double best_score = -1.0;
+    double best_score = -1e30;
     const int smax = nch < 1024 ? nch : 1024;
     for (int S = 1; S <= smax; ++S) {
         if (S > 1 && (size_t)S * slice_bytes > kPartCap) break;
@@ -313,7 +323,10 @@ inline int wg_pick_split(int tiles, int nch, size_t slice_bytes) {
         const long long rounds = (wg + 255) / 256;
         const double fill = (double)wg / (double)(rounds * 256);
         const double per = (double)nch / S;                     // chunks per workgroup
-        const double score = fill * per / (per + 1.5) - 2e-4 * S;
+        // the slices are written once and read once at ~3 TB/s next to ~100 TFLOP/s of products
+        const double extra = (double)S * slice_bytes * 2.0 / 3e12;
+        const double work = (double)nch * flop_per_chunk / 1e14 / (fill * per / (per + 1.5));
+        const double score = -(work + extra);
         if (score > best_score) {
             best_score = score;
             best = S;
@@ -387,7 +400,8 @@ extern "C" int mas_conv_wgrad_plan(int N, int Cin, int H, int W, int Cout, int k
     wg_shape(Cout, ksize, stride, dil, Wo, &g);
     const int mtiles = (Cout + g.BM - 1) / g.BM, ctiles = (Cin + g.BC - 1) / g.BC;
     const int nch = g.flat ? N * ((H * W + g.KP - 1) / g.KP) : N * ((Wo + g.TW - 1) / g.TW) * ((Ho + g.KP / g.TW - 1) / (g.KP / g.TW));
-    const int S = wg_pick_split(mtiles * ctiles, nch, sizeof(float) * (size_t)Cout * Cin * ksize * ksize);
+    const int S = wg_pick_split(mtiles * ctiles, nch, sizeof(float) * (size_t)Cout * Cin * ksize * ksize,
+                                2.0 * mtiles * g.BM * ctiles * g.BC * ksize * ksize * g.KP);
     out6[0] = g.BM; out6[1] = g.BC; out6[2] = g.KP; out6[3] = nch; out6[4] = S; out6[5] = mtiles * ctiles * S;
     return 0;
 }
@@ -420,7 +434,7 @@ extern "C" int mas_conv_wgrad(const float* x, const float* dy, int N, int Cin, i
         p.nch = N * p.tiles_x * p.tiles_y;
     }
     const size_t slice = sizeof(float) * (size_t)Cout * Cin * taps;
-    p.S = wg_pick_split(p.mtiles * p.ctiles, p.nch, slice);
+    p.S = wg_pick_split(p.mtiles * p.ctiles, p.nch, slice, 2.0 * p.mtiles * g.BM * p.ctiles * g.BC * taps * g.KP);
     while (p.S > 1 && (size_t)p.S * slice > workspace_bytes) --p.S;
     if ((size_t)p.S * slice > workspace_bytes) return MAS_ERR_WORKSPACE;
     const bool al = ((uintptr_t)x % 16 == 0) && ((uintptr_t)dy % 16 == 0);

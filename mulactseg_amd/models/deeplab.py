@@ -11,10 +11,13 @@ Architecture and parameter names follow the reference so that checkpoints interc
 ``convert_to_separable_conv`` (``deeplabv3.py:249-261``) semantics are built in: every k > 1 conv of the HEAD
 is depthwise(k, dilation, no bias) followed by pointwise 1x1 (no bias), with nothing in between.
 
-Convolutions and GEMMs run on MIOpen / hipBLASLt (MFMA).  On the GPU the memory-bound layers around them take the
-HIP kernels of this package: BatchNorm + ReLU + residual add (csrc/bn.hip), every depthwise 3x3 (csrc/aspp.hip; the
-three ASPP dilations from one read of the feature map), the bilinear upsamplings (csrc/upsample.hip).  On the CPU the
-same modules run as plain PyTorch ops (parity tests against the executed reference, tests/test_model.py).
+On the GPU the dense convolutions run on this package's f32-MFMA kernels: at inference csrc/conv_mfma.hip with the BatchNorm,
+residual add and ReLU in its epilogue (no MIOpen kernel in a pool forward); in training the weight gradient of every dense
+convolution on csrc/conv_wgrad.hip and the forward / input gradient on csrc/conv_mfma.hip where ops.conv_train_plan selects
+them (path_report() says which products of which layer took which kernel).  The memory-bound layers around them take the HIP
+kernels of this package too: BatchNorm + ReLU + residual add (csrc/bn.hip), every depthwise 3x3 (csrc/aspp.hip; the three ASPP
+dilations from one read of the feature map), the bilinear upsamplings (csrc/upsample.hip).  On the CPU the same modules run as
+plain PyTorch ops (parity tests against the executed reference, tests/test_model.py).
 """
 from collections import OrderedDict
 
@@ -77,6 +80,12 @@ def _conv_bn_act(conv, bn, x, relu=True, residual=None):
             scale, shift = ops._bn_fold(bn)
             y = torch.addmm(shift, x.flatten(1), (conv.weight.flatten(1) * scale[:, None]).t())
             return (F.relu(y) if relu else y)[:, :, None, None]
+    if x.is_cuda and torch.is_grad_enabled():
+        from .. import ops
+        own = ops.conv_train_plan(conv, x)          # training: (forward, input gradient, weight gradient) on the f32-MFMA kernels
+        if own is not None and any(own):
+            _took("conv_bn_act", "train:" + "".join(n if o else "-" for n, o in zip("fdw", own)))
+            return _bn_act(bn, ops.conv_train(conv, x, own), relu, residual)
     _took("conv_bn_act", "miopen+bn")
     return _bn_act(bn, conv(x), relu, residual)
 

@@ -4,6 +4,8 @@ Every function launches on the current torch stream and never synchronises with 
 These are the only callers of ``_lib``; the plugin-level code (``active_selection``, ``utils.loss``)
 is written against this module.
 """
+import os
+
 import numpy as np
 import torch
 
@@ -1065,47 +1067,163 @@ def _conv_fwd_raw(x, wt, Cout, ksize, stride, dil):
     return y
 
 
+_SK_WS = {}
+
+
+def _sk_workspace(dev):
+    """(workspace, epoch) of the stream-K convolution for the current stream of `dev`: partial-tile slots + epoch flags, zero-filled
+    once; launches of one stream run in order and may share it, the epoch differs from launch to launch."""
+    key = (dev, torch.cuda.current_stream(dev).cuda_stream)
+    ent = _SK_WS.get(key)
+    if ent is None:
+        ent = _SK_WS[key] = [torch.zeros(int(_lib.load().mas_conv_sk_workspace_bytes()), dtype=torch.uint8, device=dev), 0]
+    ent[1] = ent[1] % 0xfffffff0 + 1
+    return ent[0], ent[1]
+
+
+def conv_sk(x, w, stride=1, dil=1, dgrad=False, scale=None, shift=None, residual=None, relu=False):
+    """Training-mode dense convolution on the persistent stream-K MFMA kernel (mas_conv_sk), weight `w` [Cout,Cin,k,k] as PyTorch
+    stores it.  dgrad=False: y = conv2d(x, w, stride, padding = dil (k 3) / 0 (k 1), dilation); dgrad=True: x is dY [N,Cout,H,W] and
+    the result is dX [N,Cin,H,W] of the stride-1 convolution.  Optional epilogue y*scale[m] + shift[m] + residual, ReLU."""
+    _need(x, "x", torch.float32)
+    _need(w, "w", torch.float32)
+    Cout, Cin, ks, _ = w.shape
+    N, Cx, H, W = x.shape
+    if Cx != (Cout if dgrad else Cin):
+        raise ValueError("input has %d channels, weight %s (dgrad=%s)" % (Cx, tuple(w.shape), dgrad))
+    M = Cin if dgrad else Cout
+    Ho, Wo = (H, W) if dgrad else ((H - 1) // stride + 1, (W - 1) // stride + 1)
+    y = torch.empty((N, M, Ho, Wo), dtype=torch.float32, device=x.device)
+    if residual is not None:
+        _need(residual, "residual", torch.float32)
+        if residual.shape != y.shape:
+            raise ValueError("residual %s does not match the output %s" % (tuple(residual.shape), tuple(y.shape)))
+    for t, name in ((scale, "scale"), (shift, "shift")):
+        if t is not None:
+            _need(t, name, torch.float32)
+            if t.numel() != M:
+                raise ValueError("%s must have %d entries" % (name, M))
+    ws, epoch = _sk_workspace(x.device)
+    with torch.cuda.device(x.device):
+        _lib.check(_lib.load().mas_conv_sk(x.data_ptr(), w.data_ptr(), N, Cin, H, W, Cout, ks, stride, dil, int(dgrad), _opt(scale), _opt(shift),
+                                           _opt(residual), int(relu), y.data_ptr(), ws.data_ptr(), ws.numel(), epoch, _stream(x)),
+                   "mas_conv_sk")
+    return y
+
+
+def conv_sk_error(dev=None):
+    """Non-zero when a stream-K launch on the current stream's workspace gave up waiting for another workgroup (synchronises)."""
+    import ctypes
+    dev = torch.device('cuda', torch.cuda.current_device()) if dev is None else dev
+    ent = _SK_WS.get((dev, torch.cuda.current_stream(dev).cuda_stream))
+    if ent is None:
+        return 0
+    torch.cuda.synchronize(dev)
+    out = ctypes.c_uint(0)
+    _lib.check(_lib.load().mas_conv_sk_error(ent[0].data_ptr(), ctypes.byref(out)), "mas_conv_sk_error")
+    return int(out.value)
+
+
+_SIDE_STREAMS = {}
+
+
+def _side_stream(dev):
+    """The stream the weight gradients run on: dW is a leaf of the backward graph, so k_wgrad of a layer runs beside the
+    input-gradient kernel of the same layer instead of in front of it."""
+    st = _SIDE_STREAMS.get(dev)
+    if st is None:
+        st = _SIDE_STREAMS[dev] = torch.cuda.Stream(device=dev)
+    return st
+
+
+def _aten_pad(ks, dil):
+    return (dil, dil) if ks == 3 else (0, 0)
+
+
 class _ConvTrain(torch.autograd.Function):
-    """y = conv2d(x, w) with autograd: forward and input gradient on k_conv_mfma (the input gradient is the same kernel on
-    the transposed, tap-flipped weight), weight gradient on k_wgrad."""
+    """y = conv2d(x, w) with autograd.  ``own`` = (forward, input gradient, weight gradient) on this package's f32-MFMA kernels:
+    forward and input gradient on the stream-K kernel k_conv_sk (it reads the weight as PyTorch stores it; the input gradient
+    is the same kernel with the weight's channel axes swapped and the taps mirrored; stride 1), weight gradient on k_wgrad; a
+    False entry takes MIOpen through ATen for that product."""
 
     @staticmethod
-    def forward(ctx, x, w, stride, dil):
+    def forward(ctx, x, w, stride, dil, own):
         x = x.contiguous()
         ks = w.shape[2]
         with torch.no_grad():
-            y = _conv_fwd_raw(x, _pack_conv_weight(w.detach()), w.shape[0], ks, stride, dil)
+            if own[0]:
+                y = conv_sk(x, w.detach().contiguous(), stride, dil)
+            else:
+                y = torch.nn.functional.conv2d(x, w, None, stride, _aten_pad(ks, dil), dil)
         ctx.save_for_backward(x, w)
-        ctx.geom = (ks, stride, dil)
+        ctx.geom = (ks, stride, dil, own)
         return y
 
     @staticmethod
     def backward(ctx, dy):
         x, w = ctx.saved_tensors
-        ks, stride, dil = ctx.geom
+        ks, stride, dil, own = ctx.geom
         dy = dy.contiguous()
         dx = dw = None
-        if ctx.needs_input_grad[0]:
-            if stride == 1:
-                wt = _pack_conv_weight(w.detach().permute(1, 0, 2, 3).flip(2, 3))
-                dx = _conv_fwd_raw(dy, wt, w.shape[1], ks, 1, dil)
+        need_dx, need_dw = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
+        side = None
+        if need_dw and own[2]:
+            main = torch.cuda.current_stream(x.device)
+            if need_dx and os.environ.get("MAS_WGRAD_STREAM", "side") == "side":
+                side = _side_stream(x.device)
+                side.wait_stream(main)                      # dy (and x) are ready on the main stream
+                with torch.cuda.stream(side):
+                    dw = conv_wgrad(x, dy, ks, stride, dil)
+                x.record_stream(side)
+                dy.record_stream(side)
             else:
-                pad = dil if ks == 3 else 0
-                dx = torch.ops.aten.convolution_backward(dy, x, w, None, (stride, stride), (pad, pad), (dil, dil), False, (0, 0), 1,
+                dw = conv_wgrad(x, dy, ks, stride, dil)
+        if need_dx:
+            if own[1] and stride == 1:
+                dx = conv_sk(dy, w.detach().contiguous(), 1, dil, dgrad=True)
+            else:
+                dx = torch.ops.aten.convolution_backward(dy, x, w, None, (stride, stride), _aten_pad(ks, dil), (dil, dil), False, (0, 0), 1,
                                                          (True, False, False))[0]
-        if ctx.needs_input_grad[1]:
-            dw = conv_wgrad(x, dy, ks, stride, dil)
-        return dx, dw, None, None
+        if need_dw and not own[2]:
+            dw = torch.ops.aten.convolution_backward(dy, x, w, None, (stride, stride), _aten_pad(ks, dil), (dil, dil), False, (0, 0), 1,
+                                                     (False, True, False))[1]
+        if side is not None:
+            main.wait_stream(side)                          # dW joins the main stream behind the input gradient
+            dw.record_stream(main)
+        return dx, dw, None, None, None
 
 
-def conv_train_supported(conv, x):
-    """Training-mode path of a dense convolution: the shapes conv_mfma_supported takes whose output-channel count also
-    works as the K extent of the input-gradient product (Cout % 8 for 3x3, % 16 for 1x1)."""
-    if not conv_mfma_supported(conv, x):
+def conv_wgrad_supported(conv, x):
+    """mas_conv_wgrad takes every dense 1x1 / 3x3 convolution of the network: any channel counts and plane sizes, stride 1 / 2,
+    padding = dilation (3x3) / 0 (1x1), dilation 1 / 2 / 4 at stride 1."""
+    if not (x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and conv.groups == 1 and conv.bias is None):
         return False
-    k = conv.kernel_size[0]
-    return _lib.load().mas_conv_chunk(k, conv.out_channels) > 0 and x.shape[2] * x.shape[3] >= 64
+    k, s, d, pd = conv.kernel_size, conv.stride, conv.dilation, conv.padding
+    if k[0] != k[1] or s[0] != s[1] or d[0] != d[1] or pd[0] != pd[1] or k[0] not in (1, 3) or s[0] not in (1, 2):
+        return False
+    if k[0] == 3 and (pd[0] != d[0] or d[0] not in (1, 2, 4) or (s[0] == 2 and d[0] != 1)):
+        return False
+    if k[0] == 1 and (pd[0] != 0 or d[0] != 1):
+        return False
+    return x.shape[1] == conv.in_channels and max(conv.in_channels, conv.out_channels) * x.shape[2] * x.shape[3] < 2 ** 31
 
 
-def conv_train(conv, x):
-    return _ConvTrain.apply(x, conv.weight, conv.stride[0], conv.dilation[0])
+def conv_train_plan(conv, x):
+    """(forward, input gradient, weight gradient) -> True where this package's kernel runs the product, or None when the layer
+    is outside all three (then the caller keeps the nn.Module call).  MAS_TRAIN_CONV = own: every product the kernels support;
+    miopen: none; default: the measured per-geometry choice of tools/conv_train_table.py (profiles/r03/a_*): the weight gradient
+    everywhere, forward on planes of >= 192 x 192 pixels, input gradient on planes of >= 384 x 384."""
+    mode = os.environ.get("MAS_TRAIN_CONV", "auto")
+    if mode == "miopen" or not conv_wgrad_supported(conv, x):
+        return None
+    hw = x.shape[2] * x.shape[3]
+    fwd_ok = conv.dilation[0] <= 4 and hw >= 64
+    dgrad_ok = fwd_ok and conv.stride[0] == 1
+    wgrad_ok = conv.in_channels >= 8
+    if mode == "own":
+        return (fwd_ok, dgrad_ok, True)
+    return (fwd_ok and hw >= 192 * 192, dgrad_ok and hw >= 384 * 384, wgrad_ok)
+
+
+def conv_train(conv, x, own=(True, True, True)):
+    return _ConvTrain.apply(x, conv.weight, conv.stride[0], conv.dilation[0], tuple(bool(v) for v in own))

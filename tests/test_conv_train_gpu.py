@@ -4,6 +4,8 @@ input gradient and forward against float64 autograd of torch's conv2d on every l
 odd planes (the 769-crop sizes scaled down), channel counts that are not multiples of the tiles (3, 48, 304, 200), planes
 smaller than one chunk.  v_mfma_f32_32x32x2_f32 is an exact-f32 fma chain, so the tolerance is that of a differently ordered
 f32 sum: 2e-5 of the result's scale."""
+import os
+
 import pytest
 import torch
 import torch.nn.functional as F
@@ -80,7 +82,60 @@ def test_wgrad_exact_on_integers():
         assert torch.equal(dw.double(), ref), (Cin, Cout, k, stride, dil)
 
 
-@pytest.mark.parametrize("Cin,Cout,k,stride,dil,N,H,W", [c for c in CASES if c[0] % 16 == 0 and c[1] % 16 == 0])
+@pytest.mark.parametrize("Cin,Cout,k,stride,dil,N,H,W", CASES)
+@pytest.mark.parametrize("epi", ["bare", "scale_res_relu"])
+def test_stream_k_forward_and_input_gradient(Cin, Cout, k, stride, dil, N, H, W, epi):
+    """mas_conv_sk in both roles against float64 conv2d / its autograd, with and without the epilogue, on shapes whose tiles
+    straddle workgroups (every case: iterations are dealt in equal runs to 256 workgroups)."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from mulactseg_amd import ops
+    torch.manual_seed(Cin * 5 + Cout + 13 * k + stride + dil + W)
+    x = torch.randn(N, Cin, H, W, device='cuda')
+    w = torch.randn(Cout, Cin, k, k, device='cuda')
+    Ho, Wo = (H - 1) // stride + 1, (W - 1) // stride + 1
+    dy = torch.randn(N, Cout, Ho, Wo, device='cuda')
+    y_ref, dx_ref, _ = _ref_grads(x, w, dy, stride, dil)
+    sc = torch.rand(Cout, device='cuda') + 0.5 if epi != "bare" else None
+    sh = torch.randn(Cout, device='cuda') if epi != "bare" else None
+    res = torch.randn(N, Cout, Ho, Wo, device='cuda') if epi != "bare" else None
+    y = ops.conv_sk(x, w, stride, dil, scale=sc, shift=sh, residual=res, relu=epi != "bare")
+    if epi != "bare":
+        y_ref = torch.relu(y_ref * sc.double()[None, :, None, None] + sh.double()[None, :, None, None] + res.double())
+    scale = float(y_ref.abs().max())
+    assert float((y.double() - y_ref).abs().max()) <= 2e-5 * scale
+    if stride == 1 and Cin > 3:
+        acc = torch.randn(N, Cin, H, W, device='cuda') if epi != "bare" else None
+        dx = ops.conv_sk(dy, w, 1, dil, dgrad=True, residual=acc)
+        ref = dx_ref if acc is None else dx_ref + acc.double()
+        assert float((dx.double() - ref).abs().max()) <= 2e-5 * float(ref.abs().max())
+        assert torch.equal(dx, ops.conv_sk(dy, w, 1, dil, dgrad=True, residual=acc)), "run-to-run identical"
+    assert ops.conv_sk_error() == 0
+
+
+def test_stream_k_exact_on_integers_at_layer_sizes():
+    """Integer data (exact in f32 in any order) at the plane sizes of the deep layers, where every tile is shared by two or three
+    workgroups: operand lane maps, the weight scatter from PyTorch's layout in both roles, tap mirroring, the slot hand-off."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from mulactseg_amd import ops
+    g = torch.Generator(device='cuda').manual_seed(9)
+    for Cin, Cout, k, stride, dil, N, H, W in ((1024, 256, 1, 1, 1, 4, 48, 48), (256, 256, 3, 1, 1, 4, 48, 48), (512, 512, 3, 1, 2, 2, 48, 48),
+                                              (64, 64, 3, 1, 1, 1, 96, 96), (128, 128, 3, 2, 1, 2, 64, 96), (256, 512, 1, 2, 1, 2, 64, 64),
+                                              (304, 256, 1, 1, 1, 1, 64, 64), (256, 48, 1, 1, 1, 1, 64, 64)):
+        x = torch.randint(-2, 3, (N, Cin, H, W), generator=g, device='cuda').float()
+        w = torch.randint(-2, 3, (Cout, Cin, k, k), generator=g, device='cuda').float()
+        Ho, Wo = (H - 1) // stride + 1, (W - 1) // stride + 1
+        dy = torch.randint(-2, 3, (N, Cout, Ho, Wo), generator=g, device='cuda').float()
+        y_ref, dx_ref, _ = _ref_grads(x, w, dy, stride, dil)
+        for rep in range(3):
+            assert torch.equal(ops.conv_sk(x, w, stride, dil).double(), y_ref), (Cin, Cout, k, stride, dil, rep)
+            if stride == 1:
+                assert torch.equal(ops.conv_sk(dy, w, 1, dil, dgrad=True).double(), dx_ref), (Cin, Cout, k, stride, dil, rep)
+    assert ops.conv_sk_error() == 0
+
+
+@pytest.mark.parametrize("Cin,Cout,k,stride,dil,N,H,W", [c for c in CASES if c[0] > 3])
 def test_conv_train_forward_and_gradients(Cin, Cout, k, stride, dil, N, H, W):
     if not torch.cuda.is_available():
         pytest.skip("needs a GPU")
@@ -88,9 +143,14 @@ def test_conv_train_forward_and_gradients(Cin, Cout, k, stride, dil, N, H, W):
     torch.manual_seed(Cin + 5 * Cout + k + stride + dil + W)
     conv = torch.nn.Conv2d(Cin, Cout, k, stride=stride, padding=dil if k == 3 else 0, dilation=dil, bias=False).cuda()
     x = torch.randn(N, Cin, H, W, device='cuda', requires_grad=True)
-    if not ops.conv_train_supported(conv, x):
-        pytest.skip("geometry outside the training path")
-    y = ops.conv_train(conv, x)
+    os.environ["MAS_TRAIN_CONV"] = "own"
+    try:
+        own = ops.conv_train_plan(conv, x)
+    finally:
+        os.environ.pop("MAS_TRAIN_CONV")
+    if own is None or not own[0]:
+        pytest.skip("geometry outside the forward kernel")
+    y = ops.conv_train(conv, x, own)
     dy = torch.randn_like(y)
     y.backward(dy)
     y_ref, dx_ref, dw_ref = _ref_grads(x.detach(), conv.weight.detach(), dy, stride, dil)
@@ -98,3 +158,55 @@ def test_conv_train_forward_and_gradients(Cin, Cout, k, stride, dil, N, H, W):
         scale = float(ref.abs().max())
         err = float((got.double() - ref).abs().max())
         assert err <= 2e-5 * scale, (name, err, scale)
+
+
+def test_train_step_on_own_convolutions_matches_float64():
+    """One training step of the whole network (logits and every parameter gradient) with forward / input gradient / weight
+    gradient on this package's kernels (MAS_TRAIN_CONV=own) and with all convolutions on MIOpen, both against the same step in
+    float64 on the host.  Batch statistics over 2 x 256 x 256 pictures (16 x 16 maps in the deep layers) and ~60 layers amplify
+    f32 rounding to ~1e-4 of the logits' range on EITHER path (observed: 1.8e-4 here, 1.0e-4 on MIOpen, whose blocked sums are
+    shorter than the k-ordered fma chain of the MFMA kernel); the bar: within 3e-4 absolute or 3x MIOpen's error, per tensor."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from mulactseg_amd.models import deeplab, get_model
+    dev = torch.device('cuda:0')
+    x = torch.randn(2, 3, 256, 256, generator=torch.Generator(device=dev).manual_seed(3), device=dev)
+    res = {}
+    for mode in ("f64", "miopen", "own"):
+        os.environ["MAS_TRAIN_CONV"] = mode if mode != "f64" else "miopen"
+        try:
+            torch.manual_seed(11)
+            net = get_model('deeplabv3pluswn_resnet50deepstem', 20, 16, True, pretrained_backbone=False).train()
+            net = net.double() if mode == "f64" else net.to(dev)
+            for m in net.modules():
+                if isinstance(m, torch.nn.Dropout):
+                    m.p = 0.0
+            deeplab.path_report(reset=True)
+            xin = x.cpu().double() if mode == "f64" else x
+            z = net(xin, lowres=True)
+            wts = torch.linspace(-1.0, 1.0, z.numel(), device=z.device, dtype=z.dtype).view_as(z)
+            (z * wts).sum().backward()
+            if mode != "f64":
+                torch.cuda.synchronize()
+            res[mode] = (z.detach().double().cpu(), {n: p.grad.detach().double().cpu() for n, p in net.named_parameters() if p.grad is not None},
+                         deeplab.path_report(reset=True).get("conv_bn_act"))
+        finally:
+            os.environ.pop("MAS_TRAIN_CONV")
+    assert set(res["own"][2]) <= {"train:fdw", "train:f-w", "train:--w", "miopen+bn"} and "train:fdw" in res["own"][2]
+    assert set(res["miopen"][2]) == {"miopen+bn"}
+    zref, gref = res["f64"][0], res["f64"][1]
+    ez_own, ez_mi = float((res["own"][0] - zref).abs().max()), float((res["miopen"][0] - zref).abs().max())
+    assert ez_own <= max(3e-4, 3.0 * ez_mi), (ez_own, ez_mi)              # cosine logits in [-1, 1]
+    worst_own = worst_mi = 0.0
+    rows = []
+    for n, g in gref.items():
+        sc = float(g.abs().max().clamp_min(1e-30))
+        e_own, e_mi = float((res["own"][1][n] - g).abs().max()) / sc, float((res["miopen"][1][n] - g).abs().max()) / sc
+        rows.append((e_own, e_mi, sc, n))
+    rows.sort(reverse=True)
+    for r in rows[:12]:
+        print("grad rel err own %.2e miopen %.2e scale %.2e %s" % r)
+    for e_own, e_mi, sc, n in rows:
+        worst_own, worst_mi = max(worst_own, e_own), max(worst_mi, e_mi)
+        assert e_own <= max(3e-4, 3.0 * e_mi), (n, e_own, e_mi)
+    print("vs float64: logits own %.2e / miopen %.2e; worst relative gradient error own %.2e / miopen %.2e" % (ez_own, ez_mi, worst_own, worst_mi))

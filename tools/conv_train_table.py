@@ -52,10 +52,9 @@ def main():
     for name, m in net.named_modules():
         if isinstance(m, nn.Conv2d):
             m.register_forward_hook(hook(name))
-    os.environ["MAS_TRAIN_CONV"] = "miopen"            # module hooks only fire on the nn.Module path
-    with torch.no_grad():
+    with torch.no_grad():                              # (no autograd: every convolution goes through its nn.Module call, hooks fire)
         net(torch.randn(N, 3, H, W, device=dev))
-    os.environ.pop("MAS_TRAIN_CONV")
+    os.environ["MAS_TRAIN_CONV"] = "own"               # the table times every product the kernels support
     rows, tot = [], collections.Counter()
     for (cin, cout, k, s, d, groups, xs), names in shapes.items():
         if groups != 1 or xs[2] * xs[3] == 1:
@@ -74,13 +73,11 @@ def main():
              "mi_d": timeit(mi((True, False, False))) if cin > 3 else 0.0,
              "mi_w": timeit(mi((False, True, False)))}
         t["my_w"] = timeit(lambda: ops.conv_wgrad(x, dy, k, s, d))
-        sup = ops.conv_train_supported(conv, x)
-        if sup:
-            wt = ops._pack_conv_weight(w)
-            t["my_f"] = timeit(lambda: ops._conv_fwd_raw(x, wt, cout, k, s, d))
-            if s == 1:
-                wtd = ops._pack_conv_weight(w.permute(1, 0, 2, 3).flip(2, 3))
-                t["my_d"] = timeit(lambda: ops._conv_fwd_raw(dy, wtd, cin, k, 1, d))
+        own = ops.conv_train_plan(conv, x)
+        if own is not None and own[0]:
+            t["my_f"] = timeit(lambda: ops.conv_sk(x, w, s, d))
+            if own[1]:
+                t["my_d"] = timeit(lambda: ops.conv_sk(dy, w, 1, d, dgrad=True))
         dw = ops.conv_wgrad(x, dy, k, s, d)
         ref = torch.ops.aten.convolution_backward(dy.double(), x.double(), w.double(), None, (s, s), pad, (d, d), False, (0, 0), 1,
                                                   (False, True, False))[1]

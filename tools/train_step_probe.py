@@ -1,0 +1,71 @@
+#!/usr/bin/env python
+"""Time the stage-1 training step (model fwd + fused losses + bwd + AdamW, batch [4,3,crop,crop]) under the training-convolution
+modes of ops.conv_train_plan:  python tools/train_step_probe.py [--crop 768] [--modes miopen,auto,own] [--steps 10]"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--crop", type=int, default=768)
+    ap.add_argument("--modes", default="miopen,auto,own")
+    ap.add_argument("--streams", default="side")
+    ap.add_argument("--steps", type=int, default=10)
+    args = ap.parse_args()
+    from mulactseg_amd import synth
+    from mulactseg_amd.models import deeplab, get_model
+    from mulactseg_amd.utils.loss import FusedPartialLabelLoss
+    dev = torch.device('cuda:0')
+    N, C, S, crop = 4, 20, 2048, args.crop
+    spx, msk = zip(*[synth.train_crop(50 + i, crop, crop, S, frac_selected=0.09) for i in range(N)])
+    spx = torch.from_numpy(np.stack(spx)).to(dev)
+    msk = torch.from_numpy(np.stack(msk)).to(dev)
+    tgt = torch.from_numpy(np.stack([synth.multi_hot_targets(70 + i, S, C) for i in range(N)])).to(dev)
+    crit = FusedPartialLabelLoss(S, 0.1, 0.1, sync_normalisers=True)
+    g = torch.Generator(device=dev)
+    g.manual_seed(5)
+    images = torch.randn((N, 3, crop, crop), generator=g, device=dev)
+    out = {}
+    for mode in args.modes.split(","):
+        for st in args.streams.split(","):
+            os.environ["MAS_TRAIN_CONV"] = mode
+            os.environ["MAS_WGRAD_STREAM"] = st
+            torch.manual_seed(0)
+            net = get_model('deeplabv3pluswn_resnet50deepstem', C, 16, True, pretrained_backbone=False).to(dev).train()
+            opt = torch.optim.AdamW([{'params': net.backbone.parameters(), 'lr': 2e-5}, {'params': net.classifier.parameters(), 'lr': 2e-4}],
+                                    lr=2e-5, weight_decay=1e-5, fused=True)
+
+            def step():
+                opt.zero_grad(set_to_none=True)
+                total, _, _, _ = crit.weighted_lowres(net(images, lowres=True), (crop, crop), tgt, spx, msk, 16.0, 8.0, 1.0)
+                total.backward()
+                opt.step()
+                return total
+            for _ in range(3):
+                loss = step()
+            deeplab.path_report(reset=True)
+            step()
+            paths = deeplab.path_report(reset=True)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(args.steps):
+                loss = step()
+            torch.cuda.synchronize()
+            ms = (time.perf_counter() - t0) / args.steps * 1e3
+            out["%s/%s" % (mode, st)] = {"ms_per_step": ms, "loss": float(loss), "conv_paths": paths.get("conv_bn_act")}
+            print(mode, st, "%.2f ms" % ms, float(loss), paths.get("conv_bn_act"), flush=True)
+            del net, opt
+            torch.cuda.empty_cache()
+    print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()
