@@ -410,7 +410,7 @@ int mas_conv_fwd(const float* x, const float* wt, int N, int Cin, int H, int W, 
  * models/segmentation/deeplabv3.py:85-137,168-245 inside trainer/active_joint_multi_predignore_lossdecomp.py:83-116.
  *   dgrad = 0:  y[n,m,oy,ox] = sum_{c,r,s} w[m,c,r,s] x[n,c, oy*stride + r*dil - pad, ox*stride + s*dil - pad]   x [N,Cin,H,W], y [N,Cout,Ho,Wo]
  *   dgrad = 1:  y[n,c,iy,ix] = sum_{m,r,s} w[m,c,r,s] x[n,m, iy - r*dil + pad, ix - s*dil + pad]  (stride 1)       x [N,Cout,H,W], y [N,Cin,H,W]
- * pad = dil (ksize 3) / 0 (ksize 1); ksize 1 | 3; stride 1 | 2 (stride 2: forward only, dil 1); dil <= 4 (ksize 3).  Epilogue as
+ * pad = dil (ksize 3) / 0 (ksize 1); ksize 1 | 3; stride 1 | 2 (stride 2: forward only, dil 1); dil 1 | 2 | 4 (ksize 3).  Epilogue as
  * mas_conv_fwd: y*scale[m] + shift[m] (both or neither), + residual (same shape as y, may be NULL), ReLU if `relu`.
  * One workgroup per CU; the (tile, K-chunk) iterations of the layer are dealt to the workgroups in equal runs, tiles that
  * straddle two workgroups are combined through `workspace` (mas_conv_sk_workspace_bytes(), zero-filled ONCE by the caller, then

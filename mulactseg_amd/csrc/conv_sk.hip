@@ -1,5 +1,5 @@
 // conv_sk.hip -- forward and input gradient of the dense convolutions in TRAINING (1x1 / 3x3, stride 1 / 2 forward, stride 1
-// input gradient, any dilation <= 4) as a persistent stream-K implicit GEMM on the f32 matrix cores of gfx950
+// input gradient, dilation 1 / 2 / 4) as a persistent stream-K implicit GEMM on the f32 matrix cores of gfx950
 // (v_mfma_f32_32x32x2_f32), NCHW in and out.  The weight is read as a sequence of ready-made LDS images, one per (M tile,
 // K chunk), that k_sk_pack writes from PyTorch's [Cout][Cin][k][k] tensor in one small launch per optimizer step and product
 // (a workgroup's staging is then a linear 16-byte copy; building the image in the kernel costs 8-way bank-conflicted LDS
@@ -44,11 +44,26 @@ struct SkP {
     float* slots;               // [P][128 * 128] partial accumulator images
     unsigned* flags;            // [512] epoch flags, then one error word
     unsigned epoch;
-    int K, H, W, M, Ho, Wo, stride, dil, pad, relu;
-    int TH, tw_log2, tiles_x, tiles_y, ptiles, mtiles, nch;
-    int PH, PWL, CS, PADL;              // LDS input patch: rows, row length (multiple of 4), channel stride, left halo columns
+    int K, H, W, M, Ho, Wo, relu;
+    int tiles_x, tiles_y, ptiles, mtiles, nch;
     int iters;
     int P;
+};
+
+// Compile-time geometry of a kernel family: TH x TW output pixels per tile, the LDS input patch PH rows x PWL columns per
+// channel (PWL a multiple of 4, PADL columns of halo on the left so that 16-byte groups stay aligned in memory), channel
+// stride CS.  With these fixed, every LDS operand address of the multiply loop is one base register + an immediate.
+template <int TAPS, int CK_, int TW_, int STRIDE_, int DIL_>
+struct SkG {
+    static constexpr int CK = CK_, TW = TW_, STRIDE = STRIDE_, DIL = DIL_;
+    static constexpr int TH = kSkBN / TW;
+    static constexpr int TWLOG = TW == 32 ? 5 : 4;
+    static constexpr int PAD = TAPS == 9 ? DIL : 0;
+    static constexpr int PADL = TAPS == 9 ? 4 : 0;
+    static constexpr int PH = (TH - 1) * STRIDE + 1 + 2 * PAD;
+    static constexpr int PWL = ((TW - 1) * STRIDE + 1 + 2 * PADL + 3) & ~3;
+    static constexpr int CS = PH * PWL;
+    static constexpr int NXS = (CK * CS / 4 + kSkThreads - 1) / kSkThreads;
 };
 
 __device__ __forceinline__ void sk_store_sc1(float* p, v4f v) {
@@ -97,28 +112,28 @@ struct SkSlots {
     int c[NXS], rc[NXS], lds[NXS];
 };
 
-template <int CK, int NXS>
-__device__ __forceinline__ void sk_slots(const SkP& p, int tid, SkSlots<NXS>& s) {
-    const int f4r = p.PWL >> 2, f4c = p.PH * f4r;
+template <typename G>
+__device__ __forceinline__ void sk_slots(int tid, SkSlots<G::NXS>& s) {
+    constexpr int f4r = G::PWL >> 2, f4c = G::PH * f4r;
 #pragma unroll
-    for (int j = 0; j < NXS; ++j) {
+    for (int j = 0; j < G::NXS; ++j) {
         const int f = tid + j * kSkThreads;
         const int c = f / f4c, rem = f - c * f4c;
         const int row = rem / f4r, col = (rem - row * f4r) * 4;
-        const bool live = f < CK * f4c;
+        const bool live = f < G::CK * f4c;
         s.c[j] = live ? c : -1;
         s.rc[j] = row | (col << 16);
-        s.lds[j] = c * p.CS + rem * 4;
+        s.lds[j] = c * G::CS + rem * 4;
     }
 }
 
 // global -> registers of the chunk at the cursor (its tile may differ from the one being multiplied: the pipeline crosses tile
 // boundaries)
-template <int TAPS, int CK, int WM, bool VEC, int NWS, int NXS>
-__device__ __forceinline__ void sk_fetch(const SkP& p, const SkCursor& cur, const SkSlots<NXS>& sl, int tid, v4f (&wr)[NWS], v4f (&xr)[NXS]) {
-    constexpr int BM = 32 * WM;
+template <typename G, int TAPS, int WM, bool VEC, int NWS>
+__device__ __forceinline__ void sk_fetch(const SkP& p, const SkCursor& cur, const SkSlots<G::NXS>& sl, int tid, v4f (&wr)[NWS],
+                                         v4f (&xr)[G::NXS]) {
+    constexpr int BM = 32 * WM, CK = G::CK, NXS = G::NXS, TW = G::TW;
     constexpr int KC = TAPS * CK;
-    const int TW = 1 << p.tw_log2;
     const int k0 = cur.chunk * CK;
     // ---- weight: the LDS image of (M tile, chunk), a linear copy --------------------------------------------------------------
     const float* wb = p.w + ((size_t)cur.mt * p.nch + cur.chunk) * (size_t)(KC * BM);
@@ -128,7 +143,7 @@ __device__ __forceinline__ void sk_fetch(const SkP& p, const SkCursor& cur, cons
         wr[j] = (NWS * kSkThreads * 4 == BM * KC || e < BM * KC) ? *reinterpret_cast<const v4f*>(wb + e) : (v4f){0.f, 0.f, 0.f, 0.f};
     }
     // ---- input patch: CK channels x PH rows x PWL columns, 16-byte groups aligned in memory --------------------------------
-    const int iy0 = cur.tyi * p.TH * p.stride - p.pad, ix0 = cur.txi * TW * p.stride - p.PADL;
+    const int iy0 = cur.tyi * G::TH * G::STRIDE - G::PAD, ix0 = cur.txi * TW * G::STRIDE - G::PADL;
     const int HW = p.H * p.W;
     const float* xb = p.x + ((size_t)cur.n * p.K + k0) * HW;
 #pragma unroll
@@ -149,10 +164,10 @@ __device__ __forceinline__ void sk_fetch(const SkP& p, const SkCursor& cur, cons
 // registers -> LDS.  Weight image [KC / 8][2][BM][4] (written by k_sk_pack): k-step kk = tap * (CK / 2) + c / 2 pairs the channels
 // 2 cp + h of one tap (h = lane half of the MFMA), the four k-steps 4 q .. 4 q + 3 of one (half, row) are adjacent: one 16-byte
 // read = four MFMAs.
-template <int TAPS, int CK, int WM, int NWS, int NXS>
-__device__ __forceinline__ void sk_stage(const SkSlots<NXS>& sl, float* __restrict__ sW, float* __restrict__ sX, int tid, const v4f (&wr)[NWS],
-                                         const v4f (&xr)[NXS]) {
-    constexpr int BM = 32 * WM;
+template <typename G, int TAPS, int WM, int NWS>
+__device__ __forceinline__ void sk_stage(const SkSlots<G::NXS>& sl, float* __restrict__ sW, float* __restrict__ sX, int tid, const v4f (&wr)[NWS],
+                                         const v4f (&xr)[G::NXS]) {
+    constexpr int BM = 32 * WM, CK = G::CK, NXS = G::NXS;
     constexpr int KC = TAPS * CK;
 #pragma unroll
     for (int j = 0; j < NWS; ++j) {
@@ -164,8 +179,10 @@ __device__ __forceinline__ void sk_stage(const SkSlots<NXS>& sl, float* __restri
         if (sl.c[j] >= 0) *reinterpret_cast<v4f*>(sX + sl.lds[j]) = xr[j];
 }
 
-template <int TAPS, int CK, int WM, bool VEC, int NXS>
+template <int TAPS, int CK, int WM, int TW, int STRIDE, int DIL, bool VEC>
 __global__ __launch_bounds__(kSkThreads) void k_conv_sk(const SkP p) {
+    using G = SkG<TAPS, CK, TW, STRIDE, DIL>;
+    constexpr int NXS = G::NXS, CS = G::CS, PWL = G::PWL;
     constexpr int BM = 32 * WM, BN = kSkBN;
     constexpr int NG = 8 / WM;                  // pixel groups of the 8 waves
     constexpr int TN = BN / NG / 32;            // 32-pixel accumulator tiles per wave: 2 (BM 128) / 1 (BM 64)
@@ -176,7 +193,7 @@ __global__ __launch_bounds__(kSkThreads) void k_conv_sk(const SkP p) {
     static_assert(KC % 8 == 0 && TN >= 1, "tile");
     extern __shared__ __attribute__((aligned(16))) float sk_smem[];
     // [2][sW: KC * BM | sX: CK * CS] then sE [2 tile parities][2][BM]
-    const int bufsz = KC * BM + CK * p.CS;
+    constexpr int bufsz = KC * BM + CK * CS;
     float* sEbase = sk_smem + 2 * bufsz;
     int tile_parity = 0;
 
@@ -188,14 +205,13 @@ __global__ __launch_bounds__(kSkThreads) void k_conv_sk(const SkP p) {
     const int it0 = (int)((long long)p.iters * g / P), it1 = (int)((long long)p.iters * (g + 1) / P);
     if (it0 >= it1) return;
 
-    const int TW = 1 << p.tw_log2;
     const int aBase = (h * BM + mtw * 32 + l31) * 4;
     int bBase[TN], pl[TN];
 #pragma unroll
     for (int tn = 0; tn < TN; ++tn) {
         pl[tn] = ng * (BN / NG) + tn * 32 + l31;
-        const int ty = pl[tn] >> p.tw_log2, tx = pl[tn] & (TW - 1);
-        bBase[tn] = h * p.CS + ty * p.stride * p.PWL + tx * p.stride + p.PADL - p.pad;
+        const int ty = pl[tn] >> G::TWLOG, tx = pl[tn] & (TW - 1);
+        bBase[tn] = h * CS + ty * STRIDE * PWL + tx * STRIDE + G::PADL - G::PAD;
     }
     f32x16 acc[TN];
     v4f wr[NWS], xr[NXS];
@@ -216,8 +232,8 @@ __global__ __launch_bounds__(kSkThreads) void k_conv_sk(const SkP p) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const int kk = 4 * q + j, tap = kk / (CK / 2), cp = kk - tap * (CK / 2);
-                const int toff = (TAPS == 1) ? 0 : ((tap / 3) * p.PWL + (tap % 3)) * p.dil;
-                const float* xrow = sX + 2 * cp * p.CS + toff;
+                const int toff = (TAPS == 1) ? 0 : ((tap / 3) * PWL + (tap % 3)) * DIL;
+                const float* xrow = sX + 2 * cp * CS + toff;
 #pragma unroll
                 for (int tn = 0; tn < TN; ++tn) o.b[j][tn] = xrow[bBase[tn]];
             }
@@ -239,11 +255,33 @@ __global__ __launch_bounds__(kSkThreads) void k_conv_sk(const SkP p) {
 
     int buf = 0;
     SkSlots<NXS> slots;
-    sk_slots<CK, NXS>(p, tid, slots);
+    sk_slots<G>(tid, slots);
+    // The registers that carried chunk it + 1 to LDS are refilled with chunk it + 2 right behind that store, three quarters into
+    // iteration it: a load then has a whole iteration to arrive (issued at the start of an iteration it had 3/4 of one, and
+    // the loop ran at the global-load round trip, ~5 us, whatever the chunk's MFMA count).
     SkCursor pre = sk_cursor(p, it0);           // the chunk the prefetch stream is at
-    sk_fetch<TAPS, CK, WM, VEC, NWS, NXS>(p, pre, slots, tid, wr, xr);
-    sk_stage<TAPS, CK, WM, NWS, NXS>(slots, sk_smem, sk_smem + KC * BM, tid, wr, xr);
+    sk_fetch<G, TAPS, WM, VEC, NWS>(p, pre, slots, tid, wr, xr);
+    sk_stage<G, TAPS, WM, NWS>(slots, sk_smem, sk_smem + KC * BM, tid, wr, xr);
+    if (it0 + 1 < it1) {
+        sk_advance(p, pre);
+        sk_fetch<G, TAPS, WM, VEC, NWS>(p, pre, slots, tid, wr, xr);
+    }
     __syncthreads();
+
+    auto iteration = [&](int it) {
+        mfma_part(buf, std::integral_constant<int, 0>{}, std::integral_constant<int, QSPLIT>{});
+        if (it + 1 < it1) {
+            float* nW = sk_smem + (buf ^ 1) * bufsz;
+            sk_stage<G, TAPS, WM, NWS>(slots, nW, nW + KC * BM, tid, wr, xr);
+            if (it + 2 < it1) {
+                sk_advance(p, pre);
+                sk_fetch<G, TAPS, WM, VEC, NWS>(p, pre, slots, tid, wr, xr);
+            }
+        }
+        mfma_part(buf, std::integral_constant<int, QSPLIT>{}, std::integral_constant<int, NQ>{});
+        __syncthreads();
+        buf ^= 1;
+    };
 
     int it = it0;
     while (it < it1) {
@@ -265,21 +303,7 @@ __global__ __launch_bounds__(kSkThreads) void k_conv_sk(const SkP p) {
         for (int tn = 0; tn < TN; ++tn)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[tn][r] = 0.0f;
-        for (int c = c0; c < c1; ++c, ++it) {
-            const bool more = it + 1 < it1;
-            if (more) {
-                sk_advance(p, pre);
-                sk_fetch<TAPS, CK, WM, VEC, NWS, NXS>(p, pre, slots, tid, wr, xr);
-            }
-            mfma_part(buf, std::integral_constant<int, 0>{}, std::integral_constant<int, QSPLIT>{});
-            if (more) {
-                float* nW = sk_smem + (buf ^ 1) * bufsz;
-                sk_stage<TAPS, CK, WM, NWS, NXS>(slots, nW, nW + KC * BM, tid, wr, xr);
-            }
-            mfma_part(buf, std::integral_constant<int, QSPLIT>{}, std::integral_constant<int, NQ>{});
-            __syncthreads();
-            buf ^= 1;
-        }
+        for (int c = c0; c < c1; ++c, ++it) iteration(it);
         // ---- the tile's segment [c0, c1) is in the accumulators ------------------------------------------------------------
         const bool first = c0 == 0, last = c1 == p.nch;
         if (!first) {
@@ -331,14 +355,14 @@ __global__ __launch_bounds__(kSkThreads) void k_conv_sk(const SkP p) {
         const int tpi = p.tiles_x * p.tiles_y;
         const int n = pt / tpi, trem = pt - n * tpi;
         const int tyi = trem / p.tiles_x, txi = trem - tyi * p.tiles_x;
-        const int oy0 = tyi * p.TH, ox0 = txi * TW;
+        const int oy0 = tyi * G::TH, ox0 = txi * TW;
         float* yb = p.y + ((size_t)n * p.M + m0) * HWo;
         const float* rb = p.res ? p.res + ((size_t)n * p.M + m0) * HWo : nullptr;
         const float lo = p.relu ? 0.0f : -INFINITY;
         const int mlim = p.M - m0;
 #pragma unroll
         for (int tn = 0; tn < TN; ++tn) {
-            const int oy = oy0 + (pl[tn] >> p.tw_log2), ox = ox0 + (pl[tn] & (TW - 1));
+            const int oy = oy0 + (pl[tn] >> G::TWLOG), ox = ox0 + (pl[tn] & (TW - 1));
             const bool inside = oy < p.Ho && ox < p.Wo;
             const int po = inside ? oy * p.Wo + ox : 0;
             const int mb = mtw * 32 + 4 * h;
@@ -392,30 +416,15 @@ __global__ __launch_bounds__(256) void k_sk_pack(const float* __restrict__ w, in
 }
 
 struct SkGeom {
-    int TAPS, CK, BM, TW, TH, PH, PWL, CS, PADL, nxs;
-    size_t smem;
+    int TAPS, CK, BM, TW, TH;
 };
 
-inline int sk_ilog2(int v) {
-    int l = 0;
-    while ((1 << l) < v) ++l;
-    return l;
-}
-
-inline void sk_geom(int ksize, int stride, int dil, int M, int Wo, SkGeom* g) {
+inline void sk_geom(int ksize, int stride, int M, int Wo, SkGeom* g) {
     g->TAPS = ksize * ksize;
     g->CK = ksize == 3 ? 8 : (stride == 2 ? 16 : 64);       // (the stride-2 patch of a 1x1 holds 4x the pixels it uses)
     g->BM = M > 64 ? 128 : 64;
     g->TW = (Wo >= 32 && !(Wo % 32 != 0 && Wo % 16 == 0)) ? 32 : 16;       // 48-wide planes: three exact 16-wide tiles
     g->TH = kSkBN / g->TW;
-    const int pad = ksize == 3 ? dil : 0;
-    g->PADL = ksize == 3 ? 4 : 0;
-    g->PH = (g->TH - 1) * stride + 1 + 2 * pad;
-    g->PWL = ((g->TW - 1) * stride + 1 + 2 * g->PADL + 3) & ~3;
-    g->CS = g->PH * g->PWL;                          // multiple of 4: 16-byte LDS stores
-    const int f4 = g->CK * g->CS / 4;
-    g->nxs = (f4 + kSkThreads - 1) / kSkThreads;
-    g->smem = sizeof(float) * (2 * ((size_t)g->TAPS * g->CK * g->BM + (size_t)g->CK * g->CS) + 4 * g->BM);
 }
 
 int sk_num_cus() {
@@ -429,16 +438,19 @@ int sk_num_cus() {
     return cus[dev];
 }
 
-template <int TAPS, int CK, int WM, bool VEC, int NXS>
-int sk_launch(const SkP& p, size_t smem, hipStream_t st) {
-    auto kern = &k_conv_sk<TAPS, CK, WM, VEC, NXS>;
+template <int TAPS, int CK, int WM, int TW, int STRIDE, int DIL, bool VEC>
+int sk_launch(const SkP& p, hipStream_t st) {
+    using G = SkG<TAPS, CK, TW, STRIDE, DIL>;
+    constexpr size_t smem = sizeof(float) * (2 * ((size_t)TAPS * CK * 32 * WM + (size_t)CK * G::CS) + 4 * 32 * WM);
+    static_assert(smem <= 160 * 1024, "LDS");
+    auto kern = &k_conv_sk<TAPS, CK, WM, TW, STRIDE, DIL, VEC>;
     if (smem > 64 * 1024) {
         static bool raised[64] = {};
         int dev = 0;
         hipError_t e = hipGetDevice(&dev);
         if (e != hipSuccess) return (int)e;
         if (dev < 0 || dev >= 64 || !raised[dev]) {
-            e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
             if (e != hipSuccess) return (int)e;
             if (dev >= 0 && dev < 64) raised[dev] = true;
         }
@@ -447,13 +459,13 @@ int sk_launch(const SkP& p, size_t smem, hipStream_t st) {
     return mas_launch_status();
 }
 
-// staged 16-byte groups of the input patch per thread: fixed per kernel family (checked against the geometry at launch)
-//   3x3 stride 1: CK 8 x (TH + 2 dil) x (TW + 8) floats <= 2 groups;  3x3 stride 2: 3;  1x1: 4
-template <int TAPS, int CK, int NXS>
+template <int TAPS, int CK, int STRIDE, int DIL>
 int sk_dispatch(const SkP& p, const SkGeom& g, bool vec, hipStream_t st) {
-    if (g.nxs > NXS) return MAS_ERR_SHAPE;
-    if (g.BM == 128) return vec ? sk_launch<TAPS, CK, 4, true, NXS>(p, g.smem, st) : sk_launch<TAPS, CK, 4, false, NXS>(p, g.smem, st);
-    return vec ? sk_launch<TAPS, CK, 2, true, NXS>(p, g.smem, st) : sk_launch<TAPS, CK, 2, false, NXS>(p, g.smem, st);
+#define SK_TW(TW)                                                                                                                 \
+    (g.BM == 128 ? (vec ? sk_launch<TAPS, CK, 4, TW, STRIDE, DIL, true>(p, st) : sk_launch<TAPS, CK, 4, TW, STRIDE, DIL, false>(p, st)) \
+                 : (vec ? sk_launch<TAPS, CK, 2, TW, STRIDE, DIL, true>(p, st) : sk_launch<TAPS, CK, 2, TW, STRIDE, DIL, false>(p, st)))
+    return g.TW == 32 ? SK_TW(32) : SK_TW(16);
+#undef SK_TW
 }
 }  // namespace
 
@@ -466,7 +478,7 @@ extern "C" size_t mas_conv_sk_packed_elems(int Cin, int Cout, int ksize, int str
     if (Cin <= 0 || Cout <= 0 || (ksize != 1 && ksize != 3) || (stride != 1 && stride != 2)) return 0;
     SkGeom g;
     const int M = dgrad ? Cin : Cout, K = dgrad ? Cout : Cin;
-    sk_geom(ksize, stride, 1, M, 32, &g);
+    sk_geom(ksize, stride, M, 32, &g);
     return (size_t)((M + g.BM - 1) / g.BM) * ((K + g.CK - 1) / g.CK) * (size_t)g.TAPS * g.CK * g.BM;
 }
 
@@ -476,7 +488,7 @@ extern "C" int mas_conv_sk_pack(const float* w, int Cin, int Cout, int ksize, in
     if (total == 0) return MAS_ERR_SHAPE;
     SkGeom g;
     const int M = dgrad ? Cin : Cout, K = dgrad ? Cout : Cin;
-    sk_geom(ksize, stride, 1, M, 32, &g);
+    sk_geom(ksize, stride, M, 32, &g);
     hipLaunchKernelGGL(k_sk_pack, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream), w, Cout, Cin, g.TAPS,
                        g.CK, g.BM, (M + g.BM - 1) / g.BM, (K + g.CK - 1) / g.CK, dgrad, out);
     return mas_launch_status();
@@ -488,7 +500,7 @@ extern "C" int mas_conv_sk(const float* x, const float* w, int N, int Cin, int H
     if (!x || !w || !y || !workspace) return MAS_ERR_NULL;
     if ((scale == nullptr) != (shift == nullptr)) return MAS_ERR_NULL;
     if (N <= 0 || Cin <= 0 || H <= 0 || W <= 0 || Cout <= 0) return MAS_ERR_SHAPE;
-    if ((ksize != 1 && ksize != 3) || (stride != 1 && stride != 2) || dil < 1 || dil > 4) return MAS_ERR_RANGE;
+    if ((ksize != 1 && ksize != 3) || (stride != 1 && stride != 2) || (dil != 1 && dil != 2 && dil != 4)) return MAS_ERR_RANGE;
     if (ksize == 1 && dil != 1) return MAS_ERR_RANGE;
     if (dgrad && stride != 1) return MAS_ERR_RANGE;
     if (stride == 2 && dil != 1) return MAS_ERR_RANGE;
@@ -501,7 +513,7 @@ extern "C" int mas_conv_sk(const float* x, const float* w, int N, int Cin, int H
     p.slots = static_cast<float*>(workspace);
     p.flags = reinterpret_cast<unsigned*>(static_cast<char*>(workspace) + (size_t)512 * kSkSlotFloats * sizeof(float));
     p.epoch = epoch;
-    p.stride = stride; p.dil = dil; p.pad = ksize == 3 ? dil : 0; p.relu = relu;
+    p.relu = relu;
     p.H = H; p.W = W;
     if (!dgrad) {
         p.K = Cin; p.M = Cout;
@@ -511,15 +523,12 @@ extern "C" int mas_conv_sk(const float* x, const float* w, int N, int Cin, int H
         p.Ho = H; p.Wo = W;
     }
     SkGeom g;
-    sk_geom(ksize, stride, dil, p.M, p.Wo, &g);
-    if (g.smem > 160 * 1024) return MAS_ERR_SHAPE;
-    p.TH = g.TH; p.tw_log2 = sk_ilog2(g.TW);
+    sk_geom(ksize, stride, p.M, p.Wo, &g);
     p.tiles_x = (p.Wo + g.TW - 1) / g.TW;
     p.tiles_y = (p.Ho + g.TH - 1) / g.TH;
     p.ptiles = N * p.tiles_x * p.tiles_y;
     p.mtiles = (p.M + g.BM - 1) / g.BM;
     p.nch = (p.K + g.CK - 1) / g.CK;
-    p.PH = g.PH; p.PWL = g.PWL; p.CS = g.CS; p.PADL = g.PADL;
     const long long iters = (long long)p.ptiles * p.mtiles * p.nch;
     if (iters > 0x7fffffffLL) return MAS_ERR_SHAPE;
     p.iters = (int)iters;
@@ -530,8 +539,12 @@ extern "C" int mas_conv_sk(const float* x, const float* w, int N, int Cin, int H
     if ((uintptr_t)w % 16 != 0) return MAS_ERR_ALIGN;
     const bool vec = ((uintptr_t)x % 16 == 0) && (W % 4 == 0);     // 16-byte loads of the input patch: whole, aligned groups
     // (forward and input gradient are the same kernel: the role lives in the packed weight image)
-    if (ksize == 3) return stride == 2 ? sk_dispatch<9, 8, 3>(p, g, vec, st) : sk_dispatch<9, 8, 2>(p, g, vec, st);
-    return stride == 2 ? sk_dispatch<1, 16, 4>(p, g, vec, st) : sk_dispatch<1, 64, 4>(p, g, vec, st);
+    if (ksize == 3) {
+        if (stride == 2) return sk_dispatch<9, 8, 2, 1>(p, g, vec, st);
+        if (dil == 4) return sk_dispatch<9, 8, 1, 4>(p, g, vec, st);
+        return dil == 1 ? sk_dispatch<9, 8, 1, 1>(p, g, vec, st) : sk_dispatch<9, 8, 1, 2>(p, g, vec, st);
+    }
+    return stride == 2 ? sk_dispatch<1, 16, 2, 1>(p, g, vec, st) : sk_dispatch<1, 64, 1, 1>(p, g, vec, st);
 }
 
 /* error word of the last launches on this workspace: non-zero = a bounded spin gave up (host-side read, for tests) */

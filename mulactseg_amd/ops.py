@@ -1230,7 +1230,7 @@ def conv_train_plan(conv, x):
     if mode == "miopen" or not conv_wgrad_supported(conv, x):
         return None
     hw = x.shape[2] * x.shape[3]
-    fwd_ok = conv.dilation[0] <= 4 and hw >= 64
+    fwd_ok = conv.dilation[0] in (1, 2, 4) and hw >= 64
     dgrad_ok = fwd_ok and conv.stride[0] == 1
     wgrad_ok = conv.in_channels >= 8
     if mode == "own":
