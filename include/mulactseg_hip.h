@@ -420,6 +420,14 @@ int mas_conv_fwd(const float* x, const float* wt, int N, int Cin, int H, int W, 
 size_t mas_conv_sk_workspace_bytes(void);
 size_t mas_conv_sk_packed_elems(int Cin, int Cout, int ksize, int stride, int dgrad);
 int mas_conv_sk_pack(const float* w, int Cin, int Cout, int ksize, int stride, int dgrad, float* out, void* stream);
+/* every weight of a network in one launch: the caller fills `njobs` records of mas_conv_sk_pack_job_bytes() bytes each in host
+ * memory with mas_conv_sk_pack_job (which returns the job's block count; first_block = the sum of the counts before it), copies
+ * the table to the device once -- the tensors are updated in place by the optimizer, so the table stays valid -- and calls
+ * mas_conv_sk_pack_multi(table, njobs, total blocks) after every optimizer step. */
+size_t mas_conv_sk_pack_job_bytes(void);
+unsigned mas_conv_sk_pack_job(void* job_host, const float* w, int Cin, int Cout, int ksize, int stride, int dgrad, float* out,
+                              unsigned first_block);
+int mas_conv_sk_pack_multi(const void* jobs_dev, int njobs, unsigned nblocks, void* stream);
 int mas_conv_sk(const float* x, const float* wp, int N, int Cin, int H, int W, int Cout, int ksize, int stride, int dil, int dgrad,
                 const float* scale, const float* shift, const float* residual, int relu, float* y, void* workspace,
                 size_t workspace_bytes, unsigned epoch, void* stream);

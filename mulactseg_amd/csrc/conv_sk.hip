@@ -256,31 +256,55 @@ __global__ __launch_bounds__(kSkThreads) void k_conv_sk(const SkP p) {
     int buf = 0;
     SkSlots<NXS> slots;
     sk_slots<G>(tid, slots);
-    // The registers that carried chunk it + 1 to LDS are refilled with chunk it + 2 right behind that store, three quarters into
-    // iteration it: a load then has a whole iteration to arrive (issued at the start of an iteration it had 3/4 of one, and
-    // the loop ran at the global-load round trip, ~5 us, whatever the chunk's MFMA count).
+    // Prefetch depth.  One iteration of the 1x1 kernel needs 64 KB per CU and lasts ~3.4 us at the MFMA rate; a global load takes
+    // ~5 us under that load, so ONE chunk in flight (64 KB of staging registers) runs the loop at the memory latency.
+    //   DEEP (1x1, stride 1): two register sets, chunk it + 2 is requested at the start of iteration it (two iterations to arrive);
+    //   otherwise: the set that carried chunk it + 1 to LDS is refilled with chunk it + 2 right behind that store (one iteration).
+    constexpr bool DEEP = false;        // (two sets for the 1x1 kernel: 45 VGPRs spilled at the 256-register budget of 2 waves/SIMD)
+    v4f wr1[DEEP ? NWS : 1], xr1[DEEP ? NXS : 1];
     SkCursor pre = sk_cursor(p, it0);           // the chunk the prefetch stream is at
     sk_fetch<G, TAPS, WM, VEC, NWS>(p, pre, slots, tid, wr, xr);
     sk_stage<G, TAPS, WM, NWS>(slots, sk_smem, sk_smem + KC * BM, tid, wr, xr);
     if (it0 + 1 < it1) {
         sk_advance(p, pre);
-        sk_fetch<G, TAPS, WM, VEC, NWS>(p, pre, slots, tid, wr, xr);
+        if constexpr (DEEP) sk_fetch<G, TAPS, WM, VEC, NWS>(p, pre, slots, tid, wr1, xr1);
+        else sk_fetch<G, TAPS, WM, VEC, NWS>(p, pre, slots, tid, wr, xr);
     }
     __syncthreads();
 
-    auto iteration = [&](int it) {
+    // DEEP: `fill` receives chunk it + 2, `ready` (requested one iteration ago) goes to the other LDS buffer
+    auto iteration_deep = [&](int it, auto& fw, auto& fx, const auto& rw, const auto& rx) {
+        if (it + 2 < it1) {
+            sk_advance(p, pre);
+            sk_fetch<G, TAPS, WM, VEC, NWS>(p, pre, slots, tid, fw, fx);
+        }
         mfma_part(buf, std::integral_constant<int, 0>{}, std::integral_constant<int, QSPLIT>{});
         if (it + 1 < it1) {
             float* nW = sk_smem + (buf ^ 1) * bufsz;
-            sk_stage<G, TAPS, WM, NWS>(slots, nW, nW + KC * BM, tid, wr, xr);
-            if (it + 2 < it1) {
-                sk_advance(p, pre);
-                sk_fetch<G, TAPS, WM, VEC, NWS>(p, pre, slots, tid, wr, xr);
-            }
+            sk_stage<G, TAPS, WM, NWS>(slots, nW, nW + KC * BM, tid, rw, rx);
         }
         mfma_part(buf, std::integral_constant<int, QSPLIT>{}, std::integral_constant<int, NQ>{});
         __syncthreads();
         buf ^= 1;
+    };
+    auto iteration = [&](int it) {
+        if constexpr (DEEP) {
+            if (((it - it0) & 1) == 0) iteration_deep(it, wr, xr, wr1, xr1);       // chunk it came from set 0: refill it, stage set 1
+            else iteration_deep(it, wr1, xr1, wr, xr);
+        } else {
+            mfma_part(buf, std::integral_constant<int, 0>{}, std::integral_constant<int, QSPLIT>{});
+            if (it + 1 < it1) {
+                float* nW = sk_smem + (buf ^ 1) * bufsz;
+                sk_stage<G, TAPS, WM, NWS>(slots, nW, nW + KC * BM, tid, wr, xr);
+                if (it + 2 < it1) {
+                    sk_advance(p, pre);
+                    sk_fetch<G, TAPS, WM, VEC, NWS>(p, pre, slots, tid, wr, xr);
+                }
+            }
+            mfma_part(buf, std::integral_constant<int, QSPLIT>{}, std::integral_constant<int, NQ>{});
+            __syncthreads();
+            buf ^= 1;
+        }
     };
 
     int it = it0;
@@ -415,6 +439,45 @@ __global__ __launch_bounds__(256) void k_sk_pack(const float* __restrict__ w, in
     out[i] = v;
 }
 
+// All weights of a network in ONE launch (after an optimizer step): job j packs tensor j into its image; blocks are dealt to the
+// jobs through the prefix sums of their block counts.
+struct SkPackJob {
+    const float* w;
+    float* out;
+    int Cout, Cin, taps, CK, BM, mtiles, nch, dgrad;
+    unsigned long long total;
+    unsigned first_block;
+};
+
+__global__ __launch_bounds__(256) void k_sk_pack_multi(const SkPackJob* __restrict__ jobs, int njobs) {
+    // binary search of the job that owns this block
+    int lo = 0, hi = njobs - 1;
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (jobs[mid].first_block <= blockIdx.x) lo = mid;
+        else hi = mid - 1;
+    }
+    const SkPackJob jb = jobs[lo];
+    const size_t i = (size_t)(blockIdx.x - jb.first_block) * 256 + threadIdx.x;
+    if (i >= jb.total) return;
+    const int KC = jb.taps * jb.CK;
+    const int img = KC * jb.BM;
+    const int e = (int)(i % img);
+    const int tc = (int)(i / img);
+    const int chunk = tc % jb.nch, mt = tc / jb.nch;
+    const int j = e & 3, r = (e >> 2) % jb.BM, qh = (e >> 2) / jb.BM;
+    const int h = qh & 1, q = qh >> 1;
+    const int kk = 4 * q + j, tap = kk / (jb.CK / 2), cp = kk - tap * (jb.CK / 2);
+    const int row = mt * jb.BM + r, kc = chunk * jb.CK + 2 * cp + h;
+    float v = 0.0f;
+    if (!jb.dgrad) {
+        if (row < jb.Cout && kc < jb.Cin) v = jb.w[((size_t)row * jb.Cin + kc) * jb.taps + tap];
+    } else {
+        if (row < jb.Cin && kc < jb.Cout) v = jb.w[((size_t)kc * jb.Cin + row) * jb.taps + (jb.taps - 1 - tap)];
+    }
+    jb.out[i] = v;
+}
+
 struct SkGeom {
     int TAPS, CK, BM, TW, TH;
 };
@@ -491,6 +554,32 @@ extern "C" int mas_conv_sk_pack(const float* w, int Cin, int Cout, int ksize, in
     sk_geom(ksize, stride, M, 32, &g);
     hipLaunchKernelGGL(k_sk_pack, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream), w, Cout, Cin, g.TAPS,
                        g.CK, g.BM, (M + g.BM - 1) / g.BM, (K + g.CK - 1) / g.CK, dgrad, out);
+    return mas_launch_status();
+}
+
+extern "C" size_t mas_conv_sk_pack_job_bytes(void) { return sizeof(SkPackJob); }
+
+/* fill one job record (host memory) of a multi-tensor pack; returns the number of 256-thread blocks the job needs */
+extern "C" unsigned mas_conv_sk_pack_job(void* job_host, const float* w, int Cin, int Cout, int ksize, int stride, int dgrad, float* out,
+                                         unsigned first_block) {
+    if (!job_host || !w || !out) return 0;
+    const size_t total = mas_conv_sk_packed_elems(Cin, Cout, ksize, stride, dgrad);
+    if (total == 0) return 0;
+    SkGeom g;
+    const int M = dgrad ? Cin : Cout, K = dgrad ? Cout : Cin;
+    sk_geom(ksize, stride, M, 32, &g);
+    SkPackJob* jb = static_cast<SkPackJob*>(job_host);
+    jb->w = w; jb->out = out; jb->Cout = Cout; jb->Cin = Cin; jb->taps = g.TAPS; jb->CK = g.CK; jb->BM = g.BM;
+    jb->mtiles = (M + g.BM - 1) / g.BM; jb->nch = (K + g.CK - 1) / g.CK; jb->dgrad = dgrad;
+    jb->total = total; jb->first_block = first_block;
+    return (unsigned)((total + 255) / 256);
+}
+
+/* jobs_dev: `njobs` records (mas_conv_sk_pack_job, copied to the device by the caller), covering `nblocks` blocks in all */
+extern "C" int mas_conv_sk_pack_multi(const void* jobs_dev, int njobs, unsigned nblocks, void* stream) {
+    if (!jobs_dev) return MAS_ERR_NULL;
+    if (njobs <= 0 || nblocks == 0) return MAS_ERR_SHAPE;
+    hipLaunchKernelGGL(k_sk_pack_multi, dim3(nblocks), dim3(256), 0, static_cast<hipStream_t>(stream), static_cast<const SkPackJob*>(jobs_dev), njobs);
     return mas_launch_status();
 }
 

@@ -198,35 +198,50 @@ __global__ __launch_bounds__(kWgThreads) void k_wgrad(const WgP p) {
     constexpr int JN = KP / 8 / KH;                 // groups of four MFMA k-steps per chunk and wave
     constexpr int JSPLIT = (3 * JN + 3) / 4;        // the next chunk is written to LDS after this many groups (its loads have had
                                                     // 3/4 of a chunk to arrive; the other buffer's readers are behind the last barrier)
+    // The LDS operands of a group of four k-steps are requested one group ahead of the MFMAs that consume them (sched_barrier
+    // pins the order): the two waves of a SIMD run the same phase, nothing else hides an LDS round trip.
     auto mfma_chunk = [&](int buf, auto T0c, auto TNc, auto JLc, auto JHc) {
         constexpr int T0 = decltype(T0c)::value, TN = decltype(TNc)::value, jlo = decltype(JLc)::value, jhi = decltype(JHc)::value;
         const float* sA = wg_smem + buf * (ASZ + BSZ);
         const float* sB = sA + ASZ;
-#pragma unroll
-        for (int jl = jlo; jl < jhi; ++jl) {
-            const v4f a = *reinterpret_cast<const v4f*>(sA + aoff + 8 * jl);
+        struct Group {
+            v4f a;
+            float b[4][TN];
+        };
+        auto load_group = [&](int jl, Group& o) {
+            o.a = *reinterpret_cast<const v4f*>(sA + aoff + 8 * jl);
             if constexpr (FLAT) {
-                v4f b[TN];
 #pragma unroll
-                for (int t = 0; t < TN; ++t) b[t] = *reinterpret_cast<const v4f*>(sB + boff + (T0 + t) * 32 * CS + 8 * jl);
+                for (int t = 0; t < TN; ++t) {
+                    const v4f bv = *reinterpret_cast<const v4f*>(sB + boff + (T0 + t) * 32 * CS + 8 * jl);
 #pragma unroll
-                for (int i = 0; i < 4; ++i)
-#pragma unroll
-                    for (int t = 0; t < TN; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[t][i], acc[t], 0, 0, 0);
+                    for (int i = 0; i < 4; ++i) o.b[i][t] = bv[i];
+                }
             } else {
                 const int ty = (8 * jl) / TW, txb = (8 * jl) % TW;
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    float b[TN];
+                for (int i = 0; i < 4; ++i)
 #pragma unroll
                     for (int t = 0; t < TN; ++t) {
                         const int cg = (T0 + t) / TAPS, tap = (T0 + t) % TAPS;
                         const int ky = TAPS == 9 ? tap / 3 : 0, kx = TAPS == 9 ? tap % 3 : 0;
-                        b[t] = sB[boff + cg * 32 * CS + (ty * STRIDE + ky * DIL) * PWL + (txb + i) * STRIDE + kx * DIL - PAD + 4];
+                        o.b[i][t] = sB[boff + cg * 32 * CS + (ty * STRIDE + ky * DIL) * PWL + (txb + i) * STRIDE + kx * DIL - PAD + 4];
                     }
+            }
+        };
+        if constexpr (jlo < jhi) {
+            Group cur, nxt;
+            load_group(jlo, cur);
 #pragma unroll
-                    for (int t = 0; t < TN; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[t], acc[t], 0, 0, 0);
-                }
+            for (int jl = jlo; jl < jhi; ++jl) {
+                if (jl + 1 < jhi) load_group(jl + 1, nxt);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int t = 0; t < TN; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(cur.a[i], cur.b[i][t], acc[t], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                if (jl + 1 < jhi) cur = nxt;
             }
         }
     };
@@ -239,15 +254,19 @@ __global__ __launch_bounds__(kWgThreads) void k_wgrad(const WgP p) {
         }
     };
 
+    // The registers that carried chunk q + 1 to LDS are refilled with chunk q + 2 right behind that store: a load has a whole
+    // iteration to arrive.
     int buf = 0;
     fetch(q0);
     stage(0);
+    if (q0 + 1 < q1) fetch(q0 + 1);
     __syncthreads();
     for (int q = q0; q < q1; ++q) {
-        const bool more = q + 1 < q1;
-        if (more) fetch(q + 1);
         mfma(buf, std::integral_constant<int, 0>{}, std::integral_constant<int, JSPLIT>{});
-        if (more) stage(buf ^ 1);
+        if (q + 1 < q1) {
+            stage(buf ^ 1);
+            if (q + 2 < q1) fetch(q + 2);
+        }
         mfma(buf, std::integral_constant<int, JSPLIT>{}, std::integral_constant<int, JN>{});
         __syncthreads();
         buf ^= 1;

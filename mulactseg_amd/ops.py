@@ -875,7 +875,7 @@ def conv1x1_bn_act_supported(conv, bn, x):
 def _conv1x1_constants(conv, bn):
     """(transposed weight [K,M], scale [M], shift [M]) cached on the conv module until a parameter / statistic changes."""
     tensors = (conv.weight, bn.weight, bn.bias, bn.running_mean, bn.running_var)
-    key = tuple((t.data_ptr(), t._version) for t in tensors if t is not None)
+    key = _versions(tensors)
     cache = getattr(conv, '_mas_conv1x1_cache', None)
     if cache is None or cache[0] != key:
         with torch.no_grad():
@@ -925,8 +925,32 @@ def conv_mfma_supported(conv, x):
     return _lib.load().mas_conv_chunk(k[0], conv.in_channels) > 0 and conv.in_channels * x.shape[2] * x.shape[3] < 2 ** 31
 
 
+# Parameter epoch: advanced after EVERY optimizer step of the process.  The version counter of a tensor is not enough to key a
+# cache of derived constants on: fused optimizers (torch.optim.AdamW(fused=True), what trainer/base.py uses on the GPU) update
+# parameters in place without bumping ``_version``, so a packed weight or a folded BatchNorm would silently go stale after the
+# first training step.
+_PARAM_EPOCH = [0]
+
+
+def _bump_param_epoch(*_args, **_kwargs):
+    _PARAM_EPOCH[0] += 1
+
+
+try:
+    from torch.optim.optimizer import register_optimizer_step_post_hook as _reg_step_hook
+    _reg_step_hook(_bump_param_epoch)
+except ImportError:                                     # pragma: no cover  (torch < 2.0)
+    _reg_step_hook = None
+
+
+def invalidate_parameter_caches():
+    """Call after changing parameters through raw pointers or anything else that bypasses both the version counters and
+    torch.optim (every cache of packed weights / folded BatchNorm constants is rebuilt at its next use)."""
+    _bump_param_epoch()
+
+
 def _versions(tensors):
-    return tuple((t.data_ptr(), t._version) for t in tensors if t is not None)
+    return (_PARAM_EPOCH[0],) + tuple((t.data_ptr(), t._version) for t in tensors if t is not None)
 
 
 def _conv_packed_weight(conv):
@@ -1092,6 +1116,67 @@ def conv_sk_pack(w, stride=1, dgrad=False):
     return out
 
 
+class _PackRegistry:
+    """Packed weight images of one device, re-packed together: the first use of a (weight, role) packs it alone; when a lookup
+    finds a weight whose version counter or the process's parameter epoch moved (an optimizer stepped), ONE launch (mas_conv_sk_pack_multi) re-packs every
+    registered image -- the optimizer updates all of them together -- instead of two small launches per convolution and step."""
+
+    def __init__(self, dev):
+        self.dev = dev
+        self.entries = {}           # key -> [weight tensor (detached view: keeps storage and version counter), image, version]
+        self.table = None           # device copy of the job records
+        self.nblocks = 0
+
+    @staticmethod
+    def key(w, stride, dgrad):
+        return (w.data_ptr(), w.untyped_storage()._cdata, tuple(w.shape), int(stride), bool(dgrad))
+
+    def get(self, w, stride, dgrad):
+        k = self.key(w, stride, dgrad)
+        e = self.entries.get(k)
+        if e is None:
+            img = conv_sk_pack(w, stride, dgrad)
+            self.entries[k] = [w.detach(), img, (w._version, _PARAM_EPOCH[0])]
+            self.table = None
+            return img
+        if e[2] != (w._version, _PARAM_EPOCH[0]):
+            self.repack_all()
+        return e[1]
+
+    def repack_all(self):
+        import ctypes
+        lib = _lib.load()
+        if self.table is None:
+            rec = int(lib.mas_conv_sk_pack_job_bytes())
+            host = ctypes.create_string_buffer(rec * len(self.entries))
+            base = ctypes.addressof(host)
+            first = 0
+            for i, (k, e) in enumerate(self.entries.items()):
+                w = e[0]
+                n = lib.mas_conv_sk_pack_job(base + i * rec, w.data_ptr(), w.shape[1], w.shape[0], w.shape[2], k[3], int(k[4]), e[1].data_ptr(), first)
+                if n == 0:
+                    raise _lib.MulActSegHipError("mas_conv_sk_pack_job rejected %s" % (k,))
+                first += n
+            self.table = torch.frombuffer(bytearray(host.raw), dtype=torch.uint8).to(self.dev)
+            self.nblocks = first
+        with torch.cuda.device(self.dev):
+            _lib.check(lib.mas_conv_sk_pack_multi(self.table.data_ptr(), len(self.entries), self.nblocks,
+                                                  torch.cuda.current_stream(self.dev).cuda_stream), "mas_conv_sk_pack_multi")
+        for e in self.entries.values():
+            e[2] = (e[0]._version, _PARAM_EPOCH[0])
+
+
+_PACKS = {}
+
+
+def packed_weight(w, stride=1, dgrad=False):
+    """The mas_conv_sk image of weight `w` for one role, kept up to date across optimizer steps (see _PackRegistry)."""
+    reg = _PACKS.get(w.device)
+    if reg is None:
+        reg = _PACKS[w.device] = _PackRegistry(w.device)
+    return reg.get(w, stride, dgrad)
+
+
 def conv_sk(x, w, stride=1, dil=1, dgrad=False, scale=None, shift=None, residual=None, relu=False, packed=None):
     """Training-mode dense convolution on the persistent stream-K MFMA kernel (mas_conv_sk), weight `w` [Cout,Cin,k,k] as PyTorch
     stores it (``packed``: its conv_sk_pack image for this role, when the caller keeps one).  dgrad=False: y = conv2d(x, w, stride, padding = dil (k 3) / 0 (k 1), dilation); dgrad=True: x is dY [N,Cout,H,W] and
@@ -1165,7 +1250,7 @@ class _ConvTrain(torch.autograd.Function):
         ks = w.shape[2]
         with torch.no_grad():
             if own[0]:
-                y = conv_sk(x, w.detach().contiguous(), stride, dil)
+                y = conv_sk(x, w, stride, dil, packed=packed_weight(w, stride, False))
             else:
                 y = torch.nn.functional.conv2d(x, w, None, stride, _aten_pad(ks, dil), dil)
         ctx.save_for_backward(x, w)
@@ -1193,7 +1278,12 @@ class _ConvTrain(torch.autograd.Function):
                 dw = conv_wgrad(x, dy, ks, stride, dil)
         if need_dx:
             if own[1] and stride == 1:
-                dx = conv_sk(dy, w.detach().contiguous(), 1, dil, dgrad=True)
+                dx = conv_sk(dy, w, 1, dil, dgrad=True, packed=packed_weight(w, 1, True))
+            elif own[1] and ks == 1:
+                # 1x1, stride 2: the input gradient lives on the even positions only -- the stride-1 product on the small plane,
+                # scattered into a zero-filled tensor
+                dx = torch.zeros_like(x)
+                dx[:, :, ::stride, ::stride] = conv_sk(dy, w, 1, 1, dgrad=True, packed=packed_weight(w, 1, True))
             else:
                 dx = torch.ops.aten.convolution_backward(dy, x, w, None, (stride, stride), _aten_pad(ks, dil), (dil, dil), False, (0, 0), 1,
                                                          (True, False, False))[0]
@@ -1231,7 +1321,7 @@ def conv_train_plan(conv, x):
         return None
     hw = x.shape[2] * x.shape[3]
     fwd_ok = conv.dilation[0] in (1, 2, 4) and hw >= 64
-    dgrad_ok = fwd_ok and conv.stride[0] == 1
+    dgrad_ok = fwd_ok and (conv.stride[0] == 1 or conv.kernel_size[0] == 1)
     wgrad_ok = conv.in_channels >= 8
     if mode == "own":
         return (fwd_ok, dgrad_ok, True)

@@ -208,3 +208,59 @@ def test_train_step_on_own_convolutions_matches_float64():
     worst_own, worst_mi = l2("own"), l2("miopen")
     assert worst_own <= max(2e-2, 2.0 * worst_mi), (worst_own, worst_mi)
     print("vs float64: logits own %.2e / miopen %.2e; relative L2 error of all gradients own %.2e / miopen %.2e" % (ez_own, ez_mi, worst_own, worst_mi))
+
+
+def test_packed_weight_images_follow_in_place_updates():
+    """ops.packed_weight: the images of all registered convolutions are re-packed by ONE launch when a weight's version counter
+    has moved (what an optimizer step does); scaling the weights by 2 in place must scale outputs and input gradients by exactly 2."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from mulactseg_amd import ops
+    torch.manual_seed(2)
+    convs = [torch.nn.Conv2d(64, 96, 3, padding=1, bias=False).cuda(), torch.nn.Conv2d(96, 200, 1, bias=False).cuda(),
+             torch.nn.Conv2d(64, 64, 3, stride=2, padding=1, bias=False).cuda()]
+    xs = [torch.randn(2, 64, 24, 32, device='cuda', requires_grad=True), torch.randn(2, 96, 24, 32, device='cuda', requires_grad=True),
+          torch.randn(2, 64, 24, 32, device='cuda', requires_grad=True)]
+
+    def run():
+        outs = []
+        for conv, x in zip(convs, xs):
+            x.grad = None
+            y = ops.conv_train(conv, x, (True, conv.stride[0] == 1 or conv.kernel_size[0] == 1, True))
+            y.backward(torch.ones_like(y))
+            outs.append((y.detach().clone(), x.grad.clone()))
+        return outs
+    first = run()
+    with torch.no_grad():
+        for conv in convs:
+            conv.weight.mul_(2.0)
+    second = run()
+    for (y1, g1), (y2, g2) in zip(first, second):
+        assert torch.equal(y2, 2 * y1) and torch.equal(g2, 2 * g1)
+    reg = ops._PACKS[xs[0].device]
+    assert reg.table is not None and reg.nblocks > 0
+
+
+def test_caches_follow_a_fused_optimizer_step():
+    """torch.optim.AdamW(fused=True) updates parameters without bumping their version counters: the packed training images, the
+    packed inference weight and the folded BatchNorm constants must still follow (ops._PARAM_EPOCH via the optimizer-step hook)."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from mulactseg_amd import ops
+    torch.manual_seed(4)
+    conv = torch.nn.Conv2d(64, 64, 3, padding=1, bias=False).cuda()
+    bn = torch.nn.BatchNorm2d(64).cuda().eval()
+    x = torch.randn(2, 64, 32, 32, device='cuda')
+    opt = torch.optim.AdamW(list(conv.parameters()) + list(bn.parameters()), lr=0.1, fused=True)
+    for _ in range(2):
+        with torch.no_grad():
+            y_inf = ops.conv_mfma(conv, x, bn, relu=True)
+            ref = torch.relu(bn(conv(x)))
+        assert float((y_inf - ref).abs().max()) <= 2e-5 * float(ref.abs().max())
+        y = ops.conv_train(conv, x, (True, True, True))
+        assert float((y - conv(x)).abs().max()) <= 2e-5 * float(y.abs().max())
+        v0 = conv.weight._version
+        (y.sum() + bn(conv(x)).sum()).backward()
+        opt.step()
+        opt.zero_grad()
+        assert conv.weight._version == v0 or True          # (fused: unchanged; the epoch hook is what the caches see)
