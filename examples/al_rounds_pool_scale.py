@@ -80,6 +80,23 @@ def build_pool(args, n_img, H, W, S, dev, chunk=64):
     return pool, label, mh
 
 
+def numpy_prefix(scores, valid, rank, cost, budget):
+    """The reference's ``sorted(tuples, reverse=True)`` + budget walk on arrays (active_selection/base.py:37,
+    dataloader/region_active_dataset.py:31-73): descending (score, path rank, id), stop after the region that makes the click cost
+    exceed the budget.  Returns (picture row, region id) of the consumed prefix."""
+    n, s = scores.shape
+    img = np.repeat(np.arange(n), s)
+    rid = np.tile(np.arange(s), n)
+    keep = valid.reshape(-1) != 0
+    img, rid, sc = img[keep], rid[keep], scores.reshape(-1)[keep]
+    order = np.lexsort((-rid, -rank[img], -sc.astype(np.float64)))
+    img, rid = img[order], rid[order]
+    cum = np.cumsum(cost[img, rid].astype(np.int64))
+    over = np.nonzero(cum > budget)[0]
+    m = len(img) if len(over) == 0 else int(over[0]) + 1
+    return img[:m], rid[:m]
+
+
 def region_set(suppix):
     return {(k, i) for k, ids in suppix.items() for i in ids}
 
@@ -98,6 +115,8 @@ def main(argv=None):
     ap.add_argument("--stage2-images", type=int, default=32)
     ap.add_argument("--out", default=None)
     ap.add_argument("--json", default=None)
+    ap.add_argument("--check-order", action="store_true",
+                    help="every scored round: the consumed prefix must equal a numpy lexsort restatement of the reference's tuple sort + walk")
     cli = ap.parse_args(argv)
     out_dir = cli.out or tempfile.mkdtemp(prefix="mas_al_pool_")
     os.makedirs(out_dir, exist_ok=True)
@@ -128,8 +147,20 @@ def main(argv=None):
     active_set = RegionActiveDataset(args, pool, label)
     initial_selector = importlib.import_module("active_selection." + args.initial_active_method).RegionSelector(args)
     active_selector = importlib.import_module("active_selection." + args.active_method).RegionSelector(args)
+    kept = {}
+    if cli.check_order:                      # keep the score tensor and the pool's valid table of every scored round
+        inner = active_selector.calculate_scores_tensor
+
+        def keep_scores(trainer, pool_set, want_hist=False):
+            kept['valid'] = np.array(active_selector._pool_valid(active_set, pool_set), copy=True)
+            kept['rows'] = [row_of_all[k[2]] for k in pool_set.im_idx]
+            kept['scores'] = inner(trainer, pool_set, want_hist)
+            return kept['scores']
+        active_selector.calculate_scores_tensor = keep_scores
+    row_of_all = {n[2]: i for i, n in enumerate(pool.im_idx)}
     Trainer = importlib.import_module("trainer." + args.method.lower())
     cost = mh.sum(axis=2)
+    pool_names = [list(n) for n in pool.im_idx]
     row_of = {n[2]: i for i, n in enumerate(pool.im_idx)}
 
     def clock():
@@ -169,6 +200,18 @@ def main(argv=None):
         with open(os.path.join(args.model_save_dir, 'datalist_%02d.pkl' % selection_iter), 'rb') as f:
             dl = pickle.load(f)
         assert dl['trg_label_suppix'] == label.suppix and dl['trg_pool_im_idx'] == pool.im_idx
+        if cli.check_order and selection_iter != 1:
+            sc = kept['scores'].cpu().numpy()
+            rows = np.asarray(kept['rows'])
+            paths = [','.join(pool_names[i]) for i in rows]
+            rank = np.empty(len(paths), dtype=np.int64)
+            rank[np.argsort(np.array(paths))] = np.arange(len(paths))
+            ni, nr = numpy_prefix(sc, kept['valid'], rank, cost[rows], args.active_selection_size)
+            want = [(pool_names[rows[i]][2], int(j)) for i, j in zip(ni, nr)]
+            got = [(p.split(',')[2], int(i)) for _, p, i in consumed]
+            assert got == want, "consumed prefix differs from the lexsort restatement (first mismatch at %d)" % next(
+                (k for k, (a, b) in enumerate(zip(got, want)) if a != b), min(len(got), len(want)))
+            r["order_checked_regions"] = len(want)
         labelled_before = labelled
         r.update(regions_selected=len(new), clicks=clicks, labelled_regions_total=len(labelled), labelled_pictures=len(label.im_idx))
 

@@ -93,6 +93,9 @@ int mas_region_finalize(const uint64_t* score_sum, const uint32_t* hist, int64_t
 #define MAS_LOSS_GROUP 2            /* compute the group (max-pool) loss */
 #define MAS_LOSS_GROUP_ONLY_MULTI 4 /* group loss only over superpixels with > 1 target bit
                                        (GroupMultiLabelCE_onlymulti, ..._mclossablation2.py:36,51-53) */
+#define MAS_LOSS_TCE 16             /* stage-2 temperature cross entropy (utils/loss.py:10-21): the `spx` map holds CLASS LABELS (S = C),
+                                     * `mask` = label != ignore_index; per valid pixel l = -log softmax(z / T)[label] (no epsilon) into
+                                     * the ce sum; mas_loss_values / mas_loss_scales divide by n, not 1 + n.  Combine with MAS_LOSS_CE. */
 #define MAS_LOSS_DECOMP 8           /* separate one-hot (ce) / multi-hot (mc) sums and normalisers
                                        (OnehotCEMultihotChoice, ..._lossdecomp.py:58-72); otherwise one
                                        merged sum (MultiChoiceCE_, active_joint_multi_predignore.py:59-61) */

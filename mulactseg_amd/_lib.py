@@ -12,7 +12,7 @@ LIB_PATH = os.path.join(_HERE, "libmulactseg_hip.so")
 ID_I64, ID_I32, ID_U16 = 0, 1, 2
 MAX_CLASSES = 32
 SCORE_FRAC, PROB_FRAC, LOSS_FRAC = 40, 23, 32
-LOSS_CE, LOSS_GROUP, LOSS_GROUP_ONLY_MULTI, LOSS_DECOMP = 1, 2, 4, 8
+LOSS_CE, LOSS_GROUP, LOSS_GROUP_ONLY_MULTI, LOSS_DECOMP, LOSS_TCE = 1, 2, 4, 8, 16
 ACC_WORDS = 8
 GRAD_FRAC = 44
 

@@ -182,6 +182,7 @@ __global__ __launch_bounds__(kThreads) void k_partial_loss_fwd(const float* __re
     const bool do_ce = flags & MAS_LOSS_CE;
     const bool do_group = flags & MAS_LOSS_GROUP;
     const bool only_multi = flags & MAS_LOSS_GROUP_ONLY_MULTI;
+    const bool tce = flags & MAS_LOSS_TCE;          // `spx` holds class labels, the target of a pixel is its label, no epsilon
     if (threadIdx.x == 0) *qcount = 0;
     if (do_group) {
         for (int i = threadIdx.x; i < kSlots; i += kThreads) t_keys[i] = -1;
@@ -217,7 +218,7 @@ __global__ __launch_bounds__(kThreads) void k_partial_loss_fwd(const float* __re
         float v[CT];
         LTap t_y, t_x;
         load_logits<CT, EXACT, LOWRES>(zb, C, HW, pix, py, px, lr, v, t_y, t_x);
-        const unsigned Y = bb[id];
+        const unsigned Y = tce ? (1u << id) : bb[id];
         const int nb = __popc(Y);
         if (nb == 0) { n_empty += 1; continue; }
         {
@@ -230,7 +231,7 @@ __global__ __launch_bounds__(kThreads) void k_partial_loss_fwd(const float* __re
 #pragma unroll
             for (int c = 0; c < CT; ++c)
                 if (EXACT || c < C) pos = ((Y >> c) & 1u) ? (pos + v[c]) : pos;
-            const float l = -mas_logf(pos + 1e-8f);
+            const float l = -mas_logf(tce ? pos : pos + 1e-8f);
             const mas_u64 q = mas_fix(l, MAS_LOSS_FRAC);
             if (nb == 1) { sum_ce += q; n_ce += 1; } else { sum_mc += q; n_mc += 1; }
         }
@@ -300,15 +301,22 @@ __global__ __launch_bounds__(kThreads) void k_group_finalize(const mas_u64* __re
     }
 }
 
-// loss = (sum * 2^-32) / (1 + n) in f64, rounded once to f32
-__device__ __forceinline__ float loss_value(mas_u64 sum, mas_u64 n) {
+// loss = (sum * 2^-32) / (1 + n) in f64, rounded once to f32; MAS_LOSS_TCE: the plain mean, / n (0 / 0 = NaN as torch's
+// CrossEntropyLoss over no valid pixel)
+__device__ __forceinline__ float loss_value(mas_u64 sum, mas_u64 n, int one = 1) {
     union { double d; mas_u64 u; } s;
     s.u = (mas_u64)(1023 - MAS_LOSS_FRAC) << 52;
-    return (float)(((double)sum * s.d) / (double)(n + 1));
+    return (float)(((double)sum * s.d) / (double)(n + one));
 }
 
 __global__ void k_loss_values(const mas_u64* __restrict__ acc, int flags, float* __restrict__ out) {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    if (flags & MAS_LOSS_TCE) {
+        out[0] = loss_value(acc[ACC_SUM_CE], acc[ACC_N_CE], 0);
+        out[1] = 0.0f;
+        out[2] = 0.0f;
+        return;
+    }
     if (flags & MAS_LOSS_DECOMP) {
         out[0] = loss_value(acc[ACC_SUM_CE], acc[ACC_N_CE]);
         out[1] = loss_value(acc[ACC_SUM_MC], acc[ACC_N_MC]);
@@ -359,6 +367,12 @@ __global__ void k_loss_scales_weighted(const mas_u64* __restrict__ acc, const fl
 __global__ void k_loss_scales(const mas_u64* __restrict__ acc, const float* __restrict__ grad_out, int flags,
                               float* __restrict__ scale) {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    if (flags & MAS_LOSS_TCE) {
+        scale[0] = grad_out[0] / (float)acc[ACC_N_CE];
+        scale[1] = 0.0f;
+        scale[2] = 0.0f;
+        return;
+    }
     if (flags & MAS_LOSS_DECOMP) {
         scale[0] = grad_out[0] / (float)(acc[ACC_N_CE] + 1);
         scale[1] = grad_out[1] / (float)(acc[ACC_N_MC] + 1);
@@ -434,7 +448,7 @@ __global__ __launch_bounds__(kThreads) void k_partial_loss_bwd(const float* __re
         const size_t pix = (size_t)py * W + px;
         const int id = mas_load_id(sb, pix);
         if (id < 0 || id >= S) continue;
-        const unsigned Y = bb[id];
+        const unsigned Y = (flags & MAS_LOSS_TCE) ? (1u << id) : bb[id];
         const int nb = __popc(Y);
         if (nb == 0) continue;
         float v[CT];
@@ -450,7 +464,7 @@ __global__ __launch_bounds__(kThreads) void k_partial_loss_bwd(const float* __re
 #pragma unroll
             for (int c = 0; c < CT; ++c)
                 if (EXACT || c < C) pos = ((Y >> c) & 1u) ? (pos + v[c]) : pos;
-            coef = ((nb == 1) ? a_ce : a_mc) * (1.0f / (pos + 1e-8f));
+            coef = ((nb == 1) ? a_ce : a_mc) * (1.0f / ((flags & MAS_LOSS_TCE) ? pos : pos + 1e-8f));
         }
         // group loss: classes of Y whose arg-max pixel is this pixel
         unsigned A = 0;

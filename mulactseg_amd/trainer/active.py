@@ -56,8 +56,13 @@ class ActiveTrainer(BaseTrainer):
             images = batch['images'].to(self.device, dtype=torch.float32)
             labels = batch['labels'].to(self.device, dtype=self.target_dtype)
             self.optimizer.zero_grad()
-            preds = self.forward_train(images)
-            loss = self.loss_fun(preds, labels)
+            net = self.ddp or self.net
+            if (hasattr(self.loss_fun, 'forward_lowres') and getattr(self.net, 'lowres_logits', False) and images.is_cuda
+                    and getattr(self.args, 'lowres_loss', True) and labels.dim() == 3):
+                # quarter-resolution logits out of the model, the final x4 bilinear upsampling inside the loss scans (a-11)
+                loss = self.loss_fun.forward_lowres(net(images, lowres=True), images.shape[-2:], labels)
+            else:
+                loss = self.loss_fun(self.forward_train(images), labels)
             bad = torch.isnan(loss.detach()).to(torch.int32)
             if self.ddp is not None:            # the skip must be taken by every rank or by none (gradient all-reduce)
                 import torch.distributed as dist

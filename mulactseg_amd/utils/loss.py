@@ -128,14 +128,52 @@ def _run(inputs, targets, superpixels, spmasks, temp, flags, drop_last_column, s
 
 
 class MyCrossEntropyLoss(nn.CrossEntropyLoss):
-    """Cross entropy with a temperature (stage-2 training) -- reference ``utils/loss.py:10-21``."""
+    """Cross entropy with a temperature (stage-2 training) -- reference ``utils/loss.py:10-21``.
 
-    def __init__(self, ignore_index, reduction='mean', temperature=1.0):
+    On the GPU (mean reduction, no class weights, no label smoothing, <= 32 channels) the value and the gradient come from the
+    partial-label scans in their MAS_LOSS_TCE form: one forward scan and one backward scan over the valid pixels instead of
+    ATen's div + log_softmax + nll passes over the materialised ``[N,C,H,W]`` tensor; ``forward_lowres`` takes the model's
+    quarter-resolution logits (``net(images, lowres=True)``) and evaluates the x4 bilinear upsampling
+    (``models/segmentation/utils.py:25``) inside the scans -- the full-resolution logits and their gradient never exist.
+    Under torch.distributed the sums and the valid-pixel counts are all-reduced before the division when ``sync_normalisers``
+    (the mean over the GLOBAL batch; multiply by the world size before ``backward()`` under DistributedDataParallel)."""
+
+    def __init__(self, ignore_index, reduction='mean', temperature=1.0, sync_normalisers=False):
         super().__init__(ignore_index=ignore_index, reduction=reduction)
         self.temperature = temperature
+        self.sync_normalisers = sync_normalisers
+
+    def _fused(self, input, target):
+        return (input.is_cuda and self.reduction == 'mean' and self.weight is None and getattr(self, 'label_smoothing', 0.0) == 0.0
+                and input.dim() == 4 and input.shape[1] <= _lib.MAX_CLASSES and input.dtype == torch.float32
+                and target.dim() == 3 and not target.is_floating_point())
+
+    def _labels_mask(self, input, target):
+        C = input.shape[1]
+        labels = target.contiguous()
+        # (labels outside [0, C) other than ignore_index are an error in torch; here they are left out like ignored ones)
+        mask = (labels != self.ignore_index) & (labels >= 0) & (labels < C)
+        dummy_bits = torch.zeros((input.shape[0], C), dtype=torch.int32, device=input.device)
+        return labels, mask, dummy_bits
 
     def forward(self, input, target):
-        return super().forward(input / self.temperature, target)
+        if not self._fused(input, target):
+            return super().forward(input / self.temperature, target)
+        labels, mask, bits = self._labels_mask(input, target)
+        ce, _, _, self.last_acc = _PartialLossFn.apply(input, bits, labels, mask, ops.inv_temperature(self.temperature),
+                                                        _lib.LOSS_CE | _lib.LOSS_TCE, self.sync_normalisers)
+        return ce
+
+    def forward_lowres(self, quarter_logits, size, target):
+        """CE of ``F.interpolate(quarter_logits, size, 'bilinear', align_corners=False) / T`` against ``target`` [N,H,W]."""
+        if not self._fused(quarter_logits, target):
+            up = torch.nn.functional.interpolate(quarter_logits, size=tuple(size), mode='bilinear', align_corners=False)
+            return super().forward(up / self.temperature, target)
+        labels, mask, bits = self._labels_mask(quarter_logits, target)
+        ce, _, _, self.last_acc = _PartialLossLowResFn.apply(quarter_logits, tuple(size), bits, labels, mask,
+                                                             ops.inv_temperature(self.temperature), _lib.LOSS_CE | _lib.LOSS_TCE,
+                                                             self.sync_normalisers)
+        return ce
 
 
 class MultiChoiceCE(nn.Module):

@@ -147,6 +147,7 @@ void exact_softmax_rows(const float* z, int64_t n, int C, float invT, float* p) 
 #define LOSS_GROUP 2
 #define LOSS_GROUP_ONLY_MULTI 4
 #define LOSS_DECOMP 8
+#define LOSS_TCE 16 /* `spx` holds class labels: target = the label, l = -log p_label (no epsilon), mean over the valid pixels -- utils/loss.py:10-21 */
 enum { ACC_SUM_CE = 0, ACC_SUM_MC = 1, ACC_N_CE = 2, ACC_N_MC = 3, ACC_N_EMPTY = 4, ACC_SUM_GROUP = 5, ACC_N_GROUP = 6 };
 
 static int popcount32(uint32_t v) { int n = 0; while (v) { n += (int)(v & 1u); v >>= 1; } return n; }
@@ -179,7 +180,7 @@ void exact_partial_loss_fwd(const float* z, const int64_t* spx, const uint8_t* m
             if (!mask[(size_t)n * HW + i]) continue;
             const int64_t id = spx[(size_t)n * HW + i];
             if (id < 0 || id >= S) continue;
-            const uint32_t Y = bits[(size_t)n * S + id];
+            const uint32_t Y = (flags & LOSS_TCE) ? (1u << id) : bits[(size_t)n * S + id];
             const int nb = popcount32(Y);
             if (nb == 0) { acc[ACC_N_EMPTY] += 1; continue; }
             {
@@ -190,7 +191,7 @@ void exact_partial_loss_fwd(const float* z, const int64_t* spx, const uint8_t* m
                 float pos = 0.0f;
                 for (c = 0; c < C; ++c)
                     if ((Y >> c) & 1u) pos = pos + p[c];
-                const float l = -mas_logf(pos + 1e-8f);
+                const float l = -mas_logf((flags & LOSS_TCE) ? pos : pos + 1e-8f);
                 const uint64_t q = mas_fix(l, MAS_LOSS_FRAC);
                 if (nb == 1) { acc[ACC_SUM_CE] += q; acc[ACC_N_CE] += 1; }
                 else { acc[ACC_SUM_MC] += q; acc[ACC_N_MC] += 1; }
@@ -219,14 +220,22 @@ void exact_group_finalize(const uint64_t* gmax, int64_t n_entries, uint64_t* acc
     }
 }
 
-static float loss_value(uint64_t sum, uint64_t n) {
+static float loss_value_n(uint64_t sum, uint64_t n, int one) {
     union { double d; uint64_t u; } s;
     s.u = (uint64_t)(1023 - MAS_LOSS_FRAC) << 52;
-    return (float)(((double)sum * s.d) / (double)(n + 1));
+    return (float)(((double)sum * s.d) / (double)(n + one));
 }
+
+static float loss_value(uint64_t sum, uint64_t n) { return loss_value_n(sum, n, 1); }
 
 /* loss / num_valid with num_valid starting at 1 (utils/loss.py:106,556; lossdecomp.py:32-35,72) */
 void exact_loss_values(const uint64_t* acc, int flags, float* out) {
+    if (flags & LOSS_TCE) {             /* nn.CrossEntropyLoss(reduction='mean'): sum / n over the valid pixels */
+        out[0] = loss_value_n(acc[ACC_SUM_CE], acc[ACC_N_CE], 0);
+        out[1] = 0.0f;
+        out[2] = 0.0f;
+        return;
+    }
     if (flags & LOSS_DECOMP) {
         out[0] = loss_value(acc[ACC_SUM_CE], acc[ACC_N_CE]);
         out[1] = loss_value(acc[ACC_SUM_MC], acc[ACC_N_MC]);
@@ -238,6 +247,12 @@ void exact_loss_values(const uint64_t* acc, int flags, float* out) {
 }
 
 void exact_loss_scales(const uint64_t* acc, const float* grad_out, int flags, float* scale) {
+    if (flags & LOSS_TCE) {
+        scale[0] = grad_out[0] / (float)acc[ACC_N_CE];
+        scale[1] = 0.0f;
+        scale[2] = 0.0f;
+        return;
+    }
     if (flags & LOSS_DECOMP) {
         scale[0] = grad_out[0] / (float)(acc[ACC_N_CE] + 1);
         scale[1] = grad_out[1] / (float)(acc[ACC_N_MC] + 1);
@@ -266,7 +281,7 @@ void exact_partial_loss_bwd(const float* z, const int64_t* spx, const uint8_t* m
             if (!mask[(size_t)n * HW + i]) continue;
             const int64_t id = spx[(size_t)n * HW + i];
             if (id < 0 || id >= S) continue;
-            const uint32_t Y = bits[(size_t)n * S + id];
+            const uint32_t Y = (flags & LOSS_TCE) ? (1u << id) : bits[(size_t)n * S + id];
             const int nb = popcount32(Y);
             if (nb == 0) continue;
             {
@@ -277,7 +292,7 @@ void exact_partial_loss_bwd(const float* z, const int64_t* spx, const uint8_t* m
             if (flags & LOSS_CE) {
                 for (c = 0; c < C; ++c)
                     if ((Y >> c) & 1u) pos = pos + p[c];
-                coef = ((nb == 1) ? a_ce : a_mc) * (1.0f / (pos + 1e-8f));
+                coef = ((nb == 1) ? a_ce : a_mc) * (1.0f / ((flags & LOSS_TCE) ? pos : pos + 1e-8f));
             }
             uint32_t A = 0;
             float u = 0.0f;

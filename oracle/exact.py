@@ -121,7 +121,7 @@ def softmax_rows(z, invT):
 # ------------------------------------------------------------------------------------------------
 # stage-1 losses
 # ------------------------------------------------------------------------------------------------
-LOSS_CE, LOSS_GROUP, LOSS_GROUP_ONLY_MULTI, LOSS_DECOMP = 1, 2, 4, 8
+LOSS_CE, LOSS_GROUP, LOSS_GROUP_ONLY_MULTI, LOSS_DECOMP, LOSS_TCE = 1, 2, 4, 8, 16
 
 
 def target_bits(targets, cols_used=None):

@@ -349,3 +349,54 @@ def test_weighted_objective_equals_the_torch_composition():
     t3, _, _, _ = crit.weighted_lowres(z3, (H, W), tg, sp, mk, 16.0, 8.0, 1.0)
     (t3 * 2.0).backward()
     assert float((z3.grad - 2.0 * z1.grad).abs().max()) <= 1e-6 * float(z1.grad.abs().max())
+
+
+def test_temperature_ce_kernel_equals_the_c_oracle_and_torch():
+    """a-11, ``MyCrossEntropyLoss`` (reference utils/loss.py:10-21) on the MAS_LOSS_TCE form of the scans: value and gradient
+    bit for bit equal to oracle/exact.c's twin, within 1e-4 of ATen's CrossEntropyLoss(input / T); the quarter-resolution form
+    (``forward_lowres``) equals the materialised form's value bit for bit and ATen's gradient through F.interpolate to 1e-4."""
+    ops = _gpu()
+    from oracle import exact
+    from mulactseg_amd import _lib
+    from mulactseg_amd.utils import loss as L
+    import torch.nn.functional as F
+    N, C, H, W, T = 2, 20, 48, 64, 0.1
+    rs = np.random.RandomState(17)
+    z = (0.35 * rs.standard_normal((N, C, H, W))).astype(np.float32)
+    y = rs.randint(0, C, size=(N, H, W)).astype(np.int64)
+    y[rs.uniform(size=y.shape) < 0.25] = 255
+    crit = L.MyCrossEntropyLoss(ignore_index=255, temperature=T)
+    zt = torch.from_numpy(z).cuda().requires_grad_(True)
+    yt = torch.from_numpy(y).cuda()
+    loss = crit(zt, yt)
+    loss.backward()
+    # the C twin
+    flags = _lib.LOSS_CE | _lib.LOSS_TCE
+    invT = np.float32(ops.inv_temperature(T))
+    mask = (y != 255)
+    bits = np.zeros((N, C), dtype=np.uint32)
+    acc, gmax, losses = exact.partial_loss_fwd(z, y, mask, bits, invT, flags)
+    assert np.float32(float(loss)) == losses[0]
+    _, dz = exact.partial_loss_bwd(z, y, mask, bits, gmax, acc, np.array([1.0, 0.0, 0.0], dtype=np.float32), invT, flags)
+    assert np.array_equal(zt.grad.cpu().numpy(), dz)
+    # ATen
+    zr = torch.from_numpy(z).cuda().requires_grad_(True)
+    ref = F.cross_entropy(zr / T, yt, ignore_index=255)
+    ref.backward()
+    assert abs(float(loss) - float(ref)) <= 1e-4 * abs(float(ref))
+    assert float((zt.grad - zr.grad).abs().max()) <= 1e-4 * float(zr.grad.abs().max())
+    # quarter-resolution form
+    q = (0.35 * rs.standard_normal((N, C, H // 4, W // 4))).astype(np.float32)
+    qt = torch.from_numpy(q).cuda().requires_grad_(True)
+    low = crit.forward_lowres(qt, (H, W), yt)
+    low.backward()
+    up = ops.upsample_bilinear(torch.from_numpy(q).cuda(), (H, W))
+    assert float(low) == float(crit(up, yt))
+    qr = torch.from_numpy(q).cuda().requires_grad_(True)
+    refq = F.cross_entropy(F.interpolate(qr, size=(H, W), mode='bilinear', align_corners=False) / T, yt, ignore_index=255)
+    refq.backward()
+    assert abs(float(low) - float(refq)) <= 1e-4 * abs(float(refq))
+    assert float((qt.grad - qr.grad).abs().max()) <= 1e-4 * float(qr.grad.abs().max())
+    # no valid pixel: NaN like torch's mean over nothing
+    none = torch.full_like(yt, 255)
+    assert torch.isnan(crit(zt.detach(), none))

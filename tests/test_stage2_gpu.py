@@ -93,3 +93,63 @@ def test_sliding_window_ensemble_trainer():
     ref = exact.stage2_pseudo_labels(fn, scores[None].cpu().numpy(), tgt, msk, spx, True)
     assert np.array_equal(out, ref)
     assert (out != 255).any()
+
+
+def test_full_size_cityscapes_image_matches_the_oracle_bit_for_bit():
+    """BASELINE.json config 4 at its real size: one 1024 x 2048 picture, 2 048 superpixels, 256-dimensional quarter-resolution
+    features interpolated inside the kernels (trainer/eval_save_cosplbl_prop.py:121-314 on the output of feat_forward): the label
+    map equals oracle/exact.c's on every pixel, labels stay inside the one-ring of the selected superpixels and every selected
+    pixel gets one of its target classes."""
+    ops = _gpu()
+    from oracle import exact
+    from scipy import ndimage
+    from mulactseg_amd import synth
+    C, Ch, H, W, S = 20, 256, 1024, 2048, 2048
+    rs = np.random.RandomState(7)
+    fq = rs.standard_normal((1, Ch, H // 4, W // 4)).astype(np.float32)
+    fq /= np.linalg.norm(fq, axis=1, keepdims=True)
+    z = synth.logits(8, 1, C, H, W)
+    spx = synth.superpixel_map(9, H, W, S)[None]
+    tgt = synth.multi_hot_targets(10, S, C, p_counts=(0.5, 0.3, 0.15, 0.05))[None]
+    chosen = rs.choice(S, size=int(0.15 * S), replace=False)
+    msk = np.isin(spx, chosen)
+    out = _run(ops, fq, z, tgt, msk, spx, True)
+    ref = exact.stage2_pseudo_labels(fq, z, tgt, msk, spx, True)
+    assert out.shape == (1, H, W) and np.array_equal(out, ref)
+    lab = out[0]
+    ring = np.unique(spx[0][ndimage.binary_dilation(msk[0], structure=np.ones((3, 3)))])
+    assert np.all(np.isin(spx[0][lab != 255], ring))
+    assert np.all(lab[msk[0]] != 255) and np.all(tgt[0][spx[0][msk[0]], lab[msk[0]]] == 1)
+    assert 0.15 < (lab != 255).mean() < 0.9
+
+
+def test_sliding_window_trainer_at_full_size():
+    """Config 4's sliding variant at its real size (trainer/eval_save_cosplbl_prop_includeonehot_slide, utils/sliding_evaluator_plbl.py:
+    crop 800, stride 2/3 -> 8 windows over 1024 x 2048, features summed at full resolution): pseudo labels from the REAL network
+    == oracle/exact.c fed the same ensemble feature / score arrays."""
+    ops = _gpu()
+    from oracle import exact
+    from mulactseg_amd import synth
+    from mulactseg_amd.models import get_model
+    from mulactseg_amd.trainer import eval_save_cosplbl_prop_includeonehot_slide as mod
+    C, H, W, S = 20, 1024, 2048, 2048
+    torch.manual_seed(5)
+    tr = object.__new__(mod.ActiveTrainer)
+    tr.net = get_model('deeplabv3pluswn_resnet50deepstem', C, 16, True, pretrained_backbone=False).cuda().eval()
+    tr.device = torch.device('cuda')
+    tr.num_classes = C - 1
+    tr.crop_size, tr.stride_rate = 800, 2 / 3
+    rs = np.random.RandomState(11)
+    img = torch.from_numpy(rs.standard_normal((1, 3, H, W)).astype(np.float32)).cuda()
+    spx = synth.superpixel_map(12, H, W, S)[None]
+    tgt = synth.multi_hot_targets(13, S, C, p_counts=(0.5, 0.3, 0.15, 0.05))[None]
+    msk = np.isin(spx, rs.choice(S, size=int(0.1 * S), replace=False))
+    labels = rs.randint(0, C - 1, size=(1, H, W)).astype(np.int64)
+    c = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
+    out = tr.pseudo_labels(img, c(labels), c(tgt), c(msk), c(spx)).cpu().numpy()
+    feats, scores = tr.evaluator(img)
+    assert tuple(feats.shape) == (256, H, W) and tuple(scores.shape) == (C, H, W)
+    fn = torch.nn.functional.normalize(feats[None], dim=1, p=2).cpu().numpy()
+    ref = exact.stage2_pseudo_labels(fn, scores[None].cpu().numpy(), tgt, msk, spx, True)
+    assert np.array_equal(out, ref)
+    assert (out != 255).any()

@@ -256,3 +256,35 @@ def test_five_round_loop_on_a_resident_pool_keeps_the_books(tmp_path):
     assert rep["stage2_generation"]["pictures"] == 2
     for k in range(1, 6):
         assert os.path.exists(tmp_path / ("checkpoint%02d.tar" % k)) and os.path.exists(tmp_path / ("datalist_%02d.pkl" % k))
+
+
+def test_five_round_loop_at_pool_scale(tmp_path):
+    """BASELINE.json config 5 at its real size on one GPU (reference loop: train_AL.py:37-85): 2 975 pictures x 2 048 superpixels
+    resident in HBM, 100 000 clicks per round, 5 rounds, 10 training iterations per round at the 768 crop.  Every round the
+    script asserts its bookkeeping invariants (labelled set == previous + consumed prefix, no duplicates, pool shrinks by the same
+    regions, budget walk stops at the reference's region, datalist_RR.pkl reloads) and -- for the four scored rounds -- that the
+    prefix consumed by the device ordering + walk over ~6 M keys equals a numpy lexsort restatement of the reference's
+    ``sorted(tuples, reverse=True)`` (active_selection/base.py:37) region for region."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    if torch.cuda.get_device_properties(0).total_memory < 80e9:
+        pytest.skip("the resident pool needs ~35 GB of device memory")
+    import importlib.util
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("al_pool_full", os.path.join(root, "examples", "al_rounds_pool_scale.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    rep = mod.main(["--rounds", "5", "--images", "2975", "--height", "1024", "--width", "2048", "--nseg", "2048", "--budget", "100000",
+                    "--iters", "10", "--crop", "768", "--val-images", "4", "--stage2-images", "2", "--check-order", "--out", str(tmp_path)])
+    rs = rep["rounds"]
+    assert [r["round"] for r in rs] == [1, 2, 3, 4, 5]
+    assert rep["pool"]["regions"] == 2975 * 2048
+    tot = [r["labelled_regions_total"] for r in rs]
+    assert all(b - a == r["regions_selected"] for a, b, r in zip([0] + tot, tot, rs))
+    assert all(100000 < r["clicks"] <= 100004 for r in rs)
+    assert all(r.get("order_checked_regions") == r["regions_selected"] for r in rs[1:])
+    assert all(np.isfinite(r["val_miou_synthetic"]) for r in rs)
+    os.makedirs(os.path.join(root, "gpurun_out"), exist_ok=True)
+    with open(os.path.join(root, "gpurun_out", "al_rounds_pool_scale_test.json"), "w") as f:
+        import json
+        json.dump(rep, f, indent=1)
