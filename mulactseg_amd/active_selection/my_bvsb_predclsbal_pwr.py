@@ -12,6 +12,7 @@ per-pixel f32 rounding of ``bvsb * w`` is the only difference) and give the same
 """
 
 from . import my_bvsb
+from .. import _lib
 from .engine import AcquisitionRound
 
 
@@ -37,9 +38,18 @@ class RegionSelector(my_bvsb.RegionSelector):
             for row, preds, spx in self._iterate(trainer, pool_set, rnd, lowres=low):   # the only pass
                 self._check_channels(preds, C)
                 if low:
-                    rnd.add_single_pass_lowres(row, preds, spx.shape[-2:], spx)
-                else:
-                    rnd.add_single_pass(row, preds, spx)
+                    try:
+                        rnd.add_single_pass_lowres(row, preds, spx.shape[-2:], spx)
+                        continue
+                    except _lib.MulActSegHipError as e:
+                        # the in-kernel upsampling covers ratios >= ~3.8 (the model's is 4); other ratios are refused BEFORE anything
+                        # is launched (argument check): scan the upsampled logits instead, for this and the remaining batches
+                        if "out of range" not in str(e) and "shape" not in str(e):
+                            raise
+                        low = False
+                        from .. import ops
+                        preds = ops.upsample_bilinear(preds.contiguous(), spx.shape[-2:])
+                rnd.add_single_pass(row, preds if preds.shape[-2:] == spx.shape[-2:] else self._upsampled(preds, spx), spx)
             cls_w = rnd.class_weights(self.args.cls_weight_coeff)
             self._round, self.cls_weight = rnd, cls_w
             return rnd.scores_single_pass(cls_w, ban_class=ban, want_hist=want_hist)
@@ -52,6 +62,11 @@ class RegionSelector(my_bvsb.RegionSelector):
         for row, preds, spx in self._iterate(trainer, pool_set, rnd):               # pass 2 (:49-72)
             rnd.add_regions(row, preds, spx, cls_w)
         return rnd.scores(ban_class=ban, want_hist=want_hist)
+
+    @staticmethod
+    def _upsampled(preds, spx):
+        from .. import ops
+        return ops.upsample_bilinear(preds.contiguous(), spx.shape[-2:])
 
     @property
     def cumulated_pred_prob(self):

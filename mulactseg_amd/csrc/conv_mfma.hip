@@ -285,11 +285,15 @@ int launch_res(ConvP p, int N, hipStream_t st) {
     const size_t smem = sizeof(float) * ((size_t)TAPS * CK * BM + 2 * BM + (size_t)CK * p.CS);
     if (smem > 80 * 1024) return MAS_ERR_SHAPE;        // two workgroups per CU must fit the 160 KB
     if (smem > 64 * 1024) {
-        static bool once = false;                      // above the default dynamic-LDS limit: raise it once per instantiation
-        if (!once) {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv_mfma<TAPS, CK, BM, BN, NXMAX, VEC, RES, MPAD>),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
-            once = true;
+        static bool raised[64] = {};                   // above the default dynamic-LDS limit: raise it once per (instantiation, device)
+        int dev = 0;
+        hipError_t e = hipGetDevice(&dev);
+        if (e != hipSuccess) return (int)e;
+        if (dev < 0 || dev >= 64 || !raised[dev]) {
+            e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv_mfma<TAPS, CK, BM, BN, NXMAX, VEC, RES, MPAD>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+            if (e != hipSuccess) return (int)e;
+            if (dev >= 0 && dev < 64) raised[dev] = true;
         }
     }
     const long long nblk = 8LL * ((p.ptiles + 7) / 8) * p.mtiles;

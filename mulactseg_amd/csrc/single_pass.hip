@@ -632,20 +632,27 @@ int launch_low(const float* zq, int h, int w, const void* spx, int B, int C, int
     const size_t smem = smem_bytes(C, CT) + sizeof(float) * (size_t)C * kLowRows * kLowCols;
     const bool vec = (W % 4 == 0);
     const IdT* ids = static_cast<const IdT*>(spx);
-    static bool attr_vec = false, attr_scalar = false;          // > 64 KB of dynamic LDS needs the attribute, once per kernel
+    // > 64 KB of dynamic LDS needs the attribute on every device's copy of the code object: flags per (kernel, device), the
+    // call's status is the launch's status
+    static bool attr_vec[64] = {}, attr_scalar[64] = {};
+    int dev = 0;
+    if (hipError_t e = hipGetDevice(&dev); e != hipSuccess) return (int)e;
+    const bool cached = dev >= 0 && dev < 64;
     if (vec) {
-        if (!attr_vec) {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_single_pass<CT, EXACT, IdT, true, true>),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
-            attr_vec = true;
+        if (!cached || !attr_vec[dev]) {
+            const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_single_pass<CT, EXACT, IdT, true, true>),
+                                                     hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+            if (e != hipSuccess) return (int)e;
+            if (cached) attr_vec[dev] = true;
         }
         hipLaunchKernelGGL((k_single_pass<CT, EXACT, IdT, true, true>), dim3((unsigned)nblk), dim3(kThreads), smem, st, zq, ids, C, H, W, S,
                            invT, tiles_x, tiles_y, prob_sum, class_sum, hist, lr);
     } else {
-        if (!attr_scalar) {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_single_pass<CT, EXACT, IdT, false, true>),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
-            attr_scalar = true;
+        if (!cached || !attr_scalar[dev]) {
+            const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_single_pass<CT, EXACT, IdT, false, true>),
+                                                     hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+            if (e != hipSuccess) return (int)e;
+            if (cached) attr_scalar[dev] = true;
         }
         hipLaunchKernelGGL((k_single_pass<CT, EXACT, IdT, false, true>), dim3((unsigned)nblk), dim3(kThreads), smem, st, zq, ids, C, H, W, S,
                            invT, tiles_x, tiles_y, prob_sum, class_sum, hist, lr);

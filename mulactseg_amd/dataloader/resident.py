@@ -58,8 +58,9 @@ class ResidentRegionDataset(torch.utils.data.Dataset):
         grew (expand_training_set appends; a pad id ``nseg`` is never selected) -- a sample then costs no H2D copy."""
         ids = self.suppix.get(spx_fname, [])
         hit = self._lut.get(spx_fname)
-        if hit is None or hit[0] != len(ids):
-            hit = (len(ids), selection_lut(ids, self.args.nseg, device))
+        key = (id(ids), len(ids))           # load_datalist replaces the lists wholesale: a new list object is a new table
+        if hit is None or hit[0] != key:
+            hit = (key, selection_lut(ids, self.args.nseg, device))
             self._lut[spx_fname] = hit
         return hit[1]
 
@@ -79,6 +80,6 @@ class ResidentRegionDataset(torch.utils.data.Dataset):
         if self.split == 'active-ulabel':
             return self.__getpoolitem__(k)
         image, (superpixel,) = self.transform(self.pictures[k], [self.superpixels[k]])
-        sp_mask = self._selection_lut(spx_fname, superpixel.device)[superpixel.clamp(min=0, max=self.args.nseg)]     # (:88-89)
+        sp_mask = self._selection_lut(spx_fname, superpixel.device)[superpixel.clamp(min=0, max=self.args.nseg)] & (superpixel >= 0)  # (:88-89)
         return {'images': image, 'labels': self.multi_hot_cls[k], 'spx': superpixel, 'spmask': sp_mask,
                 'fnames': self.im_idx[index]}

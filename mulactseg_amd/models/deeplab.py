@@ -72,8 +72,8 @@ def _conv_bn_act(conv, bn, x, relu=True, residual=None):
         if residual is None and ops.stem_conv_supported(conv, x):          # 3 -> 64, stride 2: output-bound, packed-f32 kernel
             _took("conv_bn_act", "hip_stem")
             return ops.stem_conv(conv, x, bn, relu)
-        if (residual is None and x.shape[2] * x.shape[3] == 1 and conv.kernel_size == (1, 1) and conv.groups == 1 and conv.bias is None
-                and x.dtype == torch.float32):
+        if (residual is None and x.shape[2] * x.shape[3] == 1 and conv.kernel_size == (1, 1) and conv.padding == (0, 0) and conv.groups == 1
+                and conv.bias is None and x.dtype == torch.float32):
             # a 1x1 convolution of a 1x1 map (the ASPP image-pooling branch) is a [N,K] x [K,M] product: rocBLAS, no MIOpen
             # solver search for every new batch size
             _took("conv_bn_act", "gemm")

@@ -998,9 +998,14 @@ def conv_mfma(conv, x, bn=None, relu=False, residual=None):
     M = conv.out_channels
     ks, s, d = conv.kernel_size[0], conv.stride[0], conv.dilation[0]
     wt = _conv_packed_weight(conv)
+    if bn is not None and bn.num_features != M:
+        raise ValueError("BatchNorm has %d features, the convolution %d output channels" % (bn.num_features, M))
     scale, shift = _bn_fold(bn) if bn is not None else (None, None)
-    res = residual.contiguous() if residual is not None else None
     Ho, Wo = (H - 1) // s + 1, (W - 1) // s + 1
+    if residual is not None and (tuple(residual.shape) != (N, M, Ho, Wo) or residual.dtype != torch.float32 or residual.device != x.device):
+        raise ValueError("residual must be float32 %s on %s, got %s %s on %s"
+                         % ((N, M, Ho, Wo), x.device, residual.dtype, tuple(residual.shape), residual.device))
+    res = residual.contiguous() if residual is not None else None
     y = torch.empty((N, M, Ho, Wo), dtype=torch.float32, device=x.device)
     with torch.cuda.device(x.device):
         _lib.check(_lib.load().mas_conv_fwd(x.data_ptr(), wt.data_ptr(), N, K, H, W, M, ks, s, d, _opt(scale), _opt(shift), _opt(res),

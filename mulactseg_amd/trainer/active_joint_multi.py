@@ -74,7 +74,9 @@ class ActiveTrainer(active.ActiveTrainer):
         # (normalisers all-reduced, identical value on every rank -- so the skip is taken by all ranks or by none), hence
         # scale by the world size to get its exact gradient.
         scale = 1
-        if self.ddp is not None:
+        if self.ddp is not None and getattr(self, 'loss_is_global', True):
+            # (trainers whose criterion does NOT all-reduce its normalisers set loss_is_global = False: their loss is the local
+            # objective and DistributedDataParallel's gradient average is already what the reference's DataParallel computes)
             import torch.distributed as dist
             scale = dist.get_world_size()
         if loss.is_cuda:

@@ -116,7 +116,13 @@ def _all_reduce_sum(acc):
 
 
 def _run(inputs, targets, superpixels, spmasks, temp, flags, drop_last_column, sync=True):
-    """``sync``: under torch.distributed (world > 1) the integer sums and counts are all-reduced before the division, so
+    """CONTRACT of the drop-in modules under torch.distributed: with ``sync`` (the default of every partial-label module below,
+    attribute ``sync_normalisers`` where it is configurable) the returned loss is the objective over the GLOBAL batch, identical
+    on every rank; a caller that lets DistributedDataParallel average the gradients must multiply it by the world size before
+    ``backward()`` (``ActiveTrainer.update`` does, guarded by ``loss_is_global``).  With ``sync=False`` the loss is the local
+    objective and must NOT be scaled.
+
+    ``sync``: under torch.distributed (world > 1) the integer sums and counts are all-reduced before the division, so
     every rank holds the SAME loss value -- the loss over the global batch.  The reference's skip-on-zero / raise-on-NaN
     decisions (``active_joint_multi.py:31-37``) are then global by construction: no rank can skip ``backward()`` while
     its peers wait in the gradient all-reduce."""

@@ -414,14 +414,32 @@ def gen_g8():
     np.savez_compressed(os.path.join(OUT, "g8_sliding.npz"), **out)
 
 
+def _reference_ext_transforms():
+    """The reference's own ``dataloader/ext_transforms.py``, imported from where it lies (by path: the package name
+    ``dataloader`` is taken by the data-layer stand-in) with ``torchvision`` replaced by oracle/refshim/torchvision_shim."""
+    import collections
+    import collections.abc
+    import importlib.util
+    from oracle.refshim import torchvision_shim
+    torchvision_shim.install_torchvision()
+    if not hasattr(collections, "Iterable"):
+        collections.Iterable = collections.abc.Iterable            # ext_transforms.py:568 (Python < 3.10 spelling)
+    spec = importlib.util.spec_from_file_location("ref_ext_transforms", os.path.join(refshim.REFERENCE_ROOT, "dataloader", "ext_transforms.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
 def gen_g9():
-    """Training-time geometry with REAL Pillow calls in the reference's order
-    (dataloader/transform.py:105-113, ext_transforms.py:172-192, 443-520, 323-341, 384-437): resize (BILINEAR / NEAREST),
-    ImageOps.expand padding, crop, horizontal flip, to-tensor, normalise.  torchvision's functional ops on PIL images
-    are thin wrappers over exactly these calls."""
+    """Training-time geometry produced by RUNNING the reference's transform classes -- ExtCompose([ExtRandomScale,
+    ExtRandomCrop(pad_if_needed), ExtRandomHorizontalFlip, ExtToTensor, ExtNormalize]) as dataloader/transform.py:91-113 builds
+    them -- on PIL images under a seeded ``random``: scale draw, pad, crop draws, flip draw, to-tensor and normalisation all come
+    from /root/reference/dataloader/ext_transforms.py:172-192,443-520,323-341,384-437.  The draws the classes made are read back
+    from the result (sizes) and cross-checked against oracle/augment.draw_params, the restatement the device data path uses."""
     import random
-    from PIL import Image, ImageOps
+    from PIL import Image
     from oracle import augment
+    et = _reference_ext_transforms()
     mean, std = [0.485, 0.456, 0.406], [0.229, 0.224, 0.225]
     out = {}
     cases = []
@@ -431,25 +449,19 @@ def gen_g9():
         img = rs.randint(0, 256, size=(H, W, 3)).astype(np.uint8)
         lbl = rs.randint(0, 19, size=(H, W)).astype(np.uint8)
         spx = rs.randint(0, nseg, size=(H, W)).astype(np.int32)
-        rng = random.Random(seed)
-        p = augment.draw_params(rng, H, W, crop, scale_range=(1.0, 1.0) if seed == 5 else (0.5, 2.0))
-        pim = Image.fromarray(img).resize((p['tw'], p['th']), Image.BILINEAR)
-        plb = Image.fromarray(lbl).resize((p['tw'], p['th']), Image.NEAREST)
-        psp = Image.fromarray(spx).convert('I').resize((p['tw'], p['th']), Image.NEAREST)
-        for gap, border in ((p['gap_y'], lambda g: (0, g, 0, g)), (p['gap_x'], lambda g: (g, 0, g, 0))):
-            if gap:
-                pim = ImageOps.expand(pim, border=border(gap), fill=(124, 116, 104))
-                plb = ImageOps.expand(plb, border=border(gap), fill=255)
-                psp = ImageOps.expand(psp, border=border(gap), fill=nseg)
-        box = (p['j'], p['i'], p['j'] + crop[1], p['i'] + crop[0])
-        pim, plb, psp = pim.crop(box), plb.crop(box), psp.crop(box)
-        if p['flip']:
-            pim, plb, psp = [im.transpose(Image.FLIP_LEFT_RIGHT) for im in (pim, plb, psp)]
-        t = torch.from_numpy(np.array(pim, dtype=np.uint8).transpose(2, 0, 1).copy()).to(torch.float32).div(255)
-        t = t.sub(torch.tensor(mean)[:, None, None]).div(torch.tensor(std)[:, None, None])
+        scale_range = (1.0, 1.0) if seed == 5 else (0.5, 2.0)
+        tf = et.ExtCompose([et.ExtRandomScale(scale_range),
+                            et.ExtRandomCrop(size=crop, pad_values=[255, nseg], padding=(124, 116, 104), pad_if_needed=True),
+                            et.ExtRandomHorizontalFlip(),
+                            et.ExtToTensor(dtype_list=['uint8', 'int']),
+                            et.ExtNormalize(mean=mean, std=std)])
+        random.seed(seed)
+        t, (tl, ts) = tf(Image.fromarray(img), [Image.fromarray(lbl), Image.fromarray(spx).convert('I')])
         out['img_%d' % k] = t.numpy()
-        out['lbl_%d' % k] = np.array(plb, dtype=np.uint8)
-        out['spx_%d' % k] = np.array(psp, dtype=np.int64)
+        out['lbl_%d' % k] = tl.numpy().astype(np.uint8)
+        out['spx_%d' % k] = ts.numpy().astype(np.int64)
+        # the same stream through the restated draw order: the parameters the device path will use for this seed
+        p = augment.draw_params(random.Random(seed), H, W, crop, scale_range=scale_range)
         cases.append([seed, H, W, crop[0], crop[1], nseg, p['th'], p['tw'], p['gap_y'], p['gap_x'], p['i'], p['j'], int(p['flip'])])
         print("g9", cases[-1])
     out['cases'] = np.array(cases)

@@ -1,7 +1,7 @@
 """Make the reference's own Python importable in the BUILD CONTAINER (never on the GPU box).
 
-ORACLE / TEST INFRASTRUCTURE ONLY -- used by ``oracle/gen_golden.py`` and by the optional
-``tests/test_reference_live.py`` (skipped when ``/root/reference`` is absent).
+ORACLE / TEST INFRASTRUCTURE ONLY -- used by ``oracle/gen_golden.py`` (which writes ``tests/golden/*.npz``); nothing under
+``tests/`` imports the reference at run time.
 
 The reference (``/root/reference``) imports third-party packages that are not installed here
 (``torch_scatter``, ``wandb``, ``skimage``) and a data layer that cannot be imported offline

@@ -1,5 +1,5 @@
 # PMC passes over single convolution geometries (csrc/conv_mfma.hip): where do the cycles of the MFMA kernel go
-cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+set -eu; cd /tmp && export TMPDIR=/tmp && cd "${GRAFT_REPO_ROOT:?}"
 O=gpurun_out/pmcconv
 rm -rf $O; mkdir -p $O
 i=0

@@ -1,5 +1,5 @@
 # MFMA utilisation of the stage-1 train step (bench.py train_iter leg): PMC pass (kernel-trace + counters only)
-cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+set -eu; cd /tmp && export TMPDIR=/tmp && cd "${GRAFT_REPO_ROOT:?}"
 rm -rf gpurun_out/mf && rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F32 GRBM_GUI_ACTIVE --output-format csv -d gpurun_out/mf -o m -- python bench.py --no-cpu-baseline --steps 2 --warmup 1 --ramp 0 --train-steps 6 --acq-steps 1 > /dev/null 2>&1
 python - <<'PY'
 import csv, collections, sys

@@ -1,5 +1,5 @@
 # PMC passes over the two forms of the scan: VALU utilisation, issue stalls, LDS instructions (profiles/r02/k_scan_forms_pmc.md)
-cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+set -eu; cd /tmp && export TMPDIR=/tmp && cd "${GRAFT_REPO_ROOT:?}"
 O=gpurun_out/pmcscan
 rm -rf $O; mkdir -p $O
 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_ANY GRBM_GUI_ACTIVE --output-format csv -d $O/a -o a -- python tools/scan_forms_probe.py > $O/a.log 2>&1

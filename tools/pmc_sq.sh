@@ -1,4 +1,4 @@
-cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+set -eu; cd /tmp && export TMPDIR=/tmp && cd "${GRAFT_REPO_ROOT:?}"
 O=gpurun_out/pmcsq
 for mode in 1 0; do
 export MAS_SINGLE_PASS_RING=$mode

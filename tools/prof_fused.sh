@@ -1,5 +1,5 @@
 # rocprofv3 kernel-trace of tools/kbench.py fused; prints median duration of k_single_pass*
-cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+set -eu; cd /tmp && export TMPDIR=/tmp && cd "${GRAFT_REPO_ROOT:?}"
 rm -rf gpurun_out/pf && rocprofv3 --kernel-trace --output-format csv -d gpurun_out/pf -o t -- python tools/kbench.py fused "$@" > /dev/null 2>&1
 python - <<'PY'
 import csv,glob

@@ -1,4 +1,4 @@
-cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+set -eu; cd /tmp && export TMPDIR=/tmp && cd "${GRAFT_REPO_ROOT:?}"
 python bench.py > gpurun_out/bench_r1f.json 2> gpurun_out/bench_r1f.err; tail -c 600 gpurun_out/bench_r1f.err
 CMD="python bench.py --no-cpu-baseline --no-train"
 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/f_stats -o f -- $CMD > /dev/null 2>&1

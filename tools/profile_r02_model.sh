@@ -1,5 +1,5 @@
 # round 2: kernel traces of the model legs (pool forward on the MFMA convolution; train step at 768 and 769) + MFMA PMC of the pool forward
-cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+set -eu; cd /tmp && export TMPDIR=/tmp && cd "${GRAFT_REPO_ROOT:?}"
 rm -rf gpurun_out/tr2 && rocprofv3 --kernel-trace --output-format csv -d gpurun_out/tr2 -o t -- python bench.py --no-cpu-baseline --no-pool --steps 2 --warmup 1 --ramp 0 --train-steps 8 --acq-steps 8 > gpurun_out/tr2_bench.json 2>/dev/null
 python - <<'PY'
 import csv, collections, sys

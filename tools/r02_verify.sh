@@ -1,5 +1,5 @@
 # round-2 verification pass: GPU tests, the driver's own bench command, the default bench, kernel stats + PMC traffic
-cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+set -eu; cd /tmp && export TMPDIR=/tmp && cd "${GRAFT_REPO_ROOT:?}"
 python -m pytest tests -m gpu -x -q > gpurun_out/r2b_gputests.log 2>&1; echo "tests rc=$?"; tail -3 gpurun_out/r2b_gputests.log
 python bench.py --gpus 1 --steps 20 --warmup 5 > gpurun_out/r2b_bench_driver.json 2> gpurun_out/r2b_bench_driver.err; echo "driver-style bench rc=$?"
 CMD="python bench.py --no-cpu-baseline --no-train --no-pool"
