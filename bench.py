@@ -331,8 +331,11 @@ def train_iter_bench(args, dev, world, crop):
     fence()
     it_ms = max_over_ranks(time.perf_counter() - t0, dev) / args.train_steps * 1e3
     return {"metric": "train-iter images/sec", "value": N * world / (it_ms * 1e-3), "unit": "images/s", "ms_per_iter": it_ms,
-            "config": {"workload": "stage-1 step: DeepLabv3+WN/ResNet50-deepstem fwd+bwd (MIOpen fp32 + HIP memory-bound layers) + fused "
-                                   "partial-label losses (HIP) + AdamW" + ("; DistributedDataParallel over RCCL, global loss normalisers" if world > 1 else ""),
+            "config": {"workload": "stage-1 step: DeepLabv3+WN/ResNet50-deepstem fwd+bwd with the dense convolutions on this package's f32-MFMA "
+                                   "kernels (k_conv_sk: persistent stream-K forward / input gradient; k_wgrad: split-K weight gradient; "
+                                   "layer_paths_per_step says which product of which layer took which kernel) + HIP memory-bound layers + "
+                                   "fused partial-label losses (HIP) + AdamW" + ("; DistributedDataParallel over RCCL, global loss normalisers" if world > 1 else ""),
+                       "train_conv_mode": os.environ.get("MAS_TRAIN_CONV", "own"),
                        "batch": [N, 3, crop, crop], "logits": [N, C, crop, crop], "nseg": S,
                        "selected_fraction": float(msk.float().mean())},
             "layer_paths_per_step": paths,

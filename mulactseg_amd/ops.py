@@ -1318,10 +1318,11 @@ def conv_wgrad_supported(conv, x):
 
 def conv_train_plan(conv, x):
     """(forward, input gradient, weight gradient) -> True where this package's kernel runs the product, or None when the layer
-    is outside all three (then the caller keeps the nn.Module call).  MAS_TRAIN_CONV = own: every product the kernels support;
-    miopen: none; default: the measured per-geometry choice of tools/conv_train_table.py (profiles/r03/a_*): the weight gradient
-    everywhere, forward on planes of >= 192 x 192 pixels, input gradient on planes of >= 384 x 384."""
-    mode = os.environ.get("MAS_TRAIN_CONV", "auto")
+    is outside all three (then the caller keeps the nn.Module call).  MAS_TRAIN_CONV = own (default): every product the kernels
+    support -- all of them except the input gradient of the two stride-2 3x3 convolutions; miopen: none; auto: the weight
+    gradient everywhere, forward / input gradient only on planes of >= 192 x 192 / 384 x 384 pixels (MIOpen's Tensile GEMMs are
+    still ahead on the 1x1 layers of the small planes: profiles/r03/b_conv_train_table_streamk.md; ~0.4 ms per step)."""
+    mode = os.environ.get("MAS_TRAIN_CONV", "own")
     if mode == "miopen" or not conv_wgrad_supported(conv, x):
         return None
     hw = x.shape[2] * x.shape[3]

@@ -23,6 +23,9 @@ def short(name):
         if k in name:
             m = re.search(r"%s[a-z_0-9]*(<[^>]*>)?" % k, name)
             return m.group(0) if m else k
+    m = re.search(r"\b(k_[a-z0-9_]+(<[^>]*>)?)", name)          # every other kernel of this package, template arguments kept
+    if m:
+        return m.group(1)
     m = re.search(r"(miopen\w+|MIOpen\w+|igemm_\w+|Cijk_\w+|naive_conv\w+|rocprim::\w+(::\w+)*|at::native::\w+(::\w+)*|\w+_kernel\w*)", name)
     return (m.group(1) if m else name)[:80]
 
