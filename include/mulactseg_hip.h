@@ -435,6 +435,13 @@ int mas_conv_sk(const float* x, const float* wp, int N, int Cin, int H, int W, i
                 const float* scale, const float* shift, const float* residual, int relu, float* y, void* workspace,
                 size_t workspace_bytes, unsigned epoch, void* stream);
 int mas_conv_sk_error(const void* workspace, unsigned* out_host);
+/* staging of the K chunks, process-wide: 0 (default) = global -> registers -> LDS, two LDS buffers; 1 = LDS-DMA ring
+ * (global_load_lds into 2..4 LDS buffers, up to three chunks in flight, no staging registers; measured 3-5 % slower on the
+ * training shapes); returns the previous setting (any other argument only queries) */
+int mas_conv_sk_set_mode(int dma);
+/* tools only: the following mas_conv_sk launches write per-workgroup wall-clock stamps (100 MHz; start, pipeline primed, last
+ * tile done, end) into stamps_dev [512][4] uint64, indexed by the logical workgroup; NULL switches it off */
+int mas_conv_sk_debug_stamps(void* stamps_dev);
 
 /* Weight gradient of a dense convolution on the f32 matrix cores (csrc/conv_wgrad.hip), NCHW operands as autograd holds them:
  *   dw[m,c,r,s] = sum_{n,oy,ox} dy[n,m,oy,ox] * x[n,c, oy*stride + r*dil - pad, ox*stride + s*dil - pad],  pad = dil (ksize 3) / 0 (ksize 1)

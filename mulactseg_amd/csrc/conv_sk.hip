@@ -43,11 +43,14 @@ struct SkP {
     float* y;                   // [N, M, Ho, Wo]
     float* slots;               // [P][128 * 128] partial accumulator images
     unsigned* flags;            // [512] epoch flags, then one error word
+    const float* zero;          // 64 bytes of zeros (source of the LDS-DMA of padding / out-of-range elements)
     unsigned epoch;
+    unsigned long long* stamps; // optional [P][4]: wall-clock stamps of every workgroup (start, pipeline primed, loop done, end): tools only
     int K, H, W, M, Ho, Wo, relu;
     int tiles_x, tiles_y, ptiles, mtiles, nch;
-    int iters;
-    int P;
+    int iters;                  // all (tile, chunk) iterations of the layer
+    int P;                      // workgroups (one per CU)
+    int rdp, sk_iters;          // whole tiles per workgroup (rounds of P tiles), iterations of the remaining tiles (stream-K part)
 };
 
 // Compile-time geometry of a kernel family: TH x TW output pixels per tile, the LDS input patch PH rows x PWL columns per
@@ -66,19 +69,48 @@ struct SkG {
     static constexpr int NXS = (CK * CS / 4 + kSkThreads - 1) / kSkThreads;
 };
 
+template <int I, int N, typename F>
+__device__ __forceinline__ void sk_static_for(F&& f) {
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        sk_static_for<I + 1, N>(f);
+    }
+}
+
 __device__ __forceinline__ void sk_store_sc1(float* p, v4f v) {
     asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(v) : "memory");
 }
 
 // Position of the prefetch stream in the iteration space; advanced by one chunk at a time (no divisions in the loop).
+// Work of workgroup g as a sequence of "virtual" iterations v = 0 .. V - 1:
+//   v <  rdp * nch : round r = v / nch, WHOLE tile r * P + g, chunk v % nch.  In a round the 32 workgroups of an XCD hold 32
+//                    consecutive tiles (M tile fastest), i.e. a 2-D block of pixel tiles x M tiles, and walk K in step: every weight
+//                    image and every input patch they read is shared in the XCD's L2 while it is hot (contiguous tile runs per
+//                    workgroup had L2 hit rates of 11-42 % and global-load latencies of ~5 us under load);
+//   v >= rdp * nch : the remaining ntiles - rdp * P tiles, their iterations dealt to the workgroups in equal contiguous runs
+//                    (stream-K: iteration sk0(g) + (v - rdp * nch) of that space).
 struct SkCursor {
-    int chunk, mt, n, tyi, txi;
+    int v, chunk, mt, n, tyi, txi;
+    bool moved;                 // the pixel tile changed since the patch offsets were computed (sk_xoffsets clears it)
 };
 
-__device__ __forceinline__ SkCursor sk_cursor(const SkP& p, int it) {
-    SkCursor c;
-    const int tile = it / p.nch;
-    c.chunk = it - tile * p.nch;
+__device__ __forceinline__ void sk_decode(const SkP& p, int g, int sk0, int v, int& tile, int& chunk) {
+    const int vdp = p.rdp * p.nch;
+    if (v < vdp) {
+        const int r = v / p.nch;
+        chunk = v - r * p.nch;
+        tile = r * p.P + g;
+    } else {
+        const int w = v - vdp + sk0;
+        const int t = w / p.nch;
+        chunk = w - t * p.nch;
+        tile = p.rdp * p.P + t;
+    }
+}
+
+__device__ __forceinline__ void sk_locate(const SkP& p, int g, int sk0, SkCursor& c) {
+    int tile;
+    sk_decode(p, g, sk0, c.v, tile, c.chunk);
     c.mt = tile % p.mtiles;
     const int pt = tile / p.mtiles;
     const int tpi = p.tiles_x * p.tiles_y;
@@ -86,23 +118,19 @@ __device__ __forceinline__ SkCursor sk_cursor(const SkP& p, int it) {
     const int trem = pt - c.n * tpi;
     c.tyi = trem / p.tiles_x;
     c.txi = trem - c.tyi * p.tiles_x;
+    c.moved = true;
+}
+
+__device__ __forceinline__ SkCursor sk_cursor(const SkP& p, int g, int sk0, int v) {
+    SkCursor c;
+    c.v = v;
+    sk_locate(p, g, sk0, c);
     return c;
 }
 
-__device__ __forceinline__ void sk_advance(const SkP& p, SkCursor& c) {
-    if (++c.chunk == p.nch) {
-        c.chunk = 0;
-        if (++c.mt == p.mtiles) {
-            c.mt = 0;
-            if (++c.txi == p.tiles_x) {
-                c.txi = 0;
-                if (++c.tyi == p.tiles_y) {
-                    c.tyi = 0;
-                    ++c.n;
-                }
-            }
-        }
-    }
+__device__ __forceinline__ void sk_advance(const SkP& p, int g, int sk0, SkCursor& c) {
+    ++c.v;
+    if (++c.chunk == p.nch) sk_locate(p, g, sk0, c);        // next tile of the workgroup's list (once per tile)
 }
 
 // Per-thread description of its 16-byte groups of the input patch (depends on the thread only): channel, patch row / column
@@ -127,10 +155,36 @@ __device__ __forceinline__ void sk_slots(int tid, SkSlots<G::NXS>& s) {
     }
 }
 
+// Offsets of a thread's patch groups from the (picture, chunk) base of the input, and which of them lie inside the plane:
+// functions of the pixel tile only, recomputed when the prefetch stream enters a new one.  Per chunk a group then costs one
+// compare and one load from (uniform base + offset) -- the address arithmetic of the staging code competes with the partner
+// wave's MFMA issue (measured: ~3k of the 11.6k cycles of an iteration in "stage + refetch" before this).
+template <int NXS>
+struct SkXOff {
+    int off[NXS];
+    unsigned mask;
+};
+
+template <typename G>
+__device__ __forceinline__ void sk_xoffsets(const SkP& p, SkCursor& cur, const SkSlots<G::NXS>& sl, SkXOff<G::NXS>& xo) {
+    const int iy0 = cur.tyi * G::TH * G::STRIDE - G::PAD, ix0 = cur.txi * G::TW * G::STRIDE - G::PADL;
+    const int HW = p.H * p.W;
+    xo.mask = 0;
+#pragma unroll
+    for (int j = 0; j < G::NXS; ++j) {
+        const int c = sl.c[j];
+        const int iy = iy0 + (sl.rc[j] & 0xffff), ix = ix0 + (sl.rc[j] >> 16);
+        const bool ok = c >= 0 && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+        xo.off[j] = ok ? c * HW + iy * p.W + ix : 0;
+        xo.mask |= ok ? 1u << j : 0u;
+    }
+    cur.moved = false;
+}
+
 // global -> registers of the chunk at the cursor (its tile may differ from the one being multiplied: the pipeline crosses tile
 // boundaries)
 template <typename G, int TAPS, int WM, bool VEC, int NWS>
-__device__ __forceinline__ void sk_fetch(const SkP& p, const SkCursor& cur, const SkSlots<G::NXS>& sl, int tid, v4f (&wr)[NWS],
+__device__ __forceinline__ void sk_fetch(const SkP& p, SkCursor& cur, const SkSlots<G::NXS>& sl, SkXOff<G::NXS>& xo, int tid, v4f (&wr)[NWS],
                                          v4f (&xr)[G::NXS]) {
     constexpr int BM = 32 * WM, CK = G::CK, NXS = G::NXS, TW = G::TW;
     constexpr int KC = TAPS * CK;
@@ -143,18 +197,24 @@ __device__ __forceinline__ void sk_fetch(const SkP& p, const SkCursor& cur, cons
         wr[j] = (NWS * kSkThreads * 4 == BM * KC || e < BM * KC) ? *reinterpret_cast<const v4f*>(wb + e) : (v4f){0.f, 0.f, 0.f, 0.f};
     }
     // ---- input patch: CK channels x PH rows x PWL columns, 16-byte groups aligned in memory --------------------------------
-    const int iy0 = cur.tyi * G::TH * G::STRIDE - G::PAD, ix0 = cur.txi * TW * G::STRIDE - G::PADL;
     const int HW = p.H * p.W;
     const float* xb = p.x + ((size_t)cur.n * p.K + k0) * HW;
+    if constexpr (VEC) {
+        if (cur.moved) sk_xoffsets<G>(p, cur, sl, xo);
+        const int kleft = p.K - k0;
 #pragma unroll
-    for (int j = 0; j < NXS; ++j) {
-        const int c = sl.c[j];
-        const int iy = iy0 + (sl.rc[j] & 0xffff), ix = ix0 + (sl.rc[j] >> 16);
-        const bool ok = c >= 0 && k0 + c < p.K && (unsigned)iy < (unsigned)p.H;
-        const float* src = xb + (size_t)(c < 0 ? 0 : c) * HW + (long long)iy * p.W + ix;
-        if (VEC) {
-            xr[j] = (ok && (unsigned)ix < (unsigned)p.W) ? *reinterpret_cast<const v4f*>(src) : (v4f){0.f, 0.f, 0.f, 0.f};
-        } else {
+        for (int j = 0; j < NXS; ++j) {
+            const bool ok = ((xo.mask >> j) & 1u) && sl.c[j] < kleft;
+            xr[j] = ok ? *reinterpret_cast<const v4f*>(xb + xo.off[j]) : (v4f){0.f, 0.f, 0.f, 0.f};
+        }
+    } else {
+        const int iy0 = cur.tyi * G::TH * G::STRIDE - G::PAD, ix0 = cur.txi * TW * G::STRIDE - G::PADL;
+#pragma unroll
+        for (int j = 0; j < NXS; ++j) {
+            const int c = sl.c[j];
+            const int iy = iy0 + (sl.rc[j] & 0xffff), ix = ix0 + (sl.rc[j] >> 16);
+            const bool ok = c >= 0 && k0 + c < p.K && (unsigned)iy < (unsigned)p.H;
+            const float* src = xb + (size_t)(c < 0 ? 0 : c) * HW + (long long)iy * p.W + ix;
 #pragma unroll
             for (int i = 0; i < 4; ++i) xr[j][i] = (ok && (unsigned)(ix + i) < (unsigned)p.W) ? src[i] : 0.0f;
         }
@@ -179,22 +239,72 @@ __device__ __forceinline__ void sk_stage(const SkSlots<G::NXS>& sl, float* __res
         if (sl.c[j] >= 0) *reinterpret_cast<v4f*>(sX + sl.lds[j]) = xr[j];
 }
 
-template <int TAPS, int CK, int WM, int TW, int STRIDE, int DIL, bool VEC>
+// NB == 0: chunks travel global -> registers -> LDS (two LDS buffers).  NB >= 2: LDS-DMA (global_load_lds) into a ring of NB
+// buffers, NB - 1 chunks in flight, no staging registers and no LDS store instructions; padding and out-of-range elements are
+// read from a zero page; planes whose rows are not 16-byte aligned take 4-byte DMA for the input patch.
+// one slot of the staging registers: J < NWS = weight group J, else patch group J - NWS
+template <typename G, int TAPS, int WM, bool VEC, int NWS, int J>
+__device__ __forceinline__ void sk_fetch_slot(const SkP& p, const SkCursor& cur, const SkSlots<G::NXS>& sl, int tid, v4f (&wr)[NWS],
+                                              v4f (&xr)[G::NXS]) {
+    constexpr int BM = 32 * WM, CK = G::CK, TW = G::TW;
+    constexpr int KC = TAPS * CK;
+    if constexpr (J < NWS) {
+        const float* wb = p.w + ((size_t)cur.mt * p.nch + cur.chunk) * (size_t)(KC * BM);
+        const int e = (tid + J * kSkThreads) * 4;
+        wr[J] = (NWS * kSkThreads * 4 == BM * KC || e < BM * KC) ? *reinterpret_cast<const v4f*>(wb + e) : (v4f){0.f, 0.f, 0.f, 0.f};
+    } else {
+        constexpr int j = J - NWS;
+        const int k0 = cur.chunk * CK;
+        const int iy0 = cur.tyi * G::TH * G::STRIDE - G::PAD, ix0 = cur.txi * TW * G::STRIDE - G::PADL;
+        const int HW = p.H * p.W;
+        const float* xb = p.x + ((size_t)cur.n * p.K + k0) * HW;
+        const int c = sl.c[j];
+        const int iy = iy0 + (sl.rc[j] & 0xffff), ix = ix0 + (sl.rc[j] >> 16);
+        const bool ok = c >= 0 && k0 + c < p.K && (unsigned)iy < (unsigned)p.H;
+        const float* src = xb + (size_t)(c < 0 ? 0 : c) * HW + (long long)iy * p.W + ix;
+        if (VEC) {
+            xr[j] = (ok && (unsigned)ix < (unsigned)p.W) ? *reinterpret_cast<const v4f*>(src) : (v4f){0.f, 0.f, 0.f, 0.f};
+        } else {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) xr[j][i] = (ok && (unsigned)(ix + i) < (unsigned)p.W) ? src[i] : 0.0f;
+        }
+    }
+}
+
+template <typename G, int TAPS, int WM, int NWS, int J>
+__device__ __forceinline__ void sk_stage_slot(const SkSlots<G::NXS>& sl, float* __restrict__ sW, float* __restrict__ sX, int tid,
+                                              const v4f (&wr)[NWS], const v4f (&xr)[G::NXS]) {
+    constexpr int BM = 32 * WM, KC = TAPS * G::CK;
+    if constexpr (J < NWS) {
+        const int e = (tid + J * kSkThreads) * 4;
+        if (NWS * kSkThreads * 4 == BM * KC || e < BM * KC) *reinterpret_cast<v4f*>(sW + e) = wr[J];
+    } else {
+        constexpr int j = J - NWS;
+        if (sl.c[j] >= 0) *reinterpret_cast<v4f*>(sX + sl.lds[j]) = xr[j];
+    }
+}
+
+template <int TAPS, int CK, int WM, int TW, int STRIDE, int DIL, bool VEC, int NB>
 __global__ __launch_bounds__(kSkThreads) void k_conv_sk(const SkP p) {
     using G = SkG<TAPS, CK, TW, STRIDE, DIL>;
     constexpr int NXS = G::NXS, CS = G::CS, PWL = G::PWL;
+    constexpr bool DMA = NB >= 2;
     constexpr int BM = 32 * WM, BN = kSkBN;
     constexpr int NG = 8 / WM;                  // pixel groups of the 8 waves
     constexpr int TN = BN / NG / 32;            // 32-pixel accumulator tiles per wave: 2 (BM 128) / 1 (BM 64)
     constexpr int KC = TAPS * CK;
     constexpr int NQ = KC / 8;                  // groups of four k-steps per chunk
-    constexpr int QSPLIT = (3 * NQ + 3) / 4;
+    constexpr int QSPLIT = NQ;      // waves 0-3 stage after all their MFMA groups,
+    constexpr int QEARLY = 0;       // waves 4-7 before theirs
     constexpr int NWS = (BM * KC / 4 + kSkThreads - 1) / kSkThreads;
     static_assert(KC % 8 == 0 && TN >= 1, "tile");
     extern __shared__ __attribute__((aligned(16))) float sk_smem[];
-    // [2][sW: KC * BM | sX: CK * CS] then sE [2 tile parities][2][BM]
-    constexpr int bufsz = KC * BM + CK * CS;
-    float* sEbase = sk_smem + 2 * bufsz;
+    // [NBUF][sW: KC * BM | sX: CK * CS (DMA: rounded up to 1 KB pieces)] then sE [2 tile parities][2][BM], then 1 KB DMA dump
+    constexpr int NBUF = DMA ? NB : 2;
+    constexpr int XF = DMA ? ((CK * CS + 255) / 256) * 256 : CK * CS;
+    constexpr int bufsz = KC * BM + XF;
+    float* sEbase = sk_smem + NBUF * bufsz;
+    float* sDump = sEbase + 4 * BM;
     int tile_parity = 0;
 
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, l31 = lane & 31, h = lane >> 5;
@@ -202,8 +312,11 @@ __global__ __launch_bounds__(kSkThreads) void k_conv_sk(const SkP p) {
     // logical workgroup index: the workgroups of one XCD (blocks b, b + 8, ...) own one contiguous run of iterations
     const int P = p.P;
     const int g = (P % 8 == 0) ? (int)(blockIdx.x & 7) * (P >> 3) + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
-    const int it0 = (int)((long long)p.iters * g / P), it1 = (int)((long long)p.iters * (g + 1) / P);
+    const int sk0 = (int)((long long)p.sk_iters * g / P), sk1 = (int)((long long)p.sk_iters * (g + 1) / P);
+    const int vdp = p.rdp * p.nch;
+    const int it0 = 0, it1 = vdp + (sk1 - sk0);             // virtual iterations of this workgroup
     if (it0 >= it1) return;
+    if (p.stamps && tid == 0) p.stamps[4 * g] = wall_clock64();
 
     const int aBase = (h * BM + mtw * 32 + l31) * 4;
     int bBase[TN], pl[TN];
@@ -214,7 +327,7 @@ __global__ __launch_bounds__(kSkThreads) void k_conv_sk(const SkP p) {
         bBase[tn] = h * CS + ty * STRIDE * PWL + tx * STRIDE + G::PADL - G::PAD;
     }
     f32x16 acc[TN];
-    v4f wr[NWS], xr[NXS];
+    v4f wr[DMA ? 1 : NWS], xr[DMA ? 1 : NXS];
     const int HWo = p.Ho * p.Wo;
 
     // The LDS operands of a group of four k-steps (one 16-byte A read + 4 * TN B reads) are requested one whole group ahead of
@@ -223,7 +336,7 @@ __global__ __launch_bounds__(kSkThreads) void k_conv_sk(const SkP p) {
         v4f a;
         float b[4][TN];
     };
-    auto mfma_part = [&](int buf, auto QLc, auto QHc) {
+    auto mfma_part = [&](int buf, auto QLc, auto QHc, auto&& hook) {
         constexpr int qlo = decltype(QLc)::value, qhi = decltype(QHc)::value;
         const float* sW = sk_smem + buf * bufsz;
         const float* sX = sW + KC * BM;
@@ -238,10 +351,11 @@ __global__ __launch_bounds__(kSkThreads) void k_conv_sk(const SkP p) {
                 for (int tn = 0; tn < TN; ++tn) o.b[j][tn] = xrow[bBase[tn]];
             }
         };
+        if constexpr (qlo >= qhi) return;
         Group cur, nxt;
         load_group(qlo, cur);
-#pragma unroll
-        for (int q = qlo; q < qhi; ++q) {
+        sk_static_for<qlo, qhi>([&](auto qc) {
+            constexpr int q = decltype(qc)::value;
             if (q + 1 < qhi) load_group(q + 1, nxt);
             __builtin_amdgcn_sched_barrier(0);          // the next group's reads stay in front of this group's MFMAs
 #pragma unroll
@@ -249,59 +363,174 @@ __global__ __launch_bounds__(kSkThreads) void k_conv_sk(const SkP p) {
 #pragma unroll
                 for (int tn = 0; tn < TN; ++tn) acc[tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(cur.a[j], cur.b[j][tn], acc[tn], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
+            hook(qc);                                   // staging work that rides in the shadow of this group's MFMAs
+            __builtin_amdgcn_sched_barrier(0);
             if (q + 1 < qhi) cur = nxt;
-        }
+        });
     };
+    auto no_hook = [](auto) {};
 
     int buf = 0;
-    SkSlots<NXS> slots;
-    sk_slots<G>(tid, slots);
-    // Prefetch depth.  One iteration of the 1x1 kernel needs 64 KB per CU and lasts ~3.4 us at the MFMA rate; a global load takes
-    // ~5 us under that load, so ONE chunk in flight (64 KB of staging registers) runs the loop at the memory latency.
-    //   DEEP (1x1, stride 1): two register sets, chunk it + 2 is requested at the start of iteration it (two iterations to arrive);
-    //   otherwise: the set that carried chunk it + 1 to LDS is refilled with chunk it + 2 right behind that store (one iteration).
-    constexpr bool DEEP = false;        // (two sets for the 1x1 kernel: 45 VGPRs spilled at the 256-register budget of 2 waves/SIMD)
-    v4f wr1[DEEP ? NWS : 1], xr1[DEEP ? NXS : 1];
-    SkCursor pre = sk_cursor(p, it0);           // the chunk the prefetch stream is at
-    sk_fetch<G, TAPS, WM, VEC, NWS>(p, pre, slots, tid, wr, xr);
-    sk_stage<G, TAPS, WM, NWS>(slots, sk_smem, sk_smem + KC * BM, tid, wr, xr);
-    if (it0 + 1 < it1) {
-        sk_advance(p, pre);
-        if constexpr (DEEP) sk_fetch<G, TAPS, WM, VEC, NWS>(p, pre, slots, tid, wr1, xr1);
-        else sk_fetch<G, TAPS, WM, VEC, NWS>(p, pre, slots, tid, wr, xr);
-    }
-    __syncthreads();
-
-    // DEEP: `fill` receives chunk it + 2, `ready` (requested one iteration ago) goes to the other LDS buffer
-    auto iteration_deep = [&](int it, auto& fw, auto& fx, const auto& rw, const auto& rx) {
-        if (it + 2 < it1) {
-            sk_advance(p, pre);
-            sk_fetch<G, TAPS, WM, VEC, NWS>(p, pre, slots, tid, fw, fx);
-        }
-        mfma_part(buf, std::integral_constant<int, 0>{}, std::integral_constant<int, QSPLIT>{});
-        if (it + 1 < it1) {
-            float* nW = sk_smem + (buf ^ 1) * bufsz;
-            sk_stage<G, TAPS, WM, NWS>(slots, nW, nW + KC * BM, tid, rw, rx);
-        }
-        mfma_part(buf, std::integral_constant<int, QSPLIT>{}, std::integral_constant<int, NQ>{});
-        __syncthreads();
-        buf ^= 1;
-    };
-    auto iteration = [&](int it) {
-        if constexpr (DEEP) {
-            if (((it - it0) & 1) == 0) iteration_deep(it, wr, xr, wr1, xr1);       // chunk it came from set 0: refill it, stage set 1
-            else iteration_deep(it, wr1, xr1, wr, xr);
-        } else {
-            mfma_part(buf, std::integral_constant<int, 0>{}, std::integral_constant<int, QSPLIT>{});
-            if (it + 1 < it1) {
-                float* nW = sk_smem + (buf ^ 1) * bufsz;
-                sk_stage<G, TAPS, WM, NWS>(slots, nW, nW + KC * BM, tid, wr, xr);
-                if (it + 2 < it1) {
-                    sk_advance(p, pre);
-                    sk_fetch<G, TAPS, WM, VEC, NWS>(p, pre, slots, tid, wr, xr);
+    // ---- LDS-DMA pipeline (NB >= 2) ------------------------------------------------------------------------------------------
+    // per wave and chunk: PWW pieces of the weight image + PXW pieces of the input patch, every wave the same count (pieces
+    // past the end go zero page -> dump area), so one counted s_waitcnt retires exactly one chunk
+    constexpr int WPIECES = KC * BM / 256;                      // 1 KB pieces of the weight image
+    constexpr int PWW = (WPIECES + 7) / 8;
+    constexpr int XPIECES = VEC ? XF / 256 : XF / 64;           // 1 KB (16-byte lanes) or 256-byte (4-byte lanes) pieces
+    constexpr int PXW = (XPIECES + 7) / 8;
+    constexpr int PT = PWW + PXW;
+    constexpr int DEPTH = DMA ? NB - 1 : 1;                     // chunks in flight
+    static_assert(!DMA || (DEPTH - 1) * PT <= 63, "vmcnt");
+    SkCursor pre = sk_cursor(p, g, sk0, it0);
+    int pre_it = it0;
+    auto dma_chunk = [&](int target, int nb) {
+        if constexpr (DMA) {
+            const bool real = target < it1;
+            if (real)
+                while (pre_it < target) {
+                    sk_advance(p, g, sk0, pre);
+                    ++pre_it;
+                }
+            float* bW = sk_smem + nb * bufsz;
+            float* bX = bW + KC * BM;
+            const float* wb = p.w + ((size_t)pre.mt * p.nch + pre.chunk) * (size_t)(KC * BM);
+#pragma unroll
+            for (int j = 0; j < PWW; ++j) {
+                const int piece = wave + 8 * j;                              // wave-uniform
+                const bool ok = real && piece < WPIECES;
+                const float* g = ok ? wb + piece * 256 + lane * 4 : p.zero;
+                float* l = ok ? bW + piece * 256 : sDump;
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g, (__attribute__((address_space(3))) void*)l, 16, 0, 0);
+            }
+            const int k0 = pre.chunk * CK;
+            const int iy0 = pre.tyi * G::TH * STRIDE - G::PAD, ix0 = pre.txi * TW * STRIDE - G::PADL;
+            const int HW = p.H * p.W;
+            const float* xb = p.x + ((size_t)pre.n * p.K + k0) * HW;
+#pragma unroll
+            for (int j = 0; j < PXW; ++j) {
+                const int piece = wave + 8 * j;
+                const bool pok = real && piece < XPIECES;
+                if constexpr (VEC) {
+                    constexpr int f4r = PWL >> 2, f4c = G::PH * f4r;
+                    const int f = piece * 64 + lane;
+                    const int c = f / f4c, rem = f - c * f4c;
+                    const int row = rem / f4r, col = (rem - row * f4r) * 4;
+                    const int iy = iy0 + row, ix = ix0 + col;
+                    const bool ok = pok && f < CK * f4c && k0 + c < p.K && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+                    const float* g = ok ? xb + (size_t)c * HW + (long long)iy * p.W + ix : p.zero;
+                    float* l = pok ? bX + piece * 256 : sDump;
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g, (__attribute__((address_space(3))) void*)l, 16, 0, 0);
+                } else {
+                    const int f = piece * 64 + lane;                         // element of the patch image [CK][PH][PWL]
+                    const int c = f / CS, rem = f - c * CS;
+                    const int row = rem / PWL, col = rem - row * PWL;
+                    const int iy = iy0 + row, ix = ix0 + col;
+                    const bool ok = pok && f < CK * CS && k0 + c < p.K && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+                    const float* g = ok ? xb + (size_t)c * HW + (long long)iy * p.W + ix : p.zero;
+                    float* l = pok ? bX + piece * 64 : sDump;
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g, (__attribute__((address_space(3))) void*)l, 4, 0, 0);
                 }
             }
-            mfma_part(buf, std::integral_constant<int, QSPLIT>{}, std::integral_constant<int, NQ>{});
+        }
+    };
+    // wait until all but the (DEPTH - 1) youngest chunks of this wave have landed, then meet the other waves
+    auto dma_publish = [&]() {
+        if constexpr (DMA) {
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"((DEPTH - 1) * PT) : "memory");
+            __syncthreads();
+        }
+    };
+    // ---- register-staged pipeline (NB == 0) -------------------------------------------------------------------------------------
+    // The registers that carried chunk it + 1 to LDS are refilled with chunk it + 2 right behind that store, three quarters into
+    // iteration it: a load then has a whole iteration to arrive.  (One chunk in flight = 64 KB of staging registers per CU for the
+    // 1x1 kernel; at ~5 us per global load under load the loop runs at the memory latency, not at the 3.4 us of its MFMAs -- the
+    // reason for the LDS-DMA form.  Two register sets spilled 45 VGPRs at the 256-register budget of two waves per SIMD.)
+    SkSlots<NXS> slots;
+    SkXOff<NXS> xoff;
+    if constexpr (!DMA) {
+        sk_slots<G>(tid, slots);
+        sk_fetch<G, TAPS, WM, VEC, NWS>(p, pre, slots, xoff, tid, wr, xr);
+        sk_stage<G, TAPS, WM, NWS>(slots, sk_smem, sk_smem + KC * BM, tid, wr, xr);
+        if (it0 + 1 < it1) {
+            sk_advance(p, g, sk0, pre);
+            sk_fetch<G, TAPS, WM, VEC, NWS>(p, pre, slots, xoff, tid, wr, xr);
+        }
+        __syncthreads();
+    } else {
+#pragma unroll
+        for (int d = 0; d < DEPTH; ++d) dma_chunk(it0 + d, d);
+        dma_publish();                          // chunk it0 has landed everywhere
+    }
+
+    if (p.stamps && tid == 0) p.stamps[4 * g + 1] = wall_clock64();
+#ifdef SK_PHASE_STAMPS
+    unsigned long long t0_phase = __builtin_readcyclecounter();
+#endif
+    auto iteration = [&](int it) {
+        if constexpr (DMA) {
+            // the buffer that held chunk it - 1 (all its readers are behind the last barrier) receives chunk it + DEPTH
+            int nb = buf + DEPTH;
+            if (nb >= NBUF) nb -= NBUF;
+            dma_chunk(it + DEPTH, nb);
+            mfma_part(buf, std::integral_constant<int, 0>{}, std::integral_constant<int, NQ>{}, no_hook);
+            dma_publish();                      // chunk it + 1 has landed; (DEPTH - 1) younger ones stay in flight
+            buf = buf + 1 == NBUF ? 0 : buf + 1;
+        } else {
+            // (Spreading the stores / refills slot by slot behind the MFMA groups was tried: hipcc then waits vmcnt(0) in front of
+            // every slot's LDS store -- its counter bookkeeping does not survive the loop back edge -- which stalls on the refill issued
+            // one group earlier; the burst form below waits once, for loads that are a whole iteration old.)
+            // The two waves of a SIMD are COMPLEMENTARY: waves 0-3 (the older ones: the matrix pipe serves them first, the
+            // younger wave gets almost nothing meanwhile) multiply first and stage + refetch afterwards; waves 4-7 stage + refetch
+            // first and multiply afterwards, so each wave's memory phase sits beside its partner's MFMAs.  With both staging at 3/4
+            // the older wave ran ahead, staged, finished and idled ~2.8k cycles at the barrier while the younger one staged alone
+            // (in-kernel stamps: 11.6k cycles per iteration for 8.2k of MFMAs).
+#ifdef SK_PHASE_STAMPS
+            unsigned long long t1 = 0, t1b = 0, t2 = 0;
+#endif
+            auto body = [&](auto QS) {
+                constexpr int qs = decltype(QS)::value;
+                mfma_part(buf, std::integral_constant<int, 0>{}, std::integral_constant<int, qs>{}, no_hook);
+#ifdef SK_PHASE_STAMPS
+                t1 = __builtin_readcyclecounter();
+#endif
+                // the memory phase runs at raised priority: beside an older partner that issues MFMAs back to back the younger wave's
+                // stores and loads were served only in leftover issue slots (4-5k cycles for ~80 instructions, in-kernel stamps)
+                __builtin_amdgcn_s_setprio(3);
+#ifdef SK_PHASE_STAMPS
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                t1b = __builtin_readcyclecounter();
+#endif
+                if (it + 1 < it1) {
+                    float* nW = sk_smem + (buf ^ 1) * bufsz;
+                    sk_stage<G, TAPS, WM, NWS>(slots, nW, nW + KC * BM, tid, wr, xr);
+#ifdef SK_PHASE_STAMPS
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#endif
+                    if (it + 2 < it1) {
+                        sk_advance(p, g, sk0, pre);
+                        sk_fetch<G, TAPS, WM, VEC, NWS>(p, pre, slots, xoff, tid, wr, xr);
+                    }
+                }
+                __builtin_amdgcn_s_setprio(0);
+#ifdef SK_PHASE_STAMPS
+                t2 = __builtin_readcyclecounter();
+#endif
+                mfma_part(buf, std::integral_constant<int, qs>{}, std::integral_constant<int, NQ>{}, no_hook);
+            };
+            if (wave < 4) body(std::integral_constant<int, QSPLIT>{});
+            else body(std::integral_constant<int, QEARLY>{});
+#ifdef SK_PHASE_STAMPS
+            const unsigned long long t3 = __builtin_readcyclecounter();
+            __syncthreads();
+            const unsigned long long t4 = __builtin_readcyclecounter();
+            if (p.stamps && lane == 0 && g == 7) {
+                unsigned long long* ph = p.stamps + 2048 + wave * 8;
+                ph[0] += t1 - t0_phase; ph[1] += t2 - t1; ph[2] += t3 - t2; ph[3] += t4 - t3; ph[4] += 1; ph[5] += t1b - t1;
+            }
+            t0_phase = t4;
+            buf ^= 1;
+            return;
+#endif
             __syncthreads();
             buf ^= 1;
         }
@@ -309,10 +538,10 @@ __global__ __launch_bounds__(kSkThreads) void k_conv_sk(const SkP p) {
 
     int it = it0;
     while (it < it1) {
-        const int tile = it / p.nch;
-        const int c0 = it - tile * p.nch;
+        int tile, c0;
+        sk_decode(p, g, sk0, it, tile, c0);
         const int left = it1 - it;
-        const int c1 = (left < p.nch - c0) ? c0 + left : p.nch;
+        const int c1 = (left < p.nch - c0) ? c0 + left : p.nch;        // (whole tiles: c0 = 0, c1 = nch)
         const int mt = tile % p.mtiles, pt = tile / p.mtiles;
         const int m0 = mt * BM;
         // epilogue constants of this tile; the buffer alternates per tile: slower waves may still read the previous tile's
@@ -347,10 +576,11 @@ __global__ __launch_bounds__(kSkThreads) void k_conv_sk(const SkP p) {
         }
         if (!last) {
             // finisher: add the slots of the workgroups that own the rest of this tile, in chunk order
-            const int tile_end = (tile + 1) * p.nch;
+            const int tile_end = (tile - p.rdp * P + 1) * p.nch;        // in the iteration space of the stream-K tiles
             for (int gg = g + 1; gg < P; ++gg) {
-                const int b0 = (int)((long long)p.iters * gg / P);
+                const int b0 = (int)((long long)p.sk_iters * gg / P), b1 = (int)((long long)p.sk_iters * (gg + 1) / P);
                 if (b0 >= tile_end) break;
+                if (b1 == b0) continue;                     // (a workgroup without stream-K iterations contributes nothing)
                 if (wave == 0) {
                     unsigned spins = 0;
                     while (__hip_atomic_load((gu32*)(p.flags + gg), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != p.epoch) {
@@ -409,7 +639,9 @@ __global__ __launch_bounds__(kSkThreads) void k_conv_sk(const SkP p) {
                 }
             }
         }
+        if (p.stamps && tid == 0 && it >= it1) p.stamps[4 * g + 2] = wall_clock64();
     }
+    if (p.stamps && tid == 0) p.stamps[4 * g + 3] = wall_clock64();
 }
 
 // One thread per element of the packed image [mtiles][nch][KC / 8][2][BM][4]:
@@ -490,6 +722,9 @@ inline void sk_geom(int ksize, int stride, int M, int Wo, SkGeom* g) {
     g->TH = kSkBN / g->TW;
 }
 
+unsigned long long* g_sk_stamps = nullptr;       // tools: device buffer [512][4] for per-workgroup wall-clock stamps (mas_conv_sk_debug_stamps)
+int g_sk_dma = 0;        // 0: register-staged chunks (default: measured 3-5 % faster); 1: LDS-DMA ring (kept, tested, for A/B measurements)
+
 int sk_num_cus() {
     static int cus[64] = {};
     int dev = 0;
@@ -501,12 +736,13 @@ int sk_num_cus() {
     return cus[dev];
 }
 
-template <int TAPS, int CK, int WM, int TW, int STRIDE, int DIL, bool VEC>
+template <int TAPS, int CK, int WM, int TW, int STRIDE, int DIL, bool VEC, int NB>
 int sk_launch(const SkP& p, hipStream_t st) {
     using G = SkG<TAPS, CK, TW, STRIDE, DIL>;
-    constexpr size_t smem = sizeof(float) * (2 * ((size_t)TAPS * CK * 32 * WM + (size_t)CK * G::CS) + 4 * 32 * WM);
+    constexpr int XF = NB >= 2 ? ((CK * G::CS + 255) / 256) * 256 : CK * G::CS;
+    constexpr size_t smem = sizeof(float) * ((NB >= 2 ? NB : 2) * ((size_t)TAPS * CK * 32 * WM + XF) + 4 * 32 * WM + 256);
     static_assert(smem <= 160 * 1024, "LDS");
-    auto kern = &k_conv_sk<TAPS, CK, WM, TW, STRIDE, DIL, VEC>;
+    auto kern = &k_conv_sk<TAPS, CK, WM, TW, STRIDE, DIL, VEC, NB>;
     if (smem > 64 * 1024) {
         static bool raised[64] = {};
         int dev = 0;
@@ -522,11 +758,11 @@ int sk_launch(const SkP& p, hipStream_t st) {
     return mas_launch_status();
 }
 
-template <int TAPS, int CK, int STRIDE, int DIL>
+template <int TAPS, int CK, int STRIDE, int DIL, int NB>
 int sk_dispatch(const SkP& p, const SkGeom& g, bool vec, hipStream_t st) {
 #define SK_TW(TW)                                                                                                                 \
-    (g.BM == 128 ? (vec ? sk_launch<TAPS, CK, 4, TW, STRIDE, DIL, true>(p, st) : sk_launch<TAPS, CK, 4, TW, STRIDE, DIL, false>(p, st)) \
-                 : (vec ? sk_launch<TAPS, CK, 2, TW, STRIDE, DIL, true>(p, st) : sk_launch<TAPS, CK, 2, TW, STRIDE, DIL, false>(p, st)))
+    (g.BM == 128 ? (vec ? sk_launch<TAPS, CK, 4, TW, STRIDE, DIL, true, NB>(p, st) : sk_launch<TAPS, CK, 4, TW, STRIDE, DIL, false, NB>(p, st)) \
+                 : (vec ? sk_launch<TAPS, CK, 2, TW, STRIDE, DIL, true, NB>(p, st) : sk_launch<TAPS, CK, 2, TW, STRIDE, DIL, false, NB>(p, st)))
     return g.TW == 32 ? SK_TW(32) : SK_TW(16);
 #undef SK_TW
 }
@@ -601,6 +837,8 @@ extern "C" int mas_conv_sk(const float* x, const float* w, int N, int Cin, int H
     p.x = x; p.w = w; p.scale = scale; p.shift = shift; p.res = residual; p.y = y;
     p.slots = static_cast<float*>(workspace);
     p.flags = reinterpret_cast<unsigned*>(static_cast<char*>(workspace) + (size_t)512 * kSkSlotFloats * sizeof(float));
+    p.stamps = g_sk_stamps;
+    p.zero = reinterpret_cast<const float*>(p.flags + 768);     // bytes 3072.. of the tail: zero-filled by the caller, never written
     p.epoch = epoch;
     p.relu = relu;
     p.H = H; p.W = W;
@@ -624,16 +862,47 @@ extern "C" int mas_conv_sk(const float* x, const float* w, int N, int Cin, int H
     const int cus = sk_num_cus();
     p.P = (int)(p.iters < cus ? p.iters : cus);
     if (p.P > 512) p.P = 512;
+    const int ntiles = p.ptiles * p.mtiles;
+    p.rdp = ntiles / p.P;
+    p.sk_iters = (ntiles - p.rdp * p.P) * p.nch;
     // 16-byte global loads: the weight rows and the planes must keep 16-byte groups whole and aligned
     if ((uintptr_t)w % 16 != 0) return MAS_ERR_ALIGN;
     const bool vec = ((uintptr_t)x % 16 == 0) && (W % 4 == 0);     // 16-byte loads of the input patch: whole, aligned groups
     // (forward and input gradient are the same kernel: the role lives in the packed weight image)
+    const bool dma = g_sk_dma != 0;
     if (ksize == 3) {
-        if (stride == 2) return sk_dispatch<9, 8, 2, 1>(p, g, vec, st);
-        if (dil == 4) return sk_dispatch<9, 8, 1, 4>(p, g, vec, st);
-        return dil == 1 ? sk_dispatch<9, 8, 1, 1>(p, g, vec, st) : sk_dispatch<9, 8, 1, 2>(p, g, vec, st);
+        if (stride == 2) return dma ? sk_dispatch<9, 8, 2, 1, 2>(p, g, vec, st) : sk_dispatch<9, 8, 2, 1, 0>(p, g, vec, st);
+        if (dil == 4) return dma ? sk_dispatch<9, 8, 1, 4, 2>(p, g, vec, st) : sk_dispatch<9, 8, 1, 4, 0>(p, g, vec, st);
+        if (dil == 2) return dma ? sk_dispatch<9, 8, 1, 2, 3>(p, g, vec, st) : sk_dispatch<9, 8, 1, 2, 0>(p, g, vec, st);
+        return dma ? sk_dispatch<9, 8, 1, 1, 3>(p, g, vec, st) : sk_dispatch<9, 8, 1, 1, 0>(p, g, vec, st);
     }
-    return stride == 2 ? sk_dispatch<1, 16, 2, 1>(p, g, vec, st) : sk_dispatch<1, 64, 1, 1>(p, g, vec, st);
+    if (stride == 2) return dma ? sk_dispatch<1, 16, 2, 1, 3>(p, g, vec, st) : sk_dispatch<1, 16, 2, 1, 0>(p, g, vec, st);
+    if (dma) {
+        // the 1x1 image of a 64-channel chunk is two 32-channel images back to back: the DMA kernel walks it in 32-channel
+        // chunks (four 32 KB buffers, three chunks in flight)
+        SkP q = p;
+        q.nch = p.nch * 2;
+        q.iters = p.iters * 2;
+        if ((long long)p.iters * 2 > 0x7fffffffLL) return MAS_ERR_SHAPE;
+        q.P = (int)(q.iters < cus ? q.iters : cus);
+        q.rdp = ntiles / q.P;
+        q.sk_iters = (ntiles - q.rdp * q.P) * q.nch;
+        return sk_dispatch<1, 32, 1, 1, 4>(q, g, vec, st);
+    }
+    return sk_dispatch<1, 64, 1, 1, 0>(p, g, vec, st);
+}
+
+/* tools only: per-workgroup wall-clock stamps (100 MHz) of the following mas_conv_sk launches into `stamps_dev` [512][4] u64
+ * (start, pipeline primed, last tile done, end), indexed by the logical workgroup; NULL switches it off */
+extern "C" int mas_conv_sk_debug_stamps(void* stamps_dev) {
+    g_sk_stamps = static_cast<unsigned long long*>(stamps_dev);
+    return 0;
+}
+
+extern "C" int mas_conv_sk_set_mode(int dma) {
+    const int old = g_sk_dma;
+    if (dma == 0 || dma == 1) g_sk_dma = dma;
+    return old;
 }
 
 /* error word of the last launches on this workspace: non-zero = a bounded spin gave up (host-side read, for tests) */

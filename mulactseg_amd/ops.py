@@ -1214,6 +1214,11 @@ def conv_sk(x, w, stride=1, dil=1, dgrad=False, scale=None, shift=None, residual
     return y
 
 
+def conv_sk_set_mode(dma):
+    """Chunk staging of mas_conv_sk, process-wide: False = register-staged (default), True = LDS-DMA ring; returns the previous mode."""
+    return bool(_lib.load().mas_conv_sk_set_mode(int(bool(dma))))
+
+
 def conv_sk_error(dev=None):
     """Non-zero when a stream-K launch on the current stream's workspace gave up waiting for another workgroup (synchronises)."""
     import ctypes

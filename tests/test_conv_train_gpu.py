@@ -82,13 +82,22 @@ def test_wgrad_exact_on_integers():
         assert torch.equal(dw.double(), ref), (Cin, Cout, k, stride, dil)
 
 
-@pytest.mark.parametrize("Cin,Cout,k,stride,dil,N,H,W", CASES)
-@pytest.mark.parametrize("epi", ["bare", "scale_res_relu"])
-def test_stream_k_forward_and_input_gradient(Cin, Cout, k, stride, dil, N, H, W, epi):
-    """mas_conv_sk in both roles against float64 conv2d / its autograd, with and without the epilogue, on shapes whose tiles
-    straddle workgroups (every case: iterations are dealt in equal runs to 256 workgroups)."""
+@pytest.fixture(params=["dma", "registers"])
+def sk_mode(request):
+    """Both chunk-staging forms of mas_conv_sk: the register-staged one (default) and the LDS-DMA ring."""
     if not torch.cuda.is_available():
         pytest.skip("needs a GPU")
+    from mulactseg_amd import ops
+    old = ops.conv_sk_set_mode(request.param == "dma")
+    yield request.param
+    ops.conv_sk_set_mode(old)
+
+
+@pytest.mark.parametrize("Cin,Cout,k,stride,dil,N,H,W", CASES)
+@pytest.mark.parametrize("epi", ["bare", "scale_res_relu"])
+def test_stream_k_forward_and_input_gradient(Cin, Cout, k, stride, dil, N, H, W, epi, sk_mode):
+    """mas_conv_sk in both roles against float64 conv2d / its autograd, with and without the epilogue, on shapes whose tiles
+    straddle workgroups (every case: iterations are dealt in equal runs to 256 workgroups)."""
     from mulactseg_amd import ops
     torch.manual_seed(Cin * 5 + Cout + 13 * k + stride + dil + W)
     x = torch.randn(N, Cin, H, W, device='cuda')
@@ -113,16 +122,16 @@ def test_stream_k_forward_and_input_gradient(Cin, Cout, k, stride, dil, N, H, W,
     assert ops.conv_sk_error() == 0
 
 
-def test_stream_k_exact_on_integers_at_layer_sizes():
+def test_stream_k_exact_on_integers_at_layer_sizes(sk_mode):
     """Integer data (exact in f32 in any order) at the plane sizes of the deep layers, where every tile is shared by two or three
-    workgroups: operand lane maps, the weight scatter from PyTorch's layout in both roles, tap mirroring, the slot hand-off."""
-    if not torch.cuda.is_available():
-        pytest.skip("needs a GPU")
+    workgroups: operand lane maps, the packed weight images of both roles, tap mirroring, the slot hand-off, the DMA ring (odd
+    planes included: 4-byte DMA)."""
     from mulactseg_amd import ops
     g = torch.Generator(device='cuda').manual_seed(9)
     for Cin, Cout, k, stride, dil, N, H, W in ((1024, 256, 1, 1, 1, 4, 48, 48), (256, 256, 3, 1, 1, 4, 48, 48), (512, 512, 3, 1, 2, 2, 48, 48),
                                               (64, 64, 3, 1, 1, 1, 96, 96), (128, 128, 3, 2, 1, 2, 64, 96), (256, 512, 1, 2, 1, 2, 64, 64),
-                                              (304, 256, 1, 1, 1, 1, 64, 64), (256, 48, 1, 1, 1, 1, 64, 64)):
+                                              (304, 256, 1, 1, 1, 1, 64, 64), (256, 48, 1, 1, 1, 1, 64, 64), (256, 256, 3, 1, 1, 2, 49, 49),
+                                              (512, 128, 1, 1, 1, 2, 97, 97), (64, 64, 3, 2, 1, 1, 97, 97)):
         x = torch.randint(-2, 3, (N, Cin, H, W), generator=g, device='cuda').float()
         w = torch.randint(-2, 3, (Cout, Cin, k, k), generator=g, device='cuda').float()
         Ho, Wo = (H - 1) // stride + 1, (W - 1) // stride + 1
