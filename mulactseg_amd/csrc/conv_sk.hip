@@ -47,6 +47,7 @@ struct SkP {
     unsigned epoch;
     unsigned long long* stamps; // optional [P][4]: wall-clock stamps of every workgroup (start, pipeline primed, loop done, end): tools only
     int K, H, W, M, Ho, Wo, relu;
+    int Wy, HWy, os, oy_off, ox_off;    // where tile pixel (oy, ox) lands in the output plane: row oy * os + oy_off of Wy columns, HWy per channel
     int tiles_x, tiles_y, ptiles, mtiles, nch;
     int iters;                  // all (tile, chunk) iterations of the layer
     int P;                      // workgroups (one per CU)
@@ -56,17 +57,23 @@ struct SkP {
 // Compile-time geometry of a kernel family: TH x TW output pixels per tile, the LDS input patch PH rows x PWL columns per
 // channel (PWL a multiple of 4, PADL columns of halo on the left so that 16-byte groups stay aligned in memory), channel
 // stride CS.  With these fixed, every LDS operand address of the multiply loop is one base register + an immediate.
-template <int TAPS, int CK_, int TW_, int STRIDE_, int DIL_>
+// SUB != 0: one parity class (py, px) = (SUB >> 1, SUB & 1) of the input gradient of a stride-2 3x3 convolution, as a stride-1
+// product over the dY plane with (1 + py) x (1 + px) taps at offsets {0, 1} (dX[2i + 1] takes dY[i] through weight row 2 and
+// dY[i + 1] through row 0; dX[2i] takes dY[i] through row 1): no padding on the left / top, the patch starts at the tile.
+template <int TAPS, int CK_, int TW_, int STRIDE_, int DIL_, int SUB_ = 0>
 struct SkG {
-    static constexpr int CK = CK_, TW = TW_, STRIDE = STRIDE_, DIL = DIL_;
+    static constexpr int CK = CK_, TW = TW_, STRIDE = STRIDE_, DIL = DIL_, SUB = SUB_;
+    static constexpr int TR = SUB ? 1 + (SUB >> 1) : (TAPS == 9 ? 3 : 1), TC = SUB ? 1 + (SUB & 1) : (TAPS == 9 ? 3 : 1);
+    static_assert(TR * TC == TAPS && (SUB == 0 || (STRIDE == 1 && DIL == 1)), "tap geometry");
     static constexpr int TH = kSkBN / TW;
     static constexpr int TWLOG = TW == 32 ? 5 : 4;
-    static constexpr int PAD = TAPS == 9 ? DIL : 0;
-    static constexpr int PADL = TAPS == 9 ? 4 : 0;
-    static constexpr int PH = (TH - 1) * STRIDE + 1 + 2 * PAD;
-    static constexpr int PWL = ((TW - 1) * STRIDE + 1 + 2 * PADL + 3) & ~3;
+    static constexpr int PAD = (TAPS == 9 && !SUB) ? DIL : 0;
+    static constexpr int PADL = (TAPS == 9 && !SUB) ? 4 : 0;
+    static constexpr int PH = SUB ? TH + TR - 1 : (TH - 1) * STRIDE + 1 + 2 * PAD;
+    static constexpr int PWL = SUB ? (TW + TC - 1 + 3) & ~3 : ((TW - 1) * STRIDE + 1 + 2 * PADL + 3) & ~3;
     static constexpr int CS = PH * PWL;
     static constexpr int NXS = (CK * CS / 4 + kSkThreads - 1) / kSkThreads;
+    static constexpr int toff(int tap) { return ((tap / TC) * PWL + (tap % TC)) * DIL; }
 };
 
 template <int I, int N, typename F>
@@ -284,9 +291,9 @@ __device__ __forceinline__ void sk_stage_slot(const SkSlots<G::NXS>& sl, float* 
     }
 }
 
-template <int TAPS, int CK, int WM, int TW, int STRIDE, int DIL, bool VEC, int NB>
+template <int TAPS, int CK, int WM, int TW, int STRIDE, int DIL, bool VEC, int NB, int SUB = 0>
 __global__ __launch_bounds__(kSkThreads) void k_conv_sk(const SkP p) {
-    using G = SkG<TAPS, CK, TW, STRIDE, DIL>;
+    using G = SkG<TAPS, CK, TW, STRIDE, DIL, SUB>;
     constexpr int NXS = G::NXS, CS = G::CS, PWL = G::PWL;
     constexpr bool DMA = NB >= 2;
     constexpr int BM = 32 * WM, BN = kSkBN;
@@ -328,7 +335,7 @@ __global__ __launch_bounds__(kSkThreads) void k_conv_sk(const SkP p) {
     }
     f32x16 acc[TN];
     v4f wr[DMA ? 1 : NWS], xr[DMA ? 1 : NXS];
-    const int HWo = p.Ho * p.Wo;
+    const int HWo = p.HWy;
 
     // The LDS operands of a group of four k-steps (one 16-byte A read + 4 * TN B reads) are requested one whole group ahead of
     // the MFMAs that consume them: the two waves of a SIMD run the same phase, so nothing else hides an LDS round trip.
@@ -345,7 +352,7 @@ __global__ __launch_bounds__(kSkThreads) void k_conv_sk(const SkP p) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const int kk = 4 * q + j, tap = kk / (CK / 2), cp = kk - tap * (CK / 2);
-                const int toff = (TAPS == 1) ? 0 : ((tap / 3) * PWL + (tap % 3)) * DIL;
+                const int toff = G::toff(tap);
                 const float* xrow = sX + 2 * cp * CS + toff;
 #pragma unroll
                 for (int tn = 0; tn < TN; ++tn) o.b[j][tn] = xrow[bBase[tn]];
@@ -618,7 +625,7 @@ __global__ __launch_bounds__(kSkThreads) void k_conv_sk(const SkP p) {
         for (int tn = 0; tn < TN; ++tn) {
             const int oy = oy0 + (pl[tn] >> G::TWLOG), ox = ox0 + (pl[tn] & (TW - 1));
             const bool inside = oy < p.Ho && ox < p.Wo;
-            const int po = inside ? oy * p.Wo + ox : 0;
+            const int po = inside ? (oy * p.os + p.oy_off) * p.Wy + ox * p.os + p.ox_off : 0;
             const int mb = mtw * 32 + 4 * h;
             float rv[16];
             if (rb) {
@@ -644,6 +651,18 @@ __global__ __launch_bounds__(kSkThreads) void k_conv_sk(const SkP p) {
     if (p.stamps && tid == 0) p.stamps[4 * g + 3] = wall_clock64();
 }
 
+// Element of the weight tensor behind (row, kc, tap) of a packed image.  mode 0: forward; 1: input gradient at stride 1 (channel
+// axes swapped, taps mirrored); 2 + SUB: parity class SUB of the input gradient of a stride-2 3x3 convolution -- tap (a, b) of
+// its (1 + py) x (1 + px) window reads weight row (py ? (a ? 0 : 2) : 1), column (px ? (b ? 0 : 2) : 1).
+__device__ __forceinline__ float sk_pack_elem(const float* __restrict__ w, int Cout, int Cin, int taps, int mode, int row, int kc, int tap) {
+    if (mode == 0) return (row < Cout && kc < Cin) ? w[((size_t)row * Cin + kc) * taps + tap] : 0.0f;
+    if (mode == 1) return (row < Cin && kc < Cout) ? w[((size_t)kc * Cin + row) * taps + (taps - 1 - tap)] : 0.0f;
+    const int py = (mode - 2) >> 1, px = (mode - 2) & 1;
+    const int a = tap / (1 + px), b = tap - a * (1 + px);
+    const int r = py ? (a ? 0 : 2) : 1, c = px ? (b ? 0 : 2) : 1;
+    return (row < Cin && kc < Cout) ? w[((size_t)kc * Cin + row) * 9 + r * 3 + c] : 0.0f;
+}
+
 // One thread per element of the packed image [mtiles][nch][KC / 8][2][BM][4]:
 //   forward:        (mt, chunk, q, h, r, j) = w[mt * BM + r][chunk * CK + 2 cp + h][tap]
 //   input gradient: (mt, chunk, q, h, r, j) = w[chunk * CK + 2 cp + h][mt * BM + r][taps - 1 - tap]      (rows = input channels)
@@ -662,13 +681,7 @@ __global__ __launch_bounds__(256) void k_sk_pack(const float* __restrict__ w, in
     const int h = qh & 1, q = qh >> 1;
     const int kk = 4 * q + j, tap = kk / (CK / 2), cp = kk - tap * (CK / 2);
     const int row = mt * BM + r, kc = chunk * CK + 2 * cp + h;
-    float v = 0.0f;
-    if (!dgrad) {
-        if (row < Cout && kc < Cin) v = w[((size_t)row * Cin + kc) * taps + tap];
-    } else {
-        if (row < Cin && kc < Cout) v = w[((size_t)kc * Cin + row) * taps + (taps - 1 - tap)];
-    }
-    out[i] = v;
+    out[i] = sk_pack_elem(w, Cout, Cin, taps, dgrad, row, kc, tap);
 }
 
 // All weights of a network in ONE launch (after an optimizer step): job j packs tensor j into its image; blocks are dealt to the
@@ -701,22 +714,21 @@ __global__ __launch_bounds__(256) void k_sk_pack_multi(const SkPackJob* __restri
     const int h = qh & 1, q = qh >> 1;
     const int kk = 4 * q + j, tap = kk / (jb.CK / 2), cp = kk - tap * (jb.CK / 2);
     const int row = mt * jb.BM + r, kc = chunk * jb.CK + 2 * cp + h;
-    float v = 0.0f;
-    if (!jb.dgrad) {
-        if (row < jb.Cout && kc < jb.Cin) v = jb.w[((size_t)row * jb.Cin + kc) * jb.taps + tap];
-    } else {
-        if (row < jb.Cin && kc < jb.Cout) v = jb.w[((size_t)kc * jb.Cin + row) * jb.taps + (jb.taps - 1 - tap)];
-    }
-    jb.out[i] = v;
+    jb.out[i] = sk_pack_elem(jb.w, jb.Cout, jb.Cin, jb.taps, jb.dgrad, row, kc, tap);
 }
 
 struct SkGeom {
     int TAPS, CK, BM, TW, TH;
 };
 
-inline void sk_geom(int ksize, int stride, int M, int Wo, SkGeom* g) {
+// mode: 0 forward, 1 input gradient (stride 1), 2 + SUB parity class of the stride-2 3x3 input gradient (1 / 2 / 2 / 4 taps)
+inline void sk_geom(int ksize, int stride, int M, int Wo, int mode, SkGeom* g) {
     g->TAPS = ksize * ksize;
     g->CK = ksize == 3 ? 8 : (stride == 2 ? 16 : 64);       // (the stride-2 patch of a 1x1 holds 4x the pixels it uses)
+    if (mode >= 2) {
+        g->TAPS = (1 + ((mode - 2) >> 1)) * (1 + ((mode - 2) & 1));
+        g->CK = 64 / g->TAPS;                               // 64 k-rows per chunk in every class
+    }
     g->BM = M > 64 ? 128 : 64;
     g->TW = (Wo >= 32 && !(Wo % 32 != 0 && Wo % 16 == 0)) ? 32 : 16;       // 48-wide planes: three exact 16-wide tiles
     g->TH = kSkBN / g->TW;
@@ -736,13 +748,13 @@ int sk_num_cus() {
     return cus[dev];
 }
 
-template <int TAPS, int CK, int WM, int TW, int STRIDE, int DIL, bool VEC, int NB>
+template <int TAPS, int CK, int WM, int TW, int STRIDE, int DIL, bool VEC, int NB, int SUB = 0>
 int sk_launch(const SkP& p, hipStream_t st) {
-    using G = SkG<TAPS, CK, TW, STRIDE, DIL>;
+    using G = SkG<TAPS, CK, TW, STRIDE, DIL, SUB>;
     constexpr int XF = NB >= 2 ? ((CK * G::CS + 255) / 256) * 256 : CK * G::CS;
     constexpr size_t smem = sizeof(float) * ((NB >= 2 ? NB : 2) * ((size_t)TAPS * CK * 32 * WM + XF) + 4 * 32 * WM + 256);
     static_assert(smem <= 160 * 1024, "LDS");
-    auto kern = &k_conv_sk<TAPS, CK, WM, TW, STRIDE, DIL, VEC, NB>;
+    auto kern = &k_conv_sk<TAPS, CK, WM, TW, STRIDE, DIL, VEC, NB, SUB>;
     if (smem > 64 * 1024) {
         static bool raised[64] = {};
         int dev = 0;
@@ -758,11 +770,29 @@ int sk_launch(const SkP& p, hipStream_t st) {
     return mas_launch_status();
 }
 
-template <int TAPS, int CK, int STRIDE, int DIL, int NB>
+// tiles, chunks and the deal of the iterations to the workgroups (p.K, p.M, p.Ho, p.Wo set)
+inline int sk_plan(SkP& p, const SkGeom& g, int N, int cus) {
+    p.tiles_x = (p.Wo + g.TW - 1) / g.TW;
+    p.tiles_y = (p.Ho + g.TH - 1) / g.TH;
+    p.ptiles = N * p.tiles_x * p.tiles_y;
+    p.mtiles = (p.M + g.BM - 1) / g.BM;
+    p.nch = (p.K + g.CK - 1) / g.CK;
+    const long long iters = (long long)p.ptiles * p.mtiles * p.nch;
+    if (iters > 0x7fffffffLL) return MAS_ERR_SHAPE;
+    p.iters = (int)iters;
+    p.P = (int)(p.iters < cus ? p.iters : cus);
+    if (p.P > 512) p.P = 512;
+    const int ntiles = p.ptiles * p.mtiles;
+    p.rdp = ntiles / p.P;
+    p.sk_iters = (ntiles - p.rdp * p.P) * p.nch;
+    return 0;
+}
+
+template <int TAPS, int CK, int STRIDE, int DIL, int NB, int SUB = 0>
 int sk_dispatch(const SkP& p, const SkGeom& g, bool vec, hipStream_t st) {
 #define SK_TW(TW)                                                                                                                 \
-    (g.BM == 128 ? (vec ? sk_launch<TAPS, CK, 4, TW, STRIDE, DIL, true, NB>(p, st) : sk_launch<TAPS, CK, 4, TW, STRIDE, DIL, false, NB>(p, st)) \
-                 : (vec ? sk_launch<TAPS, CK, 2, TW, STRIDE, DIL, true, NB>(p, st) : sk_launch<TAPS, CK, 2, TW, STRIDE, DIL, false, NB>(p, st)))
+    (g.BM == 128 ? (vec ? sk_launch<TAPS, CK, 4, TW, STRIDE, DIL, true, NB, SUB>(p, st) : sk_launch<TAPS, CK, 4, TW, STRIDE, DIL, false, NB, SUB>(p, st)) \
+                 : (vec ? sk_launch<TAPS, CK, 2, TW, STRIDE, DIL, true, NB, SUB>(p, st) : sk_launch<TAPS, CK, 2, TW, STRIDE, DIL, false, NB, SUB>(p, st)))
     return g.TW == 32 ? SK_TW(32) : SK_TW(16);
 #undef SK_TW
 }
@@ -774,10 +804,11 @@ extern "C" size_t mas_conv_sk_workspace_bytes(void) {
 }
 
 extern "C" size_t mas_conv_sk_packed_elems(int Cin, int Cout, int ksize, int stride, int dgrad) {
-    if (Cin <= 0 || Cout <= 0 || (ksize != 1 && ksize != 3) || (stride != 1 && stride != 2)) return 0;
+    if (Cin <= 0 || Cout <= 0 || (ksize != 1 && ksize != 3) || (stride != 1 && stride != 2) || dgrad < 0 || dgrad > 5) return 0;
+    if (dgrad >= 2 && (ksize != 3 || stride != 2)) return 0;
     SkGeom g;
     const int M = dgrad ? Cin : Cout, K = dgrad ? Cout : Cin;
-    sk_geom(ksize, stride, M, 32, &g);
+    sk_geom(ksize, stride, M, 32, dgrad, &g);
     return (size_t)((M + g.BM - 1) / g.BM) * ((K + g.CK - 1) / g.CK) * (size_t)g.TAPS * g.CK * g.BM;
 }
 
@@ -787,7 +818,7 @@ extern "C" int mas_conv_sk_pack(const float* w, int Cin, int Cout, int ksize, in
     if (total == 0) return MAS_ERR_SHAPE;
     SkGeom g;
     const int M = dgrad ? Cin : Cout, K = dgrad ? Cout : Cin;
-    sk_geom(ksize, stride, M, 32, &g);
+    sk_geom(ksize, stride, M, 32, dgrad, &g);
     hipLaunchKernelGGL(k_sk_pack, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream), w, Cout, Cin, g.TAPS,
                        g.CK, g.BM, (M + g.BM - 1) / g.BM, (K + g.CK - 1) / g.CK, dgrad, out);
     return mas_launch_status();
@@ -803,7 +834,7 @@ extern "C" unsigned mas_conv_sk_pack_job(void* job_host, const float* w, int Cin
     if (total == 0) return 0;
     SkGeom g;
     const int M = dgrad ? Cin : Cout, K = dgrad ? Cout : Cin;
-    sk_geom(ksize, stride, M, 32, &g);
+    sk_geom(ksize, stride, M, 32, dgrad, &g);
     SkPackJob* jb = static_cast<SkPackJob*>(job_host);
     jb->w = w; jb->out = out; jb->Cout = Cout; jb->Cin = Cin; jb->taps = g.TAPS; jb->CK = g.CK; jb->BM = g.BM;
     jb->mtiles = (M + g.BM - 1) / g.BM; jb->nch = (K + g.CK - 1) / g.CK; jb->dgrad = dgrad;
@@ -849,22 +880,12 @@ extern "C" int mas_conv_sk(const float* x, const float* w, int N, int Cin, int H
         p.K = Cout; p.M = Cin;
         p.Ho = H; p.Wo = W;
     }
+    p.Wy = p.Wo; p.HWy = p.Ho * p.Wo; p.os = 1; p.oy_off = 0; p.ox_off = 0;
     SkGeom g;
-    sk_geom(ksize, stride, p.M, p.Wo, &g);
-    p.tiles_x = (p.Wo + g.TW - 1) / g.TW;
-    p.tiles_y = (p.Ho + g.TH - 1) / g.TH;
-    p.ptiles = N * p.tiles_x * p.tiles_y;
-    p.mtiles = (p.M + g.BM - 1) / g.BM;
-    p.nch = (p.K + g.CK - 1) / g.CK;
-    const long long iters = (long long)p.ptiles * p.mtiles * p.nch;
-    if (iters > 0x7fffffffLL) return MAS_ERR_SHAPE;
-    p.iters = (int)iters;
+    sk_geom(ksize, stride, p.M, p.Wo, dgrad ? 1 : 0, &g);
     const int cus = sk_num_cus();
-    p.P = (int)(p.iters < cus ? p.iters : cus);
-    if (p.P > 512) p.P = 512;
+    if (int rc = sk_plan(p, g, N, cus)) return rc;
     const int ntiles = p.ptiles * p.mtiles;
-    p.rdp = ntiles / p.P;
-    p.sk_iters = (ntiles - p.rdp * p.P) * p.nch;
     // 16-byte global loads: the weight rows and the planes must keep 16-byte groups whole and aligned
     if ((uintptr_t)w % 16 != 0) return MAS_ERR_ALIGN;
     const bool vec = ((uintptr_t)x % 16 == 0) && (W % 4 == 0);     // 16-byte loads of the input patch: whole, aligned groups
@@ -890,6 +911,46 @@ extern "C" int mas_conv_sk(const float* x, const float* w, int N, int Cin, int H
         return sk_dispatch<1, 32, 1, 1, 4>(q, g, vec, st);
     }
     return sk_dispatch<1, 64, 1, 1, 0>(p, g, vec, st);
+}
+
+/* One parity class (sub = 2 py + px) of the input gradient of a 3x3, stride-2, padding-1 convolution: dy [N,Cout,Hd,Wd] with
+ * Hd = (H - 1) / 2 + 1, wp = the class image of the weight (mas_conv_sk_pack with dgrad = 2 + sub); writes the pixels
+ * (2 i + py, 2 j + px) of dx [N,Cin,H,W] -- the four classes together write every pixel once.  Epilogue as mas_conv_sk. */
+extern "C" int mas_conv_sk_dgrad_s2(const float* dy, const float* wp, int N, int Cin, int H, int W, int Cout, int sub, const float* scale,
+                                    const float* shift, const float* residual, int relu, float* dx, void* workspace, size_t workspace_bytes,
+                                    unsigned epoch, void* stream) {
+    if (!dy || !wp || !dx || !workspace) return MAS_ERR_NULL;
+    if ((scale == nullptr) != (shift == nullptr)) return MAS_ERR_NULL;
+    if (N <= 0 || Cin <= 0 || H <= 0 || W <= 0 || Cout <= 0) return MAS_ERR_SHAPE;
+    if (sub < 0 || sub > 3 || epoch == 0) return MAS_ERR_RANGE;
+    if (workspace_bytes < mas_conv_sk_workspace_bytes()) return MAS_ERR_WORKSPACE;
+    if ((long long)(Cin > Cout ? Cin : Cout) * H * W > 0x7fffffffLL) return MAS_ERR_SHAPE;
+    if ((uintptr_t)wp % 16 != 0) return MAS_ERR_ALIGN;
+    const int py = sub >> 1, px = sub & 1;
+    SkP p;
+    p.x = dy; p.w = wp; p.scale = scale; p.shift = shift; p.res = residual; p.y = dx;
+    p.slots = static_cast<float*>(workspace);
+    p.flags = reinterpret_cast<unsigned*>(static_cast<char*>(workspace) + (size_t)512 * kSkSlotFloats * sizeof(float));
+    p.stamps = g_sk_stamps;
+    p.zero = reinterpret_cast<const float*>(p.flags + 768);
+    p.epoch = epoch;
+    p.relu = relu;
+    p.K = Cout; p.M = Cin;
+    p.H = (H - 1) / 2 + 1; p.W = (W - 1) / 2 + 1;               // the plane the patches are read from: dY
+    p.Ho = (H - py + 1) / 2; p.Wo = (W - px + 1) / 2;           // pixels of this class
+    p.Wy = W; p.HWy = H * W; p.os = 2; p.oy_off = py; p.ox_off = px;
+    if (p.Ho == 0 || p.Wo == 0) return 0;
+    SkGeom g;
+    sk_geom(3, 2, p.M, p.Wo, 2 + sub, &g);
+    if (int rc = sk_plan(p, g, N, sk_num_cus())) return rc;
+    const bool vec = ((uintptr_t)dy % 16 == 0) && (p.W % 4 == 0);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    switch (sub) {
+        case 0: return sk_dispatch<1, 64, 1, 1, 0, 0>(p, g, vec, st);
+        case 1: return sk_dispatch<2, 32, 1, 1, 0, 1>(p, g, vec, st);
+        case 2: return sk_dispatch<2, 32, 1, 1, 0, 2>(p, g, vec, st);
+        default: return sk_dispatch<4, 16, 1, 1, 0, 3>(p, g, vec, st);
+    }
 }
 
 /* tools only: per-workgroup wall-clock stamps (100 MHz) of the following mas_conv_sk launches into `stamps_dev` [512][4] u64

@@ -1111,7 +1111,8 @@ def _sk_workspace(dev):
 
 
 def conv_sk_pack(w, stride=1, dgrad=False):
-    """The weight [Cout,Cin,k,k] as mas_conv_sk reads it for one role (one small launch)."""
+    """The weight [Cout,Cin,k,k] as mas_conv_sk reads it for one role (one small launch): dgrad False / 0 forward, True / 1 input
+    gradient at stride 1, 2 + sub the parity class `sub` of the input gradient of a 3x3 stride-2 convolution."""
     _need(w, "w", torch.float32)
     Cout, Cin, ks, _ = w.shape
     lib = _lib.load()
@@ -1134,7 +1135,7 @@ class _PackRegistry:
 
     @staticmethod
     def key(w, stride, dgrad):
-        return (w.data_ptr(), w.untyped_storage()._cdata, tuple(w.shape), int(stride), bool(dgrad))
+        return (w.data_ptr(), w.untyped_storage()._cdata, tuple(w.shape), int(stride), int(dgrad))
 
     def get(self, w, stride, dgrad):
         k = self.key(w, stride, dgrad)
@@ -1212,6 +1213,28 @@ def conv_sk(x, w, stride=1, dil=1, dgrad=False, scale=None, shift=None, residual
                                            _opt(residual), int(relu), y.data_ptr(), ws.data_ptr(), ws.numel(), epoch, _stream(x)),
                    "mas_conv_sk")
     return y
+
+
+def conv_sk_dgrad_s2(dy, w, H, W, packed=None):
+    """dX [N,Cin,H,W] of y = conv2d(x, w, stride 2, padding 1) for a 3x3 weight `w` [Cout,Cin,3,3] from dY [N,Cout,(H-1)//2+1,
+    (W-1)//2+1]: four launches of the stream-K kernel, one per parity class of the dX pixels (mas_conv_sk_dgrad_s2) -- each a
+    stride-1 product over the dY plane with 1 / 2 / 2 / 4 taps, together the exact FLOPs of the gradient (no zero insertion).
+    ``packed``: the four class images (conv_sk_pack(w, 2, 2 + sub))."""
+    _need(dy, "dy", torch.float32)
+    _need(w, "w", torch.float32)
+    Cout, Cin, ks, _ = w.shape
+    N = dy.shape[0]
+    if ks != 3 or tuple(dy.shape) != (N, Cout, (H - 1) // 2 + 1, (W - 1) // 2 + 1):
+        raise ValueError("dy %s does not belong to a 3x3 stride-2 convolution of a %dx%d plane with weight %s" % (tuple(dy.shape), H, W, tuple(w.shape)))
+    dx = torch.empty((N, Cin, H, W), dtype=torch.float32, device=dy.device)
+    lib = _lib.load()
+    with torch.cuda.device(dy.device):
+        for sub in range(4):
+            img = packed[sub] if packed is not None else conv_sk_pack(w, 2, 2 + sub)
+            ws, epoch = _sk_workspace(dy.device)
+            _lib.check(lib.mas_conv_sk_dgrad_s2(dy.data_ptr(), img.data_ptr(), N, Cin, H, W, Cout, sub, None, None, None, 0, dx.data_ptr(),
+                                                ws.data_ptr(), ws.numel(), epoch, _stream(dy)), "mas_conv_sk_dgrad_s2")
+    return dx
 
 
 def conv_sk_set_mode(dma):
@@ -1294,6 +1317,8 @@ class _ConvTrain(torch.autograd.Function):
                 # scattered into a zero-filled tensor
                 dx = torch.zeros_like(x)
                 dx[:, :, ::stride, ::stride] = conv_sk(dy, w, 1, 1, dgrad=True, packed=packed_weight(w, 1, True))
+            elif own[1] and ks == 3 and stride == 2 and dil == 1:
+                dx = conv_sk_dgrad_s2(dy, w, x.shape[2], x.shape[3], packed=[packed_weight(w, 2, 2 + sub) for sub in range(4)])
             else:
                 dx = torch.ops.aten.convolution_backward(dy, x, w, None, (stride, stride), _aten_pad(ks, dil), (dil, dil), False, (0, 0), 1,
                                                          (True, False, False))[0]
@@ -1324,7 +1349,7 @@ def conv_wgrad_supported(conv, x):
 def conv_train_plan(conv, x):
     """(forward, input gradient, weight gradient) -> True where this package's kernel runs the product, or None when the layer
     is outside all three (then the caller keeps the nn.Module call).  MAS_TRAIN_CONV = own (default): every product the kernels
-    support -- all of them except the input gradient of the two stride-2 3x3 convolutions; miopen: none; auto: the weight
+    support -- all three of every dense convolution of the network; miopen: none; auto: the weight
     gradient everywhere, forward / input gradient only on planes of >= 192 x 192 / 384 x 384 pixels (MIOpen's Tensile GEMMs are
     still ahead on the 1x1 layers of the small planes: profiles/r03/b_conv_train_table_streamk.md; ~0.4 ms per step)."""
     mode = os.environ.get("MAS_TRAIN_CONV", "own")
@@ -1332,7 +1357,7 @@ def conv_train_plan(conv, x):
         return None
     hw = x.shape[2] * x.shape[3]
     fwd_ok = conv.dilation[0] in (1, 2, 4) and hw >= 64
-    dgrad_ok = fwd_ok and (conv.stride[0] == 1 or conv.kernel_size[0] == 1)
+    dgrad_ok = fwd_ok and (conv.stride[0] == 1 or conv.kernel_size[0] == 1 or conv.dilation[0] == 1)
     wgrad_ok = conv.in_channels >= 8
     if mode == "own":
         return (fwd_ok, dgrad_ok, True)

@@ -144,6 +144,26 @@ def test_stream_k_exact_on_integers_at_layer_sizes(sk_mode):
     assert ops.conv_sk_error() == 0
 
 
+def test_stride2_input_gradient_exact_on_integers():
+    """mas_conv_sk_dgrad_s2: the four parity classes of the input gradient of a 3x3 stride-2 convolution (1 / 2 / 2 / 4 taps over
+    the dY plane, strided stores) on integer data, exact in any order: even and odd planes (odd: the last row / column belongs to
+    class 0 only), planes of one pixel row, Cin that is not a multiple of the M tile, the layer sizes at the 768 and 769 crops."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from mulactseg_amd import ops
+    g = torch.Generator(device='cuda').manual_seed(21)
+    for Cin, Cout, N, H, W in ((128, 128, 2, 96, 96), (256, 256, 1, 48, 48), (128, 128, 1, 97, 97), (64, 96, 2, 33, 66), (40, 72, 1, 1, 9),
+                               (64, 64, 1, 2, 2), (200, 64, 1, 17, 40), (128, 128, 4, 192, 192)):
+        w = torch.randint(-2, 3, (Cout, Cin, 3, 3), generator=g, device='cuda').float()
+        x = torch.zeros(N, Cin, H, W, device='cuda')
+        dy = torch.randint(-2, 3, (N, Cout, (H - 1) // 2 + 1, (W - 1) // 2 + 1), generator=g, device='cuda').float()
+        _, dx_ref, _ = _ref_grads(x, w, dy, 2, 1)
+        for rep in range(2):
+            dx = ops.conv_sk_dgrad_s2(dy, w, H, W)
+            assert torch.equal(dx.double(), dx_ref), (Cin, Cout, N, H, W, rep)
+    assert ops.conv_sk_error() == 0
+
+
 @pytest.mark.parametrize("Cin,Cout,k,stride,dil,N,H,W", [c for c in CASES if c[0] > 3])
 def test_conv_train_forward_and_gradients(Cin, Cout, k, stride, dil, N, H, W):
     if not torch.cuda.is_available():
@@ -235,7 +255,7 @@ def test_packed_weight_images_follow_in_place_updates():
         outs = []
         for conv, x in zip(convs, xs):
             x.grad = None
-            y = ops.conv_train(conv, x, (True, conv.stride[0] == 1 or conv.kernel_size[0] == 1, True))
+            y = ops.conv_train(conv, x, (True, True, True))      # (the stride-2 3x3: four parity-class images)
             y.backward(torch.ones_like(y))
             outs.append((y.detach().clone(), x.grad.clone()))
         return outs
