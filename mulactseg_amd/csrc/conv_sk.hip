@@ -50,6 +50,7 @@ struct SkP {
     int Wy, HWy, os, oy_off, ox_off;    // where tile pixel (oy, ox) lands in the output plane: row oy * os + oy_off of Wy columns, HWy per channel
     int tiles_x, tiles_y, ptiles, mtiles, nch;
     int iters;                  // all (tile, chunk) iterations of the layer
+    int N;                      // pictures
     int P;                      // workgroups (one per CU)
     int rdp, sk_iters;          // whole tiles per workgroup (rounds of P tiles), iterations of the remaining tiles (stream-K part)
 };
@@ -66,7 +67,7 @@ struct SkG {
     static constexpr int TR = SUB ? 1 + (SUB >> 1) : (TAPS == 9 ? 3 : 1), TC = SUB ? 1 + (SUB & 1) : (TAPS == 9 ? 3 : 1);
     static_assert(TR * TC == TAPS && (SUB == 0 || (STRIDE == 1 && DIL == 1)), "tap geometry");
     static constexpr int TH = kSkBN / TW;
-    static constexpr int TWLOG = TW == 32 ? 5 : 4;
+    static constexpr int TWLOG = TW == 128 ? 7 : (TW == 32 ? 5 : 4);
     static constexpr int PAD = (TAPS == 9 && !SUB) ? DIL : 0;
     static constexpr int PADL = (TAPS == 9 && !SUB) ? 4 : 0;
     static constexpr int PH = SUB ? TH + TR - 1 : (TH - 1) * STRIDE + 1 + 2 * PAD;
@@ -141,17 +142,35 @@ __device__ __forceinline__ void sk_advance(const SkP& p, int g, int sk0, SkCurso
 }
 
 // Per-thread description of its 16-byte groups of the input patch (depends on the thread only): channel, patch row / column
-// (packed), LDS offset; -1 = no group.
+// (packed), LDS offset; -1 = no group.  A group is four consecutive patch columns: one 16-byte global load, one 16-byte LDS store.
+// VEC: the rows of the plane are 16-byte aligned (W % 4 == 0, aligned base) and a group is inside the plane's row or outside it.
+// !VEC (the 769-crop planes 385 / 193 / 97 / 49: every row starts at another alignment): the same groups, loaded with 16-byte
+// loads at 4-byte aligned addresses (gfx950 runs them at the aligned rate: tools/micro/unaligned.hip); the one group per row that
+// straddles the row's right end reads on into the next row and has its elements past the end zeroed -- when it is written to LDS,
+// not behind the load: any use of a loaded value in the fetch code makes hipcc wait for the load there, which serialises the
+// prefetch (46.1 ms per step) -- except at the very end of the tensor, where it would leave the allocation: that group is
+// loaded so that it ENDS at the tensor's end and is rotated into place before the LDS store.  (First forms of this path:
+// element-wise 4-byte loads, 4x the load instructions, 48.4 ms per step at the 769 crop; aligned groups of memory written to LDS
+// with four predicated 4-byte stores at the row's shift, 44.2 ms.)
+typedef float v4fu __attribute__((ext_vector_type(4), aligned(4)));
+
+template <typename G>
+struct SkX {
+    static constexpr int F4R = G::PWL >> 2;                                   // groups per patch row
+    static constexpr int F4C = G::PH * F4R;                                   // per channel
+    static constexpr int NXS = (G::CK * F4C + kSkThreads - 1) / kSkThreads;   // per thread
+};
+
 template <int NXS>
 struct SkSlots {
     int c[NXS], rc[NXS], lds[NXS];
 };
 
 template <typename G>
-__device__ __forceinline__ void sk_slots(int tid, SkSlots<G::NXS>& s) {
-    constexpr int f4r = G::PWL >> 2, f4c = G::PH * f4r;
+__device__ __forceinline__ void sk_slots(int tid, SkSlots<SkX<G>::NXS>& s) {
+    constexpr int f4r = SkX<G>::F4R, f4c = SkX<G>::F4C;
 #pragma unroll
-    for (int j = 0; j < G::NXS; ++j) {
+    for (int j = 0; j < SkX<G>::NXS; ++j) {
         const int f = tid + j * kSkThreads;
         const int c = f / f4c, rem = f - c * f4c;
         const int row = rem / f4r, col = (rem - row * f4r) * 4;
@@ -166,24 +185,30 @@ __device__ __forceinline__ void sk_slots(int tid, SkSlots<G::NXS>& s) {
 // functions of the pixel tile only, recomputed when the prefetch stream enters a new one.  Per chunk a group then costs one
 // compare and one load from (uniform base + offset) -- the address arithmetic of the staging code competes with the partner
 // wave's MFMA issue (measured: ~3k of the 11.6k cycles of an iteration in "stage + refetch" before this).
+// !VEC: meta = number of elements of the group inside the row (1..4) | 8 in the last row of the last picture (fetch turns that
+// into | 16 for the last channel = the end of the tensor: loaded 4 - nv elements early, rotated by sk_stage).
 template <int NXS>
 struct SkXOff {
-    int off[NXS];
+    int off[NXS], meta[NXS];
     unsigned mask;
 };
 
-template <typename G>
-__device__ __forceinline__ void sk_xoffsets(const SkP& p, SkCursor& cur, const SkSlots<G::NXS>& sl, SkXOff<G::NXS>& xo) {
+template <typename G, bool VEC>
+__device__ __forceinline__ void sk_xoffsets(const SkP& p, SkCursor& cur, const SkSlots<SkX<G>::NXS>& sl, SkXOff<SkX<G>::NXS>& xo) {
     const int iy0 = cur.tyi * G::TH * G::STRIDE - G::PAD, ix0 = cur.txi * G::TW * G::STRIDE - G::PADL;
     const int HW = p.H * p.W;
     xo.mask = 0;
 #pragma unroll
-    for (int j = 0; j < G::NXS; ++j) {
+    for (int j = 0; j < SkX<G>::NXS; ++j) {
         const int c = sl.c[j];
-        const int iy = iy0 + (sl.rc[j] & 0xffff), ix = ix0 + (sl.rc[j] >> 16);
+        const int iy = iy0 + (sl.rc[j] & 0xffff), ix = ix0 + (sl.rc[j] >> 16);        // (ix is a multiple of 4: never astride the left end)
         const bool ok = c >= 0 && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
         xo.off[j] = ok ? c * HW + iy * p.W + ix : 0;
         xo.mask |= ok ? 1u << j : 0u;
+        if constexpr (!VEC) {
+            const int nv = p.W - ix < 4 ? p.W - ix : 4;
+            xo.meta[j] = nv | ((nv < 4 && cur.n == p.N - 1 && iy == p.H - 1) ? 8 : 0);
+        }
     }
     cur.moved = false;
 }
@@ -191,9 +216,9 @@ __device__ __forceinline__ void sk_xoffsets(const SkP& p, SkCursor& cur, const S
 // global -> registers of the chunk at the cursor (its tile may differ from the one being multiplied: the pipeline crosses tile
 // boundaries)
 template <typename G, int TAPS, int WM, bool VEC, int NWS>
-__device__ __forceinline__ void sk_fetch(const SkP& p, SkCursor& cur, const SkSlots<G::NXS>& sl, SkXOff<G::NXS>& xo, int tid, v4f (&wr)[NWS],
-                                         v4f (&xr)[G::NXS]) {
-    constexpr int BM = 32 * WM, CK = G::CK, NXS = G::NXS, TW = G::TW;
+__device__ __forceinline__ void sk_fetch(const SkP& p, SkCursor& cur, const SkSlots<SkX<G>::NXS>& sl, SkXOff<SkX<G>::NXS>& xo, int tid,
+                                         v4f (&wr)[NWS], v4f (&xr)[SkX<G>::NXS]) {
+    constexpr int BM = 32 * WM, CK = G::CK, NXS = SkX<G>::NXS;
     constexpr int KC = TAPS * CK;
     const int k0 = cur.chunk * CK;
     // ---- weight: the LDS image of (M tile, chunk), a linear copy --------------------------------------------------------------
@@ -203,27 +228,28 @@ __device__ __forceinline__ void sk_fetch(const SkP& p, SkCursor& cur, const SkSl
         const int e = (tid + j * kSkThreads) * 4;
         wr[j] = (NWS * kSkThreads * 4 == BM * KC || e < BM * KC) ? *reinterpret_cast<const v4f*>(wb + e) : (v4f){0.f, 0.f, 0.f, 0.f};
     }
-    // ---- input patch: CK channels x PH rows x PWL columns, 16-byte groups aligned in memory --------------------------------
+    // ---- input patch: CK channels x PH rows x PWL columns --------------------------------------------------------------------
     const int HW = p.H * p.W;
     const float* xb = p.x + ((size_t)cur.n * p.K + k0) * HW;
-    if constexpr (VEC) {
-        if (cur.moved) sk_xoffsets<G>(p, cur, sl, xo);
-        const int kleft = p.K - k0;
+    if (cur.moved) sk_xoffsets<G, VEC>(p, cur, sl, xo);
+    const int kleft = p.K - k0;
 #pragma unroll
-        for (int j = 0; j < NXS; ++j) {
-            const bool ok = ((xo.mask >> j) & 1u) && sl.c[j] < kleft;
+    for (int j = 0; j < NXS; ++j) {
+        const bool ok = ((xo.mask >> j) & 1u) && sl.c[j] < kleft;
+        if constexpr (VEC) {
             xr[j] = ok ? *reinterpret_cast<const v4f*>(xb + xo.off[j]) : (v4f){0.f, 0.f, 0.f, 0.f};
-        }
-    } else {
-        const int iy0 = cur.tyi * G::TH * G::STRIDE - G::PAD, ix0 = cur.txi * TW * G::STRIDE - G::PADL;
-#pragma unroll
-        for (int j = 0; j < NXS; ++j) {
-            const int c = sl.c[j];
-            const int iy = iy0 + (sl.rc[j] & 0xffff), ix = ix0 + (sl.rc[j] >> 16);
-            const bool ok = c >= 0 && k0 + c < p.K && (unsigned)iy < (unsigned)p.H;
-            const float* src = xb + (size_t)(c < 0 ? 0 : c) * HW + (long long)iy * p.W + ix;
-#pragma unroll
-            for (int i = 0; i < 4; ++i) xr[j][i] = (ok && (unsigned)(ix + i) < (unsigned)p.W) ? src[i] : 0.0f;
+        } else {
+            // (no use of the loaded values here: masks and the rotation are applied by sk_stage)
+            const int nv = xo.meta[j] & 7;
+            const bool tail = (xo.meta[j] & 8) && sl.c[j] == kleft - 1;        // the group would leave the tensor
+            xo.meta[j] = (xo.meta[j] & 15) | (tail ? 16 : 0);
+            const float* src = xb + xo.off[j] - (tail ? 4 - nv : 0);
+            if (ok) {
+                const v4fu u = *reinterpret_cast<const v4fu*>(src);
+                xr[j] = (v4f){u[0], u[1], u[2], u[3]};
+            } else {
+                xr[j] = (v4f){0.f, 0.f, 0.f, 0.f};
+            }
         }
     }
 }
@@ -231,10 +257,10 @@ __device__ __forceinline__ void sk_fetch(const SkP& p, SkCursor& cur, const SkSl
 // registers -> LDS.  Weight image [KC / 8][2][BM][4] (written by k_sk_pack): k-step kk = tap * (CK / 2) + c / 2 pairs the channels
 // 2 cp + h of one tap (h = lane half of the MFMA), the four k-steps 4 q .. 4 q + 3 of one (half, row) are adjacent: one 16-byte
 // read = four MFMAs.
-template <typename G, int TAPS, int WM, int NWS>
-__device__ __forceinline__ void sk_stage(const SkSlots<G::NXS>& sl, float* __restrict__ sW, float* __restrict__ sX, int tid, const v4f (&wr)[NWS],
-                                         const v4f (&xr)[G::NXS]) {
-    constexpr int BM = 32 * WM, CK = G::CK, NXS = G::NXS;
+template <typename G, int TAPS, int WM, bool VEC, int NWS>
+__device__ __forceinline__ void sk_stage(const SkSlots<SkX<G>::NXS>& sl, const SkXOff<SkX<G>::NXS>& xo, float* __restrict__ sW,
+                                         float* __restrict__ sX, int tid, const v4f (&wr)[NWS], const v4f (&xr)[SkX<G>::NXS]) {
+    constexpr int BM = 32 * WM, CK = G::CK, NXS = SkX<G>::NXS;
     constexpr int KC = TAPS * CK;
 #pragma unroll
     for (int j = 0; j < NWS; ++j) {
@@ -242,59 +268,29 @@ __device__ __forceinline__ void sk_stage(const SkSlots<G::NXS>& sl, float* __res
         if (NWS * kSkThreads * 4 == BM * KC || e < BM * KC) *reinterpret_cast<v4f*>(sW + e) = wr[j];
     }
 #pragma unroll
-    for (int j = 0; j < NXS; ++j)
-        if (sl.c[j] >= 0) *reinterpret_cast<v4f*>(sX + sl.lds[j]) = xr[j];
-}
-
-// NB == 0: chunks travel global -> registers -> LDS (two LDS buffers).  NB >= 2: LDS-DMA (global_load_lds) into a ring of NB
-// buffers, NB - 1 chunks in flight, no staging registers and no LDS store instructions; padding and out-of-range elements are
-// read from a zero page; planes whose rows are not 16-byte aligned take 4-byte DMA for the input patch.
-// one slot of the staging registers: J < NWS = weight group J, else patch group J - NWS
-template <typename G, int TAPS, int WM, bool VEC, int NWS, int J>
-__device__ __forceinline__ void sk_fetch_slot(const SkP& p, const SkCursor& cur, const SkSlots<G::NXS>& sl, int tid, v4f (&wr)[NWS],
-                                              v4f (&xr)[G::NXS]) {
-    constexpr int BM = 32 * WM, CK = G::CK, TW = G::TW;
-    constexpr int KC = TAPS * CK;
-    if constexpr (J < NWS) {
-        const float* wb = p.w + ((size_t)cur.mt * p.nch + cur.chunk) * (size_t)(KC * BM);
-        const int e = (tid + J * kSkThreads) * 4;
-        wr[J] = (NWS * kSkThreads * 4 == BM * KC || e < BM * KC) ? *reinterpret_cast<const v4f*>(wb + e) : (v4f){0.f, 0.f, 0.f, 0.f};
-    } else {
-        constexpr int j = J - NWS;
-        const int k0 = cur.chunk * CK;
-        const int iy0 = cur.tyi * G::TH * G::STRIDE - G::PAD, ix0 = cur.txi * TW * G::STRIDE - G::PADL;
-        const int HW = p.H * p.W;
-        const float* xb = p.x + ((size_t)cur.n * p.K + k0) * HW;
-        const int c = sl.c[j];
-        const int iy = iy0 + (sl.rc[j] & 0xffff), ix = ix0 + (sl.rc[j] >> 16);
-        const bool ok = c >= 0 && k0 + c < p.K && (unsigned)iy < (unsigned)p.H;
-        const float* src = xb + (size_t)(c < 0 ? 0 : c) * HW + (long long)iy * p.W + ix;
-        if (VEC) {
-            xr[j] = (ok && (unsigned)ix < (unsigned)p.W) ? *reinterpret_cast<const v4f*>(src) : (v4f){0.f, 0.f, 0.f, 0.f};
-        } else {
-#pragma unroll
-            for (int i = 0; i < 4; ++i) xr[j][i] = (ok && (unsigned)(ix + i) < (unsigned)p.W) ? src[i] : 0.0f;
+    for (int j = 0; j < NXS; ++j) {
+        v4f v = xr[j];
+        if constexpr (!VEC) {
+            // xo still describes the tile of the chunk in `xr`: the caller stages a chunk BEFORE it fetches the next one
+            const int nv = xo.meta[j] & 7;
+            if (xo.meta[j] & 16) {              // loaded 4 - nv elements early: element i of the group is u[i + 4 - nv]
+                const v4f u = v;
+                v[0] = nv == 1 ? u[3] : (nv == 2 ? u[2] : u[1]);
+                v[1] = nv == 2 ? u[3] : u[2];
+                v[2] = u[3];
+            }
+            v[1] = nv > 1 ? v[1] : 0.0f;
+            v[2] = nv > 2 ? v[2] : 0.0f;
+            v[3] = nv > 3 ? v[3] : 0.0f;
         }
-    }
-}
-
-template <typename G, int TAPS, int WM, int NWS, int J>
-__device__ __forceinline__ void sk_stage_slot(const SkSlots<G::NXS>& sl, float* __restrict__ sW, float* __restrict__ sX, int tid,
-                                              const v4f (&wr)[NWS], const v4f (&xr)[G::NXS]) {
-    constexpr int BM = 32 * WM, KC = TAPS * G::CK;
-    if constexpr (J < NWS) {
-        const int e = (tid + J * kSkThreads) * 4;
-        if (NWS * kSkThreads * 4 == BM * KC || e < BM * KC) *reinterpret_cast<v4f*>(sW + e) = wr[J];
-    } else {
-        constexpr int j = J - NWS;
-        if (sl.c[j] >= 0) *reinterpret_cast<v4f*>(sX + sl.lds[j]) = xr[j];
+        if (sl.c[j] >= 0) *reinterpret_cast<v4f*>(sX + sl.lds[j]) = v;
     }
 }
 
 template <int TAPS, int CK, int WM, int TW, int STRIDE, int DIL, bool VEC, int NB, int SUB = 0>
 __global__ __launch_bounds__(kSkThreads) void k_conv_sk(const SkP p) {
     using G = SkG<TAPS, CK, TW, STRIDE, DIL, SUB>;
-    constexpr int NXS = G::NXS, CS = G::CS, PWL = G::PWL;
+    constexpr int NXS = SkX<G>::NXS, CS = G::CS, PWL = G::PWL;
     constexpr bool DMA = NB >= 2;
     constexpr int BM = 32 * WM, BN = kSkBN;
     constexpr int NG = 8 / WM;                  // pixel groups of the 8 waves
@@ -457,7 +453,7 @@ __global__ __launch_bounds__(kSkThreads) void k_conv_sk(const SkP p) {
     if constexpr (!DMA) {
         sk_slots<G>(tid, slots);
         sk_fetch<G, TAPS, WM, VEC, NWS>(p, pre, slots, xoff, tid, wr, xr);
-        sk_stage<G, TAPS, WM, NWS>(slots, sk_smem, sk_smem + KC * BM, tid, wr, xr);
+        sk_stage<G, TAPS, WM, VEC, NWS>(slots, xoff, sk_smem, sk_smem + KC * BM, tid, wr, xr);
         if (it0 + 1 < it1) {
             sk_advance(p, g, sk0, pre);
             sk_fetch<G, TAPS, WM, VEC, NWS>(p, pre, slots, xoff, tid, wr, xr);
@@ -509,7 +505,7 @@ __global__ __launch_bounds__(kSkThreads) void k_conv_sk(const SkP p) {
 #endif
                 if (it + 1 < it1) {
                     float* nW = sk_smem + (buf ^ 1) * bufsz;
-                    sk_stage<G, TAPS, WM, NWS>(slots, nW, nW + KC * BM, tid, wr, xr);
+                    sk_stage<G, TAPS, WM, VEC, NWS>(slots, xoff, nW, nW + KC * BM, tid, wr, xr);
 #ifdef SK_PHASE_STAMPS
                     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #endif
@@ -722,7 +718,7 @@ struct SkGeom {
 };
 
 // mode: 0 forward, 1 input gradient (stride 1), 2 + SUB parity class of the stride-2 3x3 input gradient (1 / 2 / 2 / 4 taps)
-inline void sk_geom(int ksize, int stride, int M, int Wo, int mode, SkGeom* g) {
+inline void sk_geom(int ksize, int stride, int M, int Ho, int Wo, int mode, SkGeom* g) {
     g->TAPS = ksize * ksize;
     g->CK = ksize == 3 ? 8 : (stride == 2 ? 16 : 64);       // (the stride-2 patch of a 1x1 holds 4x the pixels it uses)
     if (mode >= 2) {
@@ -730,7 +726,10 @@ inline void sk_geom(int ksize, int stride, int M, int Wo, int mode, SkGeom* g) {
         g->CK = 64 / g->TAPS;                               // 64 k-rows per chunk in every class
     }
     g->BM = M > 64 ? 128 : 64;
-    g->TW = (Wo >= 32 && !(Wo % 32 != 0 && Wo % 16 == 0)) ? 32 : 16;       // 48-wide planes: three exact 16-wide tiles
+    // 4 x 32 or 8 x 16 pixels per tile: whichever covers the plane with fewer tiles (48 x 48: 18 exact 8 x 16 tiles; the 769-crop
+    // planes 385 / 193 / 97: 3-9 % fewer 8 x 16 tiles, 49: 26 4 x 32 tiles against 28)
+    const long long t32 = (long long)((Wo + 31) / 32) * ((Ho + 3) / 4), t16 = (long long)((Wo + 15) / 16) * ((Ho + 7) / 8);
+    g->TW = t32 <= t16 ? 32 : 16;
     g->TH = kSkBN / g->TW;
 }
 
@@ -772,6 +771,7 @@ int sk_launch(const SkP& p, hipStream_t st) {
 
 // tiles, chunks and the deal of the iterations to the workgroups (p.K, p.M, p.Ho, p.Wo set)
 inline int sk_plan(SkP& p, const SkGeom& g, int N, int cus) {
+    p.N = N;
     p.tiles_x = (p.Wo + g.TW - 1) / g.TW;
     p.tiles_y = (p.Ho + g.TH - 1) / g.TH;
     p.ptiles = N * p.tiles_x * p.tiles_y;
@@ -808,7 +808,7 @@ extern "C" size_t mas_conv_sk_packed_elems(int Cin, int Cout, int ksize, int str
     if (dgrad >= 2 && (ksize != 3 || stride != 2)) return 0;
     SkGeom g;
     const int M = dgrad ? Cin : Cout, K = dgrad ? Cout : Cin;
-    sk_geom(ksize, stride, M, 32, dgrad, &g);
+    sk_geom(ksize, stride, M, 4, 32, dgrad, &g);
     return (size_t)((M + g.BM - 1) / g.BM) * ((K + g.CK - 1) / g.CK) * (size_t)g.TAPS * g.CK * g.BM;
 }
 
@@ -818,7 +818,7 @@ extern "C" int mas_conv_sk_pack(const float* w, int Cin, int Cout, int ksize, in
     if (total == 0) return MAS_ERR_SHAPE;
     SkGeom g;
     const int M = dgrad ? Cin : Cout, K = dgrad ? Cout : Cin;
-    sk_geom(ksize, stride, M, 32, dgrad, &g);
+    sk_geom(ksize, stride, M, 4, 32, dgrad, &g);
     hipLaunchKernelGGL(k_sk_pack, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream), w, Cout, Cin, g.TAPS,
                        g.CK, g.BM, (M + g.BM - 1) / g.BM, (K + g.CK - 1) / g.CK, dgrad, out);
     return mas_launch_status();
@@ -834,7 +834,7 @@ extern "C" unsigned mas_conv_sk_pack_job(void* job_host, const float* w, int Cin
     if (total == 0) return 0;
     SkGeom g;
     const int M = dgrad ? Cin : Cout, K = dgrad ? Cout : Cin;
-    sk_geom(ksize, stride, M, 32, dgrad, &g);
+    sk_geom(ksize, stride, M, 4, 32, dgrad, &g);
     SkPackJob* jb = static_cast<SkPackJob*>(job_host);
     jb->w = w; jb->out = out; jb->Cout = Cout; jb->Cin = Cin; jb->taps = g.TAPS; jb->CK = g.CK; jb->BM = g.BM;
     jb->mtiles = (M + g.BM - 1) / g.BM; jb->nch = (K + g.CK - 1) / g.CK; jb->dgrad = dgrad;
@@ -880,17 +880,27 @@ extern "C" int mas_conv_sk(const float* x, const float* w, int N, int Cin, int H
         p.K = Cout; p.M = Cin;
         p.Ho = H; p.Wo = W;
     }
+    const bool dma = g_sk_dma != 0;
+    const bool flat = ksize == 1 && stride == 1 && !dma;
+    if (flat) {
+        // a 1x1 product at stride 1 does not see the plane's rows: the plane is walked as ONE row of H * W pixels in tiles of 128
+        // consecutive pixels -- no partial tiles at the right edge of every row (49 x 49: 19 tiles instead of 26), the same
+        // kernel for every plane size
+        p.W = H * W; p.H = 1;
+        p.Wo = p.W; p.Ho = 1;
+    }
     p.Wy = p.Wo; p.HWy = p.Ho * p.Wo; p.os = 1; p.oy_off = 0; p.ox_off = 0;
     SkGeom g;
-    sk_geom(ksize, stride, p.M, p.Wo, dgrad ? 1 : 0, &g);
+    sk_geom(ksize, stride, p.M, p.Ho, p.Wo, dgrad ? 1 : 0, &g);
     const int cus = sk_num_cus();
+    if (flat) { g.TW = 128; g.TH = 1; }
     if (int rc = sk_plan(p, g, N, cus)) return rc;
     const int ntiles = p.ptiles * p.mtiles;
     // 16-byte global loads: the weight rows and the planes must keep 16-byte groups whole and aligned
     if ((uintptr_t)w % 16 != 0) return MAS_ERR_ALIGN;
-    const bool vec = ((uintptr_t)x % 16 == 0) && (W % 4 == 0);     // 16-byte loads of the input patch: whole, aligned groups
+    const bool vec = ((uintptr_t)x % 16 == 0) && (p.W % 4 == 0);   // 16-byte loads of the input patch: whole, aligned groups
+    if (!vec && (long long)N * p.K * H * W < 4) return MAS_ERR_SHAPE;   // (the unaligned path reads the tensor's last four elements as one group)
     // (forward and input gradient are the same kernel: the role lives in the packed weight image)
-    const bool dma = g_sk_dma != 0;
     if (ksize == 3) {
         if (stride == 2) return dma ? sk_dispatch<9, 8, 2, 1, 2>(p, g, vec, st) : sk_dispatch<9, 8, 2, 1, 0>(p, g, vec, st);
         if (dil == 4) return dma ? sk_dispatch<9, 8, 1, 4, 2>(p, g, vec, st) : sk_dispatch<9, 8, 1, 4, 0>(p, g, vec, st);
@@ -910,7 +920,8 @@ extern "C" int mas_conv_sk(const float* x, const float* w, int N, int Cin, int H
         q.sk_iters = (ntiles - q.rdp * q.P) * q.nch;
         return sk_dispatch<1, 32, 1, 1, 4>(q, g, vec, st);
     }
-    return sk_dispatch<1, 64, 1, 1, 0>(p, g, vec, st);
+    if (g.BM == 128) return vec ? sk_launch<1, 64, 4, 128, 1, 1, true, 0>(p, st) : sk_launch<1, 64, 4, 128, 1, 1, false, 0>(p, st);
+    return vec ? sk_launch<1, 64, 2, 128, 1, 1, true, 0>(p, st) : sk_launch<1, 64, 2, 128, 1, 1, false, 0>(p, st);
 }
 
 /* One parity class (sub = 2 py + px) of the input gradient of a 3x3, stride-2, padding-1 convolution: dy [N,Cout,Hd,Wd] with
@@ -941,9 +952,10 @@ extern "C" int mas_conv_sk_dgrad_s2(const float* dy, const float* wp, int N, int
     p.Wy = W; p.HWy = H * W; p.os = 2; p.oy_off = py; p.ox_off = px;
     if (p.Ho == 0 || p.Wo == 0) return 0;
     SkGeom g;
-    sk_geom(3, 2, p.M, p.Wo, 2 + sub, &g);
+    sk_geom(3, 2, p.M, p.Ho, p.Wo, 2 + sub, &g);
     if (int rc = sk_plan(p, g, N, sk_num_cus())) return rc;
     const bool vec = ((uintptr_t)dy % 16 == 0) && (p.W % 4 == 0);
+    if (!vec && (long long)N * p.K * p.H * p.W < 4) return MAS_ERR_SHAPE;
     hipStream_t st = static_cast<hipStream_t>(stream);
     switch (sub) {
         case 0: return sk_dispatch<1, 64, 1, 1, 0, 0>(p, g, vec, st);

@@ -27,6 +27,7 @@
 namespace {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float v4f __attribute__((ext_vector_type(4)));
+typedef float v4fu __attribute__((ext_vector_type(4), aligned(4)));
 constexpr int kWgThreads = 512;
 
 struct WgP {
@@ -65,9 +66,18 @@ __global__ __launch_bounds__(kWgThreads) void k_wgrad(const WgP p) {
     constexpr int BM = G::BM, BC = G::BC, NT = G::NT, KH = G::KH, PAD = G::PAD, PH = G::PH, PWL = G::PWL, CS = G::CS, RS = G::RS;
     constexpr int ASZ = G::ASZ, BSZ = G::BSZ;
     constexpr int NG = G::NG, NT0 = G::NT0;
-    constexpr int F4R = KP / 4;                             // float4 per dY row
-    constexpr int NA = (BM * F4R + kWgThreads - 1) / kWgThreads;
-    constexpr int F4C = FLAT ? F4R : PH * PWL / 4;          // float4 per staged input channel
+    // 16-byte groups staged per dY row and per input channel: four consecutive elements of the chunk, one 16-byte global load.
+    // VEC: the rows of both planes are 16-byte aligned and a group is inside its row or outside.  !VEC (the 769-crop planes 385^2,
+    // 193^2, 97^2, 49^2: every row of every plane starts at another alignment): 16-byte loads at 4-byte aligned addresses (same
+    // rate on gfx950); the group astride the end of a run reads on into the next row / plane and has the elements past the end
+    // zeroed, except where it could leave the tensor (last row of the last picture): there it is loaded element by element.
+    // (Element-wise 4-byte loads, the first form: 5.7 vs 3.5 ms per step on the 1x1 layers.)
+    constexpr int AL = 0;
+    constexpr int ARUN = FLAT ? KP : TW, ARUNS = FLAT ? 1 : G::TH;         // runs of a dY row in one chunk
+    constexpr int F4A = ARUNS * (ARUN / 4 + AL);            // groups per dY row
+    constexpr int NA = (BM * F4A + kWgThreads - 1) / kWgThreads;
+    constexpr int BRUN = FLAT ? KP : PWL, BRUNS = FLAT ? 1 : PH;
+    constexpr int F4C = BRUNS * (BRUN / 4 + AL);            // groups per staged input channel
     constexpr int NB = (BC * F4C + kWgThreads - 1) / kWgThreads;
     static_assert(KP % 8 == 0 && (FLAT || (KP % TW == 0 && TW % 8 == 0)), "chunk");
     static_assert(KH == 1 || (KP / 2) % TW == 0, "K halves must split the chunk at a row boundary");
@@ -93,6 +103,35 @@ __global__ __launch_bounds__(kWgThreads) void k_wgrad(const WgP p) {
     const int HW = p.H * p.W, HWo = p.Ho * p.Wo;
 
     v4f ra[NA], rb[NB];
+    int ma[VEC ? 1 : NA], mb[VEC ? 1 : NB];         // !VEC: elements of the group that exist (0..4) | 8: loaded 4 - nv elements early
+
+    // !VEC: the group at `src` of which the first nv (<= 0: none, >= 4: all) elements exist; `last`: the run ends the tensor -- a
+    // partial group is then loaded so that it ENDS at the run's end (una_fix rotates it into place).  The loaded values are not
+    // touched here: any use behind the load makes hipcc wait for it in the fetch code, which serialises the prefetch.
+    auto una_load = [&](const float* src, int nv, bool last, v4f& out, int& meta) {
+        nv = nv < 0 ? 0 : (nv > 4 ? 4 : nv);
+        const bool early = last && nv > 0 && nv < 4;
+        meta = nv | (early ? 8 : 0);
+        if (nv > 0) {
+            const v4fu u = *reinterpret_cast<const v4fu*>(src - (early ? 4 - nv : 0));
+            out = (v4f){u[0], u[1], u[2], u[3]};
+        } else {
+            out = (v4f){0.f, 0.f, 0.f, 0.f};
+        }
+    };
+    auto una_fix = [&](v4f v, int meta) -> v4f {
+        const int nv = meta & 7;
+        if (meta & 8) {
+            const v4f u = v;
+            v[0] = nv == 1 ? u[3] : (nv == 2 ? u[2] : u[1]);
+            v[1] = nv == 2 ? u[3] : u[2];
+            v[2] = u[3];
+        }
+        v[1] = nv > 1 ? v[1] : 0.0f;
+        v[2] = nv > 2 ? v[2] : 0.0f;
+        v[3] = nv > 3 ? v[3] : 0.0f;
+        return v;
+    };
 
     auto fetch = [&](int q) {
         if (FLAT) {
@@ -103,28 +142,20 @@ __global__ __launch_bounds__(kWgThreads) void k_wgrad(const WgP p) {
 #pragma unroll
             for (int j = 0; j < NA; ++j) {
                 const int f = tid + j * kWgThreads;
-                const int m = f / F4R, kp = (f % F4R) * 4;
-                const bool rowok = f < BM * F4R && m0 + m < p.Cout;
-                const float* src = dyb + (size_t)(m0 + m) * HWo + kp;
-                if (VEC) {
-                    ra[j] = (rowok && k0 + kp < HW) ? *reinterpret_cast<const v4f*>(src) : (v4f){0.f, 0.f, 0.f, 0.f};
-                } else {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) ra[j][e] = (rowok && k0 + kp + e < HW) ? src[e] : 0.0f;
-                }
+                const int m = f / F4A, g = f % F4A;
+                const bool rowok = f < BM * F4A && m0 + m < p.Cout;
+                const float* src = dyb + (size_t)(m0 + m) * HWo;
+                if constexpr (VEC) ra[j] = (rowok && k0 + 4 * g < HW) ? *reinterpret_cast<const v4f*>(src + 4 * g) : (v4f){0.f, 0.f, 0.f, 0.f};
+                else una_load(src + 4 * g, rowok ? HW - k0 - 4 * g : 0, n == p.N - 1 && m0 + m == p.Cout - 1, ra[j], ma[j]);
             }
 #pragma unroll
             for (int j = 0; j < NB; ++j) {
                 const int f = tid + j * kWgThreads;
-                const int c = f / F4R, kp = (f % F4R) * 4;
-                const bool rowok = f < BC * F4R && c0 + c < p.Cin;
-                const float* src = xb + (size_t)(c0 + c) * HW + kp;
-                if (VEC) {
-                    rb[j] = (rowok && k0 + kp < HW) ? *reinterpret_cast<const v4f*>(src) : (v4f){0.f, 0.f, 0.f, 0.f};
-                } else {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) rb[j][e] = (rowok && k0 + kp + e < HW) ? src[e] : 0.0f;
-                }
+                const int c = f / F4C, g = f % F4C;
+                const bool rowok = f < BC * F4C && c0 + c < p.Cin;
+                const float* src = xb + (size_t)(c0 + c) * HW;
+                if constexpr (VEC) rb[j] = (rowok && k0 + 4 * g < HW) ? *reinterpret_cast<const v4f*>(src + 4 * g) : (v4f){0.f, 0.f, 0.f, 0.f};
+                else una_load(src + 4 * g, rowok ? HW - k0 - 4 * g : 0, n == p.N - 1 && c0 + c == p.Cin - 1, rb[j], mb[j]);
             }
         } else {
             const int tpi = p.tiles_x * p.tiles_y;
@@ -134,34 +165,28 @@ __global__ __launch_bounds__(kWgThreads) void k_wgrad(const WgP p) {
             const int iy0 = oy0 * STRIDE - PAD, ix0 = ox0 * STRIDE - 4;
             const float* dyb = p.dy + (size_t)n * p.Cout * HWo;
             const float* xb = p.x + (size_t)n * p.Cin * HW;
+            constexpr int GA = ARUN / 4 + AL, GB = BRUN / 4 + AL;       // groups per run
 #pragma unroll
             for (int j = 0; j < NA; ++j) {
                 const int f = tid + j * kWgThreads;
-                const int m = f / F4R, kp = (f % F4R) * 4;
-                const int oy = oy0 + kp / TW, ox = ox0 + kp % TW;
-                const bool rowok = f < BM * F4R && m0 + m < p.Cout && oy < p.Ho;
-                const float* src = dyb + (size_t)(m0 + m) * HWo + oy * p.Wo + ox;
-                if (VEC) {
-                    ra[j] = (rowok && ox < p.Wo) ? *reinterpret_cast<const v4f*>(src) : (v4f){0.f, 0.f, 0.f, 0.f};
-                } else {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) ra[j][e] = (rowok && ox + e < p.Wo) ? src[e] : 0.0f;
-                }
+                const int m = f / F4A, rem = f % F4A;
+                const int ty = rem / GA, g = rem % GA;
+                const int oy = oy0 + ty;
+                const bool rowok = f < BM * F4A && m0 + m < p.Cout && oy < p.Ho;
+                const float* src = dyb + (size_t)(m0 + m) * HWo + oy * p.Wo + ox0;
+                if constexpr (VEC) ra[j] = (rowok && ox0 + 4 * g < p.Wo) ? *reinterpret_cast<const v4f*>(src + 4 * g) : (v4f){0.f, 0.f, 0.f, 0.f};
+                else una_load(src + 4 * g, rowok ? p.Wo - ox0 - 4 * g : 0, n == p.N - 1 && oy == p.Ho - 1 && m0 + m == p.Cout - 1, ra[j], ma[j]);
             }
 #pragma unroll
             for (int j = 0; j < NB; ++j) {
                 const int f = tid + j * kWgThreads;
                 const int c = f / F4C, rem = f % F4C;
-                const int row = rem / (PWL / 4), col = (rem % (PWL / 4)) * 4;
-                const int iy = iy0 + row, ix = ix0 + col;
+                const int row = rem / GB, g = rem % GB;
+                const int iy = iy0 + row;
                 const bool rowok = f < BC * F4C && c0 + c < p.Cin && (unsigned)iy < (unsigned)p.H;
-                const float* src = xb + (size_t)(c0 + c) * HW + iy * p.W + ix;
-                if (VEC) {
-                    rb[j] = (rowok && (unsigned)ix < (unsigned)p.W) ? *reinterpret_cast<const v4f*>(src) : (v4f){0.f, 0.f, 0.f, 0.f};
-                } else {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) rb[j][e] = (rowok && (unsigned)(ix + e) < (unsigned)p.W) ? src[e] : 0.0f;
-                }
+                const float* src = xb + ((long long)(c0 + c) * HW + (long long)iy * p.W + ix0);
+                if constexpr (VEC) rb[j] = (rowok && (unsigned)(ix0 + 4 * g) < (unsigned)p.W) ? *reinterpret_cast<const v4f*>(src + 4 * g) : (v4f){0.f, 0.f, 0.f, 0.f};
+                else una_load(src + 4 * g, (rowok && ix0 + 4 * g >= 0) ? p.W - ix0 - 4 * g : 0, n == p.N - 1 && iy == p.H - 1 && c0 + c == p.Cin - 1, rb[j], mb[j]);
             }
         }
     };
@@ -169,19 +194,27 @@ __global__ __launch_bounds__(kWgThreads) void k_wgrad(const WgP p) {
     auto stage = [&](int buf) {
         float* sA = wg_smem + buf * (ASZ + BSZ);
         float* sB = sA + ASZ;
+        constexpr int GA = ARUN / 4 + AL, GB = BRUN / 4 + AL;
 #pragma unroll
         for (int j = 0; j < NA; ++j) {
             const int f = tid + j * kWgThreads;
-            if (f < BM * F4R) *reinterpret_cast<v4f*>(sA + (f / F4R) * RS + (f % F4R) * 4) = ra[j];
+            if (f < BM * F4A) {
+                float* run = sA + (f / F4A) * RS + ((f % F4A) / GA) * ARUN;
+                *reinterpret_cast<v4f*>(run + ((f % F4A) % GA) * 4) = VEC ? ra[j] : una_fix(ra[j], ma[VEC ? 0 : j]);
+            }
         }
 #pragma unroll
         for (int j = 0; j < NB; ++j) {
             const int f = tid + j * kWgThreads;
-            if (FLAT) {
-                if (f < BC * F4R) *reinterpret_cast<v4f*>(sB + (f / F4R) * CS + (f % F4R) * 4) = rb[j];
-            } else if (f < BC * F4C) {
-                float* dst = sB + (f / F4C) * CS + (f % F4C) * 4;       // channel stride is odd: four 4-byte stores
-                dst[0] = rb[j][0]; dst[1] = rb[j][1]; dst[2] = rb[j][2]; dst[3] = rb[j][3];
+            if (f < BC * F4C) {
+                float* run = sB + (f / F4C) * CS + ((f % F4C) / GB) * BRUN;
+                const v4f vb = VEC ? rb[j] : una_fix(rb[j], mb[VEC ? 0 : j]);
+                if constexpr (FLAT) {
+                    *reinterpret_cast<v4f*>(run + ((f % F4C) % GB) * 4) = vb;
+                } else {
+                    float* dst = run + ((f % F4C) % GB) * 4;            // channel stride is odd: four 4-byte stores
+                    dst[0] = vb[0]; dst[1] = vb[1]; dst[2] = vb[2]; dst[3] = vb[3];
+                }
             }
         }
     };
@@ -458,6 +491,8 @@ extern "C" int mas_conv_wgrad(const float* x, const float* dy, int N, int Cin, i
     if ((size_t)p.S * slice > workspace_bytes) return MAS_ERR_WORKSPACE;
     const bool al = ((uintptr_t)x % 16 == 0) && ((uintptr_t)dy % 16 == 0);
     const bool vec = al && (g.flat ? (H * W) % 4 == 0 : (W % 4 == 0 && p.Wo % 4 == 0));
+    // (the unaligned path loads the last partial group of a tensor so that it ends at the tensor's end: four elements at least)
+    if (!vec && ((long long)N * Cin * H * W < 4 || (long long)N * Cout * p.Ho * p.Wo < 4)) return MAS_ERR_SHAPE;
     int rc = MAS_ERR_SHAPE;
     const bool big = g.BM == 128;
 #define WG_GO(TAPS, CG, TW, KP, STRIDE, DIL, FLAT)                                                                            \
