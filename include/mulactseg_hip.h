@@ -365,6 +365,11 @@ int64_t mas_bn_mask_bytes(int N, int C, int HW);
 int mas_bn_act_train_fwd(const float* x, const float* gamma, const float* beta, const float* residual, int N, int C, int HW, float eps,
                          float momentum, int relu, float* running_mean, float* running_var, int64_t* num_batches_tracked,
                          float* save_mean, float* save_invstd, void* workspace, float* y, uint8_t* relu_mask, void* stream);
+/* train_fwd with the partial sums formed by the producer of x (mas_conv_sk_stats): partials [C][per_channel] pairs of doubles */
+int mas_bn_act_train_fwd_stats(const float* x, const double* partials, int per_channel, const float* gamma, const float* beta,
+                               const float* residual, int N, int C, int HW, float eps, float momentum, int relu, float* running_mean,
+                               float* running_var, int64_t* num_batches_tracked, float* save_mean, float* save_invstd, float* y,
+                               uint8_t* relu_mask, void* stream);
 int mas_bn_act_eval_fwd(const float* x, const float* gamma, const float* beta, const float* running_mean, const float* running_var,
                         const float* residual, int N, int C, int HW, float eps, int relu, float* y, void* stream);
 int mas_bn_act_train_bwd(const float* dy, const float* x, const float* y, const uint8_t* relu_mask, const float* gamma,
@@ -435,6 +440,13 @@ int mas_conv_sk(const float* x, const float* wp, int N, int Cin, int H, int W, i
                 const float* scale, const float* shift, const float* residual, int relu, float* y, void* workspace,
                 size_t workspace_bytes, unsigned epoch, void* stream);
 int mas_conv_sk_error(const void* workspace, unsigned* out_host);
+/* mas_conv_sk in the forward role without epilogue that also forms the BatchNorm partial sums of its output in the epilogue of
+ * every tile (the relu(bn(conv(x))) triples of backbone/resnet.py:143-160 in training mode: removes the reduction pass over y):
+ * stats [Cout][mas_conv_sk_stats_slots(...)] pairs of doubles (sum y, sum y^2) over disjoint pixel sets, every entry written;
+ * fixed summation order (run-to-run identical).  Consumer: mas_bn_act_train_fwd_stats. */
+int mas_conv_sk_stats_slots(int N, int Cin, int H, int W, int Cout, int ksize, int stride);
+int mas_conv_sk_stats(const float* x, const float* wp, int N, int Cin, int H, int W, int Cout, int ksize, int stride, int dil, float* y,
+                      double* stats, void* workspace, size_t workspace_bytes, unsigned epoch, void* stream);
 /* Input gradient of a 3x3, stride-2, padding-1 convolution (torch.autograd of nn.Conv2d(k=3, stride=2, padding=1), the conv2 of
  * layer2.0 / layer3.0: backbone/resnet.py:129-141), one parity class per launch: sub = 2 py + px writes dx[n, c, 2 i + py, 2 j + px]
  * as a stride-1 product over dy [N,Cout,(H-1)/2+1,(W-1)/2+1] with (1 + py) x (1 + px) taps; wp = mas_conv_sk_pack(..., ksize 3,

@@ -53,6 +53,7 @@ SIGNATURES = {
     "mas_bn_workspace_bytes": (_i64, [_i, _i, _i]),
     "mas_bn_mask_bytes": (_i64, [_i, _i, _i]),
     "mas_bn_act_train_fwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _f, _f, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "mas_bn_act_train_fwd_stats": (_i, [_vp, _vp, _i, _vp, _vp, _vp, _i, _i, _i, _f, _f, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "mas_bn_act_eval_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _f, _i, _vp, _vp]),
     "mas_bn_act_train_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
     "mas_cosine_head_fwd": (_i, [_vp, _vp, _i, _i, _i, _i, _f, _vp, _vp, _vp]),
@@ -71,6 +72,8 @@ SIGNATURES = {
     "mas_conv_sk_pack_multi": (_i, [_vp, _i, _c.c_uint, _vp]),
     "mas_conv_sk": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _i, _vp, _vp, _c.c_size_t, _c.c_uint, _vp]),
     "mas_conv_sk_error": (_i, [_vp, _vp]),
+    "mas_conv_sk_stats_slots": (_i, [_i, _i, _i, _i, _i, _i, _i]),
+    "mas_conv_sk_stats": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _c.c_size_t, _c.c_uint, _vp]),
     "mas_conv_sk_dgrad_s2": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _i, _vp, _vp, _c.c_size_t, _c.c_uint, _vp]),
     "mas_conv_sk_set_mode": (_i, [_i]),
     "mas_conv_sk_debug_stamps": (_i, [_vp]),

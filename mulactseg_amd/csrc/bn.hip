@@ -110,6 +110,34 @@ __global__ __launch_bounds__(kThreads) void k_bn_stats(const double2* __restrict
     }
 }
 
+// The same statistics from MANY partials per channel (the epilogue partials of mas_conv_sk_stats: one pair per tile row group, up to
+// ~18 000 per channel at 384 x 384): one workgroup per channel, thread t adds entries t, t + 256, ... in index order, then a fixed
+// tree over the 256 threads -- a fixed order for a given per_channel, in double.  (k_bn_stats walks them with one thread per
+// channel: 10 ms per step at these counts.)
+__global__ __launch_bounds__(kThreads) void k_bn_stats_wide(const double2* __restrict__ part, int C, int per_channel, double count, float eps,
+                                                             float momentum, float* __restrict__ mean, float* __restrict__ invstd,
+                                                             float* __restrict__ running_mean, float* __restrict__ running_var,
+                                                             long long* __restrict__ num_batches_tracked) {
+    __shared__ double s_red[kThreads / MAS_WAVE];
+    const int c = blockIdx.x;
+    if (c == 0 && threadIdx.x == 0 && num_batches_tracked) num_batches_tracked[0] += 1;
+    double S = 0.0, Q = 0.0;
+    for (int i = threadIdx.x; i < per_channel; i += kThreads) { const double2 v = part[(size_t)c * per_channel + i]; S += v.x; Q += v.y; }
+    S = block_sum(S, s_red);
+    Q = block_sum(Q, s_red);
+    if (threadIdx.x != 0) return;
+    const double m = S / count;
+    double var = Q / count - m * m;
+    var = var < 0.0 ? 0.0 : var;
+    mean[c] = (float)m;
+    invstd[c] = (float)(1.0 / sqrt(var + (double)eps));
+    if (running_mean) {
+        const double unbiased = count > 1.0 ? var * count / (count - 1.0) : var;
+        running_mean[c] = (float)((1.0 - (double)momentum) * (double)running_mean[c] + (double)momentum * m);
+        running_var[c] = (float)((1.0 - (double)momentum) * (double)running_var[c] + (double)momentum * unbiased);
+    }
+}
+
 // grid (ceil(groups / 256), N * C), one aligned group per thread.  FROM_VAR: `stat2` holds the running variance (inference),
 // else invstd.  mask: one byte per group, mask_stride bytes per plane (bit k = output k of the group is positive).
 template <bool FROM_VAR, bool VEC>
@@ -246,6 +274,29 @@ extern "C" int mas_bn_act_train_fwd(const float* x, const float* gamma, const fl
     if (vec) hipLaunchKernelGGL(k_bn_partial<true>, dim3((unsigned)chunks, (unsigned)N, (unsigned)C), dim3(kThreads), 0, st, x, C, HW, chunks, part);
     else hipLaunchKernelGGL(k_bn_partial<false>, dim3((unsigned)chunks, (unsigned)N, (unsigned)C), dim3(kThreads), 0, st, x, C, HW, chunks, part);
     hipLaunchKernelGGL(k_bn_stats, dim3((unsigned)((C + kThreads - 1) / kThreads)), dim3(kThreads), 0, st, part, C, N * chunks,
+                       (double)N * (double)HW, eps, momentum, save_mean, save_invstd, running_mean, running_var,
+                       reinterpret_cast<long long*>(num_batches_tracked));
+    unsigned char* mk = relu ? relu_mask : nullptr;
+    if (vec) hipLaunchKernelGGL((k_bn_apply<false, true>), apply_grid(N, C, HW), dim3(kThreads), 0, st, x, gamma, beta, save_mean, save_invstd, eps,
+                                residual, C, HW, relu, y, mk, max_groups(HW));
+    else hipLaunchKernelGGL((k_bn_apply<false, false>), apply_grid(N, C, HW), dim3(kThreads), 0, st, x, gamma, beta, save_mean, save_invstd, eps,
+                            residual, C, HW, relu, y, mk, max_groups(HW));
+    return mas_launch_status();
+}
+
+/* mas_bn_act_train_fwd with the partial sums already formed by the producer of x (mas_conv_sk_stats: `per_channel` pairs
+ * (sum, sum of squares) per channel over disjoint pixel sets, doubles): statistics + apply, no reduction pass over x. */
+extern "C" int mas_bn_act_train_fwd_stats(const float* x, const double* partials, int per_channel, const float* gamma, const float* beta,
+                                          const float* residual, int N, int C, int HW, float eps, float momentum, int relu, float* running_mean,
+                                          float* running_var, int64_t* num_batches_tracked, float* save_mean, float* save_invstd, float* y,
+                                          uint8_t* relu_mask, void* stream) {
+    if (!x || !partials || !save_mean || !save_invstd || !y) return MAS_ERR_NULL;
+    if ((running_mean == nullptr) != (running_var == nullptr)) return MAS_ERR_NULL;
+    if (per_channel <= 0) return MAS_ERR_SHAPE;
+    if (int e = check(N, C, HW)) return e;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const bool vec = congruent(x, y) && congruent(x, residual) && ((uintptr_t)x & 3) == 0;
+    hipLaunchKernelGGL(k_bn_stats_wide, dim3((unsigned)C), dim3(kThreads), 0, st, reinterpret_cast<const double2*>(partials), C, per_channel,
                        (double)N * (double)HW, eps, momentum, save_mean, save_invstd, running_mean, running_var,
                        reinterpret_cast<long long*>(num_batches_tracked));
     unsigned char* mk = relu ? relu_mask : nullptr;

@@ -43,6 +43,7 @@ struct SkP {
     float* y;                   // [N, M, Ho, Wo]
     float* slots;               // [P][128 * 128] partial accumulator images
     unsigned* flags;            // [512] epoch flags, then one error word
+    double2* stats;             // optional [M][ptiles * (8 / WM)] (sum y, sum y^2) of every tile row: the BatchNorm partials (k_bn_stats reads them)
     const float* zero;          // 64 bytes of zeros (source of the LDS-DMA of padding / out-of-range elements)
     unsigned epoch;
     unsigned long long* stamps; // optional [P][4]: wall-clock stamps of every workgroup (start, pipeline primed, loop done, end): tools only
@@ -148,8 +149,8 @@ __device__ __forceinline__ void sk_advance(const SkP& p, int g, int sk0, SkCurso
 // loads at 4-byte aligned addresses (gfx950 runs them at the aligned rate: tools/micro/unaligned.hip); the one group per row that
 // straddles the row's right end reads on into the next row and has its elements past the end zeroed -- when it is written to LDS,
 // not behind the load: any use of a loaded value in the fetch code makes hipcc wait for the load there, which serialises the
-// prefetch (46.1 ms per step) -- except at the very end of the tensor, where it would leave the allocation: that group is
-// loaded so that it ENDS at the tensor's end and is rotated into place before the LDS store.  (First forms of this path:
+// prefetch (46.1 ms per step) -- except within three elements of the tensor's end, where it would leave the allocation: such a
+// group is loaded so that it ENDS at the tensor's end and is rotated into place before the LDS store.  (First forms of this path:
 // element-wise 4-byte loads, 4x the load instructions, 48.4 ms per step at the 769 crop; aligned groups of memory written to LDS
 // with four predicated 4-byte stores at the row's shift, 44.2 ms.)
 typedef float v4fu __attribute__((ext_vector_type(4), aligned(4)));
@@ -185,8 +186,8 @@ __device__ __forceinline__ void sk_slots(int tid, SkSlots<SkX<G>::NXS>& s) {
 // functions of the pixel tile only, recomputed when the prefetch stream enters a new one.  Per chunk a group then costs one
 // compare and one load from (uniform base + offset) -- the address arithmetic of the staging code competes with the partner
 // wave's MFMA issue (measured: ~3k of the 11.6k cycles of an iteration in "stage + refetch" before this).
-// !VEC: meta = number of elements of the group inside the row (1..4) | 8 in the last row of the last picture (fetch turns that
-// into | 16 for the last channel = the end of the tensor: loaded 4 - nv elements early, rotated by sk_stage).
+// !VEC: meta = number of elements of the group inside the row (1..4); fetch adds (elements the group was loaded early << 3) for
+// the groups within three elements of the tensor's end (rotated into place by sk_stage).
 template <int NXS>
 struct SkXOff {
     int off[NXS], meta[NXS];
@@ -207,7 +208,7 @@ __device__ __forceinline__ void sk_xoffsets(const SkP& p, SkCursor& cur, const S
         xo.mask |= ok ? 1u << j : 0u;
         if constexpr (!VEC) {
             const int nv = p.W - ix < 4 ? p.W - ix : 4;
-            xo.meta[j] = nv | ((nv < 4 && cur.n == p.N - 1 && iy == p.H - 1) ? 8 : 0);
+            xo.meta[j] = nv;
         }
     }
     cur.moved = false;
@@ -233,6 +234,8 @@ __device__ __forceinline__ void sk_fetch(const SkP& p, SkCursor& cur, const SkSl
     const float* xb = p.x + ((size_t)cur.n * p.K + k0) * HW;
     if (cur.moved) sk_xoffsets<G, VEC>(p, cur, sl, xo);
     const int kleft = p.K - k0;
+    const long long rem64 = ((long long)(p.N - cur.n) * p.K - k0) * HW;        // elements from xb to the end of the tensor
+    const int rem = rem64 > 0x7fffffffLL ? 0x7fffffff : (int)rem64;
 #pragma unroll
     for (int j = 0; j < NXS; ++j) {
         const bool ok = ((xo.mask >> j) & 1u) && sl.c[j] < kleft;
@@ -240,10 +243,10 @@ __device__ __forceinline__ void sk_fetch(const SkP& p, SkCursor& cur, const SkSl
             xr[j] = ok ? *reinterpret_cast<const v4f*>(xb + xo.off[j]) : (v4f){0.f, 0.f, 0.f, 0.f};
         } else {
             // (no use of the loaded values here: masks and the rotation are applied by sk_stage)
-            const int nv = xo.meta[j] & 7;
-            const bool tail = (xo.meta[j] & 8) && sl.c[j] == kleft - 1;        // the group would leave the tensor
-            xo.meta[j] = (xo.meta[j] & 15) | (tail ? 16 : 0);
-            const float* src = xb + xo.off[j] - (tail ? 4 - nv : 0);
+            const int avail = rem - xo.off[j];                                  // elements from the group's first to the tensor's end
+            const int early = (ok && avail < 4) ? 4 - avail : 0;
+            xo.meta[j] = (xo.meta[j] & 7) | (early << 3);
+            const float* src = xb + xo.off[j] - early;
             if (ok) {
                 const v4fu u = *reinterpret_cast<const v4fu*>(src);
                 xr[j] = (v4f){u[0], u[1], u[2], u[3]};
@@ -273,10 +276,11 @@ __device__ __forceinline__ void sk_stage(const SkSlots<SkX<G>::NXS>& sl, const S
         if constexpr (!VEC) {
             // xo still describes the tile of the chunk in `xr`: the caller stages a chunk BEFORE it fetches the next one
             const int nv = xo.meta[j] & 7;
-            if (xo.meta[j] & 16) {              // loaded 4 - nv elements early: element i of the group is u[i + 4 - nv]
+            const int early = xo.meta[j] >> 3;
+            if (early) {                        // loaded `early` elements early: element i of the group is u[i + early]
                 const v4f u = v;
-                v[0] = nv == 1 ? u[3] : (nv == 2 ? u[2] : u[1]);
-                v[1] = nv == 2 ? u[3] : u[2];
+                v[0] = early == 1 ? u[1] : (early == 2 ? u[2] : u[3]);
+                v[1] = early == 1 ? u[2] : u[3];
                 v[2] = u[3];
             }
             v[1] = nv > 1 ? v[1] : 0.0f;
@@ -642,6 +646,57 @@ __global__ __launch_bounds__(kSkThreads) void k_conv_sk(const SkP p) {
                 }
             }
         }
+        if (p.stats) {
+            // (the host admits statistics only for the bare product: y = acc)
+            float ssum[16], ssq[16];            // per accumulator row of this lane: sum and sum of squares over its pixels
+#pragma unroll
+            for (int r = 0; r < 16; ++r) ssum[r] = ssq[r] = 0.0f;
+#pragma unroll
+            for (int tn = 0; tn < TN; ++tn) {
+                const int oy = oy0 + (pl[tn] >> G::TWLOG), ox = ox0 + (pl[tn] & (TW - 1));
+                if (oy < p.Ho && ox < p.Wo) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        ssum[r] += acc[tn][r];
+                        ssq[r] += acc[tn][r] * acc[tn][r];
+                    }
+                }
+            }
+            // BatchNorm partials of the tile: the 32 lanes of a half-wave hold the same 16 rows; a halving butterfly (lane bit k
+            // keeps one half of the rows and receives the partner's sums of them: 8 + 4 + 2 + 1 exchanges, then one across the two
+            // 16-lane groups) leaves row 8 b0 + 4 b1 + 2 b2 + b3 of the lane's bits with the sum over all 32 pixels columns --
+            // a fixed order, so the partials (and the statistics k_bn_stats forms from them, in double) are run-to-run identical
+            auto fold = [&](float (&a)[16]) -> float {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const bool up = lane & 1;
+                    const float send = up ? a[i] : a[i + 8], keep = up ? a[i + 8] : a[i];
+                    a[i] = keep + __shfl_xor(send, 1, 64);
+                }
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const bool up = lane & 2;
+                    const float send = up ? a[i] : a[i + 4], keep = up ? a[i + 4] : a[i];
+                    a[i] = keep + __shfl_xor(send, 2, 64);
+                }
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    const bool up = lane & 4;
+                    const float send = up ? a[i] : a[i + 2], keep = up ? a[i + 2] : a[i];
+                    a[i] = keep + __shfl_xor(send, 4, 64);
+                }
+                {
+                    const bool up = lane & 8;
+                    const float send = up ? a[0] : a[1], keep = up ? a[1] : a[0];
+                    a[0] = keep + __shfl_xor(send, 8, 64);
+                }
+                return a[0] + __shfl_xor(a[0], 16, 64);
+            };
+            const float S = fold(ssum), Q = fold(ssq);
+            const int r = 8 * (lane & 1) + 4 * ((lane >> 1) & 1) + 2 * ((lane >> 2) & 1) + ((lane >> 3) & 1);
+            const int m = mtw * 32 + 4 * h + (r & 3) + 8 * (r >> 2);
+            if (!(lane & 16) && m < mlim) p.stats[((size_t)(m0 + m) * p.ptiles + pt) * NG + ng] = make_double2((double)S, (double)Q);
+        }
         if (p.stamps && tid == 0 && it >= it1) p.stamps[4 * g + 2] = wall_clock64();
     }
     if (p.stamps && tid == 0) p.stamps[4 * g + 3] = wall_clock64();
@@ -850,10 +905,12 @@ extern "C" int mas_conv_sk_pack_multi(const void* jobs_dev, int njobs, unsigned 
     return mas_launch_status();
 }
 
-extern "C" int mas_conv_sk(const float* x, const float* w, int N, int Cin, int H, int W, int Cout, int ksize, int stride, int dil, int dgrad,
-                           const float* scale, const float* shift, const float* residual, int relu, float* y, void* workspace,
-                           size_t workspace_bytes, unsigned epoch, void* stream) {
+namespace {
+int sk_run(const float* x, const float* w, int N, int Cin, int H, int W, int Cout, int ksize, int stride, int dil, int dgrad,
+           const float* scale, const float* shift, const float* residual, int relu, float* y, double2* stats, void* workspace,
+           size_t workspace_bytes, unsigned epoch, void* stream) {
     if (!x || !w || !y || !workspace) return MAS_ERR_NULL;
+    if (stats && (scale || residual || relu)) return MAS_ERR_RANGE;        // statistics of the bare product only
     if ((scale == nullptr) != (shift == nullptr)) return MAS_ERR_NULL;
     if (N <= 0 || Cin <= 0 || H <= 0 || W <= 0 || Cout <= 0) return MAS_ERR_SHAPE;
     if ((ksize != 1 && ksize != 3) || (stride != 1 && stride != 2) || (dil != 1 && dil != 2 && dil != 4)) return MAS_ERR_RANGE;
@@ -869,6 +926,7 @@ extern "C" int mas_conv_sk(const float* x, const float* w, int N, int Cin, int H
     p.slots = static_cast<float*>(workspace);
     p.flags = reinterpret_cast<unsigned*>(static_cast<char*>(workspace) + (size_t)512 * kSkSlotFloats * sizeof(float));
     p.stamps = g_sk_stamps;
+    p.stats = stats;
     p.zero = reinterpret_cast<const float*>(p.flags + 768);     // bytes 3072.. of the tail: zero-filled by the caller, never written
     p.epoch = epoch;
     p.relu = relu;
@@ -923,6 +981,37 @@ extern "C" int mas_conv_sk(const float* x, const float* w, int N, int Cin, int H
     if (g.BM == 128) return vec ? sk_launch<1, 64, 4, 128, 1, 1, true, 0>(p, st) : sk_launch<1, 64, 4, 128, 1, 1, false, 0>(p, st);
     return vec ? sk_launch<1, 64, 2, 128, 1, 1, true, 0>(p, st) : sk_launch<1, 64, 2, 128, 1, 1, false, 0>(p, st);
 }
+}  // namespace
+
+extern "C" int mas_conv_sk(const float* x, const float* w, int N, int Cin, int H, int W, int Cout, int ksize, int stride, int dil, int dgrad,
+                           const float* scale, const float* shift, const float* residual, int relu, float* y, void* workspace,
+                           size_t workspace_bytes, unsigned epoch, void* stream) {
+    return sk_run(x, w, N, Cin, H, W, Cout, ksize, stride, dil, dgrad, scale, shift, residual, relu, y, nullptr, workspace, workspace_bytes, epoch,
+                  stream);
+}
+
+/* Entries per output channel of the BatchNorm partials mas_conv_sk_stats writes for this forward product (0: unsupported). */
+extern "C" int mas_conv_sk_stats_slots(int N, int Cin, int H, int W, int Cout, int ksize, int stride) {
+    if (N <= 0 || Cin <= 0 || H <= 0 || W <= 0 || Cout <= 0 || (ksize != 1 && ksize != 3) || (stride != 1 && stride != 2)) return 0;
+    int Ho = (H - 1) / stride + 1, Wo = (W - 1) / stride + 1;
+    const bool flat = ksize == 1 && stride == 1 && g_sk_dma == 0;
+    if (flat) { Wo = H * W; Ho = 1; }
+    SkGeom g;
+    sk_geom(ksize, stride, Cout, Ho, Wo, 0, &g);
+    if (flat) { g.TW = 128; g.TH = 1; }
+    const long long pt = (long long)N * ((Wo + g.TW - 1) / g.TW) * ((Ho + g.TH - 1) / g.TH) * (g.BM == 128 ? 2 : 4);
+    return pt > 0x7fffffffLL ? 0 : (int)pt;
+}
+
+/* mas_conv_sk (forward, bare: no scale / residual / ReLU) that also writes the BatchNorm partial sums of its output:
+ * stats [Cout][mas_conv_sk_stats_slots()] pairs of doubles (sum y, sum y^2) over disjoint pixel sets -- the input of
+ * mas_bn_act_train_fwd_stats. */
+extern "C" int mas_conv_sk_stats(const float* x, const float* w, int N, int Cin, int H, int W, int Cout, int ksize, int stride, int dil, float* y,
+                                 double* stats, void* workspace, size_t workspace_bytes, unsigned epoch, void* stream) {
+    if (!stats) return MAS_ERR_NULL;
+    return sk_run(x, w, N, Cin, H, W, Cout, ksize, stride, dil, 0, nullptr, nullptr, nullptr, 0, y, reinterpret_cast<double2*>(stats), workspace,
+                  workspace_bytes, epoch, stream);
+}
 
 /* One parity class (sub = 2 py + px) of the input gradient of a 3x3, stride-2, padding-1 convolution: dy [N,Cout,Hd,Wd] with
  * Hd = (H - 1) / 2 + 1, wp = the class image of the weight (mas_conv_sk_pack with dgrad = 2 + sub); writes the pixels
@@ -943,6 +1032,7 @@ extern "C" int mas_conv_sk_dgrad_s2(const float* dy, const float* wp, int N, int
     p.slots = static_cast<float*>(workspace);
     p.flags = reinterpret_cast<unsigned*>(static_cast<char*>(workspace) + (size_t)512 * kSkSlotFloats * sizeof(float));
     p.stamps = g_sk_stamps;
+    p.stats = nullptr;
     p.zero = reinterpret_cast<const float*>(p.flags + 768);
     p.epoch = epoch;
     p.relu = relu;

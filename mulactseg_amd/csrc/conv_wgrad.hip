@@ -103,28 +103,30 @@ __global__ __launch_bounds__(kWgThreads) void k_wgrad(const WgP p) {
     const int HW = p.H * p.W, HWo = p.Ho * p.Wo;
 
     v4f ra[NA], rb[NB];
-    int ma[VEC ? 1 : NA], mb[VEC ? 1 : NB];         // !VEC: elements of the group that exist (0..4) | 8: loaded 4 - nv elements early
+    int ma[VEC ? 1 : NA], mb[VEC ? 1 : NB];         // !VEC: elements of the group that exist (0..4) | elements it was loaded early << 3
 
-    // !VEC: the group at `src` of which the first nv (<= 0: none, >= 4: all) elements exist; `last`: the run ends the tensor -- a
-    // partial group is then loaded so that it ENDS at the run's end (una_fix rotates it into place).  The loaded values are not
-    // touched here: any use behind the load makes hipcc wait for it in the fetch code, which serialises the prefetch.
-    auto una_load = [&](const float* src, int nv, bool last, v4f& out, int& meta) {
+    // !VEC: the group at `src` of which the first nv (<= 0: none, >= 4: all) elements exist; `end`: one past the tensor's last
+    // element -- a group that would cross it is loaded so that it ENDS there (una_fix rotates it into place; short rows, e.g. the
+    // 1 x 1 map of the ASPP pooling branch, put several rows within three elements of the end).  The loaded values are not touched
+    // here: any use behind the load makes hipcc wait for it in the fetch code, which serialises the prefetch.
+    auto una_load = [&](const float* src, int nv, const float* end, v4f& out, int& meta) {
         nv = nv < 0 ? 0 : (nv > 4 ? 4 : nv);
-        const bool early = last && nv > 0 && nv < 4;
-        meta = nv | (early ? 8 : 0);
+        const long long avail = end - src;
+        const int early = (nv > 0 && avail < 4) ? 4 - (int)avail : 0;
+        meta = nv | (early << 3);
         if (nv > 0) {
-            const v4fu u = *reinterpret_cast<const v4fu*>(src - (early ? 4 - nv : 0));
+            const v4fu u = *reinterpret_cast<const v4fu*>(src - early);
             out = (v4f){u[0], u[1], u[2], u[3]};
         } else {
             out = (v4f){0.f, 0.f, 0.f, 0.f};
         }
     };
     auto una_fix = [&](v4f v, int meta) -> v4f {
-        const int nv = meta & 7;
-        if (meta & 8) {
+        const int nv = meta & 7, early = meta >> 3;
+        if (early) {                            // element i of the group is u[i + early]
             const v4f u = v;
-            v[0] = nv == 1 ? u[3] : (nv == 2 ? u[2] : u[1]);
-            v[1] = nv == 2 ? u[3] : u[2];
+            v[0] = early == 1 ? u[1] : (early == 2 ? u[2] : u[3]);
+            v[1] = early == 1 ? u[2] : u[3];
             v[2] = u[3];
         }
         v[1] = nv > 1 ? v[1] : 0.0f;
@@ -132,6 +134,8 @@ __global__ __launch_bounds__(kWgThreads) void k_wgrad(const WgP p) {
         v[3] = nv > 3 ? v[3] : 0.0f;
         return v;
     };
+    const float* const dy_end = p.dy + (size_t)p.N * p.Cout * HWo;
+    const float* const x_end = p.x + (size_t)p.N * p.Cin * HW;
 
     auto fetch = [&](int q) {
         if (FLAT) {
@@ -146,7 +150,7 @@ __global__ __launch_bounds__(kWgThreads) void k_wgrad(const WgP p) {
                 const bool rowok = f < BM * F4A && m0 + m < p.Cout;
                 const float* src = dyb + (size_t)(m0 + m) * HWo;
                 if constexpr (VEC) ra[j] = (rowok && k0 + 4 * g < HW) ? *reinterpret_cast<const v4f*>(src + 4 * g) : (v4f){0.f, 0.f, 0.f, 0.f};
-                else una_load(src + 4 * g, rowok ? HW - k0 - 4 * g : 0, n == p.N - 1 && m0 + m == p.Cout - 1, ra[j], ma[j]);
+                else una_load(src + 4 * g, rowok ? HW - k0 - 4 * g : 0, dy_end, ra[j], ma[j]);
             }
 #pragma unroll
             for (int j = 0; j < NB; ++j) {
@@ -155,7 +159,7 @@ __global__ __launch_bounds__(kWgThreads) void k_wgrad(const WgP p) {
                 const bool rowok = f < BC * F4C && c0 + c < p.Cin;
                 const float* src = xb + (size_t)(c0 + c) * HW;
                 if constexpr (VEC) rb[j] = (rowok && k0 + 4 * g < HW) ? *reinterpret_cast<const v4f*>(src + 4 * g) : (v4f){0.f, 0.f, 0.f, 0.f};
-                else una_load(src + 4 * g, rowok ? HW - k0 - 4 * g : 0, n == p.N - 1 && c0 + c == p.Cin - 1, rb[j], mb[j]);
+                else una_load(src + 4 * g, rowok ? HW - k0 - 4 * g : 0, x_end, rb[j], mb[j]);
             }
         } else {
             const int tpi = p.tiles_x * p.tiles_y;
@@ -175,7 +179,7 @@ __global__ __launch_bounds__(kWgThreads) void k_wgrad(const WgP p) {
                 const bool rowok = f < BM * F4A && m0 + m < p.Cout && oy < p.Ho;
                 const float* src = dyb + (size_t)(m0 + m) * HWo + oy * p.Wo + ox0;
                 if constexpr (VEC) ra[j] = (rowok && ox0 + 4 * g < p.Wo) ? *reinterpret_cast<const v4f*>(src + 4 * g) : (v4f){0.f, 0.f, 0.f, 0.f};
-                else una_load(src + 4 * g, rowok ? p.Wo - ox0 - 4 * g : 0, n == p.N - 1 && oy == p.Ho - 1 && m0 + m == p.Cout - 1, ra[j], ma[j]);
+                else una_load(src + 4 * g, rowok ? p.Wo - ox0 - 4 * g : 0, dy_end, ra[j], ma[j]);
             }
 #pragma unroll
             for (int j = 0; j < NB; ++j) {
@@ -186,7 +190,7 @@ __global__ __launch_bounds__(kWgThreads) void k_wgrad(const WgP p) {
                 const bool rowok = f < BC * F4C && c0 + c < p.Cin && (unsigned)iy < (unsigned)p.H;
                 const float* src = xb + ((long long)(c0 + c) * HW + (long long)iy * p.W + ix0);
                 if constexpr (VEC) rb[j] = (rowok && (unsigned)(ix0 + 4 * g) < (unsigned)p.W) ? *reinterpret_cast<const v4f*>(src + 4 * g) : (v4f){0.f, 0.f, 0.f, 0.f};
-                else una_load(src + 4 * g, (rowok && ix0 + 4 * g >= 0) ? p.W - ix0 - 4 * g : 0, n == p.N - 1 && iy == p.H - 1 && c0 + c == p.Cin - 1, rb[j], mb[j]);
+                else una_load(src + 4 * g, (rowok && ix0 + 4 * g >= 0) ? p.W - ix0 - 4 * g : 0, x_end, rb[j], mb[j]);
             }
         }
     };

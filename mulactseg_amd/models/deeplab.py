@@ -19,6 +19,7 @@ kernels of this package too: BatchNorm + ReLU + residual add (csrc/bn.hip), ever
 dilations from one read of the feature map), the bilinear upsamplings (csrc/upsample.hip).  On the CPU the same modules run as
 plain PyTorch ops (parity tests against the executed reference, tests/test_model.py).
 """
+import os
 from collections import OrderedDict
 
 import torch
@@ -85,6 +86,13 @@ def _conv_bn_act(conv, bn, x, relu=True, residual=None):
         own = ops.conv_train_plan(conv, x)          # training: (forward, input gradient, weight gradient) on the f32-MFMA kernels
         if own is not None and any(own):
             _took("conv_bn_act", "train:" + "".join(n if o else "-" for n, o in zip("fdw", own)))
+            if own[0] and bn.training and os.environ.get("MAS_BN_STATS", "fused") == "fused":
+                # the forward kernel forms the BatchNorm partial sums of its output in its epilogue: no reduction pass over y
+                y, part = ops.conv_train(conv, x, own, stats=True)
+                if part is not None and ops.bn_act_supported(bn, y, residual):
+                    _took("bn_act", "hip")
+                    return ops.bn_act(bn, y, relu, residual, partials=part)
+                return _bn_act(bn, y, relu, residual)
             return _bn_act(bn, ops.conv_train(conv, x, own), relu, residual)
     _took("conv_bn_act", "miopen+bn")
     return _bn_act(bn, conv(x), relu, residual)

@@ -690,24 +690,34 @@ def _opt(t):
 
 class _BNActTrain(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, weight, bias, residual, running_mean, running_var, num_batches_tracked, eps, momentum, relu):
+    def forward(ctx, x, weight, bias, residual, running_mean, running_var, num_batches_tracked, eps, momentum, relu, partials=None):
         x = x.contiguous()
         N, C, H, W = x.shape
         HW = H * W
         dev = x.device
         res = residual.contiguous() if residual is not None else None
         lib = _lib.load()
-        ws = torch.empty(int(lib.mas_bn_workspace_bytes(N, C, HW)), dtype=torch.uint8, device=dev)
         mean = torch.empty(C, dtype=torch.float32, device=dev)
         invstd = torch.empty(C, dtype=torch.float32, device=dev)
         y = torch.empty_like(x)
         # ReLU mask, one byte per aligned group of four outputs: the backward then reads 1/16 of the bytes of y
         mask = torch.empty(int(lib.mas_bn_mask_bytes(N, C, HW)), dtype=torch.uint8, device=dev) if relu else None
         with torch.cuda.device(dev):
-            _lib.check(lib.mas_bn_act_train_fwd(x.data_ptr(), _opt(weight), _opt(bias), _opt(res), N, C, HW, float(eps), float(momentum),
-                                                int(relu), _opt(running_mean), _opt(running_var), _opt(num_batches_tracked),
-                                                mean.data_ptr(), invstd.data_ptr(), ws.data_ptr(), y.data_ptr(), _opt(mask), _stream(x)),
-                       "mas_bn_act_train_fwd")
+            if partials is not None:
+                # (sum, sum of squares) per channel and pixel set, formed in the epilogue of the convolution that produced x
+                # (conv_sk(..., stats=True)): no reduction pass over x
+                if partials.dtype != torch.float64 or partials.dim() != 3 or partials.shape[0] != C or partials.shape[2] != 2:
+                    raise ValueError("partials must be [C, slots, 2] float64")
+                _lib.check(lib.mas_bn_act_train_fwd_stats(x.data_ptr(), partials.data_ptr(), int(partials.shape[1]), _opt(weight), _opt(bias), _opt(res),
+                                                          N, C, HW, float(eps), float(momentum), int(relu), _opt(running_mean), _opt(running_var),
+                                                          _opt(num_batches_tracked), mean.data_ptr(), invstd.data_ptr(), y.data_ptr(), _opt(mask),
+                                                          _stream(x)), "mas_bn_act_train_fwd_stats")
+            else:
+                ws = torch.empty(int(lib.mas_bn_workspace_bytes(N, C, HW)), dtype=torch.uint8, device=dev)
+                _lib.check(lib.mas_bn_act_train_fwd(x.data_ptr(), _opt(weight), _opt(bias), _opt(res), N, C, HW, float(eps), float(momentum),
+                                                    int(relu), _opt(running_mean), _opt(running_var), _opt(num_batches_tracked),
+                                                    mean.data_ptr(), invstd.data_ptr(), ws.data_ptr(), y.data_ptr(), _opt(mask), _stream(x)),
+                           "mas_bn_act_train_fwd")
         # the kernel updated the running statistics through raw pointers: bump their version counters as an in-place
         # torch op would, so caches keyed on (data_ptr, _version) -- _conv1x1_constants -- see the change
         for buf in (running_mean, running_var, num_batches_tracked):
@@ -737,7 +747,7 @@ class _BNActTrain(torch.autograd.Function):
                                                 _stream(x)), "mas_bn_act_train_bwd")
         if ctx.has_res and dres is None and ctx.needs_input_grad[3]:
             dres = dy
-        return dx, dg, db, dres, None, None, None, None, None, None
+        return dx, dg, db, dres, None, None, None, None, None, None, None
 
 
 def bn_act_supported(bn, x, residual=None):
@@ -754,12 +764,13 @@ def bn_act_supported(bn, x, residual=None):
     return not (torch.is_grad_enabled() and (x.requires_grad or (residual is not None and residual.requires_grad)))
 
 
-def bn_act(bn, x, relu=True, residual=None):
+def bn_act(bn, x, relu=True, residual=None, partials=None):
     """relu?(bn(x) + residual) for a ``torch.nn.BatchNorm2d`` module ``bn`` (parameters, running statistics and
-    ``num_batches_tracked`` are the module's own and are updated as PyTorch updates them)."""
+    ``num_batches_tracked`` are the module's own and are updated as PyTorch updates them).  ``partials`` (training): the
+    per-channel partial sums of x that conv_train(..., stats=True) returns beside x."""
     if bn.training:
         rm, rv, nbt = (bn.running_mean, bn.running_var, bn.num_batches_tracked) if bn.track_running_stats else (None, None, None)
-        return _BNActTrain.apply(x, bn.weight, bn.bias, residual, rm, rv, nbt, bn.eps, bn.momentum, relu)
+        return _BNActTrain.apply(x, bn.weight, bn.bias, residual, rm, rv, nbt, bn.eps, bn.momentum, relu, partials)
     x = x.contiguous()
     N, C, H, W = x.shape
     res = residual.contiguous() if residual is not None else None
@@ -1183,7 +1194,7 @@ def packed_weight(w, stride=1, dgrad=False):
     return reg.get(w, stride, dgrad)
 
 
-def conv_sk(x, w, stride=1, dil=1, dgrad=False, scale=None, shift=None, residual=None, relu=False, packed=None):
+def conv_sk(x, w, stride=1, dil=1, dgrad=False, scale=None, shift=None, residual=None, relu=False, packed=None, stats=False):
     """Training-mode dense convolution on the persistent stream-K MFMA kernel (mas_conv_sk), weight `w` [Cout,Cin,k,k] as PyTorch
     stores it (``packed``: its conv_sk_pack image for this role, when the caller keeps one).  dgrad=False: y = conv2d(x, w, stride, padding = dil (k 3) / 0 (k 1), dilation); dgrad=True: x is dY [N,Cout,H,W] and
     the result is dX [N,Cin,H,W] of the stride-1 convolution.  Optional epilogue y*scale[m] + shift[m] + residual, ReLU."""
@@ -1208,9 +1219,22 @@ def conv_sk(x, w, stride=1, dil=1, dgrad=False, scale=None, shift=None, residual
     if packed is None:
         packed = conv_sk_pack(w, stride, dgrad)
     ws, epoch = _sk_workspace(x.device)
+    lib = _lib.load()
+    if stats:
+        # forward without epilogue + the BatchNorm partial sums of y from the epilogue of every tile: (y, partials [Cout, slots, 2] f64)
+        if dgrad or scale is not None or residual is not None or relu:
+            raise ValueError("stats=True: bare forward product only")
+        slots = int(lib.mas_conv_sk_stats_slots(N, Cin, H, W, Cout, ks, stride))
+        if slots <= 0:
+            raise ValueError("unsupported geometry for mas_conv_sk_stats")
+        part = torch.empty((Cout, slots, 2), dtype=torch.float64, device=x.device)
+        with torch.cuda.device(x.device):
+            _lib.check(lib.mas_conv_sk_stats(x.data_ptr(), packed.data_ptr(), N, Cin, H, W, Cout, ks, stride, dil, y.data_ptr(), part.data_ptr(),
+                                             ws.data_ptr(), ws.numel(), epoch, _stream(x)), "mas_conv_sk_stats")
+        return y, part
     with torch.cuda.device(x.device):
-        _lib.check(_lib.load().mas_conv_sk(x.data_ptr(), packed.data_ptr(), N, Cin, H, W, Cout, ks, stride, dil, int(dgrad), _opt(scale), _opt(shift),
-                                           _opt(residual), int(relu), y.data_ptr(), ws.data_ptr(), ws.numel(), epoch, _stream(x)),
+        _lib.check(lib.mas_conv_sk(x.data_ptr(), packed.data_ptr(), N, Cin, H, W, Cout, ks, stride, dil, int(dgrad), _opt(scale), _opt(shift),
+                                   _opt(residual), int(relu), y.data_ptr(), ws.data_ptr(), ws.numel(), epoch, _stream(x)),
                    "mas_conv_sk")
     return y
 
@@ -1278,22 +1302,33 @@ class _ConvTrain(torch.autograd.Function):
     False entry takes MIOpen through ATen for that product."""
 
     @staticmethod
-    def forward(ctx, x, w, stride, dil, own):
+    def forward(ctx, x, w, stride, dil, own, stats=False):
         x = x.contiguous()
         ks = w.shape[2]
+        part = None
         with torch.no_grad():
-            if own[0]:
+            if own[0] and stats:
+                y, part = conv_sk(x, w, stride, dil, packed=packed_weight(w, stride, False), stats=True)
+            elif own[0]:
                 y = conv_sk(x, w, stride, dil, packed=packed_weight(w, stride, False))
             else:
                 y = torch.nn.functional.conv2d(x, w, None, stride, _aten_pad(ks, dil), dil)
         ctx.save_for_backward(x, w)
         ctx.geom = (ks, stride, dil, own)
+        if stats:
+            if part is None:
+                return y, None
+            ctx.mark_non_differentiable(part)
+            ctx.set_materialize_grads(False)        # (no zero-filled "gradient" of the partial sums in the backward)
+            return y, part
         return y
 
     @staticmethod
-    def backward(ctx, dy):
+    def backward(ctx, dy, _dpart=None):
         x, w = ctx.saved_tensors
         ks, stride, dil, own = ctx.geom
+        if dy is None:
+            return None, None, None, None, None, None
         dy = dy.contiguous()
         dx = dw = None
         need_dx, need_dw = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
@@ -1328,7 +1363,7 @@ class _ConvTrain(torch.autograd.Function):
         if side is not None:
             main.wait_stream(side)                          # dW joins the main stream behind the input gradient
             dw.record_stream(main)
-        return dx, dw, None, None, None
+        return dx, dw, None, None, None, None
 
 
 def conv_wgrad_supported(conv, x):
@@ -1364,5 +1399,12 @@ def conv_train_plan(conv, x):
     return (fwd_ok and hw >= 192 * 192, dgrad_ok and hw >= 384 * 384, wgrad_ok)
 
 
-def conv_train(conv, x, own=(True, True, True)):
-    return _ConvTrain.apply(x, conv.weight, conv.stride[0], conv.dilation[0], tuple(bool(v) for v in own))
+def conv_train(conv, x, own=(True, True, True), stats=False):
+    """conv(x) with autograd on the package's kernels (see _ConvTrain).  stats=True: (y, partials) -- the BatchNorm partial sums
+    of y from the epilogue of the forward kernel (None when the forward product is not on mas_conv_sk), for bn_act(partials=)."""
+    own = tuple(bool(v) for v in own)
+    if stats and not own[0]:
+        return _ConvTrain.apply(x, conv.weight, conv.stride[0], conv.dilation[0], own), None
+    if stats:
+        return _ConvTrain.apply(x, conv.weight, conv.stride[0], conv.dilation[0], own, True)
+    return _ConvTrain.apply(x, conv.weight, conv.stride[0], conv.dilation[0], own)

@@ -72,7 +72,8 @@ def test_wgrad_exact_on_integers():
     g = torch.Generator(device='cuda').manual_seed(5)
     for Cin, Cout, k, stride, dil, H, W in ((64, 128, 1, 1, 1, 37, 50), (64, 128, 3, 1, 1, 37, 52), (32, 64, 3, 2, 1, 37, 50),
                                             (32, 64, 3, 1, 2, 20, 48), (64, 128, 1, 2, 1, 36, 52), (32, 64, 3, 1, 1, 16, 64),
-                                            (160, 64, 1, 1, 1, 16, 16)):
+                                            (160, 64, 1, 1, 1, 16, 16), (2048, 256, 1, 1, 1, 1, 1), (64, 128, 1, 1, 1, 1, 3),
+                                            (32, 64, 3, 1, 1, 2, 3), (64, 64, 3, 2, 1, 3, 5)):      # (rows shorter than a 16-byte group)
         x = torch.randint(-3, 4, (2, Cin, H, W), generator=g, device='cuda').float()
         Ho, Wo = (H - 1) // stride + 1, (W - 1) // stride + 1
         dy = torch.randint(-2, 3, (2, Cout, Ho, Wo), generator=g, device='cuda').float()
@@ -131,7 +132,8 @@ def test_stream_k_exact_on_integers_at_layer_sizes(sk_mode):
     for Cin, Cout, k, stride, dil, N, H, W in ((1024, 256, 1, 1, 1, 4, 48, 48), (256, 256, 3, 1, 1, 4, 48, 48), (512, 512, 3, 1, 2, 2, 48, 48),
                                               (64, 64, 3, 1, 1, 1, 96, 96), (128, 128, 3, 2, 1, 2, 64, 96), (256, 512, 1, 2, 1, 2, 64, 64),
                                               (304, 256, 1, 1, 1, 1, 64, 64), (256, 48, 1, 1, 1, 1, 64, 64), (256, 256, 3, 1, 1, 2, 49, 49),
-                                              (512, 128, 1, 1, 1, 2, 97, 97), (64, 64, 3, 2, 1, 1, 97, 97)):
+                                              (512, 128, 1, 1, 1, 2, 97, 97), (64, 64, 3, 2, 1, 1, 97, 97), (64, 64, 1, 1, 1, 1, 1, 3),
+                                              (64, 64, 3, 1, 1, 2, 2, 3), (2048, 256, 1, 1, 1, 4, 1, 1)):
         x = torch.randint(-2, 3, (N, Cin, H, W), generator=g, device='cuda').float()
         w = torch.randint(-2, 3, (Cout, Cin, k, k), generator=g, device='cuda').float()
         Ho, Wo = (H - 1) // stride + 1, (W - 1) // stride + 1
@@ -141,6 +143,46 @@ def test_stream_k_exact_on_integers_at_layer_sizes(sk_mode):
             assert torch.equal(ops.conv_sk(x, w, stride, dil).double(), y_ref), (Cin, Cout, k, stride, dil, rep)
             if stride == 1:
                 assert torch.equal(ops.conv_sk(dy, w, 1, dil, dgrad=True).double(), dx_ref), (Cin, Cout, k, stride, dil, rep)
+    assert ops.conv_sk_error() == 0
+
+
+def test_forward_statistics_from_the_epilogue():
+    """mas_conv_sk_stats: the BatchNorm partial sums of y (sum, sum of squares per channel over disjoint pixel sets) formed in the
+    epilogue of the forward kernel -- summed over the slots they equal the sums over the stored y (float64 of the f32 values; the
+    partials themselves are f32 sums over <= 64 pixels), on planes with partial tiles, tiles shared by several workgroups, Cout that
+    is not a multiple of the M tile; and relu(bn(y)) from these partials equals the separate reduction pass to f32 rounding, running
+    statistics included, with identical results from run to run."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from mulactseg_amd import ops
+    torch.manual_seed(31)
+    for Cin, Cout, k, stride, dil, N, H, W in ((64, 256, 1, 1, 1, 2, 48, 48), (256, 64, 1, 1, 1, 2, 49, 49), (1024, 256, 1, 1, 1, 4, 48, 48),
+                                               (64, 64, 3, 1, 1, 2, 40, 56), (128, 128, 3, 2, 1, 2, 41, 66), (256, 256, 3, 1, 2, 1, 49, 49),
+                                               (256, 512, 1, 2, 1, 2, 33, 65), (304, 200, 1, 1, 1, 1, 20, 36), (64, 48, 3, 1, 4, 1, 20, 36)):
+        x = torch.randn(N, Cin, H, W, device='cuda')
+        w = torch.randn(Cout, Cin, k, k, device='cuda') * 0.1
+        y0 = ops.conv_sk(x, w, stride, dil)
+        y, part = ops.conv_sk(x, w, stride, dil, stats=True)
+        assert torch.equal(y, y0)
+        yd = y.double()
+        ref = torch.stack([yd.sum(dim=(0, 2, 3)), (yd * yd).sum(dim=(0, 2, 3))], dim=1)
+        got = part.sum(dim=1)
+        scale = (yd * yd).sum(dim=(0, 2, 3)).sqrt().clamp_min(1.0)
+        assert float(((got[:, 0] - ref[:, 0]).abs() / (scale * (N * y.shape[2] * y.shape[3]) ** 0.5)).max()) <= 1e-6, (Cin, Cout, k, stride, dil)
+        assert float(((got[:, 1] - ref[:, 1]).abs() / ref[:, 1].clamp_min(1e-6)).max()) <= 1e-5, (Cin, Cout, k, stride, dil)
+        y2, part2 = ops.conv_sk(x, w, stride, dil, stats=True)
+        assert torch.equal(part, part2), "run-to-run identical partials"
+        bn_a, bn_b = torch.nn.BatchNorm2d(Cout).cuda().train(), torch.nn.BatchNorm2d(Cout).cuda().train()
+        with torch.no_grad():
+            bn_a.weight.uniform_(0.5, 1.5)
+            bn_a.bias.uniform_(-0.5, 0.5)
+            bn_b.load_state_dict(bn_a.state_dict())
+        za = ops.bn_act(bn_a, y, True, None)
+        zb = ops.bn_act(bn_b, y, True, None, partials=part)
+        assert float((za - zb).abs().max()) <= 2e-5 * float(za.abs().max())
+        assert torch.allclose(bn_a.running_mean, bn_b.running_mean, rtol=1e-5, atol=1e-6)
+        assert torch.allclose(bn_a.running_var, bn_b.running_var, rtol=1e-5, atol=1e-6)
+        assert int(bn_b.num_batches_tracked) == 1
     assert ops.conv_sk_error() == 0
 
 
