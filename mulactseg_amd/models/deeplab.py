@@ -61,11 +61,15 @@ def _bn_act(bn, x, relu=True, residual=None):
     return F.relu(y) if relu else y
 
 
-def _conv_bn_act(conv, bn, x, relu=True, residual=None):
-    """relu?(bn(conv(x)) + residual).  Inference on the GPU: ONE kernel on the f32 matrix cores with the BatchNorm, the
+def _conv_bn_act(conv, bn, x, relu=True, residual=None, fork=False):
+    """relu?(bn(conv(x)) + residual); fork=True: (that, x') with x' = x for the OTHER consumer of x (in training on the package's
+    kernels an alias of x through which that consumer's gradient reaches the epilogue of this convolution's input-gradient kernel).  Inference on the GPU: ONE kernel on the f32 matrix cores with the BatchNorm, the
     residual add and the ReLU in its epilogue (csrc/conv_mfma.hip) -- no separate normalisation pass over the activation.
     Training (batch statistics, autograd) and unsupported geometries: MIOpen's convolution + the fused BatchNorm kernels."""
+    want_fork, x_other = fork, x
     if x.is_cuda and not bn.training and bn.track_running_stats and not torch.is_grad_enabled():
+        if fork:
+            return _conv_bn_act(conv, bn, x, relu, residual), x
         from .. import ops
         if x.shape[2] * x.shape[3] >= 256 and ops.conv_mfma_supported(conv, x):
             _took("conv_bn_act", "hip_mfma")
@@ -86,16 +90,23 @@ def _conv_bn_act(conv, bn, x, relu=True, residual=None):
         own = ops.conv_train_plan(conv, x)          # training: (forward, input gradient, weight gradient) on the f32-MFMA kernels
         if own is not None and any(own):
             _took("conv_bn_act", "train:" + "".join(n if o else "-" for n, o in zip("fdw", own)))
-            if own[0] and bn.training and os.environ.get("MAS_BN_STATS", "fused") == "fused":
-                # the forward kernel forms the BatchNorm partial sums of its output in its epilogue: no reduction pass over y
-                y, part = ops.conv_train(conv, x, own, stats=True)
-                if part is not None and ops.bn_act_supported(bn, y, residual):
-                    _took("bn_act", "hip")
-                    return ops.bn_act(bn, y, relu, residual, partials=part)
-                return _bn_act(bn, y, relu, residual)
-            return _bn_act(bn, ops.conv_train(conv, x, own), relu, residual)
+            # stats: the forward kernel forms the BatchNorm partial sums of its output in its epilogue (no reduction pass over y);
+            # fork: the gradient of x's other consumer is added in the epilogue of this convolution's input-gradient kernel
+            stats = own[0] and bn.training and os.environ.get("MAS_BN_STATS", "fused") == "fused"
+            fork = fork and own[1] and conv.stride[0] == 1 and x.requires_grad and os.environ.get("MAS_GRAD_FORK", "fused") == "fused"
+            res = ops.conv_train(conv, x, own, stats=stats, fork=fork)
+            y, part = (res[0], res[1]) if (stats or fork) else (res, None)
+            if fork:
+                x_other = res[2]
+            if part is not None and ops.bn_act_supported(bn, y, residual):
+                _took("bn_act", "hip")
+                out = ops.bn_act(bn, y, relu, residual, partials=part)
+            else:
+                out = _bn_act(bn, y, relu, residual)
+            return (out, x_other) if want_fork else out
     _took("conv_bn_act", "miopen+bn")
-    return _bn_act(bn, conv(x), relu, residual)
+    out = _bn_act(bn, conv(x), relu, residual)
+    return (out, x_other) if want_fork else out
 
 
 def _run(seq, x):
@@ -149,7 +160,8 @@ class Bottleneck(nn.Module):
                 _took("conv1x1_bn_act", "hip")
                 y = ops.conv1x1_bn_act(self.conv1, self.bn1, x, True)
         if y is None:
-            y = _conv_bn_act(self.conv1, self.bn1, x)
+            # x has two consumers (conv1 and the residual branch): see _conv_bn_act(fork=True)
+            y, x = _conv_bn_act(self.conv1, self.bn1, x, fork=True)
         y = _conv_bn_act(self.conv2, self.bn2, y)
         if self.downsample is not None:
             x = _run(self.downsample, x)

@@ -1299,10 +1299,14 @@ class _ConvTrain(torch.autograd.Function):
     """y = conv2d(x, w) with autograd.  ``own`` = (forward, input gradient, weight gradient) on this package's f32-MFMA kernels:
     forward and input gradient on the stream-K kernel k_conv_sk (it reads the weight as PyTorch stores it; the input gradient
     is the same kernel with the weight's channel axes swapped and the taps mirrored; stride 1), weight gradient on k_wgrad; a
-    False entry takes MIOpen through ATen for that product."""
+    False entry takes MIOpen through ATen for that product.
+    stats: also returns the BatchNorm partial sums of y (formed in the forward kernel's epilogue).  fork: also returns an alias of x
+    for the OTHER consumer of x (the residual branch of a Bottleneck: models/segmentation/backbone/resnet.py:143-160): the gradient
+    that arrives through the alias is added in the epilogue of the input-gradient kernel (its `residual` operand) instead of by a
+    separate pass over both gradients (autograd's accumulation: 16 add kernels over ~1.1 GB per step)."""
 
     @staticmethod
-    def forward(ctx, x, w, stride, dil, own, stats=False):
+    def forward(ctx, x, w, stride, dil, own, stats=False, fork=False):
         x = x.contiguous()
         ks = w.shape[2]
         part = None
@@ -1315,20 +1319,26 @@ class _ConvTrain(torch.autograd.Function):
                 y = torch.nn.functional.conv2d(x, w, None, stride, _aten_pad(ks, dil), dil)
         ctx.save_for_backward(x, w)
         ctx.geom = (ks, stride, dil, own)
+        ctx.fork = bool(fork)
+        if not stats and not fork:
+            return y
+        ctx.set_materialize_grads(False)            # (no zero-filled "gradient" of the partial sums in the backward)
+        outs = [y]
         if stats:
-            if part is None:
-                return y, None
-            ctx.mark_non_differentiable(part)
-            ctx.set_materialize_grads(False)        # (no zero-filled "gradient" of the partial sums in the backward)
-            return y, part
-        return y
+            if part is not None:
+                ctx.mark_non_differentiable(part)
+            outs.append(part)
+        if fork:
+            outs.append(x.view_as(x))
+        return tuple(outs)
 
     @staticmethod
-    def backward(ctx, dy, _dpart=None):
+    def backward(ctx, dy, *rest):
         x, w = ctx.saved_tensors
         ks, stride, dil, own = ctx.geom
+        g_other = rest[-1] if (ctx.fork and rest) else None     # gradient of the alias = of the other consumer of x
         if dy is None:
-            return None, None, None, None, None, None
+            return g_other, None, None, None, None, None, None
         dy = dy.contiguous()
         dx = dw = None
         need_dx, need_dw = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
@@ -1346,7 +1356,11 @@ class _ConvTrain(torch.autograd.Function):
                 dw = conv_wgrad(x, dy, ks, stride, dil)
         if need_dx:
             if own[1] and stride == 1:
-                dx = conv_sk(dy, w, 1, dil, dgrad=True, packed=packed_weight(w, 1, True))
+                if g_other is not None and g_other.shape == x.shape and g_other.dtype == torch.float32:
+                    dx = conv_sk(dy, w, 1, dil, dgrad=True, packed=packed_weight(w, 1, True), residual=g_other.contiguous())
+                    g_other = None
+                else:
+                    dx = conv_sk(dy, w, 1, dil, dgrad=True, packed=packed_weight(w, 1, True))
             elif own[1] and ks == 1:
                 # 1x1, stride 2: the input gradient lives on the even positions only -- the stride-1 product on the small plane,
                 # scattered into a zero-filled tensor
@@ -1363,7 +1377,9 @@ class _ConvTrain(torch.autograd.Function):
         if side is not None:
             main.wait_stream(side)                          # dW joins the main stream behind the input gradient
             dw.record_stream(main)
-        return dx, dw, None, None, None, None
+        if g_other is not None:
+            dx = g_other if dx is None else dx + g_other
+        return dx, dw, None, None, None, None, None
 
 
 def conv_wgrad_supported(conv, x):
@@ -1399,12 +1415,16 @@ def conv_train_plan(conv, x):
     return (fwd_ok and hw >= 192 * 192, dgrad_ok and hw >= 384 * 384, wgrad_ok)
 
 
-def conv_train(conv, x, own=(True, True, True), stats=False):
+def conv_train(conv, x, own=(True, True, True), stats=False, fork=False):
     """conv(x) with autograd on the package's kernels (see _ConvTrain).  stats=True: (y, partials) -- the BatchNorm partial sums
-    of y from the epilogue of the forward kernel (None when the forward product is not on mas_conv_sk), for bn_act(partials=)."""
+    of y from the epilogue of the forward kernel (None when the forward product is not on mas_conv_sk), for bn_act(partials=).
+    fork=True: one more result, an alias of x to hand to the other consumer of x (see _ConvTrain)."""
     own = tuple(bool(v) for v in own)
-    if stats and not own[0]:
-        return _ConvTrain.apply(x, conv.weight, conv.stride[0], conv.dilation[0], own), None
-    if stats:
-        return _ConvTrain.apply(x, conv.weight, conv.stride[0], conv.dilation[0], own, True)
-    return _ConvTrain.apply(x, conv.weight, conv.stride[0], conv.dilation[0], own)
+    stats = bool(stats and own[0])
+    out = _ConvTrain.apply(x, conv.weight, conv.stride[0], conv.dilation[0], own, stats, bool(fork))
+    if not stats and not fork:
+        return out
+    out = list(out)
+    if not stats:
+        out.insert(1, None)
+    return tuple(out) if fork else (out[0], out[1])

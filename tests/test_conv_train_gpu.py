@@ -186,6 +186,38 @@ def test_forward_statistics_from_the_epilogue():
     assert ops.conv_sk_error() == 0
 
 
+def test_block_input_gradient_is_accumulated_in_the_epilogue():
+    """A Bottleneck's input feeds conv1 and the residual branch (identity or downsample): with MAS_GRAD_FORK=fused the gradient of
+    the residual branch is the `residual` operand of conv1's input-gradient kernel; it must give the same gradients as autograd's
+    own accumulation (bit for bit: both round acc + g once), with and without a downsample branch."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from mulactseg_amd.models import deeplab
+    for inplanes, planes, stride, down in ((256, 64, 1, False), (128, 64, 1, True), (256, 128, 2, True)):
+        torch.manual_seed(7 + inplanes)
+        ds = None
+        if down:
+            ds = torch.nn.Sequential(torch.nn.Conv2d(inplanes, planes * 4, 1, stride=stride, bias=False), torch.nn.BatchNorm2d(planes * 4))
+        blk = deeplab.Bottleneck(inplanes, planes, stride=stride, downsample=ds).cuda().train()
+        x0 = torch.randn(2, inplanes, 40, 56, device='cuda')
+        res = {}
+        for mode in ("off", "fused"):
+            os.environ["MAS_GRAD_FORK"] = mode
+            try:
+                for prm in blk.parameters():
+                    prm.grad = None
+                x = (x0 * 1.0).requires_grad_(True)         # a non-leaf would do too; the gradient must reach x
+                y = blk(x)
+                (y * torch.linspace(-1, 1, y.numel(), device='cuda').view_as(y)).sum().backward()
+                res[mode] = (y.detach().clone(), x.grad.clone(), {n: prm.grad.clone() for n, prm in blk.named_parameters()})
+            finally:
+                os.environ.pop("MAS_GRAD_FORK")
+        assert torch.equal(res["off"][0], res["fused"][0])
+        assert torch.equal(res["off"][1], res["fused"][1]), (inplanes, planes, stride, down)
+        for n in res["off"][2]:
+            assert torch.equal(res["off"][2][n], res["fused"][2][n]), n
+
+
 def test_stride2_input_gradient_exact_on_integers():
     """mas_conv_sk_dgrad_s2: the four parity classes of the input gradient of a 3x3 stride-2 convolution (1 / 2 / 2 / 4 taps over
     the dY plane, strided stores) on integer data, exact in any order: even and odd planes (odd: the last row / column belongs to
