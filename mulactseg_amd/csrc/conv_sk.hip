@@ -214,39 +214,56 @@ __device__ __forceinline__ void sk_xoffsets(const SkP& p, SkCursor& cur, const S
     cur.moved = false;
 }
 
-// global -> registers of the chunk at the cursor (its tile may differ from the one being multiplied: the pipeline crosses tile
-// boundaries)
+// Where the chunk at the cursor lives: bases and limits that are the same for the whole workgroup.  Computed in code that ALL
+// waves run (the top of an iteration), never inside the `wave < 4` phases: hipcc compiles that branch as exec-mask divergence and
+// keeps everything assigned inside it in VECTOR registers -- the cursor with its divisions (~250 VALU instructions at a tile
+// change) and the 64-bit address arithmetic of every load (~40 per chunk) then run on the VALU, whose issue the partner wave's
+// MFMAs hold.  (Turning the branch into a scalar one with readfirstlane made the staging registers conditionally assigned loop
+// variables: register moves, spills and a vmcnt(0) at the loop head -- 37.2 vs 33.3 ms per step.)
+struct SkPlan {
+    const float* wb;            // the weight image of (M tile, chunk)
+    const float* xb;            // x of (picture, first channel of the chunk)
+    int kleft;                  // channels from the chunk's first to the last
+    int rem;                    // elements from xb to the end of the tensor (saturated)
+};
+
+template <typename G, int TAPS, int WM, bool VEC>
+__device__ __forceinline__ SkPlan sk_plan_fetch(const SkP& p, SkCursor& cur, const SkSlots<SkX<G>::NXS>& sl, SkXOff<SkX<G>::NXS>& xo) {
+    constexpr int KC = TAPS * G::CK;
+    const int k0 = cur.chunk * G::CK, HW = p.H * p.W;
+    SkPlan f;
+    f.wb = p.w + ((size_t)cur.mt * p.nch + cur.chunk) * (size_t)(KC * 32 * WM);
+    f.xb = p.x + ((size_t)cur.n * p.K + k0) * HW;
+    f.kleft = p.K - k0;
+    const long long rem64 = ((long long)(p.N - cur.n) * p.K - k0) * HW;
+    f.rem = rem64 > 0x7fffffffLL ? 0x7fffffff : (int)rem64;
+    if (cur.moved) sk_xoffsets<G, VEC>(p, cur, sl, xo);
+    return f;
+}
+
+// global -> registers of the planned chunk (its tile may differ from the one being multiplied: the pipeline crosses tile
+// boundaries).  !VEC: xm[j] = what sk_stage needs to know about group j (elements inside the row | elements loaded early << 3).
 template <typename G, int TAPS, int WM, bool VEC, int NWS>
-__device__ __forceinline__ void sk_fetch(const SkP& p, SkCursor& cur, const SkSlots<SkX<G>::NXS>& sl, SkXOff<SkX<G>::NXS>& xo, int tid,
-                                         v4f (&wr)[NWS], v4f (&xr)[SkX<G>::NXS]) {
-    constexpr int BM = 32 * WM, CK = G::CK, NXS = SkX<G>::NXS;
-    constexpr int KC = TAPS * CK;
-    const int k0 = cur.chunk * CK;
-    // ---- weight: the LDS image of (M tile, chunk), a linear copy --------------------------------------------------------------
-    const float* wb = p.w + ((size_t)cur.mt * p.nch + cur.chunk) * (size_t)(KC * BM);
+__device__ __forceinline__ void sk_fetch(const SkPlan& f, const SkSlots<SkX<G>::NXS>& sl, const SkXOff<SkX<G>::NXS>& xo, int tid,
+                                         v4f (&wr)[NWS], v4f (&xr)[SkX<G>::NXS], int (&xm)[VEC ? 1 : SkX<G>::NXS]) {
+    constexpr int BM = 32 * WM, NXS = SkX<G>::NXS;
+    constexpr int KC = TAPS * G::CK;
 #pragma unroll
     for (int j = 0; j < NWS; ++j) {
         const int e = (tid + j * kSkThreads) * 4;
-        wr[j] = (NWS * kSkThreads * 4 == BM * KC || e < BM * KC) ? *reinterpret_cast<const v4f*>(wb + e) : (v4f){0.f, 0.f, 0.f, 0.f};
+        wr[j] = (NWS * kSkThreads * 4 == BM * KC || e < BM * KC) ? *reinterpret_cast<const v4f*>(f.wb + e) : (v4f){0.f, 0.f, 0.f, 0.f};
     }
-    // ---- input patch: CK channels x PH rows x PWL columns --------------------------------------------------------------------
-    const int HW = p.H * p.W;
-    const float* xb = p.x + ((size_t)cur.n * p.K + k0) * HW;
-    if (cur.moved) sk_xoffsets<G, VEC>(p, cur, sl, xo);
-    const int kleft = p.K - k0;
-    const long long rem64 = ((long long)(p.N - cur.n) * p.K - k0) * HW;        // elements from xb to the end of the tensor
-    const int rem = rem64 > 0x7fffffffLL ? 0x7fffffff : (int)rem64;
 #pragma unroll
     for (int j = 0; j < NXS; ++j) {
-        const bool ok = ((xo.mask >> j) & 1u) && sl.c[j] < kleft;
+        const bool ok = ((xo.mask >> j) & 1u) && sl.c[j] < f.kleft;
         if constexpr (VEC) {
-            xr[j] = ok ? *reinterpret_cast<const v4f*>(xb + xo.off[j]) : (v4f){0.f, 0.f, 0.f, 0.f};
+            xr[j] = ok ? *reinterpret_cast<const v4f*>(f.xb + xo.off[j]) : (v4f){0.f, 0.f, 0.f, 0.f};
         } else {
             // (no use of the loaded values here: masks and the rotation are applied by sk_stage)
-            const int avail = rem - xo.off[j];                                  // elements from the group's first to the tensor's end
+            const int avail = f.rem - xo.off[j];                                // elements from the group's first to the tensor's end
             const int early = (ok && avail < 4) ? 4 - avail : 0;
-            xo.meta[j] = (xo.meta[j] & 7) | (early << 3);
-            const float* src = xb + xo.off[j] - early;
+            xm[j] = xo.meta[j] | (early << 3);
+            const float* src = f.xb + xo.off[j] - early;
             if (ok) {
                 const v4fu u = *reinterpret_cast<const v4fu*>(src);
                 xr[j] = (v4f){u[0], u[1], u[2], u[3]};
@@ -261,7 +278,7 @@ __device__ __forceinline__ void sk_fetch(const SkP& p, SkCursor& cur, const SkSl
 // 2 cp + h of one tap (h = lane half of the MFMA), the four k-steps 4 q .. 4 q + 3 of one (half, row) are adjacent: one 16-byte
 // read = four MFMAs.
 template <typename G, int TAPS, int WM, bool VEC, int NWS>
-__device__ __forceinline__ void sk_stage(const SkSlots<SkX<G>::NXS>& sl, const SkXOff<SkX<G>::NXS>& xo, float* __restrict__ sW,
+__device__ __forceinline__ void sk_stage(const SkSlots<SkX<G>::NXS>& sl, const int (&xm)[VEC ? 1 : SkX<G>::NXS], float* __restrict__ sW,
                                          float* __restrict__ sX, int tid, const v4f (&wr)[NWS], const v4f (&xr)[SkX<G>::NXS]) {
     constexpr int BM = 32 * WM, CK = G::CK, NXS = SkX<G>::NXS;
     constexpr int KC = TAPS * CK;
@@ -274,9 +291,8 @@ __device__ __forceinline__ void sk_stage(const SkSlots<SkX<G>::NXS>& sl, const S
     for (int j = 0; j < NXS; ++j) {
         v4f v = xr[j];
         if constexpr (!VEC) {
-            // xo still describes the tile of the chunk in `xr`: the caller stages a chunk BEFORE it fetches the next one
-            const int nv = xo.meta[j] & 7;
-            const int early = xo.meta[j] >> 3;
+            const int nv = xm[j] & 7;
+            const int early = xm[j] >> 3;
             if (early) {                        // loaded `early` elements early: element i of the group is u[i + early]
                 const v4f u = v;
                 v[0] = early == 1 ? u[1] : (early == 2 ? u[2] : u[3]);
@@ -454,13 +470,16 @@ __global__ __launch_bounds__(kSkThreads) void k_conv_sk(const SkP p) {
     // reason for the LDS-DMA form.  Two register sets spilled 45 VGPRs at the 256-register budget of two waves per SIMD.)
     SkSlots<NXS> slots;
     SkXOff<NXS> xoff;
+    int xm[VEC ? 1 : NXS];
     if constexpr (!DMA) {
         sk_slots<G>(tid, slots);
-        sk_fetch<G, TAPS, WM, VEC, NWS>(p, pre, slots, xoff, tid, wr, xr);
-        sk_stage<G, TAPS, WM, VEC, NWS>(slots, xoff, sk_smem, sk_smem + KC * BM, tid, wr, xr);
+        SkPlan f0 = sk_plan_fetch<G, TAPS, WM, VEC>(p, pre, slots, xoff);
+        sk_fetch<G, TAPS, WM, VEC, NWS>(f0, slots, xoff, tid, wr, xr, xm);
+        sk_stage<G, TAPS, WM, VEC, NWS>(slots, xm, sk_smem, sk_smem + KC * BM, tid, wr, xr);
         if (it0 + 1 < it1) {
             sk_advance(p, g, sk0, pre);
-            sk_fetch<G, TAPS, WM, VEC, NWS>(p, pre, slots, xoff, tid, wr, xr);
+            f0 = sk_plan_fetch<G, TAPS, WM, VEC>(p, pre, slots, xoff);
+            sk_fetch<G, TAPS, WM, VEC, NWS>(f0, slots, xoff, tid, wr, xr, xm);
         }
         __syncthreads();
     } else {
@@ -494,6 +513,12 @@ __global__ __launch_bounds__(kSkThreads) void k_conv_sk(const SkP p) {
 #ifdef SK_PHASE_STAMPS
             unsigned long long t1 = 0, t1b = 0, t2 = 0;
 #endif
+            // the part every wave runs: where chunk it + 2 lives (scalar registers, see SkPlan)
+            SkPlan f2 = {};
+            if (it + 2 < it1) {
+                sk_advance(p, g, sk0, pre);
+                f2 = sk_plan_fetch<G, TAPS, WM, VEC>(p, pre, slots, xoff);
+            }
             auto body = [&](auto QS) {
                 constexpr int qs = decltype(QS)::value;
                 mfma_part(buf, std::integral_constant<int, 0>{}, std::integral_constant<int, qs>{}, no_hook);
@@ -509,14 +534,11 @@ __global__ __launch_bounds__(kSkThreads) void k_conv_sk(const SkP p) {
 #endif
                 if (it + 1 < it1) {
                     float* nW = sk_smem + (buf ^ 1) * bufsz;
-                    sk_stage<G, TAPS, WM, VEC, NWS>(slots, xoff, nW, nW + KC * BM, tid, wr, xr);
+                    sk_stage<G, TAPS, WM, VEC, NWS>(slots, xm, nW, nW + KC * BM, tid, wr, xr);
 #ifdef SK_PHASE_STAMPS
                     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #endif
-                    if (it + 2 < it1) {
-                        sk_advance(p, g, sk0, pre);
-                        sk_fetch<G, TAPS, WM, VEC, NWS>(p, pre, slots, xoff, tid, wr, xr);
-                    }
+                    if (it + 2 < it1) sk_fetch<G, TAPS, WM, VEC, NWS>(f2, slots, xoff, tid, wr, xr, xm);
                 }
                 __builtin_amdgcn_s_setprio(0);
 #ifdef SK_PHASE_STAMPS
