@@ -256,6 +256,8 @@ int mas_single_pass_accum(const float* z, const void* spx, int spx_dtype, int B,
  * C in {19, 20, 21}; H / h and W / w >= ~3.8 (MAS_ERR_RANGE otherwise). */
 int mas_single_pass_accum_lowres(const float* zq, int h, int w, const void* spx, int spx_dtype, int B, int C, int H, int W, int S,
                                  float invT, uint64_t* prob_sum, uint64_t* class_sum, uint32_t* hist, void* stream);
+/* tests / A-B measurements: 1 = keep the generic tap reads at the exact x4 ratio too (bit-identical results); returns the previous setting */
+int mas_single_pass_lowres_generic(int on);
 
 /* score[r] = floor(((sum_c class_sum[r,c] * w31[c]) >> 31) / n_r) * 2^-40, w31[c] = floor(cls_weight[c] * 2^31)
  * (exact integer arithmetic); dominant class, ban and optional outputs as mas_region_finalize.

@@ -37,6 +37,7 @@ SIGNATURES = {
     "mas_logits_iou_counts": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i64, _vp, _vp]),
     "mas_single_pass_accum": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _f, _vp, _vp, _vp, _vp]),
     "mas_single_pass_accum_lowres": (_i, [_vp, _i, _i, _vp, _i, _i, _i, _i, _i, _i, _f, _vp, _vp, _vp, _vp]),
+    "mas_single_pass_lowres_generic": (_i, [_i]),
     "mas_class_weight": (_i, [_vp, _i, _i, _i64, _i, _i, _d, _vp, _vp, _vp, _vp]),
     "mas_region_finalize_weighted": (_i, [_vp, _vp, _i64, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp]),
     "mas_stage2_gather_protos": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _i, _vp, _vp]),

@@ -60,7 +60,11 @@ __device__ __forceinline__ void low_tap(float scale, int o, int& i0, float& l0, 
     l0 = 1.0f - l1;
 }
 
-template <int CT, bool EXACT, typename IdT, bool VEC, bool LOWRES = false>
+// X4 (LOWRES, VEC, W == 4 w): a lane's four pixels 4L .. 4L + 3 are one period of the x4 pattern -- pixels 0, 1 share their
+// left tap (column L - 1, or 0 at the picture's edge), pixels 2, 3 share theirs (column L): 8 LDS reads per class and row pair
+// instead of 16, same operands, same arithmetic (weights still from low_tap: {0.625, 0.875, 0.125, 0.375}, or (1, 0) where the
+// source coordinate is clamped at 0).
+template <int CT, bool EXACT, typename IdT, bool VEC, bool LOWRES = false, bool X4 = false>
 __global__ __launch_bounds__(kThreads) void k_single_pass(const float* __restrict__ z, const IdT* __restrict__ spx, int C, int H,
                                                            int W, int S, float invT, int tiles_x, int tiles_y,
                                                            mas_u64* __restrict__ prob_sum, mas_u64* __restrict__ class_sum,
@@ -164,9 +168,17 @@ __global__ __launch_bounds__(kThreads) void k_single_pass(const float* __restric
             auto fetch16 = [&](int c, float (&d)[16]) {
                 const float* r0 = s_low + (c * kLowRows + ly) * kLowCols;
                 const float* r1 = r0 + kLowCols;
+                if constexpr (X4) {
 #pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    d[4 * k] = r0[lx[k]]; d[4 * k + 1] = r0[lx[k] + 1]; d[4 * k + 2] = r1[lx[k]]; d[4 * k + 3] = r1[lx[k] + 1];
+                    for (int k = 0; k < 4; k += 2) {
+                        d[4 * k] = r0[lx[k]]; d[4 * k + 1] = r0[lx[k] + 1]; d[4 * k + 2] = r1[lx[k]]; d[4 * k + 3] = r1[lx[k] + 1];
+                        d[4 * k + 4] = d[4 * k]; d[4 * k + 5] = d[4 * k + 1]; d[4 * k + 6] = d[4 * k + 2]; d[4 * k + 7] = d[4 * k + 3];
+                    }
+                } else {
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        d[4 * k] = r0[lx[k]]; d[4 * k + 1] = r0[lx[k] + 1]; d[4 * k + 2] = r1[lx[k]]; d[4 * k + 3] = r1[lx[k] + 1];
+                    }
                 }
             };
             fetch16(0, raw[0]);
@@ -618,6 +630,8 @@ int launch(const float* z, const void* spx, int B, int C, int H, int W, int S, f
     return mas_launch_status();
 }
 
+bool g_low_generic = false;     // tests / A-B measurements: keep the generic tap reads at the x4 ratio (mas_single_pass_lowres_generic)
+
 template <int CT, bool EXACT, typename IdT>
 int launch_low(const float* zq, int h, int w, const void* spx, int B, int C, int H, int W, int S, float invT, mas_u64* prob_sum,
                mas_u64* class_sum, unsigned* hist, hipStream_t st) {
@@ -634,11 +648,20 @@ int launch_low(const float* zq, int h, int w, const void* spx, int B, int C, int
     const IdT* ids = static_cast<const IdT*>(spx);
     // > 64 KB of dynamic LDS needs the attribute on every device's copy of the code object: flags per (kernel, device), the
     // call's status is the launch's status
-    static bool attr_vec[64] = {}, attr_scalar[64] = {};
+    static bool attr_vec[64] = {}, attr_scalar[64] = {}, attr_x4[64] = {};
     int dev = 0;
     if (hipError_t e = hipGetDevice(&dev); e != hipSuccess) return (int)e;
     const bool cached = dev >= 0 && dev < 64;
-    if (vec) {
+    if (vec && W == 4 * w && !g_low_generic) {       // the model's own ratio: one period of the x4 pattern per lane
+        if (!cached || !attr_x4[dev]) {
+            const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_single_pass<CT, EXACT, IdT, true, true, true>),
+                                                     hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+            if (e != hipSuccess) return (int)e;
+            if (cached) attr_x4[dev] = true;
+        }
+        hipLaunchKernelGGL((k_single_pass<CT, EXACT, IdT, true, true, true>), dim3((unsigned)nblk), dim3(kThreads), smem, st, zq, ids, C, H, W,
+                           S, invT, tiles_x, tiles_y, prob_sum, class_sum, hist, lr);
+    } else if (vec) {
         if (!cached || !attr_vec[dev]) {
             const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_single_pass<CT, EXACT, IdT, true, true>),
                                                      hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
@@ -713,6 +736,14 @@ extern "C" int mas_single_pass_accum_lowres(const float* zq, int h, int w, const
         case 21: return dispatch_low_ids<21, true>(zq, h, w, spx, spx_dtype, B, C, H, W, S, invT, ps, cs, hist, st);
         default: return MAS_ERR_CLASSES;
     }
+}
+
+/* tests and A/B measurements: 1 = the quarter-resolution scan keeps its generic tap reads also at the exact x4 ratio (results are
+ * bit-identical either way); returns the previous setting */
+extern "C" int mas_single_pass_lowres_generic(int on) {
+    const int old = g_low_generic ? 1 : 0;
+    if (on == 0 || on == 1) g_low_generic = on != 0;
+    return old;
 }
 
 extern "C" int mas_region_finalize_weighted(const uint64_t* class_sum, const uint32_t* hist, int64_t n_regions, int C,

@@ -421,6 +421,12 @@ def single_pass_accum_lowres(zq, size, spx, S, invT, prob_sum=None, class_sum=No
     return prob_sum, class_sum, hist
 
 
+def single_pass_lowres_generic(on):
+    """Tests / A-B measurements: True = the quarter-resolution scan keeps its generic tap reads at the exact x4 ratio too (results are
+    bit-identical either way); returns the previous setting."""
+    return bool(_lib.load().mas_single_pass_lowres_generic(int(bool(on))))
+
+
 def region_finalize_weighted(class_sum, hist, w31, ban_class=-1, want_hist_i64=False):
     """Weighted mean per region from the single-pass accumulators.  ``w31``: int32 tensor [C] holding uint32 bits."""
     _need(class_sum, "class_sum", torch.int64)
