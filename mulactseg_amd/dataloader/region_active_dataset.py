@@ -46,7 +46,7 @@ class RegionActiveDataset:
             if hasattr(mh, 'is_cuda'):          # a (device-resident) torch tensor
                 tab = mh.sum(dim=2).to(dtype=mh.dtype).cpu().numpy().astype(np.uint8)
             else:
-                tab = np.asarray(mh).sum(axis=2, dtype=np.uint8)
+                tab = np.einsum('isc->is', np.asarray(mh), dtype=np.uint8)       # (2x faster than .sum(axis=2) over the short class axis)
             self._click_cost = (mh, np.ascontiguousarray(tab))
         return self._click_cost[1]
 
@@ -122,7 +122,7 @@ class RegionActiveDataset:
                 if len(gone) <= 4:                      # a handful: list.remove keeps the order and runs at C speed
                     for i in gone:
                         lst.remove(i)
-                else:
+                elif not self._delete_by_position(lst, row, gone):
                     pool.suppix[spx_path] = [i for i in lst if i not in gone]
             else:
                 pool.suppix.pop(spx_path)
@@ -135,6 +135,28 @@ class RegionActiveDataset:
             log({"num_selected_spx": n_sup, "num_cls_spx": selection_count / n_sup,
                  "sampling_iter": self.selection_iter}, step=step)
         return n_sup
+
+    def _delete_by_position(self, lst, row, gone):
+        """Remove the ids ``gone`` from the list ``lst`` of image ``row`` in place, order preserved, without walking the list in
+        Python: in a list that holds its ids in ascending order (how the reference builds them, ``np.unique``; removals keep it)
+        an id sits at position (number of listed ids below it), read off the valid table.  The positions are VERIFIED
+        (``lst[p] == id`` for every id) before anything is deleted -- deleting verified positions is right whatever the order of the
+        rest -- else False: the caller rewrites the list.  (The rewrite, ``[i for i in lst if i not in gone]`` over 2 975 x 2 048
+        entries, was 0.15 s of a 0.40 s pool round.)"""
+        if self._valid is None:
+            return False
+        ids = np.fromiter(gone, dtype=np.intp, count=len(gone))
+        ids.sort()
+        before = self._valid[row].copy()            # (the table already has this call's removals)
+        before[ids] = 1
+        pos = (np.cumsum(before, dtype=np.intp)[ids] - 1).tolist()
+        n = len(lst)
+        for p, i in zip(pos, ids.tolist()):
+            if p >= n or lst[p] != i:
+                return False
+        for p in reversed(pos):
+            del lst[p]
+        return True
 
     # -- persistence ----------------------------------------------------------------------------
     def dump_datalist(self):

@@ -119,6 +119,30 @@ def test_expand_training_set_equals_the_reference_loop_on_random_rounds(tmp_path
         aset.expand_training_set([(1.0, ','.join(ref_label['im_idx'][0]), gone)], 5, 'm')
 
 
+def test_removal_by_verified_position_and_its_fallback(tmp_path):
+    """Ids leave a pool list by position (read off the valid table) when the list is ascending; a list in another order fails the
+    position check and is rewritten instead -- both must equal the reference's list.remove() result, order included."""
+    import copy
+    args, names, mh, aset = _sets(tmp_path, n=2, nseg=40)
+    pool, label = aset.trg_pool_dataset, aset.trg_label_dataset
+    rs = np.random.RandomState(1)
+    shuffled = list(pool.suppix[names[1][2]])
+    rs.shuffle(shuffled)
+    pool.suppix[names[1][2]] = list(shuffled)                       # image 1: not ascending
+    aset.pool_valid_mask(args.nseg)                                 # the table exists before the round
+    want0 = [i for i in pool.suppix[names[0][2]] if i not in (3, 9, 10, 17, 30, 39)]
+    want1 = [i for i in shuffled if i not in (2, 5, 8, 13, 21, 34, 0)]
+    order = [(1.0 - 0.01 * k, ','.join(names[0]), i) for k, i in enumerate((30, 3, 39, 10, 9, 17))]
+    order += [(0.5 - 0.01 * k, ','.join(names[1]), i) for k, i in enumerate((21, 2, 34, 8, 5, 13, 0))]
+    calls = []
+    orig = aset._delete_by_position
+    aset._delete_by_position = lambda lst, row, gone: calls.append(orig(lst, row, gone)) or calls[-1]
+    assert aset.expand_training_set(order, 10 ** 6, 'p') == len(order)
+    assert calls == [True, False]
+    assert pool.suppix[names[0][2]] == want0 and pool.suppix[names[1][2]] == want1
+    assert label.suppix[names[0][2]][-6:] == [30, 3, 39, 10, 9, 17]
+
+
 def test_valid_table_is_rebuilt_from_the_lists_when_a_round_ran_before_it_existed(tmp_path):
     """A pool may offer initial_valid_table() (all ids listed when it was built); once expand_training_set has changed the lists
     without a table to mirror it (a random first round), the table must come from the lists, not from the stale initial one."""
