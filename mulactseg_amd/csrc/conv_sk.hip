@@ -143,28 +143,38 @@ __device__ __forceinline__ void sk_advance(const SkP& p, int g, int sk0, SkCurso
 }
 
 // Per-thread description of its 16-byte groups of the input patch (depends on the thread only): channel, patch row / column
-// (packed), LDS offset; -1 = no group.  A group is four consecutive patch columns: one 16-byte global load, one 16-byte LDS store.
+// (packed); -1 = no group.  A group is four consecutive patch columns: one 16-byte load, one 16-byte LDS store; group f = tid +
+// 512 j lives at float 4 f of the patch image [CK][PH][PWL] (an affine LDS address: one register + immediates).
+// The staging code of a chunk contains NO vector ALU work on aligned planes: while one wave of a SIMD issues its 64 MFMAs back to
+// back, an instruction of its partner that needs the vector ALU is issued about once per MFMA (in-kernel stamps: the ~80
+// instructions of "stage + refetch" stretched over the partner's whole multiply phase, 5.4k of the 11.2k cycles of an iteration).
+// Hence: loads through a buffer resource (scalar base and size per chunk) at per-group byte offsets that are computed once per pixel
+// tile -- a group outside the plane gets an offset beyond the resource and comes back as zeros, no exec masking, no selects;
+// channels past the tensor's last (K tail) are outside the resource by its size.
 // VEC: the rows of the plane are 16-byte aligned (W % 4 == 0, aligned base) and a group is inside the plane's row or outside it.
-// !VEC (the 769-crop planes 385 / 193 / 97 / 49: every row starts at another alignment): the same groups, loaded with 16-byte
-// loads at 4-byte aligned addresses (gfx950 runs them at the aligned rate: tools/micro/unaligned.hip); the one group per row that
+// !VEC (the 769-crop planes 385 / 193 / 97 / 49: every row starts at another alignment): the same groups, loaded at 4-byte aligned
+// addresses (gfx950 runs 16-byte loads there at the aligned rate: tools/micro/unaligned.hip); the one group per row that
 // straddles the row's right end reads on into the next row and has its elements past the end zeroed -- when it is written to LDS,
 // not behind the load: any use of a loaded value in the fetch code makes hipcc wait for the load there, which serialises the
-// prefetch (46.1 ms per step) -- except within three elements of the tensor's end, where it would leave the allocation: such a
-// group is loaded so that it ENDS at the tensor's end and is rotated into place before the LDS store.  (First forms of this path:
-// element-wise 4-byte loads, 4x the load instructions, 48.4 ms per step at the 769 crop; aligned groups of memory written to LDS
-// with four predicated 4-byte stores at the row's shift, 44.2 ms.)
+// prefetch (46.1 ms per step) -- and within three elements of the tensor's end such a group is loaded so that it ENDS at the
+// tensor's end and is rotated into place before the LDS store.  (First forms of this path: element-wise 4-byte loads, 4x the
+// load instructions, 48.4 ms per step at the 769 crop; aligned groups of memory written to LDS with four predicated 4-byte stores
+// at the row's shift, 44.2 ms.)
 typedef float v4fu __attribute__((ext_vector_type(4), aligned(4)));
+typedef int v4i __attribute__((ext_vector_type(4)));
+constexpr unsigned kSkNoGroup = 0xfffffff0u;        // byte offset of a group that does not exist: beyond every resource
 
 template <typename G>
 struct SkX {
     static constexpr int F4R = G::PWL >> 2;                                   // groups per patch row
     static constexpr int F4C = G::PH * F4R;                                   // per channel
     static constexpr int NXS = (G::CK * F4C + kSkThreads - 1) / kSkThreads;   // per thread
+    static_assert(F4C * 4 == G::CS, "patch image: group f at float 4 f");
 };
 
 template <int NXS>
 struct SkSlots {
-    int c[NXS], rc[NXS], lds[NXS];
+    int c[NXS], rc[NXS];
 };
 
 template <typename G>
@@ -178,38 +188,29 @@ __device__ __forceinline__ void sk_slots(int tid, SkSlots<SkX<G>::NXS>& s) {
         const bool live = f < G::CK * f4c;
         s.c[j] = live ? c : -1;
         s.rc[j] = row | (col << 16);
-        s.lds[j] = c * G::CS + rem * 4;
     }
 }
 
-// Offsets of a thread's patch groups from the (picture, chunk) base of the input, and which of them lie inside the plane:
-// functions of the pixel tile only, recomputed when the prefetch stream enters a new one.  Per chunk a group then costs one
-// compare and one load from (uniform base + offset) -- the address arithmetic of the staging code competes with the partner
-// wave's MFMA issue (measured: ~3k of the 11.6k cycles of an iteration in "stage + refetch" before this).
-// !VEC: meta = number of elements of the group inside the row (1..4); fetch adds (elements the group was loaded early << 3) for
-// the groups within three elements of the tensor's end (rotated into place by sk_stage).
+// Byte offsets of a thread's patch groups from the (picture, chunk) base of the input: functions of the pixel tile only,
+// recomputed when the prefetch stream enters a new one (in the part of an iteration that all waves run).
+// !VEC: nv = number of elements of the group inside its row (1..4).
 template <int NXS>
 struct SkXOff {
-    int off[NXS], meta[NXS];
-    unsigned mask;
+    unsigned voff[NXS];
+    int nv[NXS];
 };
 
 template <typename G, bool VEC>
 __device__ __forceinline__ void sk_xoffsets(const SkP& p, SkCursor& cur, const SkSlots<SkX<G>::NXS>& sl, SkXOff<SkX<G>::NXS>& xo) {
     const int iy0 = cur.tyi * G::TH * G::STRIDE - G::PAD, ix0 = cur.txi * G::TW * G::STRIDE - G::PADL;
     const int HW = p.H * p.W;
-    xo.mask = 0;
 #pragma unroll
     for (int j = 0; j < SkX<G>::NXS; ++j) {
         const int c = sl.c[j];
         const int iy = iy0 + (sl.rc[j] & 0xffff), ix = ix0 + (sl.rc[j] >> 16);        // (ix is a multiple of 4: never astride the left end)
         const bool ok = c >= 0 && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
-        xo.off[j] = ok ? c * HW + iy * p.W + ix : 0;
-        xo.mask |= ok ? 1u << j : 0u;
-        if constexpr (!VEC) {
-            const int nv = p.W - ix < 4 ? p.W - ix : 4;
-            xo.meta[j] = nv;
-        }
+        xo.voff[j] = ok ? (unsigned)(c * HW + iy * p.W + ix) * 4u : kSkNoGroup;
+        if constexpr (!VEC) xo.nv[j] = p.W - ix < 4 ? p.W - ix : 4;
     }
     cur.moved = false;
 }
@@ -221,10 +222,10 @@ __device__ __forceinline__ void sk_xoffsets(const SkP& p, SkCursor& cur, const S
 // MFMAs hold.  (Turning the branch into a scalar one with readfirstlane made the staging registers conditionally assigned loop
 // variables: register moves, spills and a vmcnt(0) at the loop head -- 37.2 vs 33.3 ms per step.)
 struct SkPlan {
-    const float* wb;            // the weight image of (M tile, chunk)
-    const float* xb;            // x of (picture, first channel of the chunk)
-    int kleft;                  // channels from the chunk's first to the last
-    int rem;                    // elements from xb to the end of the tensor (saturated)
+    __amdgpu_buffer_rsrc_t wres;    // the weight image of (M tile, chunk)
+    __amdgpu_buffer_rsrc_t xres;    // x from (picture, first channel of the chunk) to the end of the chunk's channels (or of the tensor)
+    unsigned size;              // its size in bytes
+    bool slow;                  // !VEC: a group of this chunk may lie within three elements of the tensor's end
 };
 
 template <typename G, int TAPS, int WM, bool VEC>
@@ -232,11 +233,25 @@ __device__ __forceinline__ SkPlan sk_plan_fetch(const SkP& p, SkCursor& cur, con
     constexpr int KC = TAPS * G::CK;
     const int k0 = cur.chunk * G::CK, HW = p.H * p.W;
     SkPlan f;
-    f.wb = p.w + ((size_t)cur.mt * p.nch + cur.chunk) * (size_t)(KC * 32 * WM);
-    f.xb = p.x + ((size_t)cur.n * p.K + k0) * HW;
-    f.kleft = p.K - k0;
-    const long long rem64 = ((long long)(p.N - cur.n) * p.K - k0) * HW;
-    f.rem = rem64 > 0x7fffffffLL ? 0x7fffffff : (int)rem64;
+    f.wres = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.w + ((size_t)cur.mt * p.nch + cur.chunk) * (size_t)(KC * 32 * WM)), 0,
+                                               KC * 32 * WM * 4, 0x00020000);
+    const float* xb = p.x + ((size_t)cur.n * p.K + k0) * HW;
+    const int kleft = p.K - k0;
+    // the chunk's channels: groups of channels past the tensor's last (K tail) start at or beyond this size and read as zeros
+    const unsigned long long chunk_bytes = (unsigned long long)(kleft < G::CK ? kleft : G::CK) * HW * 4ull;
+    if constexpr (VEC) {
+        f.size = (unsigned)chunk_bytes;             // (aligned groups end inside their row: none crosses the size)
+        f.slow = false;
+    } else {
+        // a group astride the end of a row reads up to three elements of what follows: allowed up to the end of the tensor
+        const unsigned long long rem_bytes = (((unsigned long long)(p.N - cur.n) * p.K - k0) * HW) * 4ull;
+        const bool full = kleft >= G::CK;
+        // (K tail: the size must end with the last channel, so its last row's astride group is loaded early like the tensor's)
+        f.slow = !full || rem_bytes < chunk_bytes + 16;
+        const unsigned long long sz = full ? (rem_bytes < chunk_bytes + 12 ? rem_bytes : chunk_bytes + 12) : chunk_bytes;
+        f.size = (unsigned)sz;
+    }
+    f.xres = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(xb), 0, (int)f.size, 0x00020000);
     if (cur.moved) sk_xoffsets<G, VEC>(p, cur, sl, xo);
     return f;
 }
@@ -244,32 +259,31 @@ __device__ __forceinline__ SkPlan sk_plan_fetch(const SkP& p, SkCursor& cur, con
 // global -> registers of the planned chunk (its tile may differ from the one being multiplied: the pipeline crosses tile
 // boundaries).  !VEC: xm[j] = what sk_stage needs to know about group j (elements inside the row | elements loaded early << 3).
 template <typename G, int TAPS, int WM, bool VEC, int NWS>
-__device__ __forceinline__ void sk_fetch(const SkPlan& f, const SkSlots<SkX<G>::NXS>& sl, const SkXOff<SkX<G>::NXS>& xo, int tid,
-                                         v4f (&wr)[NWS], v4f (&xr)[SkX<G>::NXS], int (&xm)[VEC ? 1 : SkX<G>::NXS]) {
+__device__ __forceinline__ void sk_fetch(const SkPlan& f, const SkXOff<SkX<G>::NXS>& xo, int tid, v4f (&wr)[NWS], v4f (&xr)[SkX<G>::NXS],
+                                         int (&xm)[VEC ? 1 : SkX<G>::NXS]) {
     constexpr int BM = 32 * WM, NXS = SkX<G>::NXS;
     constexpr int KC = TAPS * G::CK;
+    static_assert(BM * KC % 4 == 0, "weight image in 16-byte groups");
 #pragma unroll
-    for (int j = 0; j < NWS; ++j) {
-        const int e = (tid + j * kSkThreads) * 4;
-        wr[j] = (NWS * kSkThreads * 4 == BM * KC || e < BM * KC) ? *reinterpret_cast<const v4f*>(f.wb + e) : (v4f){0.f, 0.f, 0.f, 0.f};
-    }
+    for (int j = 0; j < NWS; ++j)       // (a group past the image -- only in a last, partial slot -- is outside the resource: zeros)
+        wr[j] = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(f.wres, tid * 16, j * kSkThreads * 16, 0));
+    if (VEC || !f.slow) {
 #pragma unroll
-    for (int j = 0; j < NXS; ++j) {
-        const bool ok = ((xo.mask >> j) & 1u) && sl.c[j] < f.kleft;
-        if constexpr (VEC) {
-            xr[j] = ok ? *reinterpret_cast<const v4f*>(f.xb + xo.off[j]) : (v4f){0.f, 0.f, 0.f, 0.f};
-        } else {
-            // (no use of the loaded values here: masks and the rotation are applied by sk_stage)
-            const int avail = f.rem - xo.off[j];                                // elements from the group's first to the tensor's end
-            const int early = (ok && avail < 4) ? 4 - avail : 0;
-            xm[j] = xo.meta[j] | (early << 3);
-            const float* src = f.xb + xo.off[j] - early;
-            if (ok) {
-                const v4fu u = *reinterpret_cast<const v4fu*>(src);
-                xr[j] = (v4f){u[0], u[1], u[2], u[3]};
-            } else {
-                xr[j] = (v4f){0.f, 0.f, 0.f, 0.f};
-            }
+        for (int j = 0; j < NXS; ++j) {
+            xr[j] = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(f.xres, (int)xo.voff[j], 0, 0));
+            if constexpr (!VEC) xm[j] = xo.nv[j];
+        }
+    } else {
+        // (no use of the loaded values here: masks and the rotation are applied by sk_stage)
+#pragma unroll
+        for (int j = 0; j < NXS; ++j) {
+            const unsigned v = xo.voff[j];
+            const bool ok = v < f.size;                                         // (false for kSkNoGroup and for the K tail)
+            const unsigned avail = ok ? (f.size - v) >> 2 : 4u;                  // elements from the group's first to the end of the resource
+            const int nv = xo.nv[j] < (int)avail ? xo.nv[j] : (int)avail;        // (K tail: what follows the last channel is not the row's)
+            const unsigned early = avail < 4u ? 4u - avail : 0u;
+            if constexpr (!VEC) xm[j] = nv | (int)(early << 3);
+            xr[j] = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(f.xres, (int)(ok ? v - 4u * early : kSkNoGroup), 0, 0));
         }
     }
 }
@@ -278,15 +292,16 @@ __device__ __forceinline__ void sk_fetch(const SkPlan& f, const SkSlots<SkX<G>::
 // 2 cp + h of one tap (h = lane half of the MFMA), the four k-steps 4 q .. 4 q + 3 of one (half, row) are adjacent: one 16-byte
 // read = four MFMAs.
 template <typename G, int TAPS, int WM, bool VEC, int NWS>
-__device__ __forceinline__ void sk_stage(const SkSlots<SkX<G>::NXS>& sl, const int (&xm)[VEC ? 1 : SkX<G>::NXS], float* __restrict__ sW,
-                                         float* __restrict__ sX, int tid, const v4f (&wr)[NWS], const v4f (&xr)[SkX<G>::NXS]) {
+__device__ __forceinline__ void sk_stage(const int (&xm)[VEC ? 1 : SkX<G>::NXS], float* __restrict__ sW, float* __restrict__ sX, int tid,
+                                         const v4f (&wr)[NWS], const v4f (&xr)[SkX<G>::NXS]) {
     constexpr int BM = 32 * WM, CK = G::CK, NXS = SkX<G>::NXS;
     constexpr int KC = TAPS * CK;
+    constexpr int step = kSkThreads * 4;
+    float* wdst = sW + tid * 4;
+    float* xdst = sX + tid * 4;
 #pragma unroll
-    for (int j = 0; j < NWS; ++j) {
-        const int e = (tid + j * kSkThreads) * 4;
-        if (NWS * kSkThreads * 4 == BM * KC || e < BM * KC) *reinterpret_cast<v4f*>(sW + e) = wr[j];
-    }
+    for (int j = 0; j < NWS; ++j)
+        if (NWS * step == BM * KC || tid * 4 + j * step < BM * KC) *reinterpret_cast<v4f*>(wdst + j * step) = wr[j];
 #pragma unroll
     for (int j = 0; j < NXS; ++j) {
         v4f v = xr[j];
@@ -303,7 +318,7 @@ __device__ __forceinline__ void sk_stage(const SkSlots<SkX<G>::NXS>& sl, const i
             v[2] = nv > 2 ? v[2] : 0.0f;
             v[3] = nv > 3 ? v[3] : 0.0f;
         }
-        if (sl.c[j] >= 0) *reinterpret_cast<v4f*>(sX + sl.lds[j]) = v;
+        if (NXS * step == CK * G::CS || tid * 4 + j * step < CK * G::CS) *reinterpret_cast<v4f*>(xdst + j * step) = v;
     }
 }
 
@@ -474,12 +489,12 @@ __global__ __launch_bounds__(kSkThreads) void k_conv_sk(const SkP p) {
     if constexpr (!DMA) {
         sk_slots<G>(tid, slots);
         SkPlan f0 = sk_plan_fetch<G, TAPS, WM, VEC>(p, pre, slots, xoff);
-        sk_fetch<G, TAPS, WM, VEC, NWS>(f0, slots, xoff, tid, wr, xr, xm);
-        sk_stage<G, TAPS, WM, VEC, NWS>(slots, xm, sk_smem, sk_smem + KC * BM, tid, wr, xr);
+        sk_fetch<G, TAPS, WM, VEC, NWS>(f0, xoff, tid, wr, xr, xm);
+        sk_stage<G, TAPS, WM, VEC, NWS>(xm, sk_smem, sk_smem + KC * BM, tid, wr, xr);
         if (it0 + 1 < it1) {
             sk_advance(p, g, sk0, pre);
             f0 = sk_plan_fetch<G, TAPS, WM, VEC>(p, pre, slots, xoff);
-            sk_fetch<G, TAPS, WM, VEC, NWS>(f0, slots, xoff, tid, wr, xr, xm);
+            sk_fetch<G, TAPS, WM, VEC, NWS>(f0, xoff, tid, wr, xr, xm);
         }
         __syncthreads();
     } else {
@@ -514,7 +529,7 @@ __global__ __launch_bounds__(kSkThreads) void k_conv_sk(const SkP p) {
             unsigned long long t1 = 0, t1b = 0, t2 = 0;
 #endif
             // the part every wave runs: where chunk it + 2 lives (scalar registers, see SkPlan)
-            SkPlan f2 = {};
+            SkPlan f2;
             if (it + 2 < it1) {
                 sk_advance(p, g, sk0, pre);
                 f2 = sk_plan_fetch<G, TAPS, WM, VEC>(p, pre, slots, xoff);
@@ -534,11 +549,11 @@ __global__ __launch_bounds__(kSkThreads) void k_conv_sk(const SkP p) {
 #endif
                 if (it + 1 < it1) {
                     float* nW = sk_smem + (buf ^ 1) * bufsz;
-                    sk_stage<G, TAPS, WM, VEC, NWS>(slots, xm, nW, nW + KC * BM, tid, wr, xr);
+                    sk_stage<G, TAPS, WM, VEC, NWS>(xm, nW, nW + KC * BM, tid, wr, xr);
 #ifdef SK_PHASE_STAMPS
                     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #endif
-                    if (it + 2 < it1) sk_fetch<G, TAPS, WM, VEC, NWS>(f2, slots, xoff, tid, wr, xr, xm);
+                    if (it + 2 < it1) sk_fetch<G, TAPS, WM, VEC, NWS>(f2, xoff, tid, wr, xr, xm);
                 }
                 __builtin_amdgcn_s_setprio(0);
 #ifdef SK_PHASE_STAMPS
@@ -979,7 +994,8 @@ int sk_run(const float* x, const float* w, int N, int Cin, int H, int W, int Cou
     // 16-byte global loads: the weight rows and the planes must keep 16-byte groups whole and aligned
     if ((uintptr_t)w % 16 != 0) return MAS_ERR_ALIGN;
     const bool vec = ((uintptr_t)x % 16 == 0) && (p.W % 4 == 0);   // 16-byte loads of the input patch: whole, aligned groups
-    if (!vec && (long long)N * p.K * H * W < 4) return MAS_ERR_SHAPE;   // (the unaligned path reads the tensor's last four elements as one group)
+    if (!vec && ((long long)N * p.K * H * W < 4 || (p.K % g.CK != 0 && (long long)(p.K % g.CK) * H * W < 4))) return MAS_ERR_SHAPE;   // (the unaligned path loads the last group of the tensor / of a K tail so that it ends there: four elements at least)
+    if ((long long)g.CK * H * W * 4 + 16 >= 0xfffffff0LL) return MAS_ERR_SHAPE;          // byte offsets inside a chunk are 32-bit
     // (forward and input gradient are the same kernel: the role lives in the packed weight image)
     if (ksize == 3) {
         if (stride == 2) return dma ? sk_dispatch<9, 8, 2, 1, 2>(p, g, vec, st) : sk_dispatch<9, 8, 2, 1, 0>(p, g, vec, st);
@@ -1067,7 +1083,8 @@ extern "C" int mas_conv_sk_dgrad_s2(const float* dy, const float* wp, int N, int
     sk_geom(3, 2, p.M, p.Ho, p.Wo, 2 + sub, &g);
     if (int rc = sk_plan(p, g, N, sk_num_cus())) return rc;
     const bool vec = ((uintptr_t)dy % 16 == 0) && (p.W % 4 == 0);
-    if (!vec && (long long)N * p.K * p.H * p.W < 4) return MAS_ERR_SHAPE;
+    if (!vec && ((long long)N * p.K * p.H * p.W < 4 || (p.K % g.CK != 0 && (long long)(p.K % g.CK) * p.H * p.W < 4))) return MAS_ERR_SHAPE;
+    if ((long long)g.CK * p.H * p.W * 4 + 16 >= 0xfffffff0LL) return MAS_ERR_SHAPE;
     hipStream_t st = static_cast<hipStream_t>(stream);
     switch (sub) {
         case 0: return sk_dispatch<1, 64, 1, 1, 0, 0>(p, g, vec, st);
