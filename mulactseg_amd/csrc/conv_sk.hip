@@ -228,13 +228,16 @@ struct SkPlan {
     bool slow;                  // !VEC: a group of this chunk may lie within three elements of the tensor's end
 };
 
+// valid == false (the cursor has run past the workgroup's last iteration): both resources are empty, every load of the chunk reads
+// zeros -- the multiply loop then needs no branch around its loads.
 template <typename G, int TAPS, int WM, bool VEC>
-__device__ __forceinline__ SkPlan sk_plan_fetch(const SkP& p, SkCursor& cur, const SkSlots<SkX<G>::NXS>& sl, SkXOff<SkX<G>::NXS>& xo) {
+__device__ __forceinline__ SkPlan sk_plan_fetch(const SkP& p, SkCursor& cur, const SkSlots<SkX<G>::NXS>& sl, SkXOff<SkX<G>::NXS>& xo,
+                                                bool valid = true) {
     constexpr int KC = TAPS * G::CK;
     const int k0 = cur.chunk * G::CK, HW = p.H * p.W;
     SkPlan f;
     f.wres = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.w + ((size_t)cur.mt * p.nch + cur.chunk) * (size_t)(KC * 32 * WM)), 0,
-                                               KC * 32 * WM * 4, 0x00020000);
+                                               valid ? KC * 32 * WM * 4 : 0, 0x00020000);
     const float* xb = p.x + ((size_t)cur.n * p.K + k0) * HW;
     const int kleft = p.K - k0;
     // the chunk's channels: groups of channels past the tensor's last (K tail) start at or beyond this size and read as zeros
@@ -251,8 +254,9 @@ __device__ __forceinline__ SkPlan sk_plan_fetch(const SkP& p, SkCursor& cur, con
         const unsigned long long sz = full ? (rem_bytes < chunk_bytes + 12 ? rem_bytes : chunk_bytes + 12) : chunk_bytes;
         f.size = (unsigned)sz;
     }
+    if (!valid) f.size = 0;
     f.xres = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(xb), 0, (int)f.size, 0x00020000);
-    if (cur.moved) sk_xoffsets<G, VEC>(p, cur, sl, xo);
+    if (valid && cur.moved) sk_xoffsets<G, VEC>(p, cur, sl, xo);
     return f;
 }
 
@@ -322,6 +326,58 @@ __device__ __forceinline__ void sk_stage(const int (&xm)[VEC ? 1 : SkX<G>::NXS],
     }
 }
 
+// One slot of the staging registers (S < NWS: weight group S, else patch group S - NWS): its LDS store and its refill, issued
+// in the shadow of the wave's own MFMAs (see k_conv_sk).
+template <typename G, int TAPS, int WM, bool VEC, int NWS, int S>
+__device__ __forceinline__ void sk_stage_slot(const int (&xm)[VEC ? 1 : SkX<G>::NXS], float* __restrict__ sW, float* __restrict__ sX, int tid,
+                                              const v4f (&wr)[NWS], const v4f (&xr)[SkX<G>::NXS]) {
+    constexpr int BM = 32 * WM, CK = G::CK, NXS = SkX<G>::NXS;
+    constexpr int KC = TAPS * CK;
+    constexpr int step = kSkThreads * 4;
+    if constexpr (S < NWS) {
+        if (NWS * step == BM * KC || tid * 4 + S * step < BM * KC) *reinterpret_cast<v4f*>(sW + tid * 4 + S * step) = wr[S];
+    } else {
+        constexpr int j = S - NWS;
+        v4f v = xr[j];
+        if constexpr (!VEC) {
+            const int nv = xm[j] & 7;
+            const int early = xm[j] >> 3;
+            if (early) {
+                const v4f u = v;
+                v[0] = early == 1 ? u[1] : (early == 2 ? u[2] : u[3]);
+                v[1] = early == 1 ? u[2] : u[3];
+                v[2] = u[3];
+            }
+            v[1] = nv > 1 ? v[1] : 0.0f;
+            v[2] = nv > 2 ? v[2] : 0.0f;
+            v[3] = nv > 3 ? v[3] : 0.0f;
+        }
+        if (NXS * step == CK * G::CS || tid * 4 + j * step < CK * G::CS) *reinterpret_cast<v4f*>(sX + tid * 4 + j * step) = v;
+    }
+}
+
+template <typename G, int TAPS, int WM, bool VEC, int NWS, int S>
+__device__ __forceinline__ void sk_fetch_slot(const SkPlan& f, const SkXOff<SkX<G>::NXS>& xo, int tid, v4f (&wr)[NWS], v4f (&xr)[SkX<G>::NXS],
+                                              int (&xm)[VEC ? 1 : SkX<G>::NXS]) {
+    if constexpr (S < NWS) {
+        wr[S] = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(f.wres, tid * 16, S * kSkThreads * 16, 0));
+    } else {
+        constexpr int j = S - NWS;
+        if (VEC || !f.slow) {
+            xr[j] = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(f.xres, (int)xo.voff[j], 0, 0));
+            if constexpr (!VEC) xm[j] = xo.nv[j];
+        } else {
+            const unsigned v = xo.voff[j];
+            const bool ok = v < f.size;
+            const unsigned avail = ok ? (f.size - v) >> 2 : 4u;
+            const int nv = xo.nv[j] < (int)avail ? xo.nv[j] : (int)avail;
+            const unsigned early = avail < 4u ? 4u - avail : 0u;
+            if constexpr (!VEC) xm[j] = nv | (int)(early << 3);
+            xr[j] = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(f.xres, (int)(ok ? v - 4u * early : kSkNoGroup), 0, 0));
+        }
+    }
+}
+
 template <int TAPS, int CK, int WM, int TW, int STRIDE, int DIL, bool VEC, int NB, int SUB = 0>
 __global__ __launch_bounds__(kSkThreads) void k_conv_sk(const SkP p) {
     using G = SkG<TAPS, CK, TW, STRIDE, DIL, SUB>;
@@ -332,8 +388,10 @@ __global__ __launch_bounds__(kSkThreads) void k_conv_sk(const SkP p) {
     constexpr int TN = BN / NG / 32;            // 32-pixel accumulator tiles per wave: 2 (BM 128) / 1 (BM 64)
     constexpr int KC = TAPS * CK;
     constexpr int NQ = KC / 8;                  // groups of four k-steps per chunk
+#ifdef SK_PHASED
     constexpr int QSPLIT = NQ;      // waves 0-3 stage after all their MFMA groups,
     constexpr int QEARLY = 0;       // waves 4-7 before theirs
+#endif
     constexpr int NWS = (BM * KC / 4 + kSkThreads - 1) / kSkThreads;
     static_assert(KC % 8 == 0 && TN >= 1, "tile");
     extern __shared__ __attribute__((aligned(16))) float sk_smem[];
@@ -517,9 +575,34 @@ __global__ __launch_bounds__(kSkThreads) void k_conv_sk(const SkP p) {
             dma_publish();                      // chunk it + 1 has landed; (DEPTH - 1) younger ones stay in flight
             buf = buf + 1 == NBUF ? 0 : buf + 1;
         } else {
-            // (Spreading the stores / refills slot by slot behind the MFMA groups was tried: hipcc then waits vmcnt(0) in front of
-            // every slot's LDS store -- its counter bookkeeping does not survive the loop back edge -- which stalls on the refill issued
-            // one group earlier; the burst form below waits once, for loads that are a whole iteration old.)
+#ifndef SK_PHASED
+            // In-kernel stamps (tools/sk_phases.py on the -DSK_PHASED build): while one wave of a SIMD issues its MFMAs back to back, its
+            // partner on the same SIMD is starved -- ANY instruction of it, scalar or memory, with or without raised priority, is issued
+            // about once per two or three MFMAs (an LDS-store + load burst of 16 instructions: 560 cycles when the partner also stages,
+            // 3.8-4.5k cycles beside the partner's multiply phase).  Work of one wave cannot hide behind the other wave's MFMAs; it hides
+            // behind its OWN: every wave runs the same program, and slot s of the staging registers -- the LDS store of chunk it + 1,
+            // then the refill with chunk it + 2 -- rides behind MFMA group q of the wave itself.  The loop body has no branch (a chunk
+            // past the end is an empty resource), so hipcc counts the outstanding loads across the back edge: the store of slot s
+            // waits for vmcnt(NS - 1), i.e. for a load that is a whole iteration old.
+            const bool v2 = it + 2 < it1;
+            if (v2) sk_advance(p, g, sk0, pre);
+            const SkPlan f2 = sk_plan_fetch<G, TAPS, WM, VEC>(p, pre, slots, xoff, v2);
+            float* nW = sk_smem + (buf ^ 1) * bufsz;
+            float* nX = nW + KC * BM;
+            constexpr int NS = NWS + NXS;
+            mfma_part(buf, std::integral_constant<int, 0>{}, std::integral_constant<int, NQ>{}, [&](auto qc) {
+                constexpr int q = decltype(qc)::value;
+                constexpr int s0 = q * NS / NQ, s1 = (q + 1) * NS / NQ;
+                sk_static_for<s0, s1>([&](auto sc) {
+                    constexpr int S = decltype(sc)::value;
+                    sk_stage_slot<G, TAPS, WM, VEC, NWS, S>(xm, nW, nX, tid, wr, xr);
+                    sk_fetch_slot<G, TAPS, WM, VEC, NWS, S>(f2, xoff, tid, wr, xr, xm);
+                });
+            });
+            __syncthreads();
+            buf ^= 1;
+#else
+            // (the phased form, kept for tools/sk_phases.py: the measurement that led to the interleaved one)
             // The two waves of a SIMD are COMPLEMENTARY: waves 0-3 (the older ones: the matrix pipe serves them first, the
             // younger wave gets almost nothing meanwhile) multiply first and stage + refetch afterwards; waves 4-7 stage + refetch
             // first and multiply afterwards, so each wave's memory phase sits beside its partner's MFMAs.  With both staging at 3/4
@@ -561,8 +644,12 @@ __global__ __launch_bounds__(kSkThreads) void k_conv_sk(const SkP p) {
 #endif
                 mfma_part(buf, std::integral_constant<int, qs>{}, std::integral_constant<int, NQ>{}, no_hook);
             };
+#ifdef SK_BOTH_EARLY
+            body(std::integral_constant<int, QEARLY>{});
+#else
             if (wave < 4) body(std::integral_constant<int, QSPLIT>{});
             else body(std::integral_constant<int, QEARLY>{});
+#endif
 #ifdef SK_PHASE_STAMPS
             const unsigned long long t3 = __builtin_readcyclecounter();
             __syncthreads();
@@ -577,6 +664,7 @@ __global__ __launch_bounds__(kSkThreads) void k_conv_sk(const SkP p) {
 #endif
             __syncthreads();
             buf ^= 1;
+#endif
         }
     };
 

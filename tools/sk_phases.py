@@ -1,5 +1,5 @@
 #!/usr/bin/env python
-"""Where one wave of mas_conv_sk spends an iteration (needs a library built with -DSK_PHASE_STAMPS): cycles of MFMA part 1,
+"""Where one wave of mas_conv_sk spends an iteration (needs a library whose conv_sk.hip was built with -DSK_PHASED -DSK_PHASE_STAMPS: the phased form of the multiply loop, kept for this measurement): cycles of MFMA part 1,
 stage + refetch, MFMA part 2, barrier, per wave of workgroup 7.   python tools/sk_phases.py Cin Cout k stride dil N H W"""
 import os
 import sys
