@@ -11,8 +11,10 @@
 // GEMM view per picture:  Y[m, p] = sum_{tap, c} A[m, (tap, c)] * X[c, pixel p shifted by tap]
 //   M tile 128 (or 64) output channels x N tile 128 output pixels (a TH x TW patch), K walked in chunks of CK channels x taps.
 //   One workgroup = 8 waves = one CU: wave w owns rows 32 (w % WM) .. and pixel group w / WM of the tile; waves w, w + 4 share a
-//   SIMD.  Two LDS buffers; chunk t + 1 travels global -> registers while chunk t is multiplied and is written to the other
-//   buffer three quarters into the multiply phase; one barrier per chunk.  The pipeline runs across tile boundaries.
+//   SIMD.  Two LDS buffers; chunk t + 2 travels global -> registers (buffer loads at byte offsets computed once per pixel tile)
+//   while chunk t is multiplied; every wave stores slot s of its staging registers (chunk t + 1) to the other buffer and refills
+//   it behind its OWN MFMA group q (a wave's partner on the SIMD is starved while it multiplies: nothing hides there); one
+//   barrier per chunk.  The pipeline runs across tile boundaries.
 // Stream-K: the launch has one workgroup per CU; the (tile, chunk) iterations of the whole layer are dealt to them in equal
 //   contiguous ranges, so the planes of the deep layers (48 x 48: 144 tiles for 256 CUs) load every CU the same.  A tile whose
 //   chunks straddle workgroups is finished by the workgroup that owns its FIRST chunk: the others (for them it is the leading
