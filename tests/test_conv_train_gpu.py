@@ -313,6 +313,28 @@ def test_train_step_on_own_convolutions_matches_float64():
     print("vs float64: logits own %.2e / miopen %.2e; relative L2 error of all gradients own %.2e / miopen %.2e" % (ez_own, ez_mi, worst_own, worst_mi))
 
 
+def test_training_step_takes_no_vendor_or_aten_fallback():
+    """Default settings, one training forward + backward: every fusable layer of the network runs on this package's kernels --
+    no 'aten' BatchNorm / upsample / pooling / depthwise path, no MIOpen convolution ('miopen+bn'); all three products of every
+    dense convolution on the own kernels ('train:fdw') except the 1x1 convolution of the ASPP pooling branch on its 1x1 map
+    (forward and input gradient are a [N,2048] x [2048,256] GEMM there: 'train:--w')."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from mulactseg_amd.models import deeplab, get_model
+    assert os.environ.get("MAS_TRAIN_CONV", "own") == "own"
+    torch.manual_seed(5)
+    net = get_model('deeplabv3pluswn_resnet50deepstem', 20, 16, True, pretrained_backbone=False).cuda().train()
+    x = torch.randn(2, 3, 256, 256, device='cuda')
+    deeplab.path_report(reset=True)
+    net(x, lowres=True).square().mean().backward()
+    torch.cuda.synchronize()
+    rep = deeplab.path_report(reset=True)
+    for kind, paths in rep.items():
+        assert 'aten' not in paths and 'miopen+bn' not in paths, (kind, paths)
+    assert set(rep["conv_bn_act"]) == {"train:fdw", "train:--w"} and rep["conv_bn_act"]["train:--w"] == 1, rep["conv_bn_act"]
+    assert rep["bn_act"] == {"hip": sum(rep["conv_bn_act"].values())} or set(rep["bn_act"]) == {"hip"}, rep["bn_act"]
+
+
 def test_packed_weight_images_follow_in_place_updates():
     """ops.packed_weight: the images of all registered convolutions are re-packed by ONE launch when a weight's version counter
     has moved (what an optimizer step does); scaling the weights by 2 in place must scale outputs and input gradients by exactly 2."""
