@@ -446,7 +446,7 @@ int mas_conv_sk_error(const void* workspace, unsigned* out_host);
  * every tile (the relu(bn(conv(x))) triples of backbone/resnet.py:143-160 in training mode: removes the reduction pass over y):
  * stats [Cout][mas_conv_sk_stats_slots(...)] pairs of doubles (sum y, sum y^2) over disjoint pixel sets, every entry written;
  * fixed summation order (run-to-run identical).  Consumer: mas_bn_act_train_fwd_stats. */
-int mas_conv_sk_stats_slots(int N, int Cin, int H, int W, int Cout, int ksize, int stride);
+int mas_conv_sk_stats_slots(int N, int Cin, int H, int W, int Cout, int ksize, int stride, int dil);
 int mas_conv_sk_stats(const float* x, const float* wp, int N, int Cin, int H, int W, int Cout, int ksize, int stride, int dil, float* y,
                       double* stats, void* workspace, size_t workspace_bytes, unsigned epoch, void* stream);
 /* Input gradient of a 3x3, stride-2, padding-1 convolution (torch.autograd of nn.Conv2d(k=3, stride=2, padding=1), the conv2 of

@@ -73,7 +73,7 @@ SIGNATURES = {
     "mas_conv_sk_pack_multi": (_i, [_vp, _i, _c.c_uint, _vp]),
     "mas_conv_sk": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _i, _vp, _vp, _c.c_size_t, _c.c_uint, _vp]),
     "mas_conv_sk_error": (_i, [_vp, _vp]),
-    "mas_conv_sk_stats_slots": (_i, [_i, _i, _i, _i, _i, _i, _i]),
+    "mas_conv_sk_stats_slots": (_i, [_i, _i, _i, _i, _i, _i, _i, _i]),
     "mas_conv_sk_stats": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _c.c_size_t, _c.c_uint, _vp]),
     "mas_conv_sk_dgrad_s2": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _i, _vp, _vp, _c.c_size_t, _c.c_uint, _vp]),
     "mas_conv_sk_set_mode": (_i, [_i]),

@@ -64,17 +64,25 @@ struct SkP {
 // SUB != 0: one parity class (py, px) = (SUB >> 1, SUB & 1) of the input gradient of a stride-2 3x3 convolution, as a stride-1
 // product over the dY plane with (1 + py) x (1 + px) taps at offsets {0, 1} (dX[2i + 1] takes dY[i] through weight row 2 and
 // dY[i + 1] through row 0; dX[2i] takes dY[i] through row 1): no padding on the left / top, the patch starts at the tile.
+// SUB = 64 / 128 (LW): a 3x3 stride-1 product on a NARROW plane (32 <= W <= 56 / 57 <= W <= 120) walks the plane's pixels in row-major
+// order, 128 consecutive pixels per tile (TW = 128), with a patch of LW columns that holds the FULL rows the tile touches (at most
+// RMAX of them) plus the halo: the 49 x 49 planes of the 769 crop take 19 tiles instead of 26 4 x 32 ones (a third of every
+// second tile lies right of the plane), 97 x 97: 74 instead of 91.  The B-operand base of a lane then depends on the tile (two
+// integer divisions per lane and tile); the tap offsets stay immediates (a row below is + PWL whatever the plane's width).
 template <int TAPS, int CK_, int TW_, int STRIDE_, int DIL_, int SUB_ = 0>
 struct SkG {
-    static constexpr int CK = CK_, TW = TW_, STRIDE = STRIDE_, DIL = DIL_, SUB = SUB_;
+    static constexpr int CK = CK_, TW = TW_, STRIDE = STRIDE_, DIL = DIL_;
+    static constexpr int LW = SUB_ >= 64 ? SUB_ : 0, SUB = SUB_ < 64 ? SUB_ : 0;
     static constexpr int TR = SUB ? 1 + (SUB >> 1) : (TAPS == 9 ? 3 : 1), TC = SUB ? 1 + (SUB & 1) : (TAPS == 9 ? 3 : 1);
     static_assert(TR * TC == TAPS && (SUB == 0 || (STRIDE == 1 && DIL == 1)), "tap geometry");
+    static_assert(LW == 0 || (TAPS == 9 && STRIDE == 1 && TW == 128 && (LW == 64 || LW == 128)), "linear pixel walk");
     static constexpr int TH = kSkBN / TW;
     static constexpr int TWLOG = TW == 128 ? 7 : (TW == 32 ? 5 : 4);
     static constexpr int PAD = (TAPS == 9 && !SUB) ? DIL : 0;
     static constexpr int PADL = (TAPS == 9 && !SUB) ? 4 : 0;
-    static constexpr int PH = SUB ? TH + TR - 1 : (TH - 1) * STRIDE + 1 + 2 * PAD;
-    static constexpr int PWL = SUB ? (TW + TC - 1 + 3) & ~3 : ((TW - 1) * STRIDE + 1 + 2 * PADL + 3) & ~3;
+    static constexpr int RMAX = LW == 64 ? 5 : 4;           // rows that 128 consecutive pixels touch when W >= 32 / W >= 57
+    static constexpr int PH = LW ? RMAX + 2 * PAD : (SUB ? TH + TR - 1 : (TH - 1) * STRIDE + 1 + 2 * PAD);
+    static constexpr int PWL = LW ? LW : (SUB ? (TW + TC - 1 + 3) & ~3 : ((TW - 1) * STRIDE + 1 + 2 * PADL + 3) & ~3);
     static constexpr int CS = PH * PWL;
     static constexpr int NXS = (CK * CS / 4 + kSkThreads - 1) / kSkThreads;
     static constexpr int toff(int tap) { return ((tap / TC) * PWL + (tap % TC)) * DIL; }
@@ -204,7 +212,9 @@ struct SkXOff {
 
 template <typename G, bool VEC>
 __device__ __forceinline__ void sk_xoffsets(const SkP& p, SkCursor& cur, const SkSlots<SkX<G>::NXS>& sl, SkXOff<SkX<G>::NXS>& xo) {
-    const int iy0 = cur.tyi * G::TH * G::STRIDE - G::PAD, ix0 = cur.txi * G::TW * G::STRIDE - G::PADL;
+    // (linear walk: the patch holds full rows from the first row the tile touches)
+    const int iy0 = G::LW ? (cur.txi * kSkBN) / p.W - G::PAD : cur.tyi * G::TH * G::STRIDE - G::PAD;
+    const int ix0 = G::LW ? -G::PADL : cur.txi * G::TW * G::STRIDE - G::PADL;
     const int HW = p.H * p.W;
 #pragma unroll
     for (int j = 0; j < SkX<G>::NXS; ++j) {
@@ -678,6 +688,16 @@ __global__ __launch_bounds__(kSkThreads) void k_conv_sk(const SkP p) {
         const int c1 = (left < p.nch - c0) ? c0 + left : p.nch;        // (whole tiles: c0 = 0, c1 = nch)
         const int mt = tile % p.mtiles, pt = tile / p.mtiles;
         const int m0 = mt * BM;
+        if constexpr (G::LW != 0) {
+            // linear walk: where this tile's pixels sit in the full-row patch
+            const int pix0 = (pt % p.tiles_x) * kSkBN, y0 = pix0 / p.W, last = p.H * p.W - 1;
+#pragma unroll
+            for (int tn = 0; tn < TN; ++tn) {
+                const int pp = pix0 + pl[tn] < last ? pix0 + pl[tn] : last;
+                const int y = pp / p.W, x = pp - y * p.W;
+                bBase[tn] = h * CS + (y - y0) * PWL + x + G::PADL - G::PAD;
+            }
+        }
         // epilogue constants of this tile; the buffer alternates per tile: slower waves may still read the previous tile's
         float* sE = sEbase + tile_parity * 2 * BM;
         tile_parity ^= 1;
@@ -915,6 +935,18 @@ inline void sk_geom(int ksize, int stride, int M, int Ho, int Wo, int mode, SkGe
     g->TH = kSkBN / g->TW;
 }
 
+// Linear pixel walk (SkG::LW) for a 3x3 stride-1 product on an H x W plane: the patch class (64 / 128 columns), or 0 when the plane
+// is outside both classes, the patch would not fit the LDS (128 columns at dilation 4) or the walk saves less than a tenth of the
+// tiles (48 x 48: 18 tiles either way).
+inline int sk_linear_class(int ksize, int stride, int dil, int H, int W) {
+    if (ksize != 3 || stride != 1) return 0;
+    const int lw = (W >= 32 && W <= 56) ? 64 : ((W >= 57 && W <= 120 && dil <= 2) ? 128 : 0);
+    if (!lw) return 0;
+    const long long t32 = (long long)((W + 31) / 32) * ((H + 3) / 4), t16 = (long long)((W + 15) / 16) * ((H + 7) / 8);
+    const long long t2d = t32 <= t16 ? t32 : t16, tl = ((long long)H * W + kSkBN - 1) / kSkBN;
+    return tl * 10 <= t2d * 9 ? lw : 0;
+}
+
 unsigned long long* g_sk_stamps = nullptr;       // tools: device buffer [512][4] for per-workgroup wall-clock stamps (mas_conv_sk_debug_stamps)
 int g_sk_dma = 0;        // 0: register-staged chunks (default: measured 3-5 % faster); 1: LDS-DMA ring (kept, tested, for A/B measurements)
 
@@ -1067,6 +1099,10 @@ int sk_run(const float* x, const float* w, int N, int Cin, int H, int W, int Cou
     }
     const bool dma = g_sk_dma != 0;
     const bool flat = ksize == 1 && stride == 1 && !dma;
+    const int lw = dma ? 0 : sk_linear_class(ksize, stride, dil, H, W);        // (input gradient at stride 1: the same plane)
+    if (lw) {
+        p.Wo = H * W; p.Ho = 1;             // tiles of 128 consecutive pixels; the input plane keeps its rows (p.H, p.W)
+    }
     if (flat) {
         // a 1x1 product at stride 1 does not see the plane's rows: the plane is walked as ONE row of H * W pixels in tiles of 128
         // consecutive pixels -- no partial tiles at the right edge of every row (49 x 49: 19 tiles instead of 26), the same
@@ -1078,7 +1114,7 @@ int sk_run(const float* x, const float* w, int N, int Cin, int H, int W, int Cou
     SkGeom g;
     sk_geom(ksize, stride, p.M, p.Ho, p.Wo, dgrad ? 1 : 0, &g);
     const int cus = sk_num_cus();
-    if (flat) { g.TW = 128; g.TH = 1; }
+    if (flat || lw) { g.TW = 128; g.TH = 1; }
     if (int rc = sk_plan(p, g, N, cus)) return rc;
     const int ntiles = p.ptiles * p.mtiles;
     // 16-byte global loads: the weight rows and the planes must keep 16-byte groups whole and aligned
@@ -1087,6 +1123,14 @@ int sk_run(const float* x, const float* w, int N, int Cin, int H, int W, int Cou
     if (!vec && ((long long)N * p.K * H * W < 4 || (p.K % g.CK != 0 && (long long)(p.K % g.CK) * H * W < 4))) return MAS_ERR_SHAPE;   // (the unaligned path loads the last group of the tensor / of a K tail so that it ends there: four elements at least)
     if ((long long)g.CK * H * W * 4 + 16 >= 0xfffffff0LL) return MAS_ERR_SHAPE;          // byte offsets inside a chunk are 32-bit
     // (forward and input gradient are the same kernel: the role lives in the packed weight image)
+    if (lw) {
+#define SK_LIN(DIL, LW)                                                                                                        \
+    (g.BM == 128 ? (vec ? sk_launch<9, 8, 4, 128, 1, DIL, true, 0, LW>(p, st) : sk_launch<9, 8, 4, 128, 1, DIL, false, 0, LW>(p, st)) \
+                 : (vec ? sk_launch<9, 8, 2, 128, 1, DIL, true, 0, LW>(p, st) : sk_launch<9, 8, 2, 128, 1, DIL, false, 0, LW>(p, st)))
+        if (lw == 64) return dil == 4 ? SK_LIN(4, 64) : (dil == 2 ? SK_LIN(2, 64) : SK_LIN(1, 64));
+        return dil == 2 ? SK_LIN(2, 128) : SK_LIN(1, 128);
+#undef SK_LIN
+    }
     if (ksize == 3) {
         if (stride == 2) return dma ? sk_dispatch<9, 8, 2, 1, 2>(p, g, vec, st) : sk_dispatch<9, 8, 2, 1, 0>(p, g, vec, st);
         if (dil == 4) return dma ? sk_dispatch<9, 8, 1, 4, 2>(p, g, vec, st) : sk_dispatch<9, 8, 1, 4, 0>(p, g, vec, st);
@@ -1119,10 +1163,10 @@ extern "C" int mas_conv_sk(const float* x, const float* w, int N, int Cin, int H
 }
 
 /* Entries per output channel of the BatchNorm partials mas_conv_sk_stats writes for this forward product (0: unsupported). */
-extern "C" int mas_conv_sk_stats_slots(int N, int Cin, int H, int W, int Cout, int ksize, int stride) {
+extern "C" int mas_conv_sk_stats_slots(int N, int Cin, int H, int W, int Cout, int ksize, int stride, int dil) {
     if (N <= 0 || Cin <= 0 || H <= 0 || W <= 0 || Cout <= 0 || (ksize != 1 && ksize != 3) || (stride != 1 && stride != 2)) return 0;
     int Ho = (H - 1) / stride + 1, Wo = (W - 1) / stride + 1;
-    const bool flat = ksize == 1 && stride == 1 && g_sk_dma == 0;
+    const bool flat = (ksize == 1 && stride == 1 && g_sk_dma == 0) || (g_sk_dma == 0 && sk_linear_class(ksize, stride, dil, H, W) != 0);
     if (flat) { Wo = H * W; Ho = 1; }
     SkGeom g;
     sk_geom(ksize, stride, Cout, Ho, Wo, 0, &g);

@@ -1230,7 +1230,7 @@ def conv_sk(x, w, stride=1, dil=1, dgrad=False, scale=None, shift=None, residual
         # forward without epilogue + the BatchNorm partial sums of y from the epilogue of every tile: (y, partials [Cout, slots, 2] f64)
         if dgrad or scale is not None or residual is not None or relu:
             raise ValueError("stats=True: bare forward product only")
-        slots = int(lib.mas_conv_sk_stats_slots(N, Cin, H, W, Cout, ks, stride))
+        slots = int(lib.mas_conv_sk_stats_slots(N, Cin, H, W, Cout, ks, stride, dil))
         if slots <= 0:
             raise ValueError("unsupported geometry for mas_conv_sk_stats")
         part = torch.empty((Cout, slots, 2), dtype=torch.float64, device=x.device)
