@@ -33,6 +33,14 @@ CASES = [
     (64, 200, 3, 1, 1, 1, 9, 33),        # Cout 200
     (3, 64, 3, 2, 1, 2, 32, 48),         # the stem's first convolution: Cin 3
     (2048, 256, 1, 1, 1, 2, 12, 12),     # ASPP 1x1
+    # 3x3 stride 1 on narrow planes: the linear pixel walk (128 consecutive pixels per tile, full-row patches of 64 / 128 columns)
+    (256, 256, 3, 1, 1, 2, 49, 49),      # layer3 at the 769 crop
+    (128, 128, 3, 1, 2, 1, 49, 49),      # dilation 2
+    (64, 64, 3, 1, 4, 1, 40, 36),        # dilation 4, 13-row patch
+    (64, 72, 3, 1, 1, 1, 33, 56),        # widest plane of the 64-column class, Cout 72
+    (128, 128, 3, 1, 1, 2, 97, 97),      # layer2 at the 769 crop: the 128-column class
+    (64, 64, 3, 1, 2, 1, 20, 120),       # its widest plane, dilation 2
+    (64, 64, 3, 1, 1, 1, 30, 57),        # its narrowest
 ]
 
 
@@ -133,7 +141,8 @@ def test_stream_k_exact_on_integers_at_layer_sizes(sk_mode):
                                               (64, 64, 3, 1, 1, 1, 96, 96), (128, 128, 3, 2, 1, 2, 64, 96), (256, 512, 1, 2, 1, 2, 64, 64),
                                               (304, 256, 1, 1, 1, 1, 64, 64), (256, 48, 1, 1, 1, 1, 64, 64), (256, 256, 3, 1, 1, 2, 49, 49),
                                               (512, 128, 1, 1, 1, 2, 97, 97), (64, 64, 3, 2, 1, 1, 97, 97), (64, 64, 1, 1, 1, 1, 1, 3),
-                                              (64, 64, 3, 1, 1, 2, 2, 3), (2048, 256, 1, 1, 1, 4, 1, 1)):
+                                              (64, 64, 3, 1, 1, 2, 2, 3), (2048, 256, 1, 1, 1, 4, 1, 1), (128, 128, 3, 1, 1, 2, 97, 97),
+                                              (512, 512, 3, 1, 2, 4, 49, 49), (64, 64, 3, 1, 4, 2, 35, 52)):
         x = torch.randint(-2, 3, (N, Cin, H, W), generator=g, device='cuda').float()
         w = torch.randint(-2, 3, (Cout, Cin, k, k), generator=g, device='cuda').float()
         Ho, Wo = (H - 1) // stride + 1, (W - 1) // stride + 1
