@@ -1289,8 +1289,8 @@ _SIDE_STREAMS = {}
 
 
 def _side_stream(dev):
-    """The stream the weight gradients run on: dW is a leaf of the backward graph, so k_wgrad of a layer runs beside the
-    input-gradient kernel of the same layer instead of in front of it."""
+    """The stream the weight gradients run on under MAS_WGRAD_STREAM=side (dW is a leaf of the backward graph; not the default:
+    see _ConvTrain.backward)."""
     st = _SIDE_STREAMS.get(dev)
     if st is None:
         st = _SIDE_STREAMS[dev] = torch.cuda.Stream(device=dev)
@@ -1351,7 +1351,11 @@ class _ConvTrain(torch.autograd.Function):
         side = None
         if need_dw and own[2]:
             main = torch.cuda.current_stream(x.device)
-            if need_dx and os.environ.get("MAS_WGRAD_STREAM", "side") == "side":
+            # MAS_WGRAD_STREAM=side puts dW on a second stream beside the input gradient of the same layer.  Both are kernels that fill
+            # the chip (one 8-wave workgroup per CU, 90-140 KB of LDS): side by side they only take CUs from each other, and the
+            # stream-K hand-off of k_conv_sk waits for workgroups that are not resident yet -- measured 34.1 vs 32.4 ms per step at
+            # the 768 crop, 39.3 vs 37.7 at 769.  Default: one stream.
+            if need_dx and os.environ.get("MAS_WGRAD_STREAM", "main") == "side":
                 side = _side_stream(x.device)
                 side.wait_stream(main)                      # dy (and x) are ready on the main stream
                 with torch.cuda.stream(side):
