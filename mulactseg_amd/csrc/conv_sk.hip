@@ -54,6 +54,8 @@ struct SkP {
     int tiles_x, tiles_y, ptiles, mtiles, nch;
     int iters;                  // all (tile, chunk) iterations of the layer
     int N;                      // pictures
+    int img, ck;                // floats of one weight image (taps * CK * BM), channels per chunk
+    long long xstep;            // floats from a chunk's first channel to the next chunk's (CK * H * W)
     int P;                      // workgroups (one per CU)
     int rdp, sk_iters;          // whole tiles per workgroup (rounds of P tiles), iterations of the remaining tiles (stream-K part)
 };
@@ -108,9 +110,16 @@ __device__ __forceinline__ void sk_store_sc1(float* p, v4f v) {
 //                    workgroup had L2 hit rates of 11-42 % and global-load latencies of ~5 us under load);
 //   v >= rdp * nch : the remaining ntiles - rdp * P tiles, their iterations dealt to the workgroups in equal contiguous runs
 //                    (stream-K: iteration sk0(g) + (v - rdp * nch) of that space).
+// The chunk's addresses travel with the cursor (a step inside a tile is three additions; they are recomputed from the indices only
+// when the tile changes): the per-iteration scalar code of the multiply loop is not hidden behind anything -- a wave issues in
+// order -- and the full recomputation was ~100 scalar instructions (64-bit multiplies, SGPR spills) per wave and chunk.
 struct SkCursor {
     int v, chunk, mt, n, tyi, txi;
     bool moved;                 // the pixel tile changed since the patch offsets were computed (sk_xoffsets clears it)
+    const float* wptr;          // the weight image of (mt, chunk)
+    const float* xptr;          // x of (picture n, first channel of the chunk)
+    int kleft;                  // channels from the chunk's first to the tensor's last
+    long long rem;              // elements from xptr to the end of the tensor
 };
 
 __device__ __forceinline__ void sk_decode(const SkP& p, int g, int sk0, int v, int& tile, int& chunk) {
@@ -138,6 +147,12 @@ __device__ __forceinline__ void sk_locate(const SkP& p, int g, int sk0, SkCursor
     c.tyi = trem / p.tiles_x;
     c.txi = trem - c.tyi * p.tiles_x;
     c.moved = true;
+    const long long HW = (long long)p.H * p.W;
+    const int k0 = c.chunk * p.ck;
+    c.wptr = p.w + ((size_t)c.mt * p.nch + c.chunk) * (size_t)p.img;
+    c.xptr = p.x + ((long long)c.n * p.K + k0) * HW;
+    c.kleft = p.K - k0;
+    c.rem = ((long long)(p.N - c.n) * p.K - k0) * HW;
 }
 
 __device__ __forceinline__ SkCursor sk_cursor(const SkP& p, int g, int sk0, int v) {
@@ -149,7 +164,14 @@ __device__ __forceinline__ SkCursor sk_cursor(const SkP& p, int g, int sk0, int 
 
 __device__ __forceinline__ void sk_advance(const SkP& p, int g, int sk0, SkCursor& c) {
     ++c.v;
-    if (++c.chunk == p.nch) sk_locate(p, g, sk0, c);        // next tile of the workgroup's list (once per tile)
+    if (++c.chunk == p.nch) {
+        sk_locate(p, g, sk0, c);                            // next tile of the workgroup's list (once per tile)
+    } else {
+        c.wptr += p.img;
+        c.xptr += p.xstep;
+        c.kleft -= p.ck;
+        c.rem -= p.xstep;
+    }
 }
 
 // Per-thread description of its 16-byte groups of the input patch (depends on the thread only): channel, patch row / column
@@ -246,12 +268,11 @@ template <typename G, int TAPS, int WM, bool VEC>
 __device__ __forceinline__ SkPlan sk_plan_fetch(const SkP& p, SkCursor& cur, const SkSlots<SkX<G>::NXS>& sl, SkXOff<SkX<G>::NXS>& xo,
                                                 bool valid = true) {
     constexpr int KC = TAPS * G::CK;
-    const int k0 = cur.chunk * G::CK, HW = p.H * p.W;
+    const int HW = p.H * p.W;
     SkPlan f;
-    f.wres = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.w + ((size_t)cur.mt * p.nch + cur.chunk) * (size_t)(KC * 32 * WM)), 0,
-                                               valid ? KC * 32 * WM * 4 : 0, 0x00020000);
-    const float* xb = p.x + ((size_t)cur.n * p.K + k0) * HW;
-    const int kleft = p.K - k0;
+    f.wres = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(cur.wptr), 0, valid ? KC * 32 * WM * 4 : 0, 0x00020000);
+    const float* xb = cur.xptr;
+    const int kleft = cur.kleft;
     // the chunk's channels: groups of channels past the tensor's last (K tail) start at or beyond this size and read as zeros
     const unsigned long long chunk_bytes = (unsigned long long)(kleft < G::CK ? kleft : G::CK) * HW * 4ull;
     if constexpr (VEC) {
@@ -259,7 +280,7 @@ __device__ __forceinline__ SkPlan sk_plan_fetch(const SkP& p, SkCursor& cur, con
         f.slow = false;
     } else {
         // a group astride the end of a row reads up to three elements of what follows: allowed up to the end of the tensor
-        const unsigned long long rem_bytes = (((unsigned long long)(p.N - cur.n) * p.K - k0) * HW) * 4ull;
+        const unsigned long long rem_bytes = (unsigned long long)cur.rem * 4ull;
         const bool full = kleft >= G::CK;
         // (K tail: the size must end with the last channel, so its last row's astride group is loaded early like the tensor's)
         f.slow = !full || rem_bytes < chunk_bytes + 16;
@@ -558,6 +579,8 @@ __global__ __launch_bounds__(kSkThreads) void k_conv_sk(const SkP p) {
     int xm[VEC ? 1 : NXS];
     if constexpr (!DMA) {
         sk_slots<G>(tid, slots);
+        // (requesting chunks it0 and it0 + 1 back to back -- one memory round trip in front of the first MFMA instead of two -- was
+        // measured: no difference, 32.6 vs 32.5 ms per step)
         SkPlan f0 = sk_plan_fetch<G, TAPS, WM, VEC>(p, pre, slots, xoff);
         sk_fetch<G, TAPS, WM, VEC, NWS>(f0, xoff, tid, wr, xr, xm);
         sk_stage<G, TAPS, WM, VEC, NWS>(xm, sk_smem, sk_smem + KC * BM, tid, wr, xr);
@@ -986,6 +1009,9 @@ int sk_launch(const SkP& p, hipStream_t st) {
 // tiles, chunks and the deal of the iterations to the workgroups (p.K, p.M, p.Ho, p.Wo set)
 inline int sk_plan(SkP& p, const SkGeom& g, int N, int cus) {
     p.N = N;
+    p.img = g.TAPS * g.CK * g.BM;
+    p.ck = g.CK;
+    p.xstep = (long long)g.CK * p.H * p.W;
     p.tiles_x = (p.Wo + g.TW - 1) / g.TW;
     p.tiles_y = (p.Ho + g.TH - 1) / g.TH;
     p.ptiles = N * p.tiles_x * p.tiles_y;
