@@ -570,10 +570,9 @@ __global__ __launch_bounds__(kSkThreads) void k_conv_sk(const SkP p) {
         }
     };
     // ---- register-staged pipeline (NB == 0) -------------------------------------------------------------------------------------
-    // The registers that carried chunk it + 1 to LDS are refilled with chunk it + 2 right behind that store, three quarters into
-    // iteration it: a load then has a whole iteration to arrive.  (One chunk in flight = 64 KB of staging registers per CU for the
-    // 1x1 kernel; at ~5 us per global load under load the loop runs at the memory latency, not at the 3.4 us of its MFMAs -- the
-    // reason for the LDS-DMA form.  Two register sets spilled 45 VGPRs at the 256-register budget of two waves per SIMD.)
+    // Every slot of the staging registers that carried chunk it + 1 to LDS is refilled with chunk it + 2 right behind its store
+    // (see `iteration`): a load has a whole iteration to arrive.  (One chunk in flight = 64 KB of staging registers per CU for the
+    // 1x1 kernel.  Two register sets spilled 45 VGPRs at the 256-register budget of two waves per SIMD.)
     SkSlots<NXS> slots;
     SkXOff<NXS> xoff;
     int xm[VEC ? 1 : NXS];
