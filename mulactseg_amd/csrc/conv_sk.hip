@@ -308,7 +308,7 @@ __device__ __forceinline__ void sk_fetch(const SkPlan& f, const SkXOff<SkX<G>::N
 #pragma unroll
         for (int j = 0; j < NXS; ++j) {
             xr[j] = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(f.xres, (int)xo.voff[j], 0, 0));
-            if constexpr (!VEC) xm[j] = xo.nv[j];
+            if constexpr (!VEC && TAPS != 1) xm[j] = xo.nv[j];          // (1x1: see sk_stage)
         }
     } else {
         // (no use of the loaded values here: masks and the rotation are applied by sk_stage)
@@ -330,7 +330,11 @@ __device__ __forceinline__ void sk_fetch(const SkPlan& f, const SkXOff<SkX<G>::N
 // read = four MFMAs.
 template <typename G, int TAPS, int WM, bool VEC, int NWS>
 __device__ __forceinline__ void sk_stage(const int (&xm)[VEC ? 1 : SkX<G>::NXS], float* __restrict__ sW, float* __restrict__ sX, int tid,
-                                         const v4f (&wr)[NWS], const v4f (&xr)[SkX<G>::NXS]) {
+                                         const v4f (&wr)[NWS], const v4f (&xr)[SkX<G>::NXS], bool slow) {
+    // `slow`: the chunk in the registers was fetched on the slow path (a group near the end of the tensor / of a K tail).  A 1x1
+    // product needs no zeros past the end of a row -- what lands in the out-of-plane columns of its patch only reaches outputs that
+    // the epilogue does not store -- so on unaligned planes its groups are fixed up (rotated, tail zeroed) only for such chunks:
+    // the fix is ~17 VALU instructions per group (9.0 vs 8.1 ms per step for the 1x1 layers of the 769 crop with it).
     constexpr int BM = 32 * WM, CK = G::CK, NXS = SkX<G>::NXS;
     constexpr int KC = TAPS * CK;
     constexpr int step = kSkThreads * 4;
@@ -343,17 +347,19 @@ __device__ __forceinline__ void sk_stage(const int (&xm)[VEC ? 1 : SkX<G>::NXS],
     for (int j = 0; j < NXS; ++j) {
         v4f v = xr[j];
         if constexpr (!VEC) {
-            const int nv = xm[j] & 7;
-            const int early = xm[j] >> 3;
-            if (early) {                        // loaded `early` elements early: element i of the group is u[i + early]
-                const v4f u = v;
-                v[0] = early == 1 ? u[1] : (early == 2 ? u[2] : u[3]);
-                v[1] = early == 1 ? u[2] : u[3];
-                v[2] = u[3];
+            if (TAPS != 1 || slow) {
+                const int nv = xm[j] & 7;
+                const int early = xm[j] >> 3;
+                if (early) {                    // loaded `early` elements early: element i of the group is u[i + early]
+                    const v4f u = v;
+                    v[0] = early == 1 ? u[1] : (early == 2 ? u[2] : u[3]);
+                    v[1] = early == 1 ? u[2] : u[3];
+                    v[2] = u[3];
+                }
+                v[1] = nv > 1 ? v[1] : 0.0f;
+                v[2] = nv > 2 ? v[2] : 0.0f;
+                v[3] = nv > 3 ? v[3] : 0.0f;
             }
-            v[1] = nv > 1 ? v[1] : 0.0f;
-            v[2] = nv > 2 ? v[2] : 0.0f;
-            v[3] = nv > 3 ? v[3] : 0.0f;
         }
         if (NXS * step == CK * G::CS || tid * 4 + j * step < CK * G::CS) *reinterpret_cast<v4f*>(xdst + j * step) = v;
     }
@@ -363,7 +369,7 @@ __device__ __forceinline__ void sk_stage(const int (&xm)[VEC ? 1 : SkX<G>::NXS],
 // in the shadow of the wave's own MFMAs (see k_conv_sk).
 template <typename G, int TAPS, int WM, bool VEC, int NWS, int S>
 __device__ __forceinline__ void sk_stage_slot(const int (&xm)[VEC ? 1 : SkX<G>::NXS], float* __restrict__ sW, float* __restrict__ sX, int tid,
-                                              const v4f (&wr)[NWS], const v4f (&xr)[SkX<G>::NXS]) {
+                                              const v4f (&wr)[NWS], const v4f (&xr)[SkX<G>::NXS], bool slow) {
     constexpr int BM = 32 * WM, CK = G::CK, NXS = SkX<G>::NXS;
     constexpr int KC = TAPS * CK;
     constexpr int step = kSkThreads * 4;
@@ -373,17 +379,19 @@ __device__ __forceinline__ void sk_stage_slot(const int (&xm)[VEC ? 1 : SkX<G>::
         constexpr int j = S - NWS;
         v4f v = xr[j];
         if constexpr (!VEC) {
-            const int nv = xm[j] & 7;
-            const int early = xm[j] >> 3;
-            if (early) {
-                const v4f u = v;
-                v[0] = early == 1 ? u[1] : (early == 2 ? u[2] : u[3]);
-                v[1] = early == 1 ? u[2] : u[3];
-                v[2] = u[3];
+            if (TAPS != 1 || slow) {            // (see sk_stage)
+                const int nv = xm[j] & 7;
+                const int early = xm[j] >> 3;
+                if (early) {
+                    const v4f u = v;
+                    v[0] = early == 1 ? u[1] : (early == 2 ? u[2] : u[3]);
+                    v[1] = early == 1 ? u[2] : u[3];
+                    v[2] = u[3];
+                }
+                v[1] = nv > 1 ? v[1] : 0.0f;
+                v[2] = nv > 2 ? v[2] : 0.0f;
+                v[3] = nv > 3 ? v[3] : 0.0f;
             }
-            v[1] = nv > 1 ? v[1] : 0.0f;
-            v[2] = nv > 2 ? v[2] : 0.0f;
-            v[3] = nv > 3 ? v[3] : 0.0f;
         }
         if (NXS * step == CK * G::CS || tid * 4 + j * step < CK * G::CS) *reinterpret_cast<v4f*>(sX + tid * 4 + j * step) = v;
     }
@@ -398,7 +406,7 @@ __device__ __forceinline__ void sk_fetch_slot(const SkPlan& f, const SkXOff<SkX<
         constexpr int j = S - NWS;
         if (VEC || !f.slow) {
             xr[j] = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(f.xres, (int)xo.voff[j], 0, 0));
-            if constexpr (!VEC) xm[j] = xo.nv[j];
+            if constexpr (!VEC && TAPS != 1) xm[j] = xo.nv[j];
         } else {
             const unsigned v = xo.voff[j];
             const bool ok = v < f.size;
@@ -576,18 +584,20 @@ __global__ __launch_bounds__(kSkThreads) void k_conv_sk(const SkP p) {
     SkSlots<NXS> slots;
     SkXOff<NXS> xoff;
     int xm[VEC ? 1 : NXS];
+    bool slow_regs = false;                 // the chunk in the staging registers was fetched on the slow path (see sk_stage)
     if constexpr (!DMA) {
         sk_slots<G>(tid, slots);
         // (requesting chunks it0 and it0 + 1 back to back -- one memory round trip in front of the first MFMA instead of two -- was
         // measured: no difference, 32.6 vs 32.5 ms per step)
         SkPlan f0 = sk_plan_fetch<G, TAPS, WM, VEC>(p, pre, slots, xoff);
         sk_fetch<G, TAPS, WM, VEC, NWS>(f0, xoff, tid, wr, xr, xm);
-        sk_stage<G, TAPS, WM, VEC, NWS>(xm, sk_smem, sk_smem + KC * BM, tid, wr, xr);
+        sk_stage<G, TAPS, WM, VEC, NWS>(xm, sk_smem, sk_smem + KC * BM, tid, wr, xr, f0.slow);
         if (it0 + 1 < it1) {
             sk_advance(p, g, sk0, pre);
             f0 = sk_plan_fetch<G, TAPS, WM, VEC>(p, pre, slots, xoff);
             sk_fetch<G, TAPS, WM, VEC, NWS>(f0, xoff, tid, wr, xr, xm);
         }
+        slow_regs = f0.slow;
         __syncthreads();
     } else {
 #pragma unroll
@@ -629,10 +639,11 @@ __global__ __launch_bounds__(kSkThreads) void k_conv_sk(const SkP p) {
                 constexpr int s0 = q * NS / NQ, s1 = (q + 1) * NS / NQ;
                 sk_static_for<s0, s1>([&](auto sc) {
                     constexpr int S = decltype(sc)::value;
-                    sk_stage_slot<G, TAPS, WM, VEC, NWS, S>(xm, nW, nX, tid, wr, xr);
+                    sk_stage_slot<G, TAPS, WM, VEC, NWS, S>(xm, nW, nX, tid, wr, xr, slow_regs);
                     sk_fetch_slot<G, TAPS, WM, VEC, NWS, S>(f2, xoff, tid, wr, xr, xm);
                 });
             });
+            slow_regs = f2.slow;
             __syncthreads();
             buf ^= 1;
 #else
@@ -666,11 +677,14 @@ __global__ __launch_bounds__(kSkThreads) void k_conv_sk(const SkP p) {
 #endif
                 if (it + 1 < it1) {
                     float* nW = sk_smem + (buf ^ 1) * bufsz;
-                    sk_stage<G, TAPS, WM, VEC, NWS>(xm, nW, nW + KC * BM, tid, wr, xr);
+                    sk_stage<G, TAPS, WM, VEC, NWS>(xm, nW, nW + KC * BM, tid, wr, xr, slow_regs);
 #ifdef SK_PHASE_STAMPS
                     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #endif
-                    if (it + 2 < it1) sk_fetch<G, TAPS, WM, VEC, NWS>(f2, xoff, tid, wr, xr, xm);
+                    if (it + 2 < it1) {
+                        sk_fetch<G, TAPS, WM, VEC, NWS>(f2, xoff, tid, wr, xr, xm);
+                        slow_regs = f2.slow;
+                    }
                 }
                 __builtin_amdgcn_s_setprio(0);
 #ifdef SK_PHASE_STAMPS
