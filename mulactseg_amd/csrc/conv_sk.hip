@@ -115,6 +115,7 @@ __device__ __forceinline__ void sk_store_sc1(float* p, v4f v) {
 // order -- and the full recomputation was ~100 scalar instructions (64-bit multiplies, SGPR spills) per wave and chunk.
 struct SkCursor {
     int v, chunk, mt, n, tyi, txi;
+    int seg;                    // iterations up to the end of the contiguous piece (sk_decode)
     bool moved;                 // the pixel tile changed since the patch offsets were computed (sk_xoffsets clears it)
     const float* wptr;          // the weight image of (mt, chunk)
     const float* xptr;          // x of (picture n, first channel of the chunk)
@@ -122,23 +123,43 @@ struct SkCursor {
     long long rem;              // elements from xptr to the end of the tensor
 };
 
-__device__ __forceinline__ void sk_decode(const SkP& p, int g, int sk0, int v, int& tile, int& chunk) {
+// Order of a workgroup's iterations (sk0, sk_len: its run of the stream-K iteration space):
+//   1. the LEADING segment of its run, if the run starts inside a tile: it is a contributor there -- done first, its slot is
+//      published early;
+//   2. its whole tiles;
+//   3. the rest of its run, whose last piece may be the first chunks of a tile it FINISHES: by then the contributors of that tile
+//      (their step 1) have long published, so the finisher adds their slots without waiting.  (With the run as one block behind
+//      the whole tiles, both sides of a split tile finished at the same moment and the hand-off -- slot write, flag, slot read,
+//      epilogue -- was a serial tail of 10-19 us per launch: tools/sk_stamps.py.)
+// seg = iterations from v to the end of the contiguous piece (a tile's end or a jump of the order).
+__device__ __forceinline__ void sk_decode(const SkP& p, int g, int sk0, int sk_len, int v, int& tile, int& chunk, int& seg) {
     const int vdp = p.rdp * p.nch;
-    if (v < vdp) {
-        const int r = v / p.nch;
-        chunk = v - r * p.nch;
+    const int c0 = sk0 % p.nch;
+    const int lead = (c0 != 0 && sk_len > 0) ? (sk_len < p.nch - c0 ? sk_len : p.nch - c0) : 0;
+    int w;
+    if (v < lead) {
+        w = sk0 + v;
+        seg = lead - v;
+    } else if (v < lead + vdp) {
+        const int u = v - lead;
+        const int r = u / p.nch;
+        chunk = u - r * p.nch;
         tile = r * p.P + g;
+        seg = p.nch - chunk;
+        return;
     } else {
-        const int w = v - vdp + sk0;
-        const int t = w / p.nch;
-        chunk = w - t * p.nch;
-        tile = p.rdp * p.P + t;
+        w = sk0 + (v - vdp);
+        seg = vdp + sk_len - v;
     }
+    const int t = w / p.nch;
+    chunk = w - t * p.nch;
+    tile = p.rdp * p.P + t;
+    seg = seg < p.nch - chunk ? seg : p.nch - chunk;
 }
 
-__device__ __forceinline__ void sk_locate(const SkP& p, int g, int sk0, SkCursor& c) {
+__device__ __forceinline__ void sk_locate(const SkP& p, int g, int sk0, int sk_len, SkCursor& c) {
     int tile;
-    sk_decode(p, g, sk0, c.v, tile, c.chunk);
+    sk_decode(p, g, sk0, sk_len, c.v, tile, c.chunk, c.seg);
     c.mt = tile % p.mtiles;
     const int pt = tile / p.mtiles;
     const int tpi = p.tiles_x * p.tiles_y;
@@ -155,18 +176,19 @@ __device__ __forceinline__ void sk_locate(const SkP& p, int g, int sk0, SkCursor
     c.rem = ((long long)(p.N - c.n) * p.K - k0) * HW;
 }
 
-__device__ __forceinline__ SkCursor sk_cursor(const SkP& p, int g, int sk0, int v) {
+__device__ __forceinline__ SkCursor sk_cursor(const SkP& p, int g, int sk0, int sk_len, int v) {
     SkCursor c;
     c.v = v;
-    sk_locate(p, g, sk0, c);
+    sk_locate(p, g, sk0, sk_len, c);
     return c;
 }
 
-__device__ __forceinline__ void sk_advance(const SkP& p, int g, int sk0, SkCursor& c) {
+__device__ __forceinline__ void sk_advance(const SkP& p, int g, int sk0, int sk_len, SkCursor& c) {
     ++c.v;
-    if (++c.chunk == p.nch) {
-        sk_locate(p, g, sk0, c);                            // next tile of the workgroup's list (once per tile)
+    if (--c.seg == 0) {
+        sk_locate(p, g, sk0, sk_len, c);                    // next piece of the workgroup's list (once per tile)
     } else {
+        ++c.chunk;
         c.wptr += p.img;
         c.xptr += p.xstep;
         c.kleft -= p.ck;
@@ -518,14 +540,14 @@ __global__ __launch_bounds__(kSkThreads) void k_conv_sk(const SkP p) {
     constexpr int PT = PWW + PXW;
     constexpr int DEPTH = DMA ? NB - 1 : 1;                     // chunks in flight
     static_assert(!DMA || (DEPTH - 1) * PT <= 63, "vmcnt");
-    SkCursor pre = sk_cursor(p, g, sk0, it0);
+    SkCursor pre = sk_cursor(p, g, sk0, sk1 - sk0, it0);
     int pre_it = it0;
     auto dma_chunk = [&](int target, int nb) {
         if constexpr (DMA) {
             const bool real = target < it1;
             if (real)
                 while (pre_it < target) {
-                    sk_advance(p, g, sk0, pre);
+                    sk_advance(p, g, sk0, sk1 - sk0, pre);
                     ++pre_it;
                 }
             float* bW = sk_smem + nb * bufsz;
@@ -593,7 +615,7 @@ __global__ __launch_bounds__(kSkThreads) void k_conv_sk(const SkP p) {
         sk_fetch<G, TAPS, WM, VEC, NWS>(f0, xoff, tid, wr, xr, xm);
         sk_stage<G, TAPS, WM, VEC, NWS>(xm, sk_smem, sk_smem + KC * BM, tid, wr, xr, f0.slow);
         if (it0 + 1 < it1) {
-            sk_advance(p, g, sk0, pre);
+            sk_advance(p, g, sk0, sk1 - sk0, pre);
             f0 = sk_plan_fetch<G, TAPS, WM, VEC>(p, pre, slots, xoff);
             sk_fetch<G, TAPS, WM, VEC, NWS>(f0, xoff, tid, wr, xr, xm);
         }
@@ -629,7 +651,7 @@ __global__ __launch_bounds__(kSkThreads) void k_conv_sk(const SkP p) {
             // past the end is an empty resource), so hipcc counts the outstanding loads across the back edge: the store of slot s
             // waits for vmcnt(NS - 1), i.e. for a load that is a whole iteration old.
             const bool v2 = it + 2 < it1;
-            if (v2) sk_advance(p, g, sk0, pre);
+            if (v2) sk_advance(p, g, sk0, sk1 - sk0, pre);
             const SkPlan f2 = sk_plan_fetch<G, TAPS, WM, VEC>(p, pre, slots, xoff, v2);
             float* nW = sk_smem + (buf ^ 1) * bufsz;
             float* nX = nW + KC * BM;
@@ -659,7 +681,7 @@ __global__ __launch_bounds__(kSkThreads) void k_conv_sk(const SkP p) {
             // the part every wave runs: where chunk it + 2 lives (scalar registers, see SkPlan)
             SkPlan f2;
             if (it + 2 < it1) {
-                sk_advance(p, g, sk0, pre);
+                sk_advance(p, g, sk0, sk1 - sk0, pre);
                 f2 = sk_plan_fetch<G, TAPS, WM, VEC>(p, pre, slots, xoff);
             }
             auto body = [&](auto QS) {
@@ -718,10 +740,9 @@ __global__ __launch_bounds__(kSkThreads) void k_conv_sk(const SkP p) {
 
     int it = it0;
     while (it < it1) {
-        int tile, c0;
-        sk_decode(p, g, sk0, it, tile, c0);
-        const int left = it1 - it;
-        const int c1 = (left < p.nch - c0) ? c0 + left : p.nch;        // (whole tiles: c0 = 0, c1 = nch)
+        int tile, c0, seg;
+        sk_decode(p, g, sk0, sk1 - sk0, it, tile, c0, seg);
+        const int c1 = c0 + seg;                                        // (whole tiles: c0 = 0, c1 = nch)
         const int mt = tile % p.mtiles, pt = tile / p.mtiles;
         const int m0 = mt * BM;
         if constexpr (G::LW != 0) {
