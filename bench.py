@@ -251,6 +251,36 @@ def pool_round_bench(args, dev, rank, world, with_model):
 # ------------------------------------------------------------------------------------------------------------------
 # model legs
 # ------------------------------------------------------------------------------------------------------------------
+F32_MFMA_PEAK_TF = 157.3        # dense f32 MFMA peak of MI355X (MI355X_MICROARCH.md), TFLOP/s
+
+
+def conv_flop(net, N, H, W, products):
+    """FLOPs of the dense (groups == 1) convolutions of `net` on a [N,3,H,W] batch, counted with forward hooks on one CPU-free
+    shape walk: 2 * taps * Cin * Cout * output pixels per product; `products` = 1 (inference) or 3 (training: the first layer has
+    no input gradient)."""
+    total = [0.0]
+    first = [True]
+    hooks = []
+
+    def hook(m, inp, out):
+        if m.groups != 1:
+            return
+        f = 2.0 * m.kernel_size[0] * m.kernel_size[1] * m.in_channels * m.out_channels * out.shape[0] * out.shape[2] * out.shape[3]
+        total[0] += f * (products - 1 if (first[0] and products == 3) else products)
+        first[0] = False
+    # a meta-device walk costs nothing and takes no kernel path of the package (plain torch ops on shapes only)
+    import copy
+    meta = copy.deepcopy(net).to('meta').eval()
+    hooks = [m.register_forward_hook(hook) for m in meta.modules() if isinstance(m, torch.nn.Conv2d)]
+    with torch.no_grad():
+        meta(torch.empty((N, 3, H, W), device='meta'))
+    return total[0]
+
+
+def train_step_flop(net, N, crop):
+    return conv_flop(net, N, crop, crop, 3)
+
+
 def train_iter_bench(args, dev, world, crop):
     """Secondary metric "train-iter images/sec" (BASELINE.json configs[1]): stage-1 step on a
     [4,20,crop,crop] batch.  (a) loss-only: fused partial-label losses fwd+bwd on resident logits;
@@ -330,7 +360,16 @@ def train_iter_bench(args, dev, world, crop):
         full_step()
     fence()
     it_ms = max_over_ranks(time.perf_counter() - t0, dev) / args.train_steps * 1e3
+    sk_err = ops.conv_sk_error(dev)         # (synchronises; the trainers read the same word with the loss)
+    if sk_err != 0:
+        raise ops.StreamKGaveUp("bench train leg: a stream-K convolution gave up (error word %d): the timed steps are invalid" % sk_err)
+    flop = train_step_flop(net.module if hasattr(net, "module") else net, N, crop)
     return {"metric": "train-iter images/sec", "value": N * world / (it_ms * 1e-3), "unit": "images/s", "ms_per_iter": it_ms,
+            "stream_k_error_word": sk_err,
+            "mfma": {"flop_per_step": flop, "achieved_TFLOPs": flop / (it_ms * 1e-3) / 1e12, "peak_TFLOPs": F32_MFMA_PEAK_TF,
+                     "mfma_frac": flop / (it_ms * 1e-3) / 1e12 / F32_MFMA_PEAK_TF,
+                     "note": "2 * taps * Cin * Cout * output pixels of every dense convolution x 3 products (forward, input gradient, "
+                             "weight gradient; no input gradient for the first layer), over the WHOLE step's wall time"},
             "config": {"workload": "stage-1 step: DeepLabv3+WN/ResNet50-deepstem fwd+bwd with the dense convolutions on this package's f32-MFMA "
                                    "kernels (k_conv_sk: persistent stream-K forward / input gradient; k_wgrad: split-K weight gradient; "
                                    "layer_paths_per_step says which product of which layer took which kernel) + HIP memory-bound layers + "
@@ -401,8 +440,12 @@ def acquisition_with_model_bench(args, dev, world):
     scan_forms = {"scan_from_quarter_logits_ms": low_ms, "upsample_then_scan_ms": mat_ms,
                   "note": "k_single_pass<LOWRES> (interpolation in registers; bound by VALU work and LDS-read latency, "
                           "profiles/r02/k_scan_forms_pmc.md) vs k_upsample_fwd + k_single_pass_ring (671 MB written and re-read)"}
+    flop = conv_flop(net, B, H, W, 1)
     return {"metric": "superpixels scored/sec incl. model forward", "scan_forms": scan_forms, "value": B * S * world / (ms * 1e-3), "unit": "superpixels/s",
             "ms_per_batch": ms, "forwards_per_image": 1, "layer_paths_per_step": paths,
+            "mfma": {"flop_per_batch": flop, "achieved_TFLOPs": flop / (ms * 1e-3) / 1e12, "peak_TFLOPs": F32_MFMA_PEAK_TF,
+                     "mfma_frac": flop / (ms * 1e-3) / 1e12 / F32_MFMA_PEAK_TF,
+                     "note": "2 * taps * Cin * Cout * output pixels of every dense convolution of one forward, over the whole batch's wall time"},
             "config": {"workload": "eval forward (f32-MFMA convolutions with BatchNorm / residual / ReLU epilogues + HIP memory-bound layers, no "
                                    "MIOpen kernel: see layer_paths_per_step) of [%d,3,%d,%d] + single-pass scan of the quarter-resolution "
                                    "logits; the reference structure runs the forward twice per pool image" % (B, H, W)}}

@@ -425,8 +425,26 @@ int mas_conv_fwd(const float* x, const float* wt, int N, int Cin, int H, int W, 
  * One workgroup per CU; the (tile, K-chunk) iterations of the layer are dealt to the workgroups in equal runs, tiles that
  * straddle two workgroups are combined through `workspace` (mas_conv_sk_workspace_bytes(), zero-filled ONCE by the caller, then
  * owned by launches of ONE stream) in a fixed order: run-to-run identical results.  `epoch` must be non-zero and differ from the
- * epoch of the previous launch on the same workspace.  mas_conv_sk_error copies the workspace's error word to the host
- * (non-zero: a bounded wait for another workgroup gave up; results of that launch are invalid). */
+ * epoch of the previous launch on the same workspace.
+ * Co-residency contract: a workgroup that CONTRIBUTES to a split tile publishes its part before it does anything else and never
+ * waits; a workgroup that FINISHES a split tile waits, at the end of its work, for contributors with a higher index only.  So the
+ * launch completes whenever its workgroups are eventually scheduled, in any order and beside any other kernel (RCCL's all-reduce
+ * under DistributedDataParallel, a second stream); nothing requires all workgroups to be resident at once.  The wait is bounded
+ * all the same (mas_sk_opts.spin_limit polls per contributor, default 2^22 = seconds): a finisher that gives up sets the
+ * workspace's error word (sticky; mas_conv_sk_error copies it to the host, trainers read it with the loss) and writes NaN into its
+ * tile -- a launch that gave up never hands out plausible numbers.  MAS_SK_NOSPLIT deals whole tiles only (no hand-off, hence no
+ * wait at all; the tail of the layer then runs on fewer CUs): the plan to re-run a launch on after a give-up.
+ * All options are per call (mas_sk_opts, NULL = defaults); the library keeps no mode state. */
+#define MAS_SK_DMA 1u       /* stage the K chunks with an LDS-DMA ring (global_load_lds into 2..4 LDS buffers, up to three chunks in
+                             * flight, no staging registers) instead of global -> registers -> LDS: measured 3-5 % slower on the
+                             * training shapes, kept for A/B runs */
+#define MAS_SK_NOSPLIT 2u   /* whole tiles only: no tile is split between workgroups */
+typedef struct mas_sk_opts {
+    unsigned flags;         /* MAS_SK_* */
+    unsigned spin_limit;    /* polls a finisher waits per contributor before it gives up; 0 = default */
+    void* stamps;           /* tools: device buffer [512][4] uint64 of per-workgroup wall-clock stamps (100 MHz; start, pipeline
+                             * primed, last tile done, end), indexed by the logical workgroup; NULL = off */
+} mas_sk_opts;
 size_t mas_conv_sk_workspace_bytes(void);
 size_t mas_conv_sk_packed_elems(int Cin, int Cout, int ksize, int stride, int dgrad);
 int mas_conv_sk_pack(const float* w, int Cin, int Cout, int ksize, int stride, int dgrad, float* out, void* stream);
@@ -440,15 +458,15 @@ unsigned mas_conv_sk_pack_job(void* job_host, const float* w, int Cin, int Cout,
 int mas_conv_sk_pack_multi(const void* jobs_dev, int njobs, unsigned nblocks, void* stream);
 int mas_conv_sk(const float* x, const float* wp, int N, int Cin, int H, int W, int Cout, int ksize, int stride, int dil, int dgrad,
                 const float* scale, const float* shift, const float* residual, int relu, float* y, void* workspace,
-                size_t workspace_bytes, unsigned epoch, void* stream);
+                size_t workspace_bytes, unsigned epoch, const mas_sk_opts* opts, void* stream);
 int mas_conv_sk_error(const void* workspace, unsigned* out_host);
 /* mas_conv_sk in the forward role without epilogue that also forms the BatchNorm partial sums of its output in the epilogue of
  * every tile (the relu(bn(conv(x))) triples of backbone/resnet.py:143-160 in training mode: removes the reduction pass over y):
  * stats [Cout][mas_conv_sk_stats_slots(...)] pairs of doubles (sum y, sum y^2) over disjoint pixel sets, every entry written;
  * fixed summation order (run-to-run identical).  Consumer: mas_bn_act_train_fwd_stats. */
-int mas_conv_sk_stats_slots(int N, int Cin, int H, int W, int Cout, int ksize, int stride, int dil);
+int mas_conv_sk_stats_slots(int N, int Cin, int H, int W, int Cout, int ksize, int stride, int dil, unsigned flags /* MAS_SK_DMA changes the tiling */);
 int mas_conv_sk_stats(const float* x, const float* wp, int N, int Cin, int H, int W, int Cout, int ksize, int stride, int dil, float* y,
-                      double* stats, void* workspace, size_t workspace_bytes, unsigned epoch, void* stream);
+                      double* stats, void* workspace, size_t workspace_bytes, unsigned epoch, const mas_sk_opts* opts, void* stream);
 /* Input gradient of a 3x3, stride-2, padding-1 convolution (torch.autograd of nn.Conv2d(k=3, stride=2, padding=1), the conv2 of
  * layer2.0 / layer3.0: backbone/resnet.py:129-141), one parity class per launch: sub = 2 py + px writes dx[n, c, 2 i + py, 2 j + px]
  * as a stride-1 product over dy [N,Cout,(H-1)/2+1,(W-1)/2+1] with (1 + py) x (1 + px) taps; wp = mas_conv_sk_pack(..., ksize 3,
@@ -456,14 +474,10 @@ int mas_conv_sk_stats(const float* x, const float* wp, int N, int Cin, int H, in
  * as mas_conv_sk (a fresh epoch per launch). */
 int mas_conv_sk_dgrad_s2(const float* dy, const float* wp, int N, int Cin, int H, int W, int Cout, int sub, const float* scale,
                          const float* shift, const float* residual, int relu, float* dx, void* workspace, size_t workspace_bytes,
-                         unsigned epoch, void* stream);
-/* staging of the K chunks, process-wide: 0 (default) = global -> registers -> LDS, two LDS buffers; 1 = LDS-DMA ring
- * (global_load_lds into 2..4 LDS buffers, up to three chunks in flight, no staging registers; measured 3-5 % slower on the
- * training shapes); returns the previous setting (any other argument only queries) */
-int mas_conv_sk_set_mode(int dma);
-/* tools only: the following mas_conv_sk launches write per-workgroup wall-clock stamps (100 MHz; start, pipeline primed, last
- * tile done, end) into stamps_dev [512][4] uint64, indexed by the logical workgroup; NULL switches it off */
-int mas_conv_sk_debug_stamps(void* stamps_dev);
+                         unsigned epoch, const mas_sk_opts* opts, void* stream);
+/* test-only: `blocks` workgroups of 256 threads with `lds_bytes` of LDS each that do nothing but wait `ticks` of the 100 MHz wall
+ * clock (bounded: every wave leaves after that) -- a CU-hogging neighbour for the co-residency tests of the stream-K hand-off. */
+int mas_test_occupy(int blocks, int lds_bytes, unsigned long long ticks, void* stream);
 
 /* Weight gradient of a dense convolution on the f32 matrix cores (csrc/conv_wgrad.hip), NCHW operands as autograd holds them:
  *   dw[m,c,r,s] = sum_{n,oy,ox} dy[n,m,oy,ox] * x[n,c, oy*stride + r*dil - pad, ox*stride + s*dil - pad],  pad = dil (ksize 3) / 0 (ksize 1)

@@ -16,8 +16,16 @@ LOSS_CE, LOSS_GROUP, LOSS_GROUP_ONLY_MULTI, LOSS_DECOMP, LOSS_TCE = 1, 2, 4, 8, 
 ACC_WORDS = 8
 GRAD_FRAC = 44
 
+SK_DMA, SK_NOSPLIT = 1, 2
+
 _c = ctypes
 _vp, _i, _f, _i64, _d = _c.c_void_p, _c.c_int, _c.c_float, _c.c_int64, _c.c_double
+
+
+class SkOpts(ctypes.Structure):
+    """mas_sk_opts of include/mulactseg_hip.h: the per-call options of the stream-K convolution."""
+    _fields_ = [("flags", _c.c_uint), ("spin_limit", _c.c_uint), ("stamps", _c.c_void_p)]
+
 
 # name -> (restype, argtypes); mirrors include/mulactseg_hip.h one to one
 SIGNATURES = {
@@ -71,13 +79,12 @@ SIGNATURES = {
     "mas_conv_sk_pack_job_bytes": (_c.c_size_t, []),
     "mas_conv_sk_pack_job": (_c.c_uint, [_vp, _vp, _i, _i, _i, _i, _i, _vp, _c.c_uint]),
     "mas_conv_sk_pack_multi": (_i, [_vp, _i, _c.c_uint, _vp]),
-    "mas_conv_sk": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _i, _vp, _vp, _c.c_size_t, _c.c_uint, _vp]),
+    "mas_conv_sk": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _i, _vp, _vp, _c.c_size_t, _c.c_uint, _vp, _vp]),
     "mas_conv_sk_error": (_i, [_vp, _vp]),
-    "mas_conv_sk_stats_slots": (_i, [_i, _i, _i, _i, _i, _i, _i, _i]),
-    "mas_conv_sk_stats": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _c.c_size_t, _c.c_uint, _vp]),
-    "mas_conv_sk_dgrad_s2": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _i, _vp, _vp, _c.c_size_t, _c.c_uint, _vp]),
-    "mas_conv_sk_set_mode": (_i, [_i]),
-    "mas_conv_sk_debug_stamps": (_i, [_vp]),
+    "mas_conv_sk_stats_slots": (_i, [_i, _i, _i, _i, _i, _i, _i, _i, _c.c_uint]),
+    "mas_conv_sk_stats": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _c.c_size_t, _c.c_uint, _vp, _vp]),
+    "mas_conv_sk_dgrad_s2": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _i, _vp, _vp, _c.c_size_t, _c.c_uint, _vp, _vp]),
+    "mas_test_occupy": (_i, [_i, _i, _c.c_ulonglong, _vp]),
     "mas_conv_wgrad_workspace_bytes": (_c.c_size_t, [_i, _i, _i, _i, _i, _i, _i, _i]),
     "mas_conv_wgrad_plan": (_i, [_i, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "mas_conv_wgrad": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _c.c_size_t, _vp]),

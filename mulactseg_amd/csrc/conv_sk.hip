@@ -34,7 +34,7 @@ typedef __attribute__((address_space(1))) unsigned gu32;
 constexpr int kSkThreads = 512;
 constexpr int kSkBN = 128;                      // pixels per tile
 constexpr int kSkSlotFloats = 128 * kSkBN;      // accumulator image of a 128 x 128 tile
-constexpr unsigned kSkSpinLimit = 1u << 22;
+constexpr unsigned kSkSpinLimit = 1u << 22;     // polls (each >= one s_sleep + one agent-scope load, ~1.5 us) before a finisher gives up: seconds
 
 struct SkP {
     const float* x;             // [N, K, H, W] input of the product (forward: activations; input gradient: dY)
@@ -58,6 +58,8 @@ struct SkP {
     long long xstep;            // floats from a chunk's first channel to the next chunk's (CK * H * W)
     int P;                      // workgroups (one per CU)
     int rdp, sk_iters;          // whole tiles per workgroup (rounds of P tiles), iterations of the remaining tiles (stream-K part)
+    int nosplit;                // MAS_SK_NOSPLIT: the remaining tiles go WHOLE to the first workgroups (no hand-off at all)
+    unsigned spin_limit;        // polls a finisher waits for one contributor before it gives up
 };
 
 // Compile-time geometry of a kernel family: TH x TW output pixels per tile, the LDS input patch PH rows x PWL columns per
@@ -458,7 +460,7 @@ __global__ __launch_bounds__(kSkThreads) void k_conv_sk(const SkP p) {
     constexpr int NWS = (BM * KC / 4 + kSkThreads - 1) / kSkThreads;
     static_assert(KC % 8 == 0 && TN >= 1, "tile");
     extern __shared__ __attribute__((aligned(16))) float sk_smem[];
-    // [NBUF][sW: KC * BM | sX: CK * CS (DMA: rounded up to 1 KB pieces)] then sE [2 tile parities][2][BM], then 1 KB DMA dump
+    // [NBUF][sW: KC * BM | sX: CK * CS (DMA: rounded up to 1 KB pieces)] then sE [2 tile parities][2][BM], then 1 KB DMA dump, then the give-up word
     constexpr int NBUF = DMA ? NB : 2;
     constexpr int XF = DMA ? ((CK * CS + 255) / 256) * 256 : CK * CS;
     constexpr int bufsz = KC * BM + XF;
@@ -471,7 +473,10 @@ __global__ __launch_bounds__(kSkThreads) void k_conv_sk(const SkP p) {
     // logical workgroup index: the workgroups of one XCD (blocks b, b + 8, ...) own one contiguous run of iterations
     const int P = p.P;
     const int g = (P % 8 == 0) ? (int)(blockIdx.x & 7) * (P >> 3) + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
-    const int sk0 = (int)((long long)p.sk_iters * g / P), sk1 = (int)((long long)p.sk_iters * (g + 1) / P);
+    // stream-K run of this workgroup; MAS_SK_NOSPLIT: the remaining tiles whole, one each to the first workgroups
+    const int sk_rem = p.sk_iters / p.nch;
+    const int sk0 = p.nosplit ? (g < sk_rem ? g : sk_rem) * p.nch : (int)((long long)p.sk_iters * g / P);
+    const int sk1 = p.nosplit ? (g + 1 < sk_rem ? g + 1 : sk_rem) * p.nch : (int)((long long)p.sk_iters * (g + 1) / P);
     const int vdp = p.rdp * p.nch;
     const int it0 = 0, it1 = vdp + (sk1 - sk0);             // virtual iterations of this workgroup
     if (it0 >= it1) return;
@@ -788,6 +793,8 @@ __global__ __launch_bounds__(kSkThreads) void k_conv_sk(const SkP p) {
         if (!last) {
             // finisher: add the slots of the workgroups that own the rest of this tile, in chunk order
             const int tile_end = (tile - p.rdp * P + 1) * p.nch;        // in the iteration space of the stream-K tiles
+            int* s_gave_up = reinterpret_cast<int*>(sDump + 256);       // (one word behind the DMA dump area)
+            if (tid == 0) *s_gave_up = 0;
             for (int gg = g + 1; gg < P; ++gg) {
                 const int b0 = (int)((long long)p.sk_iters * gg / P), b1 = (int)((long long)p.sk_iters * (gg + 1) / P);
                 if (b0 >= tile_end) break;
@@ -796,8 +803,14 @@ __global__ __launch_bounds__(kSkThreads) void k_conv_sk(const SkP p) {
                     unsigned spins = 0;
                     while (__hip_atomic_load((gu32*)(p.flags + gg), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != p.epoch) {
                         __builtin_amdgcn_s_sleep(2);
-                        if (++spins > kSkSpinLimit) {
-                            if (lane == 0) atomicOr(p.flags + 512, 1u);   // give up: the error word says so, nothing hangs
+                        if (++spins > p.spin_limit) {
+                            // give up: nothing hangs.  The error word says so (the trainer reads it with the loss, mas_conv_sk_error
+                            // for everybody else) and the tile is poisoned with NaN below -- a launch that gave up never hands out
+                            // plausible numbers.
+                            if (lane == 0) {
+                                atomicOr(p.flags + 512, 1u);
+                                *s_gave_up = 1;
+                            }
                             break;
                         }
                     }
@@ -814,6 +827,13 @@ __global__ __launch_bounds__(kSkThreads) void k_conv_sk(const SkP p) {
 #pragma unroll
                         for (int i = 0; i < 4; ++i) acc[tn][4 * r4 + i] += v[i];
                     }
+            }
+            __syncthreads();
+            if (*s_gave_up) {
+#pragma unroll
+                for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[tn][r] = __builtin_nanf("");
             }
         }
         // ---- epilogue: accumulator (row = (r & 3) + 8 (r >> 2) + 4 h, column = lane & 31) -> NCHW -----------------------------
@@ -1004,8 +1024,21 @@ inline int sk_linear_class(int ksize, int stride, int dil, int H, int W) {
     return tl * 10 <= t2d * 9 ? lw : 0;
 }
 
-unsigned long long* g_sk_stamps = nullptr;       // tools: device buffer [512][4] for per-workgroup wall-clock stamps (mas_conv_sk_debug_stamps)
-int g_sk_dma = 0;        // 0: register-staged chunks (default: measured 3-5 % faster); 1: LDS-DMA ring (kept, tested, for A/B measurements)
+// Per-call options (mas_sk_opts, include/mulactseg_hip.h): no process-wide state.  MAS_SK_DMA: LDS-DMA ring instead of the
+// register-staged chunks (default: measured 3-5 % faster; the ring is kept, tested, for A/B measurements).
+struct SkOpts {
+    bool dma, nosplit;
+    unsigned spin_limit;
+    unsigned long long* stamps;
+};
+inline SkOpts sk_opts(const mas_sk_opts* o) {
+    SkOpts r;
+    r.dma = o && (o->flags & MAS_SK_DMA);
+    r.nosplit = o && (o->flags & MAS_SK_NOSPLIT);
+    r.spin_limit = (o && o->spin_limit) ? o->spin_limit : kSkSpinLimit;
+    r.stamps = o ? static_cast<unsigned long long*>(o->stamps) : nullptr;
+    return r;
+}
 
 int sk_num_cus() {
     static int cus[64] = {};
@@ -1022,7 +1055,7 @@ template <int TAPS, int CK, int WM, int TW, int STRIDE, int DIL, bool VEC, int N
 int sk_launch(const SkP& p, hipStream_t st) {
     using G = SkG<TAPS, CK, TW, STRIDE, DIL, SUB>;
     constexpr int XF = NB >= 2 ? ((CK * G::CS + 255) / 256) * 256 : CK * G::CS;
-    constexpr size_t smem = sizeof(float) * ((NB >= 2 ? NB : 2) * ((size_t)TAPS * CK * 32 * WM + XF) + 4 * 32 * WM + 256);
+    constexpr size_t smem = sizeof(float) * ((NB >= 2 ? NB : 2) * ((size_t)TAPS * CK * 32 * WM + XF) + 4 * 32 * WM + 256 + 4);
     static_assert(smem <= 160 * 1024, "LDS");
     auto kern = &k_conv_sk<TAPS, CK, WM, TW, STRIDE, DIL, VEC, NB, SUB>;
     if (smem > 64 * 1024) {
@@ -1041,8 +1074,11 @@ int sk_launch(const SkP& p, hipStream_t st) {
 }
 
 // tiles, chunks and the deal of the iterations to the workgroups (p.K, p.M, p.Ho, p.Wo set)
-inline int sk_plan(SkP& p, const SkGeom& g, int N, int cus) {
+inline int sk_plan(SkP& p, const SkGeom& g, int N, int cus, const SkOpts& o) {
     p.N = N;
+    p.nosplit = o.nosplit ? 1 : 0;
+    p.spin_limit = o.spin_limit;
+    p.stamps = o.stamps;
     p.img = g.TAPS * g.CK * g.BM;
     p.ck = g.CK;
     p.xstep = (long long)g.CK * p.H * p.W;
@@ -1127,7 +1163,8 @@ extern "C" int mas_conv_sk_pack_multi(const void* jobs_dev, int njobs, unsigned 
 namespace {
 int sk_run(const float* x, const float* w, int N, int Cin, int H, int W, int Cout, int ksize, int stride, int dil, int dgrad,
            const float* scale, const float* shift, const float* residual, int relu, float* y, double2* stats, void* workspace,
-           size_t workspace_bytes, unsigned epoch, void* stream) {
+           size_t workspace_bytes, unsigned epoch, const mas_sk_opts* opts, void* stream) {
+    const SkOpts o = sk_opts(opts);
     if (!x || !w || !y || !workspace) return MAS_ERR_NULL;
     if (stats && (scale || residual || relu)) return MAS_ERR_RANGE;        // statistics of the bare product only
     if ((scale == nullptr) != (shift == nullptr)) return MAS_ERR_NULL;
@@ -1144,7 +1181,6 @@ int sk_run(const float* x, const float* w, int N, int Cin, int H, int W, int Cou
     p.x = x; p.w = w; p.scale = scale; p.shift = shift; p.res = residual; p.y = y;
     p.slots = static_cast<float*>(workspace);
     p.flags = reinterpret_cast<unsigned*>(static_cast<char*>(workspace) + (size_t)512 * kSkSlotFloats * sizeof(float));
-    p.stamps = g_sk_stamps;
     p.stats = stats;
     p.zero = reinterpret_cast<const float*>(p.flags + 768);     // bytes 3072.. of the tail: zero-filled by the caller, never written
     p.epoch = epoch;
@@ -1157,7 +1193,7 @@ int sk_run(const float* x, const float* w, int N, int Cin, int H, int W, int Cou
         p.K = Cout; p.M = Cin;
         p.Ho = H; p.Wo = W;
     }
-    const bool dma = g_sk_dma != 0;
+    const bool dma = o.dma;
     const bool flat = ksize == 1 && stride == 1 && !dma;
     const int lw = dma ? 0 : sk_linear_class(ksize, stride, dil, H, W);        // (input gradient at stride 1: the same plane)
     if (lw) {
@@ -1175,7 +1211,7 @@ int sk_run(const float* x, const float* w, int N, int Cin, int H, int W, int Cou
     sk_geom(ksize, stride, p.M, p.Ho, p.Wo, dgrad ? 1 : 0, &g);
     const int cus = sk_num_cus();
     if (flat || lw) { g.TW = 128; g.TH = 1; }
-    if (int rc = sk_plan(p, g, N, cus)) return rc;
+    if (int rc = sk_plan(p, g, N, cus, o)) return rc;
     const int ntiles = p.ptiles * p.mtiles;
     // 16-byte global loads: the weight rows and the planes must keep 16-byte groups whole and aligned
     if ((uintptr_t)w % 16 != 0) return MAS_ERR_ALIGN;
@@ -1217,16 +1253,17 @@ int sk_run(const float* x, const float* w, int N, int Cin, int H, int W, int Cou
 
 extern "C" int mas_conv_sk(const float* x, const float* w, int N, int Cin, int H, int W, int Cout, int ksize, int stride, int dil, int dgrad,
                            const float* scale, const float* shift, const float* residual, int relu, float* y, void* workspace,
-                           size_t workspace_bytes, unsigned epoch, void* stream) {
+                           size_t workspace_bytes, unsigned epoch, const mas_sk_opts* opts, void* stream) {
     return sk_run(x, w, N, Cin, H, W, Cout, ksize, stride, dil, dgrad, scale, shift, residual, relu, y, nullptr, workspace, workspace_bytes, epoch,
-                  stream);
+                  opts, stream);
 }
 
 /* Entries per output channel of the BatchNorm partials mas_conv_sk_stats writes for this forward product (0: unsupported). */
-extern "C" int mas_conv_sk_stats_slots(int N, int Cin, int H, int W, int Cout, int ksize, int stride, int dil) {
+extern "C" int mas_conv_sk_stats_slots(int N, int Cin, int H, int W, int Cout, int ksize, int stride, int dil, unsigned flags) {
+    const bool dma = (flags & MAS_SK_DMA) != 0;
     if (N <= 0 || Cin <= 0 || H <= 0 || W <= 0 || Cout <= 0 || (ksize != 1 && ksize != 3) || (stride != 1 && stride != 2)) return 0;
     int Ho = (H - 1) / stride + 1, Wo = (W - 1) / stride + 1;
-    const bool flat = (ksize == 1 && stride == 1 && g_sk_dma == 0) || (g_sk_dma == 0 && sk_linear_class(ksize, stride, dil, H, W) != 0);
+    const bool flat = !dma && ((ksize == 1 && stride == 1) || sk_linear_class(ksize, stride, dil, H, W) != 0);
     if (flat) { Wo = H * W; Ho = 1; }
     SkGeom g;
     sk_geom(ksize, stride, Cout, Ho, Wo, 0, &g);
@@ -1239,10 +1276,10 @@ extern "C" int mas_conv_sk_stats_slots(int N, int Cin, int H, int W, int Cout, i
  * stats [Cout][mas_conv_sk_stats_slots()] pairs of doubles (sum y, sum y^2) over disjoint pixel sets -- the input of
  * mas_bn_act_train_fwd_stats. */
 extern "C" int mas_conv_sk_stats(const float* x, const float* w, int N, int Cin, int H, int W, int Cout, int ksize, int stride, int dil, float* y,
-                                 double* stats, void* workspace, size_t workspace_bytes, unsigned epoch, void* stream) {
+                                 double* stats, void* workspace, size_t workspace_bytes, unsigned epoch, const mas_sk_opts* opts, void* stream) {
     if (!stats) return MAS_ERR_NULL;
     return sk_run(x, w, N, Cin, H, W, Cout, ksize, stride, dil, 0, nullptr, nullptr, nullptr, 0, y, reinterpret_cast<double2*>(stats), workspace,
-                  workspace_bytes, epoch, stream);
+                  workspace_bytes, epoch, opts, stream);
 }
 
 /* One parity class (sub = 2 py + px) of the input gradient of a 3x3, stride-2, padding-1 convolution: dy [N,Cout,Hd,Wd] with
@@ -1250,8 +1287,9 @@ extern "C" int mas_conv_sk_stats(const float* x, const float* w, int N, int Cin,
  * (2 i + py, 2 j + px) of dx [N,Cin,H,W] -- the four classes together write every pixel once.  Epilogue as mas_conv_sk. */
 extern "C" int mas_conv_sk_dgrad_s2(const float* dy, const float* wp, int N, int Cin, int H, int W, int Cout, int sub, const float* scale,
                                     const float* shift, const float* residual, int relu, float* dx, void* workspace, size_t workspace_bytes,
-                                    unsigned epoch, void* stream) {
+                                    unsigned epoch, const mas_sk_opts* opts, void* stream) {
     if (!dy || !wp || !dx || !workspace) return MAS_ERR_NULL;
+    const SkOpts o = sk_opts(opts);
     if ((scale == nullptr) != (shift == nullptr)) return MAS_ERR_NULL;
     if (N <= 0 || Cin <= 0 || H <= 0 || W <= 0 || Cout <= 0) return MAS_ERR_SHAPE;
     if (sub < 0 || sub > 3 || epoch == 0) return MAS_ERR_RANGE;
@@ -1263,7 +1301,6 @@ extern "C" int mas_conv_sk_dgrad_s2(const float* dy, const float* wp, int N, int
     p.x = dy; p.w = wp; p.scale = scale; p.shift = shift; p.res = residual; p.y = dx;
     p.slots = static_cast<float*>(workspace);
     p.flags = reinterpret_cast<unsigned*>(static_cast<char*>(workspace) + (size_t)512 * kSkSlotFloats * sizeof(float));
-    p.stamps = g_sk_stamps;
     p.stats = nullptr;
     p.zero = reinterpret_cast<const float*>(p.flags + 768);
     p.epoch = epoch;
@@ -1275,7 +1312,7 @@ extern "C" int mas_conv_sk_dgrad_s2(const float* dy, const float* wp, int N, int
     if (p.Ho == 0 || p.Wo == 0) return 0;
     SkGeom g;
     sk_geom(3, 2, p.M, p.Ho, p.Wo, 2 + sub, &g);
-    if (int rc = sk_plan(p, g, N, sk_num_cus())) return rc;
+    if (int rc = sk_plan(p, g, N, sk_num_cus(), o)) return rc;
     const bool vec = ((uintptr_t)dy % 16 == 0) && (p.W % 4 == 0);
     if (!vec && ((long long)N * p.K * p.H * p.W < 4 || (p.K % g.CK != 0 && (long long)(p.K % g.CK) * p.H * p.W < 4))) return MAS_ERR_SHAPE;
     if ((long long)g.CK * p.H * p.W * 4 + 16 >= 0xfffffff0LL) return MAS_ERR_SHAPE;
@@ -1286,19 +1323,6 @@ extern "C" int mas_conv_sk_dgrad_s2(const float* dy, const float* wp, int N, int
         case 2: return sk_dispatch<2, 32, 1, 1, 0, 2>(p, g, vec, st);
         default: return sk_dispatch<4, 16, 1, 1, 0, 3>(p, g, vec, st);
     }
-}
-
-/* tools only: per-workgroup wall-clock stamps (100 MHz) of the following mas_conv_sk launches into `stamps_dev` [512][4] u64
- * (start, pipeline primed, last tile done, end), indexed by the logical workgroup; NULL switches it off */
-extern "C" int mas_conv_sk_debug_stamps(void* stamps_dev) {
-    g_sk_stamps = static_cast<unsigned long long*>(stamps_dev);
-    return 0;
-}
-
-extern "C" int mas_conv_sk_set_mode(int dma) {
-    const int old = g_sk_dma;
-    if (dma == 0 || dma == 1) g_sk_dma = dma;
-    return old;
 }
 
 /* error word of the last launches on this workspace: non-zero = a bounded spin gave up (host-side read, for tests) */

@@ -1200,10 +1200,25 @@ def packed_weight(w, stride=1, dgrad=False):
     return reg.get(w, stride, dgrad)
 
 
-def conv_sk(x, w, stride=1, dil=1, dgrad=False, scale=None, shift=None, residual=None, relu=False, packed=None, stats=False):
+_SK_DEFAULT_FLAGS = [0]         # wrapper default of the per-call mas_sk_opts.flags (conv_sk_set_mode: A/B runs of the LDS-DMA ring)
+
+
+def _sk_opts(flags=None, spin_limit=0, stamps=None):
+    """mas_sk_opts for one call (NULL when everything is the default)."""
+    import ctypes
+    flags = _SK_DEFAULT_FLAGS[0] if flags is None else int(flags)
+    if not flags and not spin_limit and stamps is None:
+        return None, flags
+    o = _lib.SkOpts(flags, int(spin_limit), stamps.data_ptr() if stamps is not None else None)
+    return ctypes.byref(o), flags
+
+
+def conv_sk(x, w, stride=1, dil=1, dgrad=False, scale=None, shift=None, residual=None, relu=False, packed=None, stats=False,
+            flags=None, spin_limit=0, stamps=None):
     """Training-mode dense convolution on the persistent stream-K MFMA kernel (mas_conv_sk), weight `w` [Cout,Cin,k,k] as PyTorch
     stores it (``packed``: its conv_sk_pack image for this role, when the caller keeps one).  dgrad=False: y = conv2d(x, w, stride, padding = dil (k 3) / 0 (k 1), dilation); dgrad=True: x is dY [N,Cout,H,W] and
-    the result is dX [N,Cin,H,W] of the stride-1 convolution.  Optional epilogue y*scale[m] + shift[m] + residual, ReLU."""
+    the result is dX [N,Cin,H,W] of the stride-1 convolution.  Optional epilogue y*scale[m] + shift[m] + residual, ReLU.
+    ``flags`` (_lib.SK_DMA | _lib.SK_NOSPLIT), ``spin_limit``, ``stamps``: the per-call mas_sk_opts."""
     _need(x, "x", torch.float32)
     _need(w, "w", torch.float32)
     Cout, Cin, ks, _ = w.shape
@@ -1226,26 +1241,27 @@ def conv_sk(x, w, stride=1, dil=1, dgrad=False, scale=None, shift=None, residual
         packed = conv_sk_pack(w, stride, dgrad)
     ws, epoch = _sk_workspace(x.device)
     lib = _lib.load()
+    opts, flags = _sk_opts(flags, spin_limit, stamps)
     if stats:
         # forward without epilogue + the BatchNorm partial sums of y from the epilogue of every tile: (y, partials [Cout, slots, 2] f64)
         if dgrad or scale is not None or residual is not None or relu:
             raise ValueError("stats=True: bare forward product only")
-        slots = int(lib.mas_conv_sk_stats_slots(N, Cin, H, W, Cout, ks, stride, dil))
+        slots = int(lib.mas_conv_sk_stats_slots(N, Cin, H, W, Cout, ks, stride, dil, flags))
         if slots <= 0:
             raise ValueError("unsupported geometry for mas_conv_sk_stats")
         part = torch.empty((Cout, slots, 2), dtype=torch.float64, device=x.device)
         with torch.cuda.device(x.device):
             _lib.check(lib.mas_conv_sk_stats(x.data_ptr(), packed.data_ptr(), N, Cin, H, W, Cout, ks, stride, dil, y.data_ptr(), part.data_ptr(),
-                                             ws.data_ptr(), ws.numel(), epoch, _stream(x)), "mas_conv_sk_stats")
+                                             ws.data_ptr(), ws.numel(), epoch, opts, _stream(x)), "mas_conv_sk_stats")
         return y, part
     with torch.cuda.device(x.device):
         _lib.check(lib.mas_conv_sk(x.data_ptr(), packed.data_ptr(), N, Cin, H, W, Cout, ks, stride, dil, int(dgrad), _opt(scale), _opt(shift),
-                                   _opt(residual), int(relu), y.data_ptr(), ws.data_ptr(), ws.numel(), epoch, _stream(x)),
+                                   _opt(residual), int(relu), y.data_ptr(), ws.data_ptr(), ws.numel(), epoch, opts, _stream(x)),
                    "mas_conv_sk")
     return y
 
 
-def conv_sk_dgrad_s2(dy, w, H, W, packed=None):
+def conv_sk_dgrad_s2(dy, w, H, W, packed=None, flags=None, spin_limit=0):
     """dX [N,Cin,H,W] of y = conv2d(x, w, stride 2, padding 1) for a 3x3 weight `w` [Cout,Cin,3,3] from dY [N,Cout,(H-1)//2+1,
     (W-1)//2+1]: four launches of the stream-K kernel, one per parity class of the dX pixels (mas_conv_sk_dgrad_s2) -- each a
     stride-1 product over the dY plane with 1 / 2 / 2 / 4 taps, together the exact FLOPs of the gradient (no zero insertion).
@@ -1258,18 +1274,22 @@ def conv_sk_dgrad_s2(dy, w, H, W, packed=None):
         raise ValueError("dy %s does not belong to a 3x3 stride-2 convolution of a %dx%d plane with weight %s" % (tuple(dy.shape), H, W, tuple(w.shape)))
     dx = torch.empty((N, Cin, H, W), dtype=torch.float32, device=dy.device)
     lib = _lib.load()
+    opts, _ = _sk_opts(flags, spin_limit)
     with torch.cuda.device(dy.device):
         for sub in range(4):
             img = packed[sub] if packed is not None else conv_sk_pack(w, 2, 2 + sub)
             ws, epoch = _sk_workspace(dy.device)
             _lib.check(lib.mas_conv_sk_dgrad_s2(dy.data_ptr(), img.data_ptr(), N, Cin, H, W, Cout, sub, None, None, None, 0, dx.data_ptr(),
-                                                ws.data_ptr(), ws.numel(), epoch, _stream(dy)), "mas_conv_sk_dgrad_s2")
+                                                ws.data_ptr(), ws.numel(), epoch, opts, _stream(dy)), "mas_conv_sk_dgrad_s2")
     return dx
 
 
 def conv_sk_set_mode(dma):
-    """Chunk staging of mas_conv_sk, process-wide: False = register-staged (default), True = LDS-DMA ring; returns the previous mode."""
-    return bool(_lib.load().mas_conv_sk_set_mode(int(bool(dma))))
+    """Default chunk staging of this wrapper's conv_sk calls (the library itself keeps no mode: the flag travels with every call in
+    mas_sk_opts): False = register-staged (default), True = LDS-DMA ring; returns the previous default.  For A/B runs and tests."""
+    old = bool(_SK_DEFAULT_FLAGS[0] & _lib.SK_DMA)
+    _SK_DEFAULT_FLAGS[0] = (_SK_DEFAULT_FLAGS[0] & ~_lib.SK_DMA) | (_lib.SK_DMA if dma else 0)
+    return old
 
 
 def conv_sk_error(dev=None):
@@ -1283,6 +1303,42 @@ def conv_sk_error(dev=None):
     out = ctypes.c_uint(0)
     _lib.check(_lib.load().mas_conv_sk_error(ent[0].data_ptr(), ctypes.byref(out)), "mas_conv_sk_error")
     return int(out.value)
+
+
+def _cuda_dev(dev):
+    dev = torch.device('cuda', torch.cuda.current_device()) if dev is None else torch.device(dev)
+    return torch.device('cuda', torch.cuda.current_device()) if dev.index is None else dev
+
+
+def _sk_error_views(dev):
+    off = int(_lib.load().mas_conv_sk_workspace_bytes()) - 4096 + 512 * 4       # the word behind the 512 epoch flags
+    return [ent[0][off:off + 4] for (d, _), ent in _SK_WS.items() if d == dev]
+
+
+def conv_sk_error_words(dev=None):
+    """The error words of every stream-K workspace of `dev` as ONE device tensor [n] int32 (gathered on the current stream, no
+    synchronisation), or None when no stream-K launch has run there yet.  The words are sticky (a finisher that gives up ORs a bit
+    in; nothing but conv_sk_clear_error clears it), so a caller may look at them late: the trainers ship them to the host with the
+    loss of the NEXT step (trainer/active_joint_multi.py:_HostProbe) and raise StreamKGaveUp."""
+    views = _sk_error_views(_cuda_dev(dev))
+    return torch.cat(views).view(torch.int32) if views else None
+
+
+def conv_sk_clear_error(dev=None):
+    """Zero the error words of `dev` (after the caller has dealt with a reported give-up)."""
+    for v in _sk_error_views(_cuda_dev(dev)):
+        v.zero_()
+
+
+class StreamKGaveUp(RuntimeError):
+    """A stream-K convolution gave up waiting for another workgroup of its launch: the step's activations / gradients are poisoned
+    (NaN).  Seen only when the GPU is shared with something that keeps CUs busy for seconds."""
+
+
+def occupy_cus(blocks, lds_bytes, seconds, stream=None):
+    """Test-only neighbour kernel (mas_test_occupy): `blocks` workgroups that hold 256 threads + `lds_bytes` of LDS for `seconds`."""
+    st = torch.cuda.current_stream() if stream is None else stream
+    _lib.check(_lib.load().mas_test_occupy(int(blocks), int(lds_bytes), int(seconds * 1e8), st.cuda_stream), "mas_test_occupy")
 
 
 _SIDE_STREAMS = {}

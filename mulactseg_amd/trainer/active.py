@@ -67,7 +67,11 @@ class ActiveTrainer(BaseTrainer):
             if self.ddp is not None:            # the skip must be taken by every rank or by none (gradient all-reduce)
                 import torch.distributed as dist
                 dist.all_reduce(bad, op=dist.ReduceOp.MAX)
-            ok = not bool(bad)
+            # (the stream-K error word rides on the same host read: this forward pass and the previous step's backward pass)
+            host = torch.stack([bad.reshape(())] + [f.to(torch.int32).reshape(()) for f in self.stream_k_flag()]).tolist()
+            if len(host) > 1 and host[1] != 0:
+                self.raise_stream_k()
+            ok = not host[0]
             if ok:
                 loss.backward()
                 self.optimizer.step()
@@ -77,3 +81,4 @@ class ActiveTrainer(BaseTrainer):
                 self.am.add({'train-loss': loss.detach().cpu().item()})
             self.log_training(iteration, None, total_itrs)
             self.log_validation(iteration, val_period)
+        self.check_stream_k()

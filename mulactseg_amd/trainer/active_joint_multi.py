@@ -80,9 +80,14 @@ class ActiveTrainer(active.ActiveTrainer):
             import torch.distributed as dist
             scale = dist.get_world_size()
         if loss.is_cuda:
-            handle = self._probe().submit([loss])
+            # the error words of the stream-K convolutions travel with the loss: this forward pass and the PREVIOUS step's backward
+            # pass are covered here, the last backward pass of a round by check_stream_k() at the end of train_impl
+            handle = self._probe().submit([loss] + self.stream_k_flag())
             (loss * scale if scale != 1 else loss).backward()
-            v = _HostProbe.read(handle)[0]
+            host = _HostProbe.read(handle)
+            v = host[0]
+            if len(host) > 1 and host[1] != 0:
+                self.raise_stream_k()
             if v != v:
                 raise ValueError("NaN loss")
             if v == 0:
@@ -144,3 +149,4 @@ class ActiveTrainer(active.ActiveTrainer):
             self.log_training(iteration, None, total_itrs)
             self.log_validation(iteration, val_period)
         self.flush_meters()
+        self.check_stream_k()

@@ -53,3 +53,4 @@ class ActiveTrainer(active_joint_multi_predignore.ActiveTrainer):
             self.log_training(iteration, None, total_itrs)
             self.log_validation(iteration, val_period)
         self.flush_meters()
+        self.check_stream_k()

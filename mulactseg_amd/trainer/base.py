@@ -139,6 +139,28 @@ class BaseTrainer(object):
     def forward_train(self, images, **kw):
         return (self.ddp or self.net)(images, **kw)
 
+    # -- the stream-K convolutions' error word (csrc/conv_sk.hip: a finisher that gave up waiting poisons its tile and says so) --
+    def stream_k_flag(self):
+        """[] or [0-dim device tensor != 0 when a stream-K launch of this device has given up since the last clear]: no
+        synchronisation -- the trainers read it together with the loss."""
+        from .. import ops
+        words = ops.conv_sk_error_words(self.device)
+        return [] if words is None else [words.max()]
+
+    def raise_stream_k(self):
+        from .. import ops
+        ops.conv_sk_clear_error(self.device)
+        raise ops.StreamKGaveUp(
+            "a stream-K convolution gave up waiting for a workgroup of its own launch (mas_conv_sk error word): the GPU is shared with "
+            "something that held its CUs for seconds; the activations / gradients of that step are poisoned (NaN) and the parameters "
+            "may be -- reload the last checkpoint")
+
+    def check_stream_k(self):
+        """Synchronous form (end of a training round, tests)."""
+        flag = self.stream_k_flag()
+        if flag and int(flag[0].item()) != 0:
+            self.raise_stream_k()
+
     # -- evaluation ---------------------------------------------------------------------------------
     def inference(self, loader, prefix=''):
         """mIoU over a loader -- ``trainer/base.py:139-175`` / ``active_joint_multi_predignore.py:175-215``."""

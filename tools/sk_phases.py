@@ -17,11 +17,8 @@ pk = ops.conv_sk_pack(wt, s, False)
 for _ in range(5):
     ops.conv_sk(x, wt, s, d, packed=pk)
 st = torch.zeros((512 * 4 + 64,), dtype=torch.int64, device='cuda')
-lib = _lib.load()
-lib.mas_conv_sk_debug_stamps(st.data_ptr())
-ops.conv_sk(x, wt, s, d, packed=pk)
+ops.conv_sk(x, wt, s, d, packed=pk, stamps=st)
 torch.cuda.synchronize()
-lib.mas_conv_sk_debug_stamps(None)
 ph = st.cpu().numpy()[2048:2048 + 64].reshape(8, 8)
 print(sys.argv[1:9])
 for wv in range(8):

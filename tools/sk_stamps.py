@@ -20,13 +20,12 @@ fn = (lambda: ops.conv_sk(dy, wt, 1, d, dgrad=True, packed=pk)) if what == "dgra
 for _ in range(5):
     fn()
 st = torch.zeros((512, 4), dtype=torch.int64, device='cuda')
-lib = _lib.load()
-lib.mas_conv_sk_debug_stamps(st.data_ptr())
+fn0 = fn
+fn = (lambda: ops.conv_sk(dy, wt, 1, d, dgrad=True, packed=pk, stamps=st)) if what == "dgrad" else (lambda: ops.conv_sk(x, wt, s, d, packed=pk, stamps=st))
 a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 torch.cuda.synchronize()
 a.record(); fn(); b.record()
 torch.cuda.synchronize()
-lib.mas_conv_sk_debug_stamps(None)
 t = st.cpu().numpy().astype(np.float64)
 t = t[t[:, 0] > 0]
 t0 = t[:, 0].min()
