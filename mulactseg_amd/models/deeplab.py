@@ -278,9 +278,13 @@ class _ASPPPooling(nn.Sequential):
         super().__init__(nn.AdaptiveAvgPool2d(1), nn.Conv2d(cin, cout, 1, bias=False), nn.BatchNorm2d(cout), nn.ReLU(inplace=True))
 
     def forward(self, x):
-        # bilinear upsampling of a 1x1 map is a broadcast (F.interpolate differs from it by the rounding of l0*v + l1*v);
-        # ATen's backward for it is 2 304 atomic adds into ONE element per channel: 1.1 ms per step
-        return _run(self, x).expand(-1, -1, x.shape[-2], x.shape[-1])
+        # bilinear upsampling of a 1x1 map is a broadcast (F.interpolate differs from it by the rounding of l0*v + l1*v: 2e-7);
+        # ATen's backward for it is 2 304 atomic adds into ONE element per channel: 1.1 ms per step.  On the CPU the reference's
+        # own op (deeplabv3.py:206-207), so that the CPU form of the network equals the executed reference bit for bit (G10).
+        y = _run(self, x)
+        if not x.is_cuda:
+            return F.interpolate(y, size=x.shape[-2:], mode='bilinear', align_corners=False)
+        return y.expand(-1, -1, x.shape[-2], x.shape[-1])
 
 
 class ASPP(nn.Module):

@@ -14,6 +14,8 @@ Fixtures:
                        my_bvsb_predclsbal_pwr (C=21, S=150, odd image size)      (row a-5, config 1)
   g3_losses.npz        stage-1 losses fwd + dz for every in-scope loss class      (rows a-7, a-8, a-11)
   g5_miou.npz          MeanIoU / IoUIgnore counters incl. an unseen class         (row a-12)
+  g10_train.npz        the network in TRAINING mode + two AdamW / PolyLR steps of the production objective
+                       (batch statistics, running-stat update, shared proxy gradient, optimizer groups)   (rows a-9, a-10)
 """
 import hashlib
 import importlib.util
@@ -468,6 +470,90 @@ def gen_g9():
     np.savez_compressed(os.path.join(OUT, "g9_augment.npz"), **out)
 
 
+def sub256(a):
+    """The fixture's deterministic cut of a tensor: every (numel // 256)-th element of the flattened array, at most 256."""
+    a = np.ascontiguousarray(a).reshape(-1)
+    return a[::max(1, a.size // 256)][:256].copy()
+
+
+def train_inputs(seed, N, C, H, W, S):
+    """Batch of the G10 training step: pictures, partial-label targets, superpixel maps, selection masks (all seeded)."""
+    x = np.random.RandomState(seed).standard_normal(size=(N, 3, H, W)).astype(np.float32)
+    spx, msk = zip(*[synth.train_crop(seed * 23 + i, H, W, S, frac_selected=0.3) for i in range(N)])
+    tgt = np.stack([synth.multi_hot_targets(seed * 29 + i, S, C) for i in range(N)])
+    return x, tgt, np.stack(spx), np.stack(msk)
+
+
+def gen_g10():
+    """TRAINING-mode pin of the network and of the optimizer (rows a-9, a-10): the reference's model builder
+    (models/__init__.py:21-51: deeplabv3pluswn_resnet50deepstem + convert_to_separable_conv + set_bn_momentum(backbone, 0.1)) in
+    .train(), Dropout probabilities set to 0 by attribute, two steps of the production objective
+    (trainer/active_joint_multi_predignore_lossdecomp.py:83-116: net(images) upsampled, 16 ce + 8 mc + 1 group with the reference's
+    loss classes) under the reference's own get_optim (trainer/base.py:64-69, AdamW with the classifier at cls_lr_scale x lr) and
+    PolyLR (utils/scheduler.py:5-14).  Stored: logits and losses of both steps, a cut of every parameter gradient of step 1, every
+    BatchNorm buffer after step 1 and after step 2, a cut of every parameter after step 2, the learning rates."""
+    import models as ref_models
+    from models.segmentation.modeling import deeplabv3pluswn_resnet50deepstem
+    from models.segmentation import convert_to_separable_conv
+    from trainer.base import BaseTrainer
+    from utils.scheduler import PolyLR
+    from trainer.active_joint_multi_predignore_lossdecomp import OnehotCEMultihotChoice
+    from trainer.active_joint_multi_predignore_mclossablation2 import GroupMultiLabelCE_onlymulti
+    seed, N, C, H, W, S, T = 101, 4, 20, 129, 161, 48, 0.1
+    net = deeplabv3pluswn_resnet50deepstem(num_classes=C, output_stride=16, pretrained_backbone=False)
+    convert_to_separable_conv(net.classifier)
+    ref_models.set_bn_momentum(net.backbone, momentum=0.1)
+    shapes = {k: tuple(v.shape) for k, v in net.state_dict().items()}
+    sd = synth.synthetic_state_dict(shapes, seed=10)
+    net.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+    net.train()
+    n_drop = 0
+    for m in net.modules():
+        if isinstance(m, torch.nn.Dropout):
+            m.p = 0.0
+            n_drop += 1
+    x, tgt, spx, msk = train_inputs(seed, N, C, H, W, S)
+    xt, tt, ts, tm = torch.from_numpy(x), torch.from_numpy(tgt), torch.from_numpy(spx), torch.from_numpy(msk)
+    tr = BaseTrainer.__new__(BaseTrainer)
+    tr.args = types.SimpleNamespace(optimizer='adamw', cls_lr_scale=10.0, weight_decay=1e-5)
+    tr.net = net
+    tr.get_optim(my_lr=2e-5)
+    sched = PolyLR(tr.optimizer, 10, power=0.9, min_lr=1e-6)
+    group_fn = GroupMultiLabelCE_onlymulti(args=None, num_class=C - 1, num_superpixel=S, temperature=T)
+    pos_fn = OnehotCEMultihotChoice(num_class=C - 1, temperature=T)
+    quarter = {}
+    hook = net.classifier.register_forward_hook(lambda m, i, o: quarter.__setitem__('q', o.detach().clone()))
+    names = [n for n, _ in net.named_parameters()]
+    out = dict(seed=seed, sd_seed=10, N=N, C=C, H=H, W=W, S=S, temp=T, lr=2e-5, cls_lr_scale=10.0, weight_decay=1e-5, max_iters=10,
+               power=0.9, min_lr=1e-6, coeffs=np.array([16.0, 8.0, 1.0]), n_dropout=n_drop, input_digest=digest(x, tgt, spx, msk),
+               param_names=np.array(names), buffer_names=np.array([n for n, _ in net.named_buffers()]),
+               bn_momentum=np.array([m.momentum for m in net.modules() if isinstance(m, torch.nn.BatchNorm2d)]))
+    for step in (1, 2):
+        tr.optimizer.zero_grad()
+        preds = net(xt)
+        group = group_fn(preds, tt, ts, tm)
+        ce, mc = pos_fn(preds, tt, ts, tm)
+        loss = 16.0 * ce + 8.0 * mc + 1.0 * group
+        loss.backward()
+        out['quarter%d' % step] = quarter['q'].numpy()
+        out['full_sub%d' % step] = preds.detach()[:, :, ::3, ::3].numpy()
+        out['losses%d' % step] = np.array([float(loss), float(ce), float(mc), float(group)], dtype=np.float32)
+        if step == 1:
+            for i, (n, p) in enumerate(net.named_parameters()):
+                out['grad_%03d' % i] = sub256(p.grad.numpy())
+                out['gnorm_%03d' % i] = np.float64(p.grad.double().norm())
+        tr.optimizer.step()
+        sched.step()
+        out['lrs%d' % step] = np.array([g['lr'] for g in tr.optimizer.param_groups], dtype=np.float64)
+        for i, (n, b) in enumerate(net.named_buffers()):
+            out['buf%d_%03d' % (step, i)] = b.detach().numpy().copy()
+    for i, (n, p) in enumerate(net.named_parameters()):
+        out['param_%03d' % i] = sub256(p.detach().numpy())
+    hook.remove()
+    np.savez_compressed(os.path.join(OUT, "g10_train.npz"), **out)
+    print("g10: losses", out['losses1'], out['losses2'], "lrs", out['lrs1'], out['lrs2'], "params", len(names), "dropouts", n_drop)
+
+
 if __name__ == "__main__":
     refshim.install()
     os.makedirs(OUT, exist_ok=True)
@@ -481,5 +567,6 @@ if __name__ == "__main__":
     gen_g7()
     gen_g8()
     gen_g9()
+    gen_g10()
     for f in sorted(os.listdir(OUT)):
         print(f, os.path.getsize(os.path.join(OUT, f)))

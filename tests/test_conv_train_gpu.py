@@ -41,6 +41,17 @@ CASES = [
     (128, 128, 3, 1, 1, 2, 97, 97),      # layer2 at the 769 crop: the 128-column class
     (64, 64, 3, 1, 2, 1, 20, 120),       # its widest plane, dilation 2
     (64, 64, 3, 1, 1, 1, 30, 57),        # its narrowest
+    # BASELINE configs[1]: the two largest planes of the 769 crop at their real size (385 x 385 after the stem's stride, 193 x 193
+    # after the max-pool): every row at another 4-byte alignment, the last 16-byte group of every row astride its end
+    (64, 64, 3, 1, 1, 1, 385, 385),      # stem conv 2
+    (16, 32, 3, 1, 1, 1, 385, 385),
+    (64, 128, 3, 2, 1, 1, 385, 385),     # 385 -> 193 at stride 2 (parity classes of the input gradient on an odd plane)
+    (32, 64, 1, 1, 1, 1, 385, 385),      # 1x1 with a K tail on the flat walk
+    (64, 64, 3, 1, 1, 1, 193, 193),      # layer1 conv2
+    (128, 64, 1, 1, 1, 1, 193, 193),     # layer1.0 conv1
+    (64, 256, 1, 1, 1, 1, 193, 193),     # layer1 conv3
+    (128, 128, 3, 2, 1, 1, 193, 193),    # layer2.0 conv2: 193 -> 97
+    (256, 512, 1, 2, 1, 1, 193, 193),    # layer2.0 downsample
 ]
 
 
@@ -270,6 +281,30 @@ def test_conv_train_forward_and_gradients(Cin, Cout, k, stride, dil, N, H, W):
         scale = float(ref.abs().max())
         err = float((got.double() - ref).abs().max())
         assert err <= 2e-5 * scale, (name, err, scale)
+
+
+def test_random_geometry_cut_of_the_soak():
+    """A 40-geometry cut of tools/soak_conv_train.py (random channel counts, planes from 1 x 1 to 140 x 200, strides, dilations,
+    batch sizes; forward with the statistics epilogue, input gradient incl. the residual operand and the stride-2 classes, weight
+    gradient) against float64 autograd: the same seeds the builder's 250-geometry soak starts with."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    import importlib.util
+    from mulactseg_amd import ops
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "soak_conv_train.py")
+    spec = importlib.util.spec_from_file_location("soak_conv_train", path)
+    soak = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(soak)
+    ran, worst = 0, 0.0
+    for seed in range(9000, 9040):
+        out = soak.run_seed(seed)
+        if out is None:
+            continue
+        ran += 1
+        assert max(out[1]) <= 3e-5, (seed, out)
+        worst = max(worst, max(out[1]))
+    assert ran >= 35 and ops.conv_sk_error() == 0
+    print("soak cut: %d geometries, worst relative error %.2e" % (ran, worst))
 
 
 def test_train_step_on_own_convolutions_matches_float64():

@@ -130,7 +130,8 @@ def test_whole_tile_plan_matches_on_random_data():
         ya, pa = ops.conv_sk(x, w, stride, dil, stats=True)
         yb, pb = ops.conv_sk(x, w, stride, dil, stats=True, flags=_lib.SK_NOSPLIT)
         assert torch.equal(yb, b) and torch.equal(ya, a)
-        assert torch.allclose(pa.sum(1), pb.sum(1), rtol=1e-6, atol=1e-3)
+        # (partials are f32 sums of the tile's accumulators: the two plans round at different places)
+        assert float((pa.sum(1) - pb.sum(1)).abs().max()) <= 1e-5 * float(pa.sum(1)[:, 1].max())
     assert ops.conv_sk_error() == 0
 
 
@@ -162,8 +163,13 @@ def test_training_step_under_rccl_ddp_is_bit_identical():
     x = torch.randn(2, 3, 256, 256, generator=torch.Generator(device=dev).manual_seed(4), device=dev)
     ops.conv_sk_clear_error()
     wts = torch.linspace(-1.0, 1.0, 2 * 20 * 64 * 64, device=dev).view(2, 20, 64, 64)      # quarter-resolution logits
+    _one_step(net, x, wts)                                      # (first call of the process: MIOpen's find may time other solvers)
+    net.load_state_dict(bn_state)
     z_plain = _one_step(net, x, wts).detach().clone()
     g_plain = {n: p.grad.detach().clone() for n, p in net.named_parameters() if p.grad is not None}
+    net.load_state_dict(bn_state)
+    z_again = _one_step(net, x, wts).detach()
+    assert torch.equal(z_again, z_plain), ("the plain step is not run-to-run identical", float((z_again - z_plain).abs().max()))
     net.load_state_dict(bn_state)
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     os.environ.setdefault("MASTER_PORT", "29613")
@@ -175,7 +181,7 @@ def test_training_step_under_rccl_ddp_is_bit_identical():
             net.load_state_dict(bn_state)
             z_ddp = _one_step(ddp, x, wts).detach()
             torch.cuda.synchronize()
-            assert torch.equal(z_ddp, z_plain)
+            assert torch.equal(z_ddp, z_plain), float((z_ddp - z_plain).abs().max())
             for n, p in net.named_parameters():
                 if n in g_plain:
                     assert torch.equal(p.grad, g_plain[n]), (rep, n)

@@ -1,0 +1,192 @@
+"""TRAINING-mode pin of the network and of the optimizer to the executed reference (tests/golden/g10_train.npz, written by
+oracle/gen_golden.py:gen_g10 from the reference's own model builder, loss classes, ``get_optim`` and ``PolyLR``):
+two steps of the production objective (trainer/active_joint_multi_predignore_lossdecomp.py:83-116) on a [4,3,129,161] batch --
+batch statistics in every BatchNorm, momentum 0.1 (models/__init__.py:49), the running-statistics update, the Dropout(0.1)
+placement (deeplabv3.py:238; p set to 0 on both sides), the gradient of the Parameter shared by ``proxy`` / ``final.weight``
+(deeplabv3.py:88-89), the AdamW groups (trainer/base.py:64-69) and the poly schedule (utils/scheduler.py:11-13).
+
+CPU: this package's modules as plain PyTorch ops + the losses of oracle/port.py: logits, running statistics <= 1e-5, parameters after
+two steps <= 1e-6 -- with ONE torch thread, as the fixture was generated: batch statistics over the 9 x 11 maps of the deep layers
+(and over two samples in the ASPP pooling branch) amplify the thread-count dependence of ATen's blocked f32 sums to 4e-5 of the
+logits (the reference's own bits move that much between 1 and 8 threads; observed with one thread: 1.5e-7).  GPU (-m gpu): the own kernels end to end (stream-K / split-K convolutions, fused BatchNorm, fused low-resolution
+loss scans, fused AdamW): logits and running statistics <= 1e-4, gradients <= 2e-3 relative L2."""
+import hashlib
+import os
+import types
+
+import numpy as np
+import pytest
+import torch
+
+from mulactseg_amd import synth
+from mulactseg_amd.models import get_model
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "g10_train.npz")
+
+
+def sub256(a):
+    a = np.ascontiguousarray(a).reshape(-1)
+    return a[::max(1, a.size // 256)][:256]
+
+
+def _digest(*arrays):
+    h = hashlib.sha256()
+    for a in arrays:
+        h.update(np.ascontiguousarray(a).tobytes())
+    return np.frombuffer(h.digest()[:8], dtype=np.uint64)[0]
+
+
+def _inputs(g):
+    seed, N, C, H, W, S = (int(g[k]) for k in ('seed', 'N', 'C', 'H', 'W', 'S'))
+    x = np.random.RandomState(seed).standard_normal(size=(N, 3, H, W)).astype(np.float32)
+    spx, msk = zip(*[synth.train_crop(seed * 23 + i, H, W, S, frac_selected=0.3) for i in range(N)])
+    tgt = np.stack([synth.multi_hot_targets(seed * 29 + i, S, C) for i in range(N)])
+    spx, msk = np.stack(spx), np.stack(msk)
+    assert _digest(x, tgt, spx, msk) == g['input_digest']
+    return x, tgt, spx, msk
+
+
+def _build(g, device):
+    from mulactseg_amd.trainer.base import BaseTrainer
+    from mulactseg_amd.utils.scheduler import PolyLR
+    net = get_model('deeplabv3pluswn_resnet50deepstem', int(g['C']), 16, True, pretrained_backbone=False)
+    shapes = {k: tuple(v.shape) for k, v in net.state_dict().items()}
+    sd = synth.synthetic_state_dict(shapes, seed=int(g['sd_seed']))
+    net.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=True)
+    net.to(device).train()
+    drops = [m for m in net.modules() if isinstance(m, torch.nn.Dropout)]
+    assert len(drops) == int(g['n_dropout'])                                    # one Dropout, in ASPP.project (deeplabv3.py:238)
+    assert isinstance(net.classifier.aspp.project[-1], torch.nn.Dropout) and drops[0].p == 0.1
+    for m in drops:
+        m.p = 0.0
+    assert [n for n, _ in net.named_parameters()] == list(g['param_names'])     # same parameters, same order (optimizer groups)
+    assert [n for n, _ in net.named_buffers()] == list(g['buffer_names'])
+    assert [m.momentum for m in net.modules() if isinstance(m, torch.nn.BatchNorm2d)] == list(g['bn_momentum'])
+    tr = BaseTrainer.__new__(BaseTrainer)           # (the constructor needs datasets and a GPU: bypassed as the fixture's generator does)
+    tr.args = types.SimpleNamespace(optimizer='adamw', cls_lr_scale=float(g['cls_lr_scale']), weight_decay=float(g['weight_decay']))
+    tr.net = net
+    tr.get_optim(my_lr=float(g['lr']))
+    sched = PolyLR(tr.optimizer, int(g['max_iters']), power=float(g['power']), min_lr=float(g['min_lr']))
+    return net, tr.optimizer, sched
+
+
+def _compare_grads(g, net, rel_l2_bar, cut_bar):
+    num = den = 0.0
+    worst = (0.0, None)
+    for i, (n, p) in enumerate(net.named_parameters()):
+        ref, norm = g['grad_%03d' % i], float(g['gnorm_%03d' % i])
+        got = sub256(p.grad.detach().cpu().numpy())
+        num += float(((got.astype(np.float64) - ref) ** 2).sum())
+        den += float((ref.astype(np.float64) ** 2).sum())
+        # the whole tensor's norm pins what the cut does not sample
+        gn = float(p.grad.double().norm())
+        rel = abs(gn - norm) / max(norm, 1e-30)
+        if rel > worst[0]:
+            worst = (rel, n)
+    assert (num / den) ** 0.5 <= rel_l2_bar, ("relative L2 of the gradient cuts", (num / den) ** 0.5)
+    assert worst[0] <= cut_bar, ("gradient norm", worst)
+    return (num / den) ** 0.5, worst
+
+
+def _compare_buffers(g, net, step, tol):
+    worst = 0.0
+    for i, (n, b) in enumerate(net.named_buffers()):
+        ref = g['buf%d_%03d' % (step, i)]
+        got = b.detach().cpu().numpy()
+        if n.endswith('num_batches_tracked'):
+            assert int(got) == int(ref) == step, n
+        else:
+            worst = max(worst, float(np.abs(got - ref).max() / max(1.0, float(np.abs(ref).max()))))
+    assert worst <= tol, ("running statistics after step %d" % step, worst)
+    return worst
+
+
+def test_training_mode_network_and_two_optimizer_steps_match_the_reference_cpu():
+    from oracle import port
+    g = np.load(GOLDEN)
+    x, tgt, spx, msk = _inputs(g)
+    threads = torch.get_num_threads()
+    torch.set_num_threads(1)
+    try:
+        _two_steps_cpu(g, x, tgt, spx, msk, port)
+    finally:
+        torch.set_num_threads(threads)
+
+
+def _two_steps_cpu(g, x, tgt, spx, msk, port):
+    net, opt, sched = _build(g, 'cpu')
+    xt, tt, ts, tm = torch.from_numpy(x), torch.from_numpy(tgt), torch.from_numpy(spx), torch.from_numpy(msk)
+    S, T = int(g['S']), float(g['temp'])
+    quarter = {}
+    net.classifier.register_forward_hook(lambda m, i, o: quarter.__setitem__('q', o.detach()))
+    for step in (1, 2):
+        opt.zero_grad()
+        preds = net(xt)
+        group = port.group_max_ce(preds, tt, ts, tm, S, T, 'onlymulti')
+        ce, mc = port.merged_positive_ce(preds, tt, ts, tm, T, 'decomp')
+        loss = 16.0 * ce + 8.0 * mc + 1.0 * group
+        loss.backward()
+        assert float(np.abs(quarter['q'].numpy() - g['quarter%d' % step]).max()) <= 1e-5
+        assert float(np.abs(preds.detach()[:, :, ::3, ::3].numpy() - g['full_sub%d' % step]).max()) <= 1e-5
+        got = np.array([float(loss.detach()), float(ce.detach()), float(mc.detach()), float(group.detach())], dtype=np.float32)
+        assert np.allclose(got, g['losses%d' % step], rtol=2e-5, atol=0), (got, g['losses%d' % step])
+        if step == 1:
+            assert net.classifier.proxy.grad is net.classifier.final.weight.grad
+            _compare_grads(g, net, 1e-4, 1e-4)
+        opt.step()
+        sched.step()
+        assert [pg['lr'] for pg in opt.param_groups] == list(g['lrs%d' % step])              # poly schedule, both groups
+        _compare_buffers(g, net, step, 1e-5)
+    worst = max(float(np.abs(sub256(p.detach().numpy()) - g['param_%03d' % i]).max()) for i, (n, p) in enumerate(net.named_parameters()))
+    assert worst <= 1e-6, worst
+
+
+@pytest.mark.gpu
+def test_training_mode_network_and_two_optimizer_steps_match_the_reference_gpu():
+    """The same two steps on the GPU's production path: own convolutions (all three products), fused BatchNorm, the fused
+    quarter-resolution loss scans (weighted objective and its chain rule in the kernels), fused AdamW."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from mulactseg_amd import ops
+    from mulactseg_amd.models import deeplab
+    from mulactseg_amd.utils.loss import FusedPartialLabelLoss
+    g = np.load(GOLDEN)
+    x, tgt, spx, msk = _inputs(g)
+    dev = torch.device('cuda:0')
+    net, opt, sched = _build(g, dev)
+    xt, tt, ts, tm = (torch.from_numpy(a).to(dev) for a in (x, tgt, spx, msk))
+    crit = FusedPartialLabelLoss(int(g['S']), float(g['temp']), float(g['temp']), sync_normalisers=False)
+    H, W = int(g['H']), int(g['W'])
+    ops.conv_sk_clear_error()
+    p0 = [p.detach().clone() for p in net.parameters()]
+    for step in (1, 2):
+        opt.zero_grad()
+        deeplab.path_report(reset=True)
+        zq = net(xt, lowres=True)
+        total, group, ce, mc = crit.weighted_lowres(zq, (H, W), tt, ts, tm, 16.0, 8.0, 1.0)
+        total.backward()
+        paths = deeplab.path_report(reset=True)
+        assert float(np.abs(zq.detach().cpu().numpy() - g['quarter%d' % step]).max()) <= (1e-4 if step == 1 else 3e-4)
+        got = np.array([float(total.detach()), float(ce), float(mc), float(group)], dtype=np.float32)
+        assert np.allclose(got, g['losses%d' % step], rtol=1e-4 if step == 1 else 1e-3, atol=0), (got, g['losses%d' % step])
+        if step == 1:
+            assert "train:fdw" in paths["conv_bn_act"] and "miopen+bn" not in paths["conv_bn_act"], paths
+            rel, worst = _compare_grads(g, net, 2e-3, 2e-2)
+        opt.step()
+        sched.step()
+        assert [pg['lr'] for pg in opt.param_groups] == list(g['lrs%d' % step])
+        wb = _compare_buffers(g, net, step, 1e-4)
+    # AdamW's first steps move every element by ~lr * sign(gradient): elements whose gradient is within rounding of zero may take
+    # the other sign, so the bar is on the update as a whole (relative L2 of p2 - p0 over all cuts) and, element-wise, on 2.2 lr.
+    num = den = 0.0
+    for i, (p, q) in enumerate(zip(net.parameters(), p0)):
+        ref_delta = g['param_%03d' % i].astype(np.float64) - sub256(q.cpu().numpy()).astype(np.float64)
+        got_delta = sub256(p.detach().cpu().numpy()).astype(np.float64) - sub256(q.cpu().numpy()).astype(np.float64)
+        num += float(((got_delta - ref_delta) ** 2).sum())
+        den += float((ref_delta ** 2).sum())
+        lr = float(g['lr']) * (float(g['cls_lr_scale']) if list(g['param_names'])[i].startswith('classifier') else 1.0)
+        assert float(np.abs(got_delta - ref_delta).max()) <= 2.2 * lr + 1e-7
+    assert (num / den) ** 0.5 <= 0.1, (num / den) ** 0.5
+    assert ops.conv_sk_error() == 0
+    print("G10 on the GPU: gradient cuts rel L2 %.2e, worst tensor-norm deviation %.2e (%s), running stats %.2e, update rel L2 %.2e"
+          % (rel, worst[0], worst[1], wb, (num / den) ** 0.5))
