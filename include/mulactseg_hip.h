@@ -386,6 +386,13 @@ int mas_cosine_head_fwd(const float* feat, const float* proxy_hat, int N, int Ch
 int mas_cosine_head_bwd(const float* feat, const float* proxy_hat, const float* logits, const float* inv_norm, const float* dlogits,
                         int N, int Ch, int K, int HW, float* dfeat, void* stream);
 
+/* The 1x1 convolution of the ASPP image-pooling branch on its 1 x 1 map (models/segmentation/deeplabv3.py:194-207:
+ * AdaptiveAvgPool2d(1) -> Conv2d(2048, 256, 1) -> BatchNorm -> ReLU) and its backward: y[n,m] = sum_k x[n,k] w[m,k] for a handful of
+ * rows (x [N,K], w [M,K] = the convolution weight, y [N,M]); dx [N,K] and / or dw [M,K] (NULL = not wanted) from dy [N,M].  Fixed
+ * summation order: run-to-run identical (vendor GEMMs pick atomic split-K solutions for this shape). */
+int mas_dense_small_fwd(const float* x, const float* w, int N, int K, int M, float* y, void* stream);
+int mas_dense_small_bwd(const float* dy, const float* x, const float* w, int N, int K, int M, float* dx, float* dw, void* stream);
+
 /* MaxPool2d(kernel 3, stride 2, padding 1) of x [NC,H,W] (models/segmentation/backbone/resnet.py:171,206):
  * y [NC,Ho,Wo] with Ho = (H - 1) / 2 + 1, and a one-byte arg-max offset (0..8 inside the window, first maximum) per
  * output; bwd: dx [NC,H,W] gathered from dy through `arg` in a fixed order (no atomics). */

@@ -67,6 +67,8 @@ SIGNATURES = {
     "mas_bn_act_train_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
     "mas_cosine_head_fwd": (_i, [_vp, _vp, _i, _i, _i, _i, _f, _vp, _vp, _vp]),
     "mas_cosine_head_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp]),
+    "mas_dense_small_fwd": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp]),
+    "mas_dense_small_bwd": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp]),
     "mas_maxpool3s2_fwd": (_i, [_vp, _i64, _i, _i, _vp, _vp, _vp]),
     "mas_maxpool3s2_bwd": (_i, [_vp, _vp, _i64, _i, _i, _vp, _vp]),
     "mas_conv1x1_fwd": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _i, _vp, _vp]),

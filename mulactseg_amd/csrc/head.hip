@@ -156,3 +156,58 @@ extern "C" int mas_cosine_head_bwd(const float* feat, const float* proxy_hat, co
         default: return launch_bwd<21>(feat, proxy_hat, logits, inv_norm, dlogits, N, Ch, HW, dfeat, st);
     }
 }
+
+// ---- the 1x1 convolution of the ASPP image-pooling branch on its 1 x 1 map (deeplabv3.py:194-207): a [N,K] x [K,M] product --------
+// N = batch (4), K = 2048, M = 256: 2 MFLOP.  Vendor GEMMs take split-K solutions with atomic adds for this shape (run-to-run
+// different low bits, which the BatchNorm over N samples that follows amplifies to 1e-4 of the logits); these three kernels add in
+// a fixed order.
+namespace {
+// y[n,m] = sum_k x[n,k] w[m,k]: one wave per output, lane l adds k = l, l + 64, ... then a fixed butterfly
+__global__ __launch_bounds__(256) void k_dense_fwd(const float* __restrict__ x, const float* __restrict__ w, int N, int K, int M, float* __restrict__ y) {
+    const int o = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (o >= N * M) return;
+    const int n = o / M, m = o - n * M;
+    const float* xr = x + (size_t)n * K;
+    const float* wr = w + (size_t)m * K;
+    float a = 0.0f;
+    for (int k = lane; k < K; k += 64) a = mas_fmaf(xr[k], wr[k], a);
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) a += __shfl_xor(a, off, 64);
+    if (lane == 0) y[o] = a;
+}
+// dx[n,k] = sum_m dy[n,m] w[m,k]: one thread per (n, k), m in order
+__global__ __launch_bounds__(256) void k_dense_bwd_x(const float* __restrict__ dy, const float* __restrict__ w, int N, int K, int M, float* __restrict__ dx) {
+    const int k = blockIdx.x * 256 + threadIdx.x, n = blockIdx.y;
+    if (k >= K) return;
+    float a = 0.0f;
+    for (int m = 0; m < M; ++m) a = mas_fmaf(dy[(size_t)n * M + m], w[(size_t)m * K + k], a);
+    dx[(size_t)n * K + k] = a;
+}
+// dw[m,k] = sum_n dy[n,m] x[n,k]: one thread per (m, k), n in order
+__global__ __launch_bounds__(256) void k_dense_bwd_w(const float* __restrict__ dy, const float* __restrict__ x, int N, int K, int M, float* __restrict__ dw) {
+    const int k = blockIdx.x * 256 + threadIdx.x, m = blockIdx.y;
+    if (k >= K) return;
+    float a = 0.0f;
+    for (int n = 0; n < N; ++n) a = mas_fmaf(dy[(size_t)n * M + m], x[(size_t)n * K + k], a);
+    dw[(size_t)m * K + k] = a;
+}
+int dense_check(int N, int K, int M) {
+    return (N <= 0 || K <= 0 || M <= 0 || N > 65535 || M > 65535 || (long long)N * M > 0x3fffffffLL) ? MAS_ERR_SHAPE : 0;
+}
+}  // namespace
+
+extern "C" int mas_dense_small_fwd(const float* x, const float* w, int N, int K, int M, float* y, void* stream) {
+    if (!x || !w || !y) return MAS_ERR_NULL;
+    if (int e = dense_check(N, K, M)) return e;
+    hipLaunchKernelGGL(k_dense_fwd, dim3((unsigned)((N * M + 3) / 4)), dim3(256), 0, static_cast<hipStream_t>(stream), x, w, N, K, M, y);
+    return mas_launch_status();
+}
+
+extern "C" int mas_dense_small_bwd(const float* dy, const float* x, const float* w, int N, int K, int M, float* dx, float* dw, void* stream) {
+    if (!dy || !x || !w) return MAS_ERR_NULL;
+    if (int e = dense_check(N, K, M)) return e;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (dx) hipLaunchKernelGGL(k_dense_bwd_x, dim3((unsigned)((K + 255) / 256), (unsigned)N), dim3(256), 0, st, dy, w, N, K, M, dx);
+    if (dw) hipLaunchKernelGGL(k_dense_bwd_w, dim3((unsigned)((K + 255) / 256), (unsigned)M), dim3(256), 0, st, dy, x, N, K, M, dw);
+    return mas_launch_status();
+}

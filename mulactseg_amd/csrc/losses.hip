@@ -231,7 +231,9 @@ __global__ __launch_bounds__(kThreads) void k_partial_loss_fwd(const float* __re
 #pragma unroll
             for (int c = 0; c < CT; ++c)
                 if (EXACT || c < C) pos = ((Y >> c) & 1u) ? (pos + v[c]) : pos;
-            const float l = -mas_logf(tce ? pos : pos + 1e-8f);
+            // (temperature CE: no epsilon; a target probability below the smallest normal float -- a logit gap beyond 86 / T, outside the
+            //  cosine head's range -- is held there, so neither the logarithm nor the backward's 1 / pos leaves the finite floats)
+            const float l = -mas_logf(tce ? (pos < 1.17549435e-38f ? 1.17549435e-38f : pos) : pos + 1e-8f);
             const mas_u64 q = mas_fix(l, MAS_LOSS_FRAC);
             if (nb == 1) { sum_ce += q; n_ce += 1; } else { sum_mc += q; n_mc += 1; }
         }
@@ -464,7 +466,7 @@ __global__ __launch_bounds__(kThreads) void k_partial_loss_bwd(const float* __re
 #pragma unroll
             for (int c = 0; c < CT; ++c)
                 if (EXACT || c < C) pos = ((Y >> c) & 1u) ? (pos + v[c]) : pos;
-            coef = ((nb == 1) ? a_ce : a_mc) * (1.0f / ((flags & MAS_LOSS_TCE) ? pos : pos + 1e-8f));
+            coef = ((nb == 1) ? a_ce : a_mc) * (1.0f / ((flags & MAS_LOSS_TCE) ? (pos < 1.17549435e-38f ? 1.17549435e-38f : pos) : pos + 1e-8f));
         }
         // group loss: classes of Y whose arg-max pixel is this pixel
         unsigned A = 0;

@@ -46,7 +46,11 @@ class RegionActiveDataset:
             if hasattr(mh, 'is_cuda'):          # a (device-resident) torch tensor
                 tab = mh.sum(dim=2).to(dtype=mh.dtype).cpu().numpy().astype(np.uint8)
             else:
-                tab = np.einsum('isc->is', np.asarray(mh), dtype=np.uint8)       # (2x faster than .sum(axis=2) over the short class axis)
+                a = np.asarray(mh)
+                if a.dtype == np.uint8:
+                    tab = np.einsum('isc->is', a, dtype=np.uint8)       # (2x faster than .sum(axis=2) over the short class axis)
+                else:                           # (einsum's 'safe' casting refuses int64 / float label arrays)
+                    tab = a.sum(axis=2, dtype=np.uint8)
             self._click_cost = (mh, np.ascontiguousarray(tab))
         return self._click_cost[1]
 

@@ -13,8 +13,8 @@ is depthwise(k, dilation, no bias) followed by pointwise 1x1 (no bias), with not
 
 On the GPU the dense convolutions run on this package's f32-MFMA kernels: at inference csrc/conv_mfma.hip with the BatchNorm,
 residual add and ReLU in its epilogue (no MIOpen kernel in a pool forward); in training the weight gradient of every dense
-convolution on csrc/conv_wgrad.hip and the forward / input gradient on csrc/conv_mfma.hip where ops.conv_train_plan selects
-them (path_report() says which products of which layer took which kernel).  The memory-bound layers around them take the HIP
+convolution on csrc/conv_wgrad.hip and the forward / input gradient on the persistent stream-K kernel csrc/conv_sk.hip where
+ops.conv_train_plan selects them (path_report() says which products of which layer took which kernel).  The memory-bound layers around them take the HIP
 kernels of this package too: BatchNorm + ReLU + residual add (csrc/bn.hip), every depthwise 3x3 (csrc/aspp.hip; the three ASPP
 dilations from one read of the feature map), the bilinear upsamplings (csrc/upsample.hip).  On the CPU the same modules run as
 plain PyTorch ops (parity tests against the executed reference, tests/test_model.py).
@@ -79,14 +79,20 @@ def _conv_bn_act(conv, bn, x, relu=True, residual=None, fork=False):
             return ops.stem_conv(conv, x, bn, relu)
         if (residual is None and x.shape[2] * x.shape[3] == 1 and conv.kernel_size == (1, 1) and conv.padding == (0, 0) and conv.groups == 1
                 and conv.bias is None and x.dtype == torch.float32):
-            # a 1x1 convolution of a 1x1 map (the ASPP image-pooling branch) is a [N,K] x [K,M] product: rocBLAS, no MIOpen
-            # solver search for every new batch size
-            _took("conv_bn_act", "gemm")
+            # a 1x1 convolution of a 1x1 map (the ASPP image-pooling branch) is a [N,K] x [K,M] product: the fixed-order kernel of
+            # csrc/head.hip (no vendor GEMM, no MIOpen solver search for every new batch size)
+            _took("conv_bn_act", "dense1x1")
             scale, shift = ops._bn_fold(bn)
-            y = torch.addmm(shift, x.flatten(1), (conv.weight.flatten(1) * scale[:, None]).t())
+            y = ops.conv1x1_on_1x1(conv, x)[:, :, 0, 0] * scale + shift
             return (F.relu(y) if relu else y)[:, :, None, None]
     if x.is_cuda and torch.is_grad_enabled():
         from .. import ops
+        if os.environ.get("MAS_TRAIN_CONV", "own") != "miopen" and ops.conv1x1_on_1x1_supported(conv, x):
+            # the ASPP image-pooling branch: 2 MFLOP; a fixed-order product (the vendor GEMM / MIOpen solvers for this shape use
+            # atomic split-K: run-to-run different bits, amplified by the BatchNorm over N samples behind it)
+            _took("conv_bn_act", "train:dense1x1")
+            out = _bn_act(bn, ops.conv1x1_on_1x1(conv, x), relu, residual)
+            return (out, x_other) if want_fork else out
         own = ops.conv_train_plan(conv, x)          # training: (forward, input gradient, weight gradient) on the f32-MFMA kernels
         if own is not None and any(own):
             _took("conv_bn_act", "train:" + "".join(n if o else "-" for n, o in zip("fdw", own)))

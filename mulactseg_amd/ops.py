@@ -789,6 +789,47 @@ def bn_act(bn, x, relu=True, residual=None, partials=None):
 
 
 # ------------------------------------------------------------------------------------------------
+# the 1x1 convolution of a 1x1 map (ASPP image-pooling branch): a fixed-order [N,K] x [K,M] product (csrc/head.hip)
+# ------------------------------------------------------------------------------------------------
+class _DenseSmall(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, w):
+        x, w = x.contiguous(), w.contiguous()
+        N, K = x.shape
+        M = w.shape[0]
+        y = torch.empty((N, M), dtype=torch.float32, device=x.device)
+        with torch.cuda.device(x.device):
+            _lib.check(_lib.load().mas_dense_small_fwd(x.data_ptr(), w.data_ptr(), N, K, M, y.data_ptr(), _stream(x)), "mas_dense_small_fwd")
+        ctx.save_for_backward(x, w)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w = ctx.saved_tensors
+        dy = dy.contiguous()
+        N, K = x.shape
+        M = w.shape[0]
+        dx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
+        dw = torch.empty_like(w) if ctx.needs_input_grad[1] else None
+        with torch.cuda.device(x.device):
+            _lib.check(_lib.load().mas_dense_small_bwd(dy.data_ptr(), x.data_ptr(), w.data_ptr(), N, K, M, _opt(dx), _opt(dw), _stream(x)),
+                       "mas_dense_small_bwd")
+        return dx, dw
+
+
+def conv1x1_on_1x1_supported(conv, x):
+    return (x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and x.shape[2] * x.shape[3] == 1 and conv.kernel_size == (1, 1)
+            and conv.padding == (0, 0) and conv.groups == 1 and conv.bias is None and x.shape[1] == conv.in_channels
+            and x.shape[0] * conv.out_channels <= 1 << 20)
+
+
+def conv1x1_on_1x1(conv, x):
+    """conv(x) for a 1x1 convolution of a 1x1 map [N,K,1,1] -> [N,M,1,1] with autograd, fixed summation order (mas_dense_small_*)."""
+    y = _DenseSmall.apply(x.flatten(1), conv.weight.flatten(1))
+    return y[:, :, None, None]
+
+
+# ------------------------------------------------------------------------------------------------
 # K8: cosine classifier (csrc/head.hip)
 # ------------------------------------------------------------------------------------------------
 class _CosineHead(torch.autograd.Function):
@@ -957,7 +998,13 @@ try:
     from torch.optim.optimizer import register_optimizer_step_post_hook as _reg_step_hook
     _reg_step_hook(_bump_param_epoch)
 except ImportError:                                     # pragma: no cover  (torch < 2.0)
+    # Without the hook nothing tells this module that a fused optimizer stepped: packed weights and folded BatchNorm constants
+    # would go stale after the first step and training would go on with wrong weights.  conv_train_plan then declines every layer
+    # (the nn.Module / MIOpen path needs no derived constants) and says why, once.
     _reg_step_hook = None
+    import warnings
+    warnings.warn("torch.optim has no register_optimizer_step_post_hook: the package's training convolutions are disabled "
+                  "(MIOpen is used); call ops.invalidate_parameter_caches() after every optimizer step to re-enable them by hand")
 
 
 def invalidate_parameter_caches():
@@ -1053,8 +1100,8 @@ def stem_conv(conv, x, bn=None, relu=False):
 
 
 # ------------------------------------------------------------------------------------------------
-# training-mode dense convolutions: forward, input gradient and weight gradient on the f32 matrix cores
-# (csrc/conv_mfma.hip, csrc/conv_wgrad.hip) -- no MIOpen, no NCHW <-> NHWC copies
+# training-mode dense convolutions: forward and input gradient on the persistent stream-K kernel (csrc/conv_sk.hip), weight
+# gradient on the split-K kernel (csrc/conv_wgrad.hip), all on the f32 matrix cores -- no MIOpen, no NCHW <-> NHWC copies
 # ------------------------------------------------------------------------------------------------
 _WGRAD_WS = {}
 
@@ -1090,29 +1137,6 @@ def conv_wgrad(x, dy, ksize, stride, dil):
     return dw
 
 
-def _pack_conv_weight(w):
-    """[M,K,kh,kw] -> the layout mas_conv_fwd reads (see _conv_packed_weight), M padded to 64 with zero rows."""
-    M, K, kh, kw = w.shape
-    ck = _lib.load().mas_conv_chunk(kh, K)
-    taps = kh * kw
-    if M % 64:
-        w = torch.cat([w, w.new_zeros((64 - M % 64, K, kh, kw))], dim=0)
-        M = w.shape[0]
-    w = w.reshape(M, K // ck, ck // 2, 2, taps)
-    w = w.permute(1, 4, 2, 3, 0).reshape(K // ck, taps * ck // 8, 4, 2, M).permute(0, 1, 3, 4, 2).contiguous()
-    return w
-
-
-def _conv_fwd_raw(x, wt, Cout, ksize, stride, dil):
-    N, K, H, W = x.shape
-    Ho, Wo = (H - 1) // stride + 1, (W - 1) // stride + 1
-    y = torch.empty((N, Cout, Ho, Wo), dtype=torch.float32, device=x.device)
-    with torch.cuda.device(x.device):
-        _lib.check(_lib.load().mas_conv_fwd(x.data_ptr(), wt.data_ptr(), N, K, H, W, Cout, ksize, stride, dil, None, None, None, 0,
-                                            y.data_ptr(), _stream(x)), "mas_conv_fwd")
-    return y
-
-
 _SK_WS = {}
 
 
@@ -1142,24 +1166,37 @@ def conv_sk_pack(w, stride=1, dgrad=False):
 class _PackRegistry:
     """Packed weight images of one device, re-packed together: the first use of a (weight, role) packs it alone; when a lookup
     finds a weight whose version counter or the process's parameter epoch moved (an optimizer stepped), ONE launch (mas_conv_sk_pack_multi) re-packs every
-    registered image -- the optimizer updates all of them together -- instead of two small launches per convolution and step."""
+    registered image -- the optimizer updates all of them together -- instead of two small launches per convolution and step.
+    Entries hold the weight WEAKLY: the active-learning loop builds a new trainer and model every round (reference train_AL.py:38),
+    and a registry that kept the old weights alive would pin every dead model's convolution weights and images in HBM and re-pack
+    them after every optimizer step.  An entry dies with its weight (finalizer), and dead entries never reach the job table."""
 
     def __init__(self, dev):
         self.dev = dev
-        self.entries = {}           # key -> [weight tensor (detached view: keeps storage and version counter), image, version]
+        self.entries = {}           # key -> [weakref to the weight, image, (version, parameter epoch)]
         self.table = None           # device copy of the job records
         self.nblocks = 0
+        self.njobs = 0
 
     @staticmethod
     def key(w, stride, dgrad):
         return (w.data_ptr(), w.untyped_storage()._cdata, tuple(w.shape), int(stride), int(dgrad))
 
+    def _drop(self, k):
+        self.entries.pop(k, None)
+        self.table = None           # (its records point into freed memory)
+
     def get(self, w, stride, dgrad):
+        import weakref
         k = self.key(w, stride, dgrad)
         e = self.entries.get(k)
+        if e is not None and e[0]() is None:        # the address was recycled by a new tensor before the finalizer ran
+            self._drop(k)
+            e = None
         if e is None:
             img = conv_sk_pack(w, stride, dgrad)
-            self.entries[k] = [w.detach(), img, (w._version, _PARAM_EPOCH[0])]
+            self.entries[k] = [weakref.ref(w), img, (w._version, _PARAM_EPOCH[0])]
+            weakref.finalize(w, self._drop, k)
             self.table = None
             return img
         if e[2] != (w._version, _PARAM_EPOCH[0]):
@@ -1169,24 +1206,31 @@ class _PackRegistry:
     def repack_all(self):
         import ctypes
         lib = _lib.load()
+        live = [(k, e, e[0]()) for k, e in list(self.entries.items())]
+        for k, e, w in live:
+            if w is None:
+                self._drop(k)
+        live = [(k, e, w) for k, e, w in live if w is not None]
+        if not live:
+            return
         if self.table is None:
             rec = int(lib.mas_conv_sk_pack_job_bytes())
-            host = ctypes.create_string_buffer(rec * len(self.entries))
+            host = ctypes.create_string_buffer(rec * len(live))
             base = ctypes.addressof(host)
             first = 0
-            for i, (k, e) in enumerate(self.entries.items()):
-                w = e[0]
+            for i, (k, e, w) in enumerate(live):
                 n = lib.mas_conv_sk_pack_job(base + i * rec, w.data_ptr(), w.shape[1], w.shape[0], w.shape[2], k[3], int(k[4]), e[1].data_ptr(), first)
                 if n == 0:
                     raise _lib.MulActSegHipError("mas_conv_sk_pack_job rejected %s" % (k,))
                 first += n
             self.table = torch.frombuffer(bytearray(host.raw), dtype=torch.uint8).to(self.dev)
             self.nblocks = first
+            self.njobs = len(live)
         with torch.cuda.device(self.dev):
-            _lib.check(lib.mas_conv_sk_pack_multi(self.table.data_ptr(), len(self.entries), self.nblocks,
+            _lib.check(lib.mas_conv_sk_pack_multi(self.table.data_ptr(), self.njobs, self.nblocks,
                                                   torch.cuda.current_stream(self.dev).cuda_stream), "mas_conv_sk_pack_multi")
-        for e in self.entries.values():
-            e[2] = (e[0]._version, _PARAM_EPOCH[0])
+        for k, e, w in live:
+            e[2] = (w._version, _PARAM_EPOCH[0])
 
 
 _PACKS = {}
@@ -1471,6 +1515,8 @@ def conv_train_plan(conv, x):
     still ahead on the 1x1 layers of the small planes: profiles/r03/b_conv_train_table_streamk.md; ~0.4 ms per step)."""
     mode = os.environ.get("MAS_TRAIN_CONV", "own")
     if mode == "miopen" or not conv_wgrad_supported(conv, x):
+        return None
+    if _reg_step_hook is None and _PARAM_EPOCH[0] == 0:     # (no optimizer hook and nobody invalidates by hand: see the import above)
         return None
     hw = x.shape[2] * x.shape[3]
     fwd_ok = conv.dilation[0] in (1, 2, 4) and hw >= 64

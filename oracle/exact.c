@@ -191,7 +191,7 @@ void exact_partial_loss_fwd(const float* z, const int64_t* spx, const uint8_t* m
                 float pos = 0.0f;
                 for (c = 0; c < C; ++c)
                     if ((Y >> c) & 1u) pos = pos + p[c];
-                const float l = -mas_logf((flags & LOSS_TCE) ? pos : pos + 1e-8f);
+                const float l = -mas_logf((flags & LOSS_TCE) ? (pos < 1.17549435e-38f ? 1.17549435e-38f : pos) : pos + 1e-8f);
                 const uint64_t q = mas_fix(l, MAS_LOSS_FRAC);
                 if (nb == 1) { acc[ACC_SUM_CE] += q; acc[ACC_N_CE] += 1; }
                 else { acc[ACC_SUM_MC] += q; acc[ACC_N_MC] += 1; }
@@ -292,7 +292,7 @@ void exact_partial_loss_bwd(const float* z, const int64_t* spx, const uint8_t* m
             if (flags & LOSS_CE) {
                 for (c = 0; c < C; ++c)
                     if ((Y >> c) & 1u) pos = pos + p[c];
-                coef = ((nb == 1) ? a_ce : a_mc) * (1.0f / ((flags & LOSS_TCE) ? pos : pos + 1e-8f));
+                coef = ((nb == 1) ? a_ce : a_mc) * (1.0f / ((flags & LOSS_TCE) ? (pos < 1.17549435e-38f ? 1.17549435e-38f : pos) : pos + 1e-8f));
             }
             uint32_t A = 0;
             float u = 0.0f;

