@@ -367,12 +367,6 @@ int64_t mas_bn_mask_bytes(int N, int C, int HW);
 int mas_bn_act_train_fwd(const float* x, const float* gamma, const float* beta, const float* residual, int N, int C, int HW, float eps,
                          float momentum, int relu, float* running_mean, float* running_var, int64_t* num_batches_tracked,
                          float* save_mean, float* save_invstd, void* workspace, float* y, uint8_t* relu_mask, void* stream);
-/* train_bwd for a gradient that arrives GATED (g = dz * [z > 0]) together with its partial sums (mas_sk_opts.bn_*: `per_channel` pairs
- * (sum g, sum g * xhat) per channel, doubles): dgamma / dbeta / the two means from the partials (fixed order), then ONE pass
- * dx = gamma * invstd * (g - mean(g) - xhat * mean(g * xhat)).  The gradient of the residual operand is g itself.  workspace: 8 C bytes. */
-int mas_bn_act_train_bwd_stats(const float* g, const float* x, const double* partials, int per_channel, const float* gamma,
-                               const float* save_mean, const float* save_invstd, int N, int C, int HW, void* workspace, float* dx,
-                               float* dgamma, float* dbeta, void* stream);
 /* train_fwd with the partial sums formed by the producer of x (mas_conv_sk_stats): partials [C][per_channel] pairs of doubles */
 int mas_bn_act_train_fwd_stats(const float* x, const double* partials, int per_channel, const float* gamma, const float* beta,
                                const float* residual, int N, int C, int HW, float eps, float momentum, int relu, float* running_mean,
@@ -457,20 +451,6 @@ typedef struct mas_sk_opts {
     unsigned spin_limit;    /* polls a finisher waits per contributor before it gives up; 0 = default */
     void* stamps;           /* tools: device buffer [512][4] uint64 of per-workgroup wall-clock stamps (100 MHz; start, pipeline
                              * primed, last tile done, end), indexed by the logical workgroup; NULL = off */
-    /* Input-gradient roles (dgrad = 1, mas_conv_sk_dgrad_s2): BatchNorm backward fused into the epilogue.  The launch's output is
-     * the gradient of z = relu(bn(u) + r), the convolution's input (backbone/resnet.py:143-160: the next convolution's input is the
-     * previous block's relu(bn(.))): with bn_u = u [N,C,H,W] (same shape as the output) the epilogue gates the gradient (+ residual)
-     * with z's ReLU mask (bn_mask: the byte-per-four-outputs mask mas_bn_act_train_fwd wrote; NULL = the BatchNorm has no ReLU),
-     * stores the GATED gradient g and writes per output channel the partial sums (sum g, sum g * (u - mean) * invstd) of every tile
-     * row: bn_part [C][bn_part_pitch] pairs of doubles, this launch's entries at [c][bn_part_offset .. + mas_conv_sk_bn_slots()).
-     * Consumer: mas_bn_act_train_bwd_stats -- the reduction pass of the BatchNorm backward over (dz, u) is gone, and the residual
-     * branch's gradient of z IS g (no second tensor written).  No scale / shift / relu / forward statistics in this mode. */
-    const float* bn_u;
-    const uint8_t* bn_mask;
-    const float* bn_mean;   /* [C] batch mean and 1 / sqrt(var + eps) saved by the BatchNorm's forward */
-    const float* bn_invstd;
-    double* bn_part;
-    int bn_part_pitch, bn_part_offset;
 } mas_sk_opts;
 size_t mas_conv_sk_workspace_bytes(void);
 size_t mas_conv_sk_packed_elems(int Cin, int Cout, int ksize, int stride, int dgrad);
@@ -487,7 +467,6 @@ int mas_conv_sk(const float* x, const float* wp, int N, int Cin, int H, int W, i
                 const float* scale, const float* shift, const float* residual, int relu, float* y, void* workspace,
                 size_t workspace_bytes, unsigned epoch, const mas_sk_opts* opts, void* stream);
 int mas_conv_sk_error(const void* workspace, unsigned* out_host);
-int mas_conv_sk_bn_slots(int N, int Cin, int H, int W, int Cout, int ksize, int stride, int dil, int sub, unsigned flags);
 /* mas_conv_sk in the forward role without epilogue that also forms the BatchNorm partial sums of its output in the epilogue of
  * every tile (the relu(bn(conv(x))) triples of backbone/resnet.py:143-160 in training mode: removes the reduction pass over y):
  * stats [Cout][mas_conv_sk_stats_slots(...)] pairs of doubles (sum y, sum y^2) over disjoint pixel sets, every entry written;

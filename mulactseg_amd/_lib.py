@@ -24,9 +24,7 @@ _vp, _i, _f, _i64, _d = _c.c_void_p, _c.c_int, _c.c_float, _c.c_int64, _c.c_doub
 
 class SkOpts(ctypes.Structure):
     """mas_sk_opts of include/mulactseg_hip.h: the per-call options of the stream-K convolution."""
-    _fields_ = [("flags", _c.c_uint), ("spin_limit", _c.c_uint), ("stamps", _c.c_void_p),
-                ("bn_u", _c.c_void_p), ("bn_mask", _c.c_void_p), ("bn_mean", _c.c_void_p), ("bn_invstd", _c.c_void_p),
-                ("bn_part", _c.c_void_p), ("bn_part_pitch", _c.c_int), ("bn_part_offset", _c.c_int)]
+    _fields_ = [("flags", _c.c_uint), ("spin_limit", _c.c_uint), ("stamps", _c.c_void_p)]
 
 
 # name -> (restype, argtypes); mirrors include/mulactseg_hip.h one to one
@@ -65,7 +63,6 @@ SIGNATURES = {
     "mas_bn_mask_bytes": (_i64, [_i, _i, _i]),
     "mas_bn_act_train_fwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _f, _f, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "mas_bn_act_train_fwd_stats": (_i, [_vp, _vp, _i, _vp, _vp, _vp, _i, _i, _i, _f, _f, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
-    "mas_bn_act_train_bwd_stats": (_i, [_vp, _vp, _vp, _i, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp]),
     "mas_bn_act_eval_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _f, _i, _vp, _vp]),
     "mas_bn_act_train_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
     "mas_cosine_head_fwd": (_i, [_vp, _vp, _i, _i, _i, _i, _f, _vp, _vp, _vp]),
@@ -87,7 +84,6 @@ SIGNATURES = {
     "mas_conv_sk": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _i, _vp, _vp, _c.c_size_t, _c.c_uint, _vp, _vp]),
     "mas_conv_sk_error": (_i, [_vp, _vp]),
     "mas_conv_sk_stats_slots": (_i, [_i, _i, _i, _i, _i, _i, _i, _i, _c.c_uint]),
-    "mas_conv_sk_bn_slots": (_i, [_i, _i, _i, _i, _i, _i, _i, _i, _i, _c.c_uint]),
     "mas_conv_sk_stats": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _c.c_size_t, _c.c_uint, _vp, _vp]),
     "mas_conv_sk_dgrad_s2": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _i, _vp, _vp, _c.c_size_t, _c.c_uint, _vp, _vp]),
     "mas_test_occupy": (_i, [_i, _i, _c.c_ulonglong, _vp]),

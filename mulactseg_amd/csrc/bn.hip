@@ -208,21 +208,6 @@ __global__ __launch_bounds__(kThreads) void k_bn_bwd_stats(const double2* __rest
     coef[c] = make_float2((float)(S / count), (float)(Q / count));
 }
 
-// the same from MANY partials per channel (the epilogue partials of the input-gradient kernel): one workgroup per channel
-__global__ __launch_bounds__(kThreads) void k_bn_bwd_stats_wide(const double2* __restrict__ part, int C, int per_channel, double count,
-                                                                 float* __restrict__ dgamma, float* __restrict__ dbeta, float2* __restrict__ coef) {
-    __shared__ double s_red[kThreads / MAS_WAVE];
-    const int c = blockIdx.x;
-    double S = 0.0, Q = 0.0;
-    for (int i = threadIdx.x; i < per_channel; i += kThreads) { const double2 v = part[(size_t)c * per_channel + i]; S += v.x; Q += v.y; }
-    S = block_sum(S, s_red);
-    Q = block_sum(Q, s_red);
-    if (threadIdx.x != 0) return;
-    if (dbeta) dbeta[c] = (float)S;
-    if (dgamma) dgamma[c] = (float)Q;
-    coef[c] = make_float2((float)(S / count), (float)(Q / count));
-}
-
 template <bool VEC>
 __global__ __launch_bounds__(kThreads) void k_bn_bwd_apply(const float* __restrict__ dy, const float* __restrict__ x, const float* __restrict__ y,
                                                             const unsigned char* __restrict__ mask, int mask_stride, const float* __restrict__ gamma,
@@ -357,23 +342,5 @@ extern "C" int mas_bn_act_train_bwd(const float* dy, const float* x, const float
                                 save_invstd, coef, C, HW, relu, dx, dresidual);
     else hipLaunchKernelGGL(k_bn_bwd_apply<false>, apply_grid(N, C, HW), dim3(kThreads), 0, st, dy, x, y, relu_mask, ms, gamma, save_mean,
                             save_invstd, coef, C, HW, relu, dx, dresidual);
-    return mas_launch_status();
-}
-
-extern "C" int mas_bn_act_train_bwd_stats(const float* g, const float* x, const double* partials, int per_channel, const float* gamma,
-                                          const float* save_mean, const float* save_invstd, int N, int C, int HW, void* workspace, float* dx,
-                                          float* dgamma, float* dbeta, void* stream) {
-    if (!g || !x || !partials || !save_mean || !save_invstd || !workspace || !dx) return MAS_ERR_NULL;
-    if (per_channel <= 0) return MAS_ERR_SHAPE;
-    if (int e = check(N, C, HW)) return e;
-    hipStream_t st = static_cast<hipStream_t>(stream);
-    float2* coef = static_cast<float2*>(workspace);
-    const bool vec = congruent(x, g) && congruent(x, dx) && ((uintptr_t)x & 3) == 0;
-    hipLaunchKernelGGL(k_bn_bwd_stats_wide, dim3((unsigned)C), dim3(kThreads), 0, st, reinterpret_cast<const double2*>(partials), C, per_channel,
-                       (double)N * (double)HW, dgamma, dbeta, coef);
-    if (vec) hipLaunchKernelGGL(k_bn_bwd_apply<true>, apply_grid(N, C, HW), dim3(kThreads), 0, st, g, x, nullptr, nullptr, 0, gamma, save_mean,
-                                save_invstd, coef, C, HW, 0, dx, nullptr);
-    else hipLaunchKernelGGL(k_bn_bwd_apply<false>, apply_grid(N, C, HW), dim3(kThreads), 0, st, g, x, nullptr, nullptr, 0, gamma, save_mean,
-                            save_invstd, coef, C, HW, 0, dx, nullptr);
     return mas_launch_status();
 }

@@ -58,15 +58,6 @@ struct SkP {
     long long xstep;            // floats from a chunk's first channel to the next chunk's (CK * H * W)
     int P;                      // workgroups (one per CU)
     int rdp, sk_iters;          // whole tiles per workgroup (rounds of P tiles), iterations of the remaining tiles (stream-K part)
-    // BatchNorm backward fused into the epilogue of the input-gradient role (mas_sk_opts.bn_*): the output is the gradient of
-    // z = relu(bn(u) + residual); the epilogue gates it with z's ReLU mask, stores the GATED gradient g and forms the partial sums
-    // (sum g, sum g * uhat) of the tile rows into `stats` -- the reduction pass of the BatchNorm backward over (dz, u) is gone
-    const float* bn_u;          // [N, M, HWy]: the BatchNorm's input (same geometry as y), NULL = off
-    const unsigned char* bn_mask;   // one byte per aligned 16-byte group of a plane of u (k_bn_apply), NULL = no ReLU
-    const float* bn_mean;
-    const float* bn_invstd;
-    int bn_mask_stride;
-    int stats_pitch, stats_off; // entry of (row m, pixel tile pt, group ng): stats[m * stats_pitch + stats_off + pt * NG + ng]
     int nosplit;                // MAS_SK_NOSPLIT: the remaining tiles go WHOLE to the first workgroups (no hand-off at all)
     unsigned spin_limit;        // polls a finisher waits for one contributor before it gives up
 };
@@ -774,13 +765,8 @@ __global__ __launch_bounds__(kSkThreads) void k_conv_sk(const SkP p) {
         tile_parity ^= 1;
         if (tid < BM) {
             const bool real = m0 + tid < p.M;
-            if (p.bn_u) {           // (the host admits no scale / shift in this mode: the slots carry the BatchNorm's mean and 1 / std)
-                sE[tid] = real ? p.bn_mean[m0 + tid] : 0.0f;
-                sE[BM + tid] = real ? p.bn_invstd[m0 + tid] : 0.0f;
-            } else {
-                sE[tid] = (p.scale && real) ? p.scale[m0 + tid] : 1.0f;
-                sE[BM + tid] = (p.scale && real) ? p.shift[m0 + tid] : 0.0f;
-            }
+            sE[tid] = (p.scale && real) ? p.scale[m0 + tid] : 1.0f;
+            sE[BM + tid] = (p.scale && real) ? p.shift[m0 + tid] : 0.0f;
         }
 #pragma unroll
         for (int tn = 0; tn < TN; ++tn)
@@ -859,14 +845,6 @@ __global__ __launch_bounds__(kSkThreads) void k_conv_sk(const SkP p) {
         const float* rb = p.res ? p.res + ((size_t)n * p.M + m0) * HWo : nullptr;
         const float lo = p.relu ? 0.0f : -INFINITY;
         const int mlim = p.M - m0;
-        const bool bn = p.bn_u != nullptr;
-        float ssum[16], ssq[16];            // per accumulator row of this lane: the two statistics over its pixels
-#pragma unroll
-        for (int r = 0; r < 16; ++r) ssum[r] = ssq[r] = 0.0f;
-        const float* ub = bn ? p.bn_u + ((size_t)n * p.M + m0) * HWo : nullptr;
-        // ReLU mask of the BatchNorm (k_bn_apply): byte ((a + pixel) >> 2) of the plane's row of bytes, bit (a + pixel) & 3, with a =
-        // the misalignment (in floats) of the plane of u in memory
-        const unsigned a0 = bn ? (unsigned)((reinterpret_cast<uintptr_t>(p.bn_u) >> 2) & 3u) : 0u;
 #pragma unroll
         for (int tn = 0; tn < TN; ++tn) {
             const int oy = oy0 + (pl[tn] >> G::TWLOG), ox = ox0 + (pl[tn] & (TW - 1));
@@ -881,33 +859,7 @@ __global__ __launch_bounds__(kSkThreads) void k_conv_sk(const SkP p) {
                     rv[r] = rb[(size_t)(m < mlim ? m : 0) * HWo + po];
                 }
             }
-            if (bn) {
-                float uv[16];
-                unsigned keep = 0xffffu;
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int m = mb + (r & 3) + 8 * (r >> 2), mm = m < mlim ? m : 0;
-                    uv[r] = ub[(size_t)mm * HWo + po];
-                    if (p.bn_mask) {
-                        const size_t plane = (size_t)n * p.M + m0 + mm;
-                        const unsigned e = ((a0 + (unsigned)((plane * (size_t)HWo) & 3u)) & 3u) + (unsigned)po;
-                        const unsigned byte = p.bn_mask[plane * (size_t)p.bn_mask_stride + (e >> 2)];
-                        keep = ((byte >> (e & 3u)) & 1u) ? keep : (keep & ~(1u << r));
-                    }
-                }
-                if (inside) {
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const int m = mb + (r & 3) + 8 * (r >> 2);
-                        float v = acc[tn][r];
-                        if (rb) v += rv[r];
-                        v = ((keep >> r) & 1u) ? v : 0.0f;
-                        if (m < mlim) yb[(size_t)m * HWo + po] = v;
-                        ssum[r] += v;
-                        ssq[r] += v * ((uv[r] - sE[m]) * sE[BM + m]);
-                    }
-                }
-            } else if (inside) {
+            if (inside) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int m = mb + (r & 3) + 8 * (r >> 2);
@@ -915,14 +867,25 @@ __global__ __launch_bounds__(kSkThreads) void k_conv_sk(const SkP p) {
                     if (rb) v += rv[r];
                     v = v < lo ? lo : v;
                     if (m < mlim) yb[(size_t)m * HWo + po] = v;
-                    if (p.stats) {      // (the host admits forward statistics only for the bare product: y = acc)
+                }
+            }
+        }
+        if (p.stats) {
+            // (the host admits statistics only for the bare product: y = acc)
+            float ssum[16], ssq[16];            // per accumulator row of this lane: sum and sum of squares over its pixels
+#pragma unroll
+            for (int r = 0; r < 16; ++r) ssum[r] = ssq[r] = 0.0f;
+#pragma unroll
+            for (int tn = 0; tn < TN; ++tn) {
+                const int oy = oy0 + (pl[tn] >> G::TWLOG), ox = ox0 + (pl[tn] & (TW - 1));
+                if (oy < p.Ho && ox < p.Wo) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
                         ssum[r] += acc[tn][r];
                         ssq[r] += acc[tn][r] * acc[tn][r];
                     }
                 }
             }
-        }
-        if (p.stats) {
             // BatchNorm partials of the tile: the 32 lanes of a half-wave hold the same 16 rows; a halving butterfly (lane bit k
             // keeps one half of the rows and receives the partner's sums of them: 8 + 4 + 2 + 1 exchanges, then one across the two
             // 16-lane groups) leaves row 8 b0 + 4 b1 + 2 b2 + b3 of the lane's bits with the sum over all 32 pixels columns --
@@ -956,8 +919,7 @@ __global__ __launch_bounds__(kSkThreads) void k_conv_sk(const SkP p) {
             const float S = fold(ssum), Q = fold(ssq);
             const int r = 8 * (lane & 1) + 4 * ((lane >> 1) & 1) + 2 * ((lane >> 2) & 1) + ((lane >> 3) & 1);
             const int m = mtw * 32 + 4 * h + (r & 3) + 8 * (r >> 2);
-            if (!(lane & 16) && m < mlim)
-                p.stats[(size_t)(m0 + m) * p.stats_pitch + p.stats_off + (size_t)pt * NG + ng] = make_double2((double)S, (double)Q);
+            if (!(lane & 16) && m < mlim) p.stats[((size_t)(m0 + m) * p.ptiles + pt) * NG + ng] = make_double2((double)S, (double)Q);
         }
         if (p.stamps && tid == 0 && it >= it1) p.stamps[4 * g + 2] = wall_clock64();
     }
@@ -1068,12 +1030,6 @@ struct SkOpts {
     bool dma, nosplit;
     unsigned spin_limit;
     unsigned long long* stamps;
-    const float* bn_u;
-    const unsigned char* bn_mask;
-    const float* bn_mean;
-    const float* bn_invstd;
-    double2* bn_part;
-    int bn_pitch, bn_off;
 };
 inline SkOpts sk_opts(const mas_sk_opts* o) {
     SkOpts r;
@@ -1081,13 +1037,6 @@ inline SkOpts sk_opts(const mas_sk_opts* o) {
     r.nosplit = o && (o->flags & MAS_SK_NOSPLIT);
     r.spin_limit = (o && o->spin_limit) ? o->spin_limit : kSkSpinLimit;
     r.stamps = o ? static_cast<unsigned long long*>(o->stamps) : nullptr;
-    r.bn_u = o ? o->bn_u : nullptr;
-    r.bn_mask = o ? o->bn_mask : nullptr;
-    r.bn_mean = o ? o->bn_mean : nullptr;
-    r.bn_invstd = o ? o->bn_invstd : nullptr;
-    r.bn_part = o ? reinterpret_cast<double2*>(o->bn_part) : nullptr;
-    r.bn_pitch = o ? o->bn_part_pitch : 0;
-    r.bn_off = o ? o->bn_part_offset : 0;
     return r;
 }
 
@@ -1146,21 +1095,6 @@ inline int sk_plan(SkP& p, const SkGeom& g, int N, int cus, const SkOpts& o) {
     const int ntiles = p.ptiles * p.mtiles;
     p.rdp = ntiles / p.P;
     p.sk_iters = (ntiles - p.rdp * p.P) * p.nch;
-    const int NG = g.BM == 128 ? 2 : 4;
-    p.bn_u = nullptr; p.bn_mask = nullptr; p.bn_mean = nullptr; p.bn_invstd = nullptr; p.bn_mask_stride = 0;
-    p.stats_pitch = p.ptiles * NG;
-    p.stats_off = 0;
-    if (o.bn_u) {
-        // fused BatchNorm backward: input-gradient roles only (the caller checked), bare epilogue besides the residual
-        if (!o.bn_mean || !o.bn_invstd || !o.bn_part) return MAS_ERR_NULL;
-        if (p.scale || p.relu || p.stats) return MAS_ERR_RANGE;
-        if (o.bn_pitch < o.bn_off + p.ptiles * NG || o.bn_off < 0) return MAS_ERR_SHAPE;
-        p.bn_u = o.bn_u; p.bn_mask = o.bn_mask; p.bn_mean = o.bn_mean; p.bn_invstd = o.bn_invstd;
-        p.bn_mask_stride = (p.HWy + 3) / 4 + 1;           // mas_bn_mask_bytes: max_groups(HW) bytes per plane
-        p.stats = o.bn_part;
-        p.stats_pitch = o.bn_pitch;
-        p.stats_off = o.bn_off;
-    }
     return 0;
 }
 
@@ -1239,7 +1173,6 @@ int sk_run(const float* x, const float* w, int N, int Cin, int H, int W, int Cou
     if (ksize == 1 && dil != 1) return MAS_ERR_RANGE;
     if (dgrad && stride != 1) return MAS_ERR_RANGE;
     if (stride == 2 && dil != 1) return MAS_ERR_RANGE;
-    if (o.bn_u && !dgrad) return MAS_ERR_RANGE;            // the fused BatchNorm backward belongs to the input-gradient role
     if (epoch == 0) return MAS_ERR_RANGE;
     if (workspace_bytes < mas_conv_sk_workspace_bytes()) return MAS_ERR_WORKSPACE;
     if ((long long)(Cin > Cout ? Cin : Cout) * H * W > 0x7fffffffLL) return MAS_ERR_SHAPE;
@@ -1335,29 +1268,6 @@ extern "C" int mas_conv_sk_stats_slots(int N, int Cin, int H, int W, int Cout, i
     SkGeom g;
     sk_geom(ksize, stride, Cout, Ho, Wo, 0, &g);
     if (flat) { g.TW = 128; g.TH = 1; }
-    const long long pt = (long long)N * ((Wo + g.TW - 1) / g.TW) * ((Ho + g.TH - 1) / g.TH) * (g.BM == 128 ? 2 : 4);
-    return pt > 0x7fffffffLL ? 0 : (int)pt;
-}
-
-/* Entries per channel of dX that one input-gradient launch with the fused BatchNorm backward (mas_sk_opts.bn_*) writes: the stride-1
- * gradient of a ksize x ksize convolution (stride 1, sub ignored) or parity class `sub` of the 3x3 stride-2 gradient (stride 2);
- * x = the convolution's input [N,Cin,H,W].  0: unsupported. */
-extern "C" int mas_conv_sk_bn_slots(int N, int Cin, int H, int W, int Cout, int ksize, int stride, int dil, int sub, unsigned flags) {
-    if (N <= 0 || Cin <= 0 || H <= 0 || W <= 0 || Cout <= 0 || (ksize != 1 && ksize != 3) || (stride != 1 && stride != 2)) return 0;
-    const bool dma = (flags & MAS_SK_DMA) != 0;
-    SkGeom g;
-    int Ho = H, Wo = W;
-    if (stride == 1) {
-        const bool flat = !dma && (ksize == 1 || sk_linear_class(ksize, 1, dil, H, W) != 0);
-        if (flat) { Wo = H * W; Ho = 1; }
-        sk_geom(ksize, 1, Cin, Ho, Wo, 1, &g);
-        if (flat) { g.TW = 128; g.TH = 1; }
-    } else {
-        if (ksize != 3 || sub < 0 || sub > 3) return 0;
-        Ho = (H - (sub >> 1) + 1) / 2; Wo = (W - (sub & 1) + 1) / 2;
-        if (Ho == 0 || Wo == 0) return 0;
-        sk_geom(3, 2, Cin, Ho, Wo, 2 + sub, &g);
-    }
     const long long pt = (long long)N * ((Wo + g.TW - 1) / g.TW) * ((Ho + g.TH - 1) / g.TH) * (g.BM == 128 ? 2 : 4);
     return pt > 0x7fffffffLL ? 0 : (int)pt;
 }

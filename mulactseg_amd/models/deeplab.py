@@ -100,9 +100,7 @@ def _conv_bn_act(conv, bn, x, relu=True, residual=None, fork=False):
             # fork: the gradient of x's other consumer is added in the epilogue of this convolution's input-gradient kernel
             stats = own[0] and bn.training and os.environ.get("MAS_BN_STATS", "fused") == "fused"
             fork = fork and own[1] and conv.stride[0] == 1 and x.requires_grad and os.environ.get("MAS_GRAD_FORK", "fused") == "fused"
-            # x = relu(bn(u) + r) of the previous layer: that BatchNorm's backward reduction rides in this convolution's
-            # input-gradient epilogue (ops._BNLink)
-            res = ops.conv_train(conv, x, own, stats=stats, fork=fork, bn_link=getattr(x, '_mas_bn_link', None))
+            res = ops.conv_train(conv, x, own, stats=stats, fork=fork)
             y, part = (res[0], res[1]) if (stats or fork) else (res, None)
             if fork:
                 x_other = res[2]
@@ -232,11 +230,7 @@ class DeepStemResNetTrunk(nn.Module):
         else:
             x = self.maxpool(x)
         low = self.layer1(x)
-        if hasattr(low, '_mas_bn_link'):
-            del low._mas_bn_link        # `low` has two consumers outside one convolution (layer2 and the decoder): see ops._BNLink
         out = self.layer4(self.layer3(self.layer2(low)))
-        if hasattr(out, '_mas_bn_link'):
-            del out._mas_bn_link        # five consumers (the ASPP branches)
         return OrderedDict(low_level=low, out=out)
 
 

@@ -694,30 +694,9 @@ def _opt(t):
     return t.data_ptr() if t is not None else None
 
 
-class _BNLink:
-    """What the CONSUMER of z = relu(bn(u) + r) needs to fold this BatchNorm's backward reduction into the epilogue of its own
-    input-gradient kernel (mas_sk_opts.bn_*), and what it hands back: the gated gradient g it stored and the partial sums.  The
-    BatchNorm's backward takes the short path only if the gradient it receives IS that tensor, untouched (same storage, same
-    version counter): any other consumer of z makes autograd add its gradient in (a new tensor, or an in-place add that bumps the
-    version), and the long path -- which gates again, harmlessly: gating is idempotent and linear -- runs instead."""
-    __slots__ = ("u", "mask", "mean", "invstd", "g", "g_version", "partials", "claimed")
-
-    def __init__(self):
-        self.u = self.mask = self.mean = self.invstd = self.g = self.partials = None
-        self.g_version = -1
-        self.claimed = False
-
-    def take(self, g, partials):
-        self.g, self.g_version, self.partials = g, g._version, partials
-
-    def matches(self, dy):
-        return (self.partials is not None and self.g is not None and dy.data_ptr() == self.g.data_ptr() and dy._version == self.g_version
-                and dy.shape == self.u.shape and dy.is_contiguous())
-
-
 class _BNActTrain(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, weight, bias, residual, running_mean, running_var, num_batches_tracked, eps, momentum, relu, partials=None, link=None):
+    def forward(ctx, x, weight, bias, residual, running_mean, running_var, num_batches_tracked, eps, momentum, relu, partials=None):
         x = x.contiguous()
         N, C, H, W = x.shape
         HW = H * W
@@ -753,9 +732,6 @@ class _BNActTrain(torch.autograd.Function):
         ctx.save_for_backward(x, y if mask is None else None, weight, mean, invstd, mask)
         ctx.relu = bool(relu)
         ctx.has_res = residual is not None
-        ctx.link = link
-        if link is not None:
-            link.u, link.mask, link.mean, link.invstd = x, mask, mean, invstd
         return y
 
     @staticmethod
@@ -764,26 +740,8 @@ class _BNActTrain(torch.autograd.Function):
         N, C, H, W = x.shape
         HW = H * W
         dev = x.device
-        lib = _lib.load()
-        link = ctx.link
-        if link is not None and link.matches(dy):
-            # dy is the GATED gradient g written by the input-gradient kernel of z's consumer, and its (sum g, sum g * xhat) partial
-            # sums came out of that kernel's epilogue: statistics + ONE pass; the residual operand's gradient is g itself
-            part = link.partials
-            link.g = link.partials = None
-            dx = torch.empty_like(x)
-            dg = torch.empty(C, dtype=torch.float32, device=dev) if (weight is not None and ctx.needs_input_grad[1]) else None
-            db = torch.empty(C, dtype=torch.float32, device=dev) if ctx.needs_input_grad[2] else None
-            ws = torch.empty(8 * C, dtype=torch.uint8, device=dev)
-            with torch.cuda.device(dev):
-                _lib.check(lib.mas_bn_act_train_bwd_stats(dy.data_ptr(), x.data_ptr(), part.data_ptr(), int(part.shape[1]), _opt(weight),
-                                                          mean.data_ptr(), invstd.data_ptr(), N, C, HW, ws.data_ptr(), dx.data_ptr(), _opt(dg),
-                                                          _opt(db), _stream(x)), "mas_bn_act_train_bwd_stats")
-            dres = dy if (ctx.has_res and ctx.needs_input_grad[3]) else None
-            return dx, dg, db, dres, None, None, None, None, None, None, None, None
-        if link is not None:
-            link.g = link.partials = None
         dy = dy.contiguous()
+        lib = _lib.load()
         ws = torch.empty(int(lib.mas_bn_workspace_bytes(N, C, HW)), dtype=torch.uint8, device=dev)
         dx = torch.empty_like(x)
         dres = torch.empty_like(x) if (ctx.has_res and ctx.needs_input_grad[3]) else None
@@ -795,7 +753,7 @@ class _BNActTrain(torch.autograd.Function):
                                                 _stream(x)), "mas_bn_act_train_bwd")
         if ctx.has_res and dres is None and ctx.needs_input_grad[3]:
             dres = dy
-        return dx, dg, db, dres, None, None, None, None, None, None, None, None
+        return dx, dg, db, dres, None, None, None, None, None, None, None
 
 
 def bn_act_supported(bn, x, residual=None):
@@ -818,11 +776,7 @@ def bn_act(bn, x, relu=True, residual=None, partials=None):
     per-channel partial sums of x that conv_train(..., stats=True) returns beside x."""
     if bn.training:
         rm, rv, nbt = (bn.running_mean, bn.running_var, bn.num_batches_tracked) if bn.track_running_stats else (None, None, None)
-        link = _BNLink() if (torch.is_grad_enabled() and os.environ.get("MAS_BN_BWD", "fused") == "fused") else None
-        out = _BNActTrain.apply(x, bn.weight, bn.bias, residual, rm, rv, nbt, bn.eps, bn.momentum, relu, partials, link)
-        if link is not None and link.u is not None:
-            out._mas_bn_link = link         # picked up by the convolution that consumes `out` (models/deeplab.py:_conv_bn_act)
-        return out
+        return _BNActTrain.apply(x, bn.weight, bn.bias, residual, rm, rv, nbt, bn.eps, bn.momentum, relu, partials)
     x = x.contiguous()
     N, C, H, W = x.shape
     res = residual.contiguous() if residual is not None else None
@@ -1304,14 +1258,11 @@ def _sk_opts(flags=None, spin_limit=0, stamps=None):
 
 
 def conv_sk(x, w, stride=1, dil=1, dgrad=False, scale=None, shift=None, residual=None, relu=False, packed=None, stats=False,
-            flags=None, spin_limit=0, stamps=None, bn=None):
+            flags=None, spin_limit=0, stamps=None):
     """Training-mode dense convolution on the persistent stream-K MFMA kernel (mas_conv_sk), weight `w` [Cout,Cin,k,k] as PyTorch
     stores it (``packed``: its conv_sk_pack image for this role, when the caller keeps one).  dgrad=False: y = conv2d(x, w, stride, padding = dil (k 3) / 0 (k 1), dilation); dgrad=True: x is dY [N,Cout,H,W] and
     the result is dX [N,Cin,H,W] of the stride-1 convolution.  Optional epilogue y*scale[m] + shift[m] + residual, ReLU.
-    ``flags`` (_lib.SK_DMA | _lib.SK_NOSPLIT), ``spin_limit``, ``stamps``: the per-call mas_sk_opts.
-    ``bn`` (dgrad only): a _BNLink (or anything with .u / .mask / .mean / .invstd) of the BatchNorm whose output z = relu(bn(u) + r)
-    the convolution consumed: the result is then (g, partials) -- the gradient of z gated with z's ReLU mask and the
-    [Cin, slots, 2] float64 partial sums (sum g, sum g * uhat) for mas_bn_act_train_bwd_stats."""
+    ``flags`` (_lib.SK_DMA | _lib.SK_NOSPLIT), ``spin_limit``, ``stamps``: the per-call mas_sk_opts."""
     _need(x, "x", torch.float32)
     _need(w, "w", torch.float32)
     Cout, Cin, ks, _ = w.shape
@@ -1335,22 +1286,6 @@ def conv_sk(x, w, stride=1, dil=1, dgrad=False, scale=None, shift=None, residual
     ws, epoch = _sk_workspace(x.device)
     lib = _lib.load()
     opts, flags = _sk_opts(flags, spin_limit, stamps)
-    if bn is not None:
-        if not dgrad or stats or scale is not None or relu:
-            raise ValueError("bn=: input-gradient role with a bare epilogue only")
-        if tuple(bn.u.shape) != tuple(y.shape):
-            raise ValueError("bn.u %s does not match the gradient %s" % (tuple(bn.u.shape), tuple(y.shape)))
-        slots = int(lib.mas_conv_sk_bn_slots(N, Cin, H, W, Cout, ks, 1, dil, 0, flags))
-        if slots <= 0:
-            raise ValueError("unsupported geometry for the fused BatchNorm backward")
-        part = torch.empty((M, slots, 2), dtype=torch.float64, device=x.device)
-        import ctypes
-        o = _lib.SkOpts(flags, int(spin_limit), stamps.data_ptr() if stamps is not None else None, bn.u.data_ptr(), _opt(bn.mask),
-                        bn.mean.data_ptr(), bn.invstd.data_ptr(), part.data_ptr(), slots, 0)
-        with torch.cuda.device(x.device):
-            _lib.check(lib.mas_conv_sk(x.data_ptr(), packed.data_ptr(), N, Cin, H, W, Cout, ks, stride, dil, 1, None, None, _opt(residual), 0,
-                                       y.data_ptr(), ws.data_ptr(), ws.numel(), epoch, ctypes.byref(o), _stream(x)), "mas_conv_sk")
-        return y, part
     if stats:
         # forward without epilogue + the BatchNorm partial sums of y from the epilogue of every tile: (y, partials [Cout, slots, 2] f64)
         if dgrad or scale is not None or residual is not None or relu:
@@ -1370,7 +1305,7 @@ def conv_sk(x, w, stride=1, dil=1, dgrad=False, scale=None, shift=None, residual
     return y
 
 
-def conv_sk_dgrad_s2(dy, w, H, W, packed=None, flags=None, spin_limit=0, bn=None):
+def conv_sk_dgrad_s2(dy, w, H, W, packed=None, flags=None, spin_limit=0):
     """dX [N,Cin,H,W] of y = conv2d(x, w, stride 2, padding 1) for a 3x3 weight `w` [Cout,Cin,3,3] from dY [N,Cout,(H-1)//2+1,
     (W-1)//2+1]: four launches of the stream-K kernel, one per parity class of the dX pixels (mas_conv_sk_dgrad_s2) -- each a
     stride-1 product over the dY plane with 1 / 2 / 2 / 4 taps, together the exact FLOPs of the gradient (no zero insertion).
@@ -1383,31 +1318,14 @@ def conv_sk_dgrad_s2(dy, w, H, W, packed=None, flags=None, spin_limit=0, bn=None
         raise ValueError("dy %s does not belong to a 3x3 stride-2 convolution of a %dx%d plane with weight %s" % (tuple(dy.shape), H, W, tuple(w.shape)))
     dx = torch.empty((N, Cin, H, W), dtype=torch.float32, device=dy.device)
     lib = _lib.load()
-    opts, flags = _sk_opts(flags, spin_limit)
-    part, offs = None, [0, 0, 0, 0]
-    if bn is not None:
-        # ``bn``: see conv_sk -- the four classes write disjoint pixels of g and disjoint column ranges of the partial sums
-        import ctypes
-        if tuple(bn.u.shape) != tuple(dx.shape):
-            raise ValueError("bn.u %s does not match the gradient %s" % (tuple(bn.u.shape), tuple(dx.shape)))
-        counts = [int(lib.mas_conv_sk_bn_slots(N, Cin, H, W, Cout, 3, 2, 1, sub, flags)) for sub in range(4)]
-        if (H > 1 and W > 1 and min(counts) <= 0) or sum(counts) <= 0:
-            raise ValueError("unsupported geometry for the fused BatchNorm backward")
-        offs = [sum(counts[:i]) for i in range(4)]
-        part = torch.empty((Cin, sum(counts), 2), dtype=torch.float64, device=dy.device)
+    opts, _ = _sk_opts(flags, spin_limit)
     with torch.cuda.device(dy.device):
         for sub in range(4):
             img = packed[sub] if packed is not None else conv_sk_pack(w, 2, 2 + sub)
             ws, epoch = _sk_workspace(dy.device)
-            if bn is not None:
-                if counts[sub] <= 0:
-                    continue                                    # (a class without pixels: H or W == 1)
-                o = _lib.SkOpts(flags, int(spin_limit), None, bn.u.data_ptr(), _opt(bn.mask), bn.mean.data_ptr(), bn.invstd.data_ptr(),
-                                part.data_ptr(), int(part.shape[1]), offs[sub])
-                opts = ctypes.byref(o)
             _lib.check(lib.mas_conv_sk_dgrad_s2(dy.data_ptr(), img.data_ptr(), N, Cin, H, W, Cout, sub, None, None, None, 0, dx.data_ptr(),
                                                 ws.data_ptr(), ws.numel(), epoch, opts, _stream(dy)), "mas_conv_sk_dgrad_s2")
-    return dx if bn is None else (dx, part)
+    return dx
 
 
 def conv_sk_set_mode(dma):
@@ -1494,7 +1412,7 @@ class _ConvTrain(torch.autograd.Function):
     separate pass over both gradients (autograd's accumulation: 16 add kernels over ~1.1 GB per step)."""
 
     @staticmethod
-    def forward(ctx, x, w, stride, dil, own, stats=False, fork=False, link=None):
+    def forward(ctx, x, w, stride, dil, own, stats=False, fork=False):
         x = x.contiguous()
         ks = w.shape[2]
         part = None
@@ -1508,13 +1426,6 @@ class _ConvTrain(torch.autograd.Function):
         ctx.save_for_backward(x, w)
         ctx.geom = (ks, stride, dil, own)
         ctx.fork = bool(fork)
-        # the BatchNorm that produced x (z = relu(bn(u) + r)): its backward reduction rides in this convolution's input-gradient
-        # epilogue where that runs on the stream-K kernel (stride 1, or the 3x3 stride-2 classes)
-        ctx.link = None
-        if (link is not None and not link.claimed and own[1] and (stride == 1 or (ks == 3 and stride == 2 and dil == 1))
-                and link.u is not None and link.u.shape == x.shape):
-            link.claimed = True
-            ctx.link = link
         if not stats and not fork:
             return y
         ctx.set_materialize_grads(False)            # (no zero-filled "gradient" of the partial sums in the backward)
@@ -1533,9 +1444,8 @@ class _ConvTrain(torch.autograd.Function):
         ks, stride, dil, own = ctx.geom
         g_other = rest[-1] if (ctx.fork and rest) else None     # gradient of the alias = of the other consumer of x
         if dy is None:
-            return g_other, None, None, None, None, None, None, None
+            return g_other, None, None, None, None, None, None
         dy = dy.contiguous()
-        link = ctx.link
         dx = dw = None
         need_dx, need_dw = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
         side = None
@@ -1556,26 +1466,18 @@ class _ConvTrain(torch.autograd.Function):
                 dw = conv_wgrad(x, dy, ks, stride, dil)
         if need_dx:
             if own[1] and stride == 1:
-                res = None
                 if g_other is not None and g_other.shape == x.shape and g_other.dtype == torch.float32:
-                    res, g_other = g_other.contiguous(), None
-                if link is not None and g_other is None:
-                    dx, part = conv_sk(dy, w, 1, dil, dgrad=True, packed=packed_weight(w, 1, True), residual=res, bn=link)
-                    link.take(dx, part)
+                    dx = conv_sk(dy, w, 1, dil, dgrad=True, packed=packed_weight(w, 1, True), residual=g_other.contiguous())
+                    g_other = None
                 else:
-                    dx = conv_sk(dy, w, 1, dil, dgrad=True, packed=packed_weight(w, 1, True), residual=res)
+                    dx = conv_sk(dy, w, 1, dil, dgrad=True, packed=packed_weight(w, 1, True))
             elif own[1] and ks == 1:
                 # 1x1, stride 2: the input gradient lives on the even positions only -- the stride-1 product on the small plane,
                 # scattered into a zero-filled tensor
                 dx = torch.zeros_like(x)
                 dx[:, :, ::stride, ::stride] = conv_sk(dy, w, 1, 1, dgrad=True, packed=packed_weight(w, 1, True))
             elif own[1] and ks == 3 and stride == 2 and dil == 1:
-                packs = [packed_weight(w, 2, 2 + sub) for sub in range(4)]
-                if link is not None and g_other is None:
-                    dx, part = conv_sk_dgrad_s2(dy, w, x.shape[2], x.shape[3], packed=packs, bn=link)
-                    link.take(dx, part)
-                else:
-                    dx = conv_sk_dgrad_s2(dy, w, x.shape[2], x.shape[3], packed=packs)
+                dx = conv_sk_dgrad_s2(dy, w, x.shape[2], x.shape[3], packed=[packed_weight(w, 2, 2 + sub) for sub in range(4)])
             else:
                 dx = torch.ops.aten.convolution_backward(dy, x, w, None, (stride, stride), _aten_pad(ks, dil), (dil, dil), False, (0, 0), 1,
                                                          (True, False, False))[0]
@@ -1587,7 +1489,7 @@ class _ConvTrain(torch.autograd.Function):
             dw.record_stream(main)
         if g_other is not None:
             dx = g_other if dx is None else dx + g_other
-        return dx, dw, None, None, None, None, None, None
+        return dx, dw, None, None, None, None, None
 
 
 def conv_wgrad_supported(conv, x):
@@ -1625,13 +1527,13 @@ def conv_train_plan(conv, x):
     return (fwd_ok and hw >= 192 * 192, dgrad_ok and hw >= 384 * 384, wgrad_ok)
 
 
-def conv_train(conv, x, own=(True, True, True), stats=False, fork=False, bn_link=None):
+def conv_train(conv, x, own=(True, True, True), stats=False, fork=False):
     """conv(x) with autograd on the package's kernels (see _ConvTrain).  stats=True: (y, partials) -- the BatchNorm partial sums
     of y from the epilogue of the forward kernel (None when the forward product is not on mas_conv_sk), for bn_act(partials=).
     fork=True: one more result, an alias of x to hand to the other consumer of x (see _ConvTrain)."""
     own = tuple(bool(v) for v in own)
     stats = bool(stats and own[0])
-    out = _ConvTrain.apply(x, conv.weight, conv.stride[0], conv.dilation[0], own, stats, bool(fork), bn_link)
+    out = _ConvTrain.apply(x, conv.weight, conv.stride[0], conv.dilation[0], own, stats, bool(fork))
     if not stats and not fork:
         return out
     out = list(out)

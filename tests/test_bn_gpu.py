@@ -149,115 +149,3 @@ def test_tensors_with_a_storage_offset_take_the_element_path_and_agree():
         outs.append((y.detach(), xq.grad, rq.grad, b.weight.grad, b.running_var.clone()))
     for a, c in zip(*outs):         # the partial sums are grouped by address, so the last bits may differ between the two alignments
         assert float((a - c).abs().max()) <= 2e-6 * max(1.0, float(c.abs().max()))
-
-
-# ---- round 4: the BatchNorm backward's reduction pass folded into the input-gradient kernel of the next convolution ---------------
-FUSED_CASES = [
-    # N, C (of z), Cout (of the consumer), k, stride, dil, H, W, relu, residual, fork
-    (2, 64, 64, 3, 1, 1, 24, 40, True, False, False),       # bn1 -> conv2
-    (2, 64, 256, 1, 1, 1, 25, 33, True, False, False),      # bn2 -> conv3, odd plane (mask bits at every alignment)
-    (2, 256, 64, 1, 1, 1, 24, 24, True, True, True),        # bn3 (+ identity) -> next block's conv1, the residual branch through the fork
-    (1, 128, 128, 3, 2, 1, 41, 66, True, False, False),     # bn1 -> the stride-2 conv2 of layer2.0: four parity-class launches
-    (2, 128, 128, 3, 2, 1, 40, 64, True, False, False),
-    (1, 200, 72, 3, 1, 2, 49, 49, True, True, False),       # channel tails, the linear pixel walk, dilation 2
-    (2, 48, 64, 1, 1, 1, 20, 36, False, False, False),      # a BatchNorm without ReLU (no mask)
-    (1, 64, 64, 3, 1, 1, 193, 193, True, False, False),     # layer1 conv2 at the 769 crop
-]
-
-
-@pytest.mark.parametrize("N,C,Cout,k,stride,dil,H,W,relu,with_res,fork", FUSED_CASES)
-def test_backward_reduction_in_the_consumers_input_gradient_epilogue(N, C, Cout, k, stride, dil, H, W, relu, with_res, fork):
-    """z = relu(bn(u) + r); y = conv(z) (+ a second consumer of z through the fork alias): the gradient of z leaves the convolution's
-    input-gradient kernel GATED together with the (sum g, sum g * uhat) partials, the BatchNorm's backward is statistics + one pass
-    (ops._BNLink).  All gradients against float64 autograd; the short path must actually have been taken."""
-    ops = _gpu()
-    torch.manual_seed(N * 100 + C + Cout + k + H)
-    bn = nn.BatchNorm2d(C, momentum=0.1).cuda().train()
-    with torch.no_grad():
-        bn.weight.copy_(torch.rand(C) + 0.5)
-        bn.bias.copy_(torch.randn(C) * 0.3)
-    conv = nn.Conv2d(C, Cout, k, stride=stride, padding=dil if k == 3 else 0, dilation=dil, bias=False).cuda()
-    u = (torch.randn(N, C, H, W, device='cuda') * 2 + 0.5).requires_grad_(True)
-    r = torch.randn(N, C, H, W, device='cuda').requires_grad_(True) if with_res else None
-    Ho, Wo = (H - 1) // stride + 1, (W - 1) // stride + 1
-    go = torch.randn(N, Cout, Ho, Wo, device='cuda')
-    go2 = torch.randn(N, C, H, W, device='cuda')
-    # float64 reference
-    bn64 = copy.deepcopy(bn).double()
-    conv64 = copy.deepcopy(conv).double()
-    u64 = u.detach().double().requires_grad_(True)
-    r64 = r.detach().double().requires_grad_(True) if with_res else None
-    z64 = _ref(bn64, u64, r64, relu)
-    y64 = conv64(z64)
-    ((y64 * go.double()).sum() + ((z64 * go2.double()).sum() if fork else 0.0)).backward()
-    # the package's path
-    z = ops.bn_act(bn, u, relu, r)
-    link = getattr(z, '_mas_bn_link', None)
-    assert link is not None
-    own = ops.conv_train_plan(conv, z)
-    assert own is not None and own[1]
-    out = ops.conv_train(conv, z, own, fork=fork, bn_link=link)
-    if fork:
-        y, _, z_alias = out
-        ((y * go).sum() + (z_alias * go2).sum()).backward()
-    else:
-        (out * go).sum().backward()
-    assert link.claimed and link.g is None and link.partials is None, "the BatchNorm's backward did not consume the hand-over"
-    tol = lambda ref: 3e-5 * max(1.0, float(ref.abs().max()))
-    for got, ref, name in ((u.grad, u64.grad, "du"), (bn.weight.grad, bn64.weight.grad, "dgamma"), (bn.bias.grad, bn64.bias.grad, "dbeta"),
-                           (conv.weight.grad, conv64.weight.grad, "dw")) + (((r.grad, r64.grad, "dr"),) if with_res else ()):
-        err = float((got.double() - ref).abs().max())
-        assert err <= (5 if name == "du" else 1) * tol(ref), (name, err, float(ref.abs().max()))
-    assert ops.conv_sk_error() == 0
-
-
-def test_short_path_is_refused_when_the_gradient_is_not_the_handed_over_tensor():
-    """A second consumer of z OUTSIDE the convolution (autograd then adds its gradient to the gated one) must send the BatchNorm's
-    backward down the long path -- which gates again (idempotent) and reduces itself.  Same answers as float64."""
-    ops = _gpu()
-    torch.manual_seed(5)
-    N, C, H, W = 2, 64, 24, 32
-    bn = nn.BatchNorm2d(C).cuda().train()
-    conv = nn.Conv2d(C, 64, 3, padding=1, bias=False).cuda()
-    u = torch.randn(N, C, H, W, device='cuda').requires_grad_(True)
-    go = torch.randn(N, 64, H, W, device='cuda')
-    other = torch.randn(N, C, H, W, device='cuda')
-    u64 = u.detach().double().requires_grad_(True)
-    z64 = F.relu(copy.deepcopy(bn).double()(u64))
-    ((copy.deepcopy(conv).double()(z64) * go.double()).sum() + (z64 * other.double()).sum()).backward()
-    z = ops.bn_act(bn, u, True)
-    link = z._mas_bn_link
-    y = ops.conv_train(conv, z, ops.conv_train_plan(conv, z), bn_link=link)
-    ((y * go).sum() + (z * other).sum()).backward()             # (z * other): a consumer the convolution does not know about
-    assert float((u.grad.double() - u64.grad).abs().max()) <= 1.5e-4 * max(1.0, float(u64.grad.abs().max()))
-    assert link.g is None and link.partials is None
-
-
-def test_whole_step_with_and_without_the_fused_backward_reduction():
-    """One training step of the network under MAS_BN_BWD=fused (default) and =separate: same logits bit for bit (the forward does not
-    change), gradients equal up to the summation order of the BatchNorm reductions."""
-    ops = _gpu()
-    import os
-    from mulactseg_amd.models import get_model
-    dev = torch.device('cuda:0')
-    x = torch.randn(2, 3, 256, 256, generator=torch.Generator(device=dev).manual_seed(6), device=dev)
-    res = {}
-    for mode in ("fused", "separate"):
-        os.environ["MAS_BN_BWD"] = mode
-        try:
-            torch.manual_seed(12)
-            net = get_model('deeplabv3pluswn_resnet50deepstem', 20, 16, True, pretrained_backbone=False).to(dev).train()
-            for m in net.modules():
-                if isinstance(m, nn.Dropout):
-                    m.p = 0.0
-            z = net(x, lowres=True)
-            wts = torch.linspace(-1.0, 1.0, z.numel(), device=dev).view_as(z)
-            (z * wts).sum().backward()
-            res[mode] = (z.detach().clone(), {n: p.grad.detach().double() for n, p in net.named_parameters()})
-        finally:
-            os.environ.pop("MAS_BN_BWD")
-    assert torch.equal(res["fused"][0], res["separate"][0])
-    num = sum(float(((res["fused"][1][n] - g) ** 2).sum()) for n, g in res["separate"][1].items())
-    den = sum(float((g ** 2).sum()) for g in res["separate"][1].values())
-    assert (num / den) ** 0.5 <= 1e-4, (num / den) ** 0.5
-    assert ops.conv_sk_error() == 0
