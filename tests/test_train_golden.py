@@ -146,62 +146,77 @@ def _two_steps_cpu(g, x, tgt, spx, msk, port):
     assert worst <= 1e-6, worst
 
 
-@pytest.mark.gpu
-def test_training_mode_network_and_two_optimizer_steps_match_the_reference_gpu():
-    """The same two steps on the GPU's production path: own convolutions (all three products), fused BatchNorm, the fused
-    quarter-resolution loss scans (weighted objective and its chain rule in the kernels), fused AdamW."""
-    if not torch.cuda.is_available():
-        pytest.skip("needs a GPU")
+def _two_steps_gpu(g, mode):
+    """Both steps on the GPU with MAS_TRAIN_CONV = mode; returns the deviations from the fixture."""
     from mulactseg_amd import ops
     from mulactseg_amd.models import deeplab
     from mulactseg_amd.utils.loss import FusedPartialLabelLoss
-    g = np.load(GOLDEN)
     x, tgt, spx, msk = _inputs(g)
     dev = torch.device('cuda:0')
     xt, tt, ts, tm = (torch.from_numpy(a).to(dev) for a in (x, tgt, spx, msk))
     crit = FusedPartialLabelLoss(int(g['S']), float(g['temp']), float(g['temp']), sync_normalisers=False)
     H, W = int(g['H']), int(g['W'])
-    # the yardstick: the same first step with every convolution on MIOpen (this package's memory-bound kernels and losses stay)
-    os.environ["MAS_TRAIN_CONV"] = "miopen"
+    out = {}
+    os.environ["MAS_TRAIN_CONV"] = mode
     try:
-        net, _, _ = _build(g, dev)
-        total = crit.weighted_lowres(net(xt, lowres=True), (H, W), tt, ts, tm, 16.0, 8.0, 1.0)[0]
-        total.backward()
-        rel_miopen, _ = _compare_grads(g, net, 1.0, 1.0)
+        net, opt, sched = _build(g, dev)
+        p0 = [p.detach().clone() for p in net.parameters()]
+        for step in (1, 2):
+            opt.zero_grad()
+            deeplab.path_report(reset=True)
+            zq = net(xt, lowres=True)
+            total, group, ce, mc = crit.weighted_lowres(zq, (H, W), tt, ts, tm, 16.0, 8.0, 1.0)
+            total.backward()
+            out['paths%d' % step] = deeplab.path_report(reset=True)
+            out['logits%d' % step] = float(np.abs(zq.detach().cpu().numpy() - g['quarter%d' % step]).max())
+            got = np.array([float(total.detach()), float(ce), float(mc), float(group)], dtype=np.float64)
+            out['losses%d' % step] = float(np.abs(got / g['losses%d' % step].astype(np.float64) - 1.0).max())
+            if step == 1:
+                out['grads'], out['gnorm'] = _compare_grads(g, net, 1.0, 1e9)
+                assert net.classifier.proxy.grad is net.classifier.final.weight.grad
+            opt.step()
+            sched.step()
+            assert [pg['lr'] for pg in opt.param_groups] == list(g['lrs%d' % step])
+            out['buffers%d' % step] = _compare_buffers(g, net, step, 1.0)
+        num = den = worst = 0.0
+        names = list(g['param_names'])
+        for i, (p, q) in enumerate(zip(net.parameters(), p0)):
+            base = sub256(q.cpu().numpy()).astype(np.float64)
+            ref_delta = g['param_%03d' % i].astype(np.float64) - base
+            got_delta = sub256(p.detach().cpu().numpy()).astype(np.float64) - base
+            num += float(((got_delta - ref_delta) ** 2).sum())
+            den += float((ref_delta ** 2).sum())
+            lr = float(g['lr']) * (float(g['cls_lr_scale']) if names[i].startswith('classifier') else 1.0)
+            worst = max(worst, float(np.abs(got_delta - ref_delta).max()) / lr)
+        out['update'], out['update_worst_in_lr'] = (num / den) ** 0.5, worst
+        out['sk_error'] = ops.conv_sk_error()
     finally:
         os.environ.pop("MAS_TRAIN_CONV")
-    del net, total
-    net, opt, sched = _build(g, dev)
-    ops.conv_sk_clear_error()
-    p0 = [p.detach().clone() for p in net.parameters()]
-    for step in (1, 2):
-        opt.zero_grad()
-        deeplab.path_report(reset=True)
-        zq = net(xt, lowres=True)
-        total, group, ce, mc = crit.weighted_lowres(zq, (H, W), tt, ts, tm, 16.0, 8.0, 1.0)
-        total.backward()
-        paths = deeplab.path_report(reset=True)
-        assert float(np.abs(zq.detach().cpu().numpy() - g['quarter%d' % step]).max()) <= (1e-4 if step == 1 else 3e-4)
-        got = np.array([float(total.detach()), float(ce), float(mc), float(group)], dtype=np.float32)
-        assert np.allclose(got, g['losses%d' % step], rtol=1e-4 if step == 1 else 1e-3, atol=0), (got, g['losses%d' % step])
-        if step == 1:
-            assert "train:fdw" in paths["conv_bn_act"] and "miopen+bn" not in paths["conv_bn_act"], paths
-            rel, worst = _compare_grads(g, net, max(2e-3, 1.5 * rel_miopen), max(2e-2, 3.0 * rel_miopen))
-        opt.step()
-        sched.step()
-        assert [pg['lr'] for pg in opt.param_groups] == list(g['lrs%d' % step])
-        wb = _compare_buffers(g, net, step, 1e-4)
-    # AdamW's first steps move every element by ~lr * sign(gradient): elements whose gradient is within rounding of zero may take
-    # the other sign, so the bar is on the update as a whole (relative L2 of p2 - p0 over all cuts) and, element-wise, on 2.2 lr.
-    num = den = 0.0
-    for i, (p, q) in enumerate(zip(net.parameters(), p0)):
-        ref_delta = g['param_%03d' % i].astype(np.float64) - sub256(q.cpu().numpy()).astype(np.float64)
-        got_delta = sub256(p.detach().cpu().numpy()).astype(np.float64) - sub256(q.cpu().numpy()).astype(np.float64)
-        num += float(((got_delta - ref_delta) ** 2).sum())
-        den += float((ref_delta ** 2).sum())
-        lr = float(g['lr']) * (float(g['cls_lr_scale']) if list(g['param_names'])[i].startswith('classifier') else 1.0)
-        assert float(np.abs(got_delta - ref_delta).max()) <= 2.2 * lr + 1e-7
-    assert (num / den) ** 0.5 <= 0.1, (num / den) ** 0.5
-    assert ops.conv_sk_error() == 0
-    print("G10 on the GPU: gradient cuts rel L2 %.2e (MIOpen convolutions: %.2e), worst tensor-norm deviation %.2e (%s), running stats %.2e, update rel L2 %.2e"
-          % (rel, rel_miopen, worst[0], worst[1], wb, (num / den) ** 0.5))
+    return out
+
+
+@pytest.mark.gpu
+def test_training_mode_network_and_two_optimizer_steps_match_the_reference_gpu():
+    """The same two steps on the GPU's production path: own convolutions (all three products), fused BatchNorm, the fused
+    quarter-resolution loss scans (weighted objective and its chain rule in the kernels), fused AdamW.  Step 1 is held to the
+    north-star tolerances (logits, running statistics <= 1e-4).  What f32 rounding chaos decides -- the gradients, and everything
+    after an AdamW step, which moves EVERY element by ~lr * sign(gradient) however small the gradient -- is held to the yardstick:
+    the same two steps with every convolution on MIOpen, against the same fixture (bars: 1.5x its deviation)."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    g = np.load(GOLDEN)
+    ref = _two_steps_gpu(g, "miopen")
+    own = _two_steps_gpu(g, "own")
+    print("G10 on the GPU, own kernels:", {k: v for k, v in own.items() if not k.startswith('paths')})
+    print("G10 on the GPU, MIOpen convolutions:", {k: v for k, v in ref.items() if not k.startswith('paths')})
+    assert "train:fdw" in own["paths1"]["conv_bn_act"] and "miopen+bn" not in own["paths1"]["conv_bn_act"], own["paths1"]
+    assert set(ref["paths1"]["conv_bn_act"]) == {"miopen+bn"}
+    assert own['sk_error'] == 0
+    assert own['logits1'] <= 1e-4 and own['losses1'] <= 1e-4 and own['buffers1'] <= 1e-4, own
+    assert own['grads'] <= max(2e-3, 1.5 * ref['grads']), (own['grads'], ref['grads'])
+    assert own['gnorm'][0] <= max(2e-2, 3.0 * ref['gnorm'][0]), (own['gnorm'], ref['gnorm'])
+    assert own['update_worst_in_lr'] <= 4.0, own           # two steps of ~lr each on either side: the two can end 2 (lr1 + lr2) = 3.8 lr apart at most
+    assert own['update'] <= max(0.05, 1.5 * ref['update']), (own['update'], ref['update'])
+    assert own['logits2'] <= max(3e-4, 1.5 * ref['logits2']), (own['logits2'], ref['logits2'])
+    assert own['losses2'] <= max(1e-3, 1.5 * ref['losses2']), (own['losses2'], ref['losses2'])
+    assert own['buffers2'] <= max(1e-4, 1.5 * ref['buffers2']), (own['buffers2'], ref['buffers2'])
