@@ -7,7 +7,8 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libmulactseg_hip.so")
+# MAS_LIB: another build of the same ABI (A/B runs of a kernel change inside one GPU session); the default is the in-tree library
+LIB_PATH = os.environ.get("MAS_LIB") or os.path.join(_HERE, "libmulactseg_hip.so")
 
 ID_I64, ID_I32, ID_U16 = 0, 1, 2
 MAX_CLASSES = 32

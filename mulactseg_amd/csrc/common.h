@@ -24,6 +24,17 @@ static inline int mas_launch_status() {
     return e == hipSuccess ? 0 : (int)e;
 }
 
+// 16-byte load of logits that are read ONCE (the scans stream 671 MB per pool batch through every CU exactly once): the
+// non-temporal policy (global_load_dwordx4 ... nt) leaves the lines out of the way of the L2's replacement and shortens the
+// issue -> data round trip under load (MI355X_MICROARCH.md, "nt-weights": -18 %); the ring scan, which is bound by bytes in flight
+// divided by that round trip, went from 161 to 154 us per [4,20,1024,2048] batch.  NOT for data another kernel re-reads soon
+// (superpixel ids: static maps that stay in the Infinity Cache between batches -- measured 1.5 % slower with nt).
+__device__ __forceinline__ float4 mas_load_stream4(const float* p) {
+    typedef float mas_v4nt __attribute__((ext_vector_type(4)));
+    const mas_v4nt q = __builtin_nontemporal_load(reinterpret_cast<const mas_v4nt*>(p));
+    return make_float4(q.x, q.y, q.z, q.w);
+}
+
 template <typename IdT>
 __device__ __forceinline__ int mas_load_id(const IdT* p, size_t i) {
     return (int)p[i];

@@ -51,7 +51,7 @@ __global__ __launch_bounds__(kThreads) void k_class_prob_sum(const float* __rest
             for (int c = 0; c < CT; ++c) {
                 float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
                 const float* zc = zb + (size_t)c * HW;       // wave-uniform base, 32-bit lane offset
-                if ((EXACT || c < C) && in) t = *reinterpret_cast<const float4*>(zc + (unsigned)p);
+                if ((EXACT || c < C) && in) t = mas_load_stream4(zc + (unsigned)p);
                 v[0][c] = (mas_v2f){t.x, t.y};
                 v[1][c] = (mas_v2f){t.z, t.w};
             }
@@ -117,7 +117,7 @@ template <int CT, bool EXACT>
 __device__ __forceinline__ void k2_issue(float4 (&t)[CT], const float* __restrict__ zb, int C, int HW, unsigned off) {
 #pragma unroll
     for (int c = 0; c < CT; ++c) {
-        if (EXACT || c < C) t[c] = *reinterpret_cast<const float4*>(zb + (size_t)c * HW + off);
+        if (EXACT || c < C) t[c] = mas_load_stream4(zb + (size_t)c * HW + off);
         else t[c] = make_float4(0.f, 0.f, 0.f, 0.f);
     }
 }
@@ -282,7 +282,7 @@ __global__ __launch_bounds__(kThreads) void k_bvsb_region_accum(const float* __r
                 float v[4];
                 if (VEC) {
                     float4 q = make_float4(0.f, 0.f, 0.f, 0.f);
-                    if (ok[0]) q = *reinterpret_cast<const float4*>(zb + (size_t)c * HW + row + xs[0]);
+                    if (ok[0]) q = mas_load_stream4(zb + (size_t)c * HW + row + xs[0]);
                     v[0] = q.x; v[1] = q.y; v[2] = q.z; v[3] = q.w;
                 } else {
 #pragma unroll

@@ -202,7 +202,7 @@ __global__ __launch_bounds__(kThreads) void k_single_pass(const float* __restric
                 if (LOWRES) {
                     t = make_float4(v[0][c].x, v[0][c].y, v[1][c].x, v[1][c].y);          // interpolated before this loop
                 } else if (VEC) {
-                    if (ok[0]) t = *reinterpret_cast<const float4*>(zc + (unsigned)(row + xs[0]));
+                    if (ok[0]) t = mas_load_stream4(zc + (unsigned)(row + xs[0]));
                 } else {
                     if (ok[0]) t.x = zc[row + xs[0]];
                     if (ok[1]) t.y = zc[row + xs[1]];
@@ -363,7 +363,7 @@ __device__ __forceinline__ void ring_issue(RowRegs<CT, IdT>& r, const float* __r
     r.ids.load(sb + off);
 #pragma unroll
     for (int c = 0; c < CT; ++c) {
-        if (EXACT || c < C) r.t[c] = *reinterpret_cast<const float4*>(zb + (size_t)c * HW + off);
+        if (EXACT || c < C) r.t[c] = mas_load_stream4(zb + (size_t)c * HW + off);
         else r.t[c] = make_float4(0.f, 0.f, 0.f, 0.f);
     }
 }
