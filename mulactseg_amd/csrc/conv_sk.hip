@@ -814,19 +814,24 @@ __global__ __launch_bounds__(kSkThreads) void k_conv_sk(const SkP p) {
                             break;
                         }
                     }
-                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 }
                 __syncthreads();
+                // The slot is read with sc1 loads (they bypass this CU's L1: served by the L2 the write-through stores went to), issued
+                // after the barrier the polling wave joined -- no acquire fence: its buffer_inv + wait cost ~1.7 us per contributor at the
+                // very end of a finisher's work (MI355X_MICROARCH.md, hand-off table: "sc1 loads may replace the acquire").
                 const float* slot = p.slots + (size_t)gg * kSkSlotFloats;
+                v4f part[TN * 4];
+#pragma unroll
+                for (int i = 0; i < TN * 4; ++i)
+                    asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(part[i]) : "v"(slot + ((size_t)i * kSkThreads + tid) * 4) : "memory");
+#pragma unroll
+                for (int i = 0; i < TN * 4; ++i) asm volatile("s_waitcnt vmcnt(0)" : "+v"(part[i])::"memory");
 #pragma unroll
                 for (int tn = 0; tn < TN; ++tn)
 #pragma unroll
-                    for (int r4 = 0; r4 < 4; ++r4) {
-                        const v4f v = *reinterpret_cast<const v4f*>(slot + ((size_t)(tn * 4 + r4) * kSkThreads + tid) * 4);
+                    for (int r4 = 0; r4 < 4; ++r4)
 #pragma unroll
-                        for (int i = 0; i < 4; ++i) acc[tn][4 * r4 + i] += v[i];
-                    }
+                        for (int i = 0; i < 4; ++i) acc[tn][4 * r4 + i] += part[tn * 4 + r4][i];
             }
             __syncthreads();
             if (*s_gave_up) {

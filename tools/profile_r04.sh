@@ -1,0 +1,77 @@
+# round 4 profiles -> gpurun_out/p4/*.md|json (copied into profiles/r04/ by hand).  Usage: bash tools/profile_r04.sh <part>
+#   part scan   : bench.py scan leg: kernel stats + FETCH/WRITE PMC (roofline.traffic source)
+#   part pool   : acquisition leg ONLY (eval forward [4,3,1024,2048] + quarter-resolution scan): steady table, MFMA PMC, HBM PMC
+#   part train  : train step at 768 and 769 (own convolution kernels): steady tables, MFMA PMC, HBM PMC
+set -eu; cd /tmp && export TMPDIR=/tmp && cd "${GRAFT_REPO_ROOT:?}"
+PART=${1:-scan}; O=gpurun_out/p4; mkdir -p $O
+if [ "$PART" = scan ]; then
+  CMD="python bench.py --no-cpu-baseline --no-train --no-pool"
+  rm -rf $O/s_stats $O/s_fetch $O/s_write
+  rocprofv3 --kernel-trace --stats --output-format csv -d $O/s_stats -o s -- $CMD > $O/scan_bench.json 2> /dev/null
+  rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/s_fetch -o s -- $CMD --steps 20 --warmup 2 --ramp 0 > /dev/null 2>&1
+  rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/s_write -o s -- $CMD --steps 20 --warmup 2 --ramp 0 > /dev/null 2>&1
+  python profiles/summarize.py stats $(find $O/s_stats -name "*kernel_stats.csv") $O/a_bench_kernel_stats.md "rocprofv3 --kernel-trace --stats -- $CMD"
+  python profiles/summarize.py pmc $(find $O/s_fetch -name "*counter_collection.csv") $(find $O/s_write -name "*counter_collection.csv") $O/b_pmc_traffic.json "rocprofv3 --kernel-trace --pmc FETCH_SIZE|WRITE_SIZE -- $CMD --steps 20 --warmup 2 --ramp 0"
+  head -12 $O/a_bench_kernel_stats.md; head -c 900 $O/b_pmc_traffic.json
+elif [ "$PART" = pool ]; then
+  CMD="python bench.py --no-cpu-baseline --no-pool --no-trainleg --steps 2 --warmup 1 --ramp 0 --acq-steps 8"
+  rm -rf $O/p_tr $O/p_mf $O/p_fetch $O/p_write
+  rocprofv3 --kernel-trace --output-format csv -d $O/p_tr -o t -- $CMD > $O/pool_bench.json 2> /dev/null
+  python profiles/steady.py $O/p_tr/t_kernel_trace.csv k_cosine_fwd4 5 $O/e_pool_forward_steady.md "rocprofv3 --kernel-trace -- $CMD (acquisition leg only: no train / stage-2 leg in the process)" > /dev/null
+  head -30 $O/e_pool_forward_steady.md
+  rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/p_fetch -o f -- $CMD --acq-steps 3 > /dev/null 2>&1
+  rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/p_write -o f -- $CMD --acq-steps 3 > /dev/null 2>&1
+  python profiles/pmc_kernels.py $(find $O/p_fetch -name "*counter_collection.csv") $(find $O/p_write -name "*counter_collection.csv") $O/g_pool_forward_hbm_pmc.md "rocprofv3 --kernel-trace --pmc FETCH_SIZE|WRITE_SIZE -- $CMD --acq-steps 3"
+else
+  for CROP in 768 769; do
+    rm -rf $O/t_tr
+    rocprofv3 --kernel-trace --output-format csv -d $O/t_tr -o t -- python tools/train_step_probe.py --modes own --streams main --steps 8 --crop $CROP > $O/train_probe_$CROP.log 2>&1
+    python profiles/steady.py $O/t_tr/t_kernel_trace.csv multi_tensor_apply 6 $O/c_train_${CROP}_steady.md "rocprofv3 --kernel-trace -- python tools/train_step_probe.py --modes own --streams main --steps 8 --crop $CROP" > /dev/null
+    head -14 $O/c_train_${CROP}_steady.md; grep "^own" $O/train_probe_$CROP.log || true
+  done
+  rm -rf $O/t_mf $O/t_fetch $O/t_write
+  rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F32 GRBM_GUI_ACTIVE --output-format csv -d $O/t_mf -o m -- python tools/train_step_probe.py --modes own --streams main --steps 4 > /dev/null 2>&1
+  python - <<'PY'
+import csv, collections, sys, glob
+sys.path.insert(0, 'profiles')
+from summarize import short
+cc = list(csv.DictReader(open(glob.glob('gpurun_out/p4/t_mf/*counter_collection.csv')[0])))
+disp = collections.OrderedDict()
+for r in cc:
+    e = disp.setdefault(int(r['Dispatch_Id']), {'name': r['Kernel_Name']})
+    e[r['Counter_Name']] = e.get(r['Counter_Name'], 0.0) + float(r['Counter_Value'])
+ids = sorted(disp)
+marks = [i for i in ids if 'multi_tensor_apply' in disp[i]['name']]
+groups, last = [], None
+for i in marks:
+    if last is not None and i - last < 40 and groups: groups[-1] = i
+    else: groups.append(i)
+    last = i
+a, b = groups[-4], groups[-1]
+acc = collections.defaultdict(lambda: collections.defaultdict(float))
+for i in ids:
+    if a < i <= b:
+        e = disp[i]; k = short(e['name'])
+        for c in ('SQ_VALU_MFMA_BUSY_CYCLES', 'SQ_BUSY_CU_CYCLES', 'SQ_INSTS_VALU_MFMA_MOPS_F32', 'GRBM_GUI_ACTIVE'):
+            acc[k][c] += e.get(c, 0.0)
+        acc[k]['n'] += 1
+tot = collections.defaultdict(float)
+rows = []
+for k, v in acc.items():
+    for c in v: tot[c] += v[c]
+    rows.append((v['SQ_VALU_MFMA_BUSY_CYCLES'], k, v))
+rows.sort(reverse=True)
+out = ["# MFMA utilisation of the stage-1 train step on this package's convolution kernels (3 steady steps, rocprofv3 --pmc)", "",
+       "command: `rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F32 GRBM_GUI_ACTIVE -- python tools/train_step_probe.py --modes own --streams main --steps 4`", "",
+       "MfmaUtil = SQ_VALU_MFMA_BUSY_CYCLES / (4 SIMDs x SQ_BUSY_CU_CYCLES); MOPS_F32 x 512 = f32 MFMA FLOPs", "",
+       "whole step: MfmaUtil %.3f, f32 MFMA FLOP %.3e per step" % (tot['SQ_VALU_MFMA_BUSY_CYCLES'] / max(1.0, 4 * tot['SQ_BUSY_CU_CYCLES']), tot['SQ_INSTS_VALU_MFMA_MOPS_F32'] * 512 / 3), "",
+       "| kernel | calls/step | MfmaUtil | share of MFMA cycles |", "|---|---|---|---|"]
+for m, k, v in rows[:18]:
+    out.append("| %s | %.1f | %.3f | %.1f %% |" % (k[:90], v['n'] / 3, m / max(1.0, 4 * v['SQ_BUSY_CU_CYCLES']), 100 * m / max(1.0, tot['SQ_VALU_MFMA_BUSY_CYCLES'])))
+open('gpurun_out/p4/f_train_step_mfma_pmc.md', 'w').write("\n".join(out) + "\n")
+print("\n".join(out[:26]))
+PY
+  rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/t_fetch -o f -- python tools/train_step_probe.py --modes own --streams main --steps 3 > /dev/null 2>&1
+  rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/t_write -o f -- python tools/train_step_probe.py --modes own --streams main --steps 3 > /dev/null 2>&1
+  python profiles/pmc_kernels.py $(find $O/t_fetch -name "*counter_collection.csv") $(find $O/t_write -name "*counter_collection.csv") $O/h_train_step_hbm_pmc.md "rocprofv3 --kernel-trace --pmc FETCH_SIZE|WRITE_SIZE -- python tools/train_step_probe.py --modes own --streams main --steps 3"
+fi

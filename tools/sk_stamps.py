@@ -37,3 +37,15 @@ for i, name in enumerate(("start", "primed", "loop done", "end")):
 dur = us[:, 3] - us[:, 0]
 print("  workgroup duration: min %.2f mean %.2f max %.2f us;  prologue mean %.2f us;  after-loop (hand-off + epilogue) mean %.2f max %.2f us"
       % (dur.min(), dur.mean(), dur.max(), (us[:, 1] - us[:, 0]).mean(), (us[:, 3] - us[:, 2]).mean(), (us[:, 3] - us[:, 2]).max()))
+if os.environ.get("SK_STAMPS_RAW"):
+    full = st.cpu().numpy().astype(np.float64)
+    P = int((full[:, 0] > 0).sum())
+    d = (full[:P, 3] - full[:P, 0]) / 100.0
+    s0 = (full[:P, 0] - full[:P, 0].min()) / 100.0
+    e = (full[:P, 3] - full[:P, 0].min()) / 100.0
+    per = P // 8 if P % 8 == 0 else P
+    for x in range(P // per):
+        seg = slice(x * per, (x + 1) * per)
+        print("  XCD %d: start %.2f..%.2f  end min %.1f mean %.1f max %.1f | first 8 ends: %s | last 8 ends: %s"
+              % (x, s0[seg].min(), s0[seg].max(), e[seg].min(), e[seg].mean(), e[seg].max(),
+                 " ".join("%.1f" % v for v in e[seg][:8]), " ".join("%.1f" % v for v in e[seg][-8:])))
