@@ -500,24 +500,28 @@ __global__ __launch_bounds__(kSkThreads) void k_conv_sk(const SkP p) {
         v4f a;
         float b[4][TN];
     };
-    auto mfma_part = [&](int buf, auto QLc, auto QHc, auto&& hook) {
-        constexpr int qlo = decltype(QLc)::value, qhi = decltype(QHc)::value;
+    auto load_group_of = [&](int buf, int q, Group& o) {
         const float* sW = sk_smem + buf * bufsz;
         const float* sX = sW + KC * BM;
-        auto load_group = [&](int q, Group& o) {
-            o.a = *reinterpret_cast<const v4f*>(sW + q * 8 * BM + aBase);
+        o.a = *reinterpret_cast<const v4f*>(sW + q * 8 * BM + aBase);
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int kk = 4 * q + j, tap = kk / (CK / 2), cp = kk - tap * (CK / 2);
-                const int toff = G::toff(tap);
-                const float* xrow = sX + 2 * cp * CS + toff;
+        for (int j = 0; j < 4; ++j) {
+            const int kk = 4 * q + j, tap = kk / (CK / 2), cp = kk - tap * (CK / 2);
+            const int toff = G::toff(tap);
+            const float* xrow = sX + 2 * cp * CS + toff;
 #pragma unroll
-                for (int tn = 0; tn < TN; ++tn) o.b[j][tn] = xrow[bBase[tn]];
-            }
-        };
+            for (int tn = 0; tn < TN; ++tn) o.b[j][tn] = xrow[bBase[tn]];
+        }
+    };
+    // `pre`: the operands of group qlo, already requested by the caller (the register-staged loop asks for them right behind the
+    // barrier, BEFORE its scalar planning of chunk it + 2: the LDS round trip then runs beside that code instead of behind it)
+    auto mfma_part = [&](int buf, auto QLc, auto QHc, auto&& hook, const Group* pre = nullptr) {
+        constexpr int qlo = decltype(QLc)::value, qhi = decltype(QHc)::value;
+        auto load_group = [&](int q, Group& o) { load_group_of(buf, q, o); };
         if constexpr (qlo >= qhi) return;
         Group cur, nxt;
-        load_group(qlo, cur);
+        if (pre) cur = *pre;
+        else load_group(qlo, cur);
         sk_static_for<qlo, qhi>([&](auto qc) {
             constexpr int q = decltype(qc)::value;
             if (q + 1 < qhi) load_group(q + 1, nxt);
@@ -655,6 +659,9 @@ __global__ __launch_bounds__(kSkThreads) void k_conv_sk(const SkP p) {
             // then the refill with chunk it + 2 -- rides behind MFMA group q of the wave itself.  The loop body has no branch (a chunk
             // past the end is an empty resource), so hipcc counts the outstanding loads across the back edge: the store of slot s
             // waits for vmcnt(NS - 1), i.e. for a load that is a whole iteration old.
+            Group first;
+            load_group_of(buf, 0, first);
+            __builtin_amdgcn_sched_barrier(0);
             const bool v2 = it + 2 < it1;
             if (v2) sk_advance(p, g, sk0, sk1 - sk0, pre);
             const SkPlan f2 = sk_plan_fetch<G, TAPS, WM, VEC>(p, pre, slots, xoff, v2);
@@ -669,7 +676,7 @@ __global__ __launch_bounds__(kSkThreads) void k_conv_sk(const SkP p) {
                     sk_stage_slot<G, TAPS, WM, VEC, NWS, S>(xm, nW, nX, tid, wr, xr, slow_regs);
                     sk_fetch_slot<G, TAPS, WM, VEC, NWS, S>(f2, xoff, tid, wr, xr, xm);
                 });
-            });
+            }, &first);
             slow_regs = f2.slow;
             __syncthreads();
             buf ^= 1;

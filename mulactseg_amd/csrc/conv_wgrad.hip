@@ -30,6 +30,14 @@ typedef float v4f __attribute__((ext_vector_type(4)));
 typedef float v4fu __attribute__((ext_vector_type(4), aligned(4)));
 constexpr int kWgThreads = 512;
 
+template <int I, int N, typename F>
+__device__ __forceinline__ void wg_static_for(F&& f) {
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        wg_static_for<I + 1, N>(f);
+    }
+}
+
 struct WgP {
     const float* x;
     const float* dy;
@@ -142,99 +150,112 @@ __global__ __launch_bounds__(kWgThreads) void k_wgrad(const WgP p) {
     // is ~20 VALU instructions per group in fetch + stage, 4.2 vs 3.5 ms per step on the 1x1 layers of the 769 crop with it)
     bool fix_regs = true;               // the chunk in the staging registers carries fix-up data in ma / mb
     bool fix_next = true;
-    auto fetch = [&](int q) {
+    // where chunk q lives: scalars that are the same for every slot of the chunk (fetch_begin), then one 16-byte group per slot
+    struct FetchCtx {
+        const float* dyb;
+        const float* xb;
+        int k0, oy0, ox0, iy0, ix0;
+        bool inner;
+    };
+    FetchCtx fc;
+    auto fetch_begin = [&](int q) {
         fix_next = true;
         if (FLAT) {
             const int cpi = (HW + KP - 1) / KP;
-            const int n = q / cpi, k0 = (q - n * cpi) * KP;
-            const float* dyb = p.dy + (size_t)n * p.Cout * HWo + k0;
-            const float* xb = p.x + (size_t)n * p.Cin * HW + k0;
-            const bool inner = !VEC && k0 + KP <= HW;           // (FLAT: HW == HWo)
-            fix_next = !inner;
-#pragma unroll
-            for (int j = 0; j < NA; ++j) {
-                const int f = tid + j * kWgThreads;
-                const int m = f / F4A, g = f % F4A;
-                const bool rowok = f < BM * F4A && m0 + m < p.Cout;
-                const float* src = dyb + (size_t)(m0 + m) * HWo;
-                if constexpr (VEC) ra[j] = (rowok && k0 + 4 * g < HW) ? *reinterpret_cast<const v4f*>(src + 4 * g) : (v4f){0.f, 0.f, 0.f, 0.f};
-                else if (inner) {
-                    if (rowok) { const v4fu u = *reinterpret_cast<const v4fu*>(src + 4 * g); ra[j] = (v4f){u[0], u[1], u[2], u[3]}; }
-                    else ra[j] = (v4f){0.f, 0.f, 0.f, 0.f};
-                } else una_load(src + 4 * g, rowok ? HW - k0 - 4 * g : 0, dy_end, ra[j], ma[j]);
-            }
-#pragma unroll
-            for (int j = 0; j < NB; ++j) {
-                const int f = tid + j * kWgThreads;
-                const int c = f / F4C, g = f % F4C;
-                const bool rowok = f < BC * F4C && c0 + c < p.Cin;
-                const float* src = xb + (size_t)(c0 + c) * HW;
-                if constexpr (VEC) rb[j] = (rowok && k0 + 4 * g < HW) ? *reinterpret_cast<const v4f*>(src + 4 * g) : (v4f){0.f, 0.f, 0.f, 0.f};
-                else if (inner) {
-                    if (rowok) { const v4fu u = *reinterpret_cast<const v4fu*>(src + 4 * g); rb[j] = (v4f){u[0], u[1], u[2], u[3]}; }
-                    else rb[j] = (v4f){0.f, 0.f, 0.f, 0.f};
-                } else una_load(src + 4 * g, rowok ? HW - k0 - 4 * g : 0, x_end, rb[j], mb[j]);
-            }
+            const int n = q / cpi;
+            fc.k0 = (q - n * cpi) * KP;
+            fc.dyb = p.dy + (size_t)n * p.Cout * HWo + fc.k0;
+            fc.xb = p.x + (size_t)n * p.Cin * HW + fc.k0;
+            fc.inner = !VEC && fc.k0 + KP <= HW;           // (FLAT: HW == HWo)
+            fix_next = !fc.inner;
         } else {
             const int tpi = p.tiles_x * p.tiles_y;
             const int n = q / tpi, r = q - n * tpi;
             const int tyi = r / p.tiles_x, txi = r - tyi * p.tiles_x;
-            const int oy0 = tyi * G::TH, ox0 = txi * TW;
-            const int iy0 = oy0 * STRIDE - PAD, ix0 = ox0 * STRIDE - 4;
-            const float* dyb = p.dy + (size_t)n * p.Cout * HWo;
-            const float* xb = p.x + (size_t)n * p.Cin * HW;
-            constexpr int GA = ARUN / 4 + AL, GB = BRUN / 4 + AL;       // groups per run
-#pragma unroll
-            for (int j = 0; j < NA; ++j) {
-                const int f = tid + j * kWgThreads;
-                const int m = f / F4A, rem = f % F4A;
-                const int ty = rem / GA, g = rem % GA;
-                const int oy = oy0 + ty;
-                const bool rowok = f < BM * F4A && m0 + m < p.Cout && oy < p.Ho;
-                const float* src = dyb + (size_t)(m0 + m) * HWo + oy * p.Wo + ox0;
-                if constexpr (VEC) ra[j] = (rowok && ox0 + 4 * g < p.Wo) ? *reinterpret_cast<const v4f*>(src + 4 * g) : (v4f){0.f, 0.f, 0.f, 0.f};
-                else una_load(src + 4 * g, rowok ? p.Wo - ox0 - 4 * g : 0, dy_end, ra[j], ma[j]);
-            }
-#pragma unroll
-            for (int j = 0; j < NB; ++j) {
-                const int f = tid + j * kWgThreads;
-                const int c = f / F4C, rem = f % F4C;
-                const int row = rem / GB, g = rem % GB;
-                const int iy = iy0 + row;
-                const bool rowok = f < BC * F4C && c0 + c < p.Cin && (unsigned)iy < (unsigned)p.H;
-                const float* src = xb + ((long long)(c0 + c) * HW + (long long)iy * p.W + ix0);
-                if constexpr (VEC) rb[j] = (rowok && (unsigned)(ix0 + 4 * g) < (unsigned)p.W) ? *reinterpret_cast<const v4f*>(src + 4 * g) : (v4f){0.f, 0.f, 0.f, 0.f};
-                else una_load(src + 4 * g, (rowok && ix0 + 4 * g >= 0) ? p.W - ix0 - 4 * g : 0, x_end, rb[j], mb[j]);
+            fc.oy0 = tyi * G::TH; fc.ox0 = txi * TW;
+            fc.iy0 = fc.oy0 * STRIDE - PAD; fc.ix0 = fc.ox0 * STRIDE - 4;
+            fc.dyb = p.dy + (size_t)n * p.Cout * HWo;
+            fc.xb = p.x + (size_t)n * p.Cin * HW;
+        }
+    };
+    constexpr int GAr = ARUN / 4 + AL, GBr = BRUN / 4 + AL;       // groups per run
+    auto fetch_a = [&](auto jc) {
+        constexpr int j = decltype(jc)::value;
+        const int f = tid + j * kWgThreads;
+        if (FLAT) {
+            const int m = f / F4A, g = f % F4A;
+            const bool rowok = f < BM * F4A && m0 + m < p.Cout;
+            const float* src = fc.dyb + (size_t)(m0 + m) * HWo;
+            if constexpr (VEC) ra[j] = (rowok && fc.k0 + 4 * g < HW) ? *reinterpret_cast<const v4f*>(src + 4 * g) : (v4f){0.f, 0.f, 0.f, 0.f};
+            else if (fc.inner) {
+                if (rowok) { const v4fu u = *reinterpret_cast<const v4fu*>(src + 4 * g); ra[j] = (v4f){u[0], u[1], u[2], u[3]}; }
+                else ra[j] = (v4f){0.f, 0.f, 0.f, 0.f};
+            } else una_load(src + 4 * g, rowok ? HW - fc.k0 - 4 * g : 0, dy_end, ra[j], ma[VEC ? 0 : j]);
+        } else {
+            const int m = f / F4A, rem = f % F4A;
+            const int ty = rem / GAr, g = rem % GAr;
+            const int oy = fc.oy0 + ty;
+            const bool rowok = f < BM * F4A && m0 + m < p.Cout && oy < p.Ho;
+            const float* src = fc.dyb + (size_t)(m0 + m) * HWo + oy * p.Wo + fc.ox0;
+            if constexpr (VEC) ra[j] = (rowok && fc.ox0 + 4 * g < p.Wo) ? *reinterpret_cast<const v4f*>(src + 4 * g) : (v4f){0.f, 0.f, 0.f, 0.f};
+            else una_load(src + 4 * g, rowok ? p.Wo - fc.ox0 - 4 * g : 0, dy_end, ra[j], ma[VEC ? 0 : j]);
+        }
+    };
+    auto fetch_b = [&](auto jc) {
+        constexpr int j = decltype(jc)::value;
+        const int f = tid + j * kWgThreads;
+        if (FLAT) {
+            const int c = f / F4C, g = f % F4C;
+            const bool rowok = f < BC * F4C && c0 + c < p.Cin;
+            const float* src = fc.xb + (size_t)(c0 + c) * HW;
+            if constexpr (VEC) rb[j] = (rowok && fc.k0 + 4 * g < HW) ? *reinterpret_cast<const v4f*>(src + 4 * g) : (v4f){0.f, 0.f, 0.f, 0.f};
+            else if (fc.inner) {
+                if (rowok) { const v4fu u = *reinterpret_cast<const v4fu*>(src + 4 * g); rb[j] = (v4f){u[0], u[1], u[2], u[3]}; }
+                else rb[j] = (v4f){0.f, 0.f, 0.f, 0.f};
+            } else una_load(src + 4 * g, rowok ? HW - fc.k0 - 4 * g : 0, x_end, rb[j], mb[VEC ? 0 : j]);
+        } else {
+            const int c = f / F4C, rem = f % F4C;
+            const int row = rem / GBr, g = rem % GBr;
+            const int iy = fc.iy0 + row;
+            const bool rowok = f < BC * F4C && c0 + c < p.Cin && (unsigned)iy < (unsigned)p.H;
+            const float* src = fc.xb + ((long long)(c0 + c) * HW + (long long)iy * p.W + fc.ix0);
+            if constexpr (VEC) rb[j] = (rowok && (unsigned)(fc.ix0 + 4 * g) < (unsigned)p.W) ? *reinterpret_cast<const v4f*>(src + 4 * g) : (v4f){0.f, 0.f, 0.f, 0.f};
+            else una_load(src + 4 * g, (rowok && fc.ix0 + 4 * g >= 0) ? p.W - fc.ix0 - 4 * g : 0, x_end, rb[j], mb[VEC ? 0 : j]);
+        }
+    };
+    auto fetch = [&](int q) {
+        fetch_begin(q);
+        wg_static_for<0, NA>([&](auto jc) { fetch_a(jc); });
+        wg_static_for<0, NB>([&](auto jc) { fetch_b(jc); });
+    };
+
+    auto stage_a = [&](int buf, auto jc) {
+        constexpr int j = decltype(jc)::value;
+        float* sA = wg_smem + buf * (ASZ + BSZ);
+        const int f = tid + j * kWgThreads;
+        if (f < BM * F4A) {
+            float* run = sA + (f / F4A) * RS + ((f % F4A) / GAr) * ARUN;
+            *reinterpret_cast<v4f*>(run + ((f % F4A) % GAr) * 4) = (VEC || !fix_regs) ? ra[j] : una_fix(ra[j], ma[VEC ? 0 : j]);
+        }
+    };
+    auto stage_b = [&](int buf, auto jc) {
+        constexpr int j = decltype(jc)::value;
+        float* sB = wg_smem + buf * (ASZ + BSZ) + ASZ;
+        const int f = tid + j * kWgThreads;
+        if (f < BC * F4C) {
+            float* run = sB + (f / F4C) * CS + ((f % F4C) / GBr) * BRUN;
+            const v4f vb = (VEC || !fix_regs) ? rb[j] : una_fix(rb[j], mb[VEC ? 0 : j]);
+            if constexpr (FLAT) {
+                *reinterpret_cast<v4f*>(run + ((f % F4C) % GBr) * 4) = vb;
+            } else {
+                float* dst = run + ((f % F4C) % GBr) * 4;            // channel stride is odd: four 4-byte stores
+                dst[0] = vb[0]; dst[1] = vb[1]; dst[2] = vb[2]; dst[3] = vb[3];
             }
         }
     };
-
     auto stage = [&](int buf) {
-        float* sA = wg_smem + buf * (ASZ + BSZ);
-        float* sB = sA + ASZ;
-        constexpr int GA = ARUN / 4 + AL, GB = BRUN / 4 + AL;
-#pragma unroll
-        for (int j = 0; j < NA; ++j) {
-            const int f = tid + j * kWgThreads;
-            if (f < BM * F4A) {
-                float* run = sA + (f / F4A) * RS + ((f % F4A) / GA) * ARUN;
-                *reinterpret_cast<v4f*>(run + ((f % F4A) % GA) * 4) = (VEC || !fix_regs) ? ra[j] : una_fix(ra[j], ma[VEC ? 0 : j]);
-            }
-        }
-#pragma unroll
-        for (int j = 0; j < NB; ++j) {
-            const int f = tid + j * kWgThreads;
-            if (f < BC * F4C) {
-                float* run = sB + (f / F4C) * CS + ((f % F4C) / GB) * BRUN;
-                const v4f vb = (VEC || !fix_regs) ? rb[j] : una_fix(rb[j], mb[VEC ? 0 : j]);
-                if constexpr (FLAT) {
-                    *reinterpret_cast<v4f*>(run + ((f % F4C) % GB) * 4) = vb;
-                } else {
-                    float* dst = run + ((f % F4C) % GB) * 4;            // channel stride is odd: four 4-byte stores
-                    dst[0] = vb[0]; dst[1] = vb[1]; dst[2] = vb[2]; dst[3] = vb[3];
-                }
-            }
-        }
+        wg_static_for<0, NA>([&](auto jc) { stage_a(buf, jc); });
+        wg_static_for<0, NB>([&](auto jc) { stage_b(buf, jc); });
     };
 
     f32x16 acc[NT0];
@@ -247,11 +268,9 @@ __global__ __launch_bounds__(kWgThreads) void k_wgrad(const WgP p) {
     const int aoff = (mtw * 32 + l31) * RS + 4 * h + khw * (KP / 2);
     const int boff = FLAT ? (tg * NT0 * 32 + l31) * CS + 4 * h : l31 * CS + 4 * h * STRIDE + khw * ((KP / 2) / TW) * STRIDE * PWL;
     constexpr int JN = KP / 8 / KH;                 // groups of four MFMA k-steps per chunk and wave
-    constexpr int JSPLIT = (3 * JN + 3) / 4;        // the next chunk is written to LDS after this many groups (its loads have had
-                                                    // 3/4 of a chunk to arrive; the other buffer's readers are behind the last barrier)
     // The LDS operands of a group of four k-steps are requested one group ahead of the MFMAs that consume them (sched_barrier
     // pins the order): the two waves of a SIMD run the same phase, nothing else hides an LDS round trip.
-    auto mfma_chunk = [&](int buf, auto T0c, auto TNc, auto JLc, auto JHc) {
+    auto mfma_chunk = [&](int buf, auto T0c, auto TNc, auto JLc, auto JHc, auto&& hook) {
         constexpr int T0 = decltype(T0c)::value, TN = decltype(TNc)::value, jlo = decltype(JLc)::value, jhi = decltype(JHc)::value;
         const float* sA = wg_smem + buf * (ASZ + BSZ);
         const float* sB = sA + ASZ;
@@ -283,8 +302,8 @@ __global__ __launch_bounds__(kWgThreads) void k_wgrad(const WgP p) {
         if constexpr (jlo < jhi) {
             Group cur, nxt;
             load_group(jlo, cur);
-#pragma unroll
-            for (int jl = jlo; jl < jhi; ++jl) {
+            wg_static_for<jlo, jhi>([&](auto jlc) {
+                constexpr int jl = decltype(jlc)::value;
                 if (jl + 1 < jhi) load_group(jl + 1, nxt);
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -292,21 +311,28 @@ __global__ __launch_bounds__(kWgThreads) void k_wgrad(const WgP p) {
 #pragma unroll
                     for (int t = 0; t < TN; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(cur.a[i], cur.b[i][t], acc[t], 0, 0, 0);
                 __builtin_amdgcn_sched_barrier(0);
+                hook(jlc);                              // staging work that rides in the shadow of this group's MFMAs
+                __builtin_amdgcn_sched_barrier(0);
                 if (jl + 1 < jhi) cur = nxt;
-            }
+            });
         }
     };
-    auto mfma = [&](int buf, auto jlo, auto jhi) {
+    auto mfma = [&](int buf, auto jlo, auto jhi, auto&& hook) {
         if constexpr (FLAT) {           // the wave's tile group is an address offset (boff)
-            mfma_chunk(buf, std::integral_constant<int, 0>{}, std::integral_constant<int, NT0>{}, jlo, jhi);
+            mfma_chunk(buf, std::integral_constant<int, 0>{}, std::integral_constant<int, NT0>{}, jlo, jhi, hook);
         } else {                        // tap subsets differ per group: two instruction streams, chosen per wave
-            if (tg == 0) mfma_chunk(buf, std::integral_constant<int, 0>{}, std::integral_constant<int, NT0>{}, jlo, jhi);
-            else if constexpr (NT - NT0 > 0) mfma_chunk(buf, std::integral_constant<int, NT0>{}, std::integral_constant<int, NT - NT0>{}, jlo, jhi);
+            if (tg == 0) mfma_chunk(buf, std::integral_constant<int, 0>{}, std::integral_constant<int, NT0>{}, jlo, jhi, hook);
+            else if constexpr (NT - NT0 > 0) mfma_chunk(buf, std::integral_constant<int, NT0>{}, std::integral_constant<int, NT - NT0>{}, jlo, jhi, hook);
+            else wg_static_for<decltype(jlo)::value, decltype(jhi)::value>(hook);     // (a wave without tiles still stages its slots)
         }
     };
 
     // The registers that carried chunk q + 1 to LDS are refilled with chunk q + 2 right behind that store: a load has a whole
-    // iteration to arrive.
+    // iteration to arrive.  As in k_conv_sk, this work rides slot by slot behind the wave's OWN MFMA groups (the first form ran it as
+    // one burst after three quarters of the chunk's MFMAs: while one wave of a SIMD issues MFMAs back to back its partner's
+    // instructions are starved, so a burst of ~8 LDS stores + 8 loads + their address arithmetic stretched over the partner's whole
+    // multiply phase -- tools/sk_phases.py measured that on the forward kernel).  The loop body has no branch: past the last chunk
+    // the stores go to the buffer nobody reads any more and the loads re-read the last chunk (an L2 hit).
     int buf = 0;
     fetch(q0);
     fix_regs = fix_next;
@@ -316,16 +342,25 @@ __global__ __launch_bounds__(kWgThreads) void k_wgrad(const WgP p) {
         fix_regs = fix_next;
     }
     __syncthreads();
+    constexpr int NS = NA + NB;
     for (int q = q0; q < q1; ++q) {
-        mfma(buf, std::integral_constant<int, 0>{}, std::integral_constant<int, JSPLIT>{});
-        if (q + 1 < q1) {
-            stage(buf ^ 1);
-            if (q + 2 < q1) {
-                fetch(q + 2);
-                fix_regs = fix_next;
-            }
-        }
-        mfma(buf, std::integral_constant<int, JSPLIT>{}, std::integral_constant<int, JN>{});
+        fetch_begin(q + 2 < q1 ? q + 2 : q1 - 1);
+        const bool fix2 = fix_next;
+        mfma(buf, std::integral_constant<int, 0>{}, std::integral_constant<int, JN>{}, [&](auto jlc) {
+            constexpr int jl = decltype(jlc)::value;
+            constexpr int s0 = jl * NS / JN, s1 = (jl + 1) * NS / JN;
+            wg_static_for<s0, s1>([&](auto sc) {
+                constexpr int S = decltype(sc)::value;
+                if constexpr (S < NA) {
+                    stage_a(buf ^ 1, std::integral_constant<int, S>{});
+                    fetch_a(std::integral_constant<int, S>{});
+                } else {
+                    stage_b(buf ^ 1, std::integral_constant<int, S - NA>{});
+                    fetch_b(std::integral_constant<int, S - NA>{});
+                }
+            });
+        });
+        fix_regs = fix2;
         __syncthreads();
         buf ^= 1;
     }
