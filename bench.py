@@ -707,20 +707,22 @@ def main():
     invT = ops.inv_temperature(0.1)
     bufs = [make_batch(1000 * rank + 17 * i + 1, B, C, H, W, S, args.id_dtype, dev) for i in range(args.nbuf)]
 
-    # untimed clock ramp: the first ~50 launches after an idle period run ~20 % slower than the steady state (power
-    # management), whatever --warmup the caller passes
     p0 = torch.zeros((B, C), dtype=torch.int64, device=dev)
     c0 = torch.zeros((B, S, C), dtype=torch.int64, device=dev)
     h0 = torch.zeros((B, S, C), dtype=torch.int32, device=dev)
-    for k in range(args.ramp):
-        z, spx = bufs[k % args.nbuf]
-        ops.single_pass_accum(z, spx, S, invT, prob_sum=p0, class_sum=c0, hist=h0)
     if args.warmup:
         ScanRound(args, dev, rank, world, backend, bufs, args.warmup).run(False)
     timed = ScanRound(args, dev, rank, world, backend, bufs, args.steps)
     timed.rnd.hw = H * W
     timed.tail()            # untimed, on the still-empty accumulators: the timed round's buffers come out of torch's caching
     #                         allocator instead of hipMalloc (a long-lived trainer process is in that state from round 2 on)
+    # untimed clock ramp, LAST thing before the timed region: the first ~50 launches after an idle period run ~20 % slower than the
+    # steady state (power management), and the set-up above (allocations, the warm-up round's tail with its host read) leaves the
+    # GPU idle for milliseconds.  Until round 4 the ramp ran BEFORE that set-up: the driver's 20 timed steps (3.2 ms) then started
+    # on a GPU that had just idled and read 166 us per scan where 200 steps read 153 (same code, same box).
+    for k in range(args.ramp):
+        z, spx = bufs[k % args.nbuf]
+        ops.single_pass_accum(z, spx, S, invT, prob_sum=p0, class_sum=c0, hist=h0)
     fence()
     t0 = time.perf_counter()
     n_selected = timed.run(True)

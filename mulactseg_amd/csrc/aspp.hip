@@ -177,7 +177,13 @@ __global__ __launch_bounds__(kThreads) void k_dw_strip(const float* __restrict__
 // grid: (ceil(W / 256), ceil(H / kRowsPerLane), N*C), block: one wave per 256 columns x 4 row groups... (64 x 4 threads).
 constexpr int kRowsPerLane = 16;
 
-template <bool FLIP>
+// ALIGNED: W % 4 == 0 and 16-byte aligned tensors.  !ALIGNED (the 193 x 193 decoder plane of the 769 crop: every row starts at another
+// 4-byte alignment): the same 16-byte accesses at 4-byte aligned addresses (gfx950 runs them at the aligned rate,
+// tools/micro/unaligned.hip); the last group of a row, when it is not whole, goes element by element.  (That plane used to take the
+// LDS-strip kernel: 501 vs ~340 us per training step for the four calls.)
+typedef float dw_v4u __attribute__((ext_vector_type(4), aligned(4)));
+
+template <bool FLIP, bool ALIGNED>
 __global__ __launch_bounds__(kThreads) void k_dw_rows(const float* __restrict__ x, const float* __restrict__ w, int C, int H, int W,
                                                        float* __restrict__ y) {
     const int lane = threadIdx.x & (MAS_WAVE - 1), wave = threadIdx.x / MAS_WAVE;
@@ -196,9 +202,17 @@ __global__ __launch_bounds__(kThreads) void k_dw_rows(const float* __restrict__ 
     auto load_row = [&](int gy, float (&dst)[6]) {
         if (gy >= 0 && gy < H) {
             const float* p = xp + (size_t)gy * W + x0;
-            const float4 v = *reinterpret_cast<const float4*>(p);
             dst[0] = x0 > 0 ? p[-1] : 0.0f;
-            dst[1] = v.x; dst[2] = v.y; dst[3] = v.z; dst[4] = v.w;
+            if (ALIGNED) {
+                const float4 v = *reinterpret_cast<const float4*>(p);
+                dst[1] = v.x; dst[2] = v.y; dst[3] = v.z; dst[4] = v.w;
+            } else if (x0 + 4 <= W) {
+                const dw_v4u v = *reinterpret_cast<const dw_v4u*>(p);
+                dst[1] = v[0]; dst[2] = v[1]; dst[3] = v[2]; dst[4] = v[3];
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) dst[1 + j] = x0 + j < W ? p[j] : 0.0f;
+            }
             dst[5] = x0 + 4 < W ? p[4] : 0.0f;
         } else {
 #pragma unroll
@@ -220,7 +234,16 @@ __global__ __launch_bounds__(kThreads) void k_dw_rows(const float* __restrict__ 
                 for (int b = 0; b < 3; ++b) acc = mas_fmaf(k[a * 3 + b], r[a][j + b], acc);
             o[j] = acc;
         }
-        *reinterpret_cast<float4*>(yp + (size_t)gy * W + x0) = make_float4(o[0], o[1], o[2], o[3]);
+        float* q = yp + (size_t)gy * W + x0;
+        if (ALIGNED) {
+            *reinterpret_cast<float4*>(q) = make_float4(o[0], o[1], o[2], o[3]);
+        } else if (x0 + 4 <= W) {
+            *reinterpret_cast<dw_v4u*>(q) = (dw_v4u){o[0], o[1], o[2], o[3]};
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                if (x0 + j < W) q[j] = o[j];
+        }
 #pragma unroll
         for (int j = 0; j < 6; ++j) { r[0][j] = r[1][j]; r[1][j] = r[2][j]; }
     }
@@ -315,11 +338,17 @@ static int dw_launch(bool flip, const float* x, const float* w, int N, int C, in
     const size_t smem = sizeof(float) * (size_t)(kStripH + 2 * d) * (W + 2 * d);
     if (smem > 64 * 1024 || (long long)N * C * strips > 0x7fffffffLL) return MAS_ERR_SHAPE;
     hipStream_t st = static_cast<hipStream_t>(stream);
-    if (d == 1 && W % 4 == 0 && (((uintptr_t)x | (uintptr_t)y) & 15) == 0 && (long long)N * C <= 65535) {
+    if (d == 1 && W >= 16 && (((uintptr_t)x | (uintptr_t)y) & 3) == 0 && (long long)N * C <= 65535) {
         const dim3 grid((unsigned)((W + 4 * MAS_WAVE - 1) / (4 * MAS_WAVE)),
                         (unsigned)((H + kRowsPerLane * (kThreads / MAS_WAVE) - 1) / (kRowsPerLane * (kThreads / MAS_WAVE))), (unsigned)(N * C));
-        if (flip) hipLaunchKernelGGL((k_dw_rows<true>), grid, dim3(kThreads), 0, st, x, w, C, H, W, y);
-        else hipLaunchKernelGGL((k_dw_rows<false>), grid, dim3(kThreads), 0, st, x, w, C, H, W, y);
+        const bool aligned = W % 4 == 0 && (((uintptr_t)x | (uintptr_t)y) & 15) == 0;
+        if (aligned) {
+            if (flip) hipLaunchKernelGGL((k_dw_rows<true, true>), grid, dim3(kThreads), 0, st, x, w, C, H, W, y);
+            else hipLaunchKernelGGL((k_dw_rows<false, true>), grid, dim3(kThreads), 0, st, x, w, C, H, W, y);
+        } else {
+            if (flip) hipLaunchKernelGGL((k_dw_rows<true, false>), grid, dim3(kThreads), 0, st, x, w, C, H, W, y);
+            else hipLaunchKernelGGL((k_dw_rows<false, false>), grid, dim3(kThreads), 0, st, x, w, C, H, W, y);
+        }
         return mas_launch_status();
     }
     if (flip)

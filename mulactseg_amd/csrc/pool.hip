@@ -23,7 +23,10 @@ __global__ __launch_bounds__(kThreads) void k_maxpool3s2_fwd(const float* __rest
     float best[4] = {ninf, ninf, ninf, ninf};
     int where[4] = {-1, -1, -1, -1};
     const int c0 = ox0 * 2;                          // first even column; the window of output k spans c0 + 2k - 1 .. c0 + 2k + 1
-    const bool vec = ((W & 3) == 0) && (c0 + 7 < W);
+    // 16-byte loads at 4-byte aligned addresses run at the aligned rate on gfx950 (tools/micro/unaligned.hip): rows of any width
+    // (the 385-wide plane of the 769 crop) take them; only the group astride the row's end goes element by element
+    typedef float mp_v4u __attribute__((ext_vector_type(4), aligned(4)));
+    const bool vec = c0 + 7 < W;
 #pragma unroll
     for (int a = 0; a < 3; ++a) {
         const int iy = oy * 2 - 1 + a;
@@ -32,9 +35,9 @@ __global__ __launch_bounds__(kThreads) void k_maxpool3s2_fwd(const float* __rest
         float v[9];                                   // columns c0 - 1 .. c0 + 7
         bool in[9];
         if (vec) {
-            const float4 q0 = *reinterpret_cast<const float4*>(row + c0);
-            const float4 q1 = *reinterpret_cast<const float4*>(row + c0 + 4);
-            v[1] = q0.x; v[2] = q0.y; v[3] = q0.z; v[4] = q0.w; v[5] = q1.x; v[6] = q1.y; v[7] = q1.z; v[8] = q1.w;
+            const mp_v4u q0 = *reinterpret_cast<const mp_v4u*>(row + c0);
+            const mp_v4u q1 = *reinterpret_cast<const mp_v4u*>(row + c0 + 4);
+            v[1] = q0[0]; v[2] = q0[1]; v[3] = q0[2]; v[4] = q0[3]; v[5] = q1[0]; v[6] = q1[1]; v[7] = q1[2]; v[8] = q1[3];
             in[0] = c0 > 0;
             v[0] = in[0] ? row[c0 - 1] : ninf;
 #pragma unroll
@@ -61,9 +64,14 @@ __global__ __launch_bounds__(kThreads) void k_maxpool3s2_fwd(const float* __rest
             }
     }
     const size_t o = (nc * Ho + oy) * Wo + ox0;
-    if (ox0 + 3 < Wo && (Wo & 3) == 0) {
-        *reinterpret_cast<float4*>(y + o) = make_float4(best[0], best[1], best[2], best[3]);
-        *reinterpret_cast<uchar4*>(arg + o) = make_uchar4((unsigned char)where[0], (unsigned char)where[1], (unsigned char)where[2], (unsigned char)where[3]);
+    if (ox0 + 3 < Wo) {
+        *reinterpret_cast<mp_v4u*>(y + o) = (mp_v4u){best[0], best[1], best[2], best[3]};
+        if ((Wo & 3) == 0) {
+            *reinterpret_cast<uchar4*>(arg + o) = make_uchar4((unsigned char)where[0], (unsigned char)where[1], (unsigned char)where[2], (unsigned char)where[3]);
+        } else {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) arg[o + k] = (unsigned char)where[k];
+        }
     } else {
 #pragma unroll
         for (int k = 0; k < 4; ++k)

@@ -43,7 +43,7 @@ def test_depthwise_triple_matches_conv2d(N, C, H, W):
 
 
 @pytest.mark.parametrize("N,C,H,W,d", [(2, 48, 48, 48, 1), (4, 38, 192, 192, 1), (1, 16, 37, 53, 1), (2, 8, 20, 300, 2), (1, 4, 16, 16, 6), (1, 5, 70, 260, 1),
-                                       (2, 3, 5, 8, 1)])
+                                       (2, 3, 5, 8, 1), (2, 6, 193, 193, 1), (1, 4, 33, 18, 1), (1, 3, 20, 259, 1)])
 def test_single_depthwise_matches_conv2d(N, C, H, W, d):
     """Decoder depthwise 3x3 (mas_depthwise3x3_*) against float64 conv2d: forward, dx, dw; dw deterministic."""
     _need()

@@ -7,7 +7,7 @@ import torch.nn as nn
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("N,C,H,W", [(2, 3, 16, 20), (1, 4, 17, 23), (2, 2, 1, 5), (1, 8, 96, 192), (1, 1, 2, 2)])
+@pytest.mark.parametrize("N,C,H,W", [(2, 3, 16, 20), (1, 4, 17, 23), (2, 2, 1, 5), (1, 8, 96, 192), (1, 1, 2, 2), (1, 3, 385, 385), (2, 2, 33, 41)])
 def test_maxpool_matches_pytorch(N, C, H, W):
     if not torch.cuda.is_available():
         pytest.skip("needs a GPU")
