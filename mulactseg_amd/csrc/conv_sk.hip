@@ -58,6 +58,11 @@ struct SkP {
     long long xstep;            // floats from a chunk's first channel to the next chunk's (CK * H * W)
     int P;                      // workgroups (one per CU)
     int rdp, sk_iters;          // whole tiles per workgroup (rounds of P tiles), iterations of the remaining tiles (stream-K part)
+    // BatchNorm partials (p.stats): entry (row m, slot, group ng) at stats[m * stats_pitch + slot * NG + ng].  stats_acc: the
+    // workgroup-accumulated layout (sk_stats_layout): slot = g / mtiles for the whole tiles of workgroup g (all of ONE M tile when P
+    // is a multiple of mtiles: their sums stay in registers across the tiles and are folded and stored once), stats_w + t / mtiles
+    // for stream-K tile t.  !stats_acc: one entry per (pixel tile, group), slot = pt.
+    int stats_acc, stats_w, stats_pitch;
     int nosplit;                // MAS_SK_NOSPLIT: the remaining tiles go WHOLE to the first workgroups (no hand-off at all)
     unsigned spin_limit;        // polls a finisher waits for one contributor before it gives up
 };
@@ -750,6 +755,59 @@ __global__ __launch_bounds__(kSkThreads) void k_conv_sk(const SkP p) {
         }
     };
 
+    // the M tiles with one stream-K tile fewer than the others leave their last slot without a writer: workgroup 0 zeroes it
+    if (p.stats && p.stats_acc && g == 0) {
+        const int sk_tiles = p.sk_iters / p.nch, rem = sk_tiles % p.mtiles;
+        if (rem != 0) {
+            const int slot = p.stats_w + sk_tiles / p.mtiles;
+            for (int e = tid; e < (p.mtiles - rem) * BM * NG; e += kSkThreads) {
+                const int m = rem * BM + e / NG;
+                if (m < p.M) p.stats[(size_t)m * p.stats_pitch + (size_t)slot * NG + e % NG] = make_double2(0.0, 0.0);
+            }
+        }
+    }
+    // BatchNorm partials: per accumulator row of this lane, over the pixels of the tiles finished so far in the current slot
+    float rsum[16], rsq[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) rsum[r] = rsq[r] = 0.0f;
+    int run_slot = -1, run_m0 = 0;
+    // fold the 32 lanes of a half-wave (a fixed order) and store the entry of (row, run_slot, ng)
+    auto stats_flush = [&]() {
+        auto fold = [&](float (&a)[16]) -> float {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const bool up = lane & 1;
+                const float send = up ? a[i] : a[i + 8], keep = up ? a[i + 8] : a[i];
+                a[i] = keep + __shfl_xor(send, 1, 64);
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const bool up = lane & 2;
+                const float send = up ? a[i] : a[i + 4], keep = up ? a[i + 4] : a[i];
+                a[i] = keep + __shfl_xor(send, 2, 64);
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const bool up = lane & 4;
+                const float send = up ? a[i] : a[i + 2], keep = up ? a[i + 2] : a[i];
+                a[i] = keep + __shfl_xor(send, 4, 64);
+            }
+            {
+                const bool up = lane & 8;
+                const float send = up ? a[0] : a[1], keep = up ? a[1] : a[0];
+                a[0] = keep + __shfl_xor(send, 8, 64);
+            }
+            return a[0] + __shfl_xor(a[0], 16, 64);
+        };
+        const float S = fold(rsum), Q = fold(rsq);
+        const int r = 8 * (lane & 1) + 4 * ((lane >> 1) & 1) + 2 * ((lane >> 2) & 1) + ((lane >> 3) & 1);
+        const int m = mtw * 32 + 4 * h + (r & 3) + 8 * (r >> 2);
+        if (!(lane & 16) && run_m0 + m < p.M)
+            p.stats[(size_t)(run_m0 + m) * p.stats_pitch + (size_t)run_slot * NG + ng] = make_double2((double)S, (double)Q);
+#pragma unroll
+        for (int r2 = 0; r2 < 16; ++r2) rsum[r2] = rsq[r2] = 0.0f;
+    };
+
     int it = it0;
     while (it < it1) {
         int tile, c0, seg;
@@ -884,57 +942,32 @@ __global__ __launch_bounds__(kSkThreads) void k_conv_sk(const SkP p) {
         }
         if (p.stats) {
             // (the host admits statistics only for the bare product: y = acc)
-            float ssum[16], ssq[16];            // per accumulator row of this lane: sum and sum of squares over its pixels
-#pragma unroll
-            for (int r = 0; r < 16; ++r) ssum[r] = ssq[r] = 0.0f;
+            // BatchNorm partials: the 32 lanes of a half-wave hold the same 16 rows; stats_flush folds them with a halving butterfly
+            // (a fixed order: the partials, and the statistics k_bn_stats_wide forms from them in double, are run-to-run identical).
+            // Workgroup-accumulated layout: the sums of this workgroup's whole tiles -- one M tile -- stay in registers from tile to
+            // tile (32 fmas per tile) and are folded and stored ONCE; the per-tile form paid 2 x 15 cross-lane exchanges and 256
+            // scattered 16-byte stores per tile (one chunk per tile in layer1: 90 vs 80 us with / without statistics for 64 -> 256).
+            const int slot = p.stats_acc ? (tile < p.rdp * P ? g / p.mtiles : p.stats_w + (tile - p.rdp * P) / p.mtiles) : pt;
+            if (slot != run_slot) {
+                if (run_slot >= 0) stats_flush();
+                run_slot = slot;
+                run_m0 = m0;
+            }
 #pragma unroll
             for (int tn = 0; tn < TN; ++tn) {
                 const int oy = oy0 + (pl[tn] >> G::TWLOG), ox = ox0 + (pl[tn] & (TW - 1));
                 if (oy < p.Ho && ox < p.Wo) {
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
-                        ssum[r] += acc[tn][r];
-                        ssq[r] += acc[tn][r] * acc[tn][r];
+                        rsum[r] += acc[tn][r];
+                        rsq[r] += acc[tn][r] * acc[tn][r];
                     }
                 }
             }
-            // BatchNorm partials of the tile: the 32 lanes of a half-wave hold the same 16 rows; a halving butterfly (lane bit k
-            // keeps one half of the rows and receives the partner's sums of them: 8 + 4 + 2 + 1 exchanges, then one across the two
-            // 16-lane groups) leaves row 8 b0 + 4 b1 + 2 b2 + b3 of the lane's bits with the sum over all 32 pixels columns --
-            // a fixed order, so the partials (and the statistics k_bn_stats forms from them, in double) are run-to-run identical
-            auto fold = [&](float (&a)[16]) -> float {
-#pragma unroll
-                for (int i = 0; i < 8; ++i) {
-                    const bool up = lane & 1;
-                    const float send = up ? a[i] : a[i + 8], keep = up ? a[i + 8] : a[i];
-                    a[i] = keep + __shfl_xor(send, 1, 64);
-                }
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const bool up = lane & 2;
-                    const float send = up ? a[i] : a[i + 4], keep = up ? a[i + 4] : a[i];
-                    a[i] = keep + __shfl_xor(send, 2, 64);
-                }
-#pragma unroll
-                for (int i = 0; i < 2; ++i) {
-                    const bool up = lane & 4;
-                    const float send = up ? a[i] : a[i + 2], keep = up ? a[i + 2] : a[i];
-                    a[i] = keep + __shfl_xor(send, 4, 64);
-                }
-                {
-                    const bool up = lane & 8;
-                    const float send = up ? a[0] : a[1], keep = up ? a[1] : a[0];
-                    a[0] = keep + __shfl_xor(send, 8, 64);
-                }
-                return a[0] + __shfl_xor(a[0], 16, 64);
-            };
-            const float S = fold(ssum), Q = fold(ssq);
-            const int r = 8 * (lane & 1) + 4 * ((lane >> 1) & 1) + 2 * ((lane >> 2) & 1) + ((lane >> 3) & 1);
-            const int m = mtw * 32 + 4 * h + (r & 3) + 8 * (r >> 2);
-            if (!(lane & 16) && m < mlim) p.stats[((size_t)(m0 + m) * p.ptiles + pt) * NG + ng] = make_double2((double)S, (double)Q);
         }
         if (p.stamps && tid == 0 && it >= it1) p.stamps[4 * g + 2] = wall_clock64();
     }
+    if (p.stats && run_slot >= 0) stats_flush();
     if (p.stamps && tid == 0) p.stamps[4 * g + 3] = wall_clock64();
 }
 
@@ -1085,6 +1118,22 @@ int sk_launch(const SkP& p, hipStream_t st) {
     return mas_launch_status();
 }
 
+// Layout of the BatchNorm partials (see SkP::stats_w): entries per row = stats_pitch.  The workgroup-accumulated form needs every
+// workgroup's whole tiles in ONE M tile (tile = r * P + g with the M tile fastest: P a multiple of mtiles).
+inline void sk_stats_layout(SkP& p, const SkGeom& g) {
+    const int NG = g.BM == 128 ? 2 : 4;
+    const int ntiles = p.ptiles * p.mtiles;
+    const int sk_tiles = ntiles - p.rdp * p.P;
+    p.stats_acc = (p.rdp > 0 && p.P % p.mtiles == 0) ? 1 : 0;
+    if (p.stats_acc) {
+        p.stats_w = p.P / p.mtiles;
+        p.stats_pitch = (p.stats_w + (sk_tiles + p.mtiles - 1) / p.mtiles) * NG;
+    } else {
+        p.stats_w = 0;
+        p.stats_pitch = p.ptiles * NG;
+    }
+}
+
 // tiles, chunks and the deal of the iterations to the workgroups (p.K, p.M, p.Ho, p.Wo set)
 inline int sk_plan(SkP& p, const SkGeom& g, int N, int cus, const SkOpts& o) {
     p.N = N;
@@ -1107,6 +1156,7 @@ inline int sk_plan(SkP& p, const SkGeom& g, int N, int cus, const SkOpts& o) {
     const int ntiles = p.ptiles * p.mtiles;
     p.rdp = ntiles / p.P;
     p.sk_iters = (ntiles - p.rdp * p.P) * p.nch;
+    sk_stats_layout(p, g);
     return 0;
 }
 
@@ -1256,6 +1306,7 @@ int sk_run(const float* x, const float* w, int N, int Cin, int H, int W, int Cou
         q.P = (int)(q.iters < cus ? q.iters : cus);
         q.rdp = ntiles / q.P;
         q.sk_iters = (ntiles - q.rdp * q.P) * q.nch;
+        sk_stats_layout(q, g);
         return sk_dispatch<1, 32, 1, 1, 4>(q, g, vec, st);
     }
     if (g.BM == 128) return vec ? sk_launch<1, 64, 4, 128, 1, 1, true, 0>(p, st) : sk_launch<1, 64, 4, 128, 1, 1, false, 0>(p, st);
@@ -1270,18 +1321,33 @@ extern "C" int mas_conv_sk(const float* x, const float* w, int N, int Cin, int H
                   opts, stream);
 }
 
-/* Entries per output channel of the BatchNorm partials mas_conv_sk_stats writes for this forward product (0: unsupported). */
+/* Entries per output channel of the BatchNorm partials mas_conv_sk_stats writes for this forward product (0: unsupported): the same
+ * geometry and deal as the launch itself (sk_plan), so it depends on the device's CU count. */
 extern "C" int mas_conv_sk_stats_slots(int N, int Cin, int H, int W, int Cout, int ksize, int stride, int dil, unsigned flags) {
     const bool dma = (flags & MAS_SK_DMA) != 0;
     if (N <= 0 || Cin <= 0 || H <= 0 || W <= 0 || Cout <= 0 || (ksize != 1 && ksize != 3) || (stride != 1 && stride != 2)) return 0;
-    int Ho = (H - 1) / stride + 1, Wo = (W - 1) / stride + 1;
+    SkP p;
+    p.K = Cin; p.M = Cout; p.H = H; p.W = W;
+    p.Ho = (H - 1) / stride + 1; p.Wo = (W - 1) / stride + 1;
     const bool flat = !dma && ((ksize == 1 && stride == 1) || sk_linear_class(ksize, stride, dil, H, W) != 0);
-    if (flat) { Wo = H * W; Ho = 1; }
+    if (flat) { p.Wo = H * W; p.Ho = 1; if (ksize == 1) { p.W = H * W; p.H = 1; } }
     SkGeom g;
-    sk_geom(ksize, stride, Cout, Ho, Wo, 0, &g);
+    sk_geom(ksize, stride, Cout, p.Ho, p.Wo, 0, &g);
     if (flat) { g.TW = 128; g.TH = 1; }
-    const long long pt = (long long)N * ((Wo + g.TW - 1) / g.TW) * ((Ho + g.TH - 1) / g.TH) * (g.BM == 128 ? 2 : 4);
-    return pt > 0x7fffffffLL ? 0 : (int)pt;
+    p.scale = nullptr; p.relu = 0; p.stats = nullptr; p.HWy = p.Ho * p.Wo;
+    mas_sk_opts o = {};
+    o.flags = flags;
+    if (sk_plan(p, g, N, sk_num_cus(), sk_opts(&o)) != 0) return 0;
+    if (dma && ksize == 1 && stride == 1) {             // (the LDS-DMA 1x1 kernel walks 32-channel chunks: sk_run re-deals)
+        const int ntiles = p.ptiles * p.mtiles;
+        const long long iters = (long long)p.iters * 2;
+        p.nch *= 2;
+        p.P = (int)(iters < sk_num_cus() ? iters : sk_num_cus());
+        p.rdp = ntiles / p.P;
+        p.sk_iters = (ntiles - p.rdp * p.P) * p.nch;
+        sk_stats_layout(p, g);
+    }
+    return p.stats_pitch;
 }
 
 /* mas_conv_sk (forward, bare: no scale / residual / ReLU) that also writes the BatchNorm partial sums of its output:
