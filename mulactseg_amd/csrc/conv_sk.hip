@@ -915,20 +915,29 @@ __global__ __launch_bounds__(kSkThreads) void k_conv_sk(const SkP p) {
         const float* rb = p.res ? p.res + ((size_t)n * p.M + m0) * HWo : nullptr;
         const float lo = p.relu ? 0.0f : -INFINITY;
         const int mlim = p.M - m0;
+        // (all residual values of the tile are requested before the first of them is used: one exposed round trip, not TN)
+        const int mb = mtw * 32 + 4 * h;
+        int po_[TN];
+        bool inside_[TN];
+        float rv_[TN][16];
 #pragma unroll
         for (int tn = 0; tn < TN; ++tn) {
             const int oy = oy0 + (pl[tn] >> G::TWLOG), ox = ox0 + (pl[tn] & (TW - 1));
-            const bool inside = oy < p.Ho && ox < p.Wo;
-            const int po = inside ? (oy * p.os + p.oy_off) * p.Wy + ox * p.os + p.ox_off : 0;
-            const int mb = mtw * 32 + 4 * h;
-            float rv[16];
+            inside_[tn] = oy < p.Ho && ox < p.Wo;
+            po_[tn] = inside_[tn] ? (oy * p.os + p.oy_off) * p.Wy + ox * p.os + p.ox_off : 0;
             if (rb) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int m = mb + (r & 3) + 8 * (r >> 2);
-                    rv[r] = rb[(size_t)(m < mlim ? m : 0) * HWo + po];
+                    rv_[tn][r] = rb[(size_t)(m < mlim ? m : 0) * HWo + po_[tn]];
                 }
             }
+        }
+#pragma unroll
+        for (int tn = 0; tn < TN; ++tn) {
+            const bool inside = inside_[tn];
+            const int po = po_[tn];
+            const float (&rv)[16] = rv_[tn];
             if (inside) {
                 // Nothing overlaps the epilogue of a one-workgroup-per-CU kernel, so every instruction in it is exposed: the forms that
                 // a training step uses -- the bare product (every forward convolution), the product plus the other consumer's gradient
