@@ -283,6 +283,42 @@ def test_conv_train_forward_and_gradients(Cin, Cout, k, stride, dil, N, H, W):
         assert err <= 2e-5 * scale, (name, err, scale)
 
 
+def test_pack_registry_lets_dead_models_go():
+    """The registry of packed weight images holds its weights weakly: the active-learning loop builds a new model every round
+    (reference train_AL.py:38), and a registry that kept the old weights alive would pin every dead model's convolution weights and
+    images in HBM and re-pack them after every optimizer step.  Entries die with their weight; the re-pack launch only covers live
+    ones and still tracks an optimizer step of the survivors."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    import gc
+    from mulactseg_amd import ops
+    dev = torch.device('cuda', torch.cuda.current_device())
+    reg = ops._PACKS.get(dev)
+    before = 0 if reg is None else len(reg.entries)
+    convs = [torch.nn.Conv2d(64, 64, 3, padding=1, bias=False).cuda() for _ in range(3)]
+    x = torch.randn(1, 64, 16, 16, device='cuda', requires_grad=True)
+    for c in convs:
+        ops.conv_train(c, x, (True, True, True)).sum().backward()
+    reg = ops._PACKS[dev]
+    assert len(reg.entries) == before + 6                     # forward + input-gradient image of each
+    keep = convs[0]
+    opt = torch.optim.AdamW(keep.parameters(), lr=1e-2, fused=True)
+    del convs, c
+    gc.collect()
+    assert len(reg.entries) == before + 2, len(reg.entries)  # the two dead models' images are gone
+    w0 = keep.weight.detach().clone()
+    y0 = ops.conv_train(keep, x, (True, True, True)).detach().clone()
+    keep.weight.grad = torch.ones_like(keep.weight)
+    opt.step()                                                # bumps the parameter epoch: the next lookup re-packs the live entries
+    assert not torch.equal(keep.weight.detach(), w0)
+    y1 = ops.conv_train(keep, x, (True, True, True)).detach()
+    ref = F.conv2d(x.detach().double(), keep.weight.detach().double(), padding=1)
+    assert float((y1.double() - ref).abs().max()) <= 2e-5 * float(ref.abs().max()) and not torch.equal(y0, y1)
+    del keep, opt
+    gc.collect()
+    assert len(reg.entries) == before
+
+
 def test_random_geometry_cut_of_the_soak():
     """A 40-geometry cut of tools/soak_conv_train.py (random channel counts, planes from 1 x 1 to 140 x 200, strides, dilations,
     batch sizes; forward with the statistics epilogue, input gradient incl. the residual operand and the stride-2 classes, weight
