@@ -238,13 +238,16 @@ def pool_round_bench(args, dev, rank, world, with_model):
     sel.select_next_batch(trainer, active, POOL_CLICKS)
     fence()
     t1 = time.perf_counter()
+    active.wait_for_writes()        # (the selection pickle is written by a background thread, off the round's critical path)
+    t_write = time.perf_counter() - t1
     dt = max_over_ranks(t1 - t0, dev)
     n_sel = sum(len(v) for v in labels.suppix.values())
     return {"seconds": dt, "superpixels_per_s": POOL_IMAGES * S / dt, "regions_selected": n_sel,
             "rank0_breakdown_s": {"scores (scan%s + exchanges + class weights + finalize)" % (" + model forward" if with_model else ""):
                                   marks['scored'] - t0,
                                   "valid mask + cost table + K4 (keys, radix sort, walk)": marks['selected'] - marks['scored'],
-                                  "RegionActiveDataset.expand_training_set + selection pickle (host)": t1 - marks['selected']},
+                                  "RegionActiveDataset.expand_training_set (host; the selection pickle is written by a background thread)": t1 - marks['selected'],
+                                  "selection pickle still being written after the round returned": t_write},
             "images_per_rank": plan.n_local}
 
 

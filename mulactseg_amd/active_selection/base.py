@@ -94,8 +94,9 @@ class RegionSelector(object):
             torch.from_numpy(img_rank).to(dev), torch.from_numpy(img_of_rank).to(dev),
             None if cost is None else torch.from_numpy(cost).to(dev), int(selection_count),
             max_out=None if cost is not None and cost.min() == 0 else int(selection_count) + 1)
-        consumed = [(s, paths[i], r) for s, i, r in zip(ssc.tolist(), simg.tolist(), sid.tolist())]
-        active_set.expand_training_set(consumed, selection_count, self.active_method)
+        # the consumed prefix as arrays that still read as the reference's list of (score, path, id) tuples
+        from ..dataloader.region_active_dataset import ConsumedPrefix
+        active_set.expand_training_set(ConsumedPrefix(ssc, simg, sid, pool_set.im_idx), selection_count, self.active_method)
 
     def _backend(self, trainer):
         b = getattr(self, 'backend', None)

@@ -5,10 +5,56 @@
 after the region that makes the click cost exceed the budget; the consumed prefix is pickled as
 ``<method>_selection_RR.pkl`` and the lists as ``datalist_RR.pkl``.
 """
+import collections.abc
 import os
 import pickle
+import threading
 
 import numpy as np
+
+
+class ConsumedPrefix(collections.abc.Sequence):
+    """The consumed prefix of a round as ARRAYS -- what the device selection (K4) hands back -- that still behaves as the reference's
+    list of ``(score, "img,lbl,spx", suppix_id)`` tuples (``active_selection/base.py:37``: len, indexing, slicing, iteration build
+    the tuples on demand), so any ``expand_training_set`` can take it.  This package's ``RegionActiveDataset`` reads the arrays
+    instead: the 71 000 tuples of a 100 000-click Cityscapes round cost 33 ms to build and 70 ms to walk one by one.
+
+    ``scores`` f32 [n], ``img`` int [n] (index into ``keys`` = ``pool.im_idx`` as it was when the round was scored), ``ids`` int [n]."""
+
+    def __init__(self, scores, img, ids, keys):
+        self.scores = np.asarray(scores)
+        self.img = np.asarray(img).astype(np.intp, copy=False)
+        self.ids = np.asarray(ids).astype(np.intp, copy=False)
+        self.keys = list(keys)          # (a snapshot: expand_training_set edits pool.im_idx)
+        if not (len(self.scores) == len(self.img) == len(self.ids)):
+            raise ValueError("scores / img / ids differ in length")
+
+    def __len__(self):
+        return len(self.ids)
+
+    def tuples(self, n=None):
+        """The first ``n`` (default: all) entries as the reference's list of tuples."""
+        n = len(self) if n is None else n
+        joined = {}
+        out = []
+        for s, p, i in zip(self.scores[:n].tolist(), self.img[:n].tolist(), self.ids[:n].tolist()):
+            j = joined.get(p)
+            if j is None:
+                j = joined[p] = ','.join(self.keys[p])
+            out.append((s, j, i))
+        return out
+
+    def __getitem__(self, k):
+        if isinstance(k, slice):
+            start, stop, step = k.indices(len(self))
+            if step == 1 and start == 0:
+                return self.tuples(stop)
+            return [self[i] for i in range(start, stop, step)]
+        if k < 0:
+            k += len(self)
+        if not 0 <= k < len(self):
+            raise IndexError(k)
+        return (float(self.scores[k]), ','.join(self.keys[int(self.img[k])]), int(self.ids[k]))
 
 
 class RegionActiveDataset:
@@ -20,6 +66,7 @@ class RegionActiveDataset:
         self._valid = None          # u8 [n_img_total, S] mirror of pool.suppix (see pool_valid_mask)
         self._click_cost = None     # (multi_hot_cls it was computed from, u8 [n_img_total, S])
         self._initial_ok = True     # pool.initial_valid_table() describes the lists only until they change behind the table's back
+        self._writer = None         # background thread that writes the selection pickle (wait_for_writes)
 
     # -- cost of one region ---------------------------------------------------------------------
     def _fair(self):
@@ -80,6 +127,13 @@ class RegionActiveDataset:
         ``isselected``, the pickled prefix -- but without its per-region linear scans: ``key not in label.im_idx`` (:38) is
         answered by a set, the click cost by a table computed once, and ``pool.suppix[path].remove(id)`` (:46, O(S) each) is
         deferred: the ids leaving a list are collected and every touched list is rewritten once, order preserved."""
+        self.wait_for_writes()
+        if isinstance(sample_region, ConsumedPrefix):
+            if self._valid is not None:
+                n = self._expand_prefix(sample_region, selection_count, selection_method)
+                if n is not None:
+                    return n
+            sample_region = sample_region.tuples()          # (no table, or an entry the reference loop would raise on: walk it as it does)
         pool, label = self.trg_pool_dataset, self.trg_label_dataset
         cost = 0
         n_sup = 0
@@ -140,6 +194,94 @@ class RegionActiveDataset:
                  "sampling_iter": self.selection_iter}, step=step)
         return n_sup
 
+    # -- the same, from arrays ------------------------------------------------------------------
+    def wait_for_writes(self):
+        """Join the background write of the last selection pickle (called before anything that reads or rewrites the files)."""
+        w, self._writer = self._writer, None
+        if w is not None:
+            w.join()
+
+    def _expand_prefix(self, sr, selection_count, selection_method):
+        """``expand_training_set`` for a ``ConsumedPrefix`` with the valid table in place: the budget cut is one ``cumsum``, the table /
+        ``isselected`` updates two fancy assignments, the list edits run once per touched PICTURE (grouped with a stable sort, in the
+        order of first appearance -- the order the reference appends to ``label.im_idx``), and the selection pickle is written by a
+        background thread.  None when the prefix holds an entry the reference loop would raise on (the caller then walks it tuple by
+        tuple, raising where the reference does)."""
+        pool, label = self.trg_pool_dataset, self.trg_label_dataset
+        n_all = len(sr)
+        if n_all == 0:
+            return 0
+        S = self._valid.shape[1]
+        img, ids = sr.img, sr.ids
+        if ids.min() < 0 or ids.max() >= S or img.min() < 0 or img.max() >= len(sr.keys):
+            return None
+        row_of = np.full(len(sr.keys), -1, dtype=np.intp)
+        try:
+            for p in np.unique(img).tolist():
+                row_of[p] = self._image_index(sr.keys[p][2])
+        except KeyError:
+            return None
+        rows = row_of[img]
+        cost_tab = self.click_cost_table()
+        cost = cost_tab[rows, ids].astype(np.int64) if cost_tab is not None else np.ones(n_all, dtype=np.int64)
+        over = np.flatnonzero(np.cumsum(cost) > selection_count)
+        n = int(over[0]) + 1 if over.size else n_all
+        rows, ids, img = rows[:n], ids[:n], img[:n]
+        flat = rows * S + ids
+        if not (self._valid[rows, ids] == 1).all() or np.unique(flat).size != n:
+            return None                                     # an id that is not in the pool (or twice in the prefix): list.remove would raise
+        if over.size:
+            fname = os.path.join(self.args.model_save_dir, '%s_selection_%02d.pkl' % (selection_method, self.selection_iter))
+
+            def write(sr=sr, n=n, fname=fname):
+                # (every rank of a data-parallel run holds the same prefix and usually the same directory: each writes its own
+                #  temporary file and renames it into place -- atomic, so readers never see a torn pickle whoever wins)
+                tmp = "%s.tmp.%d" % (fname, os.getpid())
+                with open(tmp, "wb") as f:
+                    pickle.dump(sr.tuples(n), f)
+                os.replace(tmp, fname)
+            self._writer = threading.Thread(target=write)
+            self._writer.start()
+        self._valid[rows, ids] = 0
+        if hasattr(pool, 'isselected'):
+            pool.isselected[rows, ids] = 1
+        order = np.argsort(img, kind='stable')              # entries of one picture together, in walk order
+        simg, sids = img[order], ids[order]
+        starts = np.concatenate(([0], np.flatnonzero(np.diff(simg)) + 1))
+        ends = np.concatenate((starts[1:], [n]))
+        first_seen = order[starts]                          # (stable sort: the first entry of a group is its first appearance)
+        listed = {tuple(k) for k in label.im_idx}
+        emptied = set()
+        for j in np.argsort(first_seen).tolist():
+            a, b = int(starts[j]), int(ends[j])
+            p = int(simg[a])
+            key = sr.keys[p]
+            spx_path = key[2]
+            sel = sids[a:b]
+            if tuple(key) not in listed:
+                listed.add(tuple(key))
+                label.im_idx.append(key)
+                label.suppix[spx_path] = []
+            label.suppix[spx_path].extend(sel.tolist())
+            lst = pool.suppix[spx_path]
+            if b - a < len(lst):
+                if b - a <= 4:
+                    for i in sel.tolist():
+                        lst.remove(i)
+                elif not self._delete_by_position(lst, int(row_of[p]), sel):
+                    gone = set(sel.tolist())
+                    pool.suppix[spx_path] = [i for i in lst if i not in gone]
+            else:
+                pool.suppix.pop(spx_path)
+                emptied.add(tuple(key))
+        if emptied:
+            pool.im_idx[:] = [k for k in pool.im_idx if tuple(k) not in emptied]
+        log = getattr(getattr(self.args, 'wandb', None), 'log', None)
+        if log is not None and n:
+            step = int(getattr(self.args, 'finetune_itrs', 0)) * (self.selection_iter - 1)
+            log({"num_selected_spx": n, "num_cls_spx": selection_count / n, "sampling_iter": self.selection_iter}, step=step)
+        return n
+
     def _delete_by_position(self, lst, row, gone):
         """Remove the ids ``gone`` from the list ``lst`` of image ``row`` in place, order preserved, without walking the list in
         Python: in a list that holds its ids in ascending order (how the reference builds them, ``np.unique``; removals keep it)
@@ -149,8 +291,7 @@ class RegionActiveDataset:
         entries, was 0.15 s of a 0.40 s pool round.)"""
         if self._valid is None:
             return False
-        ids = np.fromiter(gone, dtype=np.intp, count=len(gone))
-        ids.sort()
+        ids = np.sort(gone) if isinstance(gone, np.ndarray) else np.sort(np.fromiter(gone, dtype=np.intp, count=len(gone)))
         before = self._valid[row].copy()            # (the table already has this call's removals)
         before[ids] = 1
         pos = (np.cumsum(before, dtype=np.intp)[ids] - 1).tolist()
@@ -164,6 +305,7 @@ class RegionActiveDataset:
 
     # -- persistence ----------------------------------------------------------------------------
     def dump_datalist(self):
+        self.wait_for_writes()
         path = os.path.join(self.args.model_save_dir, 'datalist_%02d.pkl' % self.selection_iter)
         with open(path, "wb") as f:
             pickle.dump({'trg_label_im_idx': self.trg_label_dataset.im_idx,
@@ -172,6 +314,7 @@ class RegionActiveDataset:
                          'trg_pool_suppix': self.trg_pool_dataset.suppix}, f)
 
     def load_datalist(self, datalist_path=None):
+        self.wait_for_writes()
         if datalist_path is None:
             datalist_path = os.path.join(self.args.model_save_dir, 'datalist_%02d.pkl' % self.selection_iter)
         with open(datalist_path, "rb") as f:

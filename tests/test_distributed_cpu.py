@@ -63,6 +63,7 @@ def _run(rank, world, port, out_dir):
     sel.backend = OracleBackend()
     scores, hist = sel.calculate_scores_tensor(fake_trainer(), pool, want_hist=True)
     sel.select_next_batch(fake_trainer(save_dir=tmp), active, 30)
+    active.wait_for_writes()
     with open(os.path.join(tmp, 'pixbal_selection_01.pkl'), 'rb') as f:
         consumed = pickle.load(f)
     res = dict(scores=scores.numpy(), hist=hist.numpy(), w=sel.cls_weight.numpy(), cum=sel.cumulated_pred_prob,

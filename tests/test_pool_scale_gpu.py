@@ -74,6 +74,7 @@ def _round(pool, labels, net, tmp, budget):
     sel.select_next_batch(trainer, active, budget)
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    active.wait_for_writes()
     assert isinstance(sel.backend, HipBackend)
     with open(os.path.join(str(tmp), 'pixbal_selection_01.pkl'), 'rb') as f:
         consumed = pickle.load(f)

@@ -119,6 +119,56 @@ def test_expand_training_set_equals_the_reference_loop_on_random_rounds(tmp_path
         aset.expand_training_set([(1.0, ','.join(ref_label['im_idx'][0]), gone)], 5, 'm')
 
 
+def test_consumed_prefix_takes_the_array_path_and_equals_the_reference_loop(tmp_path):
+    """What the device selection hands over -- a ConsumedPrefix (arrays that read as the reference's tuple list) -- goes through the
+    grouped-by-picture path of expand_training_set: same lists, same order inside every list, same isselected / valid table and the
+    same pickled prefix as the reference loop over the equivalent tuples, on three successive rounds (one stopped by the budget, one
+    emptying pictures); an entry the reference would raise on falls back to the tuple walk and raises there."""
+    import copy
+    import pickle
+    import pytest
+    from mulactseg_amd.dataloader.region_active_dataset import ConsumedPrefix
+    rs = np.random.RandomState(9)
+    args, names, mh, aset = _sets(tmp_path, n=7, nseg=40)
+    pool, label = aset.trg_pool_dataset, aset.trg_label_dataset
+    ref_pool = {'im_idx': copy.deepcopy(pool.im_idx), 'suppix': copy.deepcopy(pool.suppix)}
+    ref_label = {'im_idx': copy.deepcopy(label.im_idx), 'suppix': copy.deepcopy(label.suppix)}
+    ref_sel = np.zeros_like(pool.isselected)
+    index_of = lambda spx: label.id_to_index[spx.split('/')[-1].split('.')[0]]
+    for rnd, budget in enumerate([60, 10 ** 6, 45]):
+        aset.selection_iter = rnd + 1
+        aset.pool_valid_mask(args.nseg)                                 # (the selector builds the table before it selects)
+        keys = list(pool.im_idx)
+        cand = [(float(np.float32(rs.rand())), p, i) for p, k in enumerate(keys) for i in pool.suppix[k[2]]]
+        cand.sort(key=lambda t: (-t[0], t[1], t[2]))
+        if rnd == 1:                                                    # two whole pictures and a bit more
+            cand = [c for c in cand if c[1] in (0, 3)] + [c for c in cand if c[1] not in (0, 3)][:9]
+        sr = ConsumedPrefix(np.array([c[0] for c in cand], dtype=np.float32), [c[1] for c in cand], [c[2] for c in cand], keys)
+        as_tuples = [(c[0], ','.join(keys[c[1]]), c[2]) for c in cand]
+        assert len(sr) == len(cand) and sr[3] == as_tuples[3] and sr[:5] == as_tuples[:5] and list(sr)[-1] == as_tuples[-1]
+        n_ref = _reference_loop(ref_pool, ref_label, ref_sel, index_of, mh, as_tuples, budget)
+        n = aset.expand_training_set(sr, budget, 'm')
+        aset.wait_for_writes()
+        assert n == n_ref
+        assert pool.im_idx == ref_pool['im_idx'] and pool.suppix == ref_pool['suppix'] and list(pool.suppix) == list(ref_pool['suppix'])
+        assert label.im_idx == ref_label['im_idx'] and label.suppix == ref_label['suppix'] and list(label.suppix) == list(ref_label['suppix'])
+        assert np.array_equal(pool.isselected, ref_sel)
+        valid = aset.pool_valid_mask(args.nseg)
+        for k, key in enumerate(pool.im_idx):
+            assert sorted(np.nonzero(valid[k])[0].tolist()) == sorted(pool.suppix[key[2]])
+        if n < len(cand):
+            with open(tmp_path / ('m_selection_%02d.pkl' % (rnd + 1)), 'rb') as f:
+                assert pickle.load(f) == as_tuples[:n]
+    # an id that already left the pool: the array path declines, the tuple walk raises as list.remove does
+    aset.pool_valid_mask(args.nseg)
+    keys = list(pool.im_idx)
+    gone_key = ref_label['im_idx'][-1]
+    gone_id = ref_label['suppix'][gone_key[2]][0]
+    if gone_key in keys:
+        with pytest.raises((ValueError, KeyError)):
+            aset.expand_training_set(ConsumedPrefix(np.ones(1, np.float32), [keys.index(gone_key)], [gone_id], keys), 5, 'm')
+
+
 def test_removal_by_verified_position_and_its_fallback(tmp_path):
     """Ids leave a pool list by position (read off the valid table) when the list is ascending; a list in another order fails the
     position check and is rewritten instead -- both must equal the reference's list.remove() result, order included."""

@@ -69,6 +69,7 @@ def test_select_next_batch_reproduces_reference_selection_g1():
     sel = _selector("my_bvsb_predclsbal_pwr_banignore", args)
     n_pool_before = sum(len(v) for v in active.trg_pool_dataset.suppix.values())
     sel.select_next_batch(fake_trainer(save_dir=tmp), active, int(g['budget']))
+    active.wait_for_writes()                    # (the selection pickle is written by a background thread)
     with open(os.path.join(tmp, 'pixbal_selection_01.pkl'), 'rb') as f:
         consumed = pickle.load(f)
     cc, ci, cid = tuples_to_arrays(consumed, im_idx)
