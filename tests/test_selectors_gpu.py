@@ -53,6 +53,7 @@ def test_pixbal_banignore_on_gpu_matches_reference_and_oracle():
     active = RegionActiveDataset(args, pool, label)
     active.selection_iter = 1
     sel.select_next_batch(tr, active, int(g['budget']))
+    active.wait_for_writes()                    # (the selection pickle is written by a background thread)
     with open(os.path.join(tmp, 'pixbal_selection_01.pkl'), 'rb') as f:
         consumed = pickle.load(f)
     cc, ci, cid = tuples_to_arrays(consumed, im_idx)
