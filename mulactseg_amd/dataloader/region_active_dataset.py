@@ -242,11 +242,17 @@ class RegionActiveDataset:
                 os.replace(tmp, fname)
             self._writer = threading.Thread(target=write)
             self._writer.start()
+        # where every leaving id sits in its pool list, for all entries at once: in a list that holds its ids in ascending order (how
+        # the reference builds them, np.unique; removals keep it) that is the number of listed ids below it -- a row-wise cumsum of
+        # the touched rows of the table as it was BEFORE this call.  The positions are verified per picture before anything is deleted.
+        urows, ridx = np.unique(rows, return_inverse=True)
+        before = self._valid[urows].astype(np.int32)        # (this call's removals are still in: the table is updated below)
+        pos = np.cumsum(before, axis=1, dtype=np.int32)[ridx, ids] - 1
         self._valid[rows, ids] = 0
         if hasattr(pool, 'isselected'):
             pool.isselected[rows, ids] = 1
         order = np.argsort(img, kind='stable')              # entries of one picture together, in walk order
-        simg, sids = img[order], ids[order]
+        simg, sids, spos = img[order], ids[order], pos[order]
         starts = np.concatenate(([0], np.flatnonzero(np.diff(simg)) + 1))
         ends = np.concatenate((starts[1:], [n]))
         first_seen = order[starts]                          # (stable sort: the first entry of a group is its first appearance)
@@ -254,22 +260,23 @@ class RegionActiveDataset:
         emptied = set()
         for j in np.argsort(first_seen).tolist():
             a, b = int(starts[j]), int(ends[j])
-            p = int(simg[a])
-            key = sr.keys[p]
+            key = sr.keys[int(simg[a])]
             spx_path = key[2]
-            sel = sids[a:b]
+            sel = sids[a:b].tolist()
             if tuple(key) not in listed:
                 listed.add(tuple(key))
                 label.im_idx.append(key)
                 label.suppix[spx_path] = []
-            label.suppix[spx_path].extend(sel.tolist())
+            label.suppix[spx_path].extend(sel)
             lst = pool.suppix[spx_path]
             if b - a < len(lst):
-                if b - a <= 4:
-                    for i in sel.tolist():
-                        lst.remove(i)
-                elif not self._delete_by_position(lst, int(row_of[p]), sel):
-                    gone = set(sel.tolist())
+                ps = spos[a:b].tolist()
+                m = len(lst)
+                if all(q < m and lst[q] == i for q, i in zip(ps, sel)):     # verified positions: deleting them is right whatever the rest
+                    for q in sorted(ps, reverse=True):
+                        del lst[q]
+                else:                                                        # a list in another order: rewrite it, order preserved
+                    gone = set(sel)
                     pool.suppix[spx_path] = [i for i in lst if i not in gone]
             else:
                 pool.suppix.pop(spx_path)
