@@ -477,7 +477,9 @@ int mas_conv_sk_stats(const float* x, const float* wp, int N, int Cin, int H, in
 /* Input gradient of a 3x3, stride-2, padding-1 convolution (torch.autograd of nn.Conv2d(k=3, stride=2, padding=1), the conv2 of
  * layer2.0 / layer3.0: backbone/resnet.py:129-141), one parity class per launch: sub = 2 py + px writes dx[n, c, 2 i + py, 2 j + px]
  * as a stride-1 product over dy [N,Cout,(H-1)/2+1,(W-1)/2+1] with (1 + py) x (1 + px) taps; wp = mas_conv_sk_pack(..., ksize 3,
- * stride 2, dgrad = 2 + sub).  The four classes write every pixel of dx [N,Cin,H,W] exactly once.  Epilogue, workspace and epoch
+ * stride 2, dgrad = 2 + sub).  The four classes write every pixel of dx [N,Cin,H,W] exactly once.  (Class 0 is a one-tap product written to the
+ * pixels (2i, 2j): with the input-gradient image of a 1x1 weight (mas_conv_sk_pack(..., ksize 1, dgrad = 1)) and a zero-filled dx it
+ * is the input gradient of the 1x1 stride-2 `downsample` convolutions, backbone/resnet.py:215-223.)  Epilogue, workspace and epoch
  * as mas_conv_sk (a fresh epoch per launch). */
 int mas_conv_sk_dgrad_s2(const float* dy, const float* wp, int N, int Cin, int H, int W, int Cout, int sub, const float* scale,
                          const float* shift, const float* residual, int relu, float* dx, void* workspace, size_t workspace_bytes,

@@ -1328,6 +1328,29 @@ def conv_sk_dgrad_s2(dy, w, H, W, packed=None, flags=None, spin_limit=0):
     return dx
 
 
+def conv_sk_dgrad_1x1s2(dy, w, H, W, packed=None):
+    """dX [N,Cin,H,W] of y = conv2d(x, w, stride 2) for a 1x1 weight `w` [Cout,Cin,1,1] from dY [N,Cout,(H-1)//2+1,(W-1)//2+1]: the
+    gradient lives on the even positions only.  ONE launch of the stream-K kernel: the stride-1 product over the dY plane with the
+    strided store of the stride-2 parity classes (class 0 of mas_conv_sk_dgrad_s2 is exactly a one-tap product written to the pixels
+    (2i, 2j); it takes the 1x1 weight's input-gradient image) into a zero-filled dX.  (Until round 4: the product into a temporary,
+    then zeros_like + a strided ATen copy.)"""
+    _need(dy, "dy", torch.float32)
+    _need(w, "w", torch.float32)
+    Cout, Cin, ks, _ = w.shape
+    N = dy.shape[0]
+    if ks != 1 or tuple(dy.shape) != (N, Cout, (H - 1) // 2 + 1, (W - 1) // 2 + 1):
+        raise ValueError("dy %s does not belong to a 1x1 stride-2 convolution of a %dx%d plane with weight %s" % (tuple(dy.shape), H, W, tuple(w.shape)))
+    dx = torch.zeros((N, Cin, H, W), dtype=torch.float32, device=dy.device)
+    img = packed if packed is not None else conv_sk_pack(w, 1, True)
+    lib = _lib.load()
+    opts, _ = _sk_opts()
+    ws, epoch = _sk_workspace(dy.device)
+    with torch.cuda.device(dy.device):
+        _lib.check(lib.mas_conv_sk_dgrad_s2(dy.data_ptr(), img.data_ptr(), N, Cin, H, W, Cout, 0, None, None, None, 0, dx.data_ptr(),
+                                            ws.data_ptr(), ws.numel(), epoch, opts, _stream(dy)), "mas_conv_sk_dgrad_s2")
+    return dx
+
+
 def conv_sk_set_mode(dma):
     """Default chunk staging of this wrapper's conv_sk calls (the library itself keeps no mode: the flag travels with every call in
     mas_sk_opts): False = register-staged (default), True = LDS-DMA ring; returns the previous default.  For A/B runs and tests."""
@@ -1472,10 +1495,13 @@ class _ConvTrain(torch.autograd.Function):
                 else:
                     dx = conv_sk(dy, w, 1, dil, dgrad=True, packed=packed_weight(w, 1, True))
             elif own[1] and ks == 1:
-                # 1x1, stride 2: the input gradient lives on the even positions only -- the stride-1 product on the small plane,
-                # scattered into a zero-filled tensor
-                dx = torch.zeros_like(x)
-                dx[:, :, ::stride, ::stride] = conv_sk(dy, w, 1, 1, dgrad=True, packed=packed_weight(w, 1, True))
+                # 1x1, stride 2: the input gradient lives on the even positions only -- the stride-1 product over the small plane,
+                # stored with stride 2 into a zero-filled tensor by the kernel itself
+                if stride == 2:
+                    dx = conv_sk_dgrad_1x1s2(dy, w, x.shape[2], x.shape[3], packed=packed_weight(w, 1, True))
+                else:
+                    dx = torch.zeros_like(x)
+                    dx[:, :, ::stride, ::stride] = conv_sk(dy, w, 1, 1, dgrad=True, packed=packed_weight(w, 1, True))
             elif own[1] and ks == 3 and stride == 2 and dil == 1:
                 dx = conv_sk_dgrad_s2(dy, w, x.shape[2], x.shape[3], packed=[packed_weight(w, 2, 2 + sub) for sub in range(4)])
             else:
