@@ -229,7 +229,9 @@ __global__ __launch_bounds__(kThreads, 2) void k_conv_mfma(const ConvP p) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int m = mb + (r & 3) + 8 * (r >> 2);
-            dst[r] = rb[(size_t)(m < mlim ? m : 0) * HWo + po[tn]];
+            // (the residual is read once: non-temporal, see common.h:mas_load_stream4 -- 26.32 -> 26.20 ms per pool batch; the same policy
+            //  on the INPUT patches of layers with one M tile was measured too: 26.30 -> 26.37, not kept)
+            dst[r] = __builtin_nontemporal_load(&rb[(size_t)(m < mlim ? m : 0) * HWo + po[tn]]);
         }
     };
     if (RES) res_load(0, rv[0]);
