@@ -49,9 +49,11 @@ __device__ __forceinline__ Groups groups_of(const float* plane, int HW) {
 __device__ __forceinline__ bool group_full(const Groups& g, int i, int HW) { return 4 * i >= g.a && 4 * i + 4 <= g.a + HW; }
 __device__ __forceinline__ bool elem_in(const Groups& g, int i, int k, int HW) { return 4 * i + k >= g.a && 4 * i + k < g.a + HW; }
 
-template <bool VEC>
+// NT: the tensor is read for the LAST time by this kernel (or will have left the caches long before its next reader): non-temporal
+// load policy, as for the scans' logits (common.h:mas_load_stream4)
+template <bool VEC, bool NT = false>
 __device__ __forceinline__ float4 load_group(const float* t_start, const Groups& g, int i, int HW, float fill) {
-    if (VEC && group_full(g, i, HW)) return *reinterpret_cast<const float4*>(t_start + 4 * i);
+    if (VEC && group_full(g, i, HW)) return NT ? mas_load_stream4(t_start + 4 * i) : *reinterpret_cast<const float4*>(t_start + 4 * i);
     float v[4];
 #pragma unroll
     for (int k = 0; k < 4; ++k) v[k] = elem_in(g, i, k, HW) ? t_start[4 * i + k] : fill;
@@ -158,8 +160,8 @@ __global__ __launch_bounds__(kThreads) void k_bn_apply(const float* __restrict__
         t = t + r;
         return (relu && !(t > 0.0f)) ? 0.0f : t;
     };
-    const float4 v = load_group<VEC>(g.start, g, i, HW, 0.0f);
-    const float4 r = res ? load_group<VEC>(res + base - g.a, g, i, HW, 0.0f) : make_float4(0.f, 0.f, 0.f, 0.f);
+    const float4 v = load_group<VEC, true>(g.start, g, i, HW, 0.0f);
+    const float4 r = res ? load_group<VEC, true>(res + base - g.a, g, i, HW, 0.0f) : make_float4(0.f, 0.f, 0.f, 0.f);
     const float4 o = make_float4(f(v.x, r.x), f(v.y, r.y), f(v.z, r.z), f(v.w, r.w));
     store_group<VEC>(y + base - g.a, g, i, HW, o);
     if (mask) mask[(size_t)blockIdx.y * mask_stride + i] = (unsigned char)((o.x > 0.f) | ((o.y > 0.f) << 1) | ((o.z > 0.f) << 2) | ((o.w > 0.f) << 3));
@@ -264,8 +266,8 @@ __global__ __launch_bounds__(kThreads) void k_bn_bwd_apply(const float* __restri
         gout = gr;
         return k * ((gr - m.x) - ((xv - mu) * is) * m.y);
     };
-    const float4 gr = load_group<VEC>(dy + base - g.a, g, i, HW, 0.0f);
-    const float4 xv = load_group<VEC>(g.start, g, i, HW, 0.0f);
+    const float4 gr = load_group<VEC, true>(dy + base - g.a, g, i, HW, 0.0f);
+    const float4 xv = load_group<VEC, true>(g.start, g, i, HW, 0.0f);
     float4 yv = make_float4(1.f, 1.f, 1.f, 1.f);
     if (relu && mask) yv = mask_bits(mask[(size_t)blockIdx.y * mask_stride + i]);
     else if (relu) yv = load_group<VEC>(y + base - g.a, g, i, HW, 0.0f);

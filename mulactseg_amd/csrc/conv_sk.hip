@@ -929,7 +929,7 @@ __global__ __launch_bounds__(kSkThreads) void k_conv_sk(const SkP p) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int m = mb + (r & 3) + 8 * (r >> 2);
-                    rv_[tn][r] = rb[(size_t)(m < mlim ? m : 0) * HWo + po_[tn]];
+                    rv_[tn][r] = __builtin_nontemporal_load(&rb[(size_t)(m < mlim ? m : 0) * HWo + po_[tn]]);     // (read once)
                 }
             }
         }
