@@ -420,6 +420,22 @@ int mas_conv_chunk(int ksize, int Cin);
 int mas_conv_fwd(const float* x, const float* wt, int N, int Cin, int H, int W, int Cout, int ksize, int stride, int dil,
                  const float* scale, const float* shift, const float* residual, int relu, float* y, void* stream);
 
+/* The same convolutions (mas_conv_fwd: formulas, epilogue, reference lines) on the bf16 matrix cores with f32 operands and f32
+ * results (csrc/conv_bx.hip): every f32 operand is split exactly into three bf16 terms (8 + 8 + 8 significand bits) and a
+ * product is accumulated in f32 from its six partial products of order <= 2 (v_mfma_f32_32x32x16_bf16); the dropped terms are
+ * below 2^-23 of the product, i.e. one f32 rounding -- same error bound as the f32 MFMA form, exact on integer data, 2.67x its
+ * matrix peak.  Supported (mas_conv_bx_supported != 0): ksize 1 with Cin % 32 == 0, stride 1 (H*W % 4 == 0) or stride 2
+ * (H even, W % 8 == 0); ksize 3 with stride 1, dil 1 | 2 (padding = dil), Cin % 8 == 0, W >= 32; any Cout.
+ * `wp` is the weight [Cout][Cin][ksize][ksize] split and laid out ONCE (per checkpoint load) by mas_conv_bx_pack into
+ * mas_conv_bx_packed_bytes(ksize, Cin, Cout) bytes of caller-owned, 16-byte aligned device memory: the sequence of LDS images
+ * [M tile][chunk][term h|m|l][k group][BM rows][8 bf16] (1x1: chunk = 32 channels, k = channel; 3x3: chunk = 8 channels,
+ * k group = tap, + one zero tap; BM = 128 if ksize == 1 and Cout % 128 == 0, else 64).  x 16-byte aligned. */
+int mas_conv_bx_supported(int ksize, int stride, int dil, int Cin, int Cout, int H, int W);
+long long mas_conv_bx_packed_bytes(int ksize, int Cin, int Cout);
+int mas_conv_bx_pack(const float* w, int Cout, int Cin, int ksize, void* wp, void* stream);
+int mas_conv_bx_fwd(const float* x, const void* wp, int N, int Cin, int H, int W, int Cout, int ksize, int stride, int dil,
+                    const float* scale, const float* shift, const float* residual, int relu, float* y, void* stream);
+
 /* Forward and input gradient of a dense convolution in training, as a persistent stream-K implicit GEMM on the f32 matrix
  * cores (csrc/conv_sk.hip).  `wp` is the weight as mas_conv_sk_pack writes it from PyTorch's [Cout][Cin][ksize][ksize] tensor
  * (mas_conv_sk_packed_elems floats, 16-byte aligned; one image per role: dgrad 0 / 1; one small launch per optimizer step): the

@@ -1,0 +1,512 @@
+// conv_bx.hip -- the dense convolutions of the network at INFERENCE (1x1 stride 1 / 2; 3x3 stride 1, dilation 1 / 2) as an
+// implicit GEMM on the bf16 matrix cores of gfx950 with f32 OPERANDS AND f32 RESULTS: every f32 operand is split EXACTLY into
+// three bf16 terms
+//        x = h + m + l,    h = trunc16(x),  m = trunc16(x - h),  l = x - h - m        (8 + 8 + 8 significand bits; both
+//                                                                                      subtractions are exact in f32)
+// and a product a*b is accumulated as the six partial products of order <= 2
+//        ah*bh + ah*bm + am*bh + ah*bl + al*bh + am*bm                                (each exact in f32: 8 x 8 bits)
+// on v_mfma_f32_32x32x16_bf16 with f32 accumulation.  What is dropped (am*bl + al*bm + al*bl) is below 2^-23 |a*b| -- one
+// f32 rounding of the product, which the f32 MFMA (v_mfma_f32_32x32x2_f32, csrc/conv_mfma.hip) commits as well -- so the
+// result is f32 arithmetic by its error bound, exact on integer data, and six bf16 MFMAs of 16x the f32 rate do the work of
+// sixteen f32 ones: 2.67x the f32 matrix peak (157 -> 419 TFLOP/s of f32 convolution).
+// Reference: the convolutions of models/segmentation/backbone/resnet.py:129-160 (Bottleneck conv1/2/3 + downsample with
+// their BatchNorm / residual / ReLU), the deep stem (:163-171), the 1x1 projections of deeplabv3.py:85-137,216-245 -- the
+// model forward of the acquisition round, active_selection/my_bvsb_predclsbal_pwr_banignore.py:35-72.
+//
+// GEMM view per picture:  Y[m, p] = sum_{tap, c} W[m, (tap, c)] * X[c, pixel p shifted by tap]
+//   A = weights, split ONCE per checkpoint by k_bx_pack into ready-made LDS images [M tile][chunk][term][k group][BM][8 bf16]
+//       (a k group = 8 consecutive k values = one 16-byte MFMA fragment of a lane),
+//   B = activations, f32 NCHW in HBM, split by the VALU between the global load and the LDS store into the image
+//       [term][k group][pixel position][8 bf16]: a lane reads ITS pixel's 16-byte fragment, a tap is an address offset.
+//   1x1: a chunk is 32 channels (4 k groups), a tile 128 (64) channels x 128 (256) consecutive pixels of the flattened plane;
+//   3x3: a chunk is 8 channels x 9 taps (+ one zero-weight tap: a 16-k MFMA step is two taps), a tile 64 channels x 8 x 32
+//        pixels over an (8 + 2 dil) x (32 + 2 dil) input patch that is staged once per chunk for all taps.
+// A workgroup is 4 waves, a wave owns 64 x 64 of the tile (2 x 2 MFMA tiles: 64 accumulator registers); chunk t + 1 travels
+// global -> registers in front of the MFMAs of chunk t and registers -> (split) -> LDS behind them; two workgroups per CU
+// cover each other's staging.  Epilogue as conv_mfma.hip: y * scale[m] + shift[m] (+ residual) (ReLU), NCHW stores.
+#include "common.h"
+
+namespace {
+constexpr int kThreads = 256;
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float v4f __attribute__((ext_vector_type(4)));
+typedef unsigned v2u __attribute__((ext_vector_type(2)));
+typedef __bf16 bf8 __attribute__((ext_vector_type(8)));
+
+constexpr int kBxTaps3 = 10;                    // 3x3: nine taps + one zero-weight tap (five 16-k steps per 8-channel chunk)
+
+struct BxP {
+    const float* x;
+    const v4f* wp;
+    const float* scale;
+    const float* shift;
+    const float* res;
+    float* y;
+    int Cin, H, W, Cout, Ho, Wo, dil, relu;
+    int tiles_x, tiles_y, ptiles, mtiles;
+    int PH, PW, PP, PPA;                        // 3x3 input patch: rows, columns, pixels, pixels rounded up to 16
+};
+
+// k groups of a chunk's A image / B image
+template <int TAPS> struct BxGeo {
+    static constexpr int CK = TAPS == 1 ? 32 : 8;
+    static constexpr int GA = TAPS == 1 ? 4 : kBxTaps3;
+    static constexpr int SLABS = GA / 2;
+};
+
+// position (16-byte unit) of pixel p of a 1x1 tile inside one k group of the B image: the four pixels of a thread's 16-byte
+// global load go to four rows of 36 units, so that both the staging stores (lanes = consecutive pixel quads) and the MFMA
+// fragment reads (lanes = consecutive pixels, serviced in the 16-lane groups of ds_read_b128) are free of bank conflicts
+__device__ __forceinline__ int bx_pos1(int p) { return (p >> 7) * 144 + (p & 3) * 36 + ((p & 127) >> 2); }
+
+// (h, m, l) of two values, packed pairwise: dword = (bf16 of v1) << 16 | bf16 of v0
+__device__ __forceinline__ void bx_split2(float v0, float v1, unsigned& h, unsigned& m, unsigned& l) {
+    const unsigned u0 = __float_as_uint(v0), u1 = __float_as_uint(v1);
+    h = __builtin_amdgcn_perm(u1, u0, 0x07060302u);
+    const float r0 = v0 - __uint_as_float(u0 & 0xffff0000u), r1 = v1 - __uint_as_float(u1 & 0xffff0000u);
+    const unsigned s0 = __float_as_uint(r0), s1 = __float_as_uint(r1);
+    m = __builtin_amdgcn_perm(s1, s0, 0x07060302u);
+    const float q0 = r0 - __uint_as_float(s0 & 0xffff0000u), q1 = r1 - __uint_as_float(s1 & 0xffff0000u);
+    l = __builtin_amdgcn_perm(__float_as_uint(q1), __float_as_uint(q0), 0x07060302u);
+}
+
+// ---- weight image --------------------------------------------------------------------------------------------------------
+// one thread per 16-byte unit [M tile][chunk][term][k group][row][8]; k = 8 g + j: 1x1 channel = chunk * 32 + k,
+// 3x3 tap = g (tap 9: zeros), channel = chunk * 8 + j
+template <int TAPS>
+__global__ void k_bx_pack(const float* __restrict__ w, int Cout, int Cin, int BM, unsigned* __restrict__ out, long long units) {
+    constexpr int GA = BxGeo<TAPS>::GA, CK = BxGeo<TAPS>::CK;
+    const long long u = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (u >= units) return;
+    const int row = (int)(u % BM);
+    long long r = u / BM;
+    const int g = (int)(r % GA);
+    r /= GA;
+    const int term = (int)(r % 3);
+    r /= 3;
+    const int nch = Cin / CK;
+    const int chunk = (int)(r % nch);
+    const int mt = (int)(r / nch);
+    const int m = mt * BM + row;
+    float v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        float val = 0.0f;
+        if (m < Cout) {
+            if (TAPS == 1) val = w[(size_t)m * Cin + chunk * CK + 8 * g + j];
+            else if (g < 9) val = w[((size_t)m * Cin + chunk * CK + j) * 9 + g];
+        }
+        v[j] = val;
+    }
+    unsigned o[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        unsigned h, mm, l;
+        bx_split2(v[2 * j], v[2 * j + 1], h, mm, l);
+        o[j] = term == 0 ? h : (term == 1 ? mm : l);
+    }
+    *reinterpret_cast<uint4*>(out + 4 * u) = make_uint4(o[0], o[1], o[2], o[3]);
+}
+
+// ---- the convolution -------------------------------------------------------------------------------------------------------
+template <int TAPS, int BM, int BN, bool S2, bool RES>
+__global__ __launch_bounds__(kThreads, 2) void k_conv_bx(const BxP p) {
+    constexpr int CK = BxGeo<TAPS>::CK, GA = BxGeo<TAPS>::GA, SLABS = BxGeo<TAPS>::SLABS;
+    constexpr int WM = BM / 64, WN = 4 / WM;
+    static_assert(WN * 64 == BN, "a wave owns 64 x 64");
+    constexpr int AUNITS = 3 * GA * BM;                         // 16-byte units of a chunk's A image
+    constexpr int NW = (AUNITS + kThreads - 1) / kThreads;
+    constexpr int POS1 = 144 * (BN / 128);                      // 1x1: units per k group of the B image
+    constexpr int NT1 = BN / 128;                               // 1x1: (4 channels x 4 pixels) staging tasks per thread
+    constexpr int NX3 = 4;                                      // 3x3: (4 channels x 1 pixel) staging tasks per thread, at most
+    constexpr int NXR = TAPS == 1 ? NT1 * 4 * (S2 ? 8 : 4) : NX3 * 4;   // staging registers: 1x1 (4 channels x 4 | 8 floats) per task, 3x3 4 channels per task
+    extern __shared__ __attribute__((aligned(16))) unsigned char bx_smem[];
+    v4f* sA = reinterpret_cast<v4f*>(bx_smem);                                       // [3][GA][BM] units
+    float* sE = reinterpret_cast<float*>(bx_smem + (size_t)AUNITS * 16);             // [2][BM]
+    unsigned char* sB = bx_smem + (size_t)AUNITS * 16 + 2 * BM * 4;                  // [3][k groups][positions] units
+    const int bTerm = TAPS == 1 ? 4 * POS1 * 16 : p.PPA * 16;                      // bytes of one term of the B image
+
+    const int tid = threadIdx.x;
+    const int bid = blockIdx.x;
+    const int xcd = bid & 7, slot = bid >> 3;
+    const int mt = slot % p.mtiles;
+    const int pt = (slot / p.mtiles) * 8 + xcd;
+    if (pt >= p.ptiles) return;
+    const int HW = p.H * p.W, HWo = p.Ho * p.Wo;
+    int n, p0 = 0, oy0 = 0, ox0 = 0;
+    if (TAPS == 1) {
+        n = pt / p.tiles_x;
+        p0 = (pt - n * p.tiles_x) * BN;                          // first pixel of the tile in the flattened output plane
+    } else {
+        const int tpi = p.tiles_x * p.tiles_y;
+        n = pt / tpi;
+        const int trem = pt - n * tpi;
+        const int tyi = trem / p.tiles_x;
+        oy0 = tyi * 8;
+        ox0 = (trem - tyi * p.tiles_x) * 32;
+    }
+    const int m0 = mt * BM;
+
+    // ---- staging descriptors (the same for every chunk) ------------------------------------------------------------------------
+    int goff[TAPS == 1 ? NT1 : NX3], loff[TAPS == 1 ? NT1 : NX3];
+    unsigned ok = 0, live = 0;
+    if (TAPS == 1) {
+#pragma unroll
+        for (int j = 0; j < NT1; ++j) {
+            const int task = tid + j * kThreads;
+            const int q = task / (BN / 4), pq = task - q * (BN / 4);             // channel quad 0..7, pixel quad
+            const int po = p0 + 4 * pq;
+            goff[j] = q * 4 * HW;
+            live |= 1u << j;
+            if (po < HWo) {
+                ok |= 1u << j;
+                if (S2) {
+                    const int oy = po / p.Wo, ox = po - oy * p.Wo;
+                    goff[j] += 2 * oy * p.W + 2 * ox;
+                } else {
+                    goff[j] += po;
+                }
+            }
+            loff[j] = ((q >> 1) * POS1 + bx_pos1(4 * pq)) * 16 + (q & 1) * 8;
+        }
+    } else {
+        const int iy0 = oy0 - p.dil, ix0 = ox0 - p.dil;
+#pragma unroll
+        for (int j = 0; j < NX3; ++j) {
+            const int e = tid + j * kThreads;
+            goff[j] = 0;
+            loff[j] = 0;
+            if (e < 2 * p.PP) {
+                const int cq = e >= p.PP ? 1 : 0, pix = e - cq * p.PP;
+                const int py = pix / p.PW, px = pix - py * p.PW;
+                const int iy = iy0 + py, ix = ix0 + px;
+                live |= 1u << j;
+                loff[j] = pix * 16 + cq * 8;
+                goff[j] = cq * 4 * HW;
+                if (iy >= 0 && iy < p.H && ix >= 0 && ix < p.W) {
+                    ok |= 1u << j;
+                    goff[j] += iy * p.W + ix;
+                }
+            }
+        }
+    }
+
+    // ---- MFMA operand addressing -----------------------------------------------------------------------------------------------
+    const int wave = tid >> 6, lane = tid & 63, l31 = lane & 31, h = lane >> 5;
+    const int wm = wave / WN, wn = wave - wm * WN;
+    const int aBase = h * BM + wm * 64 + l31;                       // unit index inside a term's [GA][BM]
+    int bBase[2];                                                   // byte offset inside a term of the B image
+#pragma unroll
+    for (int tn = 0; tn < 2; ++tn) {
+        if (TAPS == 1) bBase[tn] = (h * POS1 + bx_pos1(wn * 64 + tn * 32 + l31)) * 16;
+        else bBase[tn] = ((wn * 2 + tn) * p.PW + l31) * 16;
+    }
+    int toff[SLABS];                                                // 3x3: the tap of this lane half in every 16-k step
+#pragma unroll
+    for (int s = 0; s < SLABS; ++s) {
+        const int t = 2 * s + h > 8 ? 8 : 2 * s + h;
+        toff[s] = TAPS == 1 ? 0 : ((t / 3) * p.PW + (t % 3)) * p.dil * 16;
+    }
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+        for (int tn = 0; tn < 2; ++tn)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[tm][tn][r] = 0.0f;
+
+    const float* xb = p.x + (size_t)n * p.Cin * HW;
+    const int nchunks = p.Cin / CK;
+    const v4f* wb = p.wp + (size_t)mt * nchunks * AUNITS;
+    v4f wr[NW];
+    float xr[NXR];
+
+    if (tid < BM) {
+        const bool real = m0 + tid < p.Cout;
+        sE[tid] = (p.scale && real) ? p.scale[m0 + tid] : 1.0f;
+        sE[BM + tid] = (p.scale && real) ? p.shift[m0 + tid] : 0.0f;
+    }
+
+    auto fetch = [&](int t) {
+        const v4f* wc = wb + (size_t)t * AUNITS;
+#pragma unroll
+        for (int j = 0; j < NW; ++j) {
+            int f = tid + j * kThreads;
+            if (AUNITS % kThreads != 0 && f >= AUNITS) f = AUNITS - 1;      // clamped duplicate
+            wr[j] = wc[f];
+        }
+        const float* xc = xb + (size_t)t * CK * HW;
+        if (TAPS == 1) {
+#pragma unroll
+            for (int j = 0; j < NT1; ++j) {
+                const float* src = xc + goff[j];
+#pragma unroll
+                for (int a = 0; a < 4; ++a) {
+                    if (S2) {
+                        const v4f lo = *reinterpret_cast<const v4f*>(src + (size_t)a * HW);
+                        const v4f hi = *reinterpret_cast<const v4f*>(src + (size_t)a * HW + 4);
+                        xr[(j * 4 + a) * 8 + 0] = lo.x; xr[(j * 4 + a) * 8 + 1] = lo.y; xr[(j * 4 + a) * 8 + 2] = lo.z; xr[(j * 4 + a) * 8 + 3] = lo.w;
+                        xr[(j * 4 + a) * 8 + 4] = hi.x; xr[(j * 4 + a) * 8 + 5] = hi.y; xr[(j * 4 + a) * 8 + 6] = hi.z; xr[(j * 4 + a) * 8 + 7] = hi.w;
+                    } else {
+                        const v4f v = *reinterpret_cast<const v4f*>(src + (size_t)a * HW);
+                        xr[(j * 4 + a) * 4 + 0] = v.x; xr[(j * 4 + a) * 4 + 1] = v.y; xr[(j * 4 + a) * 4 + 2] = v.z; xr[(j * 4 + a) * 4 + 3] = v.w;
+                    }
+                }
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < NX3; ++j)
+#pragma unroll
+                for (int a = 0; a < 4; ++a) xr[j * 4 + a] = xc[goff[j] + (size_t)a * HW];
+        }
+    };
+
+    auto stage = [&]() {
+#pragma unroll
+        for (int j = 0; j < NW; ++j) {
+            int f = tid + j * kThreads;
+            if (AUNITS % kThreads != 0 && f >= AUNITS) f = AUNITS - 1;
+            sA[f] = wr[j];
+        }
+        if (TAPS == 1) {
+#pragma unroll
+            for (int j = 0; j < NT1; ++j) {
+                const bool v = ok & (1u << j);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {                       // pixel i of the quad: channels a = 0..3
+                    constexpr int E = S2 ? 8 : 4, ST = S2 ? 2 : 1;
+                    const float c0 = v ? xr[(j * 4 + 0) * E + i * ST] : 0.0f, c1 = v ? xr[(j * 4 + 1) * E + i * ST] : 0.0f;
+                    const float c2 = v ? xr[(j * 4 + 2) * E + i * ST] : 0.0f, c3 = v ? xr[(j * 4 + 3) * E + i * ST] : 0.0f;
+                    unsigned h0, m0_, l0, h1, m1, l1;
+                    bx_split2(c0, c1, h0, m0_, l0);
+                    bx_split2(c2, c3, h1, m1, l1);
+                    unsigned char* dst = sB + loff[j] + i * 36 * 16;
+                    *reinterpret_cast<v2u*>(dst) = (v2u){h0, h1};
+                    *reinterpret_cast<v2u*>(dst + bTerm) = (v2u){m0_, m1};
+                    *reinterpret_cast<v2u*>(dst + 2 * bTerm) = (v2u){l0, l1};
+                }
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < NX3; ++j) {
+                if (live & (1u << j)) {
+                    const bool v = ok & (1u << j);
+                    const float c0 = v ? xr[j * 4 + 0] : 0.0f, c1 = v ? xr[j * 4 + 1] : 0.0f;
+                    const float c2 = v ? xr[j * 4 + 2] : 0.0f, c3 = v ? xr[j * 4 + 3] : 0.0f;
+                    unsigned h0, m0_, l0, h1, m1, l1;
+                    bx_split2(c0, c1, h0, m0_, l0);
+                    bx_split2(c2, c3, h1, m1, l1);
+                    unsigned char* dst = sB + loff[j];
+                    *reinterpret_cast<v2u*>(dst) = (v2u){h0, h1};
+                    *reinterpret_cast<v2u*>(dst + bTerm) = (v2u){m0_, m1};
+                    *reinterpret_cast<v2u*>(dst + 2 * bTerm) = (v2u){l0, l1};
+                }
+            }
+        }
+    };
+
+    auto mfma_chunk = [&]() {
+#pragma unroll
+        for (int s = 0; s < SLABS; ++s) {
+            bf8 a[2][3], b[2][3];
+#pragma unroll
+            for (int term = 0; term < 3; ++term)
+#pragma unroll
+                for (int tm = 0; tm < 2; ++tm) {
+                    const v4f q = sA[(term * GA + 2 * s) * BM + aBase + tm * 32];
+                    a[tm][term] = __builtin_bit_cast(bf8, q);
+                }
+#pragma unroll
+            for (int term = 0; term < 3; ++term)
+#pragma unroll
+                for (int tn = 0; tn < 2; ++tn) {
+                    const int off = bBase[tn] + term * bTerm + (TAPS == 1 ? 2 * s * POS1 * 16 : toff[s]);
+                    const v4f q = *reinterpret_cast<const v4f*>(sB + off);
+                    b[tn][term] = __builtin_bit_cast(bf8, q);
+                }
+            // the six products of order <= 2, smallest first
+#pragma unroll
+            for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+                for (int tn = 0; tn < 2; ++tn) {
+                    f32x16 c = acc[tm][tn];
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[tm][1], b[tn][1], c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[tm][0], b[tn][2], c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[tm][2], b[tn][0], c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[tm][0], b[tn][1], c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[tm][1], b[tn][0], c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[tm][0], b[tn][0], c, 0, 0, 0);
+                    acc[tm][tn] = c;
+                }
+        }
+    };
+
+    fetch(0);
+    for (int t = 0; t + 1 < nchunks; ++t) {
+        stage();
+        __syncthreads();
+        fetch(t + 1);
+        mfma_chunk();
+        __syncthreads();
+    }
+    stage();
+    __syncthreads();
+    mfma_chunk();
+
+    // ---- epilogue: accumulator (row = (r & 3) + 8 (r >> 2) + 4 h, column = lane & 31) -> NCHW ----------------------------------
+    int po[2];
+    bool inside[2];
+#pragma unroll
+    for (int tn = 0; tn < 2; ++tn) {
+        if (TAPS == 1) {
+            const int pp = p0 + wn * 64 + tn * 32 + l31;
+            inside[tn] = pp < HWo;
+            po[tn] = inside[tn] ? pp : 0;
+        } else {
+            const int oy = oy0 + wn * 2 + tn, ox = ox0 + l31;
+            inside[tn] = oy < p.Ho && ox < p.Wo;
+            po[tn] = inside[tn] ? oy * p.Wo + ox : 0;
+        }
+    }
+    float* yb = p.y + ((size_t)n * p.Cout + m0) * HWo;
+    const float* rb = RES ? p.res + ((size_t)n * p.Cout + m0) * HWo : nullptr;
+    const float lo = p.relu ? 0.0f : -INFINITY;
+    const int mlim = p.Cout - m0;
+    float rv[2][16];
+    auto res_load = [&](int i, float (&dst)[16]) {
+        const int tn = i >> 1, tm = i & 1;
+        const int mb = wm * 64 + tm * 32 + 4 * h;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int m = mb + (r & 3) + 8 * (r >> 2);
+            dst[r] = __builtin_nontemporal_load(&rb[(size_t)(m < mlim ? m : 0) * HWo + po[tn]]);
+        }
+    };
+    if (RES) res_load(0, rv[0]);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int tn = i >> 1, tm = i & 1;
+        if (RES && i + 1 < 4) res_load(i + 1, rv[(i + 1) & 1]);
+        const int mb = wm * 64 + tm * 32 + 4 * h;
+        float out[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int m = mb + (r & 3) + 8 * (r >> 2);
+            float v = mas_fmaf(acc[tm][tn][r], sE[m], sE[BM + m]);
+            if (RES) v += rv[i & 1][r];
+            out[r] = v < lo ? lo : v;
+        }
+        if (inside[tn]) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = mb + (r & 3) + 8 * (r >> 2);
+                if (m < mlim) yb[(size_t)m * HWo + po[tn]] = out[r];
+            }
+        }
+    }
+}
+
+// the M tile of a layer's weight image: a pure function of (ksize, Cout), shared by the pack and the launch
+inline int bx_bm(int ksize, int Cout) { return (ksize == 1 && Cout % 128 == 0) ? 128 : 64; }
+
+template <int TAPS, int BM, int BN, bool S2, bool RES>
+int bx_launch(BxP p, int N, hipStream_t st) {
+    constexpr int GA = BxGeo<TAPS>::GA;
+    p.mtiles = (p.Cout + BM - 1) / BM;
+    size_t bbytes;
+    if (TAPS == 1) {
+        p.tiles_x = (p.Ho * p.Wo + BN - 1) / BN;
+        p.tiles_y = 1;
+        p.PH = p.PW = p.PP = p.PPA = 0;
+        bbytes = (size_t)3 * 4 * 144 * (BN / 128) * 16;
+    } else {
+        p.tiles_x = (p.Wo + 31) / 32;
+        p.tiles_y = (p.Ho + 7) / 8;
+        p.PH = 8 + 2 * p.dil;
+        p.PW = 32 + 2 * p.dil;
+        p.PP = p.PH * p.PW;
+        p.PPA = (p.PP + 15) & ~15;
+        if (2 * p.PP > 4 * kThreads) return MAS_ERR_SHAPE;
+        bbytes = (size_t)3 * p.PPA * 16;
+    }
+    p.ptiles = N * p.tiles_x * p.tiles_y;
+    const size_t smem = (size_t)3 * GA * BM * 16 + 2 * BM * 4 + bbytes;
+    if (smem > 80 * 1024) return MAS_ERR_SHAPE;
+    if (smem > 64 * 1024) {
+        static bool raised[64] = {};
+        int dev = 0;
+        hipError_t e = hipGetDevice(&dev);
+        if (e != hipSuccess) return (int)e;
+        if (dev < 0 || dev >= 64 || !raised[dev]) {
+            e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv_bx<TAPS, BM, BN, S2, RES>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    80 * 1024);
+            if (e != hipSuccess) return (int)e;
+            if (dev >= 0 && dev < 64) raised[dev] = true;
+        }
+    }
+    const long long nblk = 8LL * ((p.ptiles + 7) / 8) * p.mtiles;
+    if (nblk <= 0 || nblk > 0x7fffffffLL) return MAS_ERR_SHAPE;
+    hipLaunchKernelGGL((k_conv_bx<TAPS, BM, BN, S2, RES>), dim3((unsigned)nblk), dim3(kThreads), smem, st, p);
+    return mas_launch_status();
+}
+
+template <int TAPS, int BM, int BN, bool S2>
+int bx_launch_r(const BxP& p, int N, hipStream_t st) {
+    return p.res ? bx_launch<TAPS, BM, BN, S2, true>(p, N, st) : bx_launch<TAPS, BM, BN, S2, false>(p, N, st);
+}
+}  // namespace
+
+extern "C" int mas_conv_bx_supported(int ksize, int stride, int dil, int Cin, int Cout, int H, int W) {
+    if (Cin <= 0 || Cout <= 0 || H <= 0 || W <= 0) return 0;
+    if ((long long)Cin * H * W > 0x7fffffffLL) return 0;
+    if (ksize == 1) {
+        if (dil != 1 || Cin % 32 != 0) return 0;
+        if (stride == 1) return (H * W) % 4 == 0;
+        if (stride == 2) return H % 2 == 0 && W % 8 == 0;        // output quads stay inside a row and start 16-byte aligned
+        return 0;
+    }
+    if (ksize == 3) return stride == 1 && (dil == 1 || dil == 2) && Cin % 8 == 0 && W >= 32;
+    return 0;
+}
+
+extern "C" long long mas_conv_bx_packed_bytes(int ksize, int Cin, int Cout) {
+    if ((ksize != 1 && ksize != 3) || Cin <= 0 || Cout <= 0) return 0;
+    const int BM = bx_bm(ksize, Cout), ck = ksize == 1 ? 32 : 8, ga = ksize == 1 ? 4 : kBxTaps3;
+    if (Cin % ck != 0) return 0;
+    return (long long)((Cout + BM - 1) / BM) * (Cin / ck) * 3 * ga * BM * 16;
+}
+
+extern "C" int mas_conv_bx_pack(const float* w, int Cout, int Cin, int ksize, void* wp, void* stream) {
+    if (!w || !wp) return MAS_ERR_NULL;
+    const long long bytes = mas_conv_bx_packed_bytes(ksize, Cin, Cout);
+    if (bytes <= 0) return MAS_ERR_SHAPE;
+    if ((uintptr_t)wp % 16 != 0) return MAS_ERR_ALIGN;
+    const long long units = bytes / 16;
+    const int BM = bx_bm(ksize, Cout);
+    const unsigned nblk = (unsigned)((units + 255) / 256);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (ksize == 1) hipLaunchKernelGGL(k_bx_pack<1>, dim3(nblk), dim3(256), 0, st, w, Cout, Cin, BM, static_cast<unsigned*>(wp), units);
+    else hipLaunchKernelGGL(k_bx_pack<9>, dim3(nblk), dim3(256), 0, st, w, Cout, Cin, BM, static_cast<unsigned*>(wp), units);
+    return mas_launch_status();
+}
+
+extern "C" int mas_conv_bx_fwd(const float* x, const void* wp, int N, int Cin, int H, int W, int Cout, int ksize, int stride, int dil,
+                               const float* scale, const float* shift, const float* residual, int relu, float* y, void* stream) {
+    if (!x || !wp || !y) return MAS_ERR_NULL;
+    if ((scale == nullptr) != (shift == nullptr)) return MAS_ERR_NULL;
+    if (N <= 0) return MAS_ERR_SHAPE;
+    if (!mas_conv_bx_supported(ksize, stride, dil, Cin, Cout, H, W)) return MAS_ERR_SHAPE;
+    if ((uintptr_t)x % 16 != 0 || (uintptr_t)wp % 16 != 0) return MAS_ERR_ALIGN;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    BxP p;
+    p.x = x; p.wp = static_cast<const v4f*>(wp); p.scale = scale; p.shift = shift; p.res = residual; p.y = y;
+    p.Cin = Cin; p.H = H; p.W = W; p.Cout = Cout; p.dil = dil; p.relu = relu;
+    p.Ho = (H - 1) / stride + 1;
+    p.Wo = (W - 1) / stride + 1;
+    const int BM = bx_bm(ksize, Cout);
+    if (ksize == 1) {
+        if (stride == 2) return BM == 128 ? bx_launch_r<1, 128, 128, true>(p, N, st) : bx_launch_r<1, 64, 256, true>(p, N, st);
+        return BM == 128 ? bx_launch_r<1, 128, 128, false>(p, N, st) : bx_launch_r<1, 64, 256, false>(p, N, st);
+    }
+    return bx_launch_r<9, 64, 256, false>(p, N, st);
+}

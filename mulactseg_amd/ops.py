@@ -1077,6 +1077,59 @@ def conv_mfma(conv, x, bn=None, relu=False, residual=None):
     return y
 
 
+# ------------------------------------------------------------------------------------------------
+# the same convolutions on the bf16 matrix cores, f32 in / f32 out through exact three-term operand splits (csrc/conv_bx.hip)
+# ------------------------------------------------------------------------------------------------
+def conv_bx_supported(conv, x):
+    """Shapes mas_conv_bx_fwd takes (a subset of conv_mfma_supported: 1x1 with Cin % 32 == 0 at stride 1 / 2, 3x3 stride 1 with
+    dilation 1 / 2 on planes at least 32 wide)."""
+    if not conv_mfma_supported(conv, x) or x.data_ptr() % 16:
+        return False
+    return bool(_lib.load().mas_conv_bx_supported(conv.kernel_size[0], conv.stride[0], conv.dilation[0], conv.in_channels,
+                                                  conv.out_channels, x.shape[2], x.shape[3]))
+
+
+def _conv_bx_weight(conv):
+    """The split weight image of mas_conv_bx_pack, cached on the module until the parameter changes (inference: once per
+    checkpoint load)."""
+    key = _versions((conv.weight,))
+    cache = getattr(conv, '_mas_conv_bx_pack', None)
+    if cache is None or cache[0] != key:
+        lib = _lib.load()
+        w = conv.weight.detach().contiguous()
+        M, K, kh, _ = w.shape
+        nbytes = lib.mas_conv_bx_packed_bytes(kh, K, M)
+        if nbytes <= 0:
+            raise ValueError("mas_conv_bx_pack does not take a %dx%d convolution with %d input channels" % (kh, kh, K))
+        wp = torch.empty(nbytes, dtype=torch.uint8, device=w.device)
+        with torch.cuda.device(w.device):
+            _lib.check(lib.mas_conv_bx_pack(w.data_ptr(), M, K, kh, wp.data_ptr(), _stream(w)), "mas_conv_bx_pack")
+        cache = conv._mas_conv_bx_pack = (key, wp)
+    return cache[1]
+
+
+def conv_bx(conv, x, bn=None, relu=False, residual=None):
+    """relu?(bn(conv(x)) + residual) in one kernel on the bf16 matrix cores with f32 operands and results (see conv_mfma)."""
+    x = x.contiguous()
+    N, K, H, W = x.shape
+    M = conv.out_channels
+    ks, s, d = conv.kernel_size[0], conv.stride[0], conv.dilation[0]
+    wp = _conv_bx_weight(conv)
+    if bn is not None and bn.num_features != M:
+        raise ValueError("BatchNorm has %d features, the convolution %d output channels" % (bn.num_features, M))
+    scale, shift = _bn_fold(bn) if bn is not None else (None, None)
+    Ho, Wo = (H - 1) // s + 1, (W - 1) // s + 1
+    if residual is not None and (tuple(residual.shape) != (N, M, Ho, Wo) or residual.dtype != torch.float32 or residual.device != x.device):
+        raise ValueError("residual must be float32 %s on %s, got %s %s on %s"
+                         % ((N, M, Ho, Wo), x.device, residual.dtype, tuple(residual.shape), residual.device))
+    res = residual.contiguous() if residual is not None else None
+    y = torch.empty((N, M, Ho, Wo), dtype=torch.float32, device=x.device)
+    with torch.cuda.device(x.device):
+        _lib.check(_lib.load().mas_conv_bx_fwd(x.data_ptr(), wp.data_ptr(), N, K, H, W, M, ks, s, d, _opt(scale), _opt(shift), _opt(res),
+                                               int(relu), y.data_ptr(), _stream(x)), "mas_conv_bx_fwd")
+    return y
+
+
 def stem_conv_supported(conv, x):
     """The deep stem's first convolution (3 -> C, 3x3, stride 2, padding 1) on csrc/stem.hip: fp32 NCHW, W % 8 == 0."""
     return (x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and x.shape[1] == 3 and conv.in_channels == 3

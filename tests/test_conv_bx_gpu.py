@@ -1,0 +1,166 @@
+"""csrc/conv_bx.hip: the inference convolutions on the bf16 matrix cores with f32 operands and results (every operand split
+exactly into three bf16 terms, six partial products, f32 accumulation) against torch's conv2d in float64 on the layer
+geometries of the network (models/segmentation/backbone/resnet.py:129-160, deeplabv3.py:85-137): 1x1 at stride 1 / 2, 3x3 at
+dilation 1 / 2, partial tiles, planes that are not a multiple of the tile, every epilogue.  The error bound is the one of
+the f32-MFMA kernel (tests/test_conv_mfma_gpu.py): 2e-5 of the output scale -- and the two kernels are compared with each
+other on the same data: the split form must not be less accurate than the f32 form by more than rounding noise."""
+import numpy as np
+import pytest
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+CASES = [
+    # Cin, Cout, k, stride, dil, N, H, W
+    (128, 256, 1, 1, 1, 2, 24, 40),      # layer1 downsample shape: 128-row M tile, partial pixel tile
+    (256, 64, 1, 1, 1, 1, 20, 52),       # layer1 conv1: 64-row M tile x 256 pixels
+    (64, 256, 1, 1, 1, 2, 16, 48),       # layer1 conv3: two chunks
+    (1024, 512, 1, 1, 1, 1, 12, 12),     # deep 1x1: 32 chunks, one partial tile
+    (256, 512, 1, 2, 1, 2, 34, 64),      # downsample: 1x1 stride 2
+    (512, 1024, 1, 2, 1, 1, 16, 40),     # downsample, plane narrower than a tile row
+    (2048, 256, 1, 1, 1, 1, 9, 36),      # ASPP 1x1
+    (32, 200, 1, 1, 1, 1, 10, 30),       # Cout 200: the last 64-row M tile is mostly padding
+    (64, 64, 3, 1, 1, 2, 20, 70),        # layer1 conv2
+    (64, 128, 3, 1, 1, 1, 33, 45),       # stem conv3, odd plane
+    (512, 512, 3, 1, 2, 1, 13, 40),      # layer4 conv2: dilation 2
+    (256, 256, 3, 1, 2, 1, 9, 33),       # dilation 2, partial tiles in both directions
+    (8, 64, 3, 1, 1, 1, 5, 32),          # one chunk, plane lower than a tile
+    (64, 200, 3, 1, 1, 1, 9, 37),        # Cout 200
+]
+
+
+def _ref(x, conv, bn, relu, res):
+    y = conv(x)
+    if bn is not None:
+        y = bn(y)
+    if res is not None:
+        y = y + res
+    return F.relu(y) if relu else y
+
+
+@pytest.mark.parametrize("Cin,Cout,k,stride,dil,N,H,W", CASES)
+@pytest.mark.parametrize("epi", ["bare", "bn_relu", "bn_res_relu"])
+def test_conv_bx_matches_conv2d(Cin, Cout, k, stride, dil, N, H, W, epi):
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from mulactseg_amd import ops
+    torch.manual_seed(Cin * 7 + Cout + k + stride + dil + H)
+    conv = nn.Conv2d(Cin, Cout, k, stride=stride, padding=dil if k == 3 else 0, dilation=dil, bias=False).cuda()
+    bn = None
+    if epi != "bare":
+        bn = nn.BatchNorm2d(Cout).cuda().eval()
+        with torch.no_grad():
+            bn.weight.uniform_(0.5, 1.5); bn.bias.normal_(); bn.running_mean.normal_(); bn.running_var.uniform_(0.5, 2.0)
+    x = torch.randn(N, Cin, H, W, device='cuda')
+    assert ops.conv_bx_supported(conv, x)
+    with torch.no_grad():
+        res = torch.randn_like(conv(x)) if epi == "bn_res_relu" else None
+        ref = _ref(x.double(), conv.double(), bn.double() if bn is not None else None, epi != "bare", res.double() if res is not None else None)
+        conv.float()
+        if bn is not None:
+            bn.float()
+        y = ops.conv_bx(conv, x, bn, relu=epi != "bare", residual=res)
+        y32 = ops.conv_mfma(conv, x, bn, relu=epi != "bare", residual=res)
+    assert y.shape == ref.shape
+    scale = float(ref.abs().max())
+    err = float((y.double() - ref).abs().max())
+    err32 = float((y32.double() - ref).abs().max())
+    assert err <= 2e-5 * scale, (err, scale)
+    assert err <= 2.0 * err32 + 1e-6 * scale, (err, err32, scale)       # as accurate as the f32 matrix cores on the same data
+
+
+def test_conv_bx_exact_on_integers():
+    """Integers below 2^8 are single bf16 terms and their products and sums are exact in f32: lane maps, tap offsets, the
+    zero tap, the position swizzle of the 1x1 image, the chunk order and the epilogue are pinned bit for bit."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from mulactseg_amd import ops
+    g = torch.Generator(device='cuda').manual_seed(3)
+    for k, stride, dil, cout in ((1, 1, 1, 128), (1, 1, 1, 64), (3, 1, 1, 128), (3, 1, 2, 64), (1, 2, 1, 128), (1, 2, 1, 64)):
+        conv = nn.Conv2d(64, cout, k, stride=stride, padding=dil if k == 3 else 0, dilation=dil, bias=False).cuda()
+        with torch.no_grad():
+            conv.weight.copy_(torch.randint(-3, 4, conv.weight.shape, generator=g, device='cuda').float())
+            x = torch.randint(-4, 5, (2, 64, 38, 56), generator=g, device='cuda').float()
+            assert ops.conv_bx_supported(conv, x)
+            y = ops.conv_bx(conv, x)
+            ref = F.conv2d(x.double(), conv.weight.double(), None, stride, dil if k == 3 else 0, dil).float()
+            assert torch.equal(y, ref), (k, stride, dil, cout)
+
+
+def test_conv_bx_keeps_all_24_bits_of_both_operands():
+    """Operands with full 24-bit significands whose products need the low terms: integers up to 2^24 times powers of two chosen so
+    that every partial sum is an integer below 2^24 ONLY if the (h, m, l) terms are all there -- x = 2^16 a + 2^8 b + c against
+    weights of 1: the sum over 32 channels of x must come back exactly (a one-term or two-term split loses c or b)."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from mulactseg_amd import ops
+    g = torch.Generator(device='cuda').manual_seed(5)
+    conv = nn.Conv2d(32, 64, 1, bias=False).cuda()
+    with torch.no_grad():
+        conv.weight.zero_()
+        conv.weight[:, 0] = 1.0                                   # y[m] = x[channel 0]: the product 1 * x must keep all of x
+        conv.weight[1, :, 0, 0] = 0.0
+        conv.weight[1, 5] = 3.0                                   # 3 * x[5]: h*h, m*h, l*h terms with a two-bit weight
+        a = torch.randint(1 << 23, 1 << 24, (1, 32, 8, 32), generator=g, device='cuda')
+        x = a.float()                                             # full 24-bit significands
+        y = ops.conv_bx(conv, x)
+        assert torch.equal(y[:, 0], x[:, 0])
+        assert torch.equal(y[:, 1].double(), (3.0 * x[:, 5].double()).float().double()) or \
+            float((y[:, 1].double() - 3.0 * x[:, 5].double()).abs().max()) <= 4.0        # 3x needs 26 bits: one rounding (ulp = 4 at 2^25)
+        # and the weight side: w with 24 bits, x = 1
+        w = torch.randint(1 << 23, 1 << 24, (64,), generator=g, device='cuda').float()
+        conv.weight.zero_()
+        conv.weight[:, 7, 0, 0] = w
+        x.zero_()
+        x[:, 7] = 1.0
+        y = ops.conv_bx(conv, x)
+        assert torch.equal(y[0, :, 3, 3], w)
+
+
+def test_conv_bx_weight_cache_follows_the_parameter():
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from mulactseg_amd import ops
+    conv = nn.Conv2d(64, 64, 1, bias=False).cuda()
+    x = torch.randn(1, 64, 8, 32, device='cuda')
+    with torch.no_grad():
+        a = ops.conv_bx(conv, x)
+        conv.weight.mul_(2.0)
+        b = ops.conv_bx(conv, x)
+    assert torch.allclose(b, 2 * a, rtol=1e-6, atol=1e-6)
+
+
+@pytest.mark.parametrize("seed", range(16))
+def test_conv_bx_randomised_geometries(seed):
+    """Random supported geometries against conv2d in float64: partial tiles, halo clamps, the chunk walk, the padding of the
+    output channels hold wherever conv_bx_supported says yes."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from mulactseg_amd import ops
+    rs = np.random.RandomState(2000 + seed)
+    k = int(rs.choice([1, 3]))
+    stride = int(rs.choice([1, 2])) if k == 1 else 1
+    dil = 1 if k == 1 else int(rs.choice([1, 2]))
+    cin = int(rs.choice([8, 16, 24, 40, 64, 72, 128])) if k == 3 else int(rs.choice([32, 64, 96, 160]))
+    cout = int(rs.choice([16, 48, 64, 80, 128, 192, 200, 256]))
+    N = int(rs.randint(1, 4))
+    if k == 3:
+        H, W = int(rs.randint(3, 40)), int(rs.randint(32, 90))
+    elif stride == 2:
+        H, W = 2 * int(rs.randint(2, 30)), 8 * int(rs.randint(1, 12))
+    else:
+        H, W = int(rs.randint(3, 60)), 4 * int(rs.randint(1, 24))
+    torch.manual_seed(seed)
+    conv = nn.Conv2d(cin, cout, k, stride=stride, padding=dil if k == 3 else 0, dilation=dil, bias=False).cuda()
+    bn = nn.BatchNorm2d(cout).cuda().eval()
+    with torch.no_grad():
+        bn.weight.uniform_(0.5, 1.5); bn.bias.normal_(); bn.running_mean.normal_(); bn.running_var.uniform_(0.5, 2.0)
+        x = torch.randn(N, cin, H, W, device='cuda')
+        assert ops.conv_bx_supported(conv, x), (k, stride, dil, cin, cout, H, W)
+        res = torch.randn_like(conv(x)) if seed % 2 else None
+        ref = _ref(x.double(), conv.double(), bn.double(), True, res.double() if res is not None else None)
+        conv.float(); bn.float()
+        y = ops.conv_bx(conv, x, bn, relu=True, residual=res)
+    assert float((y.double() - ref).abs().max()) <= 2e-5 * float(ref.abs().max()), (k, stride, dil, cin, cout, N, H, W)
