@@ -61,6 +61,11 @@ def _bn_act(bn, x, relu=True, residual=None):
     return F.relu(y) if relu else y
 
 
+def _INFER_BX():
+    """MAS_INFER_CONV=f32 keeps every inference convolution on the f32 matrix cores (csrc/conv_mfma.hip) for A/B runs."""
+    return os.environ.get("MAS_INFER_CONV", "bx") != "f32"
+
+
 def _conv_bn_act(conv, bn, x, relu=True, residual=None, fork=False):
     """relu?(bn(conv(x)) + residual); fork=True: (that, x') with x' = x for the OTHER consumer of x (in training on the package's
     kernels an alias of x through which that consumer's gradient reaches the epilogue of this convolution's input-gradient kernel).  Inference on the GPU: ONE kernel on the f32 matrix cores with the BatchNorm, the
@@ -71,6 +76,10 @@ def _conv_bn_act(conv, bn, x, relu=True, residual=None, fork=False):
         if fork:
             return _conv_bn_act(conv, bn, x, relu, residual), x
         from .. import ops
+        if _INFER_BX() and x.shape[2] * x.shape[3] >= 256 and ops.conv_bx_supported(conv, x):
+            # bf16 matrix cores, f32 operands split exactly into three terms (csrc/conv_bx.hip): f32 error bound, 1.5-2x the f32 MFMA kernel
+            _took("conv_bn_act", "hip_bx")
+            return ops.conv_bx(conv, x, bn, relu, residual)
         if x.shape[2] * x.shape[3] >= 256 and ops.conv_mfma_supported(conv, x):
             _took("conv_bn_act", "hip_mfma")
             return ops.conv_mfma(conv, x, bn, relu, residual)
@@ -162,7 +171,9 @@ class Bottleneck(nn.Module):
         y = None
         if x.is_cuda and not self.training:
             from .. import ops
-            if ops.conv1x1_bn_act_supported(self.conv1, self.bn1, x):     # small-K 1x1 + BN + ReLU in one kernel (csrc/conv1x1.hip)
+            if _INFER_BX() and x.shape[2] * x.shape[3] >= 256 and ops.conv_bx_supported(self.conv1, x):
+                pass                                                      # (the split-bf16 kernel is faster than the VALU one below)
+            elif ops.conv1x1_bn_act_supported(self.conv1, self.bn1, x):     # small-K 1x1 + BN + ReLU in one kernel (csrc/conv1x1.hip)
                 _took("conv1x1_bn_act", "hip")
                 y = ops.conv1x1_bn_act(self.conv1, self.bn1, x, True)
         if y is None:

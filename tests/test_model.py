@@ -87,7 +87,34 @@ def test_inference_forward_runs_on_this_packages_kernels_and_matches_the_cpu_mod
         paths = deeplab.path_report(reset=True)
         out_q = dev(x.cuda(), lowres=True)
     assert 'miopen+bn' not in paths.get('conv_bn_act', {}), paths
-    assert paths['conv_bn_act'].get('hip_mfma', 0) >= 55 and paths['conv_bn_act'].get('hip_stem', 0) == 1
+    took = paths['conv_bn_act']
+    assert took.get('hip_mfma', 0) + took.get('hip_bx', 0) >= 55 and took.get('hip_stem', 0) == 1, paths
+    assert took.get('hip_bx', 0) >= 40, paths           # the split-bf16 kernel (csrc/conv_bx.hip) takes every shape it supports
     assert 'aten' not in paths.get('bn_act', {}) and 'aten' not in paths.get('upsample', {})
     assert float((out_full.cpu() - ref_full).abs().max()) < 1e-4
     assert float((out_q.cpu() - ref_q).abs().max()) < 1e-4
+
+
+@pytest.mark.gpu
+def test_split_bf16_and_f32_matrix_core_forwards_agree(monkeypatch):
+    """The same eval forward with every dense convolution on the f32 matrix cores (MAS_INFER_CONV=f32, csrc/conv_mfma.hip) and with
+    the split-bf16 kernel (csrc/conv_bx.hip) where it applies: both within 1e-4 of the CPU modules, and the split form is not
+    further from them than the f32 form by more than rounding noise."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from mulactseg_amd.models import deeplab
+    g, net, _ = _load()
+    x = torch.from_numpy(np.random.RandomState(7).standard_normal(size=(2, 3, 256, 512)).astype(np.float32))
+    with torch.no_grad():
+        ref = net(x, lowres=True)
+        dev = net.cuda()
+        monkeypatch.setenv("MAS_INFER_CONV", "f32")
+        deeplab.path_report(reset=True)
+        out32 = dev(x.cuda(), lowres=True).cpu()
+        assert 'hip_bx' not in deeplab.path_report(reset=True)['conv_bn_act']
+        monkeypatch.setenv("MAS_INFER_CONV", "bx")
+        outbx = dev(x.cuda(), lowres=True).cpu()
+        assert deeplab.path_report(reset=True)['conv_bn_act'].get('hip_bx', 0) >= 40
+    e32, ebx = float((out32 - ref).abs().max()), float((outbx - ref).abs().max())
+    assert e32 < 1e-4 and ebx < 1e-4, (e32, ebx)
+    assert ebx <= 2.0 * e32 + 2e-6, (e32, ebx)
