@@ -33,6 +33,7 @@ typedef float v4f __attribute__((ext_vector_type(4)));
 typedef unsigned v2u __attribute__((ext_vector_type(2)));
 typedef __bf16 bf8 __attribute__((ext_vector_type(8)));
 
+constexpr int kBxPPA = 432;                     // 3x3: positions of one term of the B image (the 12 x 36 patch of dilation 2; 10 x 34 at dilation 1)
 constexpr int kBxTaps3 = 10;                    // 3x3: nine taps + one zero-weight tap (five 16-k steps per 8-channel chunk)
 
 struct BxP {
@@ -45,6 +46,9 @@ struct BxP {
     int Cin, H, W, Cout, Ho, Wo, dil, relu;
     int tiles_x, tiles_y, ptiles, mtiles;
     int PH, PW, PP, PPA;                        // 3x3 input patch: rows, columns, pixels, pixels rounded up to 16
+#ifdef BX_STAMPS
+    unsigned long long* stamps;
+#endif
 };
 
 // k groups of a chunk's A image / B image
@@ -108,7 +112,29 @@ __global__ void k_bx_pack(const float* __restrict__ w, int Cout, int Cin, int BM
     *reinterpret_cast<uint4*>(out + 4 * u) = make_uint4(o[0], o[1], o[2], o[3]);
 }
 
+// -DBX_STAMPS: a measurement build (tools/bx_stamps.py) -- wave 0 of every workgroup sums the cycles (s_memtime) it spends in each
+// phase of the loop and writes them to the buffer registered with mas_conv_bx_debug_stamps
+#ifdef BX_STAMPS
+static unsigned long long* g_bx_stamps = nullptr;
+#define BX_T(i) do { if (stamp) { const long long now_ = clock64(); acc_t[i] += now_ - last_t; last_t = now_; } } while (0)
+#else
+#define BX_T(i) do { } while (0)
+#endif
+
+// Buffer resources (raw, stride 0): loads / stores at `voffset` beyond the size read zeros / are dropped -- pixels outside the
+// plane, channels beyond Cout and the tail of a partial weight load need no predicates, selects or 64-bit address arithmetic;
+// the scalar offset (not range-checked) carries what is uniform (channel a of a task, piece j of the weight image).
+constexpr unsigned kBxRsrcFlags = 0x00020000;
+constexpr int kBxOut = (int)0x80000000u;        // a byte offset beyond every resource used here (sizes are checked < 2^31 by the host)
+
 // ---- the convolution -------------------------------------------------------------------------------------------------------
+// What was measured and lost on this kernel (tools/bx_ab.sh: library builds A/B in one GPU session, per-layer table of the pool
+// forward): the A image by LDS-DMA into two buffers (no staging registers, no ds_write: 2-20 % SLOWER on the layers with many M
+// tiles); two chunks in flight with two register sets (+5 %: the loop is not waiting for memory); three workgroups per CU for
+// the 1x1 form (+2 %); issue priority raised for the staging phase or for the MFMA phase (+-1 %).  In-kernel stamps
+// (tools/bx_stamps.py) show why: while the SIMD partner (a wave of the CU's other workgroup) streams MFMAs, a wave gets about one
+// instruction issued per MFMA whatever its kind, so the staging + fetch phases cost by their instruction COUNT -- hence the
+// buffer-resource forms below (no address arithmetic, no bounds selects).
 template <int TAPS, int BM, int BN, bool S2, bool RES>
 __global__ __launch_bounds__(kThreads, 2) void k_conv_bx(const BxP p) {
     constexpr int CK = BxGeo<TAPS>::CK, GA = BxGeo<TAPS>::GA, SLABS = BxGeo<TAPS>::SLABS;
@@ -116,15 +142,15 @@ __global__ __launch_bounds__(kThreads, 2) void k_conv_bx(const BxP p) {
     static_assert(WN * 64 == BN, "a wave owns 64 x 64");
     constexpr int AUNITS = 3 * GA * BM;                         // 16-byte units of a chunk's A image
     constexpr int NW = (AUNITS + kThreads - 1) / kThreads;
+    constexpr bool WTAIL = AUNITS % kThreads != 0;              // the last weight load of a thread may lie beyond the image
     constexpr int POS1 = 144 * (BN / 128);                      // 1x1: units per k group of the B image
-    constexpr int NT1 = BN / 128;                               // 1x1: (4 channels x 4 pixels) staging tasks per thread
-    constexpr int NX3 = 4;                                      // 3x3: (4 channels x 1 pixel) staging tasks per thread, at most
-    constexpr int NXR = TAPS == 1 ? NT1 * 4 * (S2 ? 8 : 4) : NX3 * 4;   // staging registers: 1x1 (4 channels x 4 | 8 floats) per task, 3x3 4 channels per task
+    constexpr int NT = TAPS == 1 ? BN / 128 : 4;                // staging tasks per thread: 1x1 (4 channels x 4 pixels), 3x3 (4 channels x 1 pixel)
+    constexpr int NXR = TAPS == 1 ? NT * 4 * (S2 ? 8 : 4) : NT * 4;
     extern __shared__ __attribute__((aligned(16))) unsigned char bx_smem[];
     v4f* sA = reinterpret_cast<v4f*>(bx_smem);                                       // [3][GA][BM] units
     float* sE = reinterpret_cast<float*>(bx_smem + (size_t)AUNITS * 16);             // [2][BM]
     unsigned char* sB = bx_smem + (size_t)AUNITS * 16 + 2 * BM * 4;                  // [3][k groups][positions] units
-    const int bTerm = TAPS == 1 ? 4 * POS1 * 16 : p.PPA * 16;                      // bytes of one term of the B image
+    constexpr int bTerm = TAPS == 1 ? 4 * POS1 * 16 : kBxPPA * 16;                 // bytes of one term of the B image (an immediate of the LDS reads)
 
     const int tid = threadIdx.x;
     const int bid = blockIdx.x;
@@ -147,34 +173,36 @@ __global__ __launch_bounds__(kThreads, 2) void k_conv_bx(const BxP p) {
     }
     const int m0 = mt * BM;
 
-    // ---- staging descriptors (the same for every chunk) ------------------------------------------------------------------------
-    int goff[TAPS == 1 ? NT1 : NX3], loff[TAPS == 1 ? NT1 : NX3];
-    unsigned ok = 0, live = 0;
+    // ---- staging descriptors (the same for every chunk): byte offset inside the chunk's x resource, byte offset in the B image --
+    int goff[NT], loff[NT];
+    unsigned live = 0;
     if (TAPS == 1) {
 #pragma unroll
-        for (int j = 0; j < NT1; ++j) {
+        for (int j = 0; j < NT; ++j) {
+            // 16 consecutive lanes = 8 pixel quads x the two channel quads of one k group: their 8-byte LDS stores (16-byte pitch,
+            // halves 0 / 8) touch 16 different bank pairs; the global loads still run over 128-byte segments
             const int task = tid + j * kThreads;
-            const int q = task / (BN / 4), pq = task - q * (BN / 4);             // channel quad 0..7, pixel quad
+            const int rest = task >> 4;
+            const int pq = (task & 7) | ((rest % (BN / 32)) << 3);                // pixel quad of the tile
+            const int q = ((rest / (BN / 32)) << 1) | ((task >> 3) & 1);          // channel quad 0..7 of the chunk
             const int po = p0 + 4 * pq;
-            goff[j] = q * 4 * HW;
-            live |= 1u << j;
+            goff[j] = kBxOut;
             if (po < HWo) {
-                ok |= 1u << j;
+                int pix = po;
                 if (S2) {
                     const int oy = po / p.Wo, ox = po - oy * p.Wo;
-                    goff[j] += 2 * oy * p.W + 2 * ox;
-                } else {
-                    goff[j] += po;
+                    pix = 2 * oy * p.W + 2 * ox;
                 }
+                goff[j] = (q * 4 * HW + pix) * 4;
             }
             loff[j] = ((q >> 1) * POS1 + bx_pos1(4 * pq)) * 16 + (q & 1) * 8;
         }
     } else {
         const int iy0 = oy0 - p.dil, ix0 = ox0 - p.dil;
 #pragma unroll
-        for (int j = 0; j < NX3; ++j) {
+        for (int j = 0; j < NT; ++j) {
             const int e = tid + j * kThreads;
-            goff[j] = 0;
+            goff[j] = kBxOut;
             loff[j] = 0;
             if (e < 2 * p.PP) {
                 const int cq = e >= p.PP ? 1 : 0, pix = e - cq * p.PP;
@@ -182,14 +210,11 @@ __global__ __launch_bounds__(kThreads, 2) void k_conv_bx(const BxP p) {
                 const int iy = iy0 + py, ix = ix0 + px;
                 live |= 1u << j;
                 loff[j] = pix * 16 + cq * 8;
-                goff[j] = cq * 4 * HW;
-                if (iy >= 0 && iy < p.H && ix >= 0 && ix < p.W) {
-                    ok |= 1u << j;
-                    goff[j] += iy * p.W + ix;
-                }
+                if (iy >= 0 && iy < p.H && ix >= 0 && ix < p.W) goff[j] = (cq * 4 * HW + iy * p.W + ix) * 4;
             }
         }
     }
+    const int wtail = (tid + (NW - 1) * kThreads < AUNITS) ? (tid + (NW - 1) * kThreads) * 16 : kBxOut;
 
     // ---- MFMA operand addressing -----------------------------------------------------------------------------------------------
     const int wave = tid >> 6, lane = tid & 63, l31 = lane & 31, h = lane >> 5;
@@ -218,6 +243,7 @@ __global__ __launch_bounds__(kThreads, 2) void k_conv_bx(const BxP p) {
     const float* xb = p.x + (size_t)n * p.Cin * HW;
     const int nchunks = p.Cin / CK;
     const v4f* wb = p.wp + (size_t)mt * nchunks * AUNITS;
+    const int hw4 = HW * 4;
     v4f wr[NW];
     float xr[NXR];
 
@@ -228,74 +254,63 @@ __global__ __launch_bounds__(kThreads, 2) void k_conv_bx(const BxP p) {
     }
 
     auto fetch = [&](int t) {
-        const v4f* wc = wb + (size_t)t * AUNITS;
+        const __amdgpu_buffer_rsrc_t wres = __builtin_amdgcn_make_buffer_rsrc(const_cast<v4f*>(wb + (size_t)t * AUNITS), 0, AUNITS * 16, kBxRsrcFlags);
 #pragma unroll
         for (int j = 0; j < NW; ++j) {
-            int f = tid + j * kThreads;
-            if (AUNITS % kThreads != 0 && f >= AUNITS) f = AUNITS - 1;      // clamped duplicate
-            wr[j] = wc[f];
+            if (WTAIL && j == NW - 1) wr[j] = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(wres, wtail, 0, 0));
+            else wr[j] = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(wres, tid * 16, j * kThreads * 16, 0));
         }
-        const float* xc = xb + (size_t)t * CK * HW;
+        const __amdgpu_buffer_rsrc_t xres = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(xb + (size_t)t * CK * HW), 0, CK * hw4, kBxRsrcFlags);
         if (TAPS == 1) {
 #pragma unroll
-            for (int j = 0; j < NT1; ++j) {
-                const float* src = xc + goff[j];
+            for (int j = 0; j < NT; ++j)
 #pragma unroll
                 for (int a = 0; a < 4; ++a) {
                     if (S2) {
-                        const v4f lo = *reinterpret_cast<const v4f*>(src + (size_t)a * HW);
-                        const v4f hi = *reinterpret_cast<const v4f*>(src + (size_t)a * HW + 4);
+                        const v4f lo = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(xres, goff[j], a * hw4, 0));
+                        const v4f hi = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(xres, goff[j], a * hw4 + 16, 0));
                         xr[(j * 4 + a) * 8 + 0] = lo.x; xr[(j * 4 + a) * 8 + 1] = lo.y; xr[(j * 4 + a) * 8 + 2] = lo.z; xr[(j * 4 + a) * 8 + 3] = lo.w;
                         xr[(j * 4 + a) * 8 + 4] = hi.x; xr[(j * 4 + a) * 8 + 5] = hi.y; xr[(j * 4 + a) * 8 + 6] = hi.z; xr[(j * 4 + a) * 8 + 7] = hi.w;
                     } else {
-                        const v4f v = *reinterpret_cast<const v4f*>(src + (size_t)a * HW);
+                        const v4f v = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(xres, goff[j], a * hw4, 0));
                         xr[(j * 4 + a) * 4 + 0] = v.x; xr[(j * 4 + a) * 4 + 1] = v.y; xr[(j * 4 + a) * 4 + 2] = v.z; xr[(j * 4 + a) * 4 + 3] = v.w;
                     }
                 }
-            }
         } else {
 #pragma unroll
-            for (int j = 0; j < NX3; ++j)
+            for (int j = 0; j < NT; ++j)
 #pragma unroll
-                for (int a = 0; a < 4; ++a) xr[j * 4 + a] = xc[goff[j] + (size_t)a * HW];
+                for (int a = 0; a < 4; ++a) xr[j * 4 + a] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xres, goff[j], a * hw4, 0));
         }
     };
 
     auto stage = [&]() {
 #pragma unroll
         for (int j = 0; j < NW; ++j) {
-            int f = tid + j * kThreads;
-            if (AUNITS % kThreads != 0 && f >= AUNITS) f = AUNITS - 1;
-            sA[f] = wr[j];
+            const int f = tid + j * kThreads;
+            if (!WTAIL || j < NW - 1 || f < AUNITS) sA[f] = wr[j];
         }
         if (TAPS == 1) {
 #pragma unroll
-            for (int j = 0; j < NT1; ++j) {
-                const bool v = ok & (1u << j);
+            for (int j = 0; j < NT; ++j)
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {                       // pixel i of the quad: channels a = 0..3
                     constexpr int E = S2 ? 8 : 4, ST = S2 ? 2 : 1;
-                    const float c0 = v ? xr[(j * 4 + 0) * E + i * ST] : 0.0f, c1 = v ? xr[(j * 4 + 1) * E + i * ST] : 0.0f;
-                    const float c2 = v ? xr[(j * 4 + 2) * E + i * ST] : 0.0f, c3 = v ? xr[(j * 4 + 3) * E + i * ST] : 0.0f;
                     unsigned h0, m0_, l0, h1, m1, l1;
-                    bx_split2(c0, c1, h0, m0_, l0);
-                    bx_split2(c2, c3, h1, m1, l1);
+                    bx_split2(xr[(j * 4 + 0) * E + i * ST], xr[(j * 4 + 1) * E + i * ST], h0, m0_, l0);
+                    bx_split2(xr[(j * 4 + 2) * E + i * ST], xr[(j * 4 + 3) * E + i * ST], h1, m1, l1);
                     unsigned char* dst = sB + loff[j] + i * 36 * 16;
                     *reinterpret_cast<v2u*>(dst) = (v2u){h0, h1};
                     *reinterpret_cast<v2u*>(dst + bTerm) = (v2u){m0_, m1};
                     *reinterpret_cast<v2u*>(dst + 2 * bTerm) = (v2u){l0, l1};
                 }
-            }
         } else {
 #pragma unroll
-            for (int j = 0; j < NX3; ++j) {
+            for (int j = 0; j < NT; ++j) {
                 if (live & (1u << j)) {
-                    const bool v = ok & (1u << j);
-                    const float c0 = v ? xr[j * 4 + 0] : 0.0f, c1 = v ? xr[j * 4 + 1] : 0.0f;
-                    const float c2 = v ? xr[j * 4 + 2] : 0.0f, c3 = v ? xr[j * 4 + 3] : 0.0f;
                     unsigned h0, m0_, l0, h1, m1, l1;
-                    bx_split2(c0, c1, h0, m0_, l0);
-                    bx_split2(c2, c3, h1, m1, l1);
+                    bx_split2(xr[j * 4 + 0], xr[j * 4 + 1], h0, m0_, l0);
+                    bx_split2(xr[j * 4 + 2], xr[j * 4 + 3], h1, m1, l1);
                     unsigned char* dst = sB + loff[j];
                     *reinterpret_cast<v2u*>(dst) = (v2u){h0, h1};
                     *reinterpret_cast<v2u*>(dst + bTerm) = (v2u){m0_, m1};
@@ -341,46 +356,59 @@ __global__ __launch_bounds__(kThreads, 2) void k_conv_bx(const BxP p) {
         }
     };
 
+#ifdef BX_STAMPS
+    const bool stamp = p.stamps != nullptr && tid == 0;
+    long long acc_t[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    long long last_t = stamp ? clock64() : 0;
+    const long long first_t = last_t;
+#endif
     fetch(0);
+    BX_T(0);
     for (int t = 0; t + 1 < nchunks; ++t) {
         stage();
+        BX_T(1);
         __syncthreads();
+        BX_T(2);
         fetch(t + 1);
+        __builtin_amdgcn_sched_barrier(0);          // the loads of chunk t + 1 are issued in FRONT of the MFMAs of chunk t
+        BX_T(3);
         mfma_chunk();
+        BX_T(4);
         __syncthreads();
+        BX_T(5);
     }
     stage();
     __syncthreads();
     mfma_chunk();
+    BX_T(6);
 
     // ---- epilogue: accumulator (row = (r & 3) + 8 (r >> 2) + 4 h, column = lane & 31) -> NCHW ----------------------------------
-    int po[2];
-    bool inside[2];
+    // y (and the residual) of this M tile as a buffer resource of min(BM, Cout - m0) rows: a row beyond Cout or a pixel outside
+    // the plane is out of range (dropped / zero) -- one 32-bit add per element, no predicates
+    const int mrows = p.Cout - m0 < BM ? p.Cout - m0 : BM;
+    const int row4 = HWo * 4;
+    const __amdgpu_buffer_rsrc_t yres = __builtin_amdgcn_make_buffer_rsrc(p.y + ((size_t)n * p.Cout + m0) * HWo, 0, mrows * row4, kBxRsrcFlags);
+    const __amdgpu_buffer_rsrc_t rres = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(RES ? p.res + ((size_t)n * p.Cout + m0) * HWo : p.x), 0, RES ? mrows * row4 : 0, kBxRsrcFlags);
+    int vo[2];
 #pragma unroll
     for (int tn = 0; tn < 2; ++tn) {
         if (TAPS == 1) {
             const int pp = p0 + wn * 64 + tn * 32 + l31;
-            inside[tn] = pp < HWo;
-            po[tn] = inside[tn] ? pp : 0;
+            vo[tn] = pp < HWo ? pp * 4 : kBxOut;
         } else {
             const int oy = oy0 + wn * 2 + tn, ox = ox0 + l31;
-            inside[tn] = oy < p.Ho && ox < p.Wo;
-            po[tn] = inside[tn] ? oy * p.Wo + ox : 0;
+            vo[tn] = (oy < p.Ho && ox < p.Wo) ? (oy * p.Wo + ox) * 4 : kBxOut;
         }
     }
-    float* yb = p.y + ((size_t)n * p.Cout + m0) * HWo;
-    const float* rb = RES ? p.res + ((size_t)n * p.Cout + m0) * HWo : nullptr;
     const float lo = p.relu ? 0.0f : -INFINITY;
-    const int mlim = p.Cout - m0;
     float rv[2][16];
     auto res_load = [&](int i, float (&dst)[16]) {
         const int tn = i >> 1, tm = i & 1;
         const int mb = wm * 64 + tm * 32 + 4 * h;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int m = mb + (r & 3) + 8 * (r >> 2);
-            dst[r] = __builtin_nontemporal_load(&rb[(size_t)(m < mlim ? m : 0) * HWo + po[tn]]);
-        }
+        for (int r = 0; r < 16; ++r)                          // (read once: non-temporal)
+            dst[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rres, vo[tn] + (mb + (r & 3) + 8 * (r >> 2)) * row4, 0, 2));
     };
     if (RES) res_load(0, rv[0]);
 #pragma unroll
@@ -388,22 +416,24 @@ __global__ __launch_bounds__(kThreads, 2) void k_conv_bx(const BxP p) {
         const int tn = i >> 1, tm = i & 1;
         if (RES && i + 1 < 4) res_load(i + 1, rv[(i + 1) & 1]);
         const int mb = wm * 64 + tm * 32 + 4 * h;
-        float out[16];
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int m = mb + (r & 3) + 8 * (r >> 2);
             float v = mas_fmaf(acc[tm][tn][r], sE[m], sE[BM + m]);
             if (RES) v += rv[i & 1][r];
-            out[r] = v < lo ? lo : v;
-        }
-        if (inside[tn]) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int m = mb + (r & 3) + 8 * (r >> 2);
-                if (m < mlim) yb[(size_t)m * HWo + po[tn]] = out[r];
-            }
+            v = v < lo ? lo : v;
+            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), yres, vo[tn] + m * row4, 0, 0);
         }
     }
+#ifdef BX_STAMPS
+    if (stamp) {
+        BX_T(7);
+        unsigned long long* o = p.stamps + (size_t)bid * 10;
+        for (int i = 0; i < 8; ++i) o[i] = (unsigned long long)acc_t[i];
+        o[8] = (unsigned long long)(last_t - first_t);
+        o[9] = (unsigned long long)first_t;
+    }
+#endif
 }
 
 // the M tile of a layer's weight image: a pure function of (ksize, Cout), shared by the pack and the launch
@@ -425,9 +455,9 @@ int bx_launch(BxP p, int N, hipStream_t st) {
         p.PH = 8 + 2 * p.dil;
         p.PW = 32 + 2 * p.dil;
         p.PP = p.PH * p.PW;
-        p.PPA = (p.PP + 15) & ~15;
-        if (2 * p.PP > 4 * kThreads) return MAS_ERR_SHAPE;
-        bbytes = (size_t)3 * p.PPA * 16;
+        p.PPA = kBxPPA;
+        if (p.PP > kBxPPA || 2 * p.PP > 4 * kThreads) return MAS_ERR_SHAPE;
+        bbytes = (size_t)3 * kBxPPA * 16;
     }
     p.ptiles = N * p.tiles_x * p.tiles_y;
     const size_t smem = (size_t)3 * GA * BM * 16 + 2 * BM * 4 + bbytes;
@@ -459,6 +489,8 @@ int bx_launch_r(const BxP& p, int N, hipStream_t st) {
 extern "C" int mas_conv_bx_supported(int ksize, int stride, int dil, int Cin, int Cout, int H, int W) {
     if (Cin <= 0 || Cout <= 0 || H <= 0 || W <= 0) return 0;
     if ((long long)Cin * H * W > 0x7fffffffLL) return 0;
+    // byte sizes of the buffer resources: a chunk of x (32 / 8 channels of one picture), one M tile of y (<= 128 rows)
+    if (32LL * H * W * 4 >= 0x7fffffffLL || 128LL * H * W * 4 >= 0x7fffffffLL) return 0;
     if (ksize == 1) {
         if (dil != 1 || Cin % 32 != 0) return 0;
         if (stride == 1) return (H * W) % 4 == 0;
@@ -501,6 +533,9 @@ extern "C" int mas_conv_bx_fwd(const float* x, const void* wp, int N, int Cin, i
     BxP p;
     p.x = x; p.wp = static_cast<const v4f*>(wp); p.scale = scale; p.shift = shift; p.res = residual; p.y = y;
     p.Cin = Cin; p.H = H; p.W = W; p.Cout = Cout; p.dil = dil; p.relu = relu;
+#ifdef BX_STAMPS
+    p.stamps = g_bx_stamps;
+#endif
     p.Ho = (H - 1) / stride + 1;
     p.Wo = (W - 1) / stride + 1;
     const int BM = bx_bm(ksize, Cout);
@@ -510,3 +545,11 @@ extern "C" int mas_conv_bx_fwd(const float* x, const void* wp, int N, int Cin, i
     }
     return bx_launch_r<9, 64, 256, false>(p, N, st);
 }
+
+#ifdef BX_STAMPS
+// measurement build only: 10 u64 per workgroup (8 phase sums, total, start) of the NEXT launches; NULL switches it off
+extern "C" int mas_conv_bx_debug_stamps(void* buf) {
+    g_bx_stamps = static_cast<unsigned long long*>(buf);
+    return 0;
+}
+#endif

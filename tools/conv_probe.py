@@ -1,6 +1,6 @@
 #!/usr/bin/env python
 """Run one convolution geometry repeatedly through csrc/conv_mfma.hip (and MIOpen) -- the target of rocprofv3 PMC passes.
-  python tools/conv_probe.py Cin Cout k stride dil N H W [reps] [hip|miopen|both]"""
+  python tools/conv_probe.py Cin Cout k stride dil N H W [reps] [hip|bx|miopen|both]      (bx: csrc/conv_bx.hip)"""
 import os
 import sys
 
@@ -18,7 +18,8 @@ conv = nn.Conv2d(cin, cout, k, stride=s, padding=d if k == 3 else 0, dilation=d,
 bn = nn.BatchNorm2d(cout).to(dev).eval()
 x = torch.randn(N, cin, H, W, device=dev)
 with torch.no_grad():
-    for name, fn in (("hip", lambda: ops.conv_mfma(conv, x, bn, relu=True)), ("miopen", lambda: conv(x))):
+    for name, fn in (("hip", lambda: ops.conv_mfma(conv, x, bn, relu=True)), ("bx", lambda: ops.conv_bx(conv, x, bn, relu=True)),
+                     ("miopen", lambda: conv(x))):
         if which not in (name, "both"):
             continue
         for _ in range(3):
