@@ -424,15 +424,25 @@ int mas_conv_fwd(const float* x, const float* wt, int N, int Cin, int H, int W, 
  * results (csrc/conv_bx.hip): every f32 operand is split exactly into three bf16 terms (8 + 8 + 8 significand bits) and a
  * product is accumulated in f32 from its six partial products of order <= 2 (v_mfma_f32_32x32x16_bf16); the dropped terms are
  * below 2^-23 of the product, i.e. one f32 rounding -- same error bound as the f32 MFMA form, exact on integer data, 2.67x its
- * matrix peak.  Supported (mas_conv_bx_supported != 0): ksize 1 with Cin % 32 == 0, stride 1 (H*W % 4 == 0) or stride 2
- * (H even, W % 8 == 0); ksize 3 with stride 1, dil 1 | 2 (padding = dil), Cin % 8 == 0, W >= 32; any Cout.
+ * matrix peak.  Supported (mas_conv_bx_supported != 0): ksize 1 at stride 1 (H*W % 4 == 0) or stride 2 (H even, W % 8 == 0);
+ * ksize 3 with stride 1, dil 1 | 2 (padding = dil), W >= 32; any Cin (a last partial chunk is zero-padded), any Cout.
  * `wp` is the weight [Cout][Cin][ksize][ksize] split and laid out ONCE (per checkpoint load) by mas_conv_bx_pack into
  * mas_conv_bx_packed_bytes(ksize, Cin, Cout) bytes of caller-owned, 16-byte aligned device memory: the sequence of LDS images
  * [M tile][chunk][term h|m|l][k group][BM rows][8 bf16] (1x1: chunk = 32 channels, k = channel; 3x3: chunk = 8 channels,
  * k group = tap, + one zero tap; BM = 128 if ksize == 1 and Cout % 128 == 0, else 64).  x 16-byte aligned. */
 int mas_conv_bx_supported(int ksize, int stride, int dil, int Cin, int Cout, int H, int W);
-long long mas_conv_bx_packed_bytes(int ksize, int Cin, int Cout);
-int mas_conv_bx_pack(const float* w, int Cout, int Cin, int ksize, void* wp, void* stream);
+long long mas_conv_bx_packed_bytes(int ksize, int Cin, int Cout, int role);
+int mas_conv_bx_pack(const float* w, int Cout, int Cin, int ksize, int role, void* wp, void* stream);
+/* role 0: the image of the forward product.  role 1: the image with which mas_conv_bx_fwd computes the INPUT GRADIENT of the
+ * stride-1 convolution (the backward of the nn.Conv2d calls above inside trainer/active_joint_multi_predignore_lossdecomp.py:83-116):
+ * channel axes swapped, taps mirrored -- call mas_conv_bx_fwd(dY, wp1, N, Cout, H, W, Cin, ksize, 1, dil, NULL, NULL, residual, 0, dX):
+ * `residual` adds the gradient of x's other consumer.  In training the weights move every optimizer step: all images of a model
+ * are rewritten by ONE launch from a device-resident job table (mas_conv_bx_pack_job fills a host record of
+ * mas_conv_bx_pack_job_bytes() bytes and returns the job's block count, 0 if it rejects the arguments; records in ascending
+ * first_block order; mas_conv_bx_pack_multi runs `njobs` records covering `nblocks` blocks). */
+size_t mas_conv_bx_pack_job_bytes(void);
+unsigned mas_conv_bx_pack_job(void* job_host, const float* w, int Cout, int Cin, int ksize, int role, void* wp, unsigned first_block);
+int mas_conv_bx_pack_multi(const void* jobs_dev, int njobs, unsigned nblocks, void* stream);
 int mas_conv_bx_fwd(const float* x, const void* wp, int N, int Cin, int H, int W, int Cout, int ksize, int stride, int dil,
                     const float* scale, const float* shift, const float* residual, int relu, float* y, void* stream);
 

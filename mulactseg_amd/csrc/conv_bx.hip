@@ -75,20 +75,30 @@ __device__ __forceinline__ void bx_split2(float v0, float v1, unsigned& h, unsig
 }
 
 // ---- weight image --------------------------------------------------------------------------------------------------------
-// one thread per 16-byte unit [M tile][chunk][term][k group][row][8]; k = 8 g + j: 1x1 channel = chunk * 32 + k,
-// 3x3 tap = g (tap 9: zeros), channel = chunk * 8 + j
-template <int TAPS>
-__global__ void k_bx_pack(const float* __restrict__ w, int Cout, int Cin, int BM, unsigned* __restrict__ out, long long units) {
-    constexpr int GA = BxGeo<TAPS>::GA, CK = BxGeo<TAPS>::CK;
-    const long long u = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (u >= units) return;
+// One job = one weight tensor in one role.  role 0: the forward product (M = Cout rows, K = Cin); role 1: the input gradient
+// of the stride-1 convolution, which is the same kernel on dY with the weight's channel axes swapped and the taps mirrored
+// (M = Cin rows, K = Cout):  a[m][k = (tap, c)] = w[c][m][8 - tap].
+// One thread per 16-byte unit [M tile][chunk][term][k group][row][8]; k = 8 g + j: 1x1 channel = chunk * 32 + k,
+// 3x3 tap = g (tap 9: zeros), channel = chunk * 8 + j; rows beyond M and channels beyond K are zeros.
+struct BxPackJob {
+    const float* w;             // [Cout][Cin][taps] as PyTorch stores it
+    unsigned* out;
+    int Cout, Cin, taps, role, BM;
+    long long units;
+    unsigned first_block;       // (multi-job launch) the job's first 256-thread block
+};
+
+__device__ __forceinline__ void bx_pack_unit(const BxPackJob& jb, long long u) {
+    const int taps = jb.taps, BM = jb.BM;
+    const int GA = taps == 1 ? 4 : kBxTaps3, CK = taps == 1 ? 32 : 8;
+    const int M = jb.role ? jb.Cin : jb.Cout, K = jb.role ? jb.Cout : jb.Cin;
     const int row = (int)(u % BM);
     long long r = u / BM;
     const int g = (int)(r % GA);
     r /= GA;
     const int term = (int)(r % 3);
     r /= 3;
-    const int nch = Cin / CK;
+    const int nch = (K + CK - 1) / CK;              // (a last, partial chunk carries zero weights for the channels that do not exist)
     const int chunk = (int)(r % nch);
     const int mt = (int)(r / nch);
     const int m = mt * BM + row;
@@ -96,9 +106,11 @@ __global__ void k_bx_pack(const float* __restrict__ w, int Cout, int Cin, int BM
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
         float val = 0.0f;
-        if (m < Cout) {
-            if (TAPS == 1) val = w[(size_t)m * Cin + chunk * CK + 8 * g + j];
-            else if (g < 9) val = w[((size_t)m * Cin + chunk * CK + j) * 9 + g];
+        const int c = chunk * CK + (taps == 1 ? 8 * g + j : j);
+        if (m < M && c < K && g < (taps == 1 ? GA : 9)) {
+            const int tap = taps == 1 ? 0 : (jb.role ? 8 - g : g);
+            const size_t co = jb.role ? c : m, ci = jb.role ? m : c;
+            val = jb.w[(co * jb.Cin + ci) * taps + tap];
         }
         v[j] = val;
     }
@@ -109,7 +121,25 @@ __global__ void k_bx_pack(const float* __restrict__ w, int Cout, int Cin, int BM
         bx_split2(v[2 * j], v[2 * j + 1], h, mm, l);
         o[j] = term == 0 ? h : (term == 1 ? mm : l);
     }
-    *reinterpret_cast<uint4*>(out + 4 * u) = make_uint4(o[0], o[1], o[2], o[3]);
+    *reinterpret_cast<uint4*>(jb.out + 4 * u) = make_uint4(o[0], o[1], o[2], o[3]);
+}
+
+__global__ void k_bx_pack(const BxPackJob jb) {
+    const long long u = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (u < jb.units) bx_pack_unit(jb, u);
+}
+
+// all weights of a model in all their roles in ONE launch (after every optimizer step in training)
+__global__ void k_bx_pack_multi(const BxPackJob* __restrict__ jobs, int njobs) {
+    int lo = 0, hi = njobs - 1;                     // the last job whose first block is <= this block (wave-uniform search)
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (jobs[mid].first_block <= blockIdx.x) lo = mid;
+        else hi = mid - 1;
+    }
+    const BxPackJob jb = jobs[lo];
+    const long long u = (long long)(blockIdx.x - jb.first_block) * blockDim.x + threadIdx.x;
+    if (u < jb.units) bx_pack_unit(jb, u);
 }
 
 // -DBX_STAMPS: a measurement build (tools/bx_stamps.py) -- wave 0 of every workgroup sums the cycles (s_memtime) it spends in each
@@ -241,7 +271,7 @@ __global__ __launch_bounds__(kThreads, 2) void k_conv_bx(const BxP p) {
             for (int r = 0; r < 16; ++r) acc[tm][tn][r] = 0.0f;
 
     const float* xb = p.x + (size_t)n * p.Cin * HW;
-    const int nchunks = p.Cin / CK;
+    const int nchunks = (p.Cin + CK - 1) / CK;
     const v4f* wb = p.wp + (size_t)mt * nchunks * AUNITS;
     const int hw4 = HW * 4;
     v4f wr[NW];
@@ -260,7 +290,9 @@ __global__ __launch_bounds__(kThreads, 2) void k_conv_bx(const BxP p) {
             if (WTAIL && j == NW - 1) wr[j] = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(wres, wtail, 0, 0));
             else wr[j] = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(wres, tid * 16, j * kThreads * 16, 0));
         }
-        const __amdgpu_buffer_rsrc_t xres = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(xb + (size_t)t * CK * HW), 0, CK * hw4, kBxRsrcFlags);
+        // (the channels of a last, partial chunk that do not exist lie beyond the resource: zeros against zero weights)
+        const int cleft = p.Cin - t * CK;
+        const __amdgpu_buffer_rsrc_t xres = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(xb + (size_t)t * CK * HW), 0, (cleft < CK ? cleft : CK) * hw4, kBxRsrcFlags);
         if (TAPS == 1) {
 #pragma unroll
             for (int j = 0; j < NT; ++j)
@@ -492,33 +524,56 @@ extern "C" int mas_conv_bx_supported(int ksize, int stride, int dil, int Cin, in
     // byte sizes of the buffer resources: a chunk of x (32 / 8 channels of one picture), one M tile of y (<= 128 rows)
     if (32LL * H * W * 4 >= 0x7fffffffLL || 128LL * H * W * 4 >= 0x7fffffffLL) return 0;
     if (ksize == 1) {
-        if (dil != 1 || Cin % 32 != 0) return 0;
+        if (dil != 1) return 0;
         if (stride == 1) return (H * W) % 4 == 0;
         if (stride == 2) return H % 2 == 0 && W % 8 == 0;        // output quads stay inside a row and start 16-byte aligned
         return 0;
     }
-    if (ksize == 3) return stride == 1 && (dil == 1 || dil == 2) && Cin % 8 == 0 && W >= 32;
+    if (ksize == 3) return stride == 1 && (dil == 1 || dil == 2) && W >= 32;
     return 0;
 }
 
-extern "C" long long mas_conv_bx_packed_bytes(int ksize, int Cin, int Cout) {
-    if ((ksize != 1 && ksize != 3) || Cin <= 0 || Cout <= 0) return 0;
-    const int BM = bx_bm(ksize, Cout), ck = ksize == 1 ? 32 : 8, ga = ksize == 1 ? 4 : kBxTaps3;
-    if (Cin % ck != 0) return 0;
-    return (long long)((Cout + BM - 1) / BM) * (Cin / ck) * 3 * ga * BM * 16;
+extern "C" long long mas_conv_bx_packed_bytes(int ksize, int Cin, int Cout, int role) {
+    if ((ksize != 1 && ksize != 3) || Cin <= 0 || Cout <= 0 || (role != 0 && role != 1)) return 0;
+    const int M = role ? Cin : Cout, K = role ? Cout : Cin;
+    const int BM = bx_bm(ksize, M), ck = ksize == 1 ? 32 : 8, ga = ksize == 1 ? 4 : kBxTaps3;
+    return (long long)((M + BM - 1) / BM) * ((K + ck - 1) / ck) * 3 * ga * BM * 16;
 }
 
-extern "C" int mas_conv_bx_pack(const float* w, int Cout, int Cin, int ksize, void* wp, void* stream) {
+namespace {
+bool bx_fill_job(BxPackJob* jb, const float* w, int Cout, int Cin, int ksize, int role, void* wp, unsigned first_block) {
+    const long long bytes = mas_conv_bx_packed_bytes(ksize, Cin, Cout, role);
+    if (bytes <= 0 || !w || !wp || (uintptr_t)wp % 16 != 0) return false;
+    jb->w = w; jb->out = static_cast<unsigned*>(wp); jb->Cout = Cout; jb->Cin = Cin; jb->taps = ksize * ksize; jb->role = role;
+    jb->BM = bx_bm(ksize, role ? Cin : Cout); jb->units = bytes / 16; jb->first_block = first_block;
+    return true;
+}
+}  // namespace
+
+extern "C" int mas_conv_bx_pack(const float* w, int Cout, int Cin, int ksize, int role, void* wp, void* stream) {
     if (!w || !wp) return MAS_ERR_NULL;
-    const long long bytes = mas_conv_bx_packed_bytes(ksize, Cin, Cout);
-    if (bytes <= 0) return MAS_ERR_SHAPE;
     if ((uintptr_t)wp % 16 != 0) return MAS_ERR_ALIGN;
-    const long long units = bytes / 16;
-    const int BM = bx_bm(ksize, Cout);
-    const unsigned nblk = (unsigned)((units + 255) / 256);
-    hipStream_t st = static_cast<hipStream_t>(stream);
-    if (ksize == 1) hipLaunchKernelGGL(k_bx_pack<1>, dim3(nblk), dim3(256), 0, st, w, Cout, Cin, BM, static_cast<unsigned*>(wp), units);
-    else hipLaunchKernelGGL(k_bx_pack<9>, dim3(nblk), dim3(256), 0, st, w, Cout, Cin, BM, static_cast<unsigned*>(wp), units);
+    BxPackJob jb;
+    if (!bx_fill_job(&jb, w, Cout, Cin, ksize, role, wp, 0)) return MAS_ERR_SHAPE;
+    hipLaunchKernelGGL(k_bx_pack, dim3((unsigned)((jb.units + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream), jb);
+    return mas_launch_status();
+}
+
+extern "C" size_t mas_conv_bx_pack_job_bytes(void) { return sizeof(BxPackJob); }
+
+/* fill one job record (host memory) of a multi-tensor pack; returns the number of 256-thread blocks the job needs (0: rejected) */
+extern "C" unsigned mas_conv_bx_pack_job(void* job_host, const float* w, int Cout, int Cin, int ksize, int role, void* wp, unsigned first_block) {
+    if (!job_host) return 0;
+    BxPackJob* jb = static_cast<BxPackJob*>(job_host);
+    if (!bx_fill_job(jb, w, Cout, Cin, ksize, role, wp, first_block)) return 0;
+    return (unsigned)((jb->units + 255) / 256);
+}
+
+/* jobs_dev: `njobs` records (mas_conv_bx_pack_job, in ascending first_block order, copied to the device by the caller), `nblocks` blocks in all */
+extern "C" int mas_conv_bx_pack_multi(const void* jobs_dev, int njobs, unsigned nblocks, void* stream) {
+    if (!jobs_dev) return MAS_ERR_NULL;
+    if (njobs <= 0 || nblocks == 0) return MAS_ERR_SHAPE;
+    hipLaunchKernelGGL(k_bx_pack_multi, dim3(nblocks), dim3(256), 0, static_cast<hipStream_t>(stream), static_cast<const BxPackJob*>(jobs_dev), njobs);
     return mas_launch_status();
 }
 

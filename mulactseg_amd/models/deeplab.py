@@ -104,10 +104,12 @@ def _conv_bn_act(conv, bn, x, relu=True, residual=None, fork=False):
             return (out, x_other) if want_fork else out
         own = ops.conv_train_plan(conv, x)          # training: (forward, input gradient, weight gradient) on the f32-MFMA kernels
         if own is not None and any(own):
-            _took("conv_bn_act", "train:" + "".join(n if o else "-" for n, o in zip("fdw", own)))
+            # "/bx": forward (and with it the input gradient) on the split-bf16 kernel csrc/conv_bx.hip instead of the stream-K one
+            bx = own[0] and ops.conv_bx_train_ok(x.shape, conv.weight.shape, conv.stride[0], conv.dilation[0], False)
+            _took("conv_bn_act", "train:" + "".join(n if o else "-" for n, o in zip("fdw", own)) + ("/bx" if bx else ""))
             # stats: the forward kernel forms the BatchNorm partial sums of its output in its epilogue (no reduction pass over y);
             # fork: the gradient of x's other consumer is added in the epilogue of this convolution's input-gradient kernel
-            stats = own[0] and bn.training and os.environ.get("MAS_BN_STATS", "fused") == "fused"
+            stats = own[0] and not bx and bn.training and os.environ.get("MAS_BN_STATS", "fused") == "fused"
             fork = fork and own[1] and conv.stride[0] == 1 and x.requires_grad and os.environ.get("MAS_GRAD_FORK", "fused") == "fused"
             res = ops.conv_train(conv, x, own, stats=stats, fork=fork)
             y, part = (res[0], res[1]) if (stats or fork) else (res, None)

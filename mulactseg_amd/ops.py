@@ -1081,9 +1081,12 @@ def conv_mfma(conv, x, bn=None, relu=False, residual=None):
 # the same convolutions on the bf16 matrix cores, f32 in / f32 out through exact three-term operand splits (csrc/conv_bx.hip)
 # ------------------------------------------------------------------------------------------------
 def conv_bx_supported(conv, x):
-    """Shapes mas_conv_bx_fwd takes (a subset of conv_mfma_supported: 1x1 with Cin % 32 == 0 at stride 1 / 2, 3x3 stride 1 with
-    dilation 1 / 2 on planes at least 32 wide)."""
-    if not conv_mfma_supported(conv, x) or x.data_ptr() % 16:
+    """Shapes mas_conv_bx_fwd takes: 1x1 at stride 1 (H*W % 4 == 0) / 2 (H even, W % 8 == 0), 3x3 stride 1 with dilation 1 / 2
+    (padding = dilation) on planes at least 32 wide; any channel counts; no groups, no bias."""
+    if not (x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and conv.groups == 1 and conv.bias is None) or x.data_ptr() % 16:
+        return False
+    k, s, d, pd = conv.kernel_size, conv.stride, conv.dilation, conv.padding
+    if k[0] != k[1] or s[0] != s[1] or d[0] != d[1] or pd[0] != pd[1] or pd[0] != (d[0] if k[0] == 3 else 0) or x.shape[1] != conv.in_channels:
         return False
     return bool(_lib.load().mas_conv_bx_supported(conv.kernel_size[0], conv.stride[0], conv.dilation[0], conv.in_channels,
                                                   conv.out_channels, x.shape[2], x.shape[3]))
@@ -1098,12 +1101,12 @@ def _conv_bx_weight(conv):
         lib = _lib.load()
         w = conv.weight.detach().contiguous()
         M, K, kh, _ = w.shape
-        nbytes = lib.mas_conv_bx_packed_bytes(kh, K, M)
+        nbytes = lib.mas_conv_bx_packed_bytes(kh, K, M, 0)
         if nbytes <= 0:
             raise ValueError("mas_conv_bx_pack does not take a %dx%d convolution with %d input channels" % (kh, kh, K))
         wp = torch.empty(nbytes, dtype=torch.uint8, device=w.device)
         with torch.cuda.device(w.device):
-            _lib.check(lib.mas_conv_bx_pack(w.data_ptr(), M, K, kh, wp.data_ptr(), _stream(w)), "mas_conv_bx_pack")
+            _lib.check(lib.mas_conv_bx_pack(w.data_ptr(), M, K, kh, 0, wp.data_ptr(), _stream(w)), "mas_conv_bx_pack")
         cache = conv._mas_conv_bx_pack = (key, wp)
     return cache[1]
 
@@ -1247,7 +1250,7 @@ class _PackRegistry:
             self._drop(k)
             e = None
         if e is None:
-            img = conv_sk_pack(w, stride, dgrad)
+            img = self._pack_one(w, stride, dgrad)
             self.entries[k] = [weakref.ref(w), img, (w._version, _PARAM_EPOCH[0])]
             weakref.finalize(w, self._drop, k)
             self.table = None
@@ -1267,27 +1270,124 @@ class _PackRegistry:
         if not live:
             return
         if self.table is None:
-            rec = int(lib.mas_conv_sk_pack_job_bytes())
+            rec = self._job_bytes(lib)
             host = ctypes.create_string_buffer(rec * len(live))
             base = ctypes.addressof(host)
             first = 0
             for i, (k, e, w) in enumerate(live):
-                n = lib.mas_conv_sk_pack_job(base + i * rec, w.data_ptr(), w.shape[1], w.shape[0], w.shape[2], k[3], int(k[4]), e[1].data_ptr(), first)
+                n = self._fill_job(lib, base + i * rec, w, k, e[1], first)
                 if n == 0:
-                    raise _lib.MulActSegHipError("mas_conv_sk_pack_job rejected %s" % (k,))
+                    raise _lib.MulActSegHipError("%s rejected the pack job %s" % (type(self).__name__, k))
                 first += n
             self.table = torch.frombuffer(bytearray(host.raw), dtype=torch.uint8).to(self.dev)
             self.nblocks = first
             self.njobs = len(live)
         with torch.cuda.device(self.dev):
-            _lib.check(lib.mas_conv_sk_pack_multi(self.table.data_ptr(), self.njobs, self.nblocks,
-                                                  torch.cuda.current_stream(self.dev).cuda_stream), "mas_conv_sk_pack_multi")
+            self._multi(lib, torch.cuda.current_stream(self.dev).cuda_stream)
         for k, e, w in live:
             e[2] = (w._version, _PARAM_EPOCH[0])
 
+    # the image format of this registry: mas_conv_sk (a subclass: mas_conv_bx)
+    @staticmethod
+    def _pack_one(w, stride, dgrad):
+        return conv_sk_pack(w, stride, dgrad)
+
+    @staticmethod
+    def _job_bytes(lib):
+        return int(lib.mas_conv_sk_pack_job_bytes())
+
+    @staticmethod
+    def _fill_job(lib, rec, w, k, img, first):
+        return lib.mas_conv_sk_pack_job(rec, w.data_ptr(), w.shape[1], w.shape[0], w.shape[2], k[3], int(k[4]), img.data_ptr(), first)
+
+    def _multi(self, lib, stream):
+        _lib.check(lib.mas_conv_sk_pack_multi(self.table.data_ptr(), self.njobs, self.nblocks, stream), "mas_conv_sk_pack_multi")
+
+
+def conv_bx_pack(w, role=0):
+    """The split-bf16 weight image of mas_conv_bx_pack for one role (0 forward, 1 input gradient at stride 1)."""
+    _need(w, "w", torch.float32)
+    w = w.contiguous()
+    M, K, kh, _ = w.shape
+    lib = _lib.load()
+    nbytes = lib.mas_conv_bx_packed_bytes(kh, K, M, int(role))
+    if nbytes <= 0:
+        raise ValueError("mas_conv_bx_pack does not take a %dx%d weight %s" % (kh, kh, tuple(w.shape)))
+    wp = torch.empty(nbytes, dtype=torch.uint8, device=w.device)
+    with torch.cuda.device(w.device):
+        _lib.check(lib.mas_conv_bx_pack(w.data_ptr(), M, K, kh, int(role), wp.data_ptr(), _stream(w)), "mas_conv_bx_pack")
+    return wp
+
+
+class _BxPackRegistry(_PackRegistry):
+    """The same bookkeeping for the split-bf16 images of csrc/conv_bx.hip (key: stride is always 1, `dgrad` is the role)."""
+
+    @staticmethod
+    def _pack_one(w, stride, dgrad):
+        return conv_bx_pack(w, int(dgrad))
+
+    @staticmethod
+    def _job_bytes(lib):
+        return int(lib.mas_conv_bx_pack_job_bytes())
+
+    @staticmethod
+    def _fill_job(lib, rec, w, k, img, first):
+        return lib.mas_conv_bx_pack_job(rec, w.data_ptr(), w.shape[0], w.shape[1], w.shape[2], int(k[4]), img.data_ptr(), first)
+
+    def _multi(self, lib, stream):
+        _lib.check(lib.mas_conv_bx_pack_multi(self.table.data_ptr(), self.njobs, self.nblocks, stream), "mas_conv_bx_pack_multi")
+
 
 _PACKS = {}
+_BX_PACKS = {}
 
+
+def bx_packed_weight(w, role=0):
+    """The mas_conv_bx image of weight `w` for one role, kept up to date across optimizer steps (one re-pack launch per step for
+    all registered weights: _BxPackRegistry)."""
+    reg = _BX_PACKS.get(w.device)
+    if reg is None:
+        reg = _BX_PACKS[w.device] = _BxPackRegistry(w.device)
+    return reg.get(w, 1, int(role))
+
+
+def conv_bx_raw(x, w, dil=1, dgrad=False, residual=None, packed=None):
+    """The bare stride-1 product of a training step on csrc/conv_bx.hip: dgrad False: y = conv2d(x, w, padding = dil (k 3) / 0 (k 1),
+    dilation); dgrad True: x is dY [N,Cout,H,W] and the result dX [N,Cin,H,W] (+ residual: the gradient of x's other consumer)."""
+    _need(x, "x", torch.float32)
+    _need(w, "w", torch.float32)
+    Cout, Cin, ks, _ = w.shape
+    N, Cx, H, W = x.shape
+    K, M = (Cout, Cin) if dgrad else (Cin, Cout)
+    if Cx != K:
+        raise ValueError("input has %d channels, weight %s (dgrad=%s)" % (Cx, tuple(w.shape), dgrad))
+    y = torch.empty((N, M, H, W), dtype=torch.float32, device=x.device)
+    if residual is not None:
+        _need(residual, "residual", torch.float32)
+        if residual.shape != y.shape:
+            raise ValueError("residual %s does not match the output %s" % (tuple(residual.shape), tuple(y.shape)))
+    if packed is None:
+        packed = conv_bx_pack(w, int(dgrad))
+    with torch.cuda.device(x.device):
+        _lib.check(_lib.load().mas_conv_bx_fwd(x.data_ptr(), packed.data_ptr(), N, K, H, W, M, ks, 1, dil, None, None, _opt(residual), 0,
+                                               y.data_ptr(), _stream(x)), "mas_conv_bx_fwd")
+    return y
+
+
+def conv_bx_train_ok(x_shape, w_shape, stride, dil, dgrad):
+    """Does the split-bf16 kernel take this product of a training step, and is it the faster one?  Stride 1 only; MAS_TRAIN_BX =
+    auto (default): every 1x1 product, 3x3 products on planes of at least 96 x 96 pixels (on the 48 x 48 planes of layer3 / layer4
+    a 3x3 layer has 192-384 tiles of which a quarter is padding: the persistent stream-K kernel stays ahead there --
+    tools/bx_train_table.py, profiles/r04/k_bx_train_table.md), all: wherever supported, off: never."""
+    mode = os.environ.get("MAS_TRAIN_BX", "auto")
+    if mode == "off" or stride != 1:
+        return False
+    Cout, Cin, ks, _ = w_shape
+    K, M = (Cout, Cin) if dgrad else (Cin, Cout)
+    N, _, H, W = x_shape
+    if not _lib.load().mas_conv_bx_supported(ks, 1, dil, K, M, H, W):
+        return False
+    return mode == "all" or ks == 1 or H * W >= 96 * 96
 
 def packed_weight(w, stride=1, dgrad=False):
     """The mas_conv_sk image of weight `w` for one role, kept up to date across optimizer steps (see _PackRegistry)."""
@@ -1493,7 +1593,10 @@ class _ConvTrain(torch.autograd.Function):
         ks = w.shape[2]
         part = None
         with torch.no_grad():
-            if own[0] and stats:
+            if own[0] and conv_bx_train_ok(x.shape, w.shape, stride, dil, False) and x.data_ptr() % 16 == 0:
+                # split-bf16 kernel (csrc/conv_bx.hip); the BatchNorm partial sums then come from the separate reduction pass
+                y = conv_bx_raw(x, w, dil, packed=bx_packed_weight(w, 0))
+            elif own[0] and stats:
                 y, part = conv_sk(x, w, stride, dil, packed=packed_weight(w, stride, False), stats=True)
             elif own[0]:
                 y = conv_sk(x, w, stride, dil, packed=packed_weight(w, stride, False))
@@ -1541,7 +1644,12 @@ class _ConvTrain(torch.autograd.Function):
             else:
                 dw = conv_wgrad(x, dy, ks, stride, dil)
         if need_dx:
-            if own[1] and stride == 1:
+            if own[1] and stride == 1 and conv_bx_train_ok(dy.shape, w.shape, 1, dil, True) and dy.data_ptr() % 16 == 0:
+                fuse = g_other is not None and g_other.shape == x.shape and g_other.dtype == torch.float32
+                dx = conv_bx_raw(dy, w, dil, dgrad=True, residual=g_other.contiguous() if fuse else None, packed=bx_packed_weight(w, 1))
+                if fuse:
+                    g_other = None
+            elif own[1] and stride == 1:
                 if g_other is not None and g_other.shape == x.shape and g_other.dtype == torch.float32:
                     dx = conv_sk(dy, w, 1, dil, dgrad=True, packed=packed_weight(w, 1, True), residual=g_other.contiguous())
                     g_other = None

@@ -28,6 +28,9 @@ CASES = [
     (256, 256, 3, 1, 2, 1, 9, 33),       # dilation 2, partial tiles in both directions
     (8, 64, 3, 1, 1, 1, 5, 32),          # one chunk, plane lower than a tile
     (64, 200, 3, 1, 1, 1, 9, 37),        # Cout 200
+    (304, 256, 1, 1, 1, 1, 16, 48),      # decoder pointwise: Cin = 9.5 chunks of 32 (the last one zero-padded)
+    (50, 64, 1, 1, 1, 2, 8, 32),         # Cin not a multiple of anything
+    (20, 64, 3, 1, 1, 1, 11, 40),        # 3x3 with 2.5 chunks of 8 channels
 ]
 
 
@@ -62,13 +65,14 @@ def test_conv_bx_matches_conv2d(Cin, Cout, k, stride, dil, N, H, W, epi):
         if bn is not None:
             bn.float()
         y = ops.conv_bx(conv, x, bn, relu=epi != "bare", residual=res)
-        y32 = ops.conv_mfma(conv, x, bn, relu=epi != "bare", residual=res)
+        y32 = ops.conv_mfma(conv, x, bn, relu=epi != "bare", residual=res) if ops.conv_mfma_supported(conv, x) else None
     assert y.shape == ref.shape
     scale = float(ref.abs().max())
     err = float((y.double() - ref).abs().max())
-    err32 = float((y32.double() - ref).abs().max())
     assert err <= 2e-5 * scale, (err, scale)
-    assert err <= 2.0 * err32 + 1e-6 * scale, (err, err32, scale)       # as accurate as the f32 matrix cores on the same data
+    if y32 is not None:                                                 # as accurate as the f32 matrix cores on the same data
+        err32 = float((y32.double() - ref).abs().max())
+        assert err <= 2.0 * err32 + 1e-6 * scale, (err, err32, scale)
 
 
 def test_conv_bx_exact_on_integers():
@@ -143,7 +147,7 @@ def test_conv_bx_randomised_geometries(seed):
     k = int(rs.choice([1, 3]))
     stride = int(rs.choice([1, 2])) if k == 1 else 1
     dil = 1 if k == 1 else int(rs.choice([1, 2]))
-    cin = int(rs.choice([8, 16, 24, 40, 64, 72, 128])) if k == 3 else int(rs.choice([32, 64, 96, 160]))
+    cin = int(rs.choice([8, 12, 16, 24, 40, 64, 72, 128])) if k == 3 else int(rs.choice([32, 48, 64, 96, 100, 160]))
     cout = int(rs.choice([16, 48, 64, 80, 128, 192, 200, 256]))
     N = int(rs.randint(1, 4))
     if k == 3:
