@@ -446,6 +446,16 @@ int mas_conv_bx_pack_multi(const void* jobs_dev, int njobs, unsigned nblocks, vo
 int mas_conv_bx_fwd(const float* x, const void* wp, int N, int Cin, int H, int W, int Cout, int ksize, int stride, int dil,
                     const float* scale, const float* shift, const float* residual, int relu, float* y, void* stream);
 
+/* Weight gradient of a 1x1 stride-1 convolution on the bf16 matrix cores with f32 operands and results (csrc/conv_wgrad_bx.hip; the
+ * operand split of mas_conv_bx_fwd applied to BOTH operands): dW[m,c] = sum_{n,p} dY[n,m,p] * X[n,c,p], x [N,Cin,H,W], dy [N,Cout,H,W],
+ * dw [Cout,Cin] -- the backward of the 1x1 nn.Conv2d layers (mas_conv_wgrad: reference lines).  Split K over the pixels with a
+ * fixed-order reduction through `workspace` (mas_conv_wgrad_bx_workspace_bytes(Cin, Cout), caller-owned): run-to-run identical.
+ * Supported (mas_conv_wgrad_bx_supported != 0): H*W % 32 == 0, x / dy 16-byte aligned, tensors of one picture below 2 GiB. */
+int mas_conv_wgrad_bx_supported(int N, int Cin, int H, int W, int Cout);
+size_t mas_conv_wgrad_bx_workspace_bytes(int Cin, int Cout);
+int mas_conv_wgrad_bx(const float* x, const float* dy, int N, int Cin, int H, int W, int Cout, float* dw, void* workspace,
+                      size_t workspace_bytes, void* stream);
+
 /* Forward and input gradient of a dense convolution in training, as a persistent stream-K implicit GEMM on the f32 matrix
  * cores (csrc/conv_sk.hip).  `wp` is the weight as mas_conv_sk_pack writes it from PyTorch's [Cout][Cin][ksize][ksize] tensor
  * (mas_conv_sk_packed_elems floats, 16-byte aligned; one image per role: dgrad 0 / 1; one small launch per optimizer step): the

@@ -25,6 +25,7 @@
 // global -> registers in front of the MFMAs of chunk t and registers -> (split) -> LDS behind them; two workgroups per CU
 // cover each other's staging.  Epilogue as conv_mfma.hip: y * scale[m] + shift[m] (+ residual) (ReLU), NCHW stores.
 #include "common.h"
+#include "bx_split.h"
 
 namespace {
 constexpr int kThreads = 256;
@@ -62,17 +63,6 @@ template <int TAPS> struct BxGeo {
 // global load go to four rows of 36 units, so that both the staging stores (lanes = consecutive pixel quads) and the MFMA
 // fragment reads (lanes = consecutive pixels, serviced in the 16-lane groups of ds_read_b128) are free of bank conflicts
 __device__ __forceinline__ int bx_pos1(int p) { return (p >> 7) * 144 + (p & 3) * 36 + ((p & 127) >> 2); }
-
-// (h, m, l) of two values, packed pairwise: dword = (bf16 of v1) << 16 | bf16 of v0
-__device__ __forceinline__ void bx_split2(float v0, float v1, unsigned& h, unsigned& m, unsigned& l) {
-    const unsigned u0 = __float_as_uint(v0), u1 = __float_as_uint(v1);
-    h = __builtin_amdgcn_perm(u1, u0, 0x07060302u);
-    const float r0 = v0 - __uint_as_float(u0 & 0xffff0000u), r1 = v1 - __uint_as_float(u1 & 0xffff0000u);
-    const unsigned s0 = __float_as_uint(r0), s1 = __float_as_uint(r1);
-    m = __builtin_amdgcn_perm(s1, s0, 0x07060302u);
-    const float q0 = r0 - __uint_as_float(s0 & 0xffff0000u), q1 = r1 - __uint_as_float(s1 & 0xffff0000u);
-    l = __builtin_amdgcn_perm(__float_as_uint(q1), __float_as_uint(q0), 0x07060302u);
-}
 
 // ---- weight image --------------------------------------------------------------------------------------------------------
 // One job = one weight tensor in one role.  role 0: the forward product (M = Cout rows, K = Cin); role 1: the input gradient

@@ -1,0 +1,251 @@
+// conv_wgrad_bx.hip -- weight gradient of the 1x1 stride-1 convolutions on the bf16 matrix cores with f32 operands and f32 results
+// (bx_split.h: both operands split exactly into three bf16 terms between the global load and the LDS store, six partial products
+// per 16-k step on v_mfma_f32_32x32x16_bf16, f32 accumulation -- the error bound of an f32 product, exact on integer data):
+//     dW[m, c] = sum_{n, p} dY[n, m, p] * X[n, c, p]
+// Reference: the backward of the 1x1 nn.Conv2d layers of models/segmentation/backbone/resnet.py:129-160 (conv1 / conv3 /
+// downsample of every Bottleneck) and models/segmentation/deeplabv3.py:85-137,216-245 (ASPP 1x1, projections, the pointwise halves
+// of the separable convolutions) under trainer/active_joint_multi_predignore_lossdecomp.py:83-116 (loss.backward()).
+//
+// GEMM view: M = output channels (A = dY), N = input channels (B = X), K = the pixels of all pictures.  Both operands are
+// pixel-contiguous in NCHW, i.e. K-contiguous, which is what the bf16 MFMA wants (a lane's fragment = 8 consecutive k): a thread
+// loads four consecutive pixels of a row, splits them and stores three 8-byte pieces -- no transposition anywhere.
+//   * tile 128 x 128 per workgroup of 4 waves (64 x 64 each), K in chunks of 32 pixels (two 16-k steps); chunk t + 1 travels
+//     global -> registers in front of the MFMAs of chunk t, registers -> (split) -> LDS behind them; two workgroups per CU.
+//   * split K: the grid is (tiles) x S pixel ranges, every workgroup writes its partial tile to workspace [S][Cout][Cin] and
+//     k_wgx_reduce adds the slices in a fixed order (no atomics: run-to-run identical).  Workgroups of one range sit on one XCD.
+#include "common.h"
+#include "bx_split.h"
+
+namespace {
+constexpr int kWxThreads = 256;
+constexpr int kWxKP = 32;                   // pixels per chunk
+constexpr int kWxGS = 129;                  // 16-byte units per k group: 128 rows + 1 (spreads the staging stores over the banks)
+constexpr int kWxImg = 3 * 4 * kWxGS;       // units of one operand image [term][k group][row]
+constexpr unsigned kWxRsrcFlags = 0x00020000;
+constexpr int kWxOut = (int)0x80000000u;    // a byte offset beyond every resource used here
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float v4f __attribute__((ext_vector_type(4)));
+typedef unsigned v2u __attribute__((ext_vector_type(2)));
+typedef __bf16 bf8 __attribute__((ext_vector_type(8)));
+
+struct WxP {
+    const float* x;
+    const float* dy;
+    float* part;
+    int N, Cin, Cout, HW;
+    int cpp, nch;                           // chunks per picture, chunks in all
+    int mtiles, ctiles, S;
+};
+
+__global__ __launch_bounds__(kWxThreads, 2) void k_wgrad_bx(const WxP p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char wx_smem[];
+    v4f* sA = reinterpret_cast<v4f*>(wx_smem);
+    v4f* sB = sA + kWxImg;
+    const int tid = threadIdx.x;
+    const int tiles = p.mtiles * p.ctiles;
+    int tile, s;
+    if (p.S % 8 == 0) {                     // the workgroups of one pixel range on one XCD: they stream the same chunks through its L2
+        const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+        tile = slot % tiles;
+        s = (slot / tiles) * 8 + xcd;
+    } else {                                // (fewer ranges than XCDs, or an odd count: every XCD must get work first)
+        tile = blockIdx.x % tiles;
+        s = blockIdx.x / tiles;
+    }
+    const int mt = tile / p.ctiles, ct = tile - mt * p.ctiles;
+    const int m0 = mt * 128, c0 = ct * 128;
+    const int HW = p.HW;
+
+    // ---- staging: thread <-> four (row, pixel quad) pairs of each operand ----------------------------------------------------------
+    // quad q = tid + 256 j: pixel quad pq = q & 7 (8 lanes = the 128 contiguous bytes of a row), row from q >> 3 with bits 0 and 2
+    // swapped, so that the two rows of a 16-lane group are four apart: their 8-byte stores then fall on 16 different bank pairs
+    int ga[4], gb[4], lo[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int q = tid + j * kWxThreads;
+        const int pq = q & 7, rr = q >> 3;
+        const int r = (rr & ~5) | ((rr & 1) << 2) | ((rr >> 2) & 1);
+        ga[j] = (m0 + r < p.Cout) ? ((m0 + r) * HW + pq * 4) * 4 : kWxOut;
+        gb[j] = (c0 + r < p.Cin) ? ((c0 + r) * HW + pq * 4) * 4 : kWxOut;
+        lo[j] = ((pq >> 1) * kWxGS + r) * 16 + (pq & 1) * 8;
+    }
+    // ---- MFMA operand addressing ---------------------------------------------------------------------------------------------------
+    const int wave = tid >> 6, lane = tid & 63, l31 = lane & 31, h = lane >> 5;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int aBase = h * kWxGS + wm * 64 + l31, bBase = h * kWxGS + wn * 64 + l31;
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+        for (int tn = 0; tn < 2; ++tn)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[tm][tn][r] = 0.0f;
+
+    const int c_lo = (int)((long long)p.nch * s / p.S), c_hi = (int)((long long)p.nch * (s + 1) / p.S);
+    v4f ra[4], rb[4];
+    auto fetch = [&](int cidx) {
+        const int n = cidx / p.cpp, px0 = (cidx - n * p.cpp) * kWxKP;
+        // the picture's rows from this chunk's first pixel on: every valid (row, quad) lies inside, kWxOut reads zeros
+        const __amdgpu_buffer_rsrc_t ares = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.dy + (size_t)n * p.Cout * HW + px0), 0,
+                                                                              (p.Cout * HW - px0) * 4, kWxRsrcFlags);
+        const __amdgpu_buffer_rsrc_t bres = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.x + (size_t)n * p.Cin * HW + px0), 0,
+                                                                              (p.Cin * HW - px0) * 4, kWxRsrcFlags);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) ra[j] = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(ares, ga[j], 0, 0));
+#pragma unroll
+        for (int j = 0; j < 4; ++j) rb[j] = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(bres, gb[j], 0, 0));
+    };
+    auto stage_one = [&](v4f* img, int off, const v4f& v) {
+        unsigned h0, m0_, l0, h1, m1, l1;
+        bx_split2(v.x, v.y, h0, m0_, l0);
+        bx_split2(v.z, v.w, h1, m1, l1);
+        unsigned char* dst = reinterpret_cast<unsigned char*>(img) + off;
+        *reinterpret_cast<v2u*>(dst) = (v2u){h0, h1};
+        *reinterpret_cast<v2u*>(dst + 4 * kWxGS * 16) = (v2u){m0_, m1};
+        *reinterpret_cast<v2u*>(dst + 8 * kWxGS * 16) = (v2u){l0, l1};
+    };
+    auto stage = [&]() {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) stage_one(sA, lo[j], ra[j]);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) stage_one(sB, lo[j], rb[j]);
+    };
+    auto mfma_chunk = [&]() {
+#pragma unroll
+        for (int st = 0; st < 2; ++st) {
+            bf8 a[2][3], b[2][3];
+#pragma unroll
+            for (int term = 0; term < 3; ++term)
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    a[t][term] = __builtin_bit_cast(bf8, sA[(term * 4 + 2 * st) * kWxGS + aBase + t * 32]);
+                    b[t][term] = __builtin_bit_cast(bf8, sB[(term * 4 + 2 * st) * kWxGS + bBase + t * 32]);
+                }
+#pragma unroll
+            for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+                for (int tn = 0; tn < 2; ++tn) {
+                    f32x16 c = acc[tm][tn];
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[tm][1], b[tn][1], c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[tm][0], b[tn][2], c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[tm][2], b[tn][0], c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[tm][0], b[tn][1], c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[tm][1], b[tn][0], c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[tm][0], b[tn][0], c, 0, 0, 0);
+                    acc[tm][tn] = c;
+                }
+        }
+    };
+    if (c_lo < c_hi) {
+        fetch(c_lo);
+        for (int t = c_lo; t + 1 < c_hi; ++t) {
+            stage();
+            __syncthreads();
+            fetch(t + 1);
+            __builtin_amdgcn_sched_barrier(0);
+            mfma_chunk();
+            __syncthreads();
+        }
+        stage();
+        __syncthreads();
+        mfma_chunk();
+    }
+    // ---- epilogue: the partial tile into slice s of the workspace (rows beyond Cout / columns beyond Cin are out of range) -------------
+    const __amdgpu_buffer_rsrc_t pres = __builtin_amdgcn_make_buffer_rsrc(p.part + (size_t)s * p.Cout * p.Cin, 0, p.Cout * p.Cin * 4, kWxRsrcFlags);
+#pragma unroll
+    for (int tn = 0; tn < 2; ++tn) {
+        const int c = c0 + wn * 64 + tn * 32 + l31;
+        const int vb = c < p.Cin ? c * 4 : kWxOut;
+#pragma unroll
+        for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + wm * 64 + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                const float v = acc[tm][tn][r];
+                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), pres, vb + m * p.Cin * 4, 0, 0);
+            }
+    }
+}
+
+__global__ __launch_bounds__(256) void k_wgx_reduce(const float* __restrict__ part, int S, size_t n, float* __restrict__ dw) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    float v0 = 0.0f, v1 = 0.0f, v2 = 0.0f, v3 = 0.0f;          // four chains in a fixed order
+    int s = 0;
+    for (; s + 4 <= S; s += 4) {
+        const float a = part[(size_t)s * n + i], b = part[(size_t)(s + 1) * n + i], c = part[(size_t)(s + 2) * n + i],
+                    d = part[(size_t)(s + 3) * n + i];
+        v0 += a; v1 += b; v2 += c; v3 += d;
+    }
+    if (s < S) v0 += part[(size_t)s * n + i];
+    if (s + 1 < S) v1 += part[(size_t)(s + 1) * n + i];
+    if (s + 2 < S) v2 += part[(size_t)(s + 2) * n + i];
+    dw[i] = (v0 + v1) + (v2 + v3);
+}
+
+constexpr size_t kWxPartCap = (size_t)64 << 20;
+// S pixel ranges: the chip holds 512 workgroups at a time (2 per CU); a workgroup pays about three chunk times of prologue and
+// epilogue, the slices are written once and read once
+inline int wx_pick_split(int tiles, int nch, size_t slice_bytes) {
+    int best = 1;
+    double best_cost = 1e30;
+    const int smax = nch < 1024 ? nch : 1024;
+    for (int S = 1; S <= smax; ++S) {
+        if (S > 1 && (size_t)S * slice_bytes > kWxPartCap) break;
+        const long long wg = (long long)tiles * S;
+        const long long rounds = (wg + 511) / 512;
+        const double per = (double)((nch + S - 1) / S);
+        const double cost = (double)rounds * (per + 3.0) * 2.0 + (double)S * (double)slice_bytes * 2.0 / 3e6;      // microseconds
+        if (cost < best_cost) {
+            best_cost = cost;
+            best = S;
+        }
+    }
+    return best;
+}
+}  // namespace
+
+extern "C" int mas_conv_wgrad_bx_supported(int N, int Cin, int H, int W, int Cout) {
+    if (N <= 0 || Cin <= 0 || Cout <= 0 || H <= 0 || W <= 0) return 0;
+    const long long HW = (long long)H * W;
+    if (HW % kWxKP != 0) return 0;
+    if ((long long)Cin * HW * 4 >= 0x7fffffffLL || (long long)Cout * HW * 4 >= 0x7fffffffLL || (long long)Cin * Cout * 4 >= 0x7fffffffLL) return 0;
+    return 1;
+}
+
+extern "C" size_t mas_conv_wgrad_bx_workspace_bytes(int Cin, int Cout) {
+    if (Cin <= 0 || Cout <= 0) return 0;
+    const size_t slice = sizeof(float) * (size_t)Cout * Cin;
+    size_t smax = kWxPartCap / slice;
+    if (smax < 1) smax = 1;
+    if (smax > 1024) smax = 1024;
+    return smax * slice;
+}
+
+extern "C" int mas_conv_wgrad_bx(const float* x, const float* dy, int N, int Cin, int H, int W, int Cout, float* dw, void* workspace,
+                                 size_t workspace_bytes, void* stream) {
+    if (!x || !dy || !dw || !workspace) return MAS_ERR_NULL;
+    if (!mas_conv_wgrad_bx_supported(N, Cin, H, W, Cout)) return MAS_ERR_SHAPE;
+    if ((uintptr_t)x % 16 != 0 || (uintptr_t)dy % 16 != 0) return MAS_ERR_ALIGN;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    WxP p;
+    p.x = x; p.dy = dy; p.part = static_cast<float*>(workspace);
+    p.N = N; p.Cin = Cin; p.Cout = Cout; p.HW = H * W;
+    p.cpp = p.HW / kWxKP;
+    p.nch = N * p.cpp;
+    p.mtiles = (Cout + 127) / 128;
+    p.ctiles = (Cin + 127) / 128;
+    const size_t slice = sizeof(float) * (size_t)Cout * Cin;
+    p.S = wx_pick_split(p.mtiles * p.ctiles, p.nch, slice);
+    while (p.S > 1 && (size_t)p.S * slice > workspace_bytes) --p.S;
+    if ((size_t)p.S * slice > workspace_bytes) return MAS_ERR_WORKSPACE;
+    const size_t smem = (size_t)2 * kWxImg * 16;
+    const long long nblk = (long long)p.S * p.mtiles * p.ctiles;
+    if (nblk <= 0 || nblk > 0x7fffffffLL) return MAS_ERR_SHAPE;
+    hipLaunchKernelGGL(k_wgrad_bx, dim3((unsigned)nblk), dim3(kWxThreads), smem, st, p);
+    int rc = mas_launch_status();
+    if (rc != 0) return rc;
+    const size_t n = (size_t)Cout * Cin;
+    hipLaunchKernelGGL(k_wgx_reduce, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, p.part, p.S, n, dw);
+    return mas_launch_status();
+}

@@ -1182,6 +1182,11 @@ def conv_wgrad(x, dy, ksize, stride, dil):
     if tuple(dy.shape) != (N, Cout, Ho, Wo):
         raise ValueError("dy %s does not match x %s under stride %d" % (tuple(dy.shape), tuple(x.shape), stride))
     lib = _lib.load()
+    if (ksize == 1 and stride == 1 and os.environ.get("MAS_TRAIN_BX", "auto") != "off" and Cout >= 96 and Cin >= 64
+            and x.data_ptr() % 16 == 0 and dy.data_ptr() % 16 == 0 and lib.mas_conv_wgrad_bx_supported(N, Cin, H, W, Cout)):
+        # 1x1: split-bf16 kernel (csrc/conv_wgrad_bx.hip), 1.3-1.7x the f32 kernel (profiles/r04/k_bx_train_table.md); with 64 or
+        # fewer output channels half of its 128 x 128 tile is padding and the f32 kernel stays ahead
+        return conv_wgrad_bx(x, dy)
     nbytes = lib.mas_conv_wgrad_workspace_bytes(N, Cin, H, W, Cout, ksize, stride, dil)
     if nbytes == 0:
         raise ValueError("unsupported convolution geometry for mas_conv_wgrad")
@@ -1190,6 +1195,26 @@ def conv_wgrad(x, dy, ksize, stride, dil):
     with torch.cuda.device(x.device):
         _lib.check(lib.mas_conv_wgrad(x.data_ptr(), dy.data_ptr(), N, Cin, H, W, Cout, ksize, stride, dil, dw.data_ptr(),
                                       ws.data_ptr(), ws.numel(), _stream(x)), "mas_conv_wgrad")
+    return dw
+
+
+def conv_wgrad_bx(x, dy):
+    """dW [Cout,Cin,1,1] of a 1x1 stride-1 convolution from x [N,Cin,H,W] and dy [N,Cout,H,W] on the bf16 matrix cores with exact
+    three-term splits of both f32 operands (mas_conv_wgrad_bx: split-K over the pixels, fixed-order reduction)."""
+    _need(x, "x", torch.float32)
+    _need(dy, "dy", torch.float32)
+    N, Cin, H, W = x.shape
+    Cout = dy.shape[1]
+    if tuple(dy.shape) != (N, Cout, H, W):
+        raise ValueError("dy %s does not match x %s" % (tuple(dy.shape), tuple(x.shape)))
+    lib = _lib.load()
+    if not lib.mas_conv_wgrad_bx_supported(N, Cin, H, W, Cout):
+        raise ValueError("unsupported geometry for mas_conv_wgrad_bx: x %s" % (tuple(x.shape),))
+    ws = _wgrad_workspace(x.device, lib.mas_conv_wgrad_bx_workspace_bytes(Cin, Cout))
+    dw = torch.empty((Cout, Cin, 1, 1), dtype=torch.float32, device=x.device)
+    with torch.cuda.device(x.device):
+        _lib.check(lib.mas_conv_wgrad_bx(x.data_ptr(), dy.data_ptr(), N, Cin, H, W, Cout, dw.data_ptr(), ws.data_ptr(), ws.numel(),
+                                         _stream(x)), "mas_conv_wgrad_bx")
     return dw
 
 

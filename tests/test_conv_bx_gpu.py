@@ -168,3 +168,49 @@ def test_conv_bx_randomised_geometries(seed):
         conv.float(); bn.float()
         y = ops.conv_bx(conv, x, bn, relu=True, residual=res)
     assert float((y.double() - ref).abs().max()) <= 2e-5 * float(ref.abs().max()), (k, stride, dil, cin, cout, N, H, W)
+
+
+WGRAD_CASES = [
+    # N, Cin, Cout, H, W
+    (2, 128, 256, 16, 32),       # one tile column, two tile rows
+    (1, 256, 128, 8, 48),
+    (3, 304, 256, 8, 16),        # Cin 304: the third column tile is mostly padding
+    (2, 512, 2048, 12, 16),      # many tiles
+    (4, 1280, 256, 4, 8),        # one chunk per picture
+    (2, 100, 72, 8, 8),          # both extents below one tile
+]
+
+
+@pytest.mark.parametrize("N,Cin,Cout,H,W", WGRAD_CASES)
+def test_wgrad_bx_matches_float64(N, Cin, Cout, H, W):
+    """csrc/conv_wgrad_bx.hip against the float64 product, and against the f32 matrix-core kernel (csrc/conv_wgrad.hip) on the same
+    data: the split form is as accurate; two runs give identical bits (fixed-order split-K reduction)."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from mulactseg_amd import ops
+    torch.manual_seed(N * 1000 + Cin + Cout)
+    x = torch.randn(N, Cin, H, W, device='cuda')
+    dy = torch.randn(N, Cout, H, W, device='cuda')
+    ref = torch.einsum('nmp,ncp->mc', dy.double().flatten(2), x.double().flatten(2))
+    dw = ops.conv_wgrad_bx(x, dy)
+    assert dw.shape == (Cout, Cin, 1, 1)
+    dw32 = ops.conv_wgrad(x, dy, 1, 1, 1) if Cout < 96 else None      # (below 96 output channels conv_wgrad keeps the f32 kernel)
+    scale = float(ref.abs().max())
+    err = float((dw[:, :, 0, 0].double() - ref).abs().max())
+    assert err <= 2e-5 * scale, (err, scale)
+    if dw32 is not None:
+        err32 = float((dw32[:, :, 0, 0].double() - ref).abs().max())
+        assert err <= 2.0 * err32 + 1e-6 * scale, (err, err32)
+    assert torch.equal(dw, ops.conv_wgrad_bx(x, dy))
+
+
+def test_wgrad_bx_exact_on_integers_and_selected_by_conv_wgrad():
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from mulactseg_amd import ops
+    g = torch.Generator(device='cuda').manual_seed(11)
+    x = torch.randint(-3, 4, (2, 256, 16, 24), generator=g, device='cuda').float()
+    dy = torch.randint(-2, 3, (2, 128, 16, 24), generator=g, device='cuda').float()
+    ref = torch.einsum('nmp,ncp->mc', dy.double().flatten(2), x.double().flatten(2)).float()
+    assert torch.equal(ops.conv_wgrad_bx(x, dy)[:, :, 0, 0], ref)
+    assert torch.equal(ops.conv_wgrad(x, dy, 1, 1, 1)[:, :, 0, 0], ref)

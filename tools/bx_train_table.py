@@ -40,7 +40,7 @@ def main():
     with torch.no_grad():
         net(torch.randn(N, 3, H, W, device=dev))
     lines = ["# training products per layer, batch [%d,3,%d,%d]: stream-K f32 kernel vs split-bf16 kernel, us per call" % (N, H, W), "",
-             "| x | Cin | Cout | k | d | H | W | GFLOP | fwd sk+stats | fwd bx | dgrad sk | dgrad bx |", "|---|---|---|---|---|---|---|---|---|---|---|---|"]
+             "| x | Cin | Cout | k | d | H | W | GFLOP | fwd sk+stats | fwd bx | dgrad sk | dgrad bx | wgrad f32 | wgrad bx |", "|---|---|---|---|---|---|---|---|---|---|---|---|---|---|"]
     tot = collections.Counter()
     lib = _lib.load()
     for (cin, cout, k, s, d, g, xs), names in shapes.items():
@@ -68,15 +68,24 @@ def main():
                 dxb = ops.conv_bx_raw(dy, w, d, dgrad=True, packed=bd)
                 assert float((dxb - dxs).abs().max()) <= 2e-5 * float(dxs.abs().max()), names[0]
                 b_d = timeit(lambda: ops.conv_bx_raw(dy, w, d, dgrad=True, packed=bd))
+            os.environ["MAS_TRAIN_BX"] = "off"
+            t_w = timeit(lambda: ops.conv_wgrad(x, dy, k, 1, d))
+            os.environ.pop("MAS_TRAIN_BX")
+            b_w = None
+            if k == 1 and lib.mas_conv_wgrad_bx_supported(xs[0], cin, xs[2], xs[3], cout):
+                b_w = timeit(lambda: ops.conv_wgrad_bx(x, dy))
+        tot['w_f32'] += mult * t_w
+        tot['w_best'] += mult * min(t_w, b_w if b_w else 1e9)
         flop = 2.0 * cin * k * k * y.numel()
         tot['f_sk'] += mult * t_f
         tot['d_sk'] += mult * t_d
         tot['f_best'] += mult * min(t_f, b_f if b_f else 1e9)
         tot['d_best'] += mult * min(t_d, b_d if b_d else 1e9)
-        lines.append("| %d | %d | %d | %d | %d | %d | %d | %.2f | %.0f | %s | %.0f | %s |" % (
-            mult, cin, cout, k, d, xs[2], xs[3], flop / 1e9, t_f, "%.0f" % b_f if b_f else "-", t_d, "%.0f" % b_d if b_d else "-"))
-    lines += ["", "per step (us, stride-1 layers): forward stream-K %.0f, best of the two per layer %.0f; input gradient stream-K %.0f, best %.0f"
-              % (tot['f_sk'], tot['f_best'], tot['d_sk'], tot['d_best'])]
+        lines.append("| %d | %d | %d | %d | %d | %d | %d | %.2f | %.0f | %s | %.0f | %s | %.0f | %s |" % (
+            mult, cin, cout, k, d, xs[2], xs[3], flop / 1e9, t_f, "%.0f" % b_f if b_f else "-", t_d, "%.0f" % b_d if b_d else "-",
+            t_w, "%.0f" % b_w if b_w else "-"))
+    lines += ["", "per step (us, stride-1 layers): forward stream-K %.0f, best of the two per layer %.0f; input gradient stream-K %.0f, best %.0f; weight gradient f32 kernel %.0f, best %.0f"
+              % (tot['f_sk'], tot['f_best'], tot['d_sk'], tot['d_best'], tot['w_f32'], tot['w_best'])]
     text = "\n".join(lines) + "\n"
     print(text)
     if args.out:
