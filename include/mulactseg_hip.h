@@ -424,12 +424,12 @@ int mas_conv_fwd(const float* x, const float* wt, int N, int Cin, int H, int W, 
  * results (csrc/conv_bx.hip): every f32 operand is split exactly into three bf16 terms (8 + 8 + 8 significand bits) and a
  * product is accumulated in f32 from its six partial products of order <= 2 (v_mfma_f32_32x32x16_bf16); the dropped terms are
  * below 2^-23 of the product, i.e. one f32 rounding -- same error bound as the f32 MFMA form, exact on integer data, 2.67x its
- * matrix peak.  Supported (mas_conv_bx_supported != 0): ksize 1 at stride 1 (H*W % 4 == 0) or stride 2 (H even, W % 8 == 0);
- * ksize 3 with stride 1, dil 1 | 2 (padding = dil), W >= 32; any Cin (a last partial chunk is zero-padded), any Cout.
+ * matrix peak.  Supported (mas_conv_bx_supported != 0): ksize 1 at stride 1 (any plane) or stride 2 (H even, W % 8 == 0, x 16-byte
+ * aligned); ksize 3 with stride 1, dil 1 | 2 (padding = dil), W >= 32; any Cin (a last partial chunk is zero-padded), any Cout.
  * `wp` is the weight [Cout][Cin][ksize][ksize] split and laid out ONCE (per checkpoint load) by mas_conv_bx_pack into
  * mas_conv_bx_packed_bytes(ksize, Cin, Cout) bytes of caller-owned, 16-byte aligned device memory: the sequence of LDS images
  * [M tile][chunk][term h|m|l][k group][BM rows][8 bf16] (1x1: chunk = 32 channels, k = channel; 3x3: chunk = 8 channels,
- * k group = tap, + one zero tap; BM = 128 if ksize == 1 and Cout % 128 == 0, else 64).  x 16-byte aligned. */
+ * k group = tap, + one zero tap; BM = 128 if ksize == 1 and Cout % 128 == 0, else 64). */
 int mas_conv_bx_supported(int ksize, int stride, int dil, int Cin, int Cout, int H, int W);
 long long mas_conv_bx_packed_bytes(int ksize, int Cin, int Cout, int role);
 int mas_conv_bx_pack(const float* w, int Cout, int Cin, int ksize, int role, void* wp, void* stream);
@@ -450,7 +450,8 @@ int mas_conv_bx_fwd(const float* x, const void* wp, int N, int Cin, int H, int W
  * operand split of mas_conv_bx_fwd applied to BOTH operands): dW[m,c] = sum_{n,p} dY[n,m,p] * X[n,c,p], x [N,Cin,H,W], dy [N,Cout,H,W],
  * dw [Cout,Cin] -- the backward of the 1x1 nn.Conv2d layers (mas_conv_wgrad: reference lines).  Split K over the pixels with a
  * fixed-order reduction through `workspace` (mas_conv_wgrad_bx_workspace_bytes(Cin, Cout), caller-owned): run-to-run identical.
- * Supported (mas_conv_wgrad_bx_supported != 0): H*W % 32 == 0, x / dy 16-byte aligned, tensors of one picture below 2 GiB. */
+ * Supported (mas_conv_wgrad_bx_supported != 0): any plane (a picture's last, partial 32-pixel chunk is masked), tensors of one
+ * picture below 2 GiB. */
 int mas_conv_wgrad_bx_supported(int N, int Cin, int H, int W, int Cout);
 size_t mas_conv_wgrad_bx_workspace_bytes(int Cin, int Cout);
 int mas_conv_wgrad_bx(const float* x, const float* dy, int N, int Cin, int H, int W, int Cout, float* dw, void* workspace,

@@ -155,8 +155,13 @@ constexpr int kBxOut = (int)0x80000000u;        // a byte offset beyond every re
 // (tools/bx_stamps.py) show why: while the SIMD partner (a wave of the CU's other workgroup) streams MFMAs, a wave gets about one
 // instruction issued per MFMA whatever its kind, so the staging + fetch phases cost by their instruction COUNT -- hence the
 // buffer-resource forms below (no address arithmetic, no bounds selects).
-template <int TAPS, int BM, int BN, bool S2, bool RES>
+// V: the stride of the 1x1 form (1 | 2), the dilation of the 3x3 form (1 | 2: the patch geometry is a compile-time constant)
+template <int TAPS, int BM, int BN, int V, bool RES>
 __global__ __launch_bounds__(kThreads, 2) void k_conv_bx(const BxP p) {
+    constexpr bool S2 = TAPS == 1 && V == 2;
+    constexpr int DIL = TAPS == 9 ? V : 1;
+    constexpr int PW = 32 + 2 * DIL, PP = (8 + 2 * DIL) * PW;      // 3x3: columns / pixels of the input patch of an 8 x 32 tile
+    static_assert(PP <= kBxPPA, "patch");
     constexpr int CK = BxGeo<TAPS>::CK, GA = BxGeo<TAPS>::GA, SLABS = BxGeo<TAPS>::SLABS;
     constexpr int WM = BM / 64, WN = 4 / WM;
     static_assert(WN * 64 == BN, "a wave owns 64 x 64");
@@ -164,7 +169,7 @@ __global__ __launch_bounds__(kThreads, 2) void k_conv_bx(const BxP p) {
     constexpr int NW = (AUNITS + kThreads - 1) / kThreads;
     constexpr bool WTAIL = AUNITS % kThreads != 0;              // the last weight load of a thread may lie beyond the image
     constexpr int POS1 = 144 * (BN / 128);                      // 1x1: units per k group of the B image
-    constexpr int NT = TAPS == 1 ? BN / 128 : 4;                // staging tasks per thread: 1x1 (4 channels x 4 pixels), 3x3 (4 channels x 1 pixel)
+    constexpr int NT = TAPS == 1 ? BN / 128 : (2 * PP + kThreads - 1) / kThreads;       // staging tasks per thread: 1x1 (4 channels x 4 pixels), 3x3 (4 channels x 1 pixel)
     constexpr int NXR = TAPS == 1 ? NT * 4 * (S2 ? 8 : 4) : NT * 4;
     extern __shared__ __attribute__((aligned(16))) unsigned char bx_smem[];
     v4f* sA = reinterpret_cast<v4f*>(bx_smem);                                       // [3][GA][BM] units
@@ -218,15 +223,15 @@ __global__ __launch_bounds__(kThreads, 2) void k_conv_bx(const BxP p) {
             loff[j] = ((q >> 1) * POS1 + bx_pos1(4 * pq)) * 16 + (q & 1) * 8;
         }
     } else {
-        const int iy0 = oy0 - p.dil, ix0 = ox0 - p.dil;
+        const int iy0 = oy0 - DIL, ix0 = ox0 - DIL;
 #pragma unroll
         for (int j = 0; j < NT; ++j) {
             const int e = tid + j * kThreads;
             goff[j] = kBxOut;
             loff[j] = 0;
-            if (e < 2 * p.PP) {
-                const int cq = e >= p.PP ? 1 : 0, pix = e - cq * p.PP;
-                const int py = pix / p.PW, px = pix - py * p.PW;
+            if (e < 2 * PP) {
+                const int cq = e >= PP ? 1 : 0, pix = e - cq * PP;
+                const int py = pix / PW, px = pix - py * PW;
                 const int iy = iy0 + py, ix = ix0 + px;
                 live |= 1u << j;
                 loff[j] = pix * 16 + cq * 8;
@@ -244,13 +249,13 @@ __global__ __launch_bounds__(kThreads, 2) void k_conv_bx(const BxP p) {
 #pragma unroll
     for (int tn = 0; tn < 2; ++tn) {
         if (TAPS == 1) bBase[tn] = (h * POS1 + bx_pos1(wn * 64 + tn * 32 + l31)) * 16;
-        else bBase[tn] = ((wn * 2 + tn) * p.PW + l31) * 16;
+        else bBase[tn] = ((wn * 2 + tn) * PW + l31) * 16;
     }
     int toff[SLABS];                                                // 3x3: the tap of this lane half in every 16-k step
 #pragma unroll
     for (int s = 0; s < SLABS; ++s) {
         const int t = 2 * s + h > 8 ? 8 : 2 * s + h;
-        toff[s] = TAPS == 1 ? 0 : ((t / 3) * p.PW + (t % 3)) * p.dil * 16;
+        toff[s] = TAPS == 1 ? 0 : ((t / 3) * PW + (t % 3)) * DIL * 16;
     }
     f32x16 acc[2][2];
 #pragma unroll
@@ -461,7 +466,7 @@ __global__ __launch_bounds__(kThreads, 2) void k_conv_bx(const BxP p) {
 // the M tile of a layer's weight image: a pure function of (ksize, Cout), shared by the pack and the launch
 inline int bx_bm(int ksize, int Cout) { return (ksize == 1 && Cout % 128 == 0) ? 128 : 64; }
 
-template <int TAPS, int BM, int BN, bool S2, bool RES>
+template <int TAPS, int BM, int BN, int V, bool RES>
 int bx_launch(BxP p, int N, hipStream_t st) {
     constexpr int GA = BxGeo<TAPS>::GA;
     p.mtiles = (p.Cout + BM - 1) / BM;
@@ -474,11 +479,11 @@ int bx_launch(BxP p, int N, hipStream_t st) {
     } else {
         p.tiles_x = (p.Wo + 31) / 32;
         p.tiles_y = (p.Ho + 7) / 8;
-        p.PH = 8 + 2 * p.dil;
-        p.PW = 32 + 2 * p.dil;
+        if (p.dil != V) return MAS_ERR_RANGE;
+        p.PH = 8 + 2 * V;
+        p.PW = 32 + 2 * V;
         p.PP = p.PH * p.PW;
         p.PPA = kBxPPA;
-        if (p.PP > kBxPPA || 2 * p.PP > 4 * kThreads) return MAS_ERR_SHAPE;
         bbytes = (size_t)3 * kBxPPA * 16;
     }
     p.ptiles = N * p.tiles_x * p.tiles_y;
@@ -490,7 +495,7 @@ int bx_launch(BxP p, int N, hipStream_t st) {
         hipError_t e = hipGetDevice(&dev);
         if (e != hipSuccess) return (int)e;
         if (dev < 0 || dev >= 64 || !raised[dev]) {
-            e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv_bx<TAPS, BM, BN, S2, RES>), hipFuncAttributeMaxDynamicSharedMemorySize,
+            e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv_bx<TAPS, BM, BN, V, RES>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                     80 * 1024);
             if (e != hipSuccess) return (int)e;
             if (dev >= 0 && dev < 64) raised[dev] = true;
@@ -498,13 +503,13 @@ int bx_launch(BxP p, int N, hipStream_t st) {
     }
     const long long nblk = 8LL * ((p.ptiles + 7) / 8) * p.mtiles;
     if (nblk <= 0 || nblk > 0x7fffffffLL) return MAS_ERR_SHAPE;
-    hipLaunchKernelGGL((k_conv_bx<TAPS, BM, BN, S2, RES>), dim3((unsigned)nblk), dim3(kThreads), smem, st, p);
+    hipLaunchKernelGGL((k_conv_bx<TAPS, BM, BN, V, RES>), dim3((unsigned)nblk), dim3(kThreads), smem, st, p);
     return mas_launch_status();
 }
 
-template <int TAPS, int BM, int BN, bool S2>
+template <int TAPS, int BM, int BN, int V>
 int bx_launch_r(const BxP& p, int N, hipStream_t st) {
-    return p.res ? bx_launch<TAPS, BM, BN, S2, true>(p, N, st) : bx_launch<TAPS, BM, BN, S2, false>(p, N, st);
+    return p.res ? bx_launch<TAPS, BM, BN, V, true>(p, N, st) : bx_launch<TAPS, BM, BN, V, false>(p, N, st);
 }
 }  // namespace
 
@@ -515,7 +520,9 @@ extern "C" int mas_conv_bx_supported(int ksize, int stride, int dil, int Cin, in
     if (32LL * H * W * 4 >= 0x7fffffffLL || 128LL * H * W * 4 >= 0x7fffffffLL) return 0;
     if (ksize == 1) {
         if (dil != 1) return 0;
-        if (stride == 1) return (H * W) % 4 == 0;
+        // (stride 1: any plane -- the product is pixel-local, so a pixel quad that runs over the end of its plane only feeds output
+        //  pixels that are never stored; gfx950 runs 16-byte loads at 4-byte aligned addresses at the aligned rate)
+        if (stride == 1) return 1;
         if (stride == 2) return H % 2 == 0 && W % 8 == 0;        // output quads stay inside a row and start 16-byte aligned
         return 0;
     }
@@ -573,7 +580,8 @@ extern "C" int mas_conv_bx_fwd(const float* x, const void* wp, int N, int Cin, i
     if ((scale == nullptr) != (shift == nullptr)) return MAS_ERR_NULL;
     if (N <= 0) return MAS_ERR_SHAPE;
     if (!mas_conv_bx_supported(ksize, stride, dil, Cin, Cout, H, W)) return MAS_ERR_SHAPE;
-    if ((uintptr_t)x % 16 != 0 || (uintptr_t)wp % 16 != 0) return MAS_ERR_ALIGN;
+    if ((uintptr_t)wp % 16 != 0 || (uintptr_t)x % 4 != 0) return MAS_ERR_ALIGN;
+    if (ksize == 1 && stride == 2 && (uintptr_t)x % 16 != 0) return MAS_ERR_ALIGN;
     hipStream_t st = static_cast<hipStream_t>(stream);
     BxP p;
     p.x = x; p.wp = static_cast<const v4f*>(wp); p.scale = scale; p.shift = shift; p.res = residual; p.y = y;
@@ -585,10 +593,10 @@ extern "C" int mas_conv_bx_fwd(const float* x, const void* wp, int N, int Cin, i
     p.Wo = (W - 1) / stride + 1;
     const int BM = bx_bm(ksize, Cout);
     if (ksize == 1) {
-        if (stride == 2) return BM == 128 ? bx_launch_r<1, 128, 128, true>(p, N, st) : bx_launch_r<1, 64, 256, true>(p, N, st);
-        return BM == 128 ? bx_launch_r<1, 128, 128, false>(p, N, st) : bx_launch_r<1, 64, 256, false>(p, N, st);
+        if (stride == 2) return BM == 128 ? bx_launch_r<1, 128, 128, 2>(p, N, st) : bx_launch_r<1, 64, 256, 2>(p, N, st);
+        return BM == 128 ? bx_launch_r<1, 128, 128, 1>(p, N, st) : bx_launch_r<1, 64, 256, 1>(p, N, st);
     }
-    return bx_launch_r<9, 64, 256, false>(p, N, st);
+    return dil == 1 ? bx_launch_r<9, 64, 256, 1>(p, N, st) : bx_launch_r<9, 64, 256, 2>(p, N, st);
 }
 
 #ifdef BX_STAMPS

@@ -83,8 +83,10 @@ __global__ __launch_bounds__(kWxThreads, 2) void k_wgrad_bx(const WxP p) {
 
     const int c_lo = (int)((long long)p.nch * s / p.S), c_hi = (int)((long long)p.nch * (s + 1) / p.S);
     v4f ra[4], rb[4];
+    int tail = 0;                           // pixels of the chunk in the staging registers that exist (32, fewer in a picture's last chunk)
     auto fetch = [&](int cidx) {
         const int n = cidx / p.cpp, px0 = (cidx - n * p.cpp) * kWxKP;
+        tail = HW - px0 < kWxKP ? HW - px0 : kWxKP;
         // the picture's rows from this chunk's first pixel on: every valid (row, quad) lies inside, kWxOut reads zeros
         const __amdgpu_buffer_rsrc_t ares = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.dy + (size_t)n * p.Cout * HW + px0), 0,
                                                                               (p.Cout * HW - px0) * 4, kWxRsrcFlags);
@@ -105,6 +107,18 @@ __global__ __launch_bounds__(kWxThreads, 2) void k_wgrad_bx(const WxP p) {
         *reinterpret_cast<v2u*>(dst + 8 * kWxGS * 16) = (v2u){l0, l1};
     };
     auto stage = [&]() {
+        if (tail < kWxKP) {
+            // a picture's last, partial chunk (H*W % 32 != 0): the pixels beyond the plane belong to the next row of dY -- zeroed on
+            // the dY side (a zero times the finite value on the x side contributes nothing)
+            const int px = (tid & 7) * 4;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                if (px + 0 >= tail) ra[j].x = 0.0f;
+                if (px + 1 >= tail) ra[j].y = 0.0f;
+                if (px + 2 >= tail) ra[j].z = 0.0f;
+                if (px + 3 >= tail) ra[j].w = 0.0f;
+            }
+        }
 #pragma unroll
         for (int j = 0; j < 4; ++j) stage_one(sA, lo[j], ra[j]);
 #pragma unroll
@@ -208,7 +222,6 @@ inline int wx_pick_split(int tiles, int nch, size_t slice_bytes) {
 extern "C" int mas_conv_wgrad_bx_supported(int N, int Cin, int H, int W, int Cout) {
     if (N <= 0 || Cin <= 0 || Cout <= 0 || H <= 0 || W <= 0) return 0;
     const long long HW = (long long)H * W;
-    if (HW % kWxKP != 0) return 0;
     if ((long long)Cin * HW * 4 >= 0x7fffffffLL || (long long)Cout * HW * 4 >= 0x7fffffffLL || (long long)Cin * Cout * 4 >= 0x7fffffffLL) return 0;
     return 1;
 }
@@ -226,12 +239,12 @@ extern "C" int mas_conv_wgrad_bx(const float* x, const float* dy, int N, int Cin
                                  size_t workspace_bytes, void* stream) {
     if (!x || !dy || !dw || !workspace) return MAS_ERR_NULL;
     if (!mas_conv_wgrad_bx_supported(N, Cin, H, W, Cout)) return MAS_ERR_SHAPE;
-    if ((uintptr_t)x % 16 != 0 || (uintptr_t)dy % 16 != 0) return MAS_ERR_ALIGN;
+    if ((uintptr_t)x % 4 != 0 || (uintptr_t)dy % 4 != 0) return MAS_ERR_ALIGN;
     hipStream_t st = static_cast<hipStream_t>(stream);
     WxP p;
     p.x = x; p.dy = dy; p.part = static_cast<float*>(workspace);
     p.N = N; p.Cin = Cin; p.Cout = Cout; p.HW = H * W;
-    p.cpp = p.HW / kWxKP;
+    p.cpp = (p.HW + kWxKP - 1) / kWxKP;
     p.nch = N * p.cpp;
     p.mtiles = (Cout + 127) / 128;
     p.ctiles = (Cin + 127) / 128;

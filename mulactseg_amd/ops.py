@@ -1081,9 +1081,11 @@ def conv_mfma(conv, x, bn=None, relu=False, residual=None):
 # the same convolutions on the bf16 matrix cores, f32 in / f32 out through exact three-term operand splits (csrc/conv_bx.hip)
 # ------------------------------------------------------------------------------------------------
 def conv_bx_supported(conv, x):
-    """Shapes mas_conv_bx_fwd takes: 1x1 at stride 1 (H*W % 4 == 0) / 2 (H even, W % 8 == 0), 3x3 stride 1 with dilation 1 / 2
+    """Shapes mas_conv_bx_fwd takes: 1x1 at stride 1 (any plane) / 2 (H even, W % 8 == 0), 3x3 stride 1 with dilation 1 / 2
     (padding = dilation) on planes at least 32 wide; any channel counts; no groups, no bias."""
-    if not (x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and conv.groups == 1 and conv.bias is None) or x.data_ptr() % 16:
+    if not (x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and conv.groups == 1 and conv.bias is None):
+        return False
+    if conv.stride[0] == 2 and x.data_ptr() % 16:
         return False
     k, s, d, pd = conv.kernel_size, conv.stride, conv.dilation, conv.padding
     if k[0] != k[1] or s[0] != s[1] or d[0] != d[1] or pd[0] != pd[1] or pd[0] != (d[0] if k[0] == 3 else 0) or x.shape[1] != conv.in_channels:
@@ -1183,7 +1185,7 @@ def conv_wgrad(x, dy, ksize, stride, dil):
         raise ValueError("dy %s does not match x %s under stride %d" % (tuple(dy.shape), tuple(x.shape), stride))
     lib = _lib.load()
     if (ksize == 1 and stride == 1 and os.environ.get("MAS_TRAIN_BX", "auto") != "off" and Cout >= 96 and Cin >= 64
-            and x.data_ptr() % 16 == 0 and dy.data_ptr() % 16 == 0 and lib.mas_conv_wgrad_bx_supported(N, Cin, H, W, Cout)):
+            and lib.mas_conv_wgrad_bx_supported(N, Cin, H, W, Cout)):
         # 1x1: split-bf16 kernel (csrc/conv_wgrad_bx.hip), 1.3-1.7x the f32 kernel (profiles/r04/k_bx_train_table.md); with 64 or
         # fewer output channels half of its 128 x 128 tile is padding and the f32 kernel stays ahead
         return conv_wgrad_bx(x, dy)
@@ -1618,7 +1620,7 @@ class _ConvTrain(torch.autograd.Function):
         ks = w.shape[2]
         part = None
         with torch.no_grad():
-            if own[0] and conv_bx_train_ok(x.shape, w.shape, stride, dil, False) and x.data_ptr() % 16 == 0:
+            if own[0] and conv_bx_train_ok(x.shape, w.shape, stride, dil, False):
                 # split-bf16 kernel (csrc/conv_bx.hip); the BatchNorm partial sums then come from the separate reduction pass
                 y = conv_bx_raw(x, w, dil, packed=bx_packed_weight(w, 0))
             elif own[0] and stats:
@@ -1669,7 +1671,7 @@ class _ConvTrain(torch.autograd.Function):
             else:
                 dw = conv_wgrad(x, dy, ks, stride, dil)
         if need_dx:
-            if own[1] and stride == 1 and conv_bx_train_ok(dy.shape, w.shape, 1, dil, True) and dy.data_ptr() % 16 == 0:
+            if own[1] and stride == 1 and conv_bx_train_ok(dy.shape, w.shape, 1, dil, True):
                 fuse = g_other is not None and g_other.shape == x.shape and g_other.dtype == torch.float32
                 dx = conv_bx_raw(dy, w, dil, dgrad=True, residual=g_other.contiguous() if fuse else None, packed=bx_packed_weight(w, 1))
                 if fuse:

@@ -31,6 +31,9 @@ CASES = [
     (304, 256, 1, 1, 1, 1, 16, 48),      # decoder pointwise: Cin = 9.5 chunks of 32 (the last one zero-padded)
     (50, 64, 1, 1, 1, 2, 8, 32),         # Cin not a multiple of anything
     (20, 64, 3, 1, 1, 1, 11, 40),        # 3x3 with 2.5 chunks of 8 channels
+    (64, 256, 1, 1, 1, 2, 25, 33),       # odd plane (the 769-crop planes 385 / 193 / 97 / 49 scaled down): quads run over plane ends
+    (256, 128, 1, 1, 1, 1, 49, 49),
+    (64, 64, 3, 1, 1, 1, 49, 49),        # 3x3 on a 49-wide plane: the second tile column is half padding
 ]
 
 
@@ -178,6 +181,8 @@ WGRAD_CASES = [
     (2, 512, 2048, 12, 16),      # many tiles
     (4, 1280, 256, 4, 8),        # one chunk per picture
     (2, 100, 72, 8, 8),          # both extents below one tile
+    (2, 128, 256, 25, 33),       # odd plane: every picture ends in a partial, masked chunk; rows start at any 4-byte alignment
+    (1, 256, 128, 49, 49),
 ]
 
 
