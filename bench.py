@@ -255,6 +255,14 @@ def pool_round_bench(args, dev, rank, world, with_model):
 # model legs
 # ------------------------------------------------------------------------------------------------------------------
 F32_MFMA_PEAK_TF = 157.3        # dense f32 MFMA peak of MI355X (MI355X_MICROARCH.md), TFLOP/s
+# The convolutions that run on csrc/conv_bx.hip / conv_wgrad_bx.hip compute the same f32 products from exact three-term bf16 splits
+# of both operands: six bf16 MFMAs (16x the f32 rate) per sixteen f32 ones -- the matrix-core bound of an f32 convolution done that
+# way is 16 / 6 x the f32 peak.  `mfma_frac` stays what it was (f32 FLOP of the convolutions / wall time / F32 peak) and may exceed
+# the share the f32 pipe alone could reach; `frac_of_split_bf16_bound` prices the same FLOP against the split form's bound.
+SPLIT_BF16_BOUND_TF = F32_MFMA_PEAK_TF * 16.0 / 6.0
+MFMA_ARITH = ("f32 operands and f32 accumulation; layers marked hip_bx / '/bx' in layer_paths_per_step and the 1x1 weight gradients run on "
+              "v_mfma_f32_32x32x16_bf16 from exact three-term bf16 splits of both operands (six partial products, dropped terms <= 2^-23 "
+              "of a product: csrc/bx_split.h), the others on v_mfma_f32_32x32x2_f32")
 
 
 def conv_flop(net, N, H, W, products):
@@ -371,11 +379,14 @@ def train_iter_bench(args, dev, world, crop):
             "stream_k_error_word": sk_err,
             "mfma": {"flop_per_step": flop, "achieved_TFLOPs": flop / (it_ms * 1e-3) / 1e12, "peak_TFLOPs": F32_MFMA_PEAK_TF,
                      "mfma_frac": flop / (it_ms * 1e-3) / 1e12 / F32_MFMA_PEAK_TF,
+                     "split_bf16_bound_TFLOPs": SPLIT_BF16_BOUND_TF, "frac_of_split_bf16_bound": flop / (it_ms * 1e-3) / 1e12 / SPLIT_BF16_BOUND_TF,
+                     "arithmetic": MFMA_ARITH,
                      "note": "2 * taps * Cin * Cout * output pixels of every dense convolution x 3 products (forward, input gradient, "
                              "weight gradient; no input gradient for the first layer), over the WHOLE step's wall time"},
-            "config": {"workload": "stage-1 step: DeepLabv3+WN/ResNet50-deepstem fwd+bwd with the dense convolutions on this package's f32-MFMA "
-                                   "kernels (k_conv_sk: persistent stream-K forward / input gradient; k_wgrad: split-K weight gradient; "
-                                   "layer_paths_per_step says which product of which layer took which kernel) + HIP memory-bound layers + "
+            "config": {"workload": "stage-1 step: DeepLabv3+WN/ResNet50-deepstem fwd+bwd with the dense convolutions on this package's matrix-core "
+                                   "kernels (k_conv_bx: forward / input gradient from three-term bf16 splits of the f32 operands; k_conv_sk: persistent "
+                                   "stream-K f32 forward / input gradient of the stride-2 layers and the 3x3 layers on 48 x 48 planes; k_wgrad_bx / k_wgrad: "
+                                   "split-K weight gradient; layer_paths_per_step says which product of which layer took which kernel) + HIP memory-bound layers + "
                                    "fused partial-label losses (HIP) + AdamW" + ("; DistributedDataParallel over RCCL, global loss normalisers" if world > 1 else ""),
                        "train_conv_mode": os.environ.get("MAS_TRAIN_CONV", "own"),
                        "batch": [N, 3, crop, crop], "logits": [N, C, crop, crop], "nseg": S,
@@ -448,9 +459,11 @@ def acquisition_with_model_bench(args, dev, world):
             "ms_per_batch": ms, "forwards_per_image": 1, "layer_paths_per_step": paths,
             "mfma": {"flop_per_batch": flop, "achieved_TFLOPs": flop / (ms * 1e-3) / 1e12, "peak_TFLOPs": F32_MFMA_PEAK_TF,
                      "mfma_frac": flop / (ms * 1e-3) / 1e12 / F32_MFMA_PEAK_TF,
+                     "split_bf16_bound_TFLOPs": SPLIT_BF16_BOUND_TF, "frac_of_split_bf16_bound": flop / (ms * 1e-3) / 1e12 / SPLIT_BF16_BOUND_TF,
+                     "arithmetic": MFMA_ARITH,
                      "note": "2 * taps * Cin * Cout * output pixels of every dense convolution of one forward, over the whole batch's wall time"},
-            "config": {"workload": "eval forward (f32-MFMA convolutions with BatchNorm / residual / ReLU epilogues + HIP memory-bound layers, no "
-                                   "MIOpen kernel: see layer_paths_per_step) of [%d,3,%d,%d] + single-pass scan of the quarter-resolution "
+            "config": {"workload": "eval forward (matrix-core convolutions with BatchNorm / residual / ReLU epilogues -- hip_bx: f32 products from three-term "
+                                   "bf16 splits, hip_mfma: f32 MFMA -- + HIP memory-bound layers, no MIOpen kernel: see layer_paths_per_step) of [%d,3,%d,%d] + single-pass scan of the quarter-resolution "
                                    "logits; the reference structure runs the forward twice per pool image" % (B, H, W)}}
 
 

@@ -34,7 +34,8 @@ typedef float v4f __attribute__((ext_vector_type(4)));
 typedef unsigned v2u __attribute__((ext_vector_type(2)));
 typedef __bf16 bf8 __attribute__((ext_vector_type(8)));
 
-constexpr int kBxPPA = 432;                     // 3x3: positions of one term of the B image (the 12 x 36 patch of dilation 2; 10 x 34 at dilation 1)
+constexpr int kBxPPA = 448;                     // 3x3: positions of one term of the B image: the 12 x 36 patch of dilation 2 (10 x 34 at dilation 1)
+constexpr int kBxDump = 432;                    //      + 16 positions where the staging tasks beyond the patch put their (unused) stores
 constexpr int kBxTaps3 = 10;                    // 3x3: nine taps + one zero-weight tap (five 16-k steps per 8-channel chunk)
 
 struct BxP {
@@ -161,7 +162,7 @@ __global__ __launch_bounds__(kThreads, 2) void k_conv_bx(const BxP p) {
     constexpr bool S2 = TAPS == 1 && V == 2;
     constexpr int DIL = TAPS == 9 ? V : 1;
     constexpr int PW = 32 + 2 * DIL, PP = (8 + 2 * DIL) * PW;      // 3x3: columns / pixels of the input patch of an 8 x 32 tile
-    static_assert(PP <= kBxPPA, "patch");
+    static_assert(PP <= kBxDump, "patch");
     constexpr int CK = BxGeo<TAPS>::CK, GA = BxGeo<TAPS>::GA, SLABS = BxGeo<TAPS>::SLABS;
     constexpr int WM = BM / 64, WN = 4 / WM;
     static_assert(WN * 64 == BN, "a wave owns 64 x 64");
@@ -200,7 +201,6 @@ __global__ __launch_bounds__(kThreads, 2) void k_conv_bx(const BxP p) {
 
     // ---- staging descriptors (the same for every chunk): byte offset inside the chunk's x resource, byte offset in the B image --
     int goff[NT], loff[NT];
-    unsigned live = 0;
     if (TAPS == 1) {
 #pragma unroll
         for (int j = 0; j < NT; ++j) {
@@ -228,18 +228,20 @@ __global__ __launch_bounds__(kThreads, 2) void k_conv_bx(const BxP p) {
         for (int j = 0; j < NT; ++j) {
             const int e = tid + j * kThreads;
             goff[j] = kBxOut;
-            loff[j] = 0;
+            loff[j] = (kBxDump + (tid & 15)) * 16;      // (a task beyond the patch stores zeros there: no branch in the loop)
             if (e < 2 * PP) {
                 const int cq = e >= PP ? 1 : 0, pix = e - cq * PP;
                 const int py = pix / PW, px = pix - py * PW;
                 const int iy = iy0 + py, ix = ix0 + px;
-                live |= 1u << j;
                 loff[j] = pix * 16 + cq * 8;
                 if (iy >= 0 && iy < p.H && ix >= 0 && ix < p.W) goff[j] = (cq * 4 * HW + iy * p.W + ix) * 4;
             }
         }
     }
-    const int wtail = (tid + (NW - 1) * kThreads < AUNITS) ? (tid + (NW - 1) * kThreads) * 16 : kBxOut;
+    // (the last weight load of a thread beyond the image re-reads the image's last unit and stores it there again: the same value
+    //  from several threads, and no predicate -- an exec-masked store inside the loop made hipcc rotate the loop and copy all 64
+    //  accumulator registers at its head)
+    const int wtail = (tid + (NW - 1) * kThreads < AUNITS ? tid + (NW - 1) * kThreads : AUNITS - 1) * 16;
 
     // ---- MFMA operand addressing -----------------------------------------------------------------------------------------------
     const int wave = tid >> 6, lane = tid & 63, l31 = lane & 31, h = lane >> 5;
@@ -279,6 +281,9 @@ __global__ __launch_bounds__(kThreads, 2) void k_conv_bx(const BxP p) {
     }
 
     auto fetch = [&](int t) {
+        // (the chunk index is wave-uniform; said explicitly, because a resource descriptor the compiler takes for divergent is
+        //  applied through a readfirstlane loop around EVERY load -- 11 more instructions per load in the 3x3 form)
+        t = __builtin_amdgcn_readfirstlane(t);
         const __amdgpu_buffer_rsrc_t wres = __builtin_amdgcn_make_buffer_rsrc(const_cast<v4f*>(wb + (size_t)t * AUNITS), 0, AUNITS * 16, kBxRsrcFlags);
 #pragma unroll
         for (int j = 0; j < NW; ++j) {
@@ -314,8 +319,8 @@ __global__ __launch_bounds__(kThreads, 2) void k_conv_bx(const BxP p) {
     auto stage = [&]() {
 #pragma unroll
         for (int j = 0; j < NW; ++j) {
-            const int f = tid + j * kThreads;
-            if (!WTAIL || j < NW - 1 || f < AUNITS) sA[f] = wr[j];
+            if (WTAIL && j == NW - 1) *reinterpret_cast<v4f*>(reinterpret_cast<unsigned char*>(sA) + wtail) = wr[j];
+            else sA[tid + j * kThreads] = wr[j];
         }
         if (TAPS == 1) {
 #pragma unroll
@@ -334,15 +339,13 @@ __global__ __launch_bounds__(kThreads, 2) void k_conv_bx(const BxP p) {
         } else {
 #pragma unroll
             for (int j = 0; j < NT; ++j) {
-                if (live & (1u << j)) {
-                    unsigned h0, m0_, l0, h1, m1, l1;
-                    bx_split2(xr[j * 4 + 0], xr[j * 4 + 1], h0, m0_, l0);
-                    bx_split2(xr[j * 4 + 2], xr[j * 4 + 3], h1, m1, l1);
-                    unsigned char* dst = sB + loff[j];
-                    *reinterpret_cast<v2u*>(dst) = (v2u){h0, h1};
-                    *reinterpret_cast<v2u*>(dst + bTerm) = (v2u){m0_, m1};
-                    *reinterpret_cast<v2u*>(dst + 2 * bTerm) = (v2u){l0, l1};
-                }
+                unsigned h0, m0_, l0, h1, m1, l1;
+                bx_split2(xr[j * 4 + 0], xr[j * 4 + 1], h0, m0_, l0);
+                bx_split2(xr[j * 4 + 2], xr[j * 4 + 3], h1, m1, l1);
+                unsigned char* dst = sB + loff[j];
+                *reinterpret_cast<v2u*>(dst) = (v2u){h0, h1};
+                *reinterpret_cast<v2u*>(dst + bTerm) = (v2u){m0_, m1};
+                *reinterpret_cast<v2u*>(dst + 2 * bTerm) = (v2u){l0, l1};
             }
         }
     };
@@ -350,14 +353,7 @@ __global__ __launch_bounds__(kThreads, 2) void k_conv_bx(const BxP p) {
     auto mfma_chunk = [&]() {
 #pragma unroll
         for (int s = 0; s < SLABS; ++s) {
-            bf8 a[2][3], b[2][3];
-#pragma unroll
-            for (int term = 0; term < 3; ++term)
-#pragma unroll
-                for (int tm = 0; tm < 2; ++tm) {
-                    const v4f q = sA[(term * GA + 2 * s) * BM + aBase + tm * 32];
-                    a[tm][term] = __builtin_bit_cast(bf8, q);
-                }
+            bf8 b[2][3];
 #pragma unroll
             for (int term = 0; term < 3; ++term)
 #pragma unroll
@@ -366,20 +362,25 @@ __global__ __launch_bounds__(kThreads, 2) void k_conv_bx(const BxP p) {
                     const v4f q = *reinterpret_cast<const v4f*>(sB + off);
                     b[tn][term] = __builtin_bit_cast(bf8, q);
                 }
-            // the six products of order <= 2, smallest first
 #pragma unroll
-            for (int tm = 0; tm < 2; ++tm)
+            for (int tm = 0; tm < 2; ++tm) {
+                bf8 a[3];
+#pragma unroll
+                for (int term = 0; term < 3; ++term) {
+                    const v4f q = sA[(term * GA + 2 * s) * BM + aBase + tm * 32];
+                    a[term] = __builtin_bit_cast(bf8, q);
+                }
+                // the six products of order <= 2, smallest first
 #pragma unroll
                 for (int tn = 0; tn < 2; ++tn) {
-                    f32x16 c = acc[tm][tn];
-                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[tm][1], b[tn][1], c, 0, 0, 0);
-                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[tm][0], b[tn][2], c, 0, 0, 0);
-                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[tm][2], b[tn][0], c, 0, 0, 0);
-                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[tm][0], b[tn][1], c, 0, 0, 0);
-                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[tm][1], b[tn][0], c, 0, 0, 0);
-                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[tm][0], b[tn][0], c, 0, 0, 0);
-                    acc[tm][tn] = c;
+                    acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], b[tn][1], acc[tm][tn], 0, 0, 0);
+                    acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[tn][2], acc[tm][tn], 0, 0, 0);
+                    acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[2], b[tn][0], acc[tm][tn], 0, 0, 0);
+                    acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[tn][1], acc[tm][tn], 0, 0, 0);
+                    acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], b[tn][0], acc[tm][tn], 0, 0, 0);
+                    acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[tn][0], acc[tm][tn], 0, 0, 0);
                 }
+            }
         }
     };
 
@@ -389,14 +390,18 @@ __global__ __launch_bounds__(kThreads, 2) void k_conv_bx(const BxP p) {
     long long last_t = stamp ? clock64() : 0;
     const long long first_t = last_t;
 #endif
+    // One loop, no peeled last iteration: the fetch in the last pass re-reads the last chunk (never used).  With the last pass
+    // peeled, hipcc merged its staging code with the loop's and copied every loop-carried register -- 64 accumulators and the
+    // staging registers -- at the head of each iteration of the 3x3 form.
     fetch(0);
     BX_T(0);
-    for (int t = 0; t + 1 < nchunks; ++t) {
+    const int nloop = __builtin_amdgcn_readfirstlane(nchunks);      // (a scalar trip count: see fetch)
+    for (int t = 0; t < nloop; ++t) {
         stage();
         BX_T(1);
         __syncthreads();
         BX_T(2);
-        fetch(t + 1);
+        fetch(t + 1 < nloop ? t + 1 : t);
         __builtin_amdgcn_sched_barrier(0);          // the loads of chunk t + 1 are issued in FRONT of the MFMAs of chunk t
         BX_T(3);
         mfma_chunk();
@@ -404,9 +409,6 @@ __global__ __launch_bounds__(kThreads, 2) void k_conv_bx(const BxP p) {
         __syncthreads();
         BX_T(5);
     }
-    stage();
-    __syncthreads();
-    mfma_chunk();
     BX_T(6);
 
     // ---- epilogue: accumulator (row = (r & 3) + 8 (r >> 2) + 4 h, column = lane & 31) -> NCHW ----------------------------------
@@ -480,6 +482,7 @@ int bx_launch(BxP p, int N, hipStream_t st) {
         p.tiles_x = (p.Wo + 31) / 32;
         p.tiles_y = (p.Ho + 7) / 8;
         if (p.dil != V) return MAS_ERR_RANGE;
+        static_assert(kBxPPA >= kBxDump + 16, "dump positions");
         p.PH = 8 + 2 * V;
         p.PW = 32 + 2 * V;
         p.PP = p.PH * p.PW;

@@ -81,10 +81,12 @@ __global__ __launch_bounds__(kWxThreads, 2) void k_wgrad_bx(const WxP p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[tm][tn][r] = 0.0f;
 
-    const int c_lo = (int)((long long)p.nch * s / p.S), c_hi = (int)((long long)p.nch * (s + 1) / p.S);
+    const int cq = p.nch / p.S, cr = p.nch - cq * p.S;       // ranges of cq or cq + 1 chunks (the first cr ranges take one more)
+    const int c_lo = s * cq + (s < cr ? s : cr), c_hi = c_lo + cq + (s < cr ? 1 : 0);
     v4f ra[4], rb[4];
     int tail = 0;                           // pixels of the chunk in the staging registers that exist (32, fewer in a picture's last chunk)
     auto fetch = [&](int cidx) {
+        cidx = __builtin_amdgcn_readfirstlane(cidx);        // wave-uniform (keeps the resource descriptors in scalar registers)
         const int n = cidx / p.cpp, px0 = (cidx - n * p.cpp) * kWxKP;
         tail = HW - px0 < kWxKP ? HW - px0 : kWxKP;
         // the picture's rows from this chunk's first pixel on: every valid (row, quad) lies inside, kWxOut reads zeros
@@ -107,17 +109,15 @@ __global__ __launch_bounds__(kWxThreads, 2) void k_wgrad_bx(const WxP p) {
         *reinterpret_cast<v2u*>(dst + 8 * kWxGS * 16) = (v2u){l0, l1};
     };
     auto stage = [&]() {
-        if (tail < kWxKP) {
-            // a picture's last, partial chunk (H*W % 32 != 0): the pixels beyond the plane belong to the next row of dY -- zeroed on
-            // the dY side (a zero times the finite value on the x side contributes nothing)
-            const int px = (tid & 7) * 4;
+        // a picture's last, partial chunk (H*W % 32 != 0): the pixels beyond the plane belong to the next row of dY -- zeroed on the
+        // dY side (a zero times the finite value on the x side contributes nothing); selects, no branch in the loop
+        const int left = tail - (tid & 7) * 4;              // pixels of this thread's quads that exist
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                if (px + 0 >= tail) ra[j].x = 0.0f;
-                if (px + 1 >= tail) ra[j].y = 0.0f;
-                if (px + 2 >= tail) ra[j].z = 0.0f;
-                if (px + 3 >= tail) ra[j].w = 0.0f;
-            }
+        for (int j = 0; j < 4; ++j) {
+            ra[j].x = left > 0 ? ra[j].x : 0.0f;
+            ra[j].y = left > 1 ? ra[j].y : 0.0f;
+            ra[j].z = left > 2 ? ra[j].z : 0.0f;
+            ra[j].w = left > 3 ? ra[j].w : 0.0f;
         }
 #pragma unroll
         for (int j = 0; j < 4; ++j) stage_one(sA, lo[j], ra[j]);
@@ -150,19 +150,17 @@ __global__ __launch_bounds__(kWxThreads, 2) void k_wgrad_bx(const WxP p) {
                 }
         }
     };
-    if (c_lo < c_hi) {
-        fetch(c_lo);
-        for (int t = c_lo; t + 1 < c_hi; ++t) {
-            stage();
-            __syncthreads();
-            fetch(t + 1);
-            __builtin_amdgcn_sched_barrier(0);
-            mfma_chunk();
-            __syncthreads();
-        }
+    // (one loop without a peeled last pass -- its fetch re-reads the last chunk, never used: with the peel hipcc merges the two
+    //  staging sequences and copies every loop-carried register at the head of each iteration, see conv_bx.hip)
+    const int c_first = __builtin_amdgcn_readfirstlane(c_lo), c_last = __builtin_amdgcn_readfirstlane(c_hi) - 1;
+    if (c_first <= c_last) fetch(c_first);
+    for (int t = c_first; t <= c_last; ++t) {
         stage();
         __syncthreads();
+        fetch(t < c_last ? t + 1 : t);
+        __builtin_amdgcn_sched_barrier(0);
         mfma_chunk();
+        __syncthreads();
     }
     // ---- epilogue: the partial tile into slice s of the workspace (rows beyond Cout / columns beyond Cin are out of range) -------------
     const __amdgpu_buffer_rsrc_t pres = __builtin_amdgcn_make_buffer_rsrc(p.part + (size_t)s * p.Cout * p.Cin, 0, p.Cout * p.Cin * 4, kWxRsrcFlags);

@@ -22,6 +22,34 @@ elif [ "$PART" = pool ]; then
   rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/p_fetch -o f -- $CMD --acq-steps 3 > /dev/null 2>&1
   rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/p_write -o f -- $CMD --acq-steps 3 > /dev/null 2>&1
   python profiles/pmc_kernels.py $(find $O/p_fetch -name "*counter_collection.csv") $(find $O/p_write -name "*counter_collection.csv") $O/g_pool_forward_hbm_pmc.md "rocprofv3 --kernel-trace --pmc FETCH_SIZE|WRITE_SIZE -- $CMD --acq-steps 3"
+  rm -rf $O/p_mf
+  rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $O/p_mf -o m -- $CMD --acq-steps 3 > /dev/null 2>&1
+  python - "$CMD --acq-steps 3" <<'PY'
+import csv, collections, sys, glob
+sys.path.insert(0, 'profiles')
+from summarize import short
+acc = collections.defaultdict(lambda: collections.defaultdict(float))
+for r in csv.DictReader(open(glob.glob('gpurun_out/p4/p_mf/*counter_collection.csv')[0])):
+    k = short(r['Kernel_Name'])
+    if k.startswith('k_conv') or k.startswith('k_stem'):
+        acc[k][r['Counter_Name']] += float(r['Counter_Value'])
+tot = collections.defaultdict(float)
+rows = []
+for k, v in acc.items():
+    for c in v: tot[c] += v[c]
+    rows.append((v['SQ_VALU_MFMA_BUSY_CYCLES'], k, v))
+rows.sort(reverse=True)
+out = ["# Matrix-pipe utilisation of the convolution kernels of the pool forward (rocprofv3 --pmc, all launches of the run)", "",
+       "command: `rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES GRBM_GUI_ACTIVE -- %s`" % sys.argv[1], "",
+       "MfmaUtil = SQ_VALU_MFMA_BUSY_CYCLES / (4 SIMDs x SQ_BUSY_CU_CYCLES): the share of the CU-busy cycles in which the matrix pipe of a SIMD is busy "
+       "(a v_mfma_f32_32x32x16_bf16 holds it for 32 cycles, a v_mfma_f32_32x32x2_f32 for 64).", "",
+       "all convolution kernels: MfmaUtil %.3f" % (tot['SQ_VALU_MFMA_BUSY_CYCLES'] / max(1.0, 4 * tot['SQ_BUSY_CU_CYCLES'])), "",
+       "| kernel | MfmaUtil | share of matrix-pipe cycles |", "|---|---|---|"]
+for m, k, v in rows:
+    out.append("| %s | %.3f | %.1f %% |" % (k[:90], m / max(1.0, 4 * v['SQ_BUSY_CU_CYCLES']), 100 * m / max(1.0, tot['SQ_VALU_MFMA_BUSY_CYCLES'])))
+open('gpurun_out/p4/l_pool_forward_mfma_pmc.md', 'w').write("\n".join(out) + "\n")
+print("\n".join(out))
+PY
 else
   for CROP in 768 769; do
     rm -rf $O/t_tr
