@@ -20,6 +20,8 @@ static __device__ __forceinline__ unsigned bx_cvt_pk(float a, float b) {
 }
 
 // (h, m, l) of two values, packed pairwise: dword = (bf16 of v1) << 16 | bf16 of v0
+// (both subtractions of a pair as one v_pk_add_f32 were measured: the packed operands need register pairs, hipcc adds 12 moves for
+//  the 16 instructions saved per chunk -- no difference.)
 static __device__ __forceinline__ void bx_split2(float v0, float v1, unsigned& h, unsigned& m, unsigned& l) {
     h = bx_cvt_pk(v0, v1);
     const float r0 = v0 - __uint_as_float(h << 16), r1 = v1 - __uint_as_float(h & 0xffff0000u);

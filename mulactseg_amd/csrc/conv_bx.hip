@@ -152,7 +152,8 @@ constexpr int kBxOut = (int)0x80000000u;        // a byte offset beyond every re
 // What was measured and lost on this kernel (tools/bx_ab.sh: library builds A/B in one GPU session, per-layer table of the pool
 // forward): the A image by LDS-DMA into two buffers (no staging registers, no ds_write: 2-20 % SLOWER on the layers with many M
 // tiles); two chunks in flight with two register sets (+5 %: the loop is not waiting for memory); three workgroups per CU for
-// the 1x1 form (+2 %); issue priority raised for the staging phase or for the MFMA phase (+-1 %).  In-kernel stamps
+// the 1x1 form (+2 %) and, at 168 registers, for the 3x3 form (+-0.5 %); issue priority raised for the staging phase or for the MFMA
+// phase (+-1 %).  In-kernel stamps
 // (tools/bx_stamps.py) show why: while the SIMD partner (a wave of the CU's other workgroup) streams MFMAs, a wave gets about one
 // instruction issued per MFMA whatever its kind, so the staging + fetch phases cost by their instruction COUNT -- hence the
 // buffer-resource forms below (no address arithmetic, no bounds selects).
