@@ -34,9 +34,8 @@ CASES = [
     (64, 256, 1, 1, 1, 2, 25, 33),       # odd plane (the 769-crop planes 385 / 193 / 97 / 49 scaled down): quads run over plane ends
     (256, 128, 1, 1, 1, 1, 49, 49),
     (64, 64, 3, 1, 1, 1, 49, 49),        # 3x3 on a 49-wide plane: the second tile column is half padding
-    (64, 1024, 1, 1, 1, 4, 64, 128),     # enough tiles for the 256-row form (a wave owns 128 x 64, 16-channel chunks)
-    (48, 1024, 1, 1, 1, 4, 60, 130),     # 256-row form: Cin = three 16-channel chunks, partial pixel tile
-    (32, 1024, 1, 2, 1, 4, 128, 256),    # 256-row form at stride 2
+    (64, 1024, 1, 1, 1, 4, 64, 128),     # many tiles: 2 048 workgroups, four rounds
+    (48, 1024, 1, 1, 1, 4, 60, 130),     # Cin = 1.5 chunks, partial pixel tile, many M tiles
 ]
 
 
@@ -92,7 +91,7 @@ def test_conv_bx_exact_on_integers():
         conv = nn.Conv2d(64, cout, k, stride=stride, padding=dil if k == 3 else 0, dilation=dil, bias=False).cuda()
         with torch.no_grad():
             conv.weight.copy_(torch.randint(-3, 4, conv.weight.shape, generator=g, device='cuda').float())
-            shape = (4, 64, 64, 128) if cout == 1024 else (2, 64, 38, 56)          # (1024 channels on 256 pixel tiles: the 256-row form)
+            shape = (4, 64, 64, 128) if cout == 1024 else (2, 64, 38, 56)          # (1024 channels on 256 pixel tiles: four rounds of workgroups)
             x = torch.randint(-4, 5, shape, generator=g, device='cuda').float()
             assert ops.conv_bx_supported(conv, x)
             y = ops.conv_bx(conv, x)
