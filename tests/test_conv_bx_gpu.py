@@ -222,3 +222,23 @@ def test_wgrad_bx_exact_on_integers_and_selected_by_conv_wgrad():
     ref = torch.einsum('nmp,ncp->mc', dy.double().flatten(2), x.double().flatten(2)).float()
     assert torch.equal(ops.conv_wgrad_bx(x, dy)[:, :, 0, 0], ref)
     assert torch.equal(ops.conv_wgrad(x, dy, 1, 1, 1)[:, :, 0, 0], ref)
+
+
+@pytest.mark.parametrize("shape,role", [((130, 40, 1, 1), 0), ((130, 40, 1, 1), 1), ((64, 20, 3, 3), 0), ((72, 16, 3, 3), 1), ((256, 304, 1, 1), 0)])
+def test_weight_image_equals_the_numpy_restatement(shape, role):
+    """mas_conv_bx_pack (and the multi-job pack the training step uses) against oracle/bx_split.py:pack_image, bit for bit: the
+    split of every weight, the zero padding of rows / channels / the tenth tap, the mirrored taps of the input-gradient role."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from mulactseg_amd import ops
+    from oracle import bx_split
+    rs = np.random.RandomState(sum(shape) + role)
+    w = rs.standard_normal(shape).astype(np.float32)
+    wt = torch.from_numpy(w).cuda()
+    want = bx_split.pack_image(w, role)
+    assert np.array_equal(ops.conv_bx_pack(wt, role).cpu().numpy().view(np.uint16), want)
+    img = ops.bx_packed_weight(wt, role)                    # registry: packs alone the first time ...
+    assert np.array_equal(img.cpu().numpy().view(np.uint16), want)
+    wt.mul_(0.5)                                            # ... and through ONE multi-job launch when a version counter moved
+    img = ops.bx_packed_weight(wt, role)
+    assert np.array_equal(img.cpu().numpy().view(np.uint16), bx_split.pack_image(w * np.float32(0.5), role))
