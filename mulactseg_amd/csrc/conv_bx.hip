@@ -1,12 +1,13 @@
-// conv_bx.hip -- the dense convolutions of the network at INFERENCE (1x1 stride 1 / 2; 3x3 stride 1, dilation 1 / 2) as an
-// implicit GEMM on the bf16 matrix cores of gfx950 with f32 OPERANDS AND f32 RESULTS: every f32 operand is split EXACTLY into
-// three bf16 terms
-//        x = h + m + l,    h = trunc16(x),  m = trunc16(x - h),  l = x - h - m        (8 + 8 + 8 significand bits; both
-//                                                                                      subtractions are exact in f32)
+// conv_bx.hip -- the dense convolutions of the network (1x1 stride 1 / 2; 3x3 stride 1, dilation 1 / 2; inference with the
+// BatchNorm / residual / ReLU epilogue, and in training the bare forward product and -- with the weight image of role 1 -- the
+// stride-1 input gradient) as an implicit GEMM on the bf16 matrix cores of gfx950 with f32 OPERANDS AND f32 RESULTS: every f32
+// operand is split EXACTLY into three bf16 terms (bx_split.h)
+//        x = h + m + l,    h = bf16(x),  m = bf16(x - h),  l = x - h - m        (round to nearest even; 8 + 8 + 8 significand
+//                                                                                bits, both subtractions exact in f32)
 // and a product a*b is accumulated as the six partial products of order <= 2
-//        ah*bh + ah*bm + am*bh + ah*bl + al*bh + am*bm                                (each exact in f32: 8 x 8 bits)
-// on v_mfma_f32_32x32x16_bf16 with f32 accumulation.  What is dropped (am*bl + al*bm + al*bl) is below 2^-23 |a*b| -- one
-// f32 rounding of the product, which the f32 MFMA (v_mfma_f32_32x32x2_f32, csrc/conv_mfma.hip) commits as well -- so the
+//        ah*bh + ah*bm + am*bh + ah*bl + al*bh + am*bm                          (each exact in f32: 8 x 8 bits)
+// on v_mfma_f32_32x32x16_bf16 with f32 accumulation.  What is dropped (am*bl + al*bm + al*bl) is at most 2^-23 |a*b|, of either
+// sign -- the size of the rounding the f32 MFMA (v_mfma_f32_32x32x2_f32, csrc/conv_mfma.hip) commits per product -- so the
 // result is f32 arithmetic by its error bound, exact on integer data, and six bf16 MFMAs of 16x the f32 rate do the work of
 // sixteen f32 ones: 2.67x the f32 matrix peak (157 -> 419 TFLOP/s of f32 convolution).
 // Reference: the convolutions of models/segmentation/backbone/resnet.py:129-160 (Bottleneck conv1/2/3 + downsample with
@@ -47,7 +48,6 @@ struct BxP {
     float* y;
     int Cin, H, W, Cout, Ho, Wo, dil, relu;
     int tiles_x, tiles_y, ptiles, mtiles;
-    int PH, PW, PP, PPA;                        // 3x3 input patch: rows, columns, pixels, pixels rounded up to 16
 #ifdef BX_STAMPS
     unsigned long long* stamps;
 #endif
@@ -477,17 +477,12 @@ int bx_launch(BxP p, int N, hipStream_t st) {
     if (TAPS == 1) {
         p.tiles_x = (p.Ho * p.Wo + BN - 1) / BN;
         p.tiles_y = 1;
-        p.PH = p.PW = p.PP = p.PPA = 0;
         bbytes = (size_t)3 * 4 * 144 * (BN / 128) * 16;
     } else {
         p.tiles_x = (p.Wo + 31) / 32;
         p.tiles_y = (p.Ho + 7) / 8;
         if (p.dil != V) return MAS_ERR_RANGE;
         static_assert(kBxPPA >= kBxDump + 16, "dump positions");
-        p.PH = 8 + 2 * V;
-        p.PW = 32 + 2 * V;
-        p.PP = p.PH * p.PW;
-        p.PPA = kBxPPA;
         bbytes = (size_t)3 * kBxPPA * 16;
     }
     p.ptiles = N * p.tiles_x * p.tiles_y;
