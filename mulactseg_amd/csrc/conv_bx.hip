@@ -25,6 +25,8 @@
 // A workgroup is 4 waves, a wave owns 64 x 64 of the tile (2 x 2 MFMA tiles: 64 accumulator registers); chunk t + 1 travels
 // global -> registers in front of the MFMAs of chunk t and registers -> (split) -> LDS behind them; two workgroups per CU
 // cover each other's staging.  Epilogue as conv_mfma.hip: y * scale[m] + shift[m] (+ residual) (ReLU), NCHW stores.
+#include <type_traits>
+
 #include "common.h"
 #include "bx_split.h"
 
@@ -431,6 +433,10 @@ __global__ __launch_bounds__(kThreads, 2) void k_conv_bx(const BxP p) {
             vo[tn] = (oy < p.Ho && ox < p.Wo) ? (oy * p.Wo + ox) * 4 : kBxOut;
         }
     }
+    // The epilogue is a large share of the layers with few chunks (K = 64 ... 256: the layer1 / layer2 1x1 layers, every bare
+    // product of a training step), and its cost is its instruction count: BARE (no scale / shift, no ReLU: what training asks for)
+    // skips the affine part; on a whole M tile (FULL) the row part of a store's address is a scalar offset -- a lane's 16 stores of
+    // an MFMA tile then share ONE address register; scale / shift come as four 16-byte LDS reads per tile, the ReLU is one v_max.
     const float lo = p.relu ? 0.0f : -INFINITY;
     float rv[2][16];
     auto res_load = [&](int i, float (&dst)[16]) {
@@ -440,20 +446,42 @@ __global__ __launch_bounds__(kThreads, 2) void k_conv_bx(const BxP p) {
         for (int r = 0; r < 16; ++r)                          // (read once: non-temporal)
             dst[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rres, vo[tn] + (mb + (r & 3) + 8 * (r >> 2)) * row4, 0, 2));
     };
-    if (RES) res_load(0, rv[0]);
+    auto epilogue = [&](auto bare_tag, auto full_tag) {
+        constexpr bool BARE = decltype(bare_tag)::value, FULL = decltype(full_tag)::value;
+        if (RES) res_load(0, rv[0]);
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int tn = i >> 1, tm = i & 1;
-        if (RES && i + 1 < 4) res_load(i + 1, rv[(i + 1) & 1]);
-        const int mb = wm * 64 + tm * 32 + 4 * h;
+        for (int i = 0; i < 4; ++i) {
+            const int tn = i >> 1, tm = i & 1;
+            if (RES && i + 1 < 4) res_load(i + 1, rv[(i + 1) & 1]);
+            const int mb = wm * 64 + tm * 32 + 4 * h;
+            const int vbase = vo[tn] + mb * row4;               // FULL: the lane's part of the address (kBxOut + mb * row4 stays out of range)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int m = mb + (r & 3) + 8 * (r >> 2);
-            float v = mas_fmaf(acc[tm][tn][r], sE[m], sE[BM + m]);
-            if (RES) v += rv[i & 1][r];
-            v = v < lo ? lo : v;
-            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), yres, vo[tn] + m * row4, 0, 0);
+            for (int g = 0; g < 4; ++g) {
+                v4f sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f};
+                if (!BARE) {
+                    sc = *reinterpret_cast<const v4f*>(sE + mb + 8 * g);
+                    sh = *reinterpret_cast<const v4f*>(sE + BM + mb + 8 * g);
+                }
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int r = 4 * g + e, mr = e + 8 * g;    // row of the tile: mb + mr
+                    float v = acc[tm][tn][r];
+                    if (!BARE) v = mas_fmaf(v, sc[e], sh[e]);
+                    if (RES) v += rv[i & 1][r];
+                    if (!BARE) v = mas_vmax(v, lo);
+                    if (FULL) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), yres, vbase, mr * row4, 0);
+                    else __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), yres, vo[tn] + (mb + mr) * row4, 0, 0);
+                }
+            }
         }
+    };
+    const bool bare = p.scale == nullptr && !p.relu, full = m0 + BM <= p.Cout;     // wave-uniform
+    if (bare) {
+        if (full) epilogue(std::true_type{}, std::true_type{});
+        else epilogue(std::true_type{}, std::false_type{});
+    } else {
+        if (full) epilogue(std::false_type{}, std::true_type{});
+        else epilogue(std::false_type{}, std::false_type{});
     }
 #ifdef BX_STAMPS
     if (stamp) {
