@@ -163,19 +163,32 @@ __global__ __launch_bounds__(kWxThreads, 2) void k_wgrad_bx(const WxP p) {
         __syncthreads();
     }
     // ---- epilogue: the partial tile into slice s of the workspace (rows beyond Cout / columns beyond Cin are out of range) -------------
+    // (on a whole M tile the row part of the address is a scalar offset: a lane's 16 stores of an MFMA tile share one address register)
     const __amdgpu_buffer_rsrc_t pres = __builtin_amdgcn_make_buffer_rsrc(p.part + (size_t)s * p.Cout * p.Cin, 0, p.Cout * p.Cin * 4, kWxRsrcFlags);
+    const bool full = m0 + 128 <= p.Cout;               // wave-uniform
+    const int row4 = p.Cin * 4;
 #pragma unroll
     for (int tn = 0; tn < 2; ++tn) {
         const int c = c0 + wn * 64 + tn * 32 + l31;
         const int vb = c < p.Cin ? c * 4 : kWxOut;
 #pragma unroll
-        for (int tm = 0; tm < 2; ++tm)
+        for (int tm = 0; tm < 2; ++tm) {
+            const int mb = m0 + wm * 64 + tm * 32 + 4 * h;
+            const int vbase = vb + mb * row4;
+            if (full) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int m = m0 + wm * 64 + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-                const float v = acc[tm][tn][r];
-                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), pres, vb + m * p.Cin * 4, 0, 0);
+                for (int r = 0; r < 16; ++r) {
+                    const float v = acc[tm][tn][r];
+                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), pres, vbase, ((r & 3) + 8 * (r >> 2)) * row4, 0);
+                }
+            } else {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float v = acc[tm][tn][r];
+                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), pres, vb + (mb + (r & 3) + 8 * (r >> 2)) * row4, 0, 0);
+                }
             }
+        }
     }
 }
 
