@@ -1403,9 +1403,10 @@ def conv_bx_raw(x, w, dil=1, dgrad=False, residual=None, packed=None):
 
 def conv_bx_train_ok(x_shape, w_shape, stride, dil, dgrad):
     """Does the split-bf16 kernel take this product of a training step, and is it the faster one?  Stride 1 only; MAS_TRAIN_BX =
-    auto (default): every 1x1 product, 3x3 products on planes of at least 96 x 96 pixels (on the 48 x 48 planes of layer3 / layer4
-    a 3x3 layer has 192-384 tiles of which a quarter is padding: the persistent stream-K kernel stays ahead there --
-    tools/bx_train_table.py, profiles/r04/k_bx_train_table.md), all: wherever supported, off: never."""
+    auto (default): every 1x1 product, 3x3 products on planes of at least 96 x 96 pixels or with at least 320 tiles (on the 48 x 48
+    planes a 3x3 layer has 192 (256 channels) / 384 (512 channels) tiles of which a quarter is padding: with 192 the persistent
+    stream-K kernel stays 4 % ahead, with 384 the split-bf16 kernel is -- tools/bx_train_table.py, profiles/r04/k_bx_train_table.md),
+    all: wherever supported, off: never."""
     mode = os.environ.get("MAS_TRAIN_BX", "auto")
     if mode == "off" or stride != 1:
         return False
@@ -1414,7 +1415,9 @@ def conv_bx_train_ok(x_shape, w_shape, stride, dil, dgrad):
     N, _, H, W = x_shape
     if not _lib.load().mas_conv_bx_supported(ks, 1, dil, K, M, H, W):
         return False
-    return mode == "all" or ks == 1 or H * W >= 96 * 96
+    if mode == "all" or ks == 1 or H * W >= 96 * 96:
+        return True
+    return N * ((H + 7) // 8) * ((W + 31) // 32) * ((M + 63) // 64) >= 320      # 3x3 on a small plane: with enough 64 x (8 x 32) tiles
 
 def packed_weight(w, stride=1, dgrad=False):
     """The mas_conv_sk image of weight `w` for one role, kept up to date across optimizer steps (see _PackRegistry)."""
