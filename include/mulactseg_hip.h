@@ -432,7 +432,7 @@ int mas_conv_fwd(const float* x, const float* wt, int N, int Cin, int H, int W, 
  * k group = tap, + one zero tap; BM = 128 if ksize == 1 and Cout % 128 == 0, else 64). */
 int mas_conv_bx_supported(int ksize, int stride, int dil, int Cin, int Cout, int H, int W);
 long long mas_conv_bx_packed_bytes(int ksize, int Cin, int Cout, int role);
-int mas_conv_bx_pack(const float* w, int Cout, int Cin, int ksize, int role, void* wp, void* stream);
+int mas_conv_bx_pack(const float* w, const float* row_scale, int Cout, int Cin, int ksize, int role, void* wp, void* stream);
 /* role 0: the image of the forward product.  role 1: the image with which mas_conv_bx_fwd computes the INPUT GRADIENT of the
  * stride-1 convolution (the backward of the nn.Conv2d calls above inside trainer/active_joint_multi_predignore_lossdecomp.py:83-116):
  * channel axes swapped, taps mirrored -- call mas_conv_bx_fwd(dY, wp1, N, Cout, H, W, Cin, ksize, 1, dil, NULL, NULL, residual, 0, dX):
@@ -440,6 +440,15 @@ int mas_conv_bx_pack(const float* w, int Cout, int Cin, int ksize, int role, voi
  * are rewritten by ONE launch from a device-resident job table (mas_conv_bx_pack_job fills a host record of
  * mas_conv_bx_pack_job_bytes() bytes and returns the job's block count, 0 if it rejects the arguments; records in ascending
  * first_block order; mas_conv_bx_pack_multi runs `njobs` records covering `nblocks` blocks). */
+/* `row_scale` (role 0; NULL or [Cout]): the image holds w[m,:,:,:] * row_scale[m] -- an inference BatchNorm's scale folded into the
+ * weight, which is what lets two convolutions share one accumulator:
+ * mas_conv_bx_fwd_dual:  y = relu?( conv1x1(x1, w1') + conv1x1(x2, w2') + shift[m] ),  x1 [N,Cin1,H,W], x2 [N,Cin2,H,W] on the same
+ * plane, both 1x1 stride 1 -- `bn3(conv3(out)) + downsample(x)` of the first Bottleneck of a stage whose downsample has stride 1
+ * (models/segmentation/backbone/resnet.py:143-160: layer1.0, and layer4.0 at output stride 16) in ONE kernel: the identity branch
+ * is never written to memory and read back.  w1' / w2' = the images packed with the two BatchNorm scales, shift = the sum of the
+ * two BatchNorm shifts. */
+int mas_conv_bx_fwd_dual(const float* x1, const void* wp1, int Cin1, const float* x2, const void* wp2, int Cin2, int N, int H, int W,
+                         int Cout, const float* shift, int relu, float* y, void* stream);
 size_t mas_conv_bx_pack_job_bytes(void);
 unsigned mas_conv_bx_pack_job(void* job_host, const float* w, int Cout, int Cin, int ksize, int role, void* wp, unsigned first_block);
 int mas_conv_bx_pack_multi(const void* jobs_dev, int njobs, unsigned nblocks, void* stream);

@@ -78,7 +78,8 @@ SIGNATURES = {
     "mas_conv_fwd": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _i, _vp, _vp]),
     "mas_conv_bx_supported": (_i, [_i, _i, _i, _i, _i, _i, _i]),
     "mas_conv_bx_packed_bytes": (_i64, [_i, _i, _i, _i]),
-    "mas_conv_bx_pack": (_i, [_vp, _i, _i, _i, _i, _vp, _vp]),
+    "mas_conv_bx_pack": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp]),
+    "mas_conv_bx_fwd_dual": (_i, [_vp, _vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _vp, _i, _vp, _vp]),
     "mas_conv_bx_pack_job_bytes": (_c.c_size_t, []),
     "mas_conv_bx_pack_job": (_c.c_uint, [_vp, _vp, _i, _i, _i, _i, _vp, _c.c_uint]),
     "mas_conv_bx_pack_multi": (_i, [_vp, _i, _c.c_uint, _vp]),

@@ -48,6 +48,9 @@ struct BxP {
     const float* shift;
     const float* res;
     float* y;
+    const float* x2;                            // dual form (1x1 stride 1): a second input on the same plane, walked behind the first
+    const v4f* wp2;                             //   with its own weight image: y = W1 x + W2 x2 (conv3 + downsample of a Bottleneck)
+    int Cin2;                                   //   0: none
     int Cin, H, W, Cout, Ho, Wo, dil, relu;
     int tiles_x, tiles_y, ptiles, mtiles;
 #ifdef BX_STAMPS
@@ -75,6 +78,7 @@ __device__ __forceinline__ int bx_pos1(int p) { return (p >> 7) * 144 + (p & 3) 
 // 3x3 tap = g (tap 9: zeros), channel = chunk * 8 + j; rows beyond M and channels beyond K are zeros.
 struct BxPackJob {
     const float* w;             // [Cout][Cin][taps] as PyTorch stores it
+    const float* row_scale;     // NULL, or [Cout]: the image holds w[m, :, :] * row_scale[m] (role 0: a BatchNorm scale folded into the weight)
     unsigned* out;
     int Cout, Cin, taps, role, BM;
     long long units;
@@ -104,6 +108,7 @@ __device__ __forceinline__ void bx_pack_unit(const BxPackJob& jb, long long u) {
             const int tap = taps == 1 ? 0 : (jb.role ? 8 - g : g);
             const size_t co = jb.role ? c : m, ci = jb.role ? m : c;
             val = jb.w[(co * jb.Cin + ci) * taps + tap];
+            if (jb.row_scale) val *= jb.row_scale[co];
         }
         v[j] = val;
     }
@@ -271,8 +276,14 @@ __global__ __launch_bounds__(kThreads, 2) void k_conv_bx(const BxP p) {
             for (int r = 0; r < 16; ++r) acc[tm][tn][r] = 0.0f;
 
     const float* xb = p.x + (size_t)n * p.Cin * HW;
-    const int nchunks = (p.Cin + CK - 1) / CK;
-    const v4f* wb = p.wp + (size_t)mt * nchunks * AUNITS;
+    // DUAL (1x1 stride 1 only): the chunks of a second input / weight image follow those of the first; one accumulator set
+    constexpr bool DUAL_OK = TAPS == 1 && !S2;
+    const int n1 = (p.Cin + CK - 1) / CK;
+    const int n2 = DUAL_OK ? (p.Cin2 + CK - 1) / CK : 0;
+    const int nchunks = n1 + n2;
+    const v4f* wb = p.wp + (size_t)mt * n1 * AUNITS;
+    const v4f* wb2 = DUAL_OK && p.Cin2 ? p.wp2 + (size_t)mt * n2 * AUNITS : nullptr;
+    const float* xb2 = DUAL_OK && p.Cin2 ? p.x2 + (size_t)n * p.Cin2 * HW : nullptr;
     const int hw4 = HW * 4;
     v4f wr[NW];
     float xr[NXR];
@@ -280,22 +291,27 @@ __global__ __launch_bounds__(kThreads, 2) void k_conv_bx(const BxP p) {
     if (tid < BM) {
         const bool real = m0 + tid < p.Cout;
         sE[tid] = (p.scale && real) ? p.scale[m0 + tid] : 1.0f;
-        sE[BM + tid] = (p.scale && real) ? p.shift[m0 + tid] : 0.0f;
+        sE[BM + tid] = (p.shift && real) ? p.shift[m0 + tid] : 0.0f;
     }
 
     auto fetch = [&](int t) {
         // (the chunk index is wave-uniform; said explicitly, because a resource descriptor the compiler takes for divergent is
         //  applied through a readfirstlane loop around EVERY load -- 11 more instructions per load in the 3x3 form)
         t = __builtin_amdgcn_readfirstlane(t);
-        const __amdgpu_buffer_rsrc_t wres = __builtin_amdgcn_make_buffer_rsrc(const_cast<v4f*>(wb + (size_t)t * AUNITS), 0, AUNITS * 16, kBxRsrcFlags);
+        const bool second = DUAL_OK && t >= n1;             // wave-uniform: scalar selects of the bases below
+        const v4f* wsrc = second ? wb2 : wb;
+        const float* xsrc = second ? xb2 : xb;
+        const int cin = second ? p.Cin2 : p.Cin;
+        if (second) t -= n1;
+        const __amdgpu_buffer_rsrc_t wres = __builtin_amdgcn_make_buffer_rsrc(const_cast<v4f*>(wsrc + (size_t)t * AUNITS), 0, AUNITS * 16, kBxRsrcFlags);
 #pragma unroll
         for (int j = 0; j < NW; ++j) {
             if (WTAIL && j == NW - 1) wr[j] = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(wres, wtail, 0, 0));
             else wr[j] = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(wres, tid * 16, j * kThreads * 16, 0));
         }
         // (the channels of a last, partial chunk that do not exist lie beyond the resource: zeros against zero weights)
-        const int cleft = p.Cin - t * CK;
-        const __amdgpu_buffer_rsrc_t xres = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(xb + (size_t)t * CK * HW), 0, (cleft < CK ? cleft : CK) * hw4, kBxRsrcFlags);
+        const int cleft = cin - t * CK;
+        const __amdgpu_buffer_rsrc_t xres = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(xsrc + (size_t)t * CK * HW), 0, (cleft < CK ? cleft : CK) * hw4, kBxRsrcFlags);
         if (TAPS == 1) {
 #pragma unroll
             for (int j = 0; j < NT; ++j)
@@ -475,7 +491,7 @@ __global__ __launch_bounds__(kThreads, 2) void k_conv_bx(const BxP p) {
             }
         }
     };
-    const bool bare = p.scale == nullptr && !p.relu, full = m0 + BM <= p.Cout;     // wave-uniform
+    const bool bare = p.scale == nullptr && p.shift == nullptr && !p.relu, full = m0 + BM <= p.Cout;     // wave-uniform
     if (bare) {
         if (full) epilogue(std::true_type{}, std::true_type{});
         else epilogue(std::true_type{}, std::false_type{});
@@ -565,20 +581,21 @@ extern "C" long long mas_conv_bx_packed_bytes(int ksize, int Cin, int Cout, int 
 }
 
 namespace {
-bool bx_fill_job(BxPackJob* jb, const float* w, int Cout, int Cin, int ksize, int role, void* wp, unsigned first_block) {
+bool bx_fill_job(BxPackJob* jb, const float* w, const float* row_scale, int Cout, int Cin, int ksize, int role, void* wp, unsigned first_block) {
     const long long bytes = mas_conv_bx_packed_bytes(ksize, Cin, Cout, role);
     if (bytes <= 0 || !w || !wp || (uintptr_t)wp % 16 != 0) return false;
-    jb->w = w; jb->out = static_cast<unsigned*>(wp); jb->Cout = Cout; jb->Cin = Cin; jb->taps = ksize * ksize; jb->role = role;
+    jb->w = w; jb->row_scale = row_scale; jb->out = static_cast<unsigned*>(wp); jb->Cout = Cout; jb->Cin = Cin; jb->taps = ksize * ksize; jb->role = role;
     jb->BM = bx_bm(ksize, role ? Cin : Cout); jb->units = bytes / 16; jb->first_block = first_block;
     return true;
 }
 }  // namespace
 
-extern "C" int mas_conv_bx_pack(const float* w, int Cout, int Cin, int ksize, int role, void* wp, void* stream) {
+extern "C" int mas_conv_bx_pack(const float* w, const float* row_scale, int Cout, int Cin, int ksize, int role, void* wp, void* stream) {
     if (!w || !wp) return MAS_ERR_NULL;
     if ((uintptr_t)wp % 16 != 0) return MAS_ERR_ALIGN;
+    if (row_scale && role != 0) return MAS_ERR_RANGE;
     BxPackJob jb;
-    if (!bx_fill_job(&jb, w, Cout, Cin, ksize, role, wp, 0)) return MAS_ERR_SHAPE;
+    if (!bx_fill_job(&jb, w, row_scale, Cout, Cin, ksize, role, wp, 0)) return MAS_ERR_SHAPE;
     hipLaunchKernelGGL(k_bx_pack, dim3((unsigned)((jb.units + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream), jb);
     return mas_launch_status();
 }
@@ -589,7 +606,7 @@ extern "C" size_t mas_conv_bx_pack_job_bytes(void) { return sizeof(BxPackJob); }
 extern "C" unsigned mas_conv_bx_pack_job(void* job_host, const float* w, int Cout, int Cin, int ksize, int role, void* wp, unsigned first_block) {
     if (!job_host) return 0;
     BxPackJob* jb = static_cast<BxPackJob*>(job_host);
-    if (!bx_fill_job(jb, w, Cout, Cin, ksize, role, wp, first_block)) return 0;
+    if (!bx_fill_job(jb, w, nullptr, Cout, Cin, ksize, role, wp, first_block)) return 0;
     return (unsigned)((jb->units + 255) / 256);
 }
 
@@ -612,6 +629,7 @@ extern "C" int mas_conv_bx_fwd(const float* x, const void* wp, int N, int Cin, i
     hipStream_t st = static_cast<hipStream_t>(stream);
     BxP p;
     p.x = x; p.wp = static_cast<const v4f*>(wp); p.scale = scale; p.shift = shift; p.res = residual; p.y = y;
+    p.x2 = nullptr; p.wp2 = nullptr; p.Cin2 = 0;
     p.Cin = Cin; p.H = H; p.W = W; p.Cout = Cout; p.dil = dil; p.relu = relu;
 #ifdef BX_STAMPS
     p.stamps = g_bx_stamps;
@@ -633,3 +651,21 @@ extern "C" int mas_conv_bx_debug_stamps(void* buf) {
     return 0;
 }
 #endif
+
+extern "C" int mas_conv_bx_fwd_dual(const float* x1, const void* wp1, int Cin1, const float* x2, const void* wp2, int Cin2, int N, int H, int W,
+                                    int Cout, const float* shift, int relu, float* y, void* stream) {
+    if (!x1 || !wp1 || !x2 || !wp2 || !y) return MAS_ERR_NULL;
+    if (N <= 0 || Cin2 <= 0) return MAS_ERR_SHAPE;
+    if (!mas_conv_bx_supported(1, 1, 1, Cin1, Cout, H, W) || !mas_conv_bx_supported(1, 1, 1, Cin2, Cout, H, W)) return MAS_ERR_SHAPE;
+    if ((uintptr_t)wp1 % 16 != 0 || (uintptr_t)wp2 % 16 != 0 || (uintptr_t)x1 % 4 != 0 || (uintptr_t)x2 % 4 != 0) return MAS_ERR_ALIGN;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    BxP p;
+    p.x = x1; p.wp = static_cast<const v4f*>(wp1); p.scale = nullptr; p.shift = shift; p.res = nullptr; p.y = y;
+    p.x2 = x2; p.wp2 = static_cast<const v4f*>(wp2); p.Cin2 = Cin2;
+    p.Cin = Cin1; p.H = H; p.W = W; p.Cout = Cout; p.dil = 1; p.relu = relu;
+#ifdef BX_STAMPS
+    p.stamps = g_bx_stamps;
+#endif
+    p.Ho = H; p.Wo = W;
+    return bx_bm(1, Cout) == 128 ? bx_launch<1, 128, 128, 1, false>(p, N, st) : bx_launch<1, 64, 256, 1, false>(p, N, st);
+}

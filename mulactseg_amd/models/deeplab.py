@@ -183,6 +183,16 @@ class Bottleneck(nn.Module):
             y, x = _conv_bn_act(self.conv1, self.bn1, x, fork=True)
         y = _conv_bn_act(self.conv2, self.bn2, y)
         if self.downsample is not None:
+            if (x.is_cuda and not self.training and not torch.is_grad_enabled() and _INFER_BX() and len(self.downsample) == 2
+                    and os.environ.get("MAS_INFER_DUAL", "on") != "off"):
+                from .. import ops
+                ds_conv, ds_bn = self.downsample[0], self.downsample[1]
+                if (isinstance(ds_conv, nn.Conv2d) and isinstance(ds_bn, nn.BatchNorm2d) and not ds_bn.training and not self.bn3.training
+                        and ops.conv_bx_dual_supported(self.conv3, y, ds_conv, x)):
+                    # stride-1 downsample (layer1.0; layer4.0 at output stride 16): conv3 + bn3 and downsample + bn in one kernel, one
+                    # accumulator set -- the identity branch is never written and read back
+                    _took("conv_bn_act", "hip_bx_dual")
+                    return ops.conv_bx_dual(self.conv3, self.bn3, y, ds_conv, ds_bn, x, True)
             x = _run(self.downsample, x)
         return _conv_bn_act(self.conv3, self.bn3, y, True, x)
 

@@ -1108,9 +1108,46 @@ def _conv_bx_weight(conv):
             raise ValueError("mas_conv_bx_pack does not take a %dx%d convolution with %d input channels" % (kh, kh, K))
         wp = torch.empty(nbytes, dtype=torch.uint8, device=w.device)
         with torch.cuda.device(w.device):
-            _lib.check(lib.mas_conv_bx_pack(w.data_ptr(), M, K, kh, 0, wp.data_ptr(), _stream(w)), "mas_conv_bx_pack")
+            _lib.check(lib.mas_conv_bx_pack(w.data_ptr(), None, M, K, kh, 0, wp.data_ptr(), _stream(w)), "mas_conv_bx_pack")
         cache = conv._mas_conv_bx_pack = (key, wp)
     return cache[1]
+
+
+def _conv_bx_folded(conv, bn):
+    """(weight image with the inference BatchNorm's scale folded into its rows, shift [Cout]) for mas_conv_bx_fwd_dual, cached on the
+    convolution until a parameter or running statistic changes."""
+    key = _versions((conv.weight, bn.weight, bn.bias, bn.running_mean, bn.running_var))
+    cache = getattr(conv, '_mas_conv_bx_folded', None)
+    if cache is None or cache[0] != key:
+        scale, shift = _bn_fold(bn)
+        cache = conv._mas_conv_bx_folded = (key, conv_bx_pack(conv.weight.detach(), 0, row_scale=scale), shift)
+    return cache[1], cache[2]
+
+
+def conv_bx_dual_supported(conv_a, xa, conv_b, xb):
+    """Two 1x1 stride-1 convolutions with the same output channels on inputs of the same plane (conv3 and a stride-1 downsample of a
+    Bottleneck), both shapes the split-bf16 kernel takes."""
+    for conv, x in ((conv_a, xa), (conv_b, xb)):
+        if conv.kernel_size != (1, 1) or conv.stride != (1, 1) or not conv_bx_supported(conv, x):
+            return False
+    return conv_a.out_channels == conv_b.out_channels and xa.shape[0] == xb.shape[0] and xa.shape[2:] == xb.shape[2:]
+
+
+def conv_bx_dual(conv_a, bn_a, xa, conv_b, bn_b, xb, relu=True):
+    """relu?(bn_a(conv_a(xa)) + bn_b(conv_b(xb))) in ONE kernel at inference (mas_conv_bx_fwd_dual): both BatchNorm scales folded into
+    the weight images, one accumulator set walks the channels of xa, then those of xb -- `out = relu(bn3(conv3(out)) + downsample(x))`
+    of models/segmentation/backbone/resnet.py:143-160 without writing the identity branch to memory."""
+    xa, xb = xa.contiguous(), xb.contiguous()
+    N, Ka, H, W = xa.shape
+    M = conv_a.out_channels
+    wa, sa = _conv_bx_folded(conv_a, bn_a)
+    wb, sb = _conv_bx_folded(conv_b, bn_b)
+    shift = (sa.double() + sb.double()).float()
+    y = torch.empty((N, M, H, W), dtype=torch.float32, device=xa.device)
+    with torch.cuda.device(xa.device):
+        _lib.check(_lib.load().mas_conv_bx_fwd_dual(xa.data_ptr(), wa.data_ptr(), Ka, xb.data_ptr(), wb.data_ptr(), xb.shape[1], N, H, W, M,
+                                                    shift.data_ptr(), int(relu), y.data_ptr(), _stream(xa)), "mas_conv_bx_fwd_dual")
+    return y
 
 
 def conv_bx(conv, x, bn=None, relu=False, residual=None):
@@ -1331,10 +1368,16 @@ class _PackRegistry:
         _lib.check(lib.mas_conv_sk_pack_multi(self.table.data_ptr(), self.njobs, self.nblocks, stream), "mas_conv_sk_pack_multi")
 
 
-def conv_bx_pack(w, role=0):
-    """The split-bf16 weight image of mas_conv_bx_pack for one role (0 forward, 1 input gradient at stride 1)."""
+def conv_bx_pack(w, role=0, row_scale=None):
+    """The split-bf16 weight image of mas_conv_bx_pack for one role (0 forward, 1 input gradient at stride 1); ``row_scale`` [Cout]
+    (role 0): every output channel's weights multiplied by its entry before the split (a folded BatchNorm scale)."""
     _need(w, "w", torch.float32)
     w = w.contiguous()
+    if row_scale is not None:
+        _need(row_scale, "row_scale", torch.float32)
+        if row_scale.numel() != w.shape[0] or role != 0:
+            raise ValueError("row_scale: %d entries for %d output channels (role %d)" % (row_scale.numel(), w.shape[0], role))
+        row_scale = row_scale.contiguous()
     M, K, kh, _ = w.shape
     lib = _lib.load()
     nbytes = lib.mas_conv_bx_packed_bytes(kh, K, M, int(role))
@@ -1342,7 +1385,7 @@ def conv_bx_pack(w, role=0):
         raise ValueError("mas_conv_bx_pack does not take a %dx%d weight %s" % (kh, kh, tuple(w.shape)))
     wp = torch.empty(nbytes, dtype=torch.uint8, device=w.device)
     with torch.cuda.device(w.device):
-        _lib.check(lib.mas_conv_bx_pack(w.data_ptr(), M, K, kh, int(role), wp.data_ptr(), _stream(w)), "mas_conv_bx_pack")
+        _lib.check(lib.mas_conv_bx_pack(w.data_ptr(), _opt(row_scale), M, K, kh, int(role), wp.data_ptr(), _stream(w)), "mas_conv_bx_pack")
     return wp
 
 

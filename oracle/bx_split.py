@@ -45,10 +45,13 @@ def bx_bm(ksize, M):
     return 128 if (ksize == 1 and M % 128 == 0) else 64
 
 
-def pack_image(w, role=0):
+def pack_image(w, role=0, row_scale=None):
     """uint16 image [M tile][chunk][term][k group][row][8] of mas_conv_bx_pack for weight w [Cout, Cin, k, k] (numpy f32).
-    role 0: rows = Cout, K = Cin; role 1 (input gradient): rows = Cin, K = Cout, taps mirrored."""
+    role 0: rows = Cout, K = Cin; role 1 (input gradient): rows = Cin, K = Cout, taps mirrored.  row_scale [Cout] (role 0): every
+    weight is multiplied by its output channel's entry (one f32 rounding) before the split."""
     w = np.asarray(w, dtype=np.float32)
+    if row_scale is not None:
+        w = (w * np.asarray(row_scale, dtype=np.float32).reshape(-1, 1, 1, 1)).astype(np.float32)
     Cout, Cin, ks, _ = w.shape
     taps = ks * ks
     wf = w.reshape(Cout, Cin, taps)

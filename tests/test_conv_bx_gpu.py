@@ -242,3 +242,34 @@ def test_weight_image_equals_the_numpy_restatement(shape, role):
     wt.mul_(0.5)                                            # ... and through ONE multi-job launch when a version counter moved
     img = ops.bx_packed_weight(wt, role)
     assert np.array_equal(img.cpu().numpy().view(np.uint16), bx_split.pack_image(w * np.float32(0.5), role))
+
+
+@pytest.mark.parametrize("Ca,Cb,Cout,N,H,W", [(64, 128, 256, 2, 24, 40), (512, 1024, 2048, 1, 12, 20), (48, 100, 192, 2, 9, 37)])
+def test_conv_bx_dual_matches_the_two_convolutions(Ca, Cb, Cout, N, H, W):
+    """mas_conv_bx_fwd_dual: relu(bn_a(conv_a(xa)) + bn_b(conv_b(xb))) -- conv3 + stride-1 downsample of a Bottleneck in one kernel,
+    both BatchNorm scales folded into the weight images -- against float64, and against the two-kernel form (downsample, then conv3
+    with the residual operand); the folded weight image against the numpy restatement bit for bit."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from mulactseg_amd import ops
+    from oracle import bx_split
+    torch.manual_seed(Ca + Cb + Cout)
+    conv_a, conv_b = nn.Conv2d(Ca, Cout, 1, bias=False).cuda(), nn.Conv2d(Cb, Cout, 1, bias=False).cuda()
+    bn_a, bn_b = nn.BatchNorm2d(Cout).cuda().eval(), nn.BatchNorm2d(Cout).cuda().eval()
+    with torch.no_grad():
+        for bn in (bn_a, bn_b):
+            bn.weight.uniform_(0.5, 1.5); bn.bias.normal_(); bn.running_mean.normal_(); bn.running_var.uniform_(0.5, 2.0)
+        xa, xb = torch.randn(N, Ca, H, W, device='cuda'), torch.randn(N, Cb, H, W, device='cuda')
+        assert ops.conv_bx_dual_supported(conv_a, xa, conv_b, xb)
+        ref = F.relu(bn_a.double()(conv_a.double()(xa.double())) + bn_b.double()(conv_b.double()(xb.double())))
+        for m in (conv_a, conv_b, bn_a, bn_b):
+            m.float()
+        y = ops.conv_bx_dual(conv_a, bn_a, xa, conv_b, bn_b, xb, True)
+        two = ops.conv_bx(conv_a, xa, bn_a, relu=True, residual=ops.conv_bx(conv_b, xb, bn_b, relu=False))
+        scale_a, _ = ops._bn_fold(bn_a)
+        img = ops.conv_bx_pack(conv_a.weight.detach(), 0, row_scale=scale_a).cpu().numpy().view(np.uint16)
+    assert np.array_equal(img, bx_split.pack_image(conv_a.weight.detach().cpu().numpy(), 0, row_scale=scale_a.cpu().numpy()))
+    sc = float(ref.abs().max())
+    err, err2 = float((y.double() - ref).abs().max()), float((two.double() - ref).abs().max())
+    assert err <= 2e-5 * sc, (err, sc)
+    assert err <= 2.0 * err2 + 2e-6 * sc, (err, err2)

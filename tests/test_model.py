@@ -90,6 +90,7 @@ def test_inference_forward_runs_on_this_packages_kernels_and_matches_the_cpu_mod
     took = paths['conv_bn_act']
     assert took.get('hip_mfma', 0) + took.get('hip_bx', 0) >= 55 and took.get('hip_stem', 0) == 1, paths
     assert took.get('hip_bx', 0) >= 40, paths           # the split-bf16 kernel (csrc/conv_bx.hip) takes every shape it supports
+    assert took.get('hip_bx_dual', 0) == 2, paths       # conv3 + stride-1 downsample of layer1.0 / layer4.0 as one kernel
     assert 'aten' not in paths.get('bn_act', {}) and 'aten' not in paths.get('upsample', {})
     assert float((out_full.cpu() - ref_full).abs().max()) < 1e-4
     assert float((out_q.cpu() - ref_q).abs().max()) < 1e-4
