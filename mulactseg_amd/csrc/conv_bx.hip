@@ -25,6 +25,9 @@
 // A workgroup is 4 waves, a wave owns 64 x 64 of the tile (2 x 2 MFMA tiles: 64 accumulator registers); chunk t + 1 travels
 // global -> registers in front of the MFMAs of chunk t and registers -> (split) -> LDS behind them; two workgroups per CU
 // cover each other's staging.  Epilogue as conv_mfma.hip: y * scale[m] + shift[m] (+ residual) (ReLU), NCHW stores.
+// Dual form (mas_conv_bx_fwd_dual, 1x1 stride 1): the chunks of a second input with its own weight image follow those of the
+// first into the same accumulators -- conv3 + stride-1 downsample of a Bottleneck with both BatchNorm scales folded into the
+// weight rows at pack time (row_scale).
 #include <type_traits>
 
 #include "common.h"
