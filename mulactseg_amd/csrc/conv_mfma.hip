@@ -363,7 +363,9 @@ extern "C" int mas_conv_fwd(const float* x, const float* wt, int N, int Cin, int
     }
     if (stride == 2) {
         if (dil != 1) return MAS_ERR_RANGE;
-        return big_m ? launch<9, 8, 128, 128, 20, false>(p, N, st) : launch<9, 8, 64, 128, 20, false>(p, N, st);
+        // (always the 64-row tile: with 20 staging registers the 128-row form needs 256 VGPRs and spills 35 of them inside its loop --
+        //  428 vs 446 us for 128 -> 128 at 256 x 512, 394 vs 405 us for 256 -> 256 at 128 x 256)
+        return launch<9, 8, 64, 128, 20, false>(p, N, st);
     }
     if (big_m) return launch<9, 8, 128, 128, 9, false>(p, N, st);
     return (dil == 1 && wide_n) ? launch<9, 8, 64, 256, 12, false>(p, N, st) : launch<9, 8, 64, 128, 12, false>(p, N, st);
