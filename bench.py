@@ -241,6 +241,13 @@ def pool_round_bench(args, dev, rank, world, with_model):
     active.wait_for_writes()        # (the selection pickle is written by a background thread, off the round's critical path)
     t_write = time.perf_counter() - t1
     dt = max_over_ranks(t1 - t0, dev)
+    # what follows the round in the reference loop (train_AL.py:69): the datalist pickle of all four lists.  The pool / label id
+    # lists are held as arrays until somebody reads them (dataloader/region_active_dataset.py:LazySuppix); this call reads all of
+    # them, so the Python lists the round did not build are built HERE -- reported beside the round, not hidden in it.
+    pending = getattr(pool.suppix, 'pending', lambda: 0)()
+    t2 = time.perf_counter()
+    active.dump_datalist()
+    t_dump = time.perf_counter() - t2
     n_sel = sum(len(v) for v in labels.suppix.values())
     return {"seconds": dt, "superpixels_per_s": POOL_IMAGES * S / dt, "regions_selected": n_sel,
             "rank0_breakdown_s": {"scores (scan%s + exchanges + class weights + finalize)" % (" + model forward" if with_model else ""):
@@ -248,6 +255,8 @@ def pool_round_bench(args, dev, rank, world, with_model):
                                   "valid mask + cost table + K4 (keys, radix sort, walk)": marks['selected'] - marks['scored'],
                                   "RegionActiveDataset.expand_training_set (host; the selection pickle is written by a background thread)": t1 - marks['selected'],
                                   "selection pickle still being written after the round returned": t_write},
+            "after_the_round_s": {"RegionActiveDataset.dump_datalist (train_AL.py:69; rank 0; builds the %d id lists the round kept as arrays, "
+                                  "pickles 6.09 M ids)" % pending: t_dump},
             "images_per_rank": plan.n_local}
 
 

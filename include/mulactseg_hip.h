@@ -9,7 +9,8 @@
  *   - every launch goes to `stream` (a hipStream_t passed as void*; NULL = the null stream);
  *   - return value: 0 = OK, > 0 = hipError_t of the failed launch, < 0 = argument error
  *     (mas_error_string() explains); never throws;
- *   - thread-safe when each host thread uses its own stream and buffers; no global state.
+ *   - thread-safe when each host thread uses its own stream and buffers; no global mode state (per-call option structs / flag
+ *     arguments carry every A/B switch).
  *
  * The reference (sehyun03/MulActSeg) is pure Python over PyTorch + torch_scatter; each entry point
  * below names the reference code (file:line, relative to the reference root) it replaces.  The
@@ -45,6 +46,13 @@ extern "C" {
 #define MAS_PROB_FRAC_BITS 23
 #define MAS_LOSS_FRAC_BITS 32
 
+/* The version of THIS header.  Any change of an exported signature or of the meaning of an argument bumps it; a binding compares
+ * mas_abi_version() of the library it loaded with the MAS_ABI_VERSION it was written against and refuses a mismatch
+ * (mulactseg_amd/_lib.py:load does).  History: 1 = rounds 1-4 (the round-4 additions -- mas_sk_opts, the split-bf16 entry points --
+ * should have bumped it and did not); 5 = round 5 (mas_single_pass_accum_lowres_opt replaces the process-wide
+ * mas_single_pass_lowres_generic switch; mas_test_occupy moved to the test-support library; the BatchNorm-fused forms of
+ * mas_conv_bx_fwd). */
+#define MAS_ABI_VERSION 5
 int mas_abi_version(void);
 const char* mas_error_string(int code);
 
@@ -256,8 +264,11 @@ int mas_single_pass_accum(const float* z, const void* spx, int spx_dtype, int B,
  * C in {19, 20, 21}; H / h and W / w >= ~3.8 (MAS_ERR_RANGE otherwise). */
 int mas_single_pass_accum_lowres(const float* zq, int h, int w, const void* spx, int spx_dtype, int B, int C, int H, int W, int S,
                                  float invT, uint64_t* prob_sum, uint64_t* class_sum, uint32_t* hist, void* stream);
-/* tests / A-B measurements: 1 = keep the generic tap reads at the exact x4 ratio too (bit-identical results); returns the previous setting */
-int mas_single_pass_lowres_generic(int on);
+/* the same call with per-call option bits (tests / A-B measurements; results are bit-identical with every combination):
+ * MAS_LOWRES_GENERIC = keep the generic tap reads at the exact x4 ratio too.  flags = 0 is mas_single_pass_accum_lowres. */
+#define MAS_LOWRES_GENERIC 1u
+int mas_single_pass_accum_lowres_opt(const float* zq, int h, int w, const void* spx, int spx_dtype, int B, int C, int H, int W, int S,
+                                     float invT, uint64_t* prob_sum, uint64_t* class_sum, uint32_t* hist, unsigned flags, void* stream);
 
 /* score[r] = floor(((sum_c class_sum[r,c] * w31[c]) >> 31) / n_r) * 2^-40, w31[c] = floor(cls_weight[c] * 2^31)
  * (exact integer arithmetic); dominant class, ban and optional outputs as mas_region_finalize.
@@ -530,9 +541,6 @@ int mas_conv_sk_stats(const float* x, const float* wp, int N, int Cin, int H, in
 int mas_conv_sk_dgrad_s2(const float* dy, const float* wp, int N, int Cin, int H, int W, int Cout, int sub, const float* scale,
                          const float* shift, const float* residual, int relu, float* dx, void* workspace, size_t workspace_bytes,
                          unsigned epoch, const mas_sk_opts* opts, void* stream);
-/* test-only: `blocks` workgroups of 256 threads with `lds_bytes` of LDS each that do nothing but wait `ticks` of the 100 MHz wall
- * clock (bounded: every wave leaves after that) -- a CU-hogging neighbour for the co-residency tests of the stream-K hand-off. */
-int mas_test_occupy(int blocks, int lds_bytes, unsigned long long ticks, void* stream);
 
 /* Weight gradient of a dense convolution on the f32 matrix cores (csrc/conv_wgrad.hip), NCHW operands as autograd holds them:
  *   dw[m,c,r,s] = sum_{n,oy,ox} dy[n,m,oy,ox] * x[n,c, oy*stride + r*dil - pad, ox*stride + s*dil - pad],  pad = dil (ksize 3) / 0 (ksize 1)

@@ -18,6 +18,8 @@ ACC_WORDS = 8
 GRAD_FRAC = 44
 
 SK_DMA, SK_NOSPLIT = 1, 2
+LOWRES_GENERIC = 1
+ABI_VERSION = 5        # MAS_ABI_VERSION of include/mulactseg_hip.h this table was written against (load() refuses any other library)
 
 _c = ctypes
 _vp, _i, _f, _i64, _d = _c.c_void_p, _c.c_int, _c.c_float, _c.c_int64, _c.c_double
@@ -46,7 +48,7 @@ SIGNATURES = {
     "mas_logits_iou_counts": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i64, _vp, _vp]),
     "mas_single_pass_accum": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _f, _vp, _vp, _vp, _vp]),
     "mas_single_pass_accum_lowres": (_i, [_vp, _i, _i, _vp, _i, _i, _i, _i, _i, _i, _f, _vp, _vp, _vp, _vp]),
-    "mas_single_pass_lowres_generic": (_i, [_i]),
+    "mas_single_pass_accum_lowres_opt": (_i, [_vp, _i, _i, _vp, _i, _i, _i, _i, _i, _i, _f, _vp, _vp, _vp, _c.c_uint, _vp]),
     "mas_class_weight": (_i, [_vp, _i, _i, _i64, _i, _i, _d, _vp, _vp, _vp, _vp]),
     "mas_region_finalize_weighted": (_i, [_vp, _vp, _i64, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp]),
     "mas_stage2_gather_protos": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _i, _vp, _vp]),
@@ -98,7 +100,6 @@ SIGNATURES = {
     "mas_conv_sk_stats_slots": (_i, [_i, _i, _i, _i, _i, _i, _i, _i, _c.c_uint]),
     "mas_conv_sk_stats": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _c.c_size_t, _c.c_uint, _vp, _vp]),
     "mas_conv_sk_dgrad_s2": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _i, _vp, _vp, _c.c_size_t, _c.c_uint, _vp, _vp]),
-    "mas_test_occupy": (_i, [_i, _i, _c.c_ulonglong, _vp]),
     "mas_conv_wgrad_workspace_bytes": (_c.c_size_t, [_i, _i, _i, _i, _i, _i, _i, _i]),
     "mas_conv_wgrad_plan": (_i, [_i, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "mas_conv_wgrad": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _c.c_size_t, _vp]),
@@ -139,6 +140,17 @@ def load():
             "libmulactseg_hip.so is not built (%s). Run `python -c 'import __graft_entry__ as g; g.build()'` "
             "or `make -C mulactseg_amd/csrc`. There is no CPU fallback." % LIB_PATH)
     lib = ctypes.CDLL(LIB_PATH)
+    # the version first: a library built from another header (a stale variant named by MAS_LIB, tools/build_variant.sh) may export
+    # every symbol of the table with OTHER argument lists -- ctypes would bind them without complaint
+    try:
+        lib.mas_abi_version.restype = ctypes.c_int
+        lib.mas_abi_version.argtypes = []
+        got = int(lib.mas_abi_version())
+    except AttributeError:
+        got = None
+    if got != ABI_VERSION:
+        raise MulActSegHipError("%s reports ABI version %s, this package binds version %d (include/mulactseg_hip.h MAS_ABI_VERSION): "
+                                "rebuild it with `make -C mulactseg_amd/csrc`" % (LIB_PATH, got, ABI_VERSION))
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)      # AttributeError if the .so does not export a declared symbol
         fn.restype = res

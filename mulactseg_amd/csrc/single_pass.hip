@@ -630,11 +630,9 @@ int launch(const float* z, const void* spx, int B, int C, int H, int W, int S, f
     return mas_launch_status();
 }
 
-bool g_low_generic = false;     // tests / A-B measurements: keep the generic tap reads at the x4 ratio (mas_single_pass_lowres_generic)
-
 template <int CT, bool EXACT, typename IdT>
 int launch_low(const float* zq, int h, int w, const void* spx, int B, int C, int H, int W, int S, float invT, mas_u64* prob_sum,
-               mas_u64* class_sum, unsigned* hist, hipStream_t st) {
+               mas_u64* class_sum, unsigned* hist, unsigned flags, hipStream_t st) {
     const int tiles_x = (W + kTileW - 1) / kTileW;
     const int tiles_y = (H + kTileH - 1) / kTileH;
     const long long nblk = (long long)B * tiles_x * tiles_y;
@@ -652,7 +650,7 @@ int launch_low(const float* zq, int h, int w, const void* spx, int B, int C, int
     int dev = 0;
     if (hipError_t e = hipGetDevice(&dev); e != hipSuccess) return (int)e;
     const bool cached = dev >= 0 && dev < 64;
-    if (vec && W == 4 * w && !g_low_generic) {       // the model's own ratio: one period of the x4 pattern per lane
+    if (vec && W == 4 * w && !(flags & MAS_LOWRES_GENERIC)) {       // the model's own ratio: one period of the x4 pattern per lane
         if (!cached || !attr_x4[dev]) {
             const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_single_pass<CT, EXACT, IdT, true, true, true>),
                                                      hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
@@ -685,11 +683,11 @@ int launch_low(const float* zq, int h, int w, const void* spx, int B, int C, int
 
 template <int CT, bool EXACT>
 int dispatch_low_ids(const float* zq, int h, int w, const void* spx, int spx_dtype, int B, int C, int H, int W, int S, float invT,
-                     mas_u64* prob_sum, mas_u64* class_sum, unsigned* hist, hipStream_t st) {
+                     mas_u64* prob_sum, mas_u64* class_sum, unsigned* hist, unsigned flags, hipStream_t st) {
     switch (spx_dtype) {
-        case MAS_ID_I64: return launch_low<CT, EXACT, long long>(zq, h, w, spx, B, C, H, W, S, invT, prob_sum, class_sum, hist, st);
-        case MAS_ID_I32: return launch_low<CT, EXACT, int>(zq, h, w, spx, B, C, H, W, S, invT, prob_sum, class_sum, hist, st);
-        case MAS_ID_U16: return launch_low<CT, EXACT, unsigned short>(zq, h, w, spx, B, C, H, W, S, invT, prob_sum, class_sum, hist, st);
+        case MAS_ID_I64: return launch_low<CT, EXACT, long long>(zq, h, w, spx, B, C, H, W, S, invT, prob_sum, class_sum, hist, flags, st);
+        case MAS_ID_I32: return launch_low<CT, EXACT, int>(zq, h, w, spx, B, C, H, W, S, invT, prob_sum, class_sum, hist, flags, st);
+        case MAS_ID_U16: return launch_low<CT, EXACT, unsigned short>(zq, h, w, spx, B, C, H, W, S, invT, prob_sum, class_sum, hist, flags, st);
         default: return MAS_ERR_DTYPE;
     }
 }
@@ -723,27 +721,25 @@ extern "C" int mas_single_pass_accum(const float* z, const void* spx, int spx_dt
     }
 }
 
-extern "C" int mas_single_pass_accum_lowres(const float* zq, int h, int w, const void* spx, int spx_dtype, int B, int C, int H, int W, int S,
-                                            float invT, uint64_t* prob_sum, uint64_t* class_sum, uint32_t* hist, void* stream) {
+extern "C" int mas_single_pass_accum_lowres_opt(const float* zq, int h, int w, const void* spx, int spx_dtype, int B, int C, int H, int W, int S,
+                                                float invT, uint64_t* prob_sum, uint64_t* class_sum, uint32_t* hist, unsigned flags, void* stream) {
     if (!zq || !spx || !prob_sum || !class_sum || !hist) return MAS_ERR_NULL;
     if (B <= 0 || H <= 0 || W <= 0 || S <= 0 || h <= 0 || w <= 0 || h > H || w > W || (long long)H * W > (1LL << 23)) return MAS_ERR_SHAPE;
+    if (flags & ~MAS_LOWRES_GENERIC) return MAS_ERR_RANGE;
     hipStream_t st = static_cast<hipStream_t>(stream);
     mas_u64* ps = reinterpret_cast<mas_u64*>(prob_sum);
     mas_u64* cs = reinterpret_cast<mas_u64*>(class_sum);
     switch (C) {                 // (the generic 32-channel footprint would not fit the LDS budget: the Cityscapes / VOC channel counts only)
-        case 19: return dispatch_low_ids<19, true>(zq, h, w, spx, spx_dtype, B, C, H, W, S, invT, ps, cs, hist, st);
-        case 20: return dispatch_low_ids<20, true>(zq, h, w, spx, spx_dtype, B, C, H, W, S, invT, ps, cs, hist, st);
-        case 21: return dispatch_low_ids<21, true>(zq, h, w, spx, spx_dtype, B, C, H, W, S, invT, ps, cs, hist, st);
+        case 19: return dispatch_low_ids<19, true>(zq, h, w, spx, spx_dtype, B, C, H, W, S, invT, ps, cs, hist, flags, st);
+        case 20: return dispatch_low_ids<20, true>(zq, h, w, spx, spx_dtype, B, C, H, W, S, invT, ps, cs, hist, flags, st);
+        case 21: return dispatch_low_ids<21, true>(zq, h, w, spx, spx_dtype, B, C, H, W, S, invT, ps, cs, hist, flags, st);
         default: return MAS_ERR_CLASSES;
     }
 }
 
-/* tests and A/B measurements: 1 = the quarter-resolution scan keeps its generic tap reads also at the exact x4 ratio (results are
- * bit-identical either way); returns the previous setting */
-extern "C" int mas_single_pass_lowres_generic(int on) {
-    const int old = g_low_generic ? 1 : 0;
-    if (on == 0 || on == 1) g_low_generic = on != 0;
-    return old;
+extern "C" int mas_single_pass_accum_lowres(const float* zq, int h, int w, const void* spx, int spx_dtype, int B, int C, int H, int W, int S,
+                                            float invT, uint64_t* prob_sum, uint64_t* class_sum, uint32_t* hist, void* stream) {
+    return mas_single_pass_accum_lowres_opt(zq, h, w, spx, spx_dtype, B, C, H, W, S, invT, prob_sum, class_sum, hist, 0u, stream);
 }
 
 extern "C" int mas_region_finalize_weighted(const uint64_t* class_sum, const uint32_t* hist, int64_t n_regions, int C,

@@ -57,6 +57,144 @@ class ConsumedPrefix(collections.abc.Sequence):
         return (float(self.scores[k]), ','.join(self.keys[int(self.img[k])]), int(self.ids[k]))
 
 
+def _atomic_pickle(fname, obj):
+    """Write to a temporary file beside the target and rename it into place: readers never see a torn pickle; a failed write leaves
+    no temporary behind."""
+    tmp = "%s.tmp.%d" % (fname, os.getpid())
+    try:
+        with open(tmp, "wb") as f:
+            pickle.dump(obj, f)
+        os.replace(tmp, fname)
+    except BaseException:
+        try:
+            os.unlink(tmp)
+        except OSError:
+            pass
+        raise
+
+
+class _Writer:
+    """The selection pickle, written by a background thread (it is off the round's critical path: nothing reads it before the next
+    ``wait_for_writes``).  ``join`` re-raises what the write raised."""
+
+    def __init__(self, fname, make):
+        self.error = None
+
+        def run():
+            try:
+                _atomic_pickle(fname, make())
+            except BaseException as e:       # noqa: B902 -- handed to the caller of join()
+                self.error = e
+        self.thread = threading.Thread(target=run)
+        self.thread.start()
+
+    def join(self):
+        self.thread.join()
+        if self.error is not None:
+            raise self.error
+
+
+class _FromTable:
+    """A pool list that nobody has looked at since it was last known to be in ascending order: it IS the set bits of its row of
+    the valid table (``RegionActiveDataset._valid``, edited in place by every round), so it is built when it is asked for."""
+    __slots__ = ("table", "row")
+
+    def __init__(self, table, row):
+        self.table, self.row = table, row
+
+    def build(self):
+        return np.flatnonzero(self.table[self.row]).tolist()
+
+
+class _Appended:
+    """A label list = what it was (a real list, or nothing) + the id runs the rounds since then selected, in selection order."""
+    __slots__ = ("base", "runs")
+
+    def __init__(self, base=None):
+        self.base, self.runs = base, []
+
+    def build(self):
+        out = self.base if self.base is not None else []
+        for r in self.runs:
+            out.extend(r.tolist())
+        return out
+
+
+class LazySuppix(dict):
+    """``{superpixel path: list of ids}`` -- the reference's ``suppix`` dictionaries (``dataloader/region_active_dataset.py:16-80``
+    edits them entry by entry) -- whose lists are BUILT ON FIRST ACCESS from the arrays ``RegionActiveDataset`` keeps.  A 100 000-click
+    Cityscapes round touches all 2 975 lists; the training loader of the next round reads the lists of the pictures it samples, the
+    next acquisition round reads none (it uses the valid table), ``dump_datalist`` reads all of them once.  Everything a ``dict``
+    offers works and returns real lists (``[]``, ``get``, ``pop``, ``items``, ``values``, ``==``, ``copy``, pickling -- as a plain
+    ``dict`` of lists, the reference's ``datalist_RR.pkl`` layout); a list that has been handed out is a real list from then on, and
+    later rounds edit it in place as the reference does."""
+
+    def _raw(self, key):
+        return dict.__getitem__(self, key)
+
+    def _real(self, key, v):
+        if isinstance(v, (_FromTable, _Appended)):
+            v = v.build()
+            dict.__setitem__(self, key, v)
+        return v
+
+    def __getitem__(self, key):
+        return self._real(key, dict.__getitem__(self, key))
+
+    def get(self, key, default=None):
+        return self[key] if key in self else default
+
+    def pop(self, key, *default):
+        if key in self:
+            v = self[key]
+            dict.__delitem__(self, key)
+            return v
+        if default:
+            return default[0]
+        raise KeyError(key)
+
+    def popitem(self):
+        k = next(reversed(self))
+        return k, self.pop(k)
+
+    def setdefault(self, key, default=None):
+        if key not in self:
+            dict.__setitem__(self, key, default)
+        return self[key]
+
+    def materialize(self):
+        for k in dict.keys(self):
+            self[k]
+        return self
+
+    def values(self):
+        return dict.values(self.materialize())
+
+    def items(self):
+        return dict.items(self.materialize())
+
+    def copy(self):
+        return dict(self.items())
+
+    def __eq__(self, other):
+        return dict.__eq__(self.materialize(), other.materialize() if isinstance(other, LazySuppix) else other)
+
+    def __ne__(self, other):
+        return not self.__eq__(other)
+
+    __hash__ = None
+
+    def __reduce_ex__(self, protocol):
+        return (dict, (), None, None, iter(self.items()))       # pickles (and deep-copies) as a plain dict of lists
+
+    def __repr__(self):
+        return dict.__repr__(self.materialize())
+
+    def pending(self):
+        """How many lists have not been built (tests, the bench's breakdown)."""
+        return sum(1 for v in dict.values(self) if isinstance(v, (_FromTable, _Appended)))
+
+
 class RegionActiveDataset:
     def __init__(self, args, trg_pool_dataset, trg_label_dataset):
         self.args = args
@@ -110,14 +248,38 @@ class RegionActiveDataset:
         if self._valid is None or self._valid.shape[1] != nseg:
             init = getattr(pool, 'initial_valid_table', None)
             tab = init() if (init is not None and self._initial_ok) else None
+            canonical = tab is not None and bool(getattr(pool, 'suppix_ascending', False))
             if tab is None:
                 n_total = len(self.trg_label_dataset.id_to_index)
                 tab = np.zeros((n_total, nseg), dtype=np.uint8)
+                canonical = True
                 for key in pool.im_idx:
-                    tab[self._image_index(key[2]), pool.suppix[key[2]]] = 1
+                    ids = np.asarray(pool.suppix[key[2]], dtype=np.intp)
+                    tab[self._image_index(key[2]), ids] = 1
+                    # (ascending and duplicate-free -- how the reference builds its lists, np.unique, and removals keep it -- : the list
+                    #  is then exactly the set bits of its table row)
+                    canonical = canonical and (ids.size < 2 or bool((ids[1:] > ids[:-1]).all()))
             self._valid = tab
+            if canonical and os.environ.get("MAS_LAZY_LISTS", "on") != "off":
+                self._install_lazy_lists()
         rows = np.fromiter((self._image_index(key[2]) for key in pool.im_idx), dtype=np.intp, count=len(pool.im_idx))
         return self._valid[rows]
+
+    def _install_lazy_lists(self):
+        """Swap ``pool.suppix`` / ``label.suppix`` for ``LazySuppix`` mappings: every pool list (just checked to be ascending) becomes
+        "the set bits of its table row, built when asked for", label lists keep what they hold and take appended id runs.  The
+        array path of ``expand_training_set`` then edits the table and appends arrays; Python lists appear where somebody reads them."""
+        pool, label = self.trg_pool_dataset, self.trg_label_dataset
+        if not isinstance(pool.suppix, dict) or not isinstance(label.suppix, dict):
+            return
+        lazy = LazySuppix()
+        for key in pool.im_idx:
+            dict.__setitem__(lazy, key[2], _FromTable(self._valid, self._image_index(key[2])))
+        if len(lazy) != len(pool.suppix):       # (entries without a picture in im_idx: leave the dictionaries alone)
+            return
+        pool.suppix = lazy
+        if not isinstance(label.suppix, LazySuppix):
+            label.suppix = LazySuppix(label.suppix)
 
     # -- selection ------------------------------------------------------------------------------
     def expand_training_set(self, sample_region, selection_count, selection_method):
@@ -168,9 +330,9 @@ class RegionActiveDataset:
             cost += int(cost_tab[row, suppix_id]) if cost_tab is not None else 1
             n_sup += 1
             if cost > selection_count:
-                fname = '%s_selection_%02d.pkl' % (selection_method, self.selection_iter)
-                with open(os.path.join(self.args.model_save_dir, fname), "wb") as f:
-                    pickle.dump(sample_region[:idx + 1], f)
+                if self._writes_files():
+                    fname = '%s_selection_%02d.pkl' % (selection_method, self.selection_iter)
+                    _atomic_pickle(os.path.join(self.args.model_save_dir, fname), sample_region[:idx + 1])
                 break
         emptied = set()
         for key, row, gone, present in leaving.values():
@@ -196,10 +358,21 @@ class RegionActiveDataset:
 
     # -- the same, from arrays ------------------------------------------------------------------
     def wait_for_writes(self):
-        """Join the background write of the last selection pickle (called before anything that reads or rewrites the files)."""
+        """Join the background write of the last selection pickle (called before anything that reads or rewrites the files); an
+        exception the write raised (disk full, missing directory, pickling error) is raised HERE -- where the reference's
+        synchronous ``pickle.dump`` (:67-68) would have raised it one call earlier."""
         w, self._writer = self._writer, None
         if w is not None:
             w.join()
+
+    @staticmethod
+    def _writes_files():
+        """Every rank of a data-parallel run holds the same prefix and lists: rank 0 writes them."""
+        try:
+            import torch.distributed as dist
+            return not (dist.is_available() and dist.is_initialized()) or dist.get_rank() == 0
+        except ImportError:
+            return True
 
     def _expand_prefix(self, sr, selection_count, selection_method):
         """``expand_training_set`` for a ``ConsumedPrefix`` with the valid table in place: the budget cut is one ``cumsum``, the table /
@@ -230,46 +403,69 @@ class RegionActiveDataset:
         flat = rows * S + ids
         if not (self._valid[rows, ids] == 1).all() or np.unique(flat).size != n:
             return None                                     # an id that is not in the pool (or twice in the prefix): list.remove would raise
-        if over.size:
+        if over.size and self._writes_files():
             fname = os.path.join(self.args.model_save_dir, '%s_selection_%02d.pkl' % (selection_method, self.selection_iter))
-
-            def write(sr=sr, n=n, fname=fname):
-                # (every rank of a data-parallel run holds the same prefix and usually the same directory: each writes its own
-                #  temporary file and renames it into place -- atomic, so readers never see a torn pickle whoever wins)
-                tmp = "%s.tmp.%d" % (fname, os.getpid())
-                with open(tmp, "wb") as f:
-                    pickle.dump(sr.tuples(n), f)
-                os.replace(tmp, fname)
-            self._writer = threading.Thread(target=write)
-            self._writer.start()
-        # where every leaving id sits in its pool list, for all entries at once: in a list that holds its ids in ascending order (how
-        # the reference builds them, np.unique; removals keep it) that is the number of listed ids below it -- a row-wise cumsum of
-        # the touched rows of the table as it was BEFORE this call.  The positions are verified per picture before anything is deleted.
-        urows, ridx = np.unique(rows, return_inverse=True)
-        before = self._valid[urows].astype(np.int32)        # (this call's removals are still in: the table is updated below)
-        pos = np.cumsum(before, axis=1, dtype=np.int32)[ridx, ids] - 1
-        self._valid[rows, ids] = 0
-        if hasattr(pool, 'isselected'):
-            pool.isselected[rows, ids] = 1
+            self._writer = _Writer(fname, lambda sr=sr, n=n: sr.tuples(n))
+        psup, lsup = pool.suppix, label.suppix
+        plazy, llazy = isinstance(psup, LazySuppix), isinstance(lsup, LazySuppix)
+        # Pool lists that exist as Python lists are edited in place, as the reference does: where every leaving id sits in its list,
+        # for all entries at once -- in a list that holds its ids in ascending order (how the reference builds them, np.unique;
+        # removals keep it) that is the number of listed ids below it, a row-wise cumsum of the touched rows of the table as it was
+        # BEFORE this call; the positions are verified per picture before anything is deleted.  Lists nobody has asked for since the
+        # table was built (LazySuppix) do not exist: their rows of the table are all there is to edit.
         order = np.argsort(img, kind='stable')              # entries of one picture together, in walk order
-        simg, sids, spos = img[order], ids[order], pos[order]
+        simg, sids = img[order], ids[order]
         starts = np.concatenate(([0], np.flatnonzero(np.diff(simg)) + 1))
         ends = np.concatenate((starts[1:], [n]))
         first_seen = order[starts]                          # (stable sort: the first entry of a group is its first appearance)
+        gkeys = [sr.keys[p] for p in simg[starts].tolist()]
+        if plazy:
+            real = np.fromiter((not isinstance(psup._raw(k[2]), _FromTable) for k in gkeys), dtype=bool, count=len(gkeys))
+        else:
+            real = np.ones(len(gkeys), dtype=bool)
+        spos = None
+        if real.any():
+            grow = row_of[simg[starts]]                     # table row of every group
+            need = np.flatnonzero(real)
+            sub = np.cumsum(self._valid[grow[need]], axis=1, dtype=np.int16 if S < 32768 else np.int32)      # (before this call's removals: the table is updated below)
+            slot = np.full(len(gkeys), -1, dtype=np.intp)
+            slot[need] = np.arange(need.size)
+            gidx = np.repeat(np.arange(len(gkeys)), ends - starts)
+            spos = np.where(slot[gidx] >= 0, sub[np.maximum(slot[gidx], 0), sids].astype(np.intp) - 1, -1)
+        self._valid[rows, ids] = 0
+        if hasattr(pool, 'isselected'):
+            pool.isselected[rows, ids] = 1
+        left = self._valid[row_of[simg[starts]]].sum(axis=1, dtype=np.int64)      # ids that stay listed, per touched picture
         listed = {tuple(k) for k in label.im_idx}
         emptied = set()
+        starts_l, ends_l, left_l, real_l = starts.tolist(), ends.tolist(), left.tolist(), real.tolist()
         for j in np.argsort(first_seen).tolist():
-            a, b = int(starts[j]), int(ends[j])
-            key = sr.keys[int(simg[a])]
+            a, b = starts_l[j], ends_l[j]
+            key = gkeys[j]
             spx_path = key[2]
-            sel = sids[a:b].tolist()
             if tuple(key) not in listed:
                 listed.add(tuple(key))
                 label.im_idx.append(key)
-                label.suppix[spx_path] = []
-            label.suppix[spx_path].extend(sel)
-            lst = pool.suppix[spx_path]
+                if llazy:
+                    dict.__setitem__(lsup, spx_path, _Appended())
+                else:
+                    lsup[spx_path] = []
+            if llazy:
+                cur = lsup._raw(spx_path)
+                if isinstance(cur, _Appended):
+                    cur.runs.append(sids[a:b])
+                else:
+                    cur.extend(sids[a:b].tolist())
+            else:
+                lsup[spx_path].extend(sids[a:b].tolist())
+            if not real_l[j]:
+                if left_l[j] == 0:
+                    dict.__delitem__(psup, spx_path)
+                    emptied.add(tuple(key))
+                continue
+            lst = psup._raw(spx_path) if plazy else psup[spx_path]
             if b - a < len(lst):
+                sel = sids[a:b].tolist()
                 ps = spos[a:b].tolist()
                 m = len(lst)
                 if all(q < m and lst[q] == i for q, i in zip(ps, sel)):     # verified positions: deleting them is right whatever the rest
@@ -277,9 +473,9 @@ class RegionActiveDataset:
                         del lst[q]
                 else:                                                        # a list in another order: rewrite it, order preserved
                     gone = set(sel)
-                    pool.suppix[spx_path] = [i for i in lst if i not in gone]
+                    psup[spx_path] = [i for i in lst if i not in gone]
             else:
-                pool.suppix.pop(spx_path)
+                psup.pop(spx_path)
                 emptied.add(tuple(key))
         if emptied:
             pool.im_idx[:] = [k for k in pool.im_idx if tuple(k) not in emptied]

@@ -398,9 +398,10 @@ def single_pass_accum(z, spx, S, invT, prob_sum=None, class_sum=None, hist=None)
     return prob_sum, class_sum, hist
 
 
-def single_pass_accum_lowres(zq, size, spx, S, invT, prob_sum=None, class_sum=None, hist=None):
+def single_pass_accum_lowres(zq, size, spx, S, invT, prob_sum=None, class_sum=None, hist=None, generic=False):
     """``single_pass_accum`` of ``F.interpolate(zq, size, 'bilinear', align_corners=False)`` without materialising it: ``zq``
-    [B,C,h,w] quarter-resolution logits, ``spx`` [B,H,W]; same outputs, bit for bit."""
+    [B,C,h,w] quarter-resolution logits, ``spx`` [B,H,W]; same outputs, bit for bit.  ``generic`` (tests / A-B measurements): keep
+    the generic tap reads at the exact x4 ratio too (a per-call flag; the results are bit-identical either way)."""
     _need(zq, "zq", torch.float32)
     _need(spx, "spx")
     B, C, h, w = zq.shape
@@ -415,16 +416,11 @@ def single_pass_accum_lowres(zq, size, spx, S, invT, prob_sum=None, class_sum=No
     if hist is None:
         hist = torch.zeros((B, S, C), dtype=torch.int32, device=dev)
     with torch.cuda.device(dev):
-        _lib.check(_lib.load().mas_single_pass_accum_lowres(zq.data_ptr(), h, w, spx.data_ptr(), _id_code(spx), B, C, H, W, S, invT,
-                                                            prob_sum.data_ptr(), class_sum.data_ptr(), hist.data_ptr(), _stream(zq)),
-                   "mas_single_pass_accum_lowres")
+        _lib.check(_lib.load().mas_single_pass_accum_lowres_opt(zq.data_ptr(), h, w, spx.data_ptr(), _id_code(spx), B, C, H, W, S, invT,
+                                                                prob_sum.data_ptr(), class_sum.data_ptr(), hist.data_ptr(),
+                                                                _lib.LOWRES_GENERIC if generic else 0, _stream(zq)),
+                   "mas_single_pass_accum_lowres_opt")
     return prob_sum, class_sum, hist
-
-
-def single_pass_lowres_generic(on):
-    """Tests / A-B measurements: True = the quarter-resolution scan keeps its generic tap reads at the exact x4 ratio too (results are
-    bit-identical either way); returns the previous setting."""
-    return bool(_lib.load().mas_single_pass_lowres_generic(int(bool(on))))
 
 
 def region_finalize_weighted(class_sum, hist, w31, ban_class=-1, want_hist_i64=False):
@@ -1473,10 +1469,29 @@ def packed_weight(w, stride=1, dgrad=False):
 _SK_DEFAULT_FLAGS = [0]         # wrapper default of the per-call mas_sk_opts.flags (conv_sk_set_mode: A/B runs of the LDS-DMA ring)
 
 
+def sk_split_default():
+    """Does a conv_sk call without explicit flags split tiles over workgroups (the stream-K hand-off)?  MAS_SK_SPLIT = auto
+    (default): yes in a single-GPU process, NO under torch.distributed with more than one rank -- the hand-off assumes that the
+    workgroups of a launch become resident together, which a neighbour holding CUs for seconds (an RCCL kernel of a wedged peer,
+    another tenant) can break; a finisher that gives up poisons its tile and the step aborts (trainer/base.py:raise_stream_k),
+    and one rank aborting while the others sit in the gradient all-reduce is a hang.  The whole-tile plan (SK_NOSPLIT) has no
+    hand-off and is exact; it costs the load balance of the few layers that still run on k_conv_sk.
+    on / off force either."""
+    mode = os.environ.get("MAS_SK_SPLIT", "auto")
+    if mode in ("on", "1"):
+        return True
+    if mode in ("off", "0"):
+        return False
+    import torch.distributed as dist
+    return not (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1)
+
+
 def _sk_opts(flags=None, spin_limit=0, stamps=None):
     """mas_sk_opts for one call (NULL when everything is the default)."""
     import ctypes
-    flags = _SK_DEFAULT_FLAGS[0] if flags is None else int(flags)
+    if flags is None:
+        flags = _SK_DEFAULT_FLAGS[0] | (0 if sk_split_default() else _lib.SK_NOSPLIT)
+    flags = int(flags)
     if not flags and not spin_limit and stamps is None:
         return None, flags
     o = _lib.SkOpts(flags, int(spin_limit), stamps.data_ptr() if stamps is not None else None)
@@ -1626,15 +1641,6 @@ def conv_sk_clear_error(dev=None):
 class StreamKGaveUp(RuntimeError):
     """A stream-K convolution gave up waiting for another workgroup of its launch: the step's activations / gradients are poisoned
     (NaN).  Seen only when the GPU is shared with something that keeps CUs busy for seconds."""
-
-
-def occupy_cus(blocks, lds_bytes, seconds, stream=None):
-    """Test-only neighbour kernel (mas_test_occupy): `blocks` workgroups that hold 256 threads + `lds_bytes` of LDS for `seconds`."""
-    st = torch.cuda.current_stream() if stream is None else stream
-    _lib.check(_lib.load().mas_test_occupy(int(blocks), int(lds_bytes), int(seconds * 1e8), st.cuda_stream), "mas_test_occupy")
-
-
-_SIDE_STREAMS = {}
 
 
 def _side_stream(dev):

@@ -95,6 +95,7 @@ class LogitSource(torch.nn.Module):
 
 class SyntheticPool(torch.utils.data.Dataset):
     device_resident = True
+    suppix_ascending = True      # every suppix list is built (and kept) in ascending id order: RegionActiveDataset may hold them as table rows
 
     def __init__(self, n_img, H, W, S, device, seed=7, duplicates=None, chunk=64, id_dtype=torch.int16, shard=None):
         """``duplicates``: {picture: picture it copies}.  ``shard`` = (lo, hi): only these pictures' maps are materialised

@@ -74,6 +74,7 @@ class ActiveTrainer(BaseTrainer):
             ok = not host[0]
             if ok:
                 loss.backward()
+                self.guard_optimizer_step()         # (device-side: a give-up in this step's passes skips the parameter update)
                 self.optimizer.step()
             if self.args.scheduler == 'poly':
                 self.scheduler.step()

@@ -84,6 +84,7 @@ class ActiveTrainer(active.ActiveTrainer):
             # pass are covered here, the last backward pass of a round by check_stream_k() at the end of train_impl
             handle = self._probe().submit([loss] + self.stream_k_flag())
             (loss * scale if scale != 1 else loss).backward()
+            self.guard_optimizer_step()             # (device-side: a give-up in this step's passes skips the parameter update)
             host = _HostProbe.read(handle)
             v = host[0]
             if len(host) > 1 and host[1] != 0:

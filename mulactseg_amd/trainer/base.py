@@ -141,19 +141,45 @@ class BaseTrainer(object):
 
     # -- the stream-K convolutions' error word (csrc/conv_sk.hip: a finisher that gave up waiting poisons its tile and says so) --
     def stream_k_flag(self):
-        """[] or [0-dim device tensor != 0 when a stream-K launch of this device has given up since the last clear]: no
-        synchronisation -- the trainers read it together with the loss."""
+        """[] or [0-dim device tensor != 0 when a stream-K launch of ANY rank's device has given up since the last clear]: no
+        host synchronisation -- the trainers read it together with the loss.  Under DDP the word is MAX-all-reduced, so every rank
+        sees the same flag at the same step and they raise together (one rank leaving while the others enter the gradient
+        all-reduce would hang them until the RCCL timeout)."""
         from .. import ops
+        if not ops.sk_split_default():              # whole-tile plan (the default under DDP): no hand-off, nothing can give up
+            return []
         words = ops.conv_sk_error_words(self.device)
-        return [] if words is None else [words.max()]
+        if words is None:
+            return []
+        flag = words.max().to(torch.int32)
+        if getattr(self, 'ddp', None) is not None:
+            import torch.distributed as dist
+            flag = flag.reshape(1)
+            dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+            flag = flag.reshape(())
+        return [flag]
+
+    def guard_optimizer_step(self):
+        """Between backward() and optimizer.step(): a give-up inside THIS step's forward or backward pass must not reach the
+        parameters.  The host does not wait for the backward pass (the flag travels to it with the NEXT step's loss), so the guard
+        is on the device: the fused AdamW kernel takes a `found_inf` scalar (the GradScaler protocol, torch/optim/adam.py) and leaves
+        parameters, moments and step counts untouched when it is non-zero.  No-op for optimizers without the fused kernel."""
+        opt = self.optimizer
+        fused = any(g.get('fused') for g in opt.param_groups)
+        flag = self.stream_k_flag() if fused else []
+        if flag:
+            opt.found_inf = (flag[0] != 0).to(torch.float32)
+        elif hasattr(opt, 'found_inf'):
+            del opt.found_inf
 
     def raise_stream_k(self):
         from .. import ops
         ops.conv_sk_clear_error(self.device)
         raise ops.StreamKGaveUp(
             "a stream-K convolution gave up waiting for a workgroup of its own launch (mas_conv_sk error word): the GPU is shared with "
-            "something that held its CUs for seconds; the activations / gradients of that step are poisoned (NaN) and the parameters "
-            "may be -- reload the last checkpoint")
+            "something that held its CUs for seconds; the activations / gradients of that step are poisoned (NaN).  The optimizer "
+            "update of that step was skipped on the device (guard_optimizer_step), BatchNorm running statistics of the layers behind "
+            "the poisoned tile are not: reload the last checkpoint, or run with MAS_SK_SPLIT=off (whole-tile plan, no hand-off)")
 
     def check_stream_k(self):
         """Synchronous form (end of a training round, tests)."""

@@ -165,3 +165,32 @@ class OracleLossOps:
         _, dz = exact.partial_loss_bwd(z.detach().numpy(), spx.numpy(), mask.numpy().astype(np.uint8), bits.numpy().view(np.uint32), g,
                                        acc.numpy().view(np.uint64), grad_out.numpy(), np.float32(invT), flags)
         return torch.from_numpy(dz)
+
+
+# ---- test-support library (tests/libmulactseg_test.so, built from mulactseg_amd/csrc/test_support.hip by build()) --------------
+_TEST_LIB = None
+
+
+def _test_lib():
+    """TEST INFRASTRUCTURE: the CU-hogging neighbour kernel lives in its own library, not in the product ABI."""
+    global _TEST_LIB
+    if _TEST_LIB is None:
+        import ctypes
+        import os
+        from mulactseg_amd import _lib
+        _lib.load()                                  # (torch's HIP runtime first: one runtime per process)
+        path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libmulactseg_test.so")
+        if not os.path.exists(path):
+            raise RuntimeError("%s is not built: run `make -C mulactseg_amd/csrc`" % path)
+        lib = ctypes.CDLL(path)
+        lib.mas_test_occupy.restype = ctypes.c_int
+        lib.mas_test_occupy.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_ulonglong, ctypes.c_void_p]
+        _TEST_LIB = lib
+    return _TEST_LIB
+
+
+def occupy_cus(blocks, lds_bytes, seconds, stream=None):
+    """`blocks` workgroups that hold 256 threads + `lds_bytes` of LDS for `seconds` (bounded: every wave leaves after that)."""
+    from mulactseg_amd import _lib
+    st = torch.cuda.current_stream() if stream is None else stream
+    _lib.check(_test_lib().mas_test_occupy(int(blocks), int(lds_bytes), int(seconds * 1e8), st.cuda_stream), "mas_test_occupy")

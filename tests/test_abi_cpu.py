@@ -35,7 +35,11 @@ def test_library_exports_every_declared_symbol():
     assert not missing, missing
     # and the ctypes table covers the header one to one
     assert sorted(_lib.SIGNATURES) == declared_symbols()
-    assert _lib.load().mas_abi_version() == 1
+    assert _lib.load().mas_abi_version() == _lib.ABI_VERSION
+    header = open(os.path.join(ROOT, "include", "mulactseg_hip.h")).read()
+    assert int(re.search(r"#define MAS_ABI_VERSION (\d+)", header).group(1)) == _lib.ABI_VERSION
+    # the test-support kernel is not part of the product ABI
+    assert not hasattr(lib, "mas_test_occupy") and os.path.exists(os.path.join(ROOT, "tests", "libmulactseg_test.so"))
     assert _lib.load().mas_error_string(-3).decode().startswith("class count")
 
 
@@ -46,3 +50,18 @@ def test_argument_errors_are_reported_without_touching_the_gpu():
     assert lib.mas_select_workspace_bytes(0) == 0
     with pytest.raises(_lib.MulActSegHipError):
         _lib.check(-2, "probe")
+
+
+def test_a_library_of_another_abi_version_is_refused(tmp_path, monkeypatch):
+    """load() compares mas_abi_version() with the version the ctypes table was written against BEFORE it binds anything: a stale
+    variant build (MAS_LIB) that exports the same names with other argument lists must not bind silently."""
+    import subprocess
+    from mulactseg_amd import _lib
+    src = tmp_path / "stale.c"
+    src.write_text("int mas_abi_version(void) { return 1; }\n")
+    so = tmp_path / "libstale.so"
+    subprocess.check_call(["gcc", "-shared", "-fPIC", "-o", str(so), str(src)])
+    monkeypatch.setattr(_lib, "LIB_PATH", str(so))
+    monkeypatch.setattr(_lib, "_lib", None)
+    with pytest.raises(_lib.MulActSegHipError, match="ABI version 1"):
+        _lib.load()

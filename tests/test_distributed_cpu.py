@@ -209,3 +209,35 @@ def test_data_order_seeds_differ_per_rank_while_the_global_stream_agrees():
     mp.spawn(_run_seeds, args=(2, _free_port(), out), nprocs=2, join=True)
     (s0, g0), (s1, g1) = [pickle.load(open(os.path.join(out, "seed%d.pkl" % r), "rb")) for r in range(2)]
     assert s0 != s1 and g0 == g1
+
+
+def _split_default_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    from mulactseg_amd import ops
+    before = ops.sk_split_default()
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        inside = ops.sk_split_default()
+        os.environ["MAS_SK_SPLIT"] = "on"
+        forced = ops.sk_split_default()
+        del os.environ["MAS_SK_SPLIT"]
+    finally:
+        dist.destroy_process_group()
+    q.put((rank, before, inside, forced))
+
+
+def test_stream_k_hand_off_is_off_by_default_under_more_than_one_rank():
+    """ops.sk_split_default: tiles are split over workgroups in a single-GPU process only; with world_size > 1 the whole-tile plan
+    (no hand-off, nothing can give up and leave the other ranks in the gradient all-reduce) unless MAS_SK_SPLIT=on."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_split_default_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = sorted(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(60)
+    assert got == [(0, True, False, True), (1, True, False, True)]

@@ -206,3 +206,105 @@ def test_valid_table_is_rebuilt_from_the_lists_when_a_round_ran_before_it_existe
     aset.expand_training_set([(0.7, ','.join(names[1]), 4)], 10 ** 6, 'x')          # now mirrored incrementally
     valid = aset.pool_valid_mask(16)
     assert valid[[k[2] for k in pool.im_idx].index(names[1][2]), 4] == 0
+
+
+def test_lists_nobody_reads_stay_arrays_and_still_equal_the_reference_loop(tmp_path):
+    """with the valid table in place and every pool list ascending, pool.suppix / label.suppix become LazySuppix
+    mappings -- the array path of expand_training_set edits the table and appends id runs, Python lists appear when somebody reads
+    them.  Four successive rounds WITHOUT a single list access in between (one round empties pictures, one picture is read half way
+    and is edited as a real list from then on), then everything is compared with the reference loop: lists, order inside every list,
+    dictionary order, im_idx, the datalist pickle (a plain dict of lists)."""
+    import copy
+    import pickle
+    from mulactseg_amd.dataloader.region_active_dataset import ConsumedPrefix, LazySuppix
+    rs = np.random.RandomState(21)
+    args, names, mh, aset = _sets(tmp_path, n=9, nseg=48)
+    pool, label = aset.trg_pool_dataset, aset.trg_label_dataset
+    ref_pool = {'im_idx': copy.deepcopy(pool.im_idx), 'suppix': copy.deepcopy(pool.suppix)}
+    ref_label = {'im_idx': copy.deepcopy(label.im_idx), 'suppix': copy.deepcopy(label.suppix)}
+    ref_sel = np.zeros_like(pool.isselected)
+    index_of = lambda spx: label.id_to_index[spx.split('/')[-1].split('.')[0]]
+    aset.pool_valid_mask(args.nseg)
+    assert isinstance(pool.suppix, LazySuppix) and isinstance(label.suppix, LazySuppix)
+    assert pool.suppix.pending() == 9 and len(pool.suppix) == 9 and names[3][2] in pool.suppix
+    for rnd, budget in enumerate([70, 10 ** 6, 55, 10 ** 6]):
+        aset.selection_iter = rnd + 1
+        valid = aset.pool_valid_mask(args.nseg)                         # candidates from the TABLE (what the selector reads)
+        keys = list(pool.im_idx)
+        cand = [(float(np.float32(rs.rand())), p, int(i)) for p in range(len(keys)) for i in np.flatnonzero(valid[p])]
+        cand.sort(key=lambda t: (-t[0], t[1], t[2]))
+        if rnd == 1:                                                    # two whole pictures and a bit more
+            cand = [c for c in cand if c[1] in (1, 4)] + [c for c in cand if c[1] not in (1, 4)][:11]
+        if rnd == 3:
+            cand = cand[:40]
+        sr = ConsumedPrefix(np.array([c[0] for c in cand], dtype=np.float32), [c[1] for c in cand], [c[2] for c in cand], keys)
+        as_tuples = [(c[0], ','.join(keys[c[1]]), c[2]) for c in cand]
+        n_ref = _reference_loop(ref_pool, ref_label, ref_sel, index_of, mh, as_tuples, budget)
+        before = pool.suppix.pending()
+        assert aset.expand_training_set(sr, budget, 'm') == n_ref
+        assert pool.suppix.pending() in (before, before - 2)            # (round 1 drops two emptied pictures; nothing was built)
+        if rnd == 2:                                                    # somebody reads one pool list and one label list ...
+            k5 = pool.im_idx[5][2]
+            assert pool.suppix[k5] == ref_pool['suppix'][k5] and label.suppix[k5] == ref_label['suppix'][k5]
+            assert isinstance(pool.suppix[k5], list) and pool.suppix[k5] is pool.suppix[k5]     # ... they are real lists from now on
+    aset.wait_for_writes()
+    assert pool.suppix.pending() >= 5
+    assert pool.im_idx == ref_pool['im_idx'] and label.im_idx == ref_label['im_idx']
+    assert list(pool.suppix) == list(ref_pool['suppix']) and list(label.suppix) == list(ref_label['suppix'])
+    assert np.array_equal(pool.isselected, ref_sel)
+    aset.dump_datalist()
+    with open(tmp_path / 'datalist_04.pkl', 'rb') as f:
+        data = pickle.load(f)
+    assert type(data['trg_pool_suppix']) is dict and type(data['trg_label_suppix']) is dict
+    assert data['trg_pool_suppix'] == ref_pool['suppix'] and data['trg_label_suppix'] == ref_label['suppix']
+    assert list(data['trg_pool_suppix']) == list(ref_pool['suppix'])
+    assert pool.suppix == ref_pool['suppix'] and label.suppix == ref_label['suppix'] and pool.suppix.pending() == 0
+    # the tuple path on the same mappings (a selector without calculate_scores_tensor) keeps working
+    key = pool.im_idx[0]
+    sid = pool.suppix[key[2]][0]
+    _reference_loop(ref_pool, ref_label, ref_sel, index_of, mh, [(1.0, ','.join(key), sid)], 5)
+    aset.expand_training_set([(1.0, ','.join(key), sid)], 5, 'm')
+    assert pool.suppix == ref_pool['suppix'] and label.suppix == ref_label['suppix']
+
+
+def test_lazy_suppix_reads_like_a_dict_of_lists():
+    import copy
+    import pickle
+    from mulactseg_amd.dataloader.region_active_dataset import LazySuppix, _Appended, _FromTable
+    tab = np.array([[1, 0, 1, 1], [0, 0, 0, 1]], dtype=np.uint8)
+    d = LazySuppix()
+    dict.__setitem__(d, 'a', _FromTable(tab, 0))
+    dict.__setitem__(d, 'b', _FromTable(tab, 1))
+    ap = _Appended([7])
+    ap.runs += [np.array([3, 1]), np.array([9])]
+    dict.__setitem__(d, 'c', ap)
+    assert len(d) == 3 and 'a' in d and list(d) == ['a', 'b', 'c'] and d.pending() == 3
+    tab[0, 0] = 0                                        # the table is edited in place until the list is asked for
+    assert d['a'] == [2, 3] and d.pending() == 2 and d.get('zz', 5) == 5 and d.get('b') == [3]
+    assert d['c'] == [7, 3, 1, 9]
+    d['a'].append(11)                                    # a handed-out list is the list
+    assert d['a'] == [2, 3, 11]
+    assert dict(d.items()) == {'a': [2, 3, 11], 'b': [3], 'c': [7, 3, 1, 9]} and sorted(map(len, d.values())) == [1, 3, 4]
+    e = pickle.loads(pickle.dumps(d))
+    assert type(e) is dict and e == d and d == e and copy.deepcopy(d) == e and not (d != e)
+    assert d.pop('b') == [3] and 'b' not in d and d.pop('b', None) is None
+    assert d.setdefault('q', []) == [] and d.setdefault('a') == [2, 3, 11]
+    assert 'FromTable' not in repr(d)
+
+
+def test_a_failed_selection_pickle_write_is_raised_not_lost(tmp_path):
+    """the background write of <method>_selection_RR.pkl must not fail silently -- wait_for_writes (called by the next
+    expand / dump / load) re-raises what the thread raised, and no temporary file is left behind."""
+    import os
+    import pytest
+    from mulactseg_amd.dataloader.region_active_dataset import ConsumedPrefix
+    args, names, mh, aset = _sets(tmp_path, n=3, nseg=16)
+    aset.pool_valid_mask(args.nseg)
+    args.model_save_dir = str(tmp_path / "does" / "not" / "exist")
+    keys = list(aset.trg_pool_dataset.im_idx)
+    sr = ConsumedPrefix(np.linspace(1, 0.5, 6).astype(np.float32), [1] * 6, [2, 3, 4, 5, 6, 7], keys)
+    assert aset.expand_training_set(sr, 3, 'm') < 6                      # stopped by the budget: a prefix is written
+    with pytest.raises(OSError):
+        aset.wait_for_writes()
+    aset.wait_for_writes()                                               # (reported once)
+    assert not [f for f in os.listdir(tmp_path) if '.tmp.' in f]

@@ -17,6 +17,8 @@ import pytest
 import torch
 import torch.nn.functional as F
 
+from helpers import occupy_cus
+
 pytestmark = pytest.mark.gpu
 
 SPLIT_CASES = [
@@ -53,7 +55,7 @@ def test_exact_beside_a_cu_hogging_stream(occupied):
     torch.cuda.synchronize()
     # one occupier per CU (96 KB of LDS: neither a second occupier nor a stream-K workgroup fits beside it), alive for 0.4 s -- the
     # launches below are all queued (and most of them run) inside that window; `busy` checks that at least the first ones did
-    ops.occupy_cus(occupied, 96 * 1024, 0.4, stream=side)
+    occupy_cus(occupied, 96 * 1024, 0.4, stream=side)
     done_side = torch.cuda.Event()
     outs = []
     for (c, (x, w, dy, y_ref, dx_ref)) in zip(SPLIT_CASES, cases):
@@ -89,7 +91,7 @@ def test_give_up_is_loud_and_the_whole_tile_plan_recovers():
         stride, dil = c[3], c[4]
         ops.conv_sk_clear_error()
         torch.cuda.synchronize()
-        ops.occupy_cus(224, 96 * 1024, 0.05, stream=side)
+        occupy_cus(224, 96 * 1024, 0.05, stream=side)
         y = ops.conv_sk(x, w, stride, dil, spin_limit=1)
         err = ops.conv_sk_error()                       # (synchronises)
         if err:
@@ -105,7 +107,7 @@ def test_give_up_is_loud_and_the_whole_tile_plan_recovers():
             assert torch.equal(y.double(), y_ref)
         torch.cuda.synchronize()
         # the whole-tile plan, with and without the neighbour: no hand-off at all, so the one-poll bound cannot matter
-        ops.occupy_cus(224, 96 * 1024, 0.05, stream=side)
+        occupy_cus(224, 96 * 1024, 0.05, stream=side)
         y2 = ops.conv_sk(x, w, stride, dil, flags=_lib.SK_NOSPLIT, spin_limit=1)
         assert torch.equal(y2.double(), y_ref), c
         if stride == 1:
@@ -210,3 +212,35 @@ def test_trainer_raises_when_the_error_word_is_set():
     with pytest.raises(ops.StreamKGaveUp):
         t.check_stream_k()
     assert ops.conv_sk_error() == 0
+
+
+def test_a_give_up_skips_the_optimizer_update_on_the_device():
+    """trainer/base.py:guard_optimizer_step -- the flag of THIS step's passes reaches the fused AdamW kernel as `found_inf` (no host
+    round trip): parameters, moments and step counts stay as they were; with the word clear the same step updates them."""
+    _need_gpu()
+    from mulactseg_amd import ops
+    from mulactseg_amd.trainer.base import BaseTrainer
+    dev = torch.device('cuda', torch.cuda.current_device())
+    ops.conv_sk(torch.randn(1, 64, 16, 16, device=dev), torch.randn(64, 64, 1, 1, device=dev))      # (the workspace exists)
+    ops.conv_sk_clear_error()
+    p = torch.nn.Parameter(torch.randn(1000, device=dev))
+    t = BaseTrainer.__new__(BaseTrainer)
+    t.device = dev
+    t.optimizer = torch.optim.AdamW([p], lr=0.1, fused=True)
+    p.grad = torch.ones_like(p)
+    t.guard_optimizer_step()
+    t.optimizer.step()                               # word clear: a normal update
+    after_one = p.detach().clone()
+    assert float(t.optimizer.state[p]['step']) == 1.0
+    for v in ops._sk_error_views(dev):
+        v.view(torch.int32).fill_(1)                 # what a finisher's atomicOr does
+    p.grad = torch.full_like(p, float('nan'))        # the gradients of a poisoned step
+    t.guard_optimizer_step()
+    t.optimizer.step()
+    assert torch.equal(p.detach(), after_one) and float(t.optimizer.state[p]['step']) == 1.0
+    assert bool(torch.isfinite(t.optimizer.state[p]['exp_avg']).all())
+    ops.conv_sk_clear_error()
+    p.grad = torch.ones_like(p)
+    t.guard_optimizer_step()
+    t.optimizer.step()
+    assert not torch.equal(p.detach(), after_one) and float(t.optimizer.state[p]['step']) == 2.0

@@ -20,14 +20,13 @@ p = torch.zeros((B, C), dtype=torch.int64, device=dev)
 c = torch.zeros((B, S, C), dtype=torch.int64, device=dev)
 h = torch.zeros((B, S, C), dtype=torch.int32, device=dev)
 for mode in (True, False, True, False):
-    ops.single_pass_lowres_generic(mode)
     for _ in range(50):
-        ops.single_pass_accum_lowres(zq, (H, W), spx, S, invT, prob_sum=p, class_sum=c, hist=h)
+        ops.single_pass_accum_lowres(zq, (H, W), spx, S, invT, prob_sum=p, class_sum=c, hist=h, generic=mode)
     a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     torch.cuda.synchronize()
     a.record()
     for _ in range(200):
-        ops.single_pass_accum_lowres(zq, (H, W), spx, S, invT, prob_sum=p, class_sum=c, hist=h)
+        ops.single_pass_accum_lowres(zq, (H, W), spx, S, invT, prob_sum=p, class_sum=c, hist=h, generic=mode)
     b.record()
     torch.cuda.synchronize()
     print("%s: %.1f us per pool batch" % ("generic tap reads" if mode else "x4 period per lane", a.elapsed_time(b) * 1e3 / 200))
