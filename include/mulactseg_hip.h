@@ -465,6 +465,19 @@ unsigned mas_conv_bx_pack_job(void* job_host, const float* w, int Cout, int Cin,
 int mas_conv_bx_pack_multi(const void* jobs_dev, int njobs, unsigned nblocks, void* stream);
 int mas_conv_bx_fwd(const float* x, const void* wp, int N, int Cin, int H, int W, int Cout, int ksize, int stride, int dil,
                     const float* scale, const float* shift, const float* residual, int relu, float* y, void* stream);
+/* The bare stride-1 products of a TRAINING step (forward with a role-0 image, input gradient with a role-1 image + the gradient of the
+ * input's other consumer as `residual`; models/segmentation/backbone/resnet.py:143-160 under
+ * trainer/active_joint_multi_predignore_lossdecomp.py:83-116) with a work-splitting plan for launches with fewer workgroups than
+ * the chip has slots (the 48 x 48 planes of layer3 / layer4 / ASPP at the training crop): the K chunks of every tile are dealt to
+ * `ksplit` workgroups, part 0 stores into y (+ residual), the others into `workspace`, and a second launch adds the parts in index
+ * order (run-to-run identical; no flags, no waiting: nothing that needs co-residency, unlike the stream-K hand-off of mas_conv_sk).
+ * 3x3: `tile_w` 32 (8 x 32 output pixels per tile) or 16 (16 x 16: no padded quarter on 48 x 48 planes).
+ * mas_conv_bx_train_plan: out3 = {ksplit, tile_w, workgroups} the library would choose; ksplit / tile_w <= 0 in mas_conv_bx_train
+ * take the plan's.  workspace: mas_conv_bx_train_workspace_bytes(N, Cout, H, W, ksplit) bytes, 16-byte aligned (none for ksplit 1). */
+int mas_conv_bx_train_plan(int N, int Cin, int H, int W, int Cout, int ksize, int dil, int* out3);
+size_t mas_conv_bx_train_workspace_bytes(int N, int Cout, int H, int W, int ksplit);
+int mas_conv_bx_train(const float* x, const void* wp, int N, int Cin, int H, int W, int Cout, int ksize, int dil, const float* residual,
+                      float* y, int ksplit, int tile_w, void* workspace, size_t workspace_bytes, void* stream);
 
 /* Weight gradient of a 1x1 stride-1 convolution on the bf16 matrix cores with f32 operands and results (csrc/conv_wgrad_bx.hip; the
  * operand split of mas_conv_bx_fwd applied to BOTH operands): dW[m,c] = sum_{n,p} dY[n,m,p] * X[n,c,p], x [N,Cin,H,W], dy [N,Cout,H,W],

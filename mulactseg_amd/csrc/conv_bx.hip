@@ -56,6 +56,10 @@ struct BxP {
     int Cin2;                                   //   0: none
     int Cin, H, W, Cout, Ho, Wo, dil, relu;
     int tiles_x, tiles_y, ptiles, mtiles;
+    int N;
+    int ksplit;                                 // split-K (bare products only): the chunks of a tile are dealt to `ksplit` workgroups; part 0
+    float* part;                                //   stores into y (with the residual), part k > 0 into part + (k - 1) * N * Cout * Ho * Wo;
+                                                //   k_bx_reduce then adds the parts into y in index order
 #ifdef BX_STAMPS
     unsigned long long* stamps;
 #endif
@@ -168,11 +172,15 @@ constexpr int kBxOut = (int)0x80000000u;        // a byte offset beyond every re
 // instruction issued per MFMA whatever its kind, so the staging + fetch phases cost by their instruction COUNT -- hence the
 // buffer-resource forms below (no address arithmetic, no bounds selects).
 // V: the stride of the 1x1 form (1 | 2), the dilation of the 3x3 form (1 | 2: the patch geometry is a compile-time constant)
-template <int TAPS, int BM, int BN, int V, bool RES>
+// TW: 3x3 form: the 256 output pixels of a tile are 8 rows x 32 columns (TW = 32) or 16 x 16 (TW = 16: the 48 x 48 planes of
+//     layer3 / layer4 at the training crop are 9 such tiles, 12 of the wide ones of which a quarter is padding); 1x1: 32
+template <int TAPS, int BM, int BN, int V, bool RES, int TW = 32>
 __global__ __launch_bounds__(kThreads, 2) void k_conv_bx(const BxP p) {
     constexpr bool S2 = TAPS == 1 && V == 2;
     constexpr int DIL = TAPS == 9 ? V : 1;
-    constexpr int PW = 32 + 2 * DIL, PP = (8 + 2 * DIL) * PW;      // 3x3: columns / pixels of the input patch of an 8 x 32 tile
+    constexpr int TH = 256 / TW;                                    // 3x3: rows of a tile
+    static_assert(TW == 32 || (TW == 16 && TAPS == 9), "tile shape");
+    constexpr int PW = TW + 2 * DIL, PP = (TH + 2 * DIL) * PW;      // 3x3: columns / pixels of the input patch of a TH x TW tile
     static_assert(PP <= kBxDump, "patch");
     constexpr int CK = BxGeo<TAPS>::CK, GA = BxGeo<TAPS>::GA, SLABS = BxGeo<TAPS>::SLABS;
     constexpr int WM = BM / 64, WN = 4 / WM;
@@ -191,7 +199,11 @@ __global__ __launch_bounds__(kThreads, 2) void k_conv_bx(const BxP p) {
 
     const int tid = threadIdx.x;
     const int bid = blockIdx.x;
-    const int xcd = bid & 7, slot = bid >> 3;
+    const int xcd = bid & 7;
+    int slot = bid >> 3;
+    const int per_part = p.mtiles * ((p.ptiles + 7) >> 3);          // slots of one K part (all of them when ksplit == 1)
+    const int kpart = slot / per_part;
+    slot -= kpart * per_part;
     const int mt = slot % p.mtiles;
     const int pt = (slot / p.mtiles) * 8 + xcd;
     if (pt >= p.ptiles) return;
@@ -205,8 +217,8 @@ __global__ __launch_bounds__(kThreads, 2) void k_conv_bx(const BxP p) {
         n = pt / tpi;
         const int trem = pt - n * tpi;
         const int tyi = trem / p.tiles_x;
-        oy0 = tyi * 8;
-        ox0 = (trem - tyi * p.tiles_x) * 32;
+        oy0 = tyi * TH;
+        ox0 = (trem - tyi * p.tiles_x) * TW;
     }
     const int m0 = mt * BM;
 
@@ -262,7 +274,8 @@ __global__ __launch_bounds__(kThreads, 2) void k_conv_bx(const BxP p) {
 #pragma unroll
     for (int tn = 0; tn < 2; ++tn) {
         if (TAPS == 1) bBase[tn] = (h * POS1 + bx_pos1(wn * 64 + tn * 32 + l31)) * 16;
-        else bBase[tn] = ((wn * 2 + tn) * PW + l31) * 16;
+        else if (TW == 32) bBase[tn] = ((wn * 2 + tn) * PW + l31) * 16;
+        else bBase[tn] = ((wn * 4 + tn * 2 + (l31 >> 4)) * PW + (l31 & 15)) * 16;        // 16 x 16: an MFMA column tile is 2 rows x 16 columns
     }
     int toff[SLABS];                                                // 3x3: the tap of this lane half in every 16-k step
 #pragma unroll
@@ -415,10 +428,12 @@ __global__ __launch_bounds__(kThreads, 2) void k_conv_bx(const BxP p) {
     // One loop, no peeled last iteration: the fetch in the last pass re-reads the last chunk (never used).  With the last pass
     // peeled, hipcc merged its staging code with the loop's and copied every loop-carried register -- 64 accumulators and the
     // staging registers -- at the head of each iteration of the 3x3 form.
-    fetch(0);
+    // split-K: part k of `ksplit` walks the chunks [k * nchunks / ksplit, (k + 1) * nchunks / ksplit)
+    const int t_lo = __builtin_amdgcn_readfirstlane((int)((long long)kpart * nchunks / p.ksplit));
+    const int nloop = __builtin_amdgcn_readfirstlane((int)((long long)(kpart + 1) * nchunks / p.ksplit));      // (a scalar trip count: see fetch)
+    fetch(t_lo);
     BX_T(0);
-    const int nloop = __builtin_amdgcn_readfirstlane(nchunks);      // (a scalar trip count: see fetch)
-    for (int t = 0; t < nloop; ++t) {
+    for (int t = t_lo; t < nloop; ++t) {
         stage();
         BX_T(1);
         __syncthreads();
@@ -438,9 +453,12 @@ __global__ __launch_bounds__(kThreads, 2) void k_conv_bx(const BxP p) {
     // the plane is out of range (dropped / zero) -- one 32-bit add per element, no predicates
     const int mrows = p.Cout - m0 < BM ? p.Cout - m0 : BM;
     const int row4 = HWo * 4;
-    const __amdgpu_buffer_rsrc_t yres = __builtin_amdgcn_make_buffer_rsrc(p.y + ((size_t)n * p.Cout + m0) * HWo, 0, mrows * row4, kBxRsrcFlags);
+    // (split-K: part 0 stores into y and adds the residual; the others store into their slice of `part` and see an EMPTY residual
+    //  resource -- out-of-range reads are zeros, so the RES code needs no branch)
+    float* ydst = kpart == 0 ? p.y : p.part + (size_t)(kpart - 1) * p.N * p.Cout * HWo;
+    const __amdgpu_buffer_rsrc_t yres = __builtin_amdgcn_make_buffer_rsrc(ydst + ((size_t)n * p.Cout + m0) * HWo, 0, mrows * row4, kBxRsrcFlags);
     const __amdgpu_buffer_rsrc_t rres = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<float*>(RES ? p.res + ((size_t)n * p.Cout + m0) * HWo : p.x), 0, RES ? mrows * row4 : 0, kBxRsrcFlags);
+        const_cast<float*>(RES ? p.res + ((size_t)n * p.Cout + m0) * HWo : p.x), 0, (RES && kpart == 0) ? mrows * row4 : 0, kBxRsrcFlags);
     int vo[2];
 #pragma unroll
     for (int tn = 0; tn < 2; ++tn) {
@@ -448,7 +466,8 @@ __global__ __launch_bounds__(kThreads, 2) void k_conv_bx(const BxP p) {
             const int pp = p0 + wn * 64 + tn * 32 + l31;
             vo[tn] = pp < HWo ? pp * 4 : kBxOut;
         } else {
-            const int oy = oy0 + wn * 2 + tn, ox = ox0 + l31;
+            const int oy = TW == 32 ? oy0 + wn * 2 + tn : oy0 + wn * 4 + tn * 2 + (l31 >> 4);
+            const int ox = TW == 32 ? ox0 + l31 : ox0 + (l31 & 15);
             vo[tn] = (oy < p.Ho && ox < p.Wo) ? (oy * p.Wo + ox) * 4 : kBxOut;
         }
     }
@@ -516,18 +535,20 @@ __global__ __launch_bounds__(kThreads, 2) void k_conv_bx(const BxP p) {
 // the M tile of a layer's weight image: a pure function of (ksize, Cout), shared by the pack and the launch
 inline int bx_bm(int ksize, int Cout) { return (ksize == 1 && Cout % 128 == 0) ? 128 : 64; }
 
-template <int TAPS, int BM, int BN, int V, bool RES>
+template <int TAPS, int BM, int BN, int V, bool RES, int TW = 32>
 int bx_launch(BxP p, int N, hipStream_t st) {
     constexpr int GA = BxGeo<TAPS>::GA;
     p.mtiles = (p.Cout + BM - 1) / BM;
+    p.N = N;
+    if (p.ksplit < 1) p.ksplit = 1;
     size_t bbytes;
     if (TAPS == 1) {
         p.tiles_x = (p.Ho * p.Wo + BN - 1) / BN;
         p.tiles_y = 1;
         bbytes = (size_t)3 * 4 * 144 * (BN / 128) * 16;
     } else {
-        p.tiles_x = (p.Wo + 31) / 32;
-        p.tiles_y = (p.Ho + 7) / 8;
+        p.tiles_x = (p.Wo + TW - 1) / TW;
+        p.tiles_y = (p.Ho + 256 / TW - 1) / (256 / TW);
         if (p.dil != V) return MAS_ERR_RANGE;
         static_assert(kBxPPA >= kBxDump + 16, "dump positions");
         bbytes = (size_t)3 * kBxPPA * 16;
@@ -541,21 +562,77 @@ int bx_launch(BxP p, int N, hipStream_t st) {
         hipError_t e = hipGetDevice(&dev);
         if (e != hipSuccess) return (int)e;
         if (dev < 0 || dev >= 64 || !raised[dev]) {
-            e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv_bx<TAPS, BM, BN, V, RES>), hipFuncAttributeMaxDynamicSharedMemorySize,
+            e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv_bx<TAPS, BM, BN, V, RES, TW>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                     80 * 1024);
             if (e != hipSuccess) return (int)e;
             if (dev >= 0 && dev < 64) raised[dev] = true;
         }
     }
-    const long long nblk = 8LL * ((p.ptiles + 7) / 8) * p.mtiles;
+    const long long nblk = 8LL * ((p.ptiles + 7) / 8) * p.mtiles * p.ksplit;
     if (nblk <= 0 || nblk > 0x7fffffffLL) return MAS_ERR_SHAPE;
-    hipLaunchKernelGGL((k_conv_bx<TAPS, BM, BN, V, RES>), dim3((unsigned)nblk), dim3(kThreads), smem, st, p);
+    hipLaunchKernelGGL((k_conv_bx<TAPS, BM, BN, V, RES, TW>), dim3((unsigned)nblk), dim3(kThreads), smem, st, p);
     return mas_launch_status();
 }
 
-template <int TAPS, int BM, int BN, int V>
+template <int TAPS, int BM, int BN, int V, int TW = 32>
 int bx_launch_r(const BxP& p, int N, hipStream_t st) {
-    return p.res ? bx_launch<TAPS, BM, BN, V, true>(p, N, st) : bx_launch<TAPS, BM, BN, V, false>(p, N, st);
+    return p.res ? bx_launch<TAPS, BM, BN, V, true, TW>(p, N, st) : bx_launch<TAPS, BM, BN, V, false, TW>(p, N, st);
+}
+
+// y[i] += part[0][i] + part[1][i] + ... in index order (the parts of a split-K launch; y already holds part 0 + residual)
+__global__ __launch_bounds__(256) void k_bx_reduce(float* __restrict__ y, const float* __restrict__ part, int nparts, long long n4, long long stride) {
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) {
+        v4f a = reinterpret_cast<const v4f*>(y)[i];
+        for (int k = 0; k < nparts; ++k) {
+            const v4f b = __builtin_nontemporal_load(reinterpret_cast<const v4f*>(part + (size_t)k * stride) + i);
+            a += b;
+        }
+        reinterpret_cast<v4f*>(y)[i] = a;
+    }
+}
+
+// ---- the work-splitting plan of a bare stride-1 product (training) --------------------------------------------------------
+// A launch has 8 * ceil(pixel tiles / 8) * M tiles workgroups for 2 x 256 resident slots.  The layers of the 48 x 48 planes have
+// 144 ... 384 of them (profiles/r04/k_bx_train_table.md: no faster than the persistent f32 kernel there): the chunks of every tile
+// are then dealt to `ksplit` workgroups whose partial tiles a second, memory-bound launch adds in index order (run-to-run
+// identical; no flags, no waiting -- nothing that needs co-residency).  3x3: the tile shape with fewer padded pixels.
+struct BxPlan { int ksplit, tw, wgs; };
+
+inline int bx_tw(int ksize, int H, int W) {
+    if (ksize != 3 || W < 16) return 32;
+    const long long wide = (long long)((H + 7) / 8) * ((W + 31) / 32), square = (long long)((H + 15) / 16) * ((W + 15) / 16);
+    return square < wide ? 16 : 32;
+}
+
+inline BxPlan bx_plan(int N, int Cin, int H, int W, int Cout, int ksize, int dil) {
+    (void)dil;
+    BxPlan pl;
+    pl.tw = bx_tw(ksize, H, W);
+    const int BM = bx_bm(ksize, Cout);
+    const int BN = ksize == 1 ? (BM == 128 ? 128 : 256) : 256;
+    const long long ptiles = ksize == 1 ? (long long)N * ((H * W + BN - 1) / BN)
+                                        : (long long)N * ((W + pl.tw - 1) / pl.tw) * ((H + 256 / pl.tw - 1) / (256 / pl.tw));
+    const long long wg1 = 8 * ((ptiles + 7) / 8) * ((Cout + BM - 1) / BM);
+    const int ck = ksize == 1 ? 32 : 8, nch = (Cin + ck - 1) / ck;
+    // cost of a plan in units of one chunk of one workgroup: rounds of 512 resident workgroups x (chunks per part + the fixed
+    // prologue / epilogue of a workgroup) + the reduction pass (its bytes at ~4 TB/s against a chunk's time)
+    const double fixed = ksize == 1 ? 3.0 : 1.2;
+    const double chunk_us = ksize == 1 ? 2.0 : 5.0;
+    const double out_mb = (double)N * Cout * H * W * 4e-6;
+    double best = 1e30;
+    pl.ksplit = 1;
+    for (int ks = 1; ks <= 8; ++ks) {
+        if (ks > 1 && nch / ks < 4) break;
+        const long long wgs = wg1 * ks;
+        const double rounds = (double)((wgs + 511) / 512);
+        // (a CU that holds one workgroup instead of two runs it faster, but not twice as fast)
+        const double alone = wgs <= 256 ? 0.7 : 1.0;
+        double cost = rounds * (((nch + ks - 1) / ks) + fixed) * chunk_us * alone;
+        if (ks > 1) cost += 4.0 + (ks + 1) * out_mb / 4.0;          // launch gap + bytes of the reduction (MB / (4 TB/s) = us)
+        if (cost < best * 0.97) { best = cost; pl.ksplit = ks; }
+    }
+    pl.wgs = (int)(wg1 * pl.ksplit);
+    return pl;
 }
 }  // namespace
 
@@ -632,7 +709,7 @@ extern "C" int mas_conv_bx_fwd(const float* x, const void* wp, int N, int Cin, i
     hipStream_t st = static_cast<hipStream_t>(stream);
     BxP p;
     p.x = x; p.wp = static_cast<const v4f*>(wp); p.scale = scale; p.shift = shift; p.res = residual; p.y = y;
-    p.x2 = nullptr; p.wp2 = nullptr; p.Cin2 = 0;
+    p.x2 = nullptr; p.wp2 = nullptr; p.Cin2 = 0; p.ksplit = 1; p.part = nullptr;
     p.Cin = Cin; p.H = H; p.W = W; p.Cout = Cout; p.dil = dil; p.relu = relu;
 #ifdef BX_STAMPS
     p.stamps = g_bx_stamps;
@@ -664,11 +741,65 @@ extern "C" int mas_conv_bx_fwd_dual(const float* x1, const void* wp1, int Cin1, 
     hipStream_t st = static_cast<hipStream_t>(stream);
     BxP p;
     p.x = x1; p.wp = static_cast<const v4f*>(wp1); p.scale = nullptr; p.shift = shift; p.res = nullptr; p.y = y;
-    p.x2 = x2; p.wp2 = static_cast<const v4f*>(wp2); p.Cin2 = Cin2;
+    p.x2 = x2; p.wp2 = static_cast<const v4f*>(wp2); p.Cin2 = Cin2; p.ksplit = 1; p.part = nullptr;
     p.Cin = Cin1; p.H = H; p.W = W; p.Cout = Cout; p.dil = 1; p.relu = relu;
 #ifdef BX_STAMPS
     p.stamps = g_bx_stamps;
 #endif
     p.Ho = H; p.Wo = W;
     return bx_bm(1, Cout) == 128 ? bx_launch<1, 128, 128, 1, false>(p, N, st) : bx_launch<1, 64, 256, 1, false>(p, N, st);
+}
+
+/* ---- the bare stride-1 product of a training step with the work-splitting plan --------------------------------------------- */
+extern "C" int mas_conv_bx_train_plan(int N, int Cin, int H, int W, int Cout, int ksize, int dil, int* out3) {
+    if (!out3) return MAS_ERR_NULL;
+    if (N <= 0 || !mas_conv_bx_supported(ksize, 1, dil, Cin, Cout, H, W)) return MAS_ERR_SHAPE;
+    const BxPlan pl = bx_plan(N, Cin, H, W, Cout, ksize, dil);
+    out3[0] = pl.ksplit; out3[1] = pl.tw; out3[2] = pl.wgs;
+    return 0;
+}
+
+extern "C" size_t mas_conv_bx_train_workspace_bytes(int N, int Cout, int H, int W, int ksplit) {
+    if (N <= 0 || Cout <= 0 || H <= 0 || W <= 0 || ksplit <= 1) return 0;
+    return (size_t)(ksplit - 1) * N * Cout * H * W * sizeof(float);
+}
+
+extern "C" int mas_conv_bx_train(const float* x, const void* wp, int N, int Cin, int H, int W, int Cout, int ksize, int dil, const float* residual,
+                                 float* y, int ksplit, int tile_w, void* workspace, size_t workspace_bytes, void* stream) {
+    if (!x || !wp || !y) return MAS_ERR_NULL;
+    if (N <= 0) return MAS_ERR_SHAPE;
+    if (!mas_conv_bx_supported(ksize, 1, dil, Cin, Cout, H, W)) return MAS_ERR_SHAPE;
+    if ((uintptr_t)wp % 16 != 0 || (uintptr_t)x % 4 != 0) return MAS_ERR_ALIGN;
+    const BxPlan pl = bx_plan(N, Cin, H, W, Cout, ksize, dil);
+    if (ksplit <= 0) ksplit = pl.ksplit;
+    if (tile_w <= 0) tile_w = pl.tw;
+    const int ck = ksize == 1 ? 32 : 8, nch = (Cin + ck - 1) / ck;
+    if (ksplit > nch || ksplit > 64) return MAS_ERR_RANGE;
+    if (tile_w != 32 && !(tile_w == 16 && ksize == 3)) return MAS_ERR_RANGE;
+    const size_t out_elems = (size_t)N * Cout * H * W;
+    if (ksplit > 1) {
+        if (!workspace) return MAS_ERR_NULL;
+        if (workspace_bytes < (size_t)(ksplit - 1) * out_elems * sizeof(float)) return MAS_ERR_WORKSPACE;
+        if ((uintptr_t)workspace % 16 != 0 || (uintptr_t)y % 16 != 0 || out_elems % 4 != 0) return MAS_ERR_ALIGN;
+    }
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    BxP p;
+    p.x = x; p.wp = static_cast<const v4f*>(wp); p.scale = nullptr; p.shift = nullptr; p.res = residual; p.y = y;
+    p.x2 = nullptr; p.wp2 = nullptr; p.Cin2 = 0; p.ksplit = ksplit; p.part = static_cast<float*>(workspace);
+    p.Cin = Cin; p.H = H; p.W = W; p.Cout = Cout; p.dil = dil; p.relu = 0;
+#ifdef BX_STAMPS
+    p.stamps = g_bx_stamps;
+#endif
+    p.Ho = H; p.Wo = W;
+    const int BM = bx_bm(ksize, Cout);
+    int rc;
+    if (ksize == 1) rc = BM == 128 ? bx_launch_r<1, 128, 128, 1>(p, N, st) : bx_launch_r<1, 64, 256, 1>(p, N, st);
+    else if (tile_w == 16) rc = dil == 1 ? bx_launch_r<9, 64, 256, 1, 16>(p, N, st) : bx_launch_r<9, 64, 256, 2, 16>(p, N, st);
+    else rc = dil == 1 ? bx_launch_r<9, 64, 256, 1>(p, N, st) : bx_launch_r<9, 64, 256, 2>(p, N, st);
+    if (rc != 0 || ksplit == 1) return rc;
+    const long long n4 = (long long)(out_elems / 4);
+    const long long blocks = (n4 + 255) / 256;
+    hipLaunchKernelGGL(k_bx_reduce, dim3((unsigned)(blocks < 4096 ? blocks : 4096)), dim3(256), 0, st, y, static_cast<const float*>(workspace),
+                       ksplit - 1, n4, (long long)out_elems);
+    return mas_launch_status();
 }

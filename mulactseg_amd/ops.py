@@ -1417,9 +1417,36 @@ def bx_packed_weight(w, role=0):
     return reg.get(w, 1, int(role))
 
 
-def conv_bx_raw(x, w, dil=1, dgrad=False, residual=None, packed=None):
+_BX_WS = {}
+
+
+def _bx_workspace(dev, nbytes):
+    """Per-(device, stream) scratch for the partial tiles of a split-K mas_conv_bx_train launch (grown on demand, never shrunk; the
+    launches of one stream run in order, so they can share it)."""
+    key = (dev, torch.cuda.current_stream(dev).cuda_stream)
+    ws = _BX_WS.get(key)
+    if ws is None or ws.numel() < nbytes:
+        ws = _BX_WS[key] = torch.empty(int(nbytes * 1.25) + 256, dtype=torch.uint8, device=dev)
+    return ws
+
+
+def conv_bx_train_plan(x_shape, w_shape, dil=1, dgrad=False):
+    """(ksplit, tile_w, workgroups) mas_conv_bx_train would choose for this product (mas_conv_bx_train_plan)."""
+    import ctypes
+    Cout, Cin, ks, _ = w_shape
+    K, M = (Cout, Cin) if dgrad else (Cin, Cout)
+    N, _, H, W = x_shape
+    out = (ctypes.c_int * 3)()
+    _lib.check(_lib.load().mas_conv_bx_train_plan(N, K, H, W, M, ks, dil, out), "mas_conv_bx_train_plan")
+    return int(out[0]), int(out[1]), int(out[2])
+
+
+def conv_bx_raw(x, w, dil=1, dgrad=False, residual=None, packed=None, ksplit=0, tile_w=0):
     """The bare stride-1 product of a training step on csrc/conv_bx.hip: dgrad False: y = conv2d(x, w, padding = dil (k 3) / 0 (k 1),
-    dilation); dgrad True: x is dY [N,Cout,H,W] and the result dX [N,Cin,H,W] (+ residual: the gradient of x's other consumer)."""
+    dilation); dgrad True: x is dY [N,Cout,H,W] and the result dX [N,Cin,H,W] (+ residual: the gradient of x's other consumer).
+    ksplit / tile_w: 0 = the library's work-splitting plan (mas_conv_bx_train_plan); explicit values for sweeps and tests.
+    Operands must be finite and within 2^-100 < |v| < 2^127 (csrc/bx_split.h): an Inf operand yields NaN where the f32 pipe would
+    propagate Inf (h = Inf, m = Inf - Inf), NaN stays NaN, values below 2^-100 lose their third term (relative error <= 2^-16)."""
     _need(x, "x", torch.float32)
     _need(w, "w", torch.float32)
     Cout, Cin, ks, _ = w.shape
@@ -1434,18 +1461,26 @@ def conv_bx_raw(x, w, dil=1, dgrad=False, residual=None, packed=None):
             raise ValueError("residual %s does not match the output %s" % (tuple(residual.shape), tuple(y.shape)))
     if packed is None:
         packed = conv_bx_pack(w, int(dgrad))
+    lib = _lib.load()
+    if not ksplit:
+        ksplit = conv_bx_train_plan(x.shape, w.shape, dil, dgrad)[0]
+    if ksplit > 1 and (y.numel() % 4 != 0):
+        ksplit = 1                                   # (the reduction pass walks 16-byte groups)
+    ws = None
     with torch.cuda.device(x.device):
-        _lib.check(_lib.load().mas_conv_bx_fwd(x.data_ptr(), packed.data_ptr(), N, K, H, W, M, ks, 1, dil, None, None, _opt(residual), 0,
-                                               y.data_ptr(), _stream(x)), "mas_conv_bx_fwd")
+        if ksplit > 1:
+            ws = _bx_workspace(x.device, int(lib.mas_conv_bx_train_workspace_bytes(N, M, H, W, ksplit)))
+        _lib.check(lib.mas_conv_bx_train(x.data_ptr(), packed.data_ptr(), N, K, H, W, M, ks, dil, _opt(residual), y.data_ptr(), int(ksplit),
+                                         int(tile_w), _opt(ws), ws.numel() if ws is not None else 0, _stream(x)), "mas_conv_bx_train")
     return y
 
 
 def conv_bx_train_ok(x_shape, w_shape, stride, dil, dgrad):
-    """Does the split-bf16 kernel take this product of a training step, and is it the faster one?  Stride 1 only; MAS_TRAIN_BX =
-    auto (default): every 1x1 product, 3x3 products on planes of at least 96 x 96 pixels or with at least 320 tiles (on the 48 x 48
-    planes a 3x3 layer has 192 (256 channels) / 384 (512 channels) tiles of which a quarter is padding: with 192 the persistent
-    stream-K kernel stays 4 % ahead, with 384 the split-bf16 kernel is -- tools/bx_train_table.py, profiles/r04/k_bx_train_table.md),
-    all: wherever supported, off: never."""
+    """Does the split-bf16 kernel take this product of a training step?  Stride 1 only.  MAS_TRAIN_BX = auto (default): every
+    supported stride-1 product -- launches with fewer workgroups than the chip has slots (the 48 x 48 planes) split their K chunks
+    over several workgroups and use 16 x 16 pixel tiles (mas_conv_bx_train_plan; profiles/r05/k_bx_train_table.md); r04: round 4's
+    rule (1x1 everywhere, 3x3 on planes of at least 96 x 96 or with at least 320 tiles -- the others on the persistent stream-K
+    kernel), for A/B runs; off: never."""
     mode = os.environ.get("MAS_TRAIN_BX", "auto")
     if mode == "off" or stride != 1:
         return False
@@ -1454,9 +1489,10 @@ def conv_bx_train_ok(x_shape, w_shape, stride, dil, dgrad):
     N, _, H, W = x_shape
     if not _lib.load().mas_conv_bx_supported(ks, 1, dil, K, M, H, W):
         return False
-    if mode == "all" or ks == 1 or H * W >= 96 * 96:
+    if mode != "r04" or ks == 1 or H * W >= 96 * 96:
         return True
-    return N * ((H + 7) // 8) * ((W + 31) // 32) * ((M + 63) // 64) >= 320      # 3x3 on a small plane: with enough 64 x (8 x 32) tiles
+    return N * ((H + 7) // 8) * ((W + 31) // 32) * ((M + 63) // 64) >= 320
+
 
 def packed_weight(w, stride=1, dgrad=False):
     """The mas_conv_sk image of weight `w` for one role, kept up to date across optimizer steps (see _PackRegistry)."""

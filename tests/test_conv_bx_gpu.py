@@ -273,3 +273,101 @@ def test_conv_bx_dual_matches_the_two_convolutions(Ca, Cb, Cout, N, H, W):
     err, err2 = float((y.double() - ref).abs().max()), float((two.double() - ref).abs().max())
     assert err <= 2e-5 * sc, (err, sc)
     assert err <= 2.0 * err2 + 2e-6 * sc, (err, err2)
+
+
+SPLIT_CASES = [
+    # Cin, Cout, k, dil, N, H, W -- the layers of the 48 x 48 (49 x 49) planes of the training crop, scaled where a full one would only add time
+    (1024, 256, 1, 1, 4, 48, 48),       # layer3 conv1: 144 workgroups for 512 slots
+    (2048, 512, 1, 1, 2, 48, 48),
+    (1280, 256, 1, 1, 2, 49, 49),       # ASPP projection on the 769-crop plane (odd plane: out % 4 != 0 falls back to one part)
+    (256, 256, 3, 1, 4, 48, 48),        # layer3 conv2: 16 x 16 tiles, no padded quarter
+    (512, 512, 3, 2, 2, 48, 48),        # layer4 conv2, dilation 2
+    (256, 256, 3, 1, 1, 49, 49),
+    (128, 128, 3, 1, 2, 97, 97),        # 97 x 97: 49 square tiles against 52 wide ones
+    (72, 64, 3, 1, 1, 20, 36),          # 9 chunks of 8 channels, partial tiles of both shapes
+    (200, 136, 1, 1, 1, 24, 40),        # Cin = 6.25 chunks, Cout = one M tile + 8 rows
+]
+
+
+@pytest.mark.parametrize("Cin,Cout,k,dil,N,H,W", SPLIT_CASES)
+def test_split_k_and_square_tiles_match_conv2d(Cin, Cout, k, dil, N, H, W):
+    """mas_conv_bx_train: every (ksplit, tile shape) of a product gives the float64 result at the bar of the unsplit kernel, both
+    roles (forward; input gradient + the other consumer's gradient as residual), run-to-run identical; the library's own plan is
+    one of them."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from mulactseg_amd import ops
+    torch.manual_seed(Cin + 3 * Cout + k + dil + H)
+    w = torch.randn(Cout, Cin, k, k, device='cuda') / (Cin * k * k) ** 0.5
+    x = torch.randn(N, Cin, H, W, device='cuda')
+    dy = torch.randn(N, Cout, H, W, device='cuda')
+    other = torch.randn(N, Cin, H, W, device='cuda')
+    pad = dil if k == 3 else 0
+    ref_y = F.conv2d(x.double(), w.double(), None, 1, pad, dil)
+    ref_dx = torch.nn.grad.conv2d_input(x.shape, w.double(), dy.double(), 1, pad, dil) + other.double()
+    plan = ops.conv_bx_train_plan(x.shape, w.shape, dil, False)
+    assert plan[0] >= 1 and plan[1] in (16, 32)
+    pk0, pk1 = ops.conv_bx_pack(w, 0), ops.conv_bx_pack(w, 1)
+    nch = -(-Cin // (32 if k == 1 else 8))
+    for ks in sorted({1, 2, 3, min(5, nch), plan[0]}):
+        if ks > nch:
+            continue
+        for tw in ((32, 16) if k == 3 else (32,)):
+            y = ops.conv_bx_raw(x, w, dil, packed=pk0, ksplit=ks, tile_w=tw)
+            err = float((y.double() - ref_y).abs().max())
+            assert err <= 2e-5 * float(ref_y.abs().max()), (ks, tw, err)
+            assert torch.equal(y, ops.conv_bx_raw(x, w, dil, packed=pk0, ksplit=ks, tile_w=tw)), (ks, tw)
+    ncd = -(-Cout // (32 if k == 1 else 8))
+    for ks in sorted({1, 2, min(4, ncd)}):
+        dx = ops.conv_bx_raw(dy, w, dil, dgrad=True, residual=other, packed=pk1, ksplit=ks, tile_w=16 if k == 3 else 32)
+        err = float((dx.double() - ref_dx).abs().max())
+        assert err <= 2e-5 * float(ref_dx.abs().max()), (ks, err)
+    y_auto = ops.conv_bx_raw(x, w, dil, packed=pk0)
+    assert float((y_auto.double() - ref_y).abs().max()) <= 2e-5 * float(ref_y.abs().max())
+
+
+def test_split_k_exact_on_integers():
+    """Integer data: every partial tile and their sum are exact, so all plans give the same bits as float64 conv2d."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from mulactseg_amd import ops
+    g = torch.Generator(device='cuda').manual_seed(11)
+    for (Cin, Cout, k, dil, N, H, W) in ((512, 128, 1, 1, 2, 48, 48), (128, 64, 3, 1, 2, 48, 48), (96, 128, 3, 2, 1, 33, 50)):
+        w = torch.randint(-3, 4, (Cout, Cin, k, k), generator=g, device='cuda').float()
+        x = torch.randint(-4, 5, (N, Cin, H, W), generator=g, device='cuda').float()
+        res = torch.randint(-9, 10, (N, Cout, H, W), generator=g, device='cuda').float()
+        ref = F.conv2d(x.double(), w.double(), None, 1, dil if k == 3 else 0, dil).float()
+        for ks in (1, 2, 3, 4):
+            for tw in ((32, 16) if k == 3 else (32,)):
+                assert torch.equal(ops.conv_bx_raw(x, w, dil, ksplit=ks, tile_w=tw), ref), (Cin, k, ks, tw)
+        # the residual operand rides on part 0 only
+        wt = torch.randint(-3, 4, (Cin, Cout, k, k), generator=g, device='cuda').float()      # (dgrad role: x is the "dY" of a Cin <- Cout layer)
+        ref_dx = torch.nn.grad.conv2d_input((N, Cout, H, W), wt.double(), x.double(), 1, dil if k == 3 else 0, dil).float() + res
+        for ks in (1, 3):
+            assert torch.equal(ops.conv_bx_raw(x, wt, dil, dgrad=True, residual=res, ksplit=ks), ref_dx), (Cin, k, ks)
+
+
+def test_non_finite_and_tiny_operands_behave_as_documented():
+    """ADVICE r4 (csrc/bx_split.h): NaN stays NaN; an Inf operand gives NaN (h = Inf, m = Inf - Inf) where the f32 pipe would propagate
+    Inf -- both poison exactly the outputs that read the bad pixel and nothing else; operands below 2^-100 lose their third term
+    only (relative error <= 2^-15 instead of 2^-23); zeros times garbage-free padding stay zeros."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from mulactseg_amd import ops
+    torch.manual_seed(2)
+    w = torch.randn(64, 32, 1, 1, device='cuda')
+    x = torch.randn(1, 32, 8, 32, device='cuda')
+    clean = ops.conv_bx_raw(x, w)
+    for bad in (float('nan'), float('inf'), float('-inf')):
+        xb = x.clone()
+        xb[0, 3, 2, 5] = bad
+        y = ops.conv_bx_raw(xb, w)
+        assert bool(torch.isnan(y[0, :, 2, 5]).all())
+        keep = torch.ones_like(y, dtype=torch.bool)
+        keep[0, :, 2, 5] = False
+        assert torch.equal(y[keep], clean[keep])
+    tiny = x * 1e-35                                              # 2^-116: below the range the three-term split covers
+    yt = ops.conv_bx_raw(tiny, w)
+    ref = F.conv2d(tiny.double(), w.double())
+    assert bool(torch.isfinite(yt).all())
+    assert float((yt.double() - ref).abs().max()) <= 2.0 ** -15 * float(ref.abs().max())
