@@ -181,6 +181,26 @@ int mas_partial_loss_bwd_lowres(const float* zq, int h, int w, const void* spx, 
 /* out[i] = (float)(fix[i] * 2^-frac_bits) */
 int mas_fix_to_float(const int64_t* fix, int64_t n, int frac_bits, float* out, void* stream);
 
+/* Fused forms: ONE call launches everything a direction needs (what the loss modules of mulactseg_amd/utils/loss.py run).
+ * Forward = a prep launch (zero the accumulators and the (superpixel, class) table; `targets` [N,S,cols_stored] u8 multi-hot rows ->
+ * bit masks over the first cols_used columns -- or pass ready `bits` [N,S] and targets = NULL), the forward scan, and the group
+ * finalize whose last workgroup writes `losses` ([3], or [4] with `weights` [3]: the fourth is (w0*ce + w1*mc) + w2*group).
+ * losses = NULL: no values -- a data-parallel caller all-reduces the first 8 u64 words of `work` (the accumulators) and then calls
+ * mas_loss_values[_weighted] on them.  h, w > 0: z is the model's quarter-resolution tensor [N,C,h,w] (as mas_partial_loss_fwd_lowres);
+ * h = w = 0: z [N,C,H,W].  `work`: mas_partial_loss_work_bytes(N, S, C, flags) bytes, 8-byte aligned, NOT initialised by the
+ * caller; layout acc u64[8] | gmax u64[N,S,C] (group flags only) | bits u32[N,S]; it is the state the backward call reads.
+ * Backward = (h > 0: a memset of `dzq_fix` [N,C,h,w] i64 scratch) + the backward scan, which forms its scale factors itself from the
+ * accumulators in `work` and `grad` ([3] upstream gradients of (ce, mc, group); with `weights`: [1], dL/dtotal) + (h > 0: the
+ * conversion into dz = dzq [N,C,h,w] f32).  h = 0: dz [N,C,H,W], dzq_fix unused.  bits = NULL: the masks the forward call left in
+ * `work`.  Same kernels and bits as the step-by-step entry points above. */
+size_t mas_partial_loss_work_bytes(int N, int S, int C, int flags);
+int mas_partial_loss_fwd_fused(const float* z, int h, int w, const void* spx, int spx_dtype, const uint8_t* mask, const uint8_t* targets,
+                               int cols_stored, int cols_used, const uint32_t* bits, int N, int C, int H, int W, int S, float invT, int flags,
+                               const float* weights, void* work, size_t work_bytes, float* losses, void* stream);
+int mas_partial_loss_bwd_fused(const float* z, int h, int w, const void* spx, int spx_dtype, const uint8_t* mask, const uint32_t* bits,
+                               const void* work, const float* grad, const float* weights, int N, int C, int H, int W, int S, float invT,
+                               int flags, float* dz, int64_t* dzq_fix, void* stream);
+
 /* =============================================================================================
  * K4  ordering of the region scores and the budgeted selection walk
  * ============================================================================================= */

@@ -120,6 +120,9 @@ SIGNATURES = {
     "mas_loss_values_weighted": (_i, [_vp, _i, _vp, _vp, _vp]),
     "mas_loss_scales_weighted": (_i, [_vp, _vp, _vp, _i, _vp, _vp]),
     "mas_fix_to_float": (_i, [_vp, _i64, _i, _vp, _vp]),
+    "mas_partial_loss_work_bytes": (_c.c_size_t, [_i, _i, _i, _i]),
+    "mas_partial_loss_fwd_fused": (_i, [_vp, _i, _i, _vp, _i, _vp, _vp, _i, _i, _vp, _i, _i, _i, _i, _i, _f, _i, _vp, _vp, _c.c_size_t, _vp, _vp]),
+    "mas_partial_loss_bwd_fused": (_i, [_vp, _i, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _i, _vp, _vp, _vp]),
 }
 
 _lib = None

@@ -614,8 +614,10 @@ inline BxPlan bx_plan(int N, int Cin, int H, int W, int Cout, int ksize, int dil
                                         : (long long)N * ((W + pl.tw - 1) / pl.tw) * ((H + 256 / pl.tw - 1) / (256 / pl.tw));
     const long long wg1 = 8 * ((ptiles + 7) / 8) * ((Cout + BM - 1) / BM);
     const int ck = ksize == 1 ? 32 : 8, nch = (Cin + ck - 1) / ck;
-    // cost of a plan in units of one chunk of one workgroup: rounds of 512 resident workgroups x (chunks per part + the fixed
-    // prologue / epilogue of a workgroup) + the reduction pass (its bytes at ~4 TB/s against a chunk's time)
+    // cost of a plan in microseconds: (workgroups / 512 resident slots, at least one "round") x (chunks per part + the fixed
+    // prologue / epilogue of a workgroup) x the time of a chunk + the reduction pass (launch gap + its bytes at ~4 TB/s).  The
+    // constants are fitted to tools/bx_splitk_sweep.py (profiles/r05/k_bx_splitk.md): the plan is within 4 % of the best (ksplit,
+    // tile) of every layer of the training step.
     const double fixed = ksize == 1 ? 3.0 : 1.2;
     const double chunk_us = ksize == 1 ? 2.0 : 5.0;
     const double out_mb = (double)N * Cout * H * W * 4e-6;
@@ -624,11 +626,12 @@ inline BxPlan bx_plan(int N, int Cin, int H, int W, int Cout, int ksize, int dil
     for (int ks = 1; ks <= 8; ++ks) {
         if (ks > 1 && nch / ks < 4) break;
         const long long wgs = wg1 * ks;
-        const double rounds = (double)((wgs + 511) / 512);
+        // (workgroups beyond the resident ones start as others end: no whole second round)
+        const double rounds = wgs <= 512 ? 1.0 : (double)wgs / 512.0;
         // (a CU that holds one workgroup instead of two runs it faster, but not twice as fast)
         const double alone = wgs <= 256 ? 0.7 : 1.0;
         double cost = rounds * (((nch + ks - 1) / ks) + fixed) * chunk_us * alone;
-        if (ks > 1) cost += 4.0 + (ks + 1) * out_mb / 4.0;          // launch gap + bytes of the reduction (MB / (4 TB/s) = us)
+        if (ks > 1) cost += 4.0 + (ks + 1) * out_mb / 4.0;
         if (cost < best * 0.97) { best = cost; pl.ksplit = ks; }
     }
     pl.wgs = (int)(wg1 * pl.ksplit);

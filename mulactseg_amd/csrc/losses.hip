@@ -275,13 +275,20 @@ __global__ __launch_bounds__(kThreads) void k_partial_loss_fwd(const float* __re
     }
 }
 
+// acc[ACC_DONE]: workgroups of k_group_finalize that have added their sums (the fused entry point: the LAST one turns the sums into
+// the loss values -- no k_loss_values launch)
+constexpr int ACC_DONE = 7;
+__device__ __forceinline__ void loss_values_of(const mas_u64* acc, int flags, const float* w, float* out);
+
 __global__ __launch_bounds__(kThreads) void k_group_finalize(const mas_u64* __restrict__ gmax, long long n_entries,
-                                                              mas_u64* __restrict__ acc) {
+                                                              mas_u64* __restrict__ acc, int flags, const float* __restrict__ w,
+                                                              float* __restrict__ values) {
     __shared__ mas_u64 s_red[kThreads / MAS_WAVE][2];
+    __shared__ int s_last;
     mas_u64 sum = 0, cnt = 0;
     for (long long i = (long long)blockIdx.x * kThreads + threadIdx.x; i < n_entries; i += (long long)gridDim.x * kThreads) {
-        const mas_u64 w = gmax[i];
-        const unsigned pb = (unsigned)(w >> 32);
+        const mas_u64 w64 = gmax[i];
+        const unsigned pb = (unsigned)(w64 >> 32);
         if (pb) {            // a (superpixel, class) with target bit set whose max prob is non-zero
             const float l = -mas_logf(mas_u2f(pb) + 1e-8f);
             sum += mas_fix(l, MAS_LOSS_FRAC);
@@ -298,8 +305,37 @@ __global__ __launch_bounds__(kThreads) void k_group_finalize(const mas_u64* __re
     __syncthreads();
     if (threadIdx.x < 2) {
         mas_u64 a = 0;
-        for (int w = 0; w < kThreads / MAS_WAVE; ++w) a += s_red[w][threadIdx.x];
+        for (int wv = 0; wv < kThreads / MAS_WAVE; ++wv) a += s_red[wv][threadIdx.x];
         if (a) atomicAdd(&acc[threadIdx.x == 0 ? ACC_SUM_GROUP : ACC_N_GROUP], a);
+    }
+    if (!values) return;
+    // the last workgroup to arrive sees every other workgroup's sums: device-scope release (fence + counter add) / acquire
+    __threadfence();
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const mas_u64 done = atomicAdd(&acc[ACC_DONE], (mas_u64)1);
+        s_last = done == (mas_u64)(gridDim.x - 1);
+    }
+    __syncthreads();
+    if (s_last && threadIdx.x == 0) {
+        __threadfence();
+        mas_u64 a[8];
+        for (int i = 0; i < 7; ++i) a[i] = __hip_atomic_load(&acc[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        loss_values_of(a, flags, w, values);
+    }
+}
+
+// the fused forward's first launch: zero the accumulators and the (superpixel, class) table, and (targets != NULL) turn the
+// multi-hot target rows into bit masks -- one launch instead of a memset and k_target_bits
+__global__ __launch_bounds__(kThreads) void k_loss_prep(mas_u64* __restrict__ zero64, long long n_zero, const unsigned char* __restrict__ tgt,
+                                                         long long n_rows, int cols_stored, int cols_used, unsigned* __restrict__ bits) {
+    const long long i = (long long)blockIdx.x * kThreads + threadIdx.x;
+    if (i < n_zero) zero64[i] = 0;
+    if (tgt && i < n_rows) {
+        const unsigned char* t = tgt + i * cols_stored;
+        unsigned b = 0;
+        for (int c = 0; c < cols_used; ++c) b |= (t[c] ? 1u : 0u) << c;
+        bits[i] = b;
     }
 }
 
@@ -311,29 +347,17 @@ __device__ __forceinline__ float loss_value(mas_u64 sum, mas_u64 n, int one = 1)
     return (float)(((double)sum * s.d) / (double)(n + one));
 }
 
-__global__ void k_loss_values(const mas_u64* __restrict__ acc, int flags, float* __restrict__ out) {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+// losses[0..2] = (ce, mc, group); with weights also losses[3] = (w_ce * ce + w_mc * mc) + w_group * group, every product and sum
+// rounded once in f32 -- the operation order of `coeff * ce_loss + coeff_mc * mc_loss + coeff_gm * group_loss`
+// (trainer/active_joint_multi_predignore_lossdecomp.py:104), so the value equals the torch expression bit for bit.
+__device__ __forceinline__ void loss_values_of(const mas_u64* acc, int flags, const float* w, float* out) {
     if (flags & MAS_LOSS_TCE) {
         out[0] = loss_value(acc[ACC_SUM_CE], acc[ACC_N_CE], 0);
         out[1] = 0.0f;
         out[2] = 0.0f;
+        if (w) out[3] = (w[0] * out[0] + w[1] * 0.0f) + w[2] * 0.0f;
         return;
     }
-    if (flags & MAS_LOSS_DECOMP) {
-        out[0] = loss_value(acc[ACC_SUM_CE], acc[ACC_N_CE]);
-        out[1] = loss_value(acc[ACC_SUM_MC], acc[ACC_N_MC]);
-    } else {
-        out[0] = loss_value(acc[ACC_SUM_CE] + acc[ACC_SUM_MC], acc[ACC_N_CE] + acc[ACC_N_MC]);
-        out[1] = 0.0f;
-    }
-    out[2] = loss_value(acc[ACC_SUM_GROUP], acc[ACC_N_GROUP]);
-}
-
-// The trainer's objective in the same launch: total = (w_ce * ce + w_mc * mc) + w_group * group, every product and sum rounded
-// once in f32 -- the operation order of `coeff * ce_loss + coeff_mc * mc_loss + coeff_gm * group_loss`
-// (trainer/active_joint_multi_predignore_lossdecomp.py:104), so the value equals the torch expression bit for bit.
-__global__ void k_loss_values_weighted(const mas_u64* __restrict__ acc, int flags, const float* __restrict__ w, float* __restrict__ out) {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
     float ce, mc;
     if (flags & MAS_LOSS_DECOMP) {
         ce = loss_value(acc[ACC_SUM_CE], acc[ACC_N_CE]);
@@ -346,44 +370,50 @@ __global__ void k_loss_values_weighted(const mas_u64* __restrict__ acc, int flag
     out[0] = ce;
     out[1] = mc;
     out[2] = gr;
-    out[3] = (w[0] * ce + w[1] * mc) + w[2] * gr;
+    if (w) out[3] = (w[0] * ce + w[1] * mc) + w[2] * gr;
 }
 
-// scale_k = (dL/dtotal * w_k) / (1 + n_k): the chain rule through the weighted sum, in the order autograd applies it
-__global__ void k_loss_scales_weighted(const mas_u64* __restrict__ acc, const float* __restrict__ grad_total, const float* __restrict__ w,
-                                       int flags, float* __restrict__ scale) {
+__global__ void k_loss_values(const mas_u64* __restrict__ acc, int flags, float* __restrict__ out) {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
-    const float g = grad_total[0];
-    if (flags & MAS_LOSS_DECOMP) {
-        scale[0] = (g * w[0]) / (float)(acc[ACC_N_CE] + 1);
-        scale[1] = (g * w[1]) / (float)(acc[ACC_N_MC] + 1);
-    } else {
-        const float sc = (g * w[0]) / (float)(acc[ACC_N_CE] + acc[ACC_N_MC] + 1);
-        scale[0] = sc;
-        scale[1] = sc;
-    }
-    scale[2] = (g * w[2]) / (float)(acc[ACC_N_GROUP] + 1);
+    loss_values_of(acc, flags, nullptr, out);
 }
 
-// scale_k = upstream_k / (1 + n_k)   (f32 division, correctly rounded)
-__global__ void k_loss_scales(const mas_u64* __restrict__ acc, const float* __restrict__ grad_out, int flags,
-                              float* __restrict__ scale) {
+__global__ void k_loss_values_weighted(const mas_u64* __restrict__ acc, int flags, const float* __restrict__ w, float* __restrict__ out) {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    loss_values_of(acc, flags, w, out);
+}
+
+// scale_k = upstream_k / (1 + n_k) (f32 division, correctly rounded); with weights: grad[0] is dL/dtotal and
+// scale_k = (dL/dtotal * w_k) / (1 + n_k) -- the chain rule through the weighted sum, in the order autograd applies it
+__device__ __forceinline__ void loss_scales_of(const mas_u64* acc, const float* grad, const float* w, int flags, float* scale) {
     if (flags & MAS_LOSS_TCE) {
-        scale[0] = grad_out[0] / (float)acc[ACC_N_CE];
+        scale[0] = (w ? grad[0] * w[0] : grad[0]) / (float)acc[ACC_N_CE];
         scale[1] = 0.0f;
         scale[2] = 0.0f;
         return;
     }
+    const float g0 = w ? grad[0] * w[0] : grad[0], g1 = w ? grad[0] * w[1] : grad[1], g2 = w ? grad[0] * w[2] : grad[2];
     if (flags & MAS_LOSS_DECOMP) {
-        scale[0] = grad_out[0] / (float)(acc[ACC_N_CE] + 1);
-        scale[1] = grad_out[1] / (float)(acc[ACC_N_MC] + 1);
+        scale[0] = g0 / (float)(acc[ACC_N_CE] + 1);
+        scale[1] = g1 / (float)(acc[ACC_N_MC] + 1);
     } else {
-        const float s = grad_out[0] / (float)(acc[ACC_N_CE] + acc[ACC_N_MC] + 1);
-        scale[0] = s;
-        scale[1] = s;
+        const float sc = g0 / (float)(acc[ACC_N_CE] + acc[ACC_N_MC] + 1);
+        scale[0] = sc;
+        scale[1] = sc;
     }
-    scale[2] = grad_out[2] / (float)(acc[ACC_N_GROUP] + 1);
+    scale[2] = g2 / (float)(acc[ACC_N_GROUP] + 1);
+}
+
+__global__ void k_loss_scales_weighted(const mas_u64* __restrict__ acc, const float* __restrict__ grad_total, const float* __restrict__ w,
+                                       int flags, float* __restrict__ scale) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    loss_scales_of(acc, grad_total, w, flags, scale);
+}
+
+__global__ void k_loss_scales(const mas_u64* __restrict__ acc, const float* __restrict__ grad_out, int flags,
+                              float* __restrict__ scale) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    loss_scales_of(acc, grad_out, nullptr, flags, scale);
 }
 
 // LOWRES: `dz` is the caller-zeroed int64 fixed-point accumulator dzq_fix [N,C,h,w] (MAS_GRAD_FRAC fractional bits): every
@@ -397,7 +427,8 @@ __global__ __launch_bounds__(kThreads) void k_partial_loss_bwd(const float* __re
                                                                 const mas_u64* __restrict__ gmax,
                                                                 const float* __restrict__ scale, int C, int H, int W, int S,
                                                                 float invT, int flags, int tiles_x, int tiles_y,
-                                                                float* __restrict__ dz, const LowRes lr) {
+                                                                float* __restrict__ dz, const LowRes lr, const mas_u64* __restrict__ acc,
+                                                                const float* __restrict__ grad, const float* __restrict__ gw) {
     __shared__ int qcount[2];
     __shared__ unsigned short queue[kTilePx];
     // LOWRES: the quarter-resolution footprint of a 4 x 256 tile (<= 4 rows x 72 columns per class for the x4 ratios of the
@@ -423,7 +454,12 @@ __global__ __launch_bounds__(kThreads) void k_partial_loss_bwd(const float* __re
     const unsigned char* mb = mask + (size_t)n * HW;
     const unsigned* bb = bits + (size_t)n * S;
     const mas_u64* gm = gmax + (size_t)n * S * C;
-    const float a_ce = scale[0] * invT, a_mc = scale[1] * invT, g6 = scale[2] * invT;
+    // scale == NULL (the fused entry points): every workgroup forms the three scale factors itself from the accumulators of the
+    // forward scan and the upstream gradient (three divisions on uniform values) -- the k_loss_scales launch is gone
+    float sc3[3];
+    if (scale) { sc3[0] = scale[0]; sc3[1] = scale[1]; sc3[2] = scale[2]; }
+    else loss_scales_of(acc, grad, gw, flags, sc3);
+    const float a_ce = sc3[0] * invT, a_mc = sc3[1] * invT, g6 = sc3[2] * invT;
 
     // phase 1: dz = 0 over the whole tile (streaming 16-B stores) while the selected pixels are compacted
     tile_compact<CT, EXACT, VEC, !LOWRES>(mb, C, H, W, HW, tx, ty, queue, qcount, db);
@@ -533,6 +569,7 @@ struct LossArgs {
     int N, C, H, W, S; float invT; int flags;
     mas_u64* gmax; mas_u64* acc; const float* scale; float* dz;
     int h = 0, w = 0;           // > 0: `z` is the quarter-resolution tensor [N,C,h,w] (LOWRES kernels)
+    const float* grad = nullptr; const float* gw = nullptr;     // backward with scale == NULL: upstream gradient(s) and optional weights
 };
 
 template <int CT, bool EXACT, typename IdT>
@@ -553,7 +590,7 @@ int launch_loss(const LossArgs& a, bool backward, hipStream_t st) {
                                a.bits, a.C, a.H, a.W, a.S, a.invT, a.flags, tiles_x, tiles_y, a.gmax, a.acc, lr);                        \
         else                                                                                                                            \
             hipLaunchKernelGGL((k_partial_loss_bwd<CT, EXACT, IdT, VECV, LOWV>), grid, block, 0, st, a.z, ids, a.mask, a.bits, a.gmax,   \
-                               a.scale, a.C, a.H, a.W, a.S, a.invT, a.flags, tiles_x, tiles_y, a.dz, lr);                                \
+                               a.scale, a.C, a.H, a.W, a.S, a.invT, a.flags, tiles_x, tiles_y, a.dz, lr, a.acc, a.grad, a.gw);           \
     } while (0)
     if (low) { if (vec) MAS_LAUNCH_LOSS(true, true); else MAS_LAUNCH_LOSS(false, true); }
     else { if (vec) MAS_LAUNCH_LOSS(true, false); else MAS_LAUNCH_LOSS(false, false); }
@@ -611,7 +648,8 @@ extern "C" int mas_group_finalize(const uint64_t* gmax, int64_t n_entries, uint6
     long long nblk = (n_entries + kThreads - 1) / kThreads;
     if (nblk > 1024) nblk = 1024;
     hipLaunchKernelGGL(k_group_finalize, dim3((unsigned)nblk), dim3(kThreads), 0, static_cast<hipStream_t>(stream),
-                       reinterpret_cast<const mas_u64*>(gmax), (long long)n_entries, reinterpret_cast<mas_u64*>(acc));
+                       reinterpret_cast<const mas_u64*>(gmax), (long long)n_entries, reinterpret_cast<mas_u64*>(acc), 0,
+                       static_cast<const float*>(nullptr), static_cast<float*>(nullptr));
     return mas_launch_status();
 }
 
@@ -694,4 +732,95 @@ extern "C" int mas_fix_to_float(const int64_t* fix, int64_t n, int frac_bits, fl
     hipLaunchKernelGGL(k_fix_to_float, dim3((unsigned)((n + kThreads - 1) / kThreads)), dim3(kThreads), 0, static_cast<hipStream_t>(stream),
                        reinterpret_cast<const long long*>(fix), (long long)n, frac_bits, out);
     return mas_launch_status();
+}
+
+// ---- fused forms: one call = every launch of a direction ---------------------------------------------------------------------------
+// forward : k_loss_prep (zero acc + table, target rows -> bit masks)  ->  forward scan  ->  k_group_finalize whose last workgroup
+//           writes the loss values (3 launches; were: memset, k_target_bits, scan, k_group_finalize, k_loss_values[_weighted])
+// backward: (LOWRES: memset of the fixed-point accumulator)  ->  backward scan that forms its scale factors itself  ->  (LOWRES:
+//           k_fix_to_float)   (1 / 3 launches; were: k_loss_scales[_weighted], scan / memset, k_loss_scales, scan, k_fix_to_float)
+// Same kernels, same arithmetic, same bits as the step-by-step entry points above (tests/test_losses_gpu.py compares both with
+// oracle/exact.c).  Reference: trainer/active_joint_multi_predignore_lossdecomp.py:21-72, ..._mclossablation2.py:22-79.
+namespace {
+struct WorkLayout { size_t gmax_off, bits_off, bytes; };
+inline WorkLayout work_layout(int N, int S, int C, int flags) {
+    WorkLayout L;
+    L.gmax_off = 8 * sizeof(mas_u64);
+    const size_t g = (flags & MAS_LOSS_GROUP) ? (size_t)N * S * C * sizeof(mas_u64) : 0;
+    L.bits_off = L.gmax_off + g;
+    L.bytes = L.bits_off + (size_t)N * S * sizeof(unsigned);
+    return L;
+}
+}  // namespace
+
+extern "C" size_t mas_partial_loss_work_bytes(int N, int S, int C, int flags) {
+    if (N <= 0 || S <= 0 || C <= 0) return 0;
+    return work_layout(N, S, C, flags).bytes;
+}
+
+extern "C" int mas_partial_loss_fwd_fused(const float* z, int h, int w, const void* spx, int spx_dtype, const uint8_t* mask,
+                                          const uint8_t* targets, int cols_stored, int cols_used, const uint32_t* bits, int N, int C, int H,
+                                          int W, int S, float invT, int flags, const float* weights, void* work, size_t work_bytes,
+                                          float* losses, void* stream) {
+    if (!z || !spx || !mask || !work || (!targets && !bits)) return MAS_ERR_NULL;
+    if (N <= 0 || S <= 0 || H <= 0 || W <= 0) return MAS_ERR_SHAPE;
+    if (C < 2 || C > MAS_MAX_CLASSES) return MAS_ERR_CLASSES;
+    if ((h > 0) != (w > 0) || h > H || w > W) return MAS_ERR_SHAPE;
+    if (targets && (cols_stored <= 0 || cols_used < 1 || cols_used > cols_stored || cols_used > MAS_MAX_CLASSES)) return MAS_ERR_CLASSES;
+    const WorkLayout L = work_layout(N, S, C, flags);
+    if (work_bytes < L.bytes) return MAS_ERR_WORKSPACE;
+    if ((uintptr_t)work % 8 != 0) return MAS_ERR_ALIGN;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    unsigned char* wb = static_cast<unsigned char*>(work);
+    mas_u64* acc = reinterpret_cast<mas_u64*>(wb);
+    mas_u64* gmax = (flags & MAS_LOSS_GROUP) ? reinterpret_cast<mas_u64*>(wb + L.gmax_off) : nullptr;
+    unsigned* wbits = reinterpret_cast<unsigned*>(wb + L.bits_off);
+    const long long n_zero = (long long)(L.bits_off / sizeof(mas_u64)), n_rows = (long long)N * S;
+    const long long n_prep = n_zero > n_rows ? n_zero : n_rows;
+    hipLaunchKernelGGL(k_loss_prep, dim3((unsigned)((n_prep + kThreads - 1) / kThreads)), dim3(kThreads), 0, st, acc, n_zero, targets, n_rows,
+                       cols_stored, cols_used, wbits);
+    if (int e = mas_launch_status()) return e;
+    LossArgs a{z, spx, mask, targets ? wbits : bits, N, C, H, W, S, invT, flags, gmax, acc, nullptr, nullptr, h > 0 ? h : 0, h > 0 ? w : 0};
+    if (int e = dispatch_loss(a, spx_dtype, false, st)) return e;
+    if (gmax) {
+        const long long n_entries = (long long)N * S * C;
+        long long nblk = (n_entries + kThreads - 1) / kThreads;
+        if (nblk > 1024) nblk = 1024;
+        hipLaunchKernelGGL(k_group_finalize, dim3((unsigned)nblk), dim3(kThreads), 0, st, gmax, n_entries, acc, flags, weights, losses);
+    } else if (losses) {
+        if (weights) hipLaunchKernelGGL(k_loss_values_weighted, dim3(1), dim3(64), 0, st, acc, flags, weights, losses);
+        else hipLaunchKernelGGL(k_loss_values, dim3(1), dim3(64), 0, st, acc, flags, losses);
+    }
+    return mas_launch_status();
+}
+
+extern "C" int mas_partial_loss_bwd_fused(const float* z, int h, int w, const void* spx, int spx_dtype, const uint8_t* mask, const uint32_t* bits,
+                                          const void* work, const float* grad, const float* weights, int N, int C, int H, int W, int S,
+                                          float invT, int flags, float* dz, int64_t* dzq_fix, void* stream) {
+    if (!z || !spx || !mask || !work || !grad || !dz) return MAS_ERR_NULL;
+    if (N <= 0 || S <= 0 || H <= 0 || W <= 0) return MAS_ERR_SHAPE;
+    if (C < 2 || C > MAS_MAX_CLASSES) return MAS_ERR_CLASSES;
+    const bool low = h > 0;
+    if ((h > 0) != (w > 0) || h > H || w > W) return MAS_ERR_SHAPE;
+    if (low && !dzq_fix) return MAS_ERR_NULL;
+    const WorkLayout L = work_layout(N, S, C, flags);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const unsigned char* wb = static_cast<const unsigned char*>(work);
+    mas_u64* acc = const_cast<mas_u64*>(reinterpret_cast<const mas_u64*>(wb));
+    mas_u64* gmax = (flags & MAS_LOSS_GROUP) ? const_cast<mas_u64*>(reinterpret_cast<const mas_u64*>(wb + L.gmax_off)) : nullptr;
+    const unsigned* wbits = bits ? bits : reinterpret_cast<const unsigned*>(wb + L.bits_off);
+    const size_t nq = low ? (size_t)N * C * h * w : 0;
+    if (low) {
+        const hipError_t e = hipMemsetAsync(dzq_fix, 0, nq * sizeof(int64_t), st);
+        if (e != hipSuccess) return (int)e;
+    }
+    LossArgs a{z, spx, mask, wbits, N, C, H, W, S, invT, flags, gmax, acc, nullptr, low ? reinterpret_cast<float*>(dzq_fix) : dz,
+               low ? h : 0, low ? w : 0, grad, weights};
+    if (int e = dispatch_loss(a, spx_dtype, true, st)) return e;
+    if (low) {
+        hipLaunchKernelGGL(k_fix_to_float, dim3((unsigned)((nq + kThreads - 1) / kThreads)), dim3(kThreads), 0, st,
+                           reinterpret_cast<const long long*>(dzq_fix), (long long)nq, MAS_GRAD_FRAC, dz);
+        return mas_launch_status();
+    }
+    return 0;
 }

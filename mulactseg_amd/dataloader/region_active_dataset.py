@@ -132,6 +132,14 @@ class LazySuppix(dict):
     def _raw(self, key):
         return dict.__getitem__(self, key)
 
+    def __iter__(self):
+        # (defined so that dict(lazy), {**lazy} and dict.update(lazy) do not take CPython's raw-slot fast path for exact-dict
+        #  iteration: with an overridden __iter__ they go through keys() and __getitem__, i.e. they see real lists)
+        return dict.__iter__(self)
+
+    def keys(self):
+        return dict.keys(self)
+
     def _real(self, key, v):
         if isinstance(v, (_FromTable, _Appended)):
             v = v.build()

@@ -169,6 +169,80 @@ def partial_loss_bwd(z, spx, mask, bits, gmax, acc, grad_out, invT, flags):
     return dz
 
 
+class LossState:
+    """What a fused forward leaves for its backward: the work buffer (accumulators | arg-pixel table | target bit masks) and views."""
+    __slots__ = ("work", "acc", "gmax", "bits", "N", "S", "C", "flags")
+
+
+def partial_loss_fwd_fused(z, size, spx, mask, invT, flags, targets=None, cols_used=None, bits=None, weights=None, reduce_acc=None):
+    """Everything the forward direction launches in ONE library call (mas_partial_loss_fwd_fused: prep, scan, finalize + values).
+    ``z`` [N,C,H,W] with ``size`` None, or the quarter-resolution logits [N,C,h,w] with ``size`` = (H, W).  Either ``targets``
+    (u8 [N,S,cols], masks over the first ``cols_used`` columns are formed in the prep launch) or ready ``bits`` (int32 [N,S]).
+    ``weights`` f32 [3]: losses gets a fourth entry, the weighted objective.  ``reduce_acc`` (data parallel): called on the
+    accumulators between the scans and the division.  Returns (losses, LossState)."""
+    _need(z, "inputs", torch.float32)
+    _need(spx, "superpixels")
+    mask = _mask_u8(mask)
+    N, C = z.shape[0], z.shape[1]
+    low = size is not None
+    H, W = (int(size[0]), int(size[1])) if low else (z.shape[2], z.shape[3])
+    h, w = (z.shape[2], z.shape[3]) if low else (0, 0)
+    if targets is not None:
+        _need(targets, "targets", torch.uint8)
+        S, cols = targets.shape[1], targets.shape[2]
+        cols_used = cols if cols_used is None else int(cols_used)
+        if targets.shape[0] != N:
+            raise ValueError("targets %s do not match the batch of %d" % (tuple(targets.shape), N))
+    else:
+        _need(bits, "bits", torch.int32)
+        S, cols, cols_used = bits.shape[1], 0, 0
+        if bits.shape[0] != N:
+            raise ValueError("bits %s do not match the batch of %d" % (tuple(bits.shape), N))
+    if tuple(spx.shape) != (N, H, W) or tuple(mask.shape) != (N, H, W):
+        raise ValueError("shape mismatch between inputs %s at size %s, superpixels %s, spmasks %s"
+                         % (tuple(z.shape), (H, W), tuple(spx.shape), tuple(mask.shape)))
+    dev = z.device
+    lib = _lib.load()
+    nbytes = int(lib.mas_partial_loss_work_bytes(N, S, C, flags))
+    work = torch.empty((nbytes + 7) // 8, dtype=torch.int64, device=dev)          # (zeroed by the prep launch)
+    losses = torch.empty(3 if weights is None else 4, dtype=torch.float32, device=dev)
+    if weights is not None:
+        _need(weights, "weights", torch.float32)
+    st8 = LossState()
+    st8.work, st8.acc, st8.N, st8.S, st8.C, st8.flags = work, work[:_lib.ACC_WORDS], N, S, C, flags
+    st8.gmax = work[_lib.ACC_WORDS:_lib.ACC_WORDS + N * S * C].view(N, S, C) if flags & _lib.LOSS_GROUP else None
+    st8.bits = bits
+    with torch.cuda.device(dev):
+        st = _stream(z)
+        _lib.check(lib.mas_partial_loss_fwd_fused(z.data_ptr(), h, w, spx.data_ptr(), _id_code(spx), mask.data_ptr(), _opt(targets), cols, cols_used,
+                                                  _opt(bits), N, C, H, W, S, invT, flags, _opt(weights), work.data_ptr(), work.numel() * 8,
+                                                  None if reduce_acc is not None else losses.data_ptr(), st), "mas_partial_loss_fwd_fused")
+        if reduce_acc is not None:
+            reduce_acc(st8.acc)
+            if weights is None:
+                _lib.check(lib.mas_loss_values(st8.acc.data_ptr(), flags, losses.data_ptr(), st), "mas_loss_values")
+            else:
+                _lib.check(lib.mas_loss_values_weighted(st8.acc.data_ptr(), flags, weights.data_ptr(), losses.data_ptr(), st), "mas_loss_values_weighted")
+    return losses, st8
+
+
+def partial_loss_bwd_fused(z, size, spx, mask, state, grad, invT, weights=None, want_fix=False):
+    """The backward direction in ONE library call (mas_partial_loss_bwd_fused): dz [N,C,H,W] (``size`` None) or dzq [N,C,h,w]."""
+    mask = _mask_u8(mask)
+    _need(grad, "grad_out", torch.float32)
+    N, C = z.shape[0], z.shape[1]
+    low = size is not None
+    H, W = (int(size[0]), int(size[1])) if low else (z.shape[2], z.shape[3])
+    h, w = (z.shape[2], z.shape[3]) if low else (0, 0)
+    dz = torch.empty_like(z)
+    fix = torch.empty((N, C, h, w), dtype=torch.int64, device=z.device) if low else None      # (zeroed inside the call)
+    with torch.cuda.device(z.device):
+        _lib.check(_lib.load().mas_partial_loss_bwd_fused(z.data_ptr(), h, w, spx.data_ptr(), _id_code(spx), mask.data_ptr(), _opt(state.bits),
+                                                          state.work.data_ptr(), grad.data_ptr(), _opt(weights), N, C, H, W, state.S, invT,
+                                                          state.flags, dz.data_ptr(), _opt(fix), _stream(z)), "mas_partial_loss_bwd_fused")
+    return (dz, fix) if want_fix else dz
+
+
 # ------------------------------------------------------------------------------------------------
 # K4: ordering + budgeted selection walk
 # ------------------------------------------------------------------------------------------------

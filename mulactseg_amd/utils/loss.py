@@ -27,28 +27,45 @@ import torch.nn as nn
 from .. import _lib, ops
 
 
+def _fused_forward(ctx, z, size, tgt, cols_used, superpixels, spmasks, invT, flags, sync, weights):
+    """Shared forward of the three autograd functions below: ONE library call (prep + scan + finalize with the loss values,
+    ops.partial_loss_fwd_fused); ``tgt`` is the u8 multi-hot target tensor (``cols_used`` columns count) or, with ``cols_used``
+    None, ready int32 bit masks."""
+    z = z.contiguous()
+    spx = superpixels.contiguous()
+    msk = spmasks.contiguous()
+    as_bits = cols_used is None
+    losses, st = ops.partial_loss_fwd_fused(z, size, spx, msk, invT, flags, targets=None if as_bits else tgt, cols_used=cols_used,
+                                            bits=tgt if as_bits else None, weights=weights, reduce_acc=_all_reduce_sum if sync else None)
+    ctx.save_for_backward(z, spx, msk, st.work, tgt if as_bits else st.work, weights if weights is not None else st.work)
+    ctx.as_bits, ctx.has_w = as_bits, weights is not None
+    ctx.geom = (st.N, st.S, st.C)
+    ctx.invT, ctx.flags, ctx.size = invT, flags, size
+    ctx.mark_non_differentiable(st.acc)
+    return losses, st.acc
+
+
+def _fused_backward(ctx, grad):
+    z, spx, msk, work, bits, weights = ctx.saved_tensors
+    st = ops.LossState()
+    st.work, st.bits, st.flags = work, bits if ctx.as_bits else None, ctx.flags
+    st.N, st.S, st.C = ctx.geom
+    return ops.partial_loss_bwd_fused(z, ctx.size, spx, msk, st, grad, ctx.invT, weights=weights if ctx.has_w else None)
+
+
 class _PartialLossFn(torch.autograd.Function):
-    """(ce, mc, group) = f(inputs): forward scan saves the fixed-point accumulators and the arg-pixel
-    table; backward is one scan writing dz.  No host synchronisation in either direction."""
+    """(ce, mc, group) = f(inputs): the forward direction (accumulators, arg-pixel table, loss values) and the backward direction
+    (one scan writing dz) are one library call each.  No host synchronisation in either direction."""
 
     @staticmethod
-    def forward(ctx, inputs, bits, superpixels, spmasks, invT, flags, sync):
-        z = inputs.contiguous()
-        spx = superpixels.contiguous()
-        msk = spmasks.contiguous()
-        losses, acc, gmax = ops.partial_loss_fwd(z, spx, msk, bits, invT, flags, _all_reduce_sum if sync else None)
-        ctx.save_for_backward(z, spx, msk, bits, acc, gmax if gmax is not None else acc)
-        ctx.has_gmax = gmax is not None
-        ctx.invT, ctx.flags = invT, flags
-        ctx.mark_non_differentiable(acc)
+    def forward(ctx, inputs, tgt, cols_used, superpixels, spmasks, invT, flags, sync):
+        losses, acc = _fused_forward(ctx, inputs, None, tgt, cols_used, superpixels, spmasks, invT, flags, sync, None)
         return losses[0], losses[1], losses[2], acc
 
     @staticmethod
     def backward(ctx, g_ce, g_mc, g_group, _g_acc):
-        z, spx, msk, bits, acc, gmax = ctx.saved_tensors
         grad_out = torch.stack([g_ce, g_mc, g_group]).to(torch.float32).contiguous()
-        dz = ops.partial_loss_bwd(z, spx, msk, bits, gmax if ctx.has_gmax else None, acc, grad_out, ctx.invT, ctx.flags)
-        return dz, None, None, None, None, None, None
+        return _fused_backward(ctx, grad_out), None, None, None, None, None, None, None
 
 
 class _PartialLossLowResFn(torch.autograd.Function):
@@ -58,53 +75,33 @@ class _PartialLossLowResFn(torch.autograd.Function):
     order-independent fixed-point sum (run-to-run identical)."""
 
     @staticmethod
-    def forward(ctx, zq, size, bits, superpixels, spmasks, invT, flags, sync):
-        zq = zq.contiguous()
-        spx = superpixels.contiguous()
-        msk = spmasks.contiguous()
-        losses, acc, gmax = ops.partial_loss_fwd_lowres(zq, size, spx, msk, bits, invT, flags, _all_reduce_sum if sync else None)
-        ctx.save_for_backward(zq, spx, msk, bits, acc, gmax if gmax is not None else acc)
-        ctx.has_gmax = gmax is not None
-        ctx.invT, ctx.flags, ctx.size = invT, flags, (int(size[0]), int(size[1]))
-        ctx.mark_non_differentiable(acc)
+    def forward(ctx, zq, size, tgt, cols_used, superpixels, spmasks, invT, flags, sync):
+        losses, acc = _fused_forward(ctx, zq, (int(size[0]), int(size[1])), tgt, cols_used, superpixels, spmasks, invT, flags, sync, None)
         return losses[0], losses[1], losses[2], acc
 
     @staticmethod
     def backward(ctx, g_ce, g_mc, g_group, _g_acc):
-        zq, spx, msk, bits, acc, gmax = ctx.saved_tensors
         grad_out = torch.stack([g_ce, g_mc, g_group]).to(torch.float32).contiguous()
-        dzq = ops.partial_loss_bwd_lowres(zq, ctx.size, spx, msk, bits, gmax if ctx.has_gmax else None, acc, grad_out, ctx.invT, ctx.flags)
-        return dzq, None, None, None, None, None, None, None
+        return _fused_backward(ctx, grad_out), None, None, None, None, None, None, None, None
 
 
 class _WeightedLowResLossFn(torch.autograd.Function):
     """total, ce, mc, group = f(zq): the trainer's objective ``w_ce*ce + w_mc*mc + w_group*group`` as ONE differentiable
-    output (its value and its chain rule are computed in the kernels that turn sums into losses / upstream gradients into
-    scales), the three parts as detached values for logging.  Same scans as ``_PartialLossLowResFn``; about half the launches of
-    composing the parts with torch arithmetic."""
+    output (its value is formed by the last workgroup of the group finalize, its chain rule inside the backward scan), the three
+    parts as detached values for logging.  Three launches forward (prep, scan, finalize), three backward (memset, scan, fixed point ->
+    float), one library call each."""
 
     @staticmethod
-    def forward(ctx, zq, size, bits, superpixels, spmasks, invT, flags, sync, weights):
-        zq = zq.contiguous()
-        spx = superpixels.contiguous()
-        msk = spmasks.contiguous()
-        losses, acc, gmax = ops.partial_loss_fwd_lowres(zq, size, spx, msk, bits, invT, flags, _all_reduce_sum if sync else None,
-                                                        weights=weights)
-        ctx.save_for_backward(zq, spx, msk, bits, acc, gmax if gmax is not None else acc, weights)
-        ctx.has_gmax = gmax is not None
-        ctx.invT, ctx.flags, ctx.size = invT, flags, (int(size[0]), int(size[1]))
-        ctx.mark_non_differentiable(acc)
+    def forward(ctx, zq, size, tgt, cols_used, superpixels, spmasks, invT, flags, sync, weights):
+        losses, acc = _fused_forward(ctx, zq, (int(size[0]), int(size[1])), tgt, cols_used, superpixels, spmasks, invT, flags, sync, weights)
         parts = losses.detach()
         ctx.mark_non_differentiable(parts)
         return losses[3], parts, acc
 
     @staticmethod
     def backward(ctx, g_total, _g_parts, _g_acc):
-        zq, spx, msk, bits, acc, gmax, weights = ctx.saved_tensors
         g = g_total.reshape(1).to(torch.float32).contiguous()
-        dzq = ops.partial_loss_bwd_lowres(zq, ctx.size, spx, msk, bits, gmax if ctx.has_gmax else None, acc, g, ctx.invT, ctx.flags,
-                                          weights=weights)
-        return dzq, None, None, None, None, None, None, None, None
+        return _fused_backward(ctx, g), None, None, None, None, None, None, None, None, None
 
 
 def _all_reduce_sum(acc):
@@ -129,8 +126,8 @@ def _run(inputs, targets, superpixels, spmasks, temp, flags, drop_last_column, s
     if targets.dtype != torch.uint8:
         targets = targets.to(torch.uint8)
     cols = targets.shape[-1]
-    bits = ops.target_bits(targets.contiguous(), cols - 1 if drop_last_column else cols)
-    return _PartialLossFn.apply(inputs, bits, superpixels, spmasks, ops.inv_temperature(temp), flags, sync)
+    return _PartialLossFn.apply(inputs, targets.contiguous(), cols - 1 if drop_last_column else cols, superpixels, spmasks,
+                                ops.inv_temperature(temp), flags, sync)
 
 
 class MyCrossEntropyLoss(nn.CrossEntropyLoss):
@@ -166,7 +163,7 @@ class MyCrossEntropyLoss(nn.CrossEntropyLoss):
         if not self._fused(input, target):
             return super().forward(input / self.temperature, target)
         labels, mask, bits = self._labels_mask(input, target)
-        ce, _, _, self.last_acc = _PartialLossFn.apply(input, bits, labels, mask, ops.inv_temperature(self.temperature),
+        ce, _, _, self.last_acc = _PartialLossFn.apply(input, bits, None, labels, mask, ops.inv_temperature(self.temperature),
                                                         _lib.LOSS_CE | _lib.LOSS_TCE, self.sync_normalisers)
         return ce
 
@@ -176,7 +173,7 @@ class MyCrossEntropyLoss(nn.CrossEntropyLoss):
             up = torch.nn.functional.interpolate(quarter_logits, size=tuple(size), mode='bilinear', align_corners=False)
             return super().forward(up / self.temperature, target)
         labels, mask, bits = self._labels_mask(quarter_logits, target)
-        ce, _, _, self.last_acc = _PartialLossLowResFn.apply(quarter_logits, tuple(size), bits, labels, mask,
+        ce, _, _, self.last_acc = _PartialLossLowResFn.apply(quarter_logits, tuple(size), bits, None, labels, mask,
                                                              ops.inv_temperature(self.temperature), _lib.LOSS_CE | _lib.LOSS_TCE,
                                                              self.sync_normalisers)
         return ce
@@ -299,8 +296,7 @@ class FusedPartialLabelLoss(nn.Module):
         bilinear upsampling (``models/segmentation/utils.py:25``) happens per selected pixel inside the scans."""
         if targets.dtype != torch.uint8:
             targets = targets.to(torch.uint8)
-        bits = ops.target_bits(targets.contiguous(), targets.shape[-1])
-        ce, mc, group, self.last_acc = _PartialLossLowResFn.apply(quarter_logits, tuple(size), bits, superpixels, spmasks,
+        ce, mc, group, self.last_acc = _PartialLossLowResFn.apply(quarter_logits, tuple(size), targets.contiguous(), targets.shape[-1], superpixels, spmasks,
                                                                   ops.inv_temperature(self.temp), self.flags, self.sync_normalisers)
         return group, ce, mc
 
@@ -310,10 +306,9 @@ class FusedPartialLabelLoss(nn.Module):
         arithmetic, in half the kernel launches."""
         if targets.dtype != torch.uint8:
             targets = targets.to(torch.uint8)
-        bits = ops.target_bits(targets.contiguous(), targets.shape[-1])
         key = (float(coeff), float(coeff_mc), float(coeff_gm), quarter_logits.device)
         if getattr(self, '_w_key', None) != key:
             self._w_key, self._w = key, torch.tensor(key[:3], dtype=torch.float32, device=quarter_logits.device)
-        total, parts, self.last_acc = _WeightedLowResLossFn.apply(quarter_logits, tuple(size), bits, superpixels, spmasks,
+        total, parts, self.last_acc = _WeightedLowResLossFn.apply(quarter_logits, tuple(size), targets.contiguous(), targets.shape[-1], superpixels, spmasks,
                                                                   ops.inv_temperature(self.temp), self.flags, self.sync_normalisers, self._w)
         return total, parts[2], parts[0], parts[1]

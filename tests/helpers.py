@@ -134,21 +134,23 @@ def selector_args(**kw):
 
 
 class OracleLossOps:
-    """CPU stand-in for the part of mulactseg_amd.ops the loss modules call (partial_loss_fwd / _bwd, target_bits,
+    """CPU stand-in for the part of mulactseg_amd.ops the loss modules call (partial_loss_fwd_fused / _bwd_fused, LossState,
     inv_temperature), backed by oracle/exact.c -- lets the world-size-2 gloo tests drive FusedPartialLabelLoss's normaliser
-    all-reduce and autograd wiring without a GPU.  TEST INFRASTRUCTURE."""
+    all-reduce and autograd wiring without a GPU.  Full-resolution logits only.  TEST INFRASTRUCTURE."""
+
+    class LossState:
+        pass
 
     @staticmethod
     def inv_temperature(T):
         return float(exact.inv_temperature(T))
 
     @staticmethod
-    def target_bits(targets, cols_used=None):
-        return torch.from_numpy(exact.target_bits(targets.numpy(), cols_used).view(np.int32))
-
-    @staticmethod
-    def partial_loss_fwd(z, spx, mask, bits, invT, flags, reduce_acc=None):
+    def partial_loss_fwd_fused(z, size, spx, mask, invT, flags, targets=None, cols_used=None, bits=None, weights=None, reduce_acc=None):
         import ctypes
+        assert size is None and weights is None
+        if bits is None:
+            bits = torch.from_numpy(exact.target_bits(targets.numpy(), cols_used).view(np.int32))
         acc, gmax, _ = exact.partial_loss_fwd(z.detach().numpy(), spx.numpy(), mask.numpy().astype(np.uint8), bits.numpy().view(np.uint32),
                                               np.float32(invT), flags)
         acc_t = torch.from_numpy(acc.view(np.int64).copy())
@@ -157,13 +159,23 @@ class OracleLossOps:
         accn = np.ascontiguousarray(acc_t.numpy().view(np.uint64))
         losses = np.zeros(3, dtype=np.float32)
         exact.lib().exact_loss_values(accn.ctypes.data_as(ctypes.c_void_p), flags, losses.ctypes.data_as(ctypes.c_void_p))
-        return torch.from_numpy(losses), acc_t, torch.from_numpy(gmax.view(np.int64))
+        st = OracleLossOps.LossState()
+        st.acc, st.flags = acc_t, flags
+        st.N, st.S, st.C = z.shape[0], bits.shape[1], z.shape[1]
+        st.bits = bits
+        # (what the product keeps in its work buffer: acc | table | bit masks)
+        st.work = torch.cat([acc_t, torch.from_numpy(gmax.view(np.int64)).reshape(-1), bits.reshape(-1).to(torch.int64)])
+        return torch.from_numpy(losses), st
 
     @staticmethod
-    def partial_loss_bwd(z, spx, mask, bits, gmax, acc, grad_out, invT, flags):
-        g = np.zeros((z.shape[0], bits.shape[1], z.shape[1]), dtype=np.uint64) if gmax is None else gmax.numpy().view(np.uint64)
-        _, dz = exact.partial_loss_bwd(z.detach().numpy(), spx.numpy(), mask.numpy().astype(np.uint8), bits.numpy().view(np.uint32), g,
-                                       acc.numpy().view(np.uint64), grad_out.numpy(), np.float32(invT), flags)
+    def partial_loss_bwd_fused(z, size, spx, mask, state, grad, invT, weights=None, want_fix=False):
+        assert size is None and weights is None
+        n_tab = state.N * state.S * state.C
+        acc = state.work[:8]
+        gmax = state.work[8:8 + n_tab].reshape(state.N, state.S, state.C)
+        bits = state.work[8 + n_tab:].to(torch.int32).reshape(state.N, state.S)
+        _, dz = exact.partial_loss_bwd(z.detach().numpy(), spx.numpy(), mask.numpy().astype(np.uint8), bits.numpy().view(np.uint32),
+                                       gmax.numpy().view(np.uint64), acc.numpy().view(np.uint64), grad.numpy(), np.float32(invT), state.flags)
         return torch.from_numpy(dz)
 
 

@@ -64,10 +64,17 @@ def _run(rank, world, port, out_dir):
     scores, hist = sel.calculate_scores_tensor(fake_trainer(), pool, want_hist=True)
     sel.select_next_batch(fake_trainer(save_dir=tmp), active, 30)
     active.wait_for_writes()
-    with open(os.path.join(tmp, 'pixbal_selection_01.pkl'), 'rb') as f:
-        consumed = pickle.load(f)
+    # every rank holds the same prefix and lists; the FILES are rank 0's business (RegionActiveDataset._writes_files)
+    fname = os.path.join(tmp, 'pixbal_selection_01.pkl')
+    consumed = None
+    if rank == 0:
+        with open(fname, 'rb') as f:
+            consumed = pickle.load(f)
+    else:
+        assert not os.path.exists(fname)
     res = dict(scores=scores.numpy(), hist=hist.numpy(), w=sel.cls_weight.numpy(), cum=sel.cumulated_pred_prob,
-               consumed=consumed, isselected=pool.isselected, n_local=sel._round.plan.n_local)
+               consumed=consumed, isselected=pool.isselected, n_local=sel._round.plan.n_local,
+               labelled=dict(label.suppix), label_idx=list(label.im_idx), pooled=dict(pool.suppix))
     with open(os.path.join(out_dir, "w%d_r%d.pkl" % (world, rank)), "wb") as f:
         pickle.dump(res, f)
     if world > 1:
@@ -90,7 +97,9 @@ def test_sharded_round_equals_single_process(world):
         n_local += res['n_local']
         for k in ('scores', 'hist', 'w', 'cum', 'isselected'):
             assert np.array_equal(res[k], single[k]), (k, r)
-        assert res['consumed'] == single['consumed']
+        for k in ('labelled', 'label_idx', 'pooled'):
+            assert res[k] == single[k], (k, r)
+        assert res['consumed'] == (single['consumed'] if r == 0 else None)
     assert n_local == 7                                     # every image scored exactly once
 
 

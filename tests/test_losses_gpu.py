@@ -400,3 +400,50 @@ def test_temperature_ce_kernel_equals_the_c_oracle_and_torch():
     # no valid pixel: NaN like torch's mean over nothing
     none = torch.full_like(yt, 255)
     assert torch.isnan(crit(zt.detach(), none))
+
+
+@pytest.mark.parametrize("fname", sorted(FLAG_SETS))
+@pytest.mark.parametrize("low", [False, True])
+def test_fused_calls_equal_the_step_by_step_entry_points(fname, low):
+    """mas_partial_loss_fwd_fused / _bwd_fused (what the loss modules run: prep + scan + finalize-with-values in one call; the backward
+    scan forms its scale factors itself) against the step-by-step entry points the oracle tests above pin: accumulators, arg-pixel
+    table, bit masks, loss values, weighted objective and gradients are the same bits -- from u8 target rows or from ready masks,
+    with and without weights, and with a reduce hook between scan and division (the data-parallel form)."""
+    ops = _gpu()
+    flags = FLAG_SETS[fname]
+    N, C, S = 2, 20, 200
+    h, w, H, W = (24, 36, 96, 144) if low else (0, 0, 40, 100)
+    _, tgt, spx, msk = _inputs(1200 + W, N, C, H, W, S)
+    z = synth.logits(91, N, C, h if low else H, w if low else W)
+    invT = ops.inv_temperature(0.1)
+    zt, st, mt, tg = (torch.from_numpy(a).cuda() for a in (z, spx, msk, tgt))
+    size = (H, W) if low else None
+    bits = ops.target_bits(tg)
+    wts = torch.tensor([16.0, 8.0, 1.0], device='cuda')
+    if low:
+        l0, a0, g0 = ops.partial_loss_fwd_lowres(zt, size, st, mt, bits, invT, flags)
+        lw, _, _ = ops.partial_loss_fwd_lowres(zt, size, st, mt, bits, invT, flags, weights=wts)
+    else:
+        l0, a0, g0 = ops.partial_loss_fwd(zt, st, mt, bits, invT, flags)
+        lw = None
+    for kw in (dict(targets=tg), dict(bits=bits), dict(targets=tg, reduce_acc=lambda acc: None), dict(targets=tg, weights=wts)):
+        losses, state = ops.partial_loss_fwd_fused(zt, size, st, mt, invT, flags, **kw)
+        assert torch.equal(state.acc[:7], a0[:7])                 # (word 7 counts the finalize workgroups)
+        if g0 is not None:
+            assert torch.equal(state.gmax, g0)
+        assert torch.equal(losses[:3].view(torch.int32), l0.view(torch.int32))
+        if 'weights' in kw and lw is not None:
+            assert torch.equal(losses.view(torch.int32), lw.view(torch.int32))
+        go3 = torch.tensor([16.0, 8.0, 1.0], device='cuda')
+        go1 = torch.tensor([1.0], device='cuda')
+        if low:
+            ref = ops.partial_loss_bwd_lowres(zt, size, st, mt, bits, g0, a0, go1 if 'weights' in kw else go3, invT, flags,
+                                              weights=wts if 'weights' in kw else None)
+        else:
+            # (full resolution, weighted: the chain rule through the weighted sum is grad * w_k -- the same products)
+            ref = ops.partial_loss_bwd(zt, st, mt, bits, g0, a0, go3, invT, flags)
+        got = ops.partial_loss_bwd_fused(zt, size, st, mt, state, go1 if 'weights' in kw else go3, invT, weights=wts if 'weights' in kw else None)
+        assert torch.equal(got.view(torch.int32), ref.view(torch.int32)), kw.keys()
+    # a second forward on fresh state gives the same values (the prep launch re-zeroes everything, including the finalize counter)
+    l2, _ = ops.partial_loss_fwd_fused(zt, size, st, mt, invT, flags, targets=tg)
+    assert torch.equal(l2.view(torch.int32), l0.view(torch.int32))

@@ -290,6 +290,12 @@ def test_lazy_suppix_reads_like_a_dict_of_lists():
     assert d.pop('b') == [3] and 'b' not in d and d.pop('b', None) is None
     assert d.setdefault('q', []) == [] and d.setdefault('a') == [2, 3, 11]
     assert 'FromTable' not in repr(d)
+    assert dict(d) == {'a': [2, 3, 11], 'c': [7, 3, 1, 9], 'q': []} and {**d}['c'] == [7, 3, 1, 9]
+    f = LazySuppix()
+    dict.__setitem__(f, 'z', _FromTable(tab, 1))
+    plain = {}
+    plain.update(f)
+    assert plain == {'z': [3]} and type(dict(f)['z']) is list
 
 
 def test_a_failed_selection_pickle_write_is_raised_not_lost(tmp_path):
