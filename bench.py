@@ -266,8 +266,9 @@ def pool_round_bench(args, dev, rank, world, with_model):
 F32_MFMA_PEAK_TF = 157.3        # dense f32 MFMA peak of MI355X (MI355X_MICROARCH.md), TFLOP/s
 # The convolutions that run on csrc/conv_bx.hip / conv_wgrad_bx.hip compute the same f32 products from exact three-term bf16 splits
 # of both operands: six bf16 MFMAs (16x the f32 rate) per sixteen f32 ones -- the matrix-core bound of an f32 convolution done that
-# way is 16 / 6 x the f32 peak.  `mfma_frac` stays what it was (f32 FLOP of the convolutions / wall time / F32 peak) and may exceed
-# the share the f32 pipe alone could reach; `frac_of_split_bf16_bound` prices the same FLOP against the split form's bound.
+# way is 16 / 6 x the f32 peak.  A leg whose layers run (almost) all in that form is priced against THAT bound (`peak_TFLOPs`,
+# `mfma_frac` <= 1); `f32_pipe_peak_TFLOPs` is printed beside it for reference only -- the f32 pipe alone could not reach the
+# achieved rate, so no fraction is formed against it.
 SPLIT_BF16_BOUND_TF = F32_MFMA_PEAK_TF * 16.0 / 6.0
 MFMA_ARITH = ("f32 operands and f32 accumulation; layers marked hip_bx / '/bx' in layer_paths_per_step and the 1x1 weight gradients run on "
               "v_mfma_f32_32x32x16_bf16 from exact three-term bf16 splits of both operands (six partial products, dropped terms <= 2^-23 "
@@ -357,6 +358,34 @@ def train_iter_bench(args, dev, world, crop):
     low_ms = timed_loss(lambda: lowres_step(zq), zq)
     mat_ms = timed_loss(lambda: loss_step(ops.upsample_bilinear(zq, (crop, crop))), zq)
 
+    # The same two directions as the GPU runs them, without the host in the measurement: the fused entry points (one library call
+    # per direction: prep + scan + finalize-with-values / memset + scan + conversion) issued back to back, timed with HIP events on
+    # their stream.  The wall-clock figures above are bound by the host (autograd bookkeeping, the torch arithmetic that composes
+    # the objective) whenever nothing else keeps the GPU busy; inside a training step these launches queue behind the model's.
+    invT, wts = ops.inv_temperature(0.1), torch.tensor([16.0, 8.0, 1.0], device=dev)
+    go3, go1 = torch.tensor([16.0, 8.0, 1.0], device=dev), torch.ones(1, device=dev)
+
+    def gpu_time(fn, n=30):
+        for _ in range(5):
+            fn()
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize()
+        a.record()
+        for _ in range(n):
+            fn()
+        b.record()
+        torch.cuda.synchronize()
+        return a.elapsed_time(b) / n
+
+    def full_raw():
+        _, st8 = ops.partial_loss_fwd_fused(z.detach(), None, spx, msk, invT, crit.flags, targets=tgt)
+        ops.partial_loss_bwd_fused(z.detach(), None, spx, msk, st8, go3, invT)
+
+    def low_raw():
+        _, st8 = ops.partial_loss_fwd_fused(zq.detach(), (crop, crop), spx, msk, invT, crit.flags, targets=tgt, weights=wts)
+        ops.partial_loss_bwd_fused(zq.detach(), (crop, crop), spx, msk, st8, go1, invT, weights=wts)
+    loss_gpu_ms, low_gpu_ms = gpu_time(full_raw), gpu_time(low_raw)
+
     net = get_model('deeplabv3pluswn_resnet50deepstem', C, 16, True, pretrained_backbone=False).to(dev).train()
     opt = torch.optim.AdamW([{'params': net.backbone.parameters(), 'lr': 2e-5},
                              {'params': net.classifier.parameters(), 'lr': 2e-4}], lr=2e-5, weight_decay=1e-5, fused=True)
@@ -386,9 +415,10 @@ def train_iter_bench(args, dev, world, crop):
     flop = train_step_flop(net.module if hasattr(net, "module") else net, N, crop)
     return {"metric": "train-iter images/sec", "value": N * world / (it_ms * 1e-3), "unit": "images/s", "ms_per_iter": it_ms,
             "stream_k_error_word": sk_err,
-            "mfma": {"flop_per_step": flop, "achieved_TFLOPs": flop / (it_ms * 1e-3) / 1e12, "peak_TFLOPs": F32_MFMA_PEAK_TF,
-                     "mfma_frac": flop / (it_ms * 1e-3) / 1e12 / F32_MFMA_PEAK_TF,
-                     "split_bf16_bound_TFLOPs": SPLIT_BF16_BOUND_TF, "frac_of_split_bf16_bound": flop / (it_ms * 1e-3) / 1e12 / SPLIT_BF16_BOUND_TF,
+            "mfma": {"flop_per_step": flop, "achieved_TFLOPs": flop / (it_ms * 1e-3) / 1e12, "peak_TFLOPs": SPLIT_BF16_BOUND_TF,
+                     "mfma_frac": flop / (it_ms * 1e-3) / 1e12 / SPLIT_BF16_BOUND_TF,
+                     "peak_is": "the matrix-core bound of f32 convolutions computed from three-term bf16 splits (16/6 x the f32 MFMA peak)",
+                     "f32_pipe_peak_TFLOPs": F32_MFMA_PEAK_TF,
                      "arithmetic": MFMA_ARITH,
                      "note": "2 * taps * Cin * Cout * output pixels of every dense convolution x 3 products (forward, input gradient, "
                              "weight gradient; no input gradient for the first layer), over the WHOLE step's wall time"},
@@ -402,9 +432,15 @@ def train_iter_bench(args, dev, world, crop):
                        "selected_fraction": float(msk.float().mean())},
             "layer_paths_per_step": paths,
             "loss_only": {"ms_fwd_bwd": loss_ms, "algorithmic_GBs": loss_bytes / (loss_ms * 1e-3) / 1e9,
-                          "bytes": loss_bytes, "note": "full-resolution logits as the leaf; includes the small launches around the two scans "
-                                                       "and the autograd glue"},
-            "loss_from_quarter_logits": {"ms_fwd_bwd_fused": low_ms, "ms_fwd_bwd_upsample_then_loss": mat_ms, "quarter_logits": [N, C, q, q],
+                          "bytes": loss_bytes,
+                          "gpu_ms_fwd_bwd": loss_gpu_ms, "gpu_algorithmic_GBs": loss_bytes / (loss_gpu_ms * 1e-3) / 1e9,
+                          "gpu_frac_of_hbm_peak": loss_bytes / (loss_gpu_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                          "note": "full-resolution logits as the leaf.  ms_fwd_bwd: wall clock of the loss modules through autograd, the objective "
+                                  "composed with torch arithmetic (host-bound when the GPU has nothing else to do); gpu_ms_fwd_bwd: the same two "
+                                  "directions through the fused entry points, HIP events (prep + forward scan + finalize, backward scan); "
+                                  "per-kernel times and PMC bytes: profiles/r05/n_loss_*.md"},
+            "loss_from_quarter_logits": {"ms_fwd_bwd_fused": low_ms, "gpu_ms_fwd_bwd_fused": low_gpu_ms,
+                                         "ms_fwd_bwd_upsample_then_loss": mat_ms, "quarter_logits": [N, C, q, q],
                                          "note": "leaf = the model's quarter-resolution logits: fused = bilinear x4 evaluated inside both scans "
                                                  "(train_iter uses this); the other = upsample kernel + loss scans + dz + upsample backward"}}
 
@@ -466,9 +502,10 @@ def acquisition_with_model_bench(args, dev, world):
     flop = conv_flop(net, B, H, W, 1)
     return {"metric": "superpixels scored/sec incl. model forward", "scan_forms": scan_forms, "value": B * S * world / (ms * 1e-3), "unit": "superpixels/s",
             "ms_per_batch": ms, "forwards_per_image": 1, "layer_paths_per_step": paths,
-            "mfma": {"flop_per_batch": flop, "achieved_TFLOPs": flop / (ms * 1e-3) / 1e12, "peak_TFLOPs": F32_MFMA_PEAK_TF,
-                     "mfma_frac": flop / (ms * 1e-3) / 1e12 / F32_MFMA_PEAK_TF,
-                     "split_bf16_bound_TFLOPs": SPLIT_BF16_BOUND_TF, "frac_of_split_bf16_bound": flop / (ms * 1e-3) / 1e12 / SPLIT_BF16_BOUND_TF,
+            "mfma": {"flop_per_batch": flop, "achieved_TFLOPs": flop / (ms * 1e-3) / 1e12, "peak_TFLOPs": SPLIT_BF16_BOUND_TF,
+                     "mfma_frac": flop / (ms * 1e-3) / 1e12 / SPLIT_BF16_BOUND_TF,
+                     "peak_is": "the matrix-core bound of f32 convolutions computed from three-term bf16 splits (16/6 x the f32 MFMA peak)",
+                     "f32_pipe_peak_TFLOPs": F32_MFMA_PEAK_TF,
                      "arithmetic": MFMA_ARITH,
                      "note": "2 * taps * Cin * Cout * output pixels of every dense convolution of one forward, over the whole batch's wall time"},
             "config": {"workload": "eval forward (matrix-core convolutions with BatchNorm / residual / ReLU epilogues -- hip_bx: f32 products from three-term "
@@ -661,17 +698,27 @@ def cpu_baseline(args, dev, bufs, backend):
 def pmc_traffic(kernel, default_shape):
     """(HBM bytes per launch, source file) of `kernel` from the latest committed rocprofv3 --pmc summary
     (profiles/r*/..pmc_traffic.json, produced by profiles/summarize.py from separate FETCH_SIZE / WRITE_SIZE
-    passes of this same command, gfx950 FETCH_SIZE x2 correction applied).  (None, None) when the bench shape is not the
-    profiled default shape or no summary is present: PMC counters cannot be read from inside this process."""
+    passes of this same command, gfx950 FETCH_SIZE x2 correction applied).  (None, reason) when the bench shape is not the
+    profiled default shape, no summary is present, or the summary was measured on OTHER kernel sources than the ones in this tree
+    (it records the sha256 of the scan sources; a stale file is refused): PMC counters cannot be read from inside this process."""
     if not default_shape:
         return None, None
     import glob
+    import hashlib
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "*pmc_traffic.json")))
     for f in reversed(files):
         try:
-            k = json.load(open(f))["kernels"].get(kernel)
-            if k:
-                return k["hbm_bytes_per_launch"], os.path.relpath(f, ROOT)
+            doc = json.load(open(f))
+            k = doc["kernels"].get(kernel)
+            if not k:
+                continue
+            shas = doc.get("kernel_source_sha16")
+            if not shas:
+                return None, "refused %s: it does not say which kernel sources it measured" % os.path.relpath(f, ROOT)
+            for rel, sha in shas.items():
+                if hashlib.sha256(open(os.path.join(ROOT, rel), "rb").read()).hexdigest()[:16] != sha:
+                    return None, "refused %s: %s has changed since it was measured (re-run tools/profile_r05.sh scan)" % (os.path.relpath(f, ROOT), rel)
+            return k["hbm_bytes_per_launch"], os.path.relpath(f, ROOT)
         except Exception:
             continue
     return None, None
@@ -829,6 +876,23 @@ def main():
     out["train_iter_769"] = None if (args.no_train or args.no_trainleg) else secondary(train_iter_bench, args, dev, world, 769)
     out["acquisition_with_model"] = None if args.no_train else secondary(acquisition_with_model_bench, args, dev, world)
     out["stage2"] = None if (args.no_train or args.no_trainleg or rank != 0) else secondary(stage2_bench, args, dev)
+    # the secondary legs' headline numbers as TOP-LEVEL keys (a reader of the parsed line need not dig through the nested objects)
+    def pick(d, *path):
+        for k in path:
+            if not isinstance(d, dict) or k not in d:
+                return None
+            d = d[k]
+        return d
+    out["train_iter_ms_768"] = pick(out, "train_iter", "ms_per_iter")
+    out["train_iter_images_per_s_768"] = pick(out, "train_iter", "value")
+    out["train_iter_mfma_frac_768"] = pick(out, "train_iter", "mfma", "mfma_frac")
+    out["train_iter_ms_769"] = pick(out, "train_iter_769", "ms_per_iter")
+    out["train_iter_images_per_s_769"] = pick(out, "train_iter_769", "value")
+    out["pool_forward_ms_per_batch"] = pick(out, "acquisition_with_model", "ms_per_batch")
+    out["pool_forward_mfma_frac"] = pick(out, "acquisition_with_model", "mfma", "mfma_frac")
+    out["pool_round_scan_only_s"] = pick(out, "pool_round", "scan_only", "seconds")
+    out["pool_round_with_model_s"] = pick(out, "pool_round", "with_model_forward", "seconds")
+    out["loss_gpu_ms_fwd_bwd"] = pick(out, "train_iter", "loss_only", "gpu_ms_fwd_bwd")
     if rank == 0:
         out["cpu_baseline"] = secondary(cpu_baseline, args, dev, cpu_bufs, backend) if cpu_bufs is not None else None
         sys.stdout.flush()

@@ -485,6 +485,16 @@ unsigned mas_conv_bx_pack_job(void* job_host, const float* w, int Cout, int Cin,
 int mas_conv_bx_pack_multi(const void* jobs_dev, int njobs, unsigned nblocks, void* stream);
 int mas_conv_bx_fwd(const float* x, const void* wp, int N, int Cin, int H, int W, int Cout, int ksize, int stride, int dil,
                     const float* scale, const float* shift, const float* residual, int relu, float* y, void* stream);
+/* Presplit activations ("bx3"): x [N,C,H,W] f32 as [N][ceil(C/8)][3 terms][H*W][8 bf16] -- one 16-byte unit = one term (h | m | l of
+ * csrc/bx_split.h) of 8 consecutive channels of one pixel, channels beyond C zero: exactly a unit of the LDS operand image of
+ * mas_conv_bx_fwd, so a consumer stages it with 16-byte copies and no VALU work (the split is then done once per element by the
+ * producer instead of once per M tile by every consumer; 6 instead of 4 bytes per element in HBM).  mas_bx3_split: the conversion as
+ * a pass of its own; mas_conv_bx_fwd_pre: mas_conv_bx_fwd (stride 1) on such an input -- same products, same bits.
+ * (models/segmentation/backbone/resnet.py:143-160: conv2 / conv3 of a Bottleneck read what conv1 / conv2 wrote.) */
+long long mas_bx3_bytes(int N, int C, int H, int W);
+int mas_bx3_split(const float* x, int N, int C, int H, int W, void* x3, void* stream);
+int mas_conv_bx_fwd_pre(const void* x3, const void* wp, int N, int Cin, int H, int W, int Cout, int ksize, int dil, const float* scale,
+                        const float* shift, const float* residual, int relu, float* y, void* stream);
 /* The bare stride-1 products of a TRAINING step (forward with a role-0 image, input gradient with a role-1 image + the gradient of the
  * input's other consumer as `residual`; models/segmentation/backbone/resnet.py:143-160 under
  * trainer/active_joint_multi_predignore_lossdecomp.py:83-116) with a work-splitting plan for launches with fewer workgroups than

@@ -86,6 +86,9 @@ SIGNATURES = {
     "mas_conv_bx_pack_job": (_c.c_uint, [_vp, _vp, _i, _i, _i, _i, _vp, _c.c_uint]),
     "mas_conv_bx_pack_multi": (_i, [_vp, _i, _c.c_uint, _vp]),
     "mas_conv_bx_fwd": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _i, _vp, _vp]),
+    "mas_bx3_bytes": (_c.c_longlong, [_i, _i, _i, _i]),
+    "mas_bx3_split": (_i, [_vp, _i, _i, _i, _i, _vp, _vp]),
+    "mas_conv_bx_fwd_pre": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _i, _vp, _vp]),
     "mas_conv_bx_train_plan": (_i, [_i, _i, _i, _i, _i, _i, _i, _vp]),
     "mas_conv_bx_train_workspace_bytes": (_c.c_size_t, [_i, _i, _i, _i, _i]),
     "mas_conv_bx_train": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _i, _i, _vp, _c.c_size_t, _vp]),

@@ -57,6 +57,7 @@ struct BxP {
     int Cin, H, W, Cout, Ho, Wo, dil, relu;
     int tiles_x, tiles_y, ptiles, mtiles;
     int N;
+    const v4f* x3;                              // PRE: the input as a bx3 tensor [N][ceil(Cin/8)][3 terms][H*W][8 bf16] (k_bx3_split / an OUT3 epilogue)
     int ksplit;                                 // split-K (bare products only): the chunks of a tile are dealt to `ksplit` workgroups; part 0
     float* part;                                //   stores into y (with the residual), part k > 0 into part + (k - 1) * N * Cout * Ho * Wo;
                                                 //   k_bx_reduce then adds the parts into y in index order
@@ -174,9 +175,12 @@ constexpr int kBxOut = (int)0x80000000u;        // a byte offset beyond every re
 // V: the stride of the 1x1 form (1 | 2), the dilation of the 3x3 form (1 | 2: the patch geometry is a compile-time constant)
 // TW: 3x3 form: the 256 output pixels of a tile are 8 rows x 32 columns (TW = 32) or 16 x 16 (TW = 16: the 48 x 48 planes of
 //     layer3 / layer4 at the training crop are 9 such tiles, 12 of the wide ones of which a quarter is padding); 1x1: 32
-template <int TAPS, int BM, int BN, int V, bool RES, int TW = 32>
+// PRE: the activations arrive ALREADY SPLIT (bx3 layout: 16-byte units of 8 channels of one pixel and one term -- exactly a unit of
+//      the B image), written by the producer of the tensor; staging is then a 16-byte copy per unit, no VALU work
+template <int TAPS, int BM, int BN, int V, bool RES, int TW = 32, bool PRE = false>
 __global__ __launch_bounds__(kThreads, 2) void k_conv_bx(const BxP p) {
     constexpr bool S2 = TAPS == 1 && V == 2;
+    static_assert(!(PRE && S2), "presplit input: stride 1");
     constexpr int DIL = TAPS == 9 ? V : 1;
     constexpr int TH = 256 / TW;                                    // 3x3: rows of a tile
     static_assert(TW == 32 || (TW == 16 && TAPS == 9), "tile shape");
@@ -188,7 +192,8 @@ __global__ __launch_bounds__(kThreads, 2) void k_conv_bx(const BxP p) {
     constexpr int AUNITS = 3 * GA * BM;                         // 16-byte units of a chunk's A image
     constexpr int NW = (AUNITS + kThreads - 1) / kThreads;
     constexpr bool WTAIL = AUNITS % kThreads != 0;              // the last weight load of a thread may lie beyond the image
-    constexpr int POS1 = 144 * (BN / 128);                      // 1x1: units per k group of the B image
+    constexpr int POS1 = PRE ? BN : 144 * (BN / 128);           // 1x1: units per k group of the B image (PRE: pixels in order, no swizzle)
+    constexpr int NPRE = TAPS == 1 ? (12 * BN) / kThreads : (3 * PP + kThreads - 1) / kThreads;      // PRE: 16-byte units per thread and chunk
     constexpr int NT = TAPS == 1 ? BN / 128 : (2 * PP + kThreads - 1) / kThreads;       // staging tasks per thread: 1x1 (4 channels x 4 pixels), 3x3 (4 channels x 1 pixel)
     constexpr int NXR = TAPS == 1 ? NT * 4 * (S2 ? 8 : 4) : NT * 4;
     extern __shared__ __attribute__((aligned(16))) unsigned char bx_smem[];
@@ -224,7 +229,32 @@ __global__ __launch_bounds__(kThreads, 2) void k_conv_bx(const BxP p) {
 
     // ---- staging descriptors (the same for every chunk): byte offset inside the chunk's x resource, byte offset in the B image --
     int goff[NT], loff[NT];
-    if (TAPS == 1) {
+    int pgoff[PRE ? NPRE : 1], ploff[PRE ? NPRE : 1];
+    if (PRE) {
+#pragma unroll
+        for (int j = 0; j < NPRE; ++j) {
+            const int idx = tid + j * kThreads;
+            pgoff[j] = kBxOut;
+            if (TAPS == 1) {
+                const int gt = idx / BN, pp = idx - gt * BN;            // memory order of a chunk: [k group 0..3][term 0..2][pixel]
+                const int g = gt / 3, term = gt - 3 * g;
+                if (p0 + pp < HWo) pgoff[j] = (gt * HW + p0 + pp) * 16;
+                ploff[j] = ((term * 4 + g) * POS1 + pp) * 16;
+            } else {
+                ploff[j] = (kBxDump + (tid & 15)) * 16;
+                if (idx < 3 * PP) {
+                    const int term = idx / PP, pix = idx - term * PP;
+                    const int py = pix / PW, px = pix - py * PW;
+                    const int iy = oy0 - DIL + py, ix = ox0 - DIL + px;
+                    ploff[j] = (term * kBxPPA + pix) * 16;
+                    if (iy >= 0 && iy < p.H && ix >= 0 && ix < p.W) pgoff[j] = (term * HW + iy * p.W + ix) * 16;
+                }
+            }
+        }
+    }
+    if (PRE) {
+        // (no f32 staging descriptors)
+    } else if (TAPS == 1) {
 #pragma unroll
         for (int j = 0; j < NT; ++j) {
             // 16 consecutive lanes = 8 pixel quads x the two channel quads of one k group: their 8-byte LDS stores (16-byte pitch,
@@ -273,7 +303,7 @@ __global__ __launch_bounds__(kThreads, 2) void k_conv_bx(const BxP p) {
     int bBase[2];                                                   // byte offset inside a term of the B image
 #pragma unroll
     for (int tn = 0; tn < 2; ++tn) {
-        if (TAPS == 1) bBase[tn] = (h * POS1 + bx_pos1(wn * 64 + tn * 32 + l31)) * 16;
+        if (TAPS == 1) bBase[tn] = PRE ? (h * POS1 + wn * 64 + tn * 32 + l31) * 16 : (h * POS1 + bx_pos1(wn * 64 + tn * 32 + l31)) * 16;
         else if (TW == 32) bBase[tn] = ((wn * 2 + tn) * PW + l31) * 16;
         else bBase[tn] = ((wn * 4 + tn * 2 + (l31 >> 4)) * PW + (l31 & 15)) * 16;        // 16 x 16: an MFMA column tile is 2 rows x 16 columns
     }
@@ -291,7 +321,7 @@ __global__ __launch_bounds__(kThreads, 2) void k_conv_bx(const BxP p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[tm][tn][r] = 0.0f;
 
-    const float* xb = p.x + (size_t)n * p.Cin * HW;
+    const float* xb = PRE ? nullptr : p.x + (size_t)n * p.Cin * HW;
     // DUAL (1x1 stride 1 only): the chunks of a second input / weight image follow those of the first; one accumulator set
     constexpr bool DUAL_OK = TAPS == 1 && !S2;
     const int n1 = (p.Cin + CK - 1) / CK;
@@ -302,7 +332,10 @@ __global__ __launch_bounds__(kThreads, 2) void k_conv_bx(const BxP p) {
     const float* xb2 = DUAL_OK && p.Cin2 ? p.x2 + (size_t)n * p.Cin2 * HW : nullptr;
     const int hw4 = HW * 4;
     v4f wr[NW];
-    float xr[NXR];
+    float xr[PRE ? 1 : NXR];
+    v4f xq[PRE ? NPRE : 1];
+    const int cgroups = (p.Cin + 7) >> 3;
+    const v4f* x3b = PRE ? p.x3 + (size_t)n * cgroups * 3 * HW : nullptr;
 
     if (tid < BM) {
         const bool real = m0 + tid < p.Cout;
@@ -328,7 +361,15 @@ __global__ __launch_bounds__(kThreads, 2) void k_conv_bx(const BxP p) {
         // (the channels of a last, partial chunk that do not exist lie beyond the resource: zeros against zero weights)
         const int cleft = cin - t * CK;
         const __amdgpu_buffer_rsrc_t xres = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(xsrc + (size_t)t * CK * HW), 0, (cleft < CK ? cleft : CK) * hw4, kBxRsrcFlags);
-        if (TAPS == 1) {
+        if (PRE) {
+            // (the k groups of a last, partial chunk that do not exist lie beyond the resource: zeros against zero weights)
+            constexpr int GPC = TAPS == 1 ? 4 : 1;
+            const int gleft = cgroups - t * GPC;
+            const __amdgpu_buffer_rsrc_t x3res = __builtin_amdgcn_make_buffer_rsrc(const_cast<v4f*>(x3b + (size_t)t * GPC * 3 * HW), 0,
+                                                                                   (gleft < GPC ? gleft : GPC) * 3 * HW * 16, kBxRsrcFlags);
+#pragma unroll
+            for (int j = 0; j < NPRE; ++j) xq[j] = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(x3res, pgoff[j], 0, 0));
+        } else if (TAPS == 1) {
 #pragma unroll
             for (int j = 0; j < NT; ++j)
 #pragma unroll
@@ -357,7 +398,10 @@ __global__ __launch_bounds__(kThreads, 2) void k_conv_bx(const BxP p) {
             if (WTAIL && j == NW - 1) *reinterpret_cast<v4f*>(reinterpret_cast<unsigned char*>(sA) + wtail) = wr[j];
             else sA[tid + j * kThreads] = wr[j];
         }
-        if (TAPS == 1) {
+        if (PRE) {
+#pragma unroll
+            for (int j = 0; j < NPRE; ++j) *reinterpret_cast<v4f*>(sB + ploff[j]) = xq[j];
+        } else if (TAPS == 1) {
 #pragma unroll
             for (int j = 0; j < NT; ++j)
 #pragma unroll
@@ -535,7 +579,7 @@ __global__ __launch_bounds__(kThreads, 2) void k_conv_bx(const BxP p) {
 // the M tile of a layer's weight image: a pure function of (ksize, Cout), shared by the pack and the launch
 inline int bx_bm(int ksize, int Cout) { return (ksize == 1 && Cout % 128 == 0) ? 128 : 64; }
 
-template <int TAPS, int BM, int BN, int V, bool RES, int TW = 32>
+template <int TAPS, int BM, int BN, int V, bool RES, int TW = 32, bool PRE = false>
 int bx_launch(BxP p, int N, hipStream_t st) {
     constexpr int GA = BxGeo<TAPS>::GA;
     p.mtiles = (p.Cout + BM - 1) / BM;
@@ -562,7 +606,7 @@ int bx_launch(BxP p, int N, hipStream_t st) {
         hipError_t e = hipGetDevice(&dev);
         if (e != hipSuccess) return (int)e;
         if (dev < 0 || dev >= 64 || !raised[dev]) {
-            e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv_bx<TAPS, BM, BN, V, RES, TW>), hipFuncAttributeMaxDynamicSharedMemorySize,
+            e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv_bx<TAPS, BM, BN, V, RES, TW, PRE>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                     80 * 1024);
             if (e != hipSuccess) return (int)e;
             if (dev >= 0 && dev < 64) raised[dev] = true;
@@ -570,13 +614,42 @@ int bx_launch(BxP p, int N, hipStream_t st) {
     }
     const long long nblk = 8LL * ((p.ptiles + 7) / 8) * p.mtiles * p.ksplit;
     if (nblk <= 0 || nblk > 0x7fffffffLL) return MAS_ERR_SHAPE;
-    hipLaunchKernelGGL((k_conv_bx<TAPS, BM, BN, V, RES, TW>), dim3((unsigned)nblk), dim3(kThreads), smem, st, p);
+    hipLaunchKernelGGL((k_conv_bx<TAPS, BM, BN, V, RES, TW, PRE>), dim3((unsigned)nblk), dim3(kThreads), smem, st, p);
     return mas_launch_status();
 }
 
-template <int TAPS, int BM, int BN, int V, int TW = 32>
+template <int TAPS, int BM, int BN, int V, int TW = 32, bool PRE = false>
 int bx_launch_r(const BxP& p, int N, hipStream_t st) {
-    return p.res ? bx_launch<TAPS, BM, BN, V, true, TW>(p, N, st) : bx_launch<TAPS, BM, BN, V, false, TW>(p, N, st);
+    return p.res ? bx_launch<TAPS, BM, BN, V, true, TW, PRE>(p, N, st) : bx_launch<TAPS, BM, BN, V, false, TW, PRE>(p, N, st);
+}
+
+// ---- bx3: an activation tensor already split ---------------------------------------------------------------------------------
+// x [N,C,H,W] f32  ->  [N][ceil(C/8)][3 terms][H*W][8 bf16]: one 16-byte unit = the (h | m | l) term of 8 consecutive channels of one
+// pixel = one unit of the B image of k_conv_bx<..., PRE>.  Channels beyond C are zeros.  One thread per (channel group, 4 pixels).
+__global__ __launch_bounds__(256) void k_bx3_split(const float* __restrict__ x, int C, int HW, int groups, unsigned* __restrict__ out) {
+    const int n = blockIdx.z, g = blockIdx.y;
+    const int q = blockIdx.x * 256 + threadIdx.x;            // pixel quad
+    if (4 * q >= HW) return;
+    const float* xb = x + ((size_t)n * C + 8 * g) * HW;
+    float v[8][4];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+        const bool real = 8 * g + c < C;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) v[c][i] = (real && 4 * q + i < HW) ? xb[(size_t)c * HW + 4 * q + i] : 0.0f;
+    }
+    unsigned* ob = out + ((size_t)(n * groups + g) * 3) * HW * 4;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        if (4 * q + i >= HW) break;
+        unsigned hh[4], mm[4], ll[4];
+#pragma unroll
+        for (int c2 = 0; c2 < 4; ++c2) bx_split2(v[2 * c2][i], v[2 * c2 + 1][i], hh[c2], mm[c2], ll[c2]);
+        const size_t u = (size_t)(4 * q + i) * 4;
+        *reinterpret_cast<uint4*>(ob + u) = make_uint4(hh[0], hh[1], hh[2], hh[3]);
+        *reinterpret_cast<uint4*>(ob + (size_t)HW * 4 + u) = make_uint4(mm[0], mm[1], mm[2], mm[3]);
+        *reinterpret_cast<uint4*>(ob + (size_t)2 * HW * 4 + u) = make_uint4(ll[0], ll[1], ll[2], ll[3]);
+    }
 }
 
 // y[i] += part[0][i] + part[1][i] + ... in index order (the parts of a split-K launch; y already holds part 0 + residual)
@@ -712,7 +785,7 @@ extern "C" int mas_conv_bx_fwd(const float* x, const void* wp, int N, int Cin, i
     hipStream_t st = static_cast<hipStream_t>(stream);
     BxP p;
     p.x = x; p.wp = static_cast<const v4f*>(wp); p.scale = scale; p.shift = shift; p.res = residual; p.y = y;
-    p.x2 = nullptr; p.wp2 = nullptr; p.Cin2 = 0; p.ksplit = 1; p.part = nullptr;
+    p.x2 = nullptr; p.wp2 = nullptr; p.Cin2 = 0; p.ksplit = 1; p.part = nullptr; p.x3 = nullptr;
     p.Cin = Cin; p.H = H; p.W = W; p.Cout = Cout; p.dil = dil; p.relu = relu;
 #ifdef BX_STAMPS
     p.stamps = g_bx_stamps;
@@ -744,7 +817,7 @@ extern "C" int mas_conv_bx_fwd_dual(const float* x1, const void* wp1, int Cin1, 
     hipStream_t st = static_cast<hipStream_t>(stream);
     BxP p;
     p.x = x1; p.wp = static_cast<const v4f*>(wp1); p.scale = nullptr; p.shift = shift; p.res = nullptr; p.y = y;
-    p.x2 = x2; p.wp2 = static_cast<const v4f*>(wp2); p.Cin2 = Cin2; p.ksplit = 1; p.part = nullptr;
+    p.x2 = x2; p.wp2 = static_cast<const v4f*>(wp2); p.Cin2 = Cin2; p.ksplit = 1; p.part = nullptr; p.x3 = nullptr;
     p.Cin = Cin1; p.H = H; p.W = W; p.Cout = Cout; p.dil = 1; p.relu = relu;
 #ifdef BX_STAMPS
     p.stamps = g_bx_stamps;
@@ -788,7 +861,7 @@ extern "C" int mas_conv_bx_train(const float* x, const void* wp, int N, int Cin,
     hipStream_t st = static_cast<hipStream_t>(stream);
     BxP p;
     p.x = x; p.wp = static_cast<const v4f*>(wp); p.scale = nullptr; p.shift = nullptr; p.res = residual; p.y = y;
-    p.x2 = nullptr; p.wp2 = nullptr; p.Cin2 = 0; p.ksplit = ksplit; p.part = static_cast<float*>(workspace);
+    p.x2 = nullptr; p.wp2 = nullptr; p.Cin2 = 0; p.ksplit = ksplit; p.part = static_cast<float*>(workspace); p.x3 = nullptr;
     p.Cin = Cin; p.H = H; p.W = W; p.Cout = Cout; p.dil = dil; p.relu = 0;
 #ifdef BX_STAMPS
     p.stamps = g_bx_stamps;
@@ -805,4 +878,42 @@ extern "C" int mas_conv_bx_train(const float* x, const void* wp, int N, int Cin,
     hipLaunchKernelGGL(k_bx_reduce, dim3((unsigned)(blocks < 4096 ? blocks : 4096)), dim3(256), 0, st, y, static_cast<const float*>(workspace),
                        ksplit - 1, n4, (long long)out_elems);
     return mas_launch_status();
+}
+
+/* ---- presplit activations (bx3) ------------------------------------------------------------------------------------------------ */
+extern "C" long long mas_bx3_bytes(int N, int C, int H, int W) {
+    if (N <= 0 || C <= 0 || H <= 0 || W <= 0) return 0;
+    return (long long)N * ((C + 7) / 8) * 3 * H * W * 16;
+}
+
+extern "C" int mas_bx3_split(const float* x, int N, int C, int H, int W, void* x3, void* stream) {
+    if (!x || !x3) return MAS_ERR_NULL;
+    if (N <= 0 || C <= 0 || H <= 0 || W <= 0 || N > 65535 || (C + 7) / 8 > 65535) return MAS_ERR_SHAPE;
+    if ((uintptr_t)x3 % 16 != 0) return MAS_ERR_ALIGN;
+    const int HW = H * W, groups = (C + 7) / 8;
+    hipLaunchKernelGGL(k_bx3_split, dim3((unsigned)((HW / 4 + 1 + 255) / 256), (unsigned)groups, (unsigned)N), dim3(256), 0, static_cast<hipStream_t>(stream), x, C,
+                       HW, groups, static_cast<unsigned*>(x3));
+    return mas_launch_status();
+}
+
+/* mas_conv_bx_fwd on an input that is already split (stride 1): x3 = the bx3 form of x [N,Cin,H,W] */
+extern "C" int mas_conv_bx_fwd_pre(const void* x3, const void* wp, int N, int Cin, int H, int W, int Cout, int ksize, int dil, const float* scale,
+                                   const float* shift, const float* residual, int relu, float* y, void* stream) {
+    if (!x3 || !wp || !y) return MAS_ERR_NULL;
+    if ((scale == nullptr) != (shift == nullptr)) return MAS_ERR_NULL;
+    if (N <= 0) return MAS_ERR_SHAPE;
+    if (!mas_conv_bx_supported(ksize, 1, dil, Cin, Cout, H, W) || 12LL * H * W * 16 >= 0x7fffffffLL) return MAS_ERR_SHAPE;
+    if ((uintptr_t)wp % 16 != 0 || (uintptr_t)x3 % 16 != 0) return MAS_ERR_ALIGN;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    BxP p;
+    p.x = nullptr; p.x3 = static_cast<const v4f*>(x3); p.wp = static_cast<const v4f*>(wp); p.scale = scale; p.shift = shift; p.res = residual; p.y = y;
+    p.x2 = nullptr; p.wp2 = nullptr; p.Cin2 = 0; p.ksplit = 1; p.part = nullptr;
+    p.Cin = Cin; p.H = H; p.W = W; p.Cout = Cout; p.dil = dil; p.relu = relu;
+#ifdef BX_STAMPS
+    p.stamps = g_bx_stamps;
+#endif
+    p.Ho = H; p.Wo = W;
+    const int BM = bx_bm(ksize, Cout);
+    if (ksize == 1) return BM == 128 ? bx_launch_r<1, 128, 128, 1, 32, true>(p, N, st) : bx_launch_r<1, 64, 256, 1, 32, true>(p, N, st);
+    return dil == 1 ? bx_launch_r<9, 64, 256, 1, 32, true>(p, N, st) : bx_launch_r<9, 64, 256, 2, 32, true>(p, N, st);
 }

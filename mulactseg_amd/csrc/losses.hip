@@ -784,8 +784,10 @@ extern "C" int mas_partial_loss_fwd_fused(const float* z, int h, int w, const vo
     if (int e = dispatch_loss(a, spx_dtype, false, st)) return e;
     if (gmax) {
         const long long n_entries = (long long)N * S * C;
-        long long nblk = (n_entries + kThreads - 1) / kThreads;
-        if (nblk > 1024) nblk = 1024;
+        // (few workgroups: every one of them ends in atomics on the same accumulator words -- with 640 of them those serialised at the
+        //  L2 for 40 us, measured; 64 x 256 threads x 10 entries each is 4 us)
+        long long nblk = (n_entries + 8 * kThreads - 1) / (8 * kThreads);
+        if (nblk > 64) nblk = 64;
         hipLaunchKernelGGL(k_group_finalize, dim3((unsigned)nblk), dim3(kThreads), 0, st, gmax, n_entries, acc, flags, weights, losses);
     } else if (losses) {
         if (weights) hipLaunchKernelGGL(k_loss_values_weighted, dim3(1), dim3(64), 0, st, acc, flags, weights, losses);

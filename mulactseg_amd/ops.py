@@ -1242,6 +1242,42 @@ def conv_bx(conv, x, bn=None, relu=False, residual=None):
     return y
 
 
+class Bx3:
+    """An activation tensor in presplit form (mas_bx3_split / an OUT3 epilogue): ``data`` int16 [N, ceil(C/8), 3, H*W, 8] (bf16 bits),
+    ``shape`` = the (N, C, H, W) of the f32 tensor it stands for."""
+    __slots__ = ("data", "shape")
+
+    def __init__(self, data, shape):
+        self.data, self.shape = data, tuple(shape)
+
+
+def bx3_split(x):
+    """The presplit form of x [N,C,H,W] f32 as a pass of its own (csrc/conv_bx.hip:k_bx3_split)."""
+    _need(x, "x", torch.float32)
+    N, C, H, W = x.shape
+    data = torch.empty((N, (C + 7) // 8, 3, H * W, 8), dtype=torch.int16, device=x.device)
+    with torch.cuda.device(x.device):
+        _lib.check(_lib.load().mas_bx3_split(x.data_ptr(), N, C, H, W, data.data_ptr(), _stream(x)), "mas_bx3_split")
+    return Bx3(data, x.shape)
+
+
+def conv_bx_pre(conv, x3, bn=None, relu=False, residual=None):
+    """conv_bx on a presplit input (stride 1): the same products and the same bits as conv_bx(conv, x, ...) on the f32 tensor."""
+    N, K, H, W = x3.shape
+    M = conv.out_channels
+    ks, s, d = conv.kernel_size[0], conv.stride[0], conv.dilation[0]
+    if s != 1 or K != conv.in_channels:
+        raise ValueError("conv_bx_pre: stride-1 convolutions on a presplit tensor of their input channels")
+    wp = _conv_bx_weight(conv)
+    scale, shift = _bn_fold(bn) if bn is not None else (None, None)
+    res = residual.contiguous() if residual is not None else None
+    y = torch.empty((N, M, H, W), dtype=torch.float32, device=x3.data.device)
+    with torch.cuda.device(y.device):
+        _lib.check(_lib.load().mas_conv_bx_fwd_pre(x3.data.data_ptr(), wp.data_ptr(), N, K, H, W, M, ks, d, _opt(scale), _opt(shift), _opt(res),
+                                                   int(relu), y.data_ptr(), _stream(y)), "mas_conv_bx_fwd_pre")
+    return y
+
+
 def stem_conv_supported(conv, x):
     """The deep stem's first convolution (3 -> C, 3x3, stride 2, padding 1) on csrc/stem.hip: fp32 NCHW, W % 8 == 0."""
     return (x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and x.shape[1] == 3 and conv.in_channels == 3

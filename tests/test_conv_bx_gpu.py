@@ -371,3 +371,33 @@ def test_non_finite_and_tiny_operands_behave_as_documented():
     ref = F.conv2d(tiny.double(), w.double())
     assert bool(torch.isfinite(yt).all())
     assert float((yt.double() - ref).abs().max()) <= 2.0 ** -15 * float(ref.abs().max())
+
+
+@pytest.mark.parametrize("Cin,Cout,k,stride,dil,N,H,W", [c for c in CASES if c[3] == 1])
+def test_presplit_input_gives_the_same_bits(Cin, Cout, k, stride, dil, N, H, W):
+    """mas_conv_bx_fwd_pre on the bx3 form of x (mas_bx3_split) == mas_conv_bx_fwd on x, bit for bit, with every epilogue: the split
+    of an element does not depend on who computes it, and the products are accumulated in the same order.  The bx3 tensor itself is
+    checked against the numpy restatement of the split (oracle/bx_split.py)."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from mulactseg_amd import ops
+    from oracle import bx_split
+    torch.manual_seed(Cin + 5 * Cout + k + H)
+    conv = nn.Conv2d(Cin, Cout, k, padding=dil if k == 3 else 0, dilation=dil, bias=False).cuda()
+    bn = nn.BatchNorm2d(Cout).cuda().eval()
+    with torch.no_grad():
+        bn.weight.uniform_(0.5, 1.5); bn.bias.normal_(); bn.running_mean.normal_(); bn.running_var.uniform_(0.5, 2.0)
+        x = torch.randn(N, Cin, H, W, device='cuda')
+        x3 = ops.bx3_split(x)
+        if Cin * H * W <= 1 << 20:
+            hml = [bx_split.bf16_bits(t) for t in bx_split.split3(x.cpu().numpy())]        # three uint16 arrays shaped like x
+            G = (Cin + 7) // 8
+            want = np.zeros((N, G, 3, H * W, 8), dtype=np.uint16)
+            for t in range(3):
+                pad = np.zeros((N, G * 8, H * W), dtype=np.uint16)
+                pad[:, :Cin] = hml[t].reshape(N, Cin, H * W)
+                want[:, :, t] = pad.reshape(N, G, 8, H * W).transpose(0, 1, 3, 2)
+            assert np.array_equal(x3.data.cpu().numpy().view(np.uint16), want)
+        res = torch.randn(N, Cout, H, W, device='cuda')
+        for kw in (dict(), dict(bn=bn, relu=True), dict(bn=bn, relu=True, residual=res)):
+            assert torch.equal(ops.conv_bx_pre(conv, x3, **kw), ops.conv_bx(conv, x, **kw)), kw.keys()
