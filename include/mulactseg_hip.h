@@ -519,6 +519,15 @@ int mas_conv_wgrad_bx_supported(int N, int Cin, int H, int W, int Cout);
 size_t mas_conv_wgrad_bx_workspace_bytes(int Cin, int Cout);
 int mas_conv_wgrad_bx(const float* x, const float* dy, int N, int Cin, int H, int W, int Cout, float* dw, void* workspace,
                       size_t workspace_bytes, void* stream);
+/* The same for the 3x3 stride-1 convolutions (padding = dilation = 1 | 2; models/segmentation/backbone/resnet.py:129-171: the deep
+ * stem, conv2 of every Bottleneck): dW[m,c,ty,tx] = sum_{n,y,x} dY[n,m,y,x] * X[n,c,y+(ty-1)d,x+(tx-1)d], dw [Cout,Cin,3,3].  With
+ * K = pixels a tap is a one-pixel shift of the K axis: the X patch is staged channel-contiguous (as the forward kernel stages it, a
+ * tap = a whole-unit offset) and read with gfx950's transposing LDS read (ds_read_b64_tr_b16), which hands the MFMA its K-contiguous
+ * fragment.  Workspace: mas_conv_wgrad_bx3_workspace_bytes(Cin, Cout); split-K partial tiles added in index order. */
+int mas_conv_wgrad_bx3_supported(int N, int Cin, int H, int W, int Cout, int dil);
+size_t mas_conv_wgrad_bx3_workspace_bytes(int Cin, int Cout);
+int mas_conv_wgrad_bx3(const float* x, const float* dy, int N, int Cin, int H, int W, int Cout, int dil, float* dw, void* workspace,
+                       size_t workspace_bytes, void* stream);
 
 /* Forward and input gradient of a dense convolution in training, as a persistent stream-K implicit GEMM on the f32 matrix
  * cores (csrc/conv_sk.hip).  `wp` is the weight as mas_conv_sk_pack writes it from PyTorch's [Cout][Cin][ksize][ksize] tensor

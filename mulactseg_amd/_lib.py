@@ -95,6 +95,9 @@ SIGNATURES = {
     "mas_conv_wgrad_bx_supported": (_i, [_i, _i, _i, _i, _i]),
     "mas_conv_wgrad_bx_workspace_bytes": (_c.c_size_t, [_i, _i]),
     "mas_conv_wgrad_bx": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _c.c_size_t, _vp]),
+    "mas_conv_wgrad_bx3_supported": (_i, [_i, _i, _i, _i, _i, _i]),
+    "mas_conv_wgrad_bx3_workspace_bytes": (_c.c_size_t, [_i, _i]),
+    "mas_conv_wgrad_bx3": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _c.c_size_t, _vp]),
     "mas_conv_sk_workspace_bytes": (_c.c_size_t, []),
     "mas_conv_sk_packed_elems": (_c.c_size_t, [_i, _i, _i, _i, _i]),
     "mas_conv_sk_pack": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _vp]),

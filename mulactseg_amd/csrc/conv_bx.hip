@@ -204,6 +204,11 @@ __global__ __launch_bounds__(kThreads, 2) void k_conv_bx(const BxP p) {
 
     const int tid = threadIdx.x;
     const int bid = blockIdx.x;
+#ifdef BX_STAGGER
+    // measurement build (tools/build_variant.sh): delay every other workgroup by ~BX_STAGGER x 64 cycles, so that the two workgroups
+    // of a CU -- same program, same length -- do not run their staging and their MFMA phases in lockstep
+    if ((BX_STAGGER_MODE == 1 && ((bid >> 3) & 1)) || (BX_STAGGER_MODE == 2 && ((bid >> 8) & 1))) __builtin_amdgcn_s_sleep(BX_STAGGER);
+#endif
     const int xcd = bid & 7;
     int slot = bid >> 3;
     const int per_part = p.mtiles * ((p.ptiles + 7) >> 3);          // slots of one K part (all of them when ksplit == 1)
@@ -429,7 +434,46 @@ __global__ __launch_bounds__(kThreads, 2) void k_conv_bx(const BxP p) {
         }
     };
 
+#ifndef BX_PIPE
+#define BX_PIPE 0
+#endif
     auto mfma_chunk = [&]() {
+        if (BX_PIPE) {
+            // the operand fragments of 16-k step s + 1 are requested BEFORE the MFMAs of step s (two register sets): no MFMA group
+            // but the first of a chunk waits for its own LDS reads
+            bf8 fa[2][2][3], fb[2][2][3];
+            auto load = [&](int s_, int st_) {
+#pragma unroll
+                for (int term = 0; term < 3; ++term) {
+#pragma unroll
+                    for (int tn = 0; tn < 2; ++tn) {
+                        const int off = bBase[tn] + term * bTerm + (TAPS == 1 ? 2 * s_ * POS1 * 16 : toff[s_]);
+                        fb[st_][tn][term] = __builtin_bit_cast(bf8, *reinterpret_cast<const v4f*>(sB + off));
+                    }
+#pragma unroll
+                    for (int tm = 0; tm < 2; ++tm) fa[st_][tm][term] = __builtin_bit_cast(bf8, sA[(term * GA + 2 * s_) * BM + aBase + tm * 32]);
+                }
+            };
+            load(0, 0);
+#pragma unroll
+            for (int s = 0; s < SLABS; ++s) {
+                if (s + 1 < SLABS) load(s + 1, (s + 1) & 1);
+                __builtin_amdgcn_sched_barrier(0);          // (the machine scheduler sinks the reads back to their uses otherwise)
+                const int st = s & 1;
+#pragma unroll
+                for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+                    for (int tn = 0; tn < 2; ++tn) {
+                        acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[st][tm][1], fb[st][tn][1], acc[tm][tn], 0, 0, 0);
+                        acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[st][tm][0], fb[st][tn][2], acc[tm][tn], 0, 0, 0);
+                        acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[st][tm][2], fb[st][tn][0], acc[tm][tn], 0, 0, 0);
+                        acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[st][tm][0], fb[st][tn][1], acc[tm][tn], 0, 0, 0);
+                        acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[st][tm][1], fb[st][tn][0], acc[tm][tn], 0, 0, 0);
+                        acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[st][tm][0], fb[st][tn][0], acc[tm][tn], 0, 0, 0);
+                    }
+            }
+            return;
+        }
 #pragma unroll
         for (int s = 0; s < SLABS; ++s) {
             bf8 b[2][3];
@@ -441,6 +485,27 @@ __global__ __launch_bounds__(kThreads, 2) void k_conv_bx(const BxP p) {
                     const v4f q = *reinterpret_cast<const v4f*>(sB + off);
                     b[tn][term] = __builtin_bit_cast(bf8, q);
                 }
+#ifndef BX_ILV
+#define BX_ILV 0
+#endif
+            if (BX_ILV) {
+                // (measurement variant: consecutive MFMAs go to DIFFERENT accumulators -- the same products in the same order per
+                //  accumulator, so the same bits -- in case a dependent accumulate chain does not issue back to back)
+                bf8 a2[2][3];
+#pragma unroll
+                for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+                    for (int term = 0; term < 3; ++term) a2[tm][term] = __builtin_bit_cast(bf8, sA[(term * GA + 2 * s) * BM + aBase + tm * 32]);
+                constexpr int ta[6] = {1, 0, 2, 0, 1, 0}, tb[6] = {1, 2, 0, 1, 0, 0};
+#pragma unroll
+                for (int st6 = 0; st6 < 6; ++st6)
+#pragma unroll
+                    for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+                        for (int tn = 0; tn < 2; ++tn)
+                            acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2[tm][ta[st6]], b[tn][tb[st6]], acc[tm][tn], 0, 0, 0);
+                continue;
+            }
 #pragma unroll
             for (int tm = 0; tm < 2; ++tm) {
                 bf8 a[3];

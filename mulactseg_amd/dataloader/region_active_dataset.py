@@ -285,9 +285,18 @@ class RegionActiveDataset:
             dict.__setitem__(lazy, key[2], _FromTable(self._valid, self._image_index(key[2])))
         if len(lazy) != len(pool.suppix):       # (entries without a picture in im_idx: leave the dictionaries alone)
             return
-        pool.suppix = lazy
+        old, pool.suppix = pool.suppix, lazy
         if not isinstance(label.suppix, LazySuppix):
             label.suppix = LazySuppix(label.suppix)
+        # The lists just replaced are 6 M Python ints for a Cityscapes pool: freeing them takes 50 ms of interpreter time.  A daemon
+        # thread drops them entry by entry (a bytecode boundary between any two, so the round's own thread -- mostly waiting for the
+        # device at this point -- is never held up for longer than one list).
+        if len(old) > 64:
+            def reap(d=old):
+                while d:
+                    d.popitem()
+            threading.Thread(target=reap, daemon=True).start()
+        del old
 
     # -- selection ------------------------------------------------------------------------------
     def expand_training_set(self, sample_region, selection_count, selection_method):

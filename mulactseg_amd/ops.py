@@ -1332,6 +1332,10 @@ def conv_wgrad(x, dy, ksize, stride, dil):
         # 1x1: split-bf16 kernel (csrc/conv_wgrad_bx.hip), 1.3-1.7x the f32 kernel (profiles/r04/k_bx_train_table.md); with 64 or
         # fewer output channels half of its 128 x 128 tile is padding and the f32 kernel stays ahead
         return conv_wgrad_bx(x, dy)
+    if (ksize == 3 and stride == 1 and os.environ.get("MAS_TRAIN_BX", "auto") not in ("off", "r04") and os.environ.get("MAS_WGRAD3", "bx") != "f32"
+            and lib.mas_conv_wgrad_bx3_supported(N, Cin, H, W, Cout, dil)):
+        # 3x3 stride 1: split-bf16 kernel with the X patch read through gfx950's transposing LDS read (csrc/conv_wgrad_bx3.hip)
+        return conv_wgrad_bx3(x, dy, dil)
     nbytes = lib.mas_conv_wgrad_workspace_bytes(N, Cin, H, W, Cout, ksize, stride, dil)
     if nbytes == 0:
         raise ValueError("unsupported convolution geometry for mas_conv_wgrad")
@@ -1360,6 +1364,27 @@ def conv_wgrad_bx(x, dy):
     with torch.cuda.device(x.device):
         _lib.check(lib.mas_conv_wgrad_bx(x.data_ptr(), dy.data_ptr(), N, Cin, H, W, Cout, dw.data_ptr(), ws.data_ptr(), ws.numel(),
                                          _stream(x)), "mas_conv_wgrad_bx")
+    return dw
+
+
+def conv_wgrad_bx3(x, dy, dil=1):
+    """dW [Cout,Cin,3,3] of a 3x3 stride-1 convolution (padding = dilation = 1 | 2) from x [N,Cin,H,W] and dy [N,Cout,H,W] on the bf16
+    matrix cores with exact three-term splits of both f32 operands (mas_conv_wgrad_bx3: the X patch staged channel-contiguous as the
+    forward kernel stages it, read with ds_read_b64_tr_b16; split-K over chunks of 4 x 16 pixels, fixed-order reduction)."""
+    _need(x, "x", torch.float32)
+    _need(dy, "dy", torch.float32)
+    N, Cin, H, W = x.shape
+    Cout = dy.shape[1]
+    if tuple(dy.shape) != (N, Cout, H, W):
+        raise ValueError("dy %s does not match x %s" % (tuple(dy.shape), tuple(x.shape)))
+    lib = _lib.load()
+    if not lib.mas_conv_wgrad_bx3_supported(N, Cin, H, W, Cout, dil):
+        raise ValueError("unsupported geometry for mas_conv_wgrad_bx3: x %s, dilation %d" % (tuple(x.shape), dil))
+    ws = _wgrad_workspace(x.device, lib.mas_conv_wgrad_bx3_workspace_bytes(Cin, Cout))
+    dw = torch.empty((Cout, Cin, 3, 3), dtype=torch.float32, device=x.device)
+    with torch.cuda.device(x.device):
+        _lib.check(lib.mas_conv_wgrad_bx3(x.data_ptr(), dy.data_ptr(), N, Cin, H, W, Cout, int(dil), dw.data_ptr(), ws.data_ptr(), ws.numel(),
+                                          _stream(x)), "mas_conv_wgrad_bx3")
     return dw
 
 

@@ -401,3 +401,73 @@ def test_presplit_input_gives_the_same_bits(Cin, Cout, k, stride, dil, N, H, W):
         res = torch.randn(N, Cout, H, W, device='cuda')
         for kw in (dict(), dict(bn=bn, relu=True), dict(bn=bn, relu=True, residual=res)):
             assert torch.equal(ops.conv_bx_pre(conv, x3, **kw), ops.conv_bx(conv, x, **kw)), kw.keys()
+
+
+WGRAD3_CASES = [
+    # Cin, Cout, dil, N, H, W
+    (64, 64, 1, 2, 48, 48),          # layer1 conv2 scaled: 1 x 2 tiles, whole chunks
+    (128, 128, 1, 1, 24, 40),        # partial chunk columns (40 = 2.5 x 16)
+    (256, 256, 1, 2, 12, 12),        # plane smaller than a chunk row, many tiles
+    (512, 512, 2, 1, 13, 21),        # dilation 2, odd plane
+    (64, 128, 1, 1, 49, 49),         # the 769-crop planes: rows that are only 4-byte aligned
+    (64, 64, 1, 1, 97, 97),
+    (40, 72, 1, 2, 18, 35),          # Cin = 1.25 tiles of 32 (the last quad partial), Cout = 1.125 tiles of 64
+    (35, 64, 2, 1, 9, 30),           # Cin not a multiple of 4: the last channel quad has three channels
+    (8, 24, 1, 1, 5, 7),             # everything smaller than one tile / chunk
+    (64, 64, 1, 4, 96, 96),          # split K over many ranges
+]
+
+
+@pytest.mark.parametrize("Cin,Cout,dil,N,H,W", WGRAD3_CASES)
+def test_wgrad_3x3_on_the_bf16_cores_matches_float64(Cin, Cout, dil, N, H, W):
+    """mas_conv_wgrad_bx3 (X patch through ds_read_b64_tr_b16) against the float64 weight gradient of conv2d, at the bar of the f32
+    kernel it replaces (2e-5 of the result's scale) and no worse than 2x that kernel's own error; run-to-run identical."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from mulactseg_amd import ops
+    torch.manual_seed(Cin + 7 * Cout + dil + H + W)
+    x = torch.randn(N, Cin, H, W, device='cuda')
+    dy = torch.randn(N, Cout, H, W, device='cuda')
+    ref = torch.nn.grad.conv2d_weight(x.double(), (Cout, Cin, 3, 3), dy.double(), 1, dil, dil)
+    got = ops.conv_wgrad_bx3(x, dy, dil)
+    scale = float(ref.abs().max())
+    err = float((got.double() - ref).abs().max())
+    assert err <= 2e-5 * scale, (err, scale)
+    import os
+    os.environ["MAS_WGRAD3"] = "f32"
+    try:
+        f32 = ops.conv_wgrad(x, dy, 3, 1, dil)
+    finally:
+        os.environ.pop("MAS_WGRAD3")
+    err32 = float((f32.double() - ref).abs().max())
+    assert err <= 2.0 * err32 + 1e-6 * scale, (err, err32, scale)
+    assert torch.equal(got, ops.conv_wgrad_bx3(x, dy, dil))
+    assert torch.equal(ops.conv_wgrad(x, dy, 3, 1, dil), got)             # the dispatcher takes this kernel
+
+
+def test_wgrad_3x3_exact_on_integers_and_tap_by_tap():
+    """Integer data: every product and partial sum is exact, so the result equals float64 bit for bit -- the lane maps of the
+    transposing read, the tap offsets, the halo, the zero padding at the plane's edges and the chunk edges are all pinned.  And a
+    one-hot probe: dY = a single 1 at (m, y, x) makes dW[m, c, ty, tx] = X[c, y + (ty-1) d, x + (tx-1) d] for every tap."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from mulactseg_amd import ops
+    g = torch.Generator(device='cuda').manual_seed(31)
+    for (Cin, Cout, dil, N, H, W) in ((64, 64, 1, 2, 20, 36), (32, 96, 2, 1, 11, 19), (96, 64, 1, 1, 8, 16), (64, 64, 2, 1, 49, 49)):
+        x = torch.randint(-4, 5, (N, Cin, H, W), generator=g, device='cuda').float()
+        dy = torch.randint(-3, 4, (N, Cout, H, W), generator=g, device='cuda').float()
+        ref = torch.nn.grad.conv2d_weight(x.double(), (Cout, Cin, 3, 3), dy.double(), 1, dil, dil).float()
+        assert torch.equal(ops.conv_wgrad_bx3(x, dy, dil), ref), (Cin, Cout, dil, H, W)
+    for dil in (1, 2):
+        H, W = 10, 23
+        x = torch.arange(1 * 32 * H * W, device='cuda', dtype=torch.float32).reshape(1, 32, H, W) % 251
+        for (m, y, xx) in ((5, 0, 0), (40, 4, 15), (63, H - 1, W - 1), (17, 3, 16)):
+            dy = torch.zeros(1, 64, H, W, device='cuda')
+            dy[0, m, y, xx] = 1.0
+            dw = ops.conv_wgrad_bx3(x, dy, dil)
+            assert float(dw[torch.arange(64, device='cuda') != m].abs().max()) == 0.0
+            for ty in range(3):
+                for tx in range(3):
+                    iy, ix = y + (ty - 1) * dil, xx + (tx - 1) * dil
+                    want = x[0, :, iy, ix] if (0 <= iy < H and 0 <= ix < W) else torch.zeros(32, device='cuda')
+                    assert torch.equal(dw[m, :, ty, tx], want), (dil, m, y, xx, ty, tx)

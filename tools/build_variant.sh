@@ -5,6 +5,6 @@ unit=$1; flags=$2; out=$3
 cd "$(dirname "$0")/../mulactseg_amd/csrc"
 make -s all
 /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -ffp-contract=off -fno-fast-math -Wall -Wno-unused-function $flags -c $unit.hip -o /tmp/variant_$unit.o
-objs=$(ls *.o | grep -v "^$unit.o$" | tr '\n' ' ')
+objs=$(ls *.o | grep -v "^$unit.o$" | grep -v "^test_support.o$" | tr '\n' ' ')
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../$out $objs /tmp/variant_$unit.o
 echo built mulactseg_amd/$out

@@ -35,17 +35,21 @@ def main():
     for name, m in net.named_modules():
         if isinstance(m, nn.Conv2d):
             m.register_forward_hook(hook(name))
-    os.environ["MAS_INFER_CONV"] = "off"
+    # (shape walk through the nn.Modules: training mode with MAS_TRAIN_CONV=miopen calls every Conv2d module, so the hooks see every
+    #  layer; a quarter-size picture, the planes scaled back by 4 below)
+    os.environ["MAS_TRAIN_CONV"] = "miopen"
+    net.train()
     with torch.no_grad():
-        import torch.nn.functional as F
-        # (shape walk through the nn.Modules: MIOpen's solver search per shape is slow at the pool size -- a quarter-size walk, scaled)
-        net(torch.randn(1, 3, H // 4, W // 4, device=dev))
+        net(torch.randn(2, 3, H // 4, W // 4, device=dev))
+    os.environ.pop("MAS_TRAIN_CONV")
     lib = _lib.load()
     lines = ["# presplit (bx3) input: consumer kernel time per layer, batch [%d,3,%d,%d] (us per call)" % (N, H, W), "",
              "| x | Cin | Cout | k | d | H | W | M tiles | f32 input | bx3 input | gain | split pass (f32 -> bx3) | first layer |", "|---|---|---|---|---|---|---|---|---|---|---|---|---|"]
     tot = collections.Counter()
     for (cin, cout, k, s, d, g, xs), names in shapes.items():
         h, w = xs[2] * 4, xs[3] * 4
+        if cin * h * w * N * 4 > 3 << 30:
+            continue
         if g != 1 or s != 1 or cin < 8 or h * w < 256 or not lib.mas_conv_bx_supported(k, 1, d, cin, cout, h, w):
             continue
         conv = nn.Conv2d(cin, cout, k, padding=d if k == 3 else 0, dilation=d, bias=False).to(dev)

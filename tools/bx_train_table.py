@@ -74,6 +74,14 @@ def main():
             b_w = None
             if k == 1 and lib.mas_conv_wgrad_bx_supported(xs[0], cin, xs[2], xs[3], cout):
                 b_w = timeit(lambda: ops.conv_wgrad_bx(x, dy))
+            if k == 3 and lib.mas_conv_wgrad_bx3_supported(xs[0], cin, xs[2], xs[3], cout, d):
+                wf = ops.conv_wgrad(x, dy, k, 1, d) if False else None
+                os.environ["MAS_TRAIN_BX"] = "off"
+                wf = ops.conv_wgrad(x, dy, k, 1, d)
+                os.environ.pop("MAS_TRAIN_BX")
+                wb = ops.conv_wgrad_bx3(x, dy, d)
+                assert float((wb - wf).abs().max()) <= 2e-5 * float(wf.abs().max()), names[0]
+                b_w = timeit(lambda: ops.conv_wgrad_bx3(x, dy, d))
         tot['w_f32'] += mult * t_w
         tot['w_best'] += mult * min(t_w, b_w if b_w else 1e9)
         flop = 2.0 * cin * k * k * y.numel()
