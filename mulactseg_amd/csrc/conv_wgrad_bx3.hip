@@ -55,12 +55,16 @@ __device__ __forceinline__ int w3_bslot(int slot, int cq) { return slot * 64 + (
 template <int DIL>
 __global__ __launch_bounds__(kW3Threads, 2) void k_wgrad_bx3(const W3P p) {
     constexpr int PR = kW3TH + 2 * DIL, PC = kW3TW + 2 * DIL;          // rows / valid columns of the X patch
-    constexpr int NPIX = PR * PC;                                       // pixels of the patch that are staged
     constexpr int PPB = PR * kW3PW;                                     // pixel slots of one term of the B image
     constexpr int TERMB = PPB * 64;                                     // bytes of one term of the B image
     constexpr int TERMA = 8 * kW3AP * 16;                               // bytes of one term of the A image ([8 pixel groups][rows])
     constexpr int NTA = (kW3BM * kW3TH * 4 + kW3Threads - 1) / kW3Threads;      // A tasks per thread: (row, strip row, pixel quad)
-    constexpr int NTB = (NPIX * 8 + kW3Threads - 1) / kW3Threads;               // B tasks per thread: (patch pixel, channel quad)
+    // the patch is staged in pixel quads ALIGNED IN THE PICTURE: columns x0 - 4 .. x0 + 19 (six quads; the taps need x0 - DIL ..
+    // x0 + 15 + DIL).  A quad then lies either wholly left of the picture or starts inside it -- no 16-byte load straddles the
+    // start of a row's first pixel, where "the element before" belongs to another row (or lies before the tensor)
+    constexpr int QX = kW3PW / 4;                                       // 6
+    constexpr int NQ = PR * QX * 8;                                     // B tasks of a chunk: (patch row, pixel quad, channel quad) = 288 / 384
+    static_assert(NQ <= kW3Threads && PC + (4 - DIL) <= kW3PW, "one B task per thread");
     extern __shared__ __attribute__((aligned(16))) unsigned char w3_smem[];
     unsigned char* sA = w3_smem;
     unsigned char* sB = w3_smem + 3 * TERMA;
@@ -95,28 +99,18 @@ __global__ __launch_bounds__(kW3Threads, 2) void k_wgrad_bx3(const W3P p) {
         arow[j] = r;
         acol[j] = pq * 4;
     }
-    // B: task e = tid + 384 j -> patch pixel pix = e % NPIX (consecutive lanes = consecutive pixels of a patch row: coalesced loads),
-    // channel quad cq = e / NPIX
-    int gb[NTB], lb[NTB], brow[NTB], bcol[NTB];
+    // B: ONE task per thread = 4 consecutive patch pixels x 4 channels (four 16-byte loads, as the 1x1 forward kernel fetches its
+    // operand): thread -> (channel quad cq, patch row py, pixel quad qx); the split pairs channels at the same pixel, so every pixel
+    // gives one 8-byte piece [pixel][4 channels] per term.  Threads beyond the NQ tasks store zeros to the unused pad slot.
+    const bool btask = tid < NQ;
+    const int bcq = tid / (PR * QX), brem = tid - bcq * (PR * QX);
+    const int bpy = brem / QX, bpx = (brem - bpy * QX) * 4;
+    const int bchan = p.Cin - (c0 + 4 * bcq);                            // channels of this task's quad that exist (>= 4: all)
+    const bool bvalid = btask && bchan > 0;
+    const int gb = ((c0 + 4 * bcq) * HW + bpy * W + bpx) * 4;
+    int lb[4];
 #pragma unroll
-    for (int j = 0; j < NTB; ++j) {
-        const int e = tid + j * kW3Threads;
-        const int cq = e / NPIX, pix = e - cq * NPIX;
-        const int py = pix / PC, px = pix - py * PC;
-        const bool real = e < NPIX * 8 && c0 + 4 * cq < p.Cin;
-        gb[j] = real ? ((c0 + 4 * cq) * HW + py * W + px) * 4 : kW3Out;
-        lb[j] = e < NPIX * 8 ? w3_bslot(py * kW3PW + px, cq) : w3_bslot(PPB - 1, tid & 7);     // (beyond the patch: the unused pad slot)
-        brow[j] = py;
-        bcol[j] = px;
-    }
-    // channels of the last quad beyond Cin: their loads must read zeros
-    int bchan[NTB];
-#pragma unroll
-    for (int j = 0; j < NTB; ++j) {
-        const int e = tid + j * kW3Threads;
-        bchan[j] = p.Cin - (c0 + 4 * (e / NPIX));                        // channels of this task's quad that exist (>= 4: all)
-    }
-
+    for (int i = 0; i < 4; ++i) lb[i] = btask ? w3_bslot(bpy * kW3PW + bpx + i, bcq) : w3_bslot(PPB - 1, tid & 7);     // (columns 22, 23 of a patch row are never read)
     // ---- MFMA operand addressing ----------------------------------------------------------------------------------------------------
     const int wave = tid >> 6, lane = tid & 63, l31 = lane & 31, h = lane >> 5;
     const int wm = wave & 1, ty = wave >> 1;                             // M half, tap row
@@ -131,7 +125,7 @@ __global__ __launch_bounds__(kW3Threads, 2) void k_wgrad_bx3(const W3P p) {
         for (int tx = 0; tx < 3; ++tx)
 #pragma unroll
             for (int jj = 0; jj < 2; ++jj) {
-                const int slot = 8 * (g >> 1) + 4 * jj + qq + tx * DIL + ty * DIL * kW3PW;      // + r * kW3PW per k step (a multiple of 8)
+                const int slot = 8 * (g >> 1) + 4 * jj + qq + (4 + (tx - 1) * DIL) + ty * DIL * kW3PW;      // + r * kW3PW per k step (a multiple of 8)
                 bBase[tx][jj] = w3_bslot(slot, cqi);
             }
     }
@@ -144,8 +138,8 @@ __global__ __launch_bounds__(kW3Threads, 2) void k_wgrad_bx3(const W3P p) {
     const int cq_ = p.nch / p.S, cr_ = p.nch - cq_ * p.S;                // ranges of cq or cq + 1 chunks (the first cr ranges take one more)
     const int c_lo = s * cq_ + (s < cr_ ? s : cr_), c_hi = c_lo + cq_ + (s < cr_ ? 1 : 0);
     v4f ra[NTA];
-    float rb[NTB][4];
-    int rows_left = 0, cols_left = 0;                                     // of the chunk in the staging registers
+    v4f rb[4];                                                            // channel a of the quad: 4 consecutive pixels
+    int rows_left = 0, cols_left = 0, bx_left = 0;                        // of the chunk in the staging registers
     const int cpp = p.cx * p.cy;
     auto fetch = [&](int cidx) {
         cidx = __builtin_amdgcn_readfirstlane(cidx);                      // wave-uniform (keeps the resource descriptors in scalar registers)
@@ -162,18 +156,15 @@ __global__ __launch_bounds__(kW3Threads, 2) void k_wgrad_bx3(const W3P p) {
         for (int j = 0; j < NTA; ++j) ra[j] = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(ares, ga[j], 0, 0));
         // X of picture n; the patch starts DIL rows / columns before the chunk: a pixel outside the plane reads zeros (kW3Out)
         const __amdgpu_buffer_rsrc_t bres = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.x + (size_t)n * p.Cin * HW), 0, p.Cin * HW * 4, kW3RsrcFlags);
-        const int boff = ((y0 - DIL) * W + (x0 - DIL)) * 4;
+        const int boff = ((y0 - DIL) * W + (x0 - 4)) * 4;
         const int hw4 = HW * 4;
+        const int iy = y0 - DIL + bpy;
+        bx_left = x0 - 4 + bpx;                                           // input column of the quad's first pixel: -4 (the quad left of the picture), or >= 0
+        const int vo = (bvalid && (unsigned)iy < (unsigned)H && (unsigned)bx_left < (unsigned)W) ? gb + boff : kW3Out;
 #pragma unroll
-        for (int j = 0; j < NTB; ++j) {
-            const int iy = y0 - DIL + brow[j], ix = x0 - DIL + bcol[j];
-            const bool ok = (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
-            const int vo = ok ? gb[j] + boff : kW3Out;
-#pragma unroll
-            for (int a = 0; a < 4; ++a) {
-                const int va = a < bchan[j] ? vo : kW3Out;
-                rb[j][a] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(bres, va, a * hw4, 0));
-            }
+        for (int a = 0; a < 4; ++a) {
+            const int va = a < bchan ? vo : kW3Out;
+            rb[a] = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(bres, va, a * hw4, 0));
         }
     };
     auto stage = [&]() {
@@ -191,12 +182,15 @@ __global__ __launch_bounds__(kW3Threads, 2) void k_wgrad_bx3(const W3P p) {
             *reinterpret_cast<v2u*>(dst + TERMA) = (v2u){m0_, m1};
             *reinterpret_cast<v2u*>(dst + 2 * TERMA) = (v2u){l0, l1};
         }
+        // X: a pixel column >= W is the convolution's zero padding (its 16-byte load ran into the next row): selects
 #pragma unroll
-        for (int j = 0; j < NTB; ++j) {
+        for (int i = 0; i < 4; ++i) {
+            const bool ok = (unsigned)(bx_left + i) < (unsigned)W;
+            const float v0 = ok ? rb[0][i] : 0.0f, v1 = ok ? rb[1][i] : 0.0f, v2 = ok ? rb[2][i] : 0.0f, v3 = ok ? rb[3][i] : 0.0f;
             unsigned h0, m0_, l0, h1, m1, l1;
-            bx_split2(rb[j][0], rb[j][1], h0, m0_, l0);
-            bx_split2(rb[j][2], rb[j][3], h1, m1, l1);
-            unsigned char* dst = sB + lb[j];
+            bx_split2(v0, v1, h0, m0_, l0);
+            bx_split2(v2, v3, h1, m1, l1);
+            unsigned char* dst = sB + lb[i];
             *reinterpret_cast<v2u*>(dst) = (v2u){h0, h1};
             *reinterpret_cast<v2u*>(dst + TERMB) = (v2u){m0_, m1};
             *reinterpret_cast<v2u*>(dst + 2 * TERMB) = (v2u){l0, l1};
