@@ -16,7 +16,7 @@
 // (four 16-k steps, one per row); nine (M x N) accumulator tiles, one per tap.  A workgroup is SIX waves = 2 (M halves) x 3 (tap
 // rows ty): a wave owns 32 x 32 x 3 taps = 48 accumulator registers, reads the A fragment of a k step once for its three taps and
 // the B fragment of every tap with two transposing reads per term.  Chunk t + 1 travels global -> registers in front of the MFMAs
-// of chunk t and registers -> (split) -> LDS behind them; 53 / 62 KB of LDS: two workgroups (twelve waves) per CU.
+// of chunk t and registers -> (split) -> LDS behind them; 53 / 62 KB of LDS, <= 128 registers: two workgroups (twelve waves) per CU.
 // Split K: the grid is (tiles) x S chunk ranges; every workgroup writes its partial tile into slice s of the workspace
 // [S][Cout][Cin][9] and k_w3_reduce adds the slices in index order (no atomics: run-to-run identical).
 #include "common.h"
@@ -52,8 +52,13 @@ struct W3P {
 // Offsets that are multiples of 8 slots (a patch row: kW3PW; a 16-k step: 16) leave the XOR term alone, so they are immediates.
 __device__ __forceinline__ int w3_bslot(int slot, int cq) { return slot * 64 + ((cq ^ (slot & 7)) << 3); }
 
+// Register budget: 128 (four waves per SIMD), not the 168 that "two workgroups of six waves per CU" would allow on paper: the six
+// waves of a workgroup land on the four SIMDs as 2 + 2 + 1 + 1, and a second workgroup may put ITS two pairs on the same SIMDs --
+// four waves on one SIMD.  With 147 registers that second workgroup did not fit: one workgroup per CU, every wave of the CU in
+// the same phase (SQ_VALU_MFMA_COEXEC_CYCLES / SQ_VALU_MFMA_BUSY_CYCLES = 0.01, MfmaUtil 0.35); at <= 128 any placement fits
+// (co-execution 0.10 - 0.15, MfmaUtil 0.49, 352 -> 302 us on the 64 -> 64 layer of the stem).
 template <int DIL>
-__global__ __launch_bounds__(kW3Threads, 2) void k_wgrad_bx3(const W3P p) {
+__global__ __attribute__((amdgpu_flat_work_group_size(384, 384), amdgpu_waves_per_eu(4, 4))) void k_wgrad_bx3(const W3P p) {
     constexpr int PR = kW3TH + 2 * DIL, PC = kW3TW + 2 * DIL;          // rows / valid columns of the X patch
     constexpr int PPB = PR * kW3PW;                                     // pixel slots of one term of the B image
     constexpr int TERMB = PPB * 64;                                     // bytes of one term of the B image
@@ -102,8 +107,12 @@ __global__ __launch_bounds__(kW3Threads, 2) void k_wgrad_bx3(const W3P p) {
     // B: ONE task per thread = 4 consecutive patch pixels x 4 channels (four 16-byte loads, as the 1x1 forward kernel fetches its
     // operand): thread -> (channel quad cq, patch row py, pixel quad qx); the split pairs channels at the same pixel, so every pixel
     // gives one 8-byte piece [pixel][4 channels] per term.  Threads beyond the NQ tasks store zeros to the unused pad slot.
+    // thread -> (channel quad = tid & 7, (patch row, pixel quad) = tid >> 3): the 8 lanes of one pixel quad write the 8 channel
+    // quads of a pixel -- 64 contiguous bytes up to the XOR -- so a 16-lane store group covers every bank position twice (2-way).
+    // (With the channel quad SLOWEST the 16 lanes of a group wrote pixels 4 apart: (slot & 7) took two values only -- an 8-way bank
+    //  conflict on every staging store: SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE = 0.48 - 0.59, MfmaUtil 0.33.)
     const bool btask = tid < NQ;
-    const int bcq = tid / (PR * QX), brem = tid - bcq * (PR * QX);
+    const int bcq = tid & 7, brem = tid >> 3;
     const int bpy = brem / QX, bpx = (brem - bpy * QX) * 4;
     const int bchan = p.Cin - (c0 + 4 * bcq);                            // channels of this task's quad that exist (>= 4: all)
     const bool bvalid = btask && bchan > 0;

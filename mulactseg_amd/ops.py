@@ -1334,7 +1334,6 @@ def conv_wgrad(x, dy, ksize, stride, dil):
         return conv_wgrad_bx(x, dy)
     w3 = os.environ.get("MAS_WGRAD3", "auto")
     if (ksize == 3 and stride == 1 and os.environ.get("MAS_TRAIN_BX", "auto") not in ("off", "r04") and w3 != "f32"
-            and (w3 == "bx" or 18.0 * N * H * W * Cin * Cout >= 2e10)        # (products of 10 GFLOP: level with the f32 kernel, profiles/r05/k_bx_train_table.md)
             and lib.mas_conv_wgrad_bx3_supported(N, Cin, H, W, Cout, dil)):
         # 3x3 stride 1: split-bf16 kernel with the X patch read through gfx950's transposing LDS read (csrc/conv_wgrad_bx3.hip)
         return conv_wgrad_bx3(x, dy, dil)

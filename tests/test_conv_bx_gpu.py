@@ -442,11 +442,7 @@ def test_wgrad_3x3_on_the_bf16_cores_matches_float64(Cin, Cout, dil, N, H, W):
     err32 = float((f32.double() - ref).abs().max())
     assert err <= 2.0 * err32 + 1e-6 * scale, (err, err32, scale)
     assert torch.equal(got, ops.conv_wgrad_bx3(x, dy, dil))
-    os.environ["MAS_WGRAD3"] = "bx"
-    try:
-        assert torch.equal(ops.conv_wgrad(x, dy, 3, 1, dil), got)         # the dispatcher takes this kernel (auto: products >= 20 GFLOP)
-    finally:
-        os.environ.pop("MAS_WGRAD3")
+    assert torch.equal(ops.conv_wgrad(x, dy, 3, 1, dil), got)             # the dispatcher takes this kernel
 
 
 def test_wgrad_3x3_exact_on_integers_and_tap_by_tap():
