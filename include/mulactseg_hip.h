@@ -392,12 +392,16 @@ int mas_upsample_bilinear_bwd(const float* gy, int64_t NC, int Hi, int Wi, int H
  * ((HW + 3) / 4 + 1 groups per plane, whatever the plane's alignment), bit k = output k of the group is positive;
  * train_bwd: dx, dresidual (= masked dy; may be NULL), dgamma, dbeta (may be NULL); the ReLU mask comes from `relu_mask`
  * when given, else from the forward output `y`.
- * eval_fwd: the same map with the running statistics. */
+ * eval_fwd: the same map with the running statistics.
+ * counters (train_fwd / train_bwd; may be NULL): C zeroed 32-bit words in device memory that STAY zeroed between calls (the caller
+ * keeps one such array per stream).  With it the workgroup that writes a channel's last partial sums turns them into the channel's
+ * statistics (forward: mean / invstd / running statistics; backward: dgamma / dbeta / the two means) -- two launches instead of
+ * three, same sums in the same order, same bits. */
 int64_t mas_bn_workspace_bytes(int N, int C, int HW);
 int64_t mas_bn_mask_bytes(int N, int C, int HW);
 int mas_bn_act_train_fwd(const float* x, const float* gamma, const float* beta, const float* residual, int N, int C, int HW, float eps,
                          float momentum, int relu, float* running_mean, float* running_var, int64_t* num_batches_tracked,
-                         float* save_mean, float* save_invstd, void* workspace, float* y, uint8_t* relu_mask, void* stream);
+                         float* save_mean, float* save_invstd, void* workspace, float* y, uint8_t* relu_mask, uint32_t* counters, void* stream);
 /* train_fwd with the partial sums formed by the producer of x (mas_conv_sk_stats): partials [C][per_channel] pairs of doubles */
 int mas_bn_act_train_fwd_stats(const float* x, const double* partials, int per_channel, const float* gamma, const float* beta,
                                const float* residual, int N, int C, int HW, float eps, float momentum, int relu, float* running_mean,
@@ -407,7 +411,7 @@ int mas_bn_act_eval_fwd(const float* x, const float* gamma, const float* beta, c
                         const float* residual, int N, int C, int HW, float eps, int relu, float* y, void* stream);
 int mas_bn_act_train_bwd(const float* dy, const float* x, const float* y, const uint8_t* relu_mask, const float* gamma,
                          const float* save_mean, const float* save_invstd, int N, int C, int HW, int relu, void* workspace, float* dx,
-                         float* dresidual, float* dgamma, float* dbeta, void* stream);
+                         float* dresidual, float* dgamma, float* dbeta, uint32_t* counters, void* stream);
 
 /* K8: cosine classifier of DeepLabHeadV3PlusWN (models/segmentation/deeplabv3.py:121-124):
  * logits[n,k,p] = <feat[n,:,p], proxy_hat[k,:]> / max(|feat[n,:,p]|, eps) for unit-norm proxies proxy_hat [K,Ch]

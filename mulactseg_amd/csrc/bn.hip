@@ -73,8 +73,57 @@ __device__ __forceinline__ float4 mask_bits(unsigned m) {
 constexpr int kGroupsPerChunk = kChunk / 4;
 
 // grid (chunks, N, C): part[(c * N + n) * chunks + chunk] = (sum x, sum x^2)
+// Hand-off of a partial pair to whichever workgroup finishes the channel, WITHOUT device-scope fences: the pair is stored
+// write-through at agent scope (sc1), the storing thread drains its stores, then a relaxed agent-scope counter add publishes it; the
+// finisher reads the pairs with sc1 loads (served by the coherence point the write-through stores went to).  A __threadfence() per
+// workgroup instead -- L2 write-back + invalidate on every XCD, thousands of times per launch, under kernels that stream at HBM speed
+// -- made k_bn_bwd_partial 7x slower (10.6 ms per step against 1.45: round 5).  The idiom of csrc/conv_sk.hip.
+typedef unsigned v4u_bn __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void bn_store_sc1(double2* p, double S, double Q) {
+    const double2 v = make_double2(S, Q);
+    asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(__builtin_bit_cast(v4u_bn, v)) : "memory");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+__device__ __forceinline__ double2 bn_load_sc1(const double2* p) {
+    v4u_bn v;
+    asm volatile("global_load_dwordx4 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(p) : "memory");
+    return __builtin_bit_cast(double2, v);
+}
+__device__ __forceinline__ bool bn_last_arriver(unsigned* counter, unsigned per_channel) {
+    if (__hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != per_channel - 1) return false;
+    __hip_atomic_store(counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);        // (ready for the next launch on this stream)
+    return true;
+}
+
+// mean / invstd / running statistics of one channel from its `per_channel` partial pairs, summed in index order (one thread)
+template <bool SC1>
+__device__ __forceinline__ void bn_channel_stats(const double2* part, int c, int per_channel, double count, float eps, float momentum, float* mean,
+                                                 float* invstd, float* running_mean, float* running_var) {
+    double S = 0.0, Q = 0.0;
+    for (int i = 0; i < per_channel; ++i) {
+        const double2 v = SC1 ? bn_load_sc1(part + (size_t)c * per_channel + i) : part[(size_t)c * per_channel + i];
+        S += v.x; Q += v.y;
+    }
+    const double m = S / count;
+    double var = Q / count - m * m;
+    var = var < 0.0 ? 0.0 : var;
+    mean[c] = (float)m;
+    invstd[c] = (float)(1.0 / sqrt(var + (double)eps));
+    if (running_mean) {
+        const double unbiased = count > 1.0 ? var * count / (count - 1.0) : var;
+        running_mean[c] = (float)((1.0 - (double)momentum) * (double)running_mean[c] + (double)momentum * m);
+        running_var[c] = (float)((1.0 - (double)momentum) * (double)running_var[c] + (double)momentum * unbiased);
+    }
+}
+
+// `counters` != NULL (one zeroed word per channel, left zeroed): the workgroup that writes a channel's LAST partial pair turns the
+// pairs into that channel's statistics -- the k_bn_stats launch (one of 115 five-microsecond launches per training step) is gone.
+// Release / acquire at device scope: partial stored, fence, counter add; the last arriver fences again before it reads the pairs.
+struct BnStatOut { float eps, momentum; float* mean; float* invstd; float* running_mean; float* running_var; long long* nbt; unsigned* counters; };
+
 template <bool VEC>
-__global__ __launch_bounds__(kThreads) void k_bn_partial(const float* __restrict__ x, int C, int HW, int chunks, double2* __restrict__ part) {
+__global__ __launch_bounds__(kThreads) void k_bn_partial(const float* __restrict__ x, int C, int HW, int chunks, double2* __restrict__ part,
+                                                          const BnStatOut so) {
     __shared__ double s_red[kThreads / MAS_WAVE];
     const int chunk = blockIdx.x, n = blockIdx.y, c = blockIdx.z;
     const Groups g = groups_of(x + ((size_t)n * C + c) * HW, HW);
@@ -87,7 +136,15 @@ __global__ __launch_bounds__(kThreads) void k_bn_partial(const float* __restrict
     }
     const double S = block_sum((double)s, s_red);
     const double Q = block_sum((double)q, s_red);
-    if (threadIdx.x == 0) part[((size_t)c * gridDim.y + n) * chunks + chunk] = make_double2(S, Q);
+    if (threadIdx.x != 0) return;
+    double2* mine = part + ((size_t)c * gridDim.y + n) * chunks + chunk;
+    if (!so.counters) { *mine = make_double2(S, Q); return; }
+    bn_store_sc1(mine, S, Q);
+    const unsigned per_channel = gridDim.x * gridDim.y;
+    if (!bn_last_arriver(&so.counters[c], per_channel)) return;
+    if (c == 0 && so.nbt) so.nbt[0] += 1;
+    bn_channel_stats<true>(part, c, (int)per_channel, (double)gridDim.y * (double)HW, so.eps, so.momentum, so.mean, so.invstd, so.running_mean,
+                           so.running_var);
 }
 
 // one thread per channel: batch mean / biased variance -> mean, invstd; running statistics (momentum, unbiased variance)
@@ -176,7 +233,8 @@ template <bool VEC>
 __global__ __launch_bounds__(kThreads) void k_bn_bwd_partial(const float* __restrict__ dy, const float* __restrict__ x, const float* __restrict__ y,
                                                               const unsigned char* __restrict__ mask, int mask_stride, const float* __restrict__ mean,
                                                               const float* __restrict__ invstd, int C, int HW, int chunks, int relu,
-                                                              double2* __restrict__ part) {
+                                                              double2* __restrict__ part, unsigned* __restrict__ counters, float* __restrict__ dgamma,
+                                                              float* __restrict__ dbeta, float2* __restrict__ coef) {
     __shared__ double s_red[kThreads / MAS_WAVE];
     const int chunk = blockIdx.x, n = blockIdx.y, c = blockIdx.z;
     const size_t plane = (size_t)n * C + c, base = plane * HW;
@@ -232,7 +290,19 @@ __global__ __launch_bounds__(kThreads) void k_bn_bwd_partial(const float* __rest
     }
     const double S = block_sum((double)s, s_red);
     const double Q = block_sum((double)q, s_red);
-    if (threadIdx.x == 0) part[((size_t)c * gridDim.y + n) * chunks + chunk] = make_double2(S, Q);
+    if (threadIdx.x != 0) return;
+    double2* mine = part + ((size_t)c * gridDim.y + n) * chunks + chunk;
+    if (!counters) { *mine = make_double2(S, Q); return; }
+    // (as k_bn_partial: the last workgroup of a channel does k_bn_bwd_stats' work for that channel)
+    bn_store_sc1(mine, S, Q);
+    const unsigned per_channel = gridDim.x * gridDim.y;
+    if (!bn_last_arriver(&counters[c], per_channel)) return;
+    double St = 0.0, Qt = 0.0;
+    for (unsigned i = 0; i < per_channel; ++i) { const double2 v = bn_load_sc1(part + (size_t)c * per_channel + i); St += v.x; Qt += v.y; }
+    const double count = (double)gridDim.y * (double)HW;
+    if (dbeta) dbeta[c] = (float)St;
+    if (dgamma) dgamma[c] = (float)Qt;
+    coef[c] = make_float2((float)(St / count), (float)(Qt / count));
 }
 
 // dbeta = sum g, dgamma = sum g * xhat; coef[c] = (mean g, mean g*xhat)
@@ -302,7 +372,7 @@ extern "C" int64_t mas_bn_workspace_bytes(int N, int C, int HW) {
 extern "C" int mas_bn_act_train_fwd(const float* x, const float* gamma, const float* beta, const float* residual, int N, int C, int HW,
                                     float eps, float momentum, int relu, float* running_mean, float* running_var,
                                     int64_t* num_batches_tracked, float* save_mean, float* save_invstd, void* workspace, float* y,
-                                    uint8_t* relu_mask, void* stream) {
+                                    uint8_t* relu_mask, uint32_t* counters, void* stream) {
     if (!x || !save_mean || !save_invstd || !workspace || !y) return MAS_ERR_NULL;
     if ((running_mean == nullptr) != (running_var == nullptr)) return MAS_ERR_NULL;
     if (int e = check(N, C, HW)) return e;
@@ -310,11 +380,13 @@ extern "C" int mas_bn_act_train_fwd(const float* x, const float* gamma, const fl
     const int chunks = chunks_of(HW);
     double2* part = static_cast<double2*>(workspace);
     const bool vec = congruent(x, y) && congruent(x, residual) && ((uintptr_t)x & 3) == 0;
-    if (vec) hipLaunchKernelGGL(k_bn_partial<true>, dim3((unsigned)chunks, (unsigned)N, (unsigned)C), dim3(kThreads), 0, st, x, C, HW, chunks, part);
-    else hipLaunchKernelGGL(k_bn_partial<false>, dim3((unsigned)chunks, (unsigned)N, (unsigned)C), dim3(kThreads), 0, st, x, C, HW, chunks, part);
-    hipLaunchKernelGGL(k_bn_stats, dim3((unsigned)((C + kThreads - 1) / kThreads)), dim3(kThreads), 0, st, part, C, N * chunks,
-                       (double)N * (double)HW, eps, momentum, save_mean, save_invstd, running_mean, running_var,
-                       reinterpret_cast<long long*>(num_batches_tracked));
+    const BnStatOut so{eps, momentum, save_mean, save_invstd, running_mean, running_var, reinterpret_cast<long long*>(num_batches_tracked), counters};
+    if (vec) hipLaunchKernelGGL(k_bn_partial<true>, dim3((unsigned)chunks, (unsigned)N, (unsigned)C), dim3(kThreads), 0, st, x, C, HW, chunks, part, so);
+    else hipLaunchKernelGGL(k_bn_partial<false>, dim3((unsigned)chunks, (unsigned)N, (unsigned)C), dim3(kThreads), 0, st, x, C, HW, chunks, part, so);
+    if (!counters)
+        hipLaunchKernelGGL(k_bn_stats, dim3((unsigned)((C + kThreads - 1) / kThreads)), dim3(kThreads), 0, st, part, C, N * chunks,
+                           (double)N * (double)HW, eps, momentum, save_mean, save_invstd, running_mean, running_var,
+                           reinterpret_cast<long long*>(num_batches_tracked));
     unsigned char* mk = relu ? relu_mask : nullptr;
     if (vec) hipLaunchKernelGGL((k_bn_apply<false, true>), apply_grid(N, C, HW), dim3(kThreads), 0, st, x, gamma, beta, save_mean, save_invstd, eps,
                                 residual, C, HW, relu, y, mk, max_groups(HW));
@@ -361,7 +433,7 @@ extern "C" int mas_bn_act_eval_fwd(const float* x, const float* gamma, const flo
 
 extern "C" int mas_bn_act_train_bwd(const float* dy, const float* x, const float* y, const uint8_t* relu_mask, const float* gamma,
                                     const float* save_mean, const float* save_invstd, int N, int C, int HW, int relu, void* workspace,
-                                    float* dx, float* dresidual, float* dgamma, float* dbeta, void* stream) {
+                                    float* dx, float* dresidual, float* dgamma, float* dbeta, uint32_t* counters, void* stream) {
     if (!dy || !x || !save_mean || !save_invstd || !workspace || !dx) return MAS_ERR_NULL;
     if (relu && !y && !relu_mask) return MAS_ERR_NULL;
     if (int e = check(N, C, HW)) return e;
@@ -372,11 +444,12 @@ extern "C" int mas_bn_act_train_bwd(const float* dy, const float* x, const float
     const bool vec = congruent(x, dy) && congruent(x, dx) && congruent(x, dresidual) && (relu_mask || congruent(x, y)) && ((uintptr_t)x & 3) == 0;
     const int ms = max_groups(HW);
     if (vec) hipLaunchKernelGGL(k_bn_bwd_partial<true>, dim3((unsigned)chunks, (unsigned)N, (unsigned)C), dim3(kThreads), 0, st, dy, x, y, relu_mask, ms,
-                                save_mean, save_invstd, C, HW, chunks, relu, part);
+                                save_mean, save_invstd, C, HW, chunks, relu, part, counters, dgamma, dbeta, coef);
     else hipLaunchKernelGGL(k_bn_bwd_partial<false>, dim3((unsigned)chunks, (unsigned)N, (unsigned)C), dim3(kThreads), 0, st, dy, x, y, relu_mask, ms,
-                            save_mean, save_invstd, C, HW, chunks, relu, part);
-    hipLaunchKernelGGL(k_bn_bwd_stats, dim3((unsigned)((C + kThreads - 1) / kThreads)), dim3(kThreads), 0, st, part, C, N * chunks,
-                       (double)N * (double)HW, dgamma, dbeta, coef);
+                            save_mean, save_invstd, C, HW, chunks, relu, part, counters, dgamma, dbeta, coef);
+    if (!counters)
+        hipLaunchKernelGGL(k_bn_bwd_stats, dim3((unsigned)((C + kThreads - 1) / kThreads)), dim3(kThreads), 0, st, part, C, N * chunks,
+                           (double)N * (double)HW, dgamma, dbeta, coef);
     if (vec) hipLaunchKernelGGL(k_bn_bwd_apply<true>, apply_grid(N, C, HW), dim3(kThreads), 0, st, dy, x, y, relu_mask, ms, gamma, save_mean,
                                 save_invstd, coef, C, HW, relu, dx, dresidual);
     else hipLaunchKernelGGL(k_bn_bwd_apply<false>, apply_grid(N, C, HW), dim3(kThreads), 0, st, dy, x, y, relu_mask, ms, gamma, save_mean,

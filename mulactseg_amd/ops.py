@@ -764,6 +764,23 @@ def _opt(t):
     return t.data_ptr() if t is not None else None
 
 
+_BN_COUNTERS = {}
+
+
+def _bn_counters(dev, C):
+    """The per-(device, stream) completion counters of the last-block form of the BatchNorm passes (one zeroed word per channel; the
+    kernels leave them zeroed) under MAS_BN_LASTBLOCK=on.  Default off: None -- the statistics come from their own launch.  (Round 5
+    measured the last-block form at 25.7-25.9 ms per training step against 25.6 for the three-launch form: the store-drain-publish
+    tail of every workgroup costs what the 115 five-microsecond launches did.  Kept for the A/B and its bit-identity test.)"""
+    if os.environ.get("MAS_BN_LASTBLOCK", "off") != "on":
+        return None
+    key = (dev, torch.cuda.current_stream(dev).cuda_stream)
+    buf = _BN_COUNTERS.get(key)
+    if buf is None or buf.numel() < C:
+        buf = _BN_COUNTERS[key] = torch.zeros(max(4096, C), dtype=torch.int32, device=dev)
+    return buf
+
+
 class _BNActTrain(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, bias, residual, running_mean, running_var, num_batches_tracked, eps, momentum, relu, partials=None):
@@ -792,7 +809,8 @@ class _BNActTrain(torch.autograd.Function):
                 ws = torch.empty(int(lib.mas_bn_workspace_bytes(N, C, HW)), dtype=torch.uint8, device=dev)
                 _lib.check(lib.mas_bn_act_train_fwd(x.data_ptr(), _opt(weight), _opt(bias), _opt(res), N, C, HW, float(eps), float(momentum),
                                                     int(relu), _opt(running_mean), _opt(running_var), _opt(num_batches_tracked),
-                                                    mean.data_ptr(), invstd.data_ptr(), ws.data_ptr(), y.data_ptr(), _opt(mask), _stream(x)),
+                                                    mean.data_ptr(), invstd.data_ptr(), ws.data_ptr(), y.data_ptr(), _opt(mask), _opt(_bn_counters(dev, C)),
+                                                    _stream(x)),
                            "mas_bn_act_train_fwd")
         # the kernel updated the running statistics through raw pointers: bump their version counters as an in-place
         # torch op would, so caches keyed on (data_ptr, _version) -- _conv1x1_constants -- see the change
@@ -820,7 +838,7 @@ class _BNActTrain(torch.autograd.Function):
         with torch.cuda.device(dev):
             _lib.check(lib.mas_bn_act_train_bwd(dy.data_ptr(), x.data_ptr(), _opt(y), _opt(mask), _opt(weight), mean.data_ptr(), invstd.data_ptr(),
                                                 N, C, HW, int(ctx.relu), ws.data_ptr(), dx.data_ptr(), _opt(dres), _opt(dg), _opt(db),
-                                                _stream(x)), "mas_bn_act_train_bwd")
+                                                _opt(_bn_counters(dev, C)), _stream(x)), "mas_bn_act_train_bwd")
         if ctx.has_res and dres is None and ctx.needs_input_grad[3]:
             dres = dy
         return dx, dg, db, dres, None, None, None, None, None, None, None
@@ -1332,6 +1350,11 @@ def conv_wgrad(x, dy, ksize, stride, dil):
         # 1x1: split-bf16 kernel (csrc/conv_wgrad_bx.hip), 1.3-1.7x the f32 kernel (profiles/r04/k_bx_train_table.md); with 64 or
         # fewer output channels half of its 128 x 128 tile is padding and the f32 kernel stays ahead
         return conv_wgrad_bx(x, dy)
+    if (ksize == 1 and stride == 2 and os.environ.get("MAS_TRAIN_BX", "auto") not in ("off", "r04") and Cout >= 96 and Cin >= 64
+            and lib.mas_conv_wgrad_bx_supported(N, Cin, Ho, Wo, Cout)):
+        # 1x1 stride 2 (`downsample`): dW only sees the even pixels of x -- gather them once (a quarter of x, one strided copy) and the
+        # product is the stride-1 one on the small plane (the f32 kernel's strided K axis ran at 29 TFLOP/s: 168 us per layer)
+        return conv_wgrad_bx(x[:, :, ::2, ::2].contiguous(), dy)
     w3 = os.environ.get("MAS_WGRAD3", "auto")
     if (ksize == 3 and stride == 1 and os.environ.get("MAS_TRAIN_BX", "auto") not in ("off", "r04") and w3 != "f32"
             and lib.mas_conv_wgrad_bx3_supported(N, Cin, H, W, Cout, dil)):
@@ -1577,6 +1600,23 @@ def conv_bx_train_plan(x_shape, w_shape, dil=1, dgrad=False):
     return int(out[0]), int(out[1]), int(out[2])
 
 
+def conv_bx_s2_raw(x, w, packed=None):
+    """y = conv2d(x, w, stride 2) for a 1x1 weight on the stride-2 form of csrc/conv_bx.hip (bare product of a training step)."""
+    _need(x, "x", torch.float32)
+    _need(w, "w", torch.float32)
+    Cout, Cin, ks, _ = w.shape
+    N, Cx, H, W = x.shape
+    if ks != 1 or Cx != Cin:
+        raise ValueError("conv_bx_s2_raw: a 1x1 weight on its input channels")
+    y = torch.empty((N, Cout, (H - 1) // 2 + 1, (W - 1) // 2 + 1), dtype=torch.float32, device=x.device)
+    if packed is None:
+        packed = conv_bx_pack(w, 0)
+    with torch.cuda.device(x.device):
+        _lib.check(_lib.load().mas_conv_bx_fwd(x.data_ptr(), packed.data_ptr(), N, Cin, H, W, Cout, 1, 2, 1, None, None, None, 0, y.data_ptr(),
+                                               _stream(x)), "mas_conv_bx_fwd")
+    return y
+
+
 def conv_bx_raw(x, w, dil=1, dgrad=False, residual=None, packed=None, ksplit=0, tile_w=0):
     """The bare stride-1 product of a training step on csrc/conv_bx.hip: dgrad False: y = conv2d(x, w, padding = dil (k 3) / 0 (k 1),
     dilation); dgrad True: x is dY [N,Cout,H,W] and the result dX [N,Cin,H,W] (+ residual: the gradient of x's other consumer).
@@ -1618,11 +1658,15 @@ def conv_bx_train_ok(x_shape, w_shape, stride, dil, dgrad):
     rule (1x1 everywhere, 3x3 on planes of at least 96 x 96 or with at least 320 tiles -- the others on the persistent stream-K
     kernel), for A/B runs; off: never."""
     mode = os.environ.get("MAS_TRAIN_BX", "auto")
+    Cout, Cin, ks, _ = w_shape
+    N, _, H, W = x_shape
+    if mode not in ("off", "r04") and stride == 2 and ks == 1 and not dgrad:
+        # the 1x1 stride-2 `downsample` convolutions (resnet.py:215-223): the stride-2 form of the forward kernel (planes with even
+        # H and W % 8 == 0 -- the 768 crop; the 769 crop's odd planes stay on the stream-K kernel)
+        return bool(_lib.load().mas_conv_bx_supported(1, 2, 1, Cin, Cout, H, W)) and x_shape[0] > 0
     if mode == "off" or stride != 1:
         return False
-    Cout, Cin, ks, _ = w_shape
     K, M = (Cout, Cin) if dgrad else (Cin, Cout)
-    N, _, H, W = x_shape
     if not _lib.load().mas_conv_bx_supported(ks, 1, dil, K, M, H, W):
         return False
     if mode != "r04" or ks == 1 or H * W >= 96 * 96:
@@ -1846,7 +1890,10 @@ class _ConvTrain(torch.autograd.Function):
         with torch.no_grad():
             if own[0] and conv_bx_train_ok(x.shape, w.shape, stride, dil, False):
                 # split-bf16 kernel (csrc/conv_bx.hip); the BatchNorm partial sums then come from the separate reduction pass
-                y = conv_bx_raw(x, w, dil, packed=bx_packed_weight(w, 0))
+                if stride == 2:
+                    y = conv_bx_s2_raw(x, w, packed=bx_packed_weight(w, 0))
+                else:
+                    y = conv_bx_raw(x, w, dil, packed=bx_packed_weight(w, 0))
             elif own[0] and stats:
                 y, part = conv_sk(x, w, stride, dil, packed=packed_weight(w, stride, False), stats=True)
             elif own[0]:

@@ -149,3 +149,44 @@ def test_tensors_with_a_storage_offset_take_the_element_path_and_agree():
         outs.append((y.detach(), xq.grad, rq.grad, b.weight.grad, b.running_var.clone()))
     for a, c in zip(*outs):         # the partial sums are grouped by address, so the last bits may differ between the two alignments
         assert float((a - c).abs().max()) <= 2e-6 * max(1.0, float(c.abs().max()))
+
+
+def test_last_block_statistics_equal_the_separate_launch_bit_for_bit():
+    """Round 5: the workgroup that writes a channel's last partial sums forms the channel's statistics (forward: mean / invstd / running
+    statistics / num_batches_tracked; backward: dgamma / dbeta / the two means) instead of a launch of their own.  Same partials, same
+    order of summation: every output equals the three-launch form (MAS_BN_LASTBLOCK=off) bit for bit, on aligned and odd planes, with
+    and without residual, across repeated calls (the completion counters must come back to zero)."""
+    import os
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from mulactseg_amd import ops
+    for (N, C, H, W, res) in ((4, 64, 48, 48, False), (2, 256, 49, 49, True), (4, 128, 97, 33, True), (1, 20, 5, 7, False), (4, 2048, 12, 12, False)):
+        torch.manual_seed(N * C + H)
+        x = torch.randn(N, C, H, W, device='cuda') * 2.0 + 0.3
+        r = torch.randn(N, C, H, W, device='cuda') if res else None
+        dy = torch.randn(N, C, H, W, device='cuda')
+        outs = {}
+        for mode in ("off", "on", "on"):
+            os.environ["MAS_BN_LASTBLOCK"] = mode
+            try:
+                bn = torch.nn.BatchNorm2d(C).cuda().train()
+                with torch.no_grad():
+                    bn.weight.copy_(torch.linspace(0.5, 1.5, C)); bn.bias.copy_(torch.linspace(-1, 1, C))
+                xi = x.clone().requires_grad_(True)
+                ri = r.clone().requires_grad_(True) if res else None
+                y = ops.bn_act(bn, xi, True, ri)
+                y.backward(dy)
+                got = [y.detach(), xi.grad, bn.weight.grad, bn.bias.grad, bn.running_mean.clone(), bn.running_var.clone(), bn.num_batches_tracked.clone()]
+                if res:
+                    got.append(ri.grad)
+            finally:
+                os.environ.pop("MAS_BN_LASTBLOCK")
+            if mode in outs:
+                for a, b in zip(outs[mode], got):
+                    assert torch.equal(a, b)
+            outs[mode] = got
+        for a, b in zip(outs["off"], outs["on"]):
+            assert torch.equal(a, b), (N, C, H, W)
+        assert int(outs["on"][6]) == 1
+    key = (torch.device('cuda', torch.cuda.current_device()), torch.cuda.current_stream().cuda_stream)
+    assert int(ops._BN_COUNTERS[key].abs().sum()) == 0
