@@ -505,7 +505,9 @@ int mas_conv_bx_fwd_pre(const void* x3, const void* wp, int N, int Cin, int H, i
  * the chip has slots (the 48 x 48 planes of layer3 / layer4 / ASPP at the training crop): the K chunks of every tile are dealt to
  * `ksplit` workgroups, part 0 stores into y (+ residual), the others into `workspace`, and a second launch adds the parts in index
  * order (run-to-run identical; no flags, no waiting: nothing that needs co-residency, unlike the stream-K hand-off of mas_conv_sk).
- * 3x3: `tile_w` 32 (8 x 32 output pixels per tile) or 16 (16 x 16: no padded quarter on 48 x 48 planes).
+ * 3x3: `tile_w` 32 (8 x 32 output pixels per tile), 16 (16 x 16: no padded quarter on 48 x 48 planes) or 1 ("flat": 256 consecutive
+ * pixels of the plane in row-major order over a patch of the full rows they touch -- narrow planes whose width is no multiple of 16:
+ * the 49 x 49 planes of the 769 crop are 10 such tiles against 14 / 16).
  * mas_conv_bx_train_plan: out3 = {ksplit, tile_w, workgroups} the library would choose; ksplit / tile_w <= 0 in mas_conv_bx_train
  * take the plan's.  workspace: mas_conv_bx_train_workspace_bytes(N, Cout, H, W, ksplit) bytes, 16-byte aligned (none for ksplit 1). */
 int mas_conv_bx_train_plan(int N, int Cin, int H, int W, int Cout, int ksize, int dil, int* out3);

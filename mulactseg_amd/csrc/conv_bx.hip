@@ -42,6 +42,8 @@ typedef __bf16 bf8 __attribute__((ext_vector_type(8)));
 
 constexpr int kBxPPA = 448;                     // 3x3: positions of one term of the B image: the 12 x 36 patch of dilation 2 (10 x 34 at dilation 1)
 constexpr int kBxDump = 432;                    //      + 16 positions where the staging tasks beyond the patch put their (unused) stores
+constexpr int kBxFlatPP = 608;                  // 3x3, flat tiles (TW = 0): patch capacity -- the FULL rows a run of 256 consecutive pixels touches, + halo
+constexpr int kBxFlatPPA = kBxFlatPP + 16;      //      + the dump positions
 constexpr int kBxTaps3 = 10;                    // 3x3: nine taps + one zero-weight tap (five 16-k steps per 8-channel chunk)
 
 struct BxP {
@@ -174,7 +176,9 @@ constexpr int kBxOut = (int)0x80000000u;        // a byte offset beyond every re
 // buffer-resource forms below (no address arithmetic, no bounds selects).
 // V: the stride of the 1x1 form (1 | 2), the dilation of the 3x3 form (1 | 2: the patch geometry is a compile-time constant)
 // TW: 3x3 form: the 256 output pixels of a tile are 8 rows x 32 columns (TW = 32) or 16 x 16 (TW = 16: the 48 x 48 planes of
-//     layer3 / layer4 at the training crop are 9 such tiles, 12 of the wide ones of which a quarter is padding); 1x1: 32
+//     layer3 / layer4 at the training crop are 9 such tiles, 12 of the wide ones of which a quarter is padding) or, TW = 0 ("flat"),
+//     256 CONSECUTIVE pixels of the plane in row-major order over a patch of the full rows they touch -- the 49 x 49 planes of the
+//     769 crop are 10 such tiles against 14 wide / 16 square ones (half of whose pixels are padding); 1x1: 32
 // PRE: the activations arrive ALREADY SPLIT (bx3 layout: 16-byte units of 8 channels of one pixel and one term -- exactly a unit of
 //      the B image), written by the producer of the tensor; staging is then a 16-byte copy per unit, no VALU work
 template <int TAPS, int BM, int BN, int V, bool RES, int TW = 32, bool PRE = false>
@@ -182,10 +186,13 @@ __global__ __launch_bounds__(kThreads, 2) void k_conv_bx(const BxP p) {
     constexpr bool S2 = TAPS == 1 && V == 2;
     static_assert(!(PRE && S2), "presplit input: stride 1");
     constexpr int DIL = TAPS == 9 ? V : 1;
-    constexpr int TH = 256 / TW;                                    // 3x3: rows of a tile
-    static_assert(TW == 32 || (TW == 16 && TAPS == 9), "tile shape");
-    constexpr int PW = TW + 2 * DIL, PP = (TH + 2 * DIL) * PW;      // 3x3: columns / pixels of the input patch of a TH x TW tile
-    static_assert(PP <= kBxDump, "patch");
+    constexpr bool FLAT = TW == 0;
+    constexpr int TH = FLAT ? 1 : 256 / (FLAT ? 1 : TW);            // 3x3: rows of a tile
+    static_assert(TW == 32 || ((TW == 16 || TW == 0) && TAPS == 9 && !PRE), "tile shape");
+    constexpr int PW = TW + 2 * DIL;                                // 3x3: columns of the input patch of a TH x TW tile (flat: p.W + 2 DIL, a run-time value)
+    constexpr int PP = FLAT ? kBxFlatPP : (TH + 2 * DIL) * PW;      //      pixels of the patch (flat: its capacity)
+    constexpr int PPA = FLAT ? kBxFlatPPA : kBxPPA, DUMP = FLAT ? kBxFlatPP : kBxDump;
+    static_assert(PP <= DUMP, "patch");
     constexpr int CK = BxGeo<TAPS>::CK, GA = BxGeo<TAPS>::GA, SLABS = BxGeo<TAPS>::SLABS;
     constexpr int WM = BM / 64, WN = 4 / WM;
     static_assert(WN * 64 == BN, "a wave owns 64 x 64");
@@ -200,7 +207,7 @@ __global__ __launch_bounds__(kThreads, 2) void k_conv_bx(const BxP p) {
     v4f* sA = reinterpret_cast<v4f*>(bx_smem);                                       // [3][GA][BM] units
     float* sE = reinterpret_cast<float*>(bx_smem + (size_t)AUNITS * 16);             // [2][BM]
     unsigned char* sB = bx_smem + (size_t)AUNITS * 16 + 2 * BM * 4;                  // [3][k groups][positions] units
-    constexpr int bTerm = TAPS == 1 ? 4 * POS1 * 16 : kBxPPA * 16;                 // bytes of one term of the B image (an immediate of the LDS reads)
+    constexpr int bTerm = TAPS == 1 ? 4 * POS1 * 16 : PPA * 16;                    // bytes of one term of the B image (an immediate of the LDS reads)
 
     const int tid = threadIdx.x;
     const int bid = blockIdx.x;
@@ -219,9 +226,16 @@ __global__ __launch_bounds__(kThreads, 2) void k_conv_bx(const BxP p) {
     if (pt >= p.ptiles) return;
     const int HW = p.H * p.W, HWo = p.Ho * p.Wo;
     int n, p0 = 0, oy0 = 0, ox0 = 0;
-    if (TAPS == 1) {
+    int fy0 = 0, fpw = 0, fpp = 0;                                   // flat 3x3: first plane row of the tile, patch row pitch, patch pixels
+    if (TAPS == 1 || FLAT) {
         n = pt / p.tiles_x;
         p0 = (pt - n * p.tiles_x) * BN;                          // first pixel of the tile in the flattened output plane
+        if (FLAT) {
+            const int last = p0 + BN - 1 < HWo - 1 ? p0 + BN - 1 : HWo - 1;
+            fy0 = p0 / p.W;
+            fpw = p.W + 2 * DIL;
+            fpp = (last / p.W - fy0 + 1 + 2 * DIL) * fpw;            // (<= kBxFlatPP: checked by the host)
+        }
     } else {
         const int tpi = p.tiles_x * p.tiles_y;
         n = pt / tpi;
@@ -246,12 +260,12 @@ __global__ __launch_bounds__(kThreads, 2) void k_conv_bx(const BxP p) {
                 if (p0 + pp < HWo) pgoff[j] = (gt * HW + p0 + pp) * 16;
                 ploff[j] = ((term * 4 + g) * POS1 + pp) * 16;
             } else {
-                ploff[j] = (kBxDump + (tid & 15)) * 16;
+                ploff[j] = (DUMP + (tid & 15)) * 16;
                 if (idx < 3 * PP) {
                     const int term = idx / PP, pix = idx - term * PP;
                     const int py = pix / PW, px = pix - py * PW;
                     const int iy = oy0 - DIL + py, ix = ox0 - DIL + px;
-                    ploff[j] = (term * kBxPPA + pix) * 16;
+                    ploff[j] = (term * PPA + pix) * 16;
                     if (iy >= 0 && iy < p.H && ix >= 0 && ix < p.W) pgoff[j] = (term * HW + iy * p.W + ix) * 16;
                 }
             }
@@ -281,15 +295,16 @@ __global__ __launch_bounds__(kThreads, 2) void k_conv_bx(const BxP p) {
             loff[j] = ((q >> 1) * POS1 + bx_pos1(4 * pq)) * 16 + (q & 1) * 8;
         }
     } else {
-        const int iy0 = oy0 - DIL, ix0 = ox0 - DIL;
+        const int iy0 = FLAT ? fy0 - DIL : oy0 - DIL, ix0 = FLAT ? -DIL : ox0 - DIL;
+        const int pp_ = FLAT ? fpp : PP, pw_ = FLAT ? fpw : PW;
 #pragma unroll
         for (int j = 0; j < NT; ++j) {
             const int e = tid + j * kThreads;
             goff[j] = kBxOut;
-            loff[j] = (kBxDump + (tid & 15)) * 16;      // (a task beyond the patch stores zeros there: no branch in the loop)
-            if (e < 2 * PP) {
-                const int cq = e >= PP ? 1 : 0, pix = e - cq * PP;
-                const int py = pix / PW, px = pix - py * PW;
+            loff[j] = (DUMP + (tid & 15)) * 16;         // (a task beyond the patch stores zeros there: no branch in the loop)
+            if (e < 2 * pp_) {
+                const int cq = e >= pp_ ? 1 : 0, pix = e - cq * pp_;
+                const int py = pix / pw_, px = pix - py * pw_;
                 const int iy = iy0 + py, ix = ix0 + px;
                 loff[j] = pix * 16 + cq * 8;
                 if (iy >= 0 && iy < p.H && ix >= 0 && ix < p.W) goff[j] = (cq * 4 * HW + iy * p.W + ix) * 4;
@@ -309,14 +324,19 @@ __global__ __launch_bounds__(kThreads, 2) void k_conv_bx(const BxP p) {
 #pragma unroll
     for (int tn = 0; tn < 2; ++tn) {
         if (TAPS == 1) bBase[tn] = PRE ? (h * POS1 + wn * 64 + tn * 32 + l31) * 16 : (h * POS1 + bx_pos1(wn * 64 + tn * 32 + l31)) * 16;
-        else if (TW == 32) bBase[tn] = ((wn * 2 + tn) * PW + l31) * 16;
+        else if (FLAT) {
+            const int pp = p0 + wn * 64 + tn * 32 + l31;
+            const int pc = pp < HWo ? pp : HWo - 1;             // (pixels beyond the plane: any position of the patch; never stored)
+            const int y = pc / p.W, x = pc - y * p.W;
+            bBase[tn] = ((y - fy0) * fpw + x) * 16;
+        } else if (TW == 32) bBase[tn] = ((wn * 2 + tn) * PW + l31) * 16;
         else bBase[tn] = ((wn * 4 + tn * 2 + (l31 >> 4)) * PW + (l31 & 15)) * 16;        // 16 x 16: an MFMA column tile is 2 rows x 16 columns
     }
     int toff[SLABS];                                                // 3x3: the tap of this lane half in every 16-k step
 #pragma unroll
     for (int s = 0; s < SLABS; ++s) {
         const int t = 2 * s + h > 8 ? 8 : 2 * s + h;
-        toff[s] = TAPS == 1 ? 0 : ((t / 3) * PW + (t % 3)) * DIL * 16;
+        toff[s] = TAPS == 1 ? 0 : ((t / 3) * (FLAT ? fpw : PW) + (t % 3)) * DIL * 16;
     }
     f32x16 acc[2][2];
 #pragma unroll
@@ -571,7 +591,7 @@ __global__ __launch_bounds__(kThreads, 2) void k_conv_bx(const BxP p) {
     int vo[2];
 #pragma unroll
     for (int tn = 0; tn < 2; ++tn) {
-        if (TAPS == 1) {
+        if (TAPS == 1 || FLAT) {
             const int pp = p0 + wn * 64 + tn * 32 + l31;
             vo[tn] = pp < HWo ? pp * 4 : kBxOut;
         } else {
@@ -641,6 +661,13 @@ __global__ __launch_bounds__(kThreads, 2) void k_conv_bx(const BxP p) {
 #endif
 }
 
+// flat 3x3 tiles: the patch of 256 consecutive pixels = the full rows they touch + DIL rows above / below, DIL columns left / right
+inline bool bx_flat_fits(int H, int W, int dil) {
+    (void)H;
+    const int rows = (256 + W - 2) / W + 1;                 // rows a run of 256 pixels can touch
+    return W >= 8 && (rows + 2 * dil) * (W + 2 * dil) <= kBxFlatPP;
+}
+
 // the M tile of a layer's weight image: a pure function of (ksize, Cout), shared by the pack and the launch
 inline int bx_bm(int ksize, int Cout) { return (ksize == 1 && Cout % 128 == 0) ? 128 : 64; }
 
@@ -655,9 +682,15 @@ int bx_launch(BxP p, int N, hipStream_t st) {
         p.tiles_x = (p.Ho * p.Wo + BN - 1) / BN;
         p.tiles_y = 1;
         bbytes = (size_t)3 * 4 * 144 * (BN / 128) * 16;
+    } else if (TW == 0) {
+        p.tiles_x = (p.Ho * p.Wo + BN - 1) / BN;
+        p.tiles_y = 1;
+        if (p.dil != V || !bx_flat_fits(p.H, p.W, V)) return MAS_ERR_RANGE;
+        bbytes = (size_t)3 * kBxFlatPPA * 16;
     } else {
-        p.tiles_x = (p.Wo + TW - 1) / TW;
-        p.tiles_y = (p.Ho + 256 / TW - 1) / (256 / TW);
+        constexpr int TWs = TW == 0 ? 32 : TW;
+        p.tiles_x = (p.Wo + TWs - 1) / TWs;
+        p.tiles_y = (p.Ho + 256 / TWs - 1) / (256 / TWs);
         if (p.dil != V) return MAS_ERR_RANGE;
         static_assert(kBxPPA >= kBxDump + 16, "dump positions");
         bbytes = (size_t)3 * kBxPPA * 16;
@@ -736,20 +769,25 @@ __global__ __launch_bounds__(256) void k_bx_reduce(float* __restrict__ y, const 
 // identical; no flags, no waiting -- nothing that needs co-residency).  3x3: the tile shape with fewer padded pixels.
 struct BxPlan { int ksplit, tw, wgs; };
 
-inline int bx_tw(int ksize, int H, int W) {
+// 32: 8 x 32 tiles, 16: 16 x 16 tiles, 1: flat tiles (256 consecutive pixels) -- the shape with the fewest tiles (ties: in that order)
+inline int bx_tw(int ksize, int H, int W, int dil) {
     if (ksize != 3 || W < 16) return 32;
     const long long wide = (long long)((H + 7) / 8) * ((W + 31) / 32), square = (long long)((H + 15) / 16) * ((W + 15) / 16);
-    return square < wide ? 16 : 32;
+    const long long flat = bx_flat_fits(H, W, dil) ? ((long long)H * W + 255) / 256 : (1LL << 60);
+    // (a tile of another shape has shorter contiguous rows: it must save a tenth of the tiles to pay -- 385 x 385 is 625 square
+    //  tiles against 637 wide ones and 9 % slower with them, profiles/r05/k_bx_splitk_769.md)
+    if (10 * flat <= 9 * wide && flat <= square) return 1;
+    return 10 * square <= 9 * wide ? 16 : 32;
 }
 
 inline BxPlan bx_plan(int N, int Cin, int H, int W, int Cout, int ksize, int dil) {
     (void)dil;
     BxPlan pl;
-    pl.tw = bx_tw(ksize, H, W);
+    pl.tw = bx_tw(ksize, H, W, dil);
     const int BM = bx_bm(ksize, Cout);
     const int BN = ksize == 1 ? (BM == 128 ? 128 : 256) : 256;
-    const long long ptiles = ksize == 1 ? (long long)N * ((H * W + BN - 1) / BN)
-                                        : (long long)N * ((W + pl.tw - 1) / pl.tw) * ((H + 256 / pl.tw - 1) / (256 / pl.tw));
+    const long long ptiles = (ksize == 1 || pl.tw == 1) ? (long long)N * ((H * W + BN - 1) / BN)
+                                                        : (long long)N * ((W + pl.tw - 1) / pl.tw) * ((H + 256 / pl.tw - 1) / (256 / pl.tw));
     const long long wg1 = 8 * ((ptiles + 7) / 8) * ((Cout + BM - 1) / BM);
     const int ck = ksize == 1 ? 32 : 8, nch = (Cin + ck - 1) / ck;
     // cost of a plan in microseconds: (workgroups / 512 resident slots, at least one "round") x (chunks per part + the fixed
@@ -916,7 +954,7 @@ extern "C" int mas_conv_bx_train(const float* x, const void* wp, int N, int Cin,
     if (tile_w <= 0) tile_w = pl.tw;
     const int ck = ksize == 1 ? 32 : 8, nch = (Cin + ck - 1) / ck;
     if (ksplit > nch || ksplit > 64) return MAS_ERR_RANGE;
-    if (tile_w != 32 && !(tile_w == 16 && ksize == 3)) return MAS_ERR_RANGE;
+    if (tile_w != 32 && !((tile_w == 16 || (tile_w == 1 && bx_flat_fits(H, W, dil))) && ksize == 3)) return MAS_ERR_RANGE;
     const size_t out_elems = (size_t)N * Cout * H * W;
     if (ksplit > 1) {
         if (!workspace) return MAS_ERR_NULL;
@@ -936,6 +974,7 @@ extern "C" int mas_conv_bx_train(const float* x, const void* wp, int N, int Cin,
     int rc;
     if (ksize == 1) rc = BM == 128 ? bx_launch_r<1, 128, 128, 1>(p, N, st) : bx_launch_r<1, 64, 256, 1>(p, N, st);
     else if (tile_w == 16) rc = dil == 1 ? bx_launch_r<9, 64, 256, 1, 16>(p, N, st) : bx_launch_r<9, 64, 256, 2, 16>(p, N, st);
+    else if (tile_w == 1) rc = dil == 1 ? bx_launch_r<9, 64, 256, 1, 0>(p, N, st) : bx_launch_r<9, 64, 256, 2, 0>(p, N, st);
     else rc = dil == 1 ? bx_launch_r<9, 64, 256, 1>(p, N, st) : bx_launch_r<9, 64, 256, 2>(p, N, st);
     if (rc != 0 || ksplit == 1) return rc;
     const long long n4 = (long long)(out_elems / 4);

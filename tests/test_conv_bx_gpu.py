@@ -285,6 +285,8 @@ SPLIT_CASES = [
     (256, 256, 3, 1, 1, 49, 49),
     (128, 128, 3, 1, 2, 97, 97),        # 97 x 97: 49 square tiles against 52 wide ones
     (72, 64, 3, 1, 1, 20, 36),          # 9 chunks of 8 channels, partial tiles of both shapes
+    (256, 256, 3, 2, 1, 49, 49),        # dilation 2 on the 49 x 49 plane: flat tiles with an 11-row patch
+    (64, 64, 3, 1, 2, 23, 37),          # flat tiles whose runs start and end in the middle of rows
     (200, 136, 1, 1, 1, 24, 40),        # Cin = 6.25 chunks, Cout = one M tile + 8 rows
 ]
 
@@ -306,20 +308,22 @@ def test_split_k_and_square_tiles_match_conv2d(Cin, Cout, k, dil, N, H, W):
     ref_y = F.conv2d(x.double(), w.double(), None, 1, pad, dil)
     ref_dx = torch.nn.grad.conv2d_input(x.shape, w.double(), dy.double(), 1, pad, dil) + other.double()
     plan = ops.conv_bx_train_plan(x.shape, w.shape, dil, False)
-    assert plan[0] >= 1 and plan[1] in (16, 32)
+    assert plan[0] >= 1
     pk0, pk1 = ops.conv_bx_pack(w, 0), ops.conv_bx_pack(w, 1)
     nch = -(-Cin // (32 if k == 1 else 8))
+    flat_ok = k == 3 and W >= 8 and (((256 + W - 2) // W + 1) + 2 * dil) * (W + 2 * dil) <= 608
+    assert plan[1] in (16, 32) or (plan[1] == 1 and flat_ok)
     for ks in sorted({1, 2, 3, min(5, nch), plan[0]}):
         if ks > nch:
             continue
-        for tw in ((32, 16) if k == 3 else (32,)):
+        for tw in (((32, 16, 1) if flat_ok else (32, 16)) if k == 3 else (32,)):
             y = ops.conv_bx_raw(x, w, dil, packed=pk0, ksplit=ks, tile_w=tw)
             err = float((y.double() - ref_y).abs().max())
             assert err <= 2e-5 * float(ref_y.abs().max()), (ks, tw, err)
             assert torch.equal(y, ops.conv_bx_raw(x, w, dil, packed=pk0, ksplit=ks, tile_w=tw)), (ks, tw)
     ncd = -(-Cout // (32 if k == 1 else 8))
     for ks in sorted({1, 2, min(4, ncd)}):
-        dx = ops.conv_bx_raw(dy, w, dil, dgrad=True, residual=other, packed=pk1, ksplit=ks, tile_w=16 if k == 3 else 32)
+        dx = ops.conv_bx_raw(dy, w, dil, dgrad=True, residual=other, packed=pk1, ksplit=ks, tile_w=(1 if flat_ok else 16) if k == 3 else 32)
         err = float((dx.double() - ref_dx).abs().max())
         assert err <= 2e-5 * float(ref_dx.abs().max()), (ks, err)
     y_auto = ops.conv_bx_raw(x, w, dil, packed=pk0)
@@ -337,8 +341,9 @@ def test_split_k_exact_on_integers():
         x = torch.randint(-4, 5, (N, Cin, H, W), generator=g, device='cuda').float()
         res = torch.randint(-9, 10, (N, Cout, H, W), generator=g, device='cuda').float()
         ref = F.conv2d(x.double(), w.double(), None, 1, dil if k == 3 else 0, dil).float()
+        flat_ok = k == 3 and (((256 + W - 2) // W + 1) + 2 * dil) * (W + 2 * dil) <= 608
         for ks in (1, 2, 3, 4):
-            for tw in ((32, 16) if k == 3 else (32,)):
+            for tw in (((32, 16, 1) if flat_ok else (32, 16)) if k == 3 else (32,)):
                 assert torch.equal(ops.conv_bx_raw(x, w, dil, ksplit=ks, tile_w=tw), ref), (Cin, k, ks, tw)
         # the residual operand rides on part 0 only
         wt = torch.randint(-3, 4, (Cin, Cout, k, k), generator=g, device='cuda').float()      # (dgrad role: x is the "dY" of a Cin <- Cout layer)

@@ -41,7 +41,7 @@ def main():
     with torch.no_grad():
         net(torch.randn(N, 3, H, W, device=dev))
     lib = _lib.load()
-    lines = ["# mas_conv_bx_train: us per call by ksplit (3x3: tile 8x32 / 16x16), batch [%d,3,%d,%d]; sk = the stream-K f32 kernel; * = the library's plan" % (N, H, W), "",
+    lines = ["# mas_conv_bx_train: us per call by ksplit (3x3: tile 8x32 / 16x16 / flat where it fits), batch [%d,3,%d,%d]; sk = the stream-K f32 kernel; * = the library's plan" % (N, H, W), "",
              "| x | role | K | M | k | d | H | W | wg@1 | sk | " + " | ".join("ks%d" % i for i in range(1, 9)) + " | plan | best |",
              "|---|---|---|---|---|---|---|---|---|---|" + "---|" * 10]
     tot = collections.Counter()
@@ -72,7 +72,8 @@ def main():
                         cells.append("-")
                         continue
                     ts = []
-                    for tw in ((32, 16) if k == 3 else (32,)):
+                    flat_ok = k == 3 and xs[3] >= 8 and (((256 + xs[3] - 2) // xs[3] + 1) + 2 * d) * (xs[3] + 2 * d) <= 608
+                    for tw in (((32, 16, 1) if flat_ok else (32, 16)) if k == 3 else (32,)):
                         y = ops.conv_bx_raw(a, w, d, dgrad=bool(role), packed=pk, ksplit=ks, tile_w=tw)
                         assert float((y - ref).abs().max()) <= 2e-5 * float(ref.abs().max()), (names[0], ks, tw)
                         t = timeit(lambda: ops.conv_bx_raw(a, w, d, dgrad=bool(role), packed=pk, ksplit=ks, tile_w=tw))
