@@ -270,7 +270,7 @@ F32_MFMA_PEAK_TF = 157.3        # dense f32 MFMA peak of MI355X (MI355X_MICROARC
 # `mfma_frac` <= 1); `f32_pipe_peak_TFLOPs` is printed beside it for reference only -- the f32 pipe alone could not reach the
 # achieved rate, so no fraction is formed against it.
 SPLIT_BF16_BOUND_TF = F32_MFMA_PEAK_TF * 16.0 / 6.0
-MFMA_ARITH = ("f32 operands and f32 accumulation; layers marked hip_bx / '/bx' in layer_paths_per_step and the 1x1 weight gradients run on "
+MFMA_ARITH = ("f32 operands and f32 accumulation; layers marked hip_bx / '/bx' in layer_paths_per_step and the 1x1 / 3x3 stride-1 weight gradients run on "
               "v_mfma_f32_32x32x16_bf16 from exact three-term bf16 splits of both operands (six partial products, dropped terms <= 2^-23 "
               "of a product: csrc/bx_split.h), the others on v_mfma_f32_32x32x2_f32")
 
@@ -423,9 +423,11 @@ def train_iter_bench(args, dev, world, crop):
                      "note": "2 * taps * Cin * Cout * output pixels of every dense convolution x 3 products (forward, input gradient, "
                              "weight gradient; no input gradient for the first layer), over the WHOLE step's wall time"},
             "config": {"workload": "stage-1 step: DeepLabv3+WN/ResNet50-deepstem fwd+bwd with the dense convolutions on this package's matrix-core "
-                                   "kernels (k_conv_bx: forward / input gradient from three-term bf16 splits of the f32 operands; k_conv_sk: persistent "
-                                   "stream-K f32 forward / input gradient of the stride-2 layers and the 3x3 layers on 48 x 48 planes; k_wgrad_bx / k_wgrad: "
-                                   "split-K weight gradient; layer_paths_per_step says which product of which layer took which kernel) + HIP memory-bound layers + "
+                                   "kernels (k_conv_bx: forward / input gradient of every stride-1 layer from three-term bf16 splits of the f32 operands, the K chunks of "
+                                   "the small planes' layers dealt to several workgroups; k_wgrad_bx / k_wgrad_bx3: 1x1 / 3x3 weight gradient on the same arithmetic "
+                                   "(the 3x3 X patch through ds_read_b64_tr_b16); k_conv_sk / k_wgrad: persistent stream-K f32 forward / input gradient and "
+                                   "split-K weight gradient of the stride-2 layers and the narrow 1x1 layers; layer_paths_per_step says which product of which "
+                                   "layer took which kernel) + HIP memory-bound layers + "
                                    "fused partial-label losses (HIP) + AdamW" + ("; DistributedDataParallel over RCCL, global loss normalisers" if world > 1 else ""),
                        "train_conv_mode": os.environ.get("MAS_TRAIN_CONV", "own"),
                        "batch": [N, 3, crop, crop], "logits": [N, C, crop, crop], "nseg": S,

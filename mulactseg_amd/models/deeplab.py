@@ -11,10 +11,13 @@ Architecture and parameter names follow the reference so that checkpoints interc
 ``convert_to_separable_conv`` (``deeplabv3.py:249-261``) semantics are built in: every k > 1 conv of the HEAD
 is depthwise(k, dilation, no bias) followed by pointwise 1x1 (no bias), with nothing in between.
 
-On the GPU the dense convolutions run on this package's f32-MFMA kernels: at inference csrc/conv_mfma.hip with the BatchNorm,
-residual add and ReLU in its epilogue (no MIOpen kernel in a pool forward); in training the weight gradient of every dense
-convolution on csrc/conv_wgrad.hip and the forward / input gradient on the persistent stream-K kernel csrc/conv_sk.hip where
-ops.conv_train_plan selects them (path_report() says which products of which layer took which kernel).  The memory-bound layers around them take the HIP
+On the GPU the dense convolutions run on this package's matrix-core kernels.  Wherever the shape allows, the f32 products are computed
+on the bf16 matrix cores from exact three-term splits of both operands (csrc/bx_split.h): at inference csrc/conv_bx.hip with the
+BatchNorm, residual add and ReLU in its epilogue (csrc/conv_mfma.hip, f32 MFMA, for the two stride-2 3x3 layers; no MIOpen kernel in a
+pool forward); in training csrc/conv_bx.hip for the forward product and the input gradient of every stride-1 layer (K chunks of the
+small planes' layers dealt to several workgroups), csrc/conv_wgrad_bx.hip / conv_wgrad_bx3.hip for the 1x1 / 3x3 weight gradients,
+and the f32-MFMA kernels csrc/conv_sk.hip (persistent stream-K) / csrc/conv_wgrad.hip for the stride-2 and the narrow layers, as
+ops.conv_train_plan / ops.conv_bx_train_ok select them (path_report() says which products of which layer took which kernel).  The memory-bound layers around them take the HIP
 kernels of this package too: BatchNorm + ReLU + residual add (csrc/bn.hip), every depthwise 3x3 (csrc/aspp.hip; the three ASPP
 dilations from one read of the feature map), the bilinear upsamplings (csrc/upsample.hip).  On the CPU the same modules run as
 plain PyTorch ops (parity tests against the executed reference, tests/test_model.py).
