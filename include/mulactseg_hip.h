@@ -513,7 +513,14 @@ int mas_conv_bx_fwd_pre(const void* x3, const void* wp, int N, int Cin, int H, i
 int mas_conv_bx_train_plan(int N, int Cin, int H, int W, int Cout, int ksize, int dil, int* out3);
 size_t mas_conv_bx_train_workspace_bytes(int N, int Cout, int H, int W, int ksplit);
 int mas_conv_bx_train(const float* x, const void* wp, int N, int Cin, int H, int W, int Cout, int ksize, int dil, const float* residual,
-                      float* y, int ksplit, int tile_w, void* workspace, size_t workspace_bytes, void* stream);
+                      float* y, int ksplit, int tile_w, void* workspace, size_t workspace_bytes, double* stats, void* stream);
+/* `stats` (forward products without residual; may be NULL): [Cout][slots][2] doubles, slots = mas_conv_bx_train_stat_slots(...) > 0 --
+ * per output channel the sums (sum y, sum y^2) of the stored outputs over disjoint pixel sets: with ksplit 1 formed in the kernel's
+ * epilogue from the accumulators (one slot per pixel tile and wave column; cross-lane halving with v_permlane16_swap / DPP adds),
+ * with ksplit > 1 by the reduction pass (one slot per picture and 4096-element chunk of a plane; H * W % 4 == 0, else 0 slots): the
+ * BatchNorm partial sums of `bn(conv(x))` (resnet.py:143-160) without a reduction pass of their own over y; feed them to
+ * mas_bn_act_train_fwd_stats.  Every slot of every channel is written. */
+int mas_conv_bx_train_stat_slots(int N, int H, int W, int Cout, int ksize, int dil, int ksplit, int tile_w);
 
 /* Weight gradient of a 1x1 stride-1 convolution on the bf16 matrix cores with f32 operands and results (csrc/conv_wgrad_bx.hip; the
  * operand split of mas_conv_bx_fwd applied to BOTH operands): dW[m,c] = sum_{n,p} dY[n,m,p] * X[n,c,p], x [N,Cin,H,W], dy [N,Cout,H,W],

@@ -91,7 +91,8 @@ SIGNATURES = {
     "mas_conv_bx_fwd_pre": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _i, _vp, _vp]),
     "mas_conv_bx_train_plan": (_i, [_i, _i, _i, _i, _i, _i, _i, _vp]),
     "mas_conv_bx_train_workspace_bytes": (_c.c_size_t, [_i, _i, _i, _i, _i]),
-    "mas_conv_bx_train": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _i, _i, _vp, _c.c_size_t, _vp]),
+    "mas_conv_bx_train": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _i, _i, _vp, _c.c_size_t, _vp, _vp]),
+    "mas_conv_bx_train_stat_slots": (_i, [_i, _i, _i, _i, _i, _i, _i, _i]),
     "mas_conv_wgrad_bx_supported": (_i, [_i, _i, _i, _i, _i]),
     "mas_conv_wgrad_bx_workspace_bytes": (_c.c_size_t, [_i, _i]),
     "mas_conv_wgrad_bx": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _c.c_size_t, _vp]),

@@ -59,6 +59,8 @@ struct BxP {
     int Cin, H, W, Cout, Ho, Wo, dil, relu;
     int tiles_x, tiles_y, ptiles, mtiles;
     int N;
+    double2* stats;                             // training forward (bare, ksplit 1): per-(row, pixel tile x wave column) sums (sum y, sum y^2) of the stored
+    int stat_slots;                             //   outputs: [Cout][stat_slots] -- the BatchNorm partial sums, formed in the epilogue (NULL: none)
     const v4f* x3;                              // PRE: the input as a bx3 tensor [N][ceil(Cin/8)][3 terms][H*W][8 bf16] (k_bx3_split / an OUT3 epilogue)
     int ksplit;                                 // split-K (bare products only): the chunks of a tile are dealt to `ksplit` workgroups; part 0
     float* part;                                //   stores into y (with the residual), part k > 0 into part + (k - 1) * N * Cout * Ho * Wo;
@@ -79,6 +81,36 @@ template <int TAPS> struct BxGeo {
 // global load go to four rows of 36 units, so that both the staging stores (lanes = consecutive pixel quads) and the MFMA
 // fragment reads (lanes = consecutive pixels, serviced in the 16-lane groups of ds_read_b128) are free of bank conflicts
 __device__ __forceinline__ int bx_pos1(int p) { return (p >> 7) * 144 + (p & 3) * 36 + ((p & 127) >> 2); }
+
+// ---- BatchNorm partial sums in the epilogue: cross-lane halving ------------------------------------------------------------
+// v[0 .. n) in every lane of a 32-lane half -> v[0 .. n / 2): the lanes whose bit `BIT` is clear keep the sums (over the lane pair
+// l, partner(l)) of entries 0 .. n/2 - 1, the others those of entries n/2 .. n - 1.  BIT 4: v_permlane16_swap (the odd 16-lane row
+// of the first register against the even row of the second: one swap + one add per pair of entries); BIT 3 .. 0: DPP adds
+// (row_ror:8, row_half_mirror, quad_perm) + one select.  After the five steps lane l holds the entries whose index (in units of
+// the final n) equals l's five bits.
+template <int BIT>
+__device__ __forceinline__ float bx_lane_pair_sum(float v) {
+    constexpr int ctrl = BIT == 3 ? 0x128 : (BIT == 2 ? 0x141 : (BIT == 1 ? 0x4E : 0xB1));      // row_ror:8 | row_half_mirror | quad_perm [2,3,0,1] | [1,0,3,2]
+    return v + __uint_as_float(__builtin_amdgcn_update_dpp(0, __float_as_uint(v), ctrl, 0xf, 0xf, false));
+}
+template <int BIT, int N>
+__device__ __forceinline__ void bx_halve(float (&v)[N], int lane) {
+    typedef unsigned v2u_ __attribute__((ext_vector_type(2)));
+    if (BIT == 4) {
+#pragma unroll
+        for (int i = 0; i < N / 2; ++i) {
+            const v2u_ r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v[i]), __float_as_uint(v[i + N / 2]), false, false);
+            v[i] = __uint_as_float(r.x) + __uint_as_float(r.y);
+        }
+    } else {
+        const bool up = (lane >> BIT) & 1;
+#pragma unroll
+        for (int i = 0; i < N / 2; ++i) {
+            const float lo = bx_lane_pair_sum<BIT>(v[i]), hi = bx_lane_pair_sum<BIT>(v[i + N / 2]);
+            v[i] = up ? hi : lo;
+        }
+    }
+}
 
 // ---- weight image --------------------------------------------------------------------------------------------------------
 // One job = one weight tensor in one role.  role 0: the forward product (M = Cout rows, K = Cin); role 1: the input gradient
@@ -643,12 +675,70 @@ __global__ __launch_bounds__(kThreads, 2) void k_conv_bx(const BxP p) {
         }
     };
     const bool bare = p.scale == nullptr && p.shift == nullptr && !p.relu, full = m0 + BM <= p.Cout;     // wave-uniform
+#ifdef BX_EPI_PAD
+    // measurement build: BX_EPI_PAD dependent VALU instructions per accumulator register pair in front of the bare epilogue -- what
+    // BatchNorm sums formed here would cost; the result reaches memory only on a condition that never holds
+    if (bare) {
+        float pad_s = 0.0f, pad_q = 0.0f;
+#pragma unroll
+        for (int rep = 0; rep < BX_EPI_PAD; ++rep)
+#pragma unroll
+            for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float a0 = vo[0] == kBxOut ? 0.0f : acc[tm][0][r], a1 = vo[1] == kBxOut ? 0.0f : acc[tm][1][r];
+                    pad_s += a0 + a1 + (float)rep;
+                    pad_q = mas_fmaf(a0, a0, mas_fmaf(a1, a1, pad_q));
+                }
+#pragma unroll
+        for (int off = 1; off < 32; off <<= 1) {
+            pad_s += __shfl_xor(pad_s, off, 64);
+            pad_q += __shfl_xor(pad_q, off, 64);
+        }
+        if (pad_s == 1.2345e-30f && pad_q == 5.4321e-30f) p.y[0] = pad_s;
+    }
+#endif
     if (bare) {
         if (full) epilogue(std::true_type{}, std::true_type{});
         else epilogue(std::true_type{}, std::false_type{});
     } else {
         if (full) epilogue(std::false_type{}, std::true_type{});
         else epilogue(std::false_type{}, std::false_type{});
+    }
+    // ---- BatchNorm partial sums of the tile (training forward): sum y, sum y^2 over the wave's 64 pixel columns, per row ------------
+    // Entry 2 j + stat of a lane = row j = 16 tm + r of its half (stat 0: sum, 1: sum of squares) over its two columns; five halving
+    // steps over the 32 lanes leave lane l31 with (sum, sum of squares) of row j = l31.  In f32 (a row of 64 values), stored as a
+    // double pair: the accumulation across tiles is k_bn_stats_wide's, in double, in index order.
+    if (!RES && p.stats != nullptr) {
+        const bool ok0 = vo[0] != kBxOut, ok1 = vo[1] != kBxOut;
+        float v[64];
+#pragma unroll
+        for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float a0 = ok0 ? acc[tm][0][r] : 0.0f, a1 = ok1 ? acc[tm][1][r] : 0.0f;
+                v[2 * (16 * tm + r)] = a0 + a1;
+                v[2 * (16 * tm + r) + 1] = mas_fmaf(a0, a0, a1 * a1);
+            }
+        float v32[32], v16[16], v8[8], v4_[4], v2_[2];
+        bx_halve<4>(v, lane);
+#pragma unroll
+        for (int i = 0; i < 32; ++i) v32[i] = v[i];
+        bx_halve<3>(v32, lane);
+#pragma unroll
+        for (int i = 0; i < 16; ++i) v16[i] = v32[i];
+        bx_halve<2>(v16, lane);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v8[i] = v16[i];
+        bx_halve<1>(v8, lane);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) v4_[i] = v8[i];
+        bx_halve<0>(v4_, lane);
+        v2_[0] = v4_[0];
+        v2_[1] = v4_[1];
+        const int j = l31, tmj = j >> 4, rj = j & 15;
+        const int m = m0 + wm * 64 + tmj * 32 + (rj & 3) + 8 * (rj >> 2) + 4 * h;
+        if (m < p.Cout) p.stats[(size_t)m * p.stat_slots + pt * WN + wn] = make_double2((double)v2_[0], (double)v2_[1]);
     }
 #ifdef BX_STAMPS
     if (stamp) {
@@ -760,6 +850,34 @@ __global__ __launch_bounds__(256) void k_bx_reduce(float* __restrict__ y, const 
         }
         reinterpret_cast<v4f*>(y)[i] = a;
     }
+}
+
+// The same pass with the BatchNorm partial sums of the finished y: one workgroup per (plane, chunk of 4096 elements) -- the pass is
+// memory-bound, its VALUs idle -- stats[c][n * chunks + chunk] = (sum y, sum y^2), a fixed tree over the 256 threads in double.
+constexpr int kBxRedChunk = 4096;
+__global__ __launch_bounds__(256) void k_bx_reduce_stats(float* __restrict__ y, const float* __restrict__ part, int nparts, int C, int HW, int chunks,
+                                                          long long stride, double2* __restrict__ stats) {
+    __shared__ double s_red[2][4];
+    const int chunk = blockIdx.x, plane = blockIdx.y;           // plane = n * C + c
+    const int n = plane / C, c = plane - n * C;
+    const long long base4 = ((long long)plane * HW + (long long)chunk * kBxRedChunk) >> 2;
+    const int n4 = (min(HW - chunk * kBxRedChunk, kBxRedChunk)) >> 2;
+    float s = 0.0f, q = 0.0f;
+    for (int i = threadIdx.x; i < n4; i += 256) {
+        v4f a = reinterpret_cast<const v4f*>(y)[base4 + i];
+        for (int k = 0; k < nparts; ++k) a += __builtin_nontemporal_load(reinterpret_cast<const v4f*>(part + (size_t)k * stride) + base4 + i);
+        reinterpret_cast<v4f*>(y)[base4 + i] = a;
+        s += (a.x + a.y) + (a.z + a.w);
+        q += (a.x * a.x + a.y * a.y) + (a.z * a.z + a.w * a.w);
+    }
+    double S = (double)s, Q = (double)q;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) { S += __shfl_down(S, off, 64); Q += __shfl_down(Q, off, 64); }
+    if ((threadIdx.x & 63) == 0) { s_red[0][threadIdx.x >> 6] = S; s_red[1][threadIdx.x >> 6] = Q; }
+    __syncthreads();
+    if (threadIdx.x == 0)
+        stats[(size_t)c * (gridDim.y / C) * chunks + (size_t)n * chunks + chunk] =
+            make_double2(((s_red[0][0] + s_red[0][1]) + s_red[0][2]) + s_red[0][3], ((s_red[1][0] + s_red[1][1]) + s_red[1][2]) + s_red[1][3]);
 }
 
 // ---- the work-splitting plan of a bare stride-1 product (training) --------------------------------------------------------
@@ -888,7 +1006,7 @@ extern "C" int mas_conv_bx_fwd(const float* x, const void* wp, int N, int Cin, i
     hipStream_t st = static_cast<hipStream_t>(stream);
     BxP p;
     p.x = x; p.wp = static_cast<const v4f*>(wp); p.scale = scale; p.shift = shift; p.res = residual; p.y = y;
-    p.x2 = nullptr; p.wp2 = nullptr; p.Cin2 = 0; p.ksplit = 1; p.part = nullptr; p.x3 = nullptr;
+    p.x2 = nullptr; p.wp2 = nullptr; p.Cin2 = 0; p.ksplit = 1; p.part = nullptr; p.x3 = nullptr; p.stats = nullptr; p.stat_slots = 0;
     p.Cin = Cin; p.H = H; p.W = W; p.Cout = Cout; p.dil = dil; p.relu = relu;
 #ifdef BX_STAMPS
     p.stamps = g_bx_stamps;
@@ -920,7 +1038,7 @@ extern "C" int mas_conv_bx_fwd_dual(const float* x1, const void* wp1, int Cin1, 
     hipStream_t st = static_cast<hipStream_t>(stream);
     BxP p;
     p.x = x1; p.wp = static_cast<const v4f*>(wp1); p.scale = nullptr; p.shift = shift; p.res = nullptr; p.y = y;
-    p.x2 = x2; p.wp2 = static_cast<const v4f*>(wp2); p.Cin2 = Cin2; p.ksplit = 1; p.part = nullptr; p.x3 = nullptr;
+    p.x2 = x2; p.wp2 = static_cast<const v4f*>(wp2); p.Cin2 = Cin2; p.ksplit = 1; p.part = nullptr; p.x3 = nullptr; p.stats = nullptr; p.stat_slots = 0;
     p.Cin = Cin1; p.H = H; p.W = W; p.Cout = Cout; p.dil = 1; p.relu = relu;
 #ifdef BX_STAMPS
     p.stamps = g_bx_stamps;
@@ -943,8 +1061,27 @@ extern "C" size_t mas_conv_bx_train_workspace_bytes(int N, int Cout, int H, int 
     return (size_t)(ksplit - 1) * N * Cout * H * W * sizeof(float);
 }
 
+/* slots per output channel of the BatchNorm partial sums a FORWARD launch can form in its epilogue (pixel tiles x wave columns);
+ * 0: this plan cannot (split K: the final values exist only after the reduction pass) */
+extern "C" int mas_conv_bx_train_stat_slots(int N, int H, int W, int Cout, int ksize, int dil, int ksplit, int tile_w) {
+    if (N <= 0 || H <= 0 || W <= 0 || Cout <= 0 || ksplit < 1) return 0;
+    if (ksplit > 1) {                       // split K: the sums come out of the reduction pass, one slot per (picture, 4096-element chunk of a plane)
+        const long long HW = (long long)H * W;
+        if (HW % 4 != 0 || (long long)N * Cout > 65535) return 0;
+        return (int)(N * ((HW + kBxRedChunk - 1) / kBxRedChunk));
+    }
+    const int BM = bx_bm(ksize, Cout), BN = ksize == 1 ? (BM == 128 ? 128 : 256) : 256;
+    long long ptiles;
+    if (ksize == 1 || tile_w == 1) ptiles = (long long)N * (((long long)H * W + BN - 1) / BN);
+    else if (tile_w == 16 || tile_w == 32) ptiles = (long long)N * ((W + tile_w - 1) / tile_w) * ((H + 256 / tile_w - 1) / (256 / tile_w));
+    else return 0;
+    (void)dil;
+    const long long slots = ptiles * (BN / 64);
+    return slots > 0 && slots < 0x7fffffffLL ? (int)slots : 0;
+}
+
 extern "C" int mas_conv_bx_train(const float* x, const void* wp, int N, int Cin, int H, int W, int Cout, int ksize, int dil, const float* residual,
-                                 float* y, int ksplit, int tile_w, void* workspace, size_t workspace_bytes, void* stream) {
+                                 float* y, int ksplit, int tile_w, void* workspace, size_t workspace_bytes, double* stats, void* stream) {
     if (!x || !wp || !y) return MAS_ERR_NULL;
     if (N <= 0) return MAS_ERR_SHAPE;
     if (!mas_conv_bx_supported(ksize, 1, dil, Cin, Cout, H, W)) return MAS_ERR_SHAPE;
@@ -955,6 +1092,7 @@ extern "C" int mas_conv_bx_train(const float* x, const void* wp, int N, int Cin,
     const int ck = ksize == 1 ? 32 : 8, nch = (Cin + ck - 1) / ck;
     if (ksplit > nch || ksplit > 64) return MAS_ERR_RANGE;
     if (tile_w != 32 && !((tile_w == 16 || (tile_w == 1 && bx_flat_fits(H, W, dil))) && ksize == 3)) return MAS_ERR_RANGE;
+    if (stats && (residual || (uintptr_t)stats % 16 != 0)) return MAS_ERR_RANGE;
     const size_t out_elems = (size_t)N * Cout * H * W;
     if (ksplit > 1) {
         if (!workspace) return MAS_ERR_NULL;
@@ -965,6 +1103,10 @@ extern "C" int mas_conv_bx_train(const float* x, const void* wp, int N, int Cin,
     BxP p;
     p.x = x; p.wp = static_cast<const v4f*>(wp); p.scale = nullptr; p.shift = nullptr; p.res = residual; p.y = y;
     p.x2 = nullptr; p.wp2 = nullptr; p.Cin2 = 0; p.ksplit = ksplit; p.part = static_cast<float*>(workspace); p.x3 = nullptr;
+    const int stat_slots = stats ? mas_conv_bx_train_stat_slots(N, H, W, Cout, ksize, dil, ksplit, tile_w) : 0;
+    if (stats && stat_slots <= 0) return MAS_ERR_RANGE;
+    p.stats = ksplit == 1 ? reinterpret_cast<double2*>(stats) : nullptr;       // (split K: formed by the reduction pass below)
+    p.stat_slots = stat_slots;
     p.Cin = Cin; p.H = H; p.W = W; p.Cout = Cout; p.dil = dil; p.relu = 0;
 #ifdef BX_STAMPS
     p.stamps = g_bx_stamps;
@@ -977,6 +1119,12 @@ extern "C" int mas_conv_bx_train(const float* x, const void* wp, int N, int Cin,
     else if (tile_w == 1) rc = dil == 1 ? bx_launch_r<9, 64, 256, 1, 0>(p, N, st) : bx_launch_r<9, 64, 256, 2, 0>(p, N, st);
     else rc = dil == 1 ? bx_launch_r<9, 64, 256, 1>(p, N, st) : bx_launch_r<9, 64, 256, 2>(p, N, st);
     if (rc != 0 || ksplit == 1) return rc;
+    if (stats) {
+        const int HW = H * W, chunks = (HW + kBxRedChunk - 1) / kBxRedChunk;
+        hipLaunchKernelGGL(k_bx_reduce_stats, dim3((unsigned)chunks, (unsigned)(N * Cout)), dim3(256), 0, st, y, static_cast<const float*>(workspace),
+                           ksplit - 1, Cout, HW, chunks, (long long)out_elems, reinterpret_cast<double2*>(stats));
+        return mas_launch_status();
+    }
     const long long n4 = (long long)(out_elems / 4);
     const long long blocks = (n4 + 255) / 256;
     hipLaunchKernelGGL(k_bx_reduce, dim3((unsigned)(blocks < 4096 ? blocks : 4096)), dim3(256), 0, st, y, static_cast<const float*>(workspace),
@@ -1011,7 +1159,7 @@ extern "C" int mas_conv_bx_fwd_pre(const void* x3, const void* wp, int N, int Ci
     hipStream_t st = static_cast<hipStream_t>(stream);
     BxP p;
     p.x = nullptr; p.x3 = static_cast<const v4f*>(x3); p.wp = static_cast<const v4f*>(wp); p.scale = scale; p.shift = shift; p.res = residual; p.y = y;
-    p.x2 = nullptr; p.wp2 = nullptr; p.Cin2 = 0; p.ksplit = 1; p.part = nullptr;
+    p.x2 = nullptr; p.wp2 = nullptr; p.Cin2 = 0; p.ksplit = 1; p.part = nullptr; p.stats = nullptr; p.stat_slots = 0;
     p.Cin = Cin; p.H = H; p.W = W; p.Cout = Cout; p.dil = dil; p.relu = relu;
 #ifdef BX_STAMPS
     p.stamps = g_bx_stamps;

@@ -112,7 +112,9 @@ def _conv_bn_act(conv, bn, x, relu=True, residual=None, fork=False):
             _took("conv_bn_act", "train:" + "".join(n if o else "-" for n, o in zip("fdw", own)) + ("/bx" if bx else ""))
             # stats: the forward kernel forms the BatchNorm partial sums of its output in its epilogue (no reduction pass over y);
             # fork: the gradient of x's other consumer is added in the epilogue of this convolution's input-gradient kernel
-            stats = own[0] and not bx and bn.training and os.environ.get("MAS_BN_STATS", "fused") == "fused"
+            # (round 5: the split-bf16 kernel forms them too, unless its plan splits K -- then `part` comes back None and the BatchNorm
+            #  runs its own reduction pass)
+            stats = own[0] and bn.training and os.environ.get("MAS_BN_STATS", "fused") == "fused" and not (bx and os.environ.get("MAS_BX_STATS", "on") == "off")
             fork = fork and own[1] and conv.stride[0] == 1 and x.requires_grad and os.environ.get("MAS_GRAD_FORK", "fused") == "fused"
             res = ops.conv_train(conv, x, own, stats=stats, fork=fork)
             y, part = (res[0], res[1]) if (stats or fork) else (res, None)

@@ -1230,7 +1230,11 @@ def conv_bx_dual(conv_a, bn_a, xa, conv_b, bn_b, xb, relu=True):
     M = conv_a.out_channels
     wa, sa = _conv_bx_folded(conv_a, bn_a)
     wb, sb = _conv_bx_folded(conv_b, bn_b)
-    shift = (sa.double() + sb.double()).float()
+    # the sum of the two shifts, cached with the folded images it belongs to (three ATen launches per call otherwise)
+    cache = getattr(conv_a, '_mas_conv_bx_dual_shift', None)
+    if cache is None or cache[0] is not sa or cache[1] is not sb:
+        cache = conv_a._mas_conv_bx_dual_shift = (sa, sb, (sa.double() + sb.double()).float())
+    shift = cache[2]
     y = torch.empty((N, M, H, W), dtype=torch.float32, device=xa.device)
     with torch.cuda.device(xa.device):
         _lib.check(_lib.load().mas_conv_bx_fwd_dual(xa.data_ptr(), wa.data_ptr(), Ka, xb.data_ptr(), wb.data_ptr(), xb.shape[1], N, H, W, M,
@@ -1617,10 +1621,13 @@ def conv_bx_s2_raw(x, w, packed=None):
     return y
 
 
-def conv_bx_raw(x, w, dil=1, dgrad=False, residual=None, packed=None, ksplit=0, tile_w=0):
+def conv_bx_raw(x, w, dil=1, dgrad=False, residual=None, packed=None, ksplit=0, tile_w=0, stats=False):
     """The bare stride-1 product of a training step on csrc/conv_bx.hip: dgrad False: y = conv2d(x, w, padding = dil (k 3) / 0 (k 1),
     dilation); dgrad True: x is dY [N,Cout,H,W] and the result dX [N,Cin,H,W] (+ residual: the gradient of x's other consumer).
     ksplit / tile_w: 0 = the library's work-splitting plan (mas_conv_bx_train_plan); explicit values for sweeps and tests.
+    stats=True (forward, no residual): returns (y, partials) -- partials [Cout, slots, 2] float64, the BatchNorm partial sums
+    (sum y, sum y^2 over disjoint pixel sets) formed in the kernel's epilogue (ksplit 1) or by the reduction pass of a split-K plan, or
+    None where neither can (split K on a plane of odd size).
     Operands must be finite and within 2^-100 < |v| < 2^127 (csrc/bx_split.h): an Inf operand yields NaN where the f32 pipe would
     propagate Inf (h = Inf, m = Inf - Inf), NaN stays NaN, values below 2^-100 lose their third term (relative error <= 2^-16)."""
     _need(x, "x", torch.float32)
@@ -1638,17 +1645,23 @@ def conv_bx_raw(x, w, dil=1, dgrad=False, residual=None, packed=None, ksplit=0, 
     if packed is None:
         packed = conv_bx_pack(w, int(dgrad))
     lib = _lib.load()
-    if not ksplit:
-        ksplit = conv_bx_train_plan(x.shape, w.shape, dil, dgrad)[0]
+    if not ksplit or not tile_w:
+        plan = conv_bx_train_plan(x.shape, w.shape, dil, dgrad)
+        ksplit = ksplit or plan[0]
+        tile_w = tile_w or plan[1]
     if ksplit > 1 and (y.numel() % 4 != 0):
         ksplit = 1                                   # (the reduction pass walks 16-byte groups)
-    ws = None
+    ws = part = None
     with torch.cuda.device(x.device):
         if ksplit > 1:
             ws = _bx_workspace(x.device, int(lib.mas_conv_bx_train_workspace_bytes(N, M, H, W, ksplit)))
+        if stats and not dgrad and residual is None:
+            slots = int(lib.mas_conv_bx_train_stat_slots(N, H, W, M, ks, dil, int(ksplit), int(tile_w)))
+            if slots > 0:
+                part = torch.empty((M, slots, 2), dtype=torch.float64, device=x.device)
         _lib.check(lib.mas_conv_bx_train(x.data_ptr(), packed.data_ptr(), N, K, H, W, M, ks, dil, _opt(residual), y.data_ptr(), int(ksplit),
-                                         int(tile_w), _opt(ws), ws.numel() if ws is not None else 0, _stream(x)), "mas_conv_bx_train")
-    return y
+                                         int(tile_w), _opt(ws), ws.numel() if ws is not None else 0, _opt(part), _stream(x)), "mas_conv_bx_train")
+    return (y, part) if stats else y
 
 
 def conv_bx_train_ok(x_shape, w_shape, stride, dil, dgrad):
@@ -1892,6 +1905,9 @@ class _ConvTrain(torch.autograd.Function):
                 # split-bf16 kernel (csrc/conv_bx.hip); the BatchNorm partial sums then come from the separate reduction pass
                 if stride == 2:
                     y = conv_bx_s2_raw(x, w, packed=bx_packed_weight(w, 0))
+                elif stats:
+                    # (the BatchNorm partial sums from the kernel's epilogue / the split-K reduction pass)
+                    y, part = conv_bx_raw(x, w, dil, packed=bx_packed_weight(w, 0), stats=True)
                 else:
                     y = conv_bx_raw(x, w, dil, packed=bx_packed_weight(w, 0))
             elif own[0] and stats:

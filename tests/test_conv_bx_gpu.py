@@ -476,3 +476,60 @@ def test_wgrad_3x3_exact_on_integers_and_tap_by_tap():
                     iy, ix = y + (ty - 1) * dil, xx + (tx - 1) * dil
                     want = x[0, :, iy, ix] if (0 <= iy < H and 0 <= ix < W) else torch.zeros(32, device='cuda')
                     assert torch.equal(dw[m, :, ty, tx], want), (dil, m, y, xx, ty, tx)
+
+
+STAT_CASES = [
+    # Cin, Cout, k, dil, N, H, W, tile_w
+    (64, 256, 1, 1, 2, 48, 48, 32),      # 128-row M tiles, whole pixel tiles
+    (256, 64, 1, 1, 2, 20, 36, 32),      # 64-row M tile x 256 pixels, partial pixel tile
+    (32, 200, 1, 1, 1, 25, 33, 32),      # Cout 200: the last M tile is mostly padding; odd plane
+    (64, 64, 3, 1, 2, 40, 72, 32),       # 3x3, 8 x 32 tiles, partial tiles in both directions
+    (64, 128, 3, 1, 1, 48, 48, 16),      # 16 x 16 tiles
+    (72, 64, 3, 2, 1, 49, 49, 1),        # flat tiles, dilation 2
+    (128, 1024, 1, 1, 4, 24, 24, 32),    # many M tiles
+]
+
+
+@pytest.mark.parametrize("Cin,Cout,k,dil,N,H,W,tw", STAT_CASES)
+def test_epilogue_batchnorm_partials_are_the_sums_of_the_stored_outputs(Cin, Cout, k, dil, N, H, W, tw):
+    """mas_conv_bx_train(stats): [Cout, slots, 2] partial sums formed in the epilogue (v_permlane16_swap / DPP halving over the 32
+    lanes of a row) -- summed over the slots they are sum y and sum y^2 of the y the same launch stored: exactly on integer data,
+    to f32 rounding on real data; pixels beyond the plane and rows beyond Cout contribute nothing; y itself is unchanged."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from mulactseg_amd import ops
+    g = torch.Generator(device='cuda').manual_seed(Cin + Cout + H)
+    pad = dil if k == 3 else 0
+    for integer in (True, False):
+        if integer:
+            w = torch.randint(-2, 3, (Cout, Cin, k, k), generator=g, device='cuda').float()
+            x = torch.randint(-3, 4, (N, Cin, H, W), generator=g, device='cuda').float()
+        else:
+            w = torch.randn(Cout, Cin, k, k, generator=g, device='cuda') / (Cin * k * k) ** 0.5
+            x = torch.randn(N, Cin, H, W, generator=g, device='cuda')
+        y0 = ops.conv_bx_raw(x, w, dil, ksplit=1, tile_w=tw)
+        y, part = ops.conv_bx_raw(x, w, dil, ksplit=1, tile_w=tw, stats=True)
+        assert torch.equal(y, y0)
+        assert part is not None and part.shape[0] == Cout and part.shape[2] == 2 and part.dtype == torch.float64
+        s = part[:, :, 0].sum(1)
+        q = part[:, :, 1].sum(1)
+        ys = y.double().sum(dim=(0, 2, 3))
+        yq = (y.double() ** 2).sum(dim=(0, 2, 3))
+        if integer:
+            assert torch.equal(s, ys) and torch.equal(q, yq), (float((s - ys).abs().max()), float((q - yq).abs().max()))
+        else:
+            assert float((s - ys).abs().max()) <= 1e-5 * float(y.abs().double().sum(dim=(0, 2, 3)).max())
+            assert float((q - yq).abs().max()) <= 1e-5 * float(yq.max())
+    # a plan that splits K forms them in its reduction pass (planes of a multiple of four pixels; None otherwise: the caller's
+    # BatchNorm then runs its own reduction pass)
+    nch = -(-Cin // (32 if k == 1 else 8))
+    if nch >= 2:
+        y2, part2 = ops.conv_bx_raw(x, w, dil, ksplit=2, tile_w=tw, stats=True)
+        assert torch.equal(y2, ops.conv_bx_raw(x, w, dil, ksplit=2, tile_w=tw))
+        if (H * W) % 4 == 0:
+            assert part2 is not None and part2.shape == (Cout, N * (-(-H * W // 4096)), 2)
+            ys2, yq2 = y2.double().sum(dim=(0, 2, 3)), (y2.double() ** 2).sum(dim=(0, 2, 3))
+            assert float((part2[:, :, 0].sum(1) - ys2).abs().max()) <= 1e-5 * float(y2.abs().double().sum(dim=(0, 2, 3)).max())
+            assert float((part2[:, :, 1].sum(1) - yq2).abs().max()) <= 1e-5 * float(yq2.max())
+        else:
+            assert part2 is None
