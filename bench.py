@@ -27,6 +27,7 @@ scaling), scan-only and with the model forward; "train_iter" / "train_iter_769" 
 Prints ONE JSON line on rank 0.
 """
 import argparse
+import gc
 import json
 import os
 import sys
@@ -874,9 +875,15 @@ def main():
                              "scan_only": secondary(pool_round_bench, args, dev, rank, world, False),
                              "with_model_forward": None if args.no_train else secondary(pool_round_bench, args, dev, rank, world, True)}
         torch.cuda.empty_cache()
-    out["train_iter"] = None if (args.no_train or args.no_trainleg) else secondary(train_iter_bench, args, dev, world, args.crop)
-    out["train_iter_769"] = None if (args.no_train or args.no_trainleg) else secondary(train_iter_bench, args, dev, world, 769)
-    out["acquisition_with_model"] = None if args.no_train else secondary(acquisition_with_model_bench, args, dev, world)
+    def leg(fn, *a):
+        # every leg starts from an empty caching allocator: the blocks a previous leg left behind fit the next leg's shapes badly (the
+        # 769 crop after the 768 one) and what the allocator then carves out of them is scattered -- not part of any timed region
+        gc.collect()
+        torch.cuda.empty_cache()
+        return secondary(fn, *a)
+    out["train_iter"] = None if (args.no_train or args.no_trainleg) else leg(train_iter_bench, args, dev, world, args.crop)
+    out["train_iter_769"] = None if (args.no_train or args.no_trainleg) else leg(train_iter_bench, args, dev, world, 769)
+    out["acquisition_with_model"] = None if args.no_train else leg(acquisition_with_model_bench, args, dev, world)
     out["stage2"] = None if (args.no_train or args.no_trainleg or rank != 0) else secondary(stage2_bench, args, dev)
     # the secondary legs' headline numbers as TOP-LEVEL keys (a reader of the parsed line need not dig through the nested objects)
     def pick(d, *path):
