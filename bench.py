@@ -45,6 +45,7 @@ if ROOT not in sys.path:
 HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6.3 TB/s is achievable
 EVENT_EVERY = 4            # HIP-event pairs around every 4th scan launch of the timed region
 POOL_IMAGES, POOL_CLICKS = 2975, 100000
+POOL_WARM_IMAGES, POOL_WARM_CLICKS = 64, 2000
 
 
 def parse():
@@ -187,17 +188,18 @@ class ModelOnRotatingPictures(torch.nn.Module):
         return self.net(self.pictures[self.k % self.pictures.shape[0]][:indices.shape[0]])
 
 
-def pool_round_bench(args, dev, rank, world, with_model):
+def pool_round_bench(args, dev, rank, world, with_model, n_images=POOL_IMAGES, clicks=POOL_CLICKS):
     """BASELINE.json config 3 at its real size: 2 975 pictures x 2 048 superpixels, 100 000 clicks (fair counting), through
     RegionSelector.select_next_batch -- scan (+ model forward), two exchanges, device class weights, finalize + ban, K4 on
-    6.09 M keys, RegionActiveDataset bookkeeping.  The pool is sharded over the ranks: strong scaling."""
+    6.09 M keys, RegionActiveDataset bookkeeping.  The pool is sharded over the ranks: strong scaling.
+    (n_images / clicks: the warm-up round on a small pool that precedes the timed one.)"""
     from mulactseg_amd.active_selection import my_bvsb_predclsbal_pwr_banignore as banignore
     from mulactseg_amd.active_selection.engine import ShardPlan
     from mulactseg_amd.dataloader import RegionActiveDataset
     from mulactseg_amd.synth_pool import LogitSource, SyntheticLabels, SyntheticPool
     B, C, H, W, S = args.batch, args.classes, args.height, args.width, args.nseg
-    plan = ShardPlan(POOL_IMAGES, B, rank, world)
-    pool = SyntheticPool(POOL_IMAGES, H, W, S, dev, shard=(plan.img_lo, plan.img_hi))
+    plan = ShardPlan(n_images, B, rank, world)
+    pool = SyntheticPool(n_images, H, W, S, dev, shard=(plan.img_lo, plan.img_hi))
     labels = SyntheticLabels(pool, C)
     if with_model:
         from mulactseg_amd.models import get_model
@@ -236,7 +238,7 @@ def pool_round_bench(args, dev, rank, world, with_model):
                 net(torch.zeros(B))
     fence()
     t0 = time.perf_counter()
-    sel.select_next_batch(trainer, active, POOL_CLICKS)
+    sel.select_next_batch(trainer, active, clicks)
     fence()
     t1 = time.perf_counter()
     active.wait_for_writes()        # (the selection pickle is written by a background thread, off the round's critical path)
@@ -250,7 +252,7 @@ def pool_round_bench(args, dev, rank, world, with_model):
     active.dump_datalist()
     t_dump = time.perf_counter() - t2
     n_sel = sum(len(v) for v in labels.suppix.values())
-    return {"seconds": dt, "superpixels_per_s": POOL_IMAGES * S / dt, "regions_selected": n_sel,
+    return {"seconds": dt, "superpixels_per_s": n_images * S / dt, "regions_selected": n_sel,
             "rank0_breakdown_s": {"scores (scan%s + exchanges + class weights + finalize)" % (" + model forward" if with_model else ""):
                                   marks['scored'] - t0,
                                   "valid mask + cost table + K4 (keys, radix sort, walk)": marks['selected'] - marks['scored'],
@@ -872,7 +874,12 @@ def main():
         out["pool_round"] = {"metric": "acquisition round over the fixed %d-picture x %d-superpixel pool, %d clicks, through "
                                        "RegionSelector.select_next_batch; sharded over %d rank(s)" % (POOL_IMAGES, S, POOL_CLICKS, world),
                              "scaling": "strong",
-                             "scan_only": secondary(pool_round_bench, args, dev, rank, world, False),
+                             # the first round of a process pays first-use costs that no later round of the loop sees (code objects
+                             # of the ordering / walk kernels and of the ATen ops behind the tail, allocator growth: ~0.05 s): one
+                             # round over a 64-picture pool of the same shapes is run before the timed one, as the W warm-up steps are
+                             "warm_up": "one untimed round over a %d-picture pool (%d clicks) before the timed ones" % (POOL_WARM_IMAGES, POOL_WARM_CLICKS),
+                             "scan_only": (secondary(pool_round_bench, args, dev, rank, world, False, POOL_WARM_IMAGES, POOL_WARM_CLICKS),
+                                           secondary(pool_round_bench, args, dev, rank, world, False))[1],
                              "with_model_forward": None if args.no_train else secondary(pool_round_bench, args, dev, rank, world, True)}
         torch.cuda.empty_cache()
     def leg(fn, *a):
