@@ -25,6 +25,9 @@
 // A workgroup is 4 waves, a wave owns 64 x 64 of the tile (2 x 2 MFMA tiles: 64 accumulator registers); chunk t + 1 travels
 // global -> registers in front of the MFMAs of chunk t and registers -> (split) -> LDS behind them; two workgroups per CU
 // cover each other's staging.  Epilogue as conv_mfma.hip: y * scale[m] + shift[m] (+ residual) (ReLU), NCHW stores.
+// 3x3 stride 2 (layer2.0.conv2 / layer3.0.conv2): nine shifted 1x1 stride-2 products into one accumulator set -- the chunks run
+// over (tap, 32 channels), the tap is a byte offset of the chunk's global loads (no patch in LDS: a tile's input patch at stride
+// 2 is four times its output); weight image of role 2 (tap-major chunks).
 // Dual form (mas_conv_bx_fwd_dual, 1x1 stride 1): the chunks of a second input with its own weight image follow those of the
 // first into the same accumulators -- conv3 + stride-1 downsample of a Bottleneck with both BatchNorm scales folded into the
 // weight rows at pack time (row_scale).
@@ -62,6 +65,7 @@ struct BxP {
     double2* stats;                             // training forward (bare, ksplit 1): per-(row, pixel tile x wave column) sums (sum y, sum y^2) of the stored
     int stat_slots;                             //   outputs: [Cout][stat_slots] -- the BatchNorm partial sums, formed in the epilogue (NULL: none)
     const v4f* x3;                              // PRE: the input as a bx3 tensor [N][ceil(Cin/8)][3 terms][H*W][8 bf16] (k_bx3_split / an OUT3 epilogue)
+    int t9;                                     // stride-2 form: 1 = the 3x3 convolution as nine shifted 1x1 products (chunks = tap x 32 channels)
     int ksplit;                                 // split-K (bare products only): the chunks of a tile are dealt to `ksplit` workgroups; part 0
     float* part;                                //   stores into y (with the residual), part k > 0 into part + (k - 1) * N * Cout * Ho * Wo;
                                                 //   k_bx_reduce then adds the parts into y in index order
@@ -123,12 +127,41 @@ struct BxPackJob {
     const float* row_scale;     // NULL, or [Cout]: the image holds w[m, :, :] * row_scale[m] (role 0: a BatchNorm scale folded into the weight)
     unsigned* out;
     int Cout, Cin, taps, role, BM;
+    int t9;                     // role 2: the 3x3 weight as 9 x (Cin / 32) chunks of the 1x1 form, tap-major (the strided 3x3 forward)
     long long units;
     unsigned first_block;       // (multi-job launch) the job's first 256-thread block
 };
 
 __device__ __forceinline__ void bx_pack_unit(const BxPackJob& jb, long long u) {
     const int taps = jb.taps, BM = jb.BM;
+    if (jb.t9) {                                    // [M tile][chunk = tap * (Cin / 32) + cc][term][k group 0..3][row][8]: channel = cc * 32 + 8 g + j
+        const int row = (int)(u % BM);
+        long long r = u / BM;
+        const int g = (int)(r % 4);
+        r /= 4;
+        const int term = (int)(r % 3);
+        r /= 3;
+        const int cpt = jb.Cin / 32, nch = 9 * cpt;
+        const int chunk = (int)(r % nch), mt = (int)(r / nch);
+        const int tap = chunk / cpt, cc = chunk - tap * cpt;
+        const int m = mt * BM + row;
+        unsigned o[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float v0 = 0.0f, v1 = 0.0f;
+            if (m < jb.Cout) {
+                const size_t base = ((size_t)m * jb.Cin + cc * 32 + 8 * g + 2 * j) * 9 + tap;
+                v0 = jb.w[base];
+                v1 = jb.w[base + 9];
+                if (jb.row_scale) { v0 *= jb.row_scale[m]; v1 *= jb.row_scale[m]; }
+            }
+            unsigned h, mm, l;
+            bx_split2(v0, v1, h, mm, l);
+            o[j] = term == 0 ? h : (term == 1 ? mm : l);
+        }
+        *reinterpret_cast<uint4*>(jb.out + 4 * u) = make_uint4(o[0], o[1], o[2], o[3]);
+        return;
+    }
     const int GA = taps == 1 ? 4 : kBxTaps3, CK = taps == 1 ? 32 : 8;
     const int M = jb.role ? jb.Cin : jb.Cout, K = jb.role ? jb.Cout : jb.Cin;
     const int row = (int)(u % BM);
@@ -280,6 +313,7 @@ __global__ __launch_bounds__(kThreads, 2) void k_conv_bx(const BxP p) {
 
     // ---- staging descriptors (the same for every chunk): byte offset inside the chunk's x resource, byte offset in the B image --
     int goff[NT], loff[NT];
+    bool s2top[NT], s2left[NT];                 // stride-2 form with taps: the task's output quad lies in output row 0 / starts at output column 0
     int pgoff[PRE ? NPRE : 1], ploff[PRE ? NPRE : 1];
     if (PRE) {
 #pragma unroll
@@ -316,11 +350,14 @@ __global__ __launch_bounds__(kThreads, 2) void k_conv_bx(const BxP p) {
             const int q = ((rest / (BN / 32)) << 1) | ((task >> 3) & 1);          // channel quad 0..7 of the chunk
             const int po = p0 + 4 * pq;
             goff[j] = kBxOut;
+            s2top[j] = s2left[j] = false;
             if (po < HWo) {
                 int pix = po;
                 if (S2) {
                     const int oy = po / p.Wo, ox = po - oy * p.Wo;
                     pix = 2 * oy * p.W + 2 * ox;
+                    s2top[j] = oy == 0;
+                    s2left[j] = ox == 0;
                 }
                 goff[j] = (q * 4 * HW + pix) * 4;
             }
@@ -381,7 +418,8 @@ __global__ __launch_bounds__(kThreads, 2) void k_conv_bx(const BxP p) {
     const float* xb = PRE ? nullptr : p.x + (size_t)n * p.Cin * HW;
     // DUAL (1x1 stride 1 only): the chunks of a second input / weight image follow those of the first; one accumulator set
     constexpr bool DUAL_OK = TAPS == 1 && !S2;
-    const int n1 = (p.Cin + CK - 1) / CK;
+    const int cpt = (p.Cin + CK - 1) / CK;                           // chunks per tap
+    const int n1 = (S2 && p.t9) ? 9 * cpt : cpt;
     const int n2 = DUAL_OK ? (p.Cin2 + CK - 1) / CK : 0;
     const int nchunks = n1 + n2;
     const v4f* wb = p.wp + (size_t)mt * n1 * AUNITS;
@@ -400,6 +438,7 @@ __global__ __launch_bounds__(kThreads, 2) void k_conv_bx(const BxP p) {
         sE[BM + tid] = (p.shift && real) ? p.shift[m0 + tid] : 0.0f;
     }
 
+    bool pend_kx0 = false;                      // stride-2 form with taps: the chunk in the staging registers belongs to a tap of column kx = 0
     auto fetch = [&](int t) {
         // (the chunk index is wave-uniform; said explicitly, because a resource descriptor the compiler takes for divergent is
         //  applied through a readfirstlane loop around EVERY load -- 11 more instructions per load in the 3x3 form)
@@ -410,6 +449,21 @@ __global__ __launch_bounds__(kThreads, 2) void k_conv_bx(const BxP p) {
         const int cin = second ? p.Cin2 : p.Cin;
         if (second) t -= n1;
         const __amdgpu_buffer_rsrc_t wres = __builtin_amdgcn_make_buffer_rsrc(const_cast<v4f*>(wsrc + (size_t)t * AUNITS), 0, AUNITS * 16, kBxRsrcFlags);
+        // stride-2 form with taps: chunk t = (tap, channel chunk); the tap (ky, kx) shifts the loads by (ky - 1) rows and (kx - 1)
+        // columns.  What falls outside the picture: row -1 (ky 0 on output row 0: the task reads nothing -- zeros) and column -1
+        // (kx 0 on output column 0: the task loads from column 0 instead and stage() takes its elements one place further left,
+        // a zero first).  Rows / columns beyond the other edges do not occur (H even, W % 8 == 0).
+        int tapoff = 0;
+        bool ky0 = false, kx0 = false;
+        if (S2 && p.t9) {
+            const int tap = t / cpt;
+            t -= tap * cpt;
+            const int ky = tap / 3, kx = tap - 3 * ky;
+            tapoff = ((ky - 1) * p.W + (kx - 1)) * 4;
+            ky0 = ky == 0;
+            kx0 = kx == 0;
+        }
+        pend_kx0 = kx0;
 #pragma unroll
         for (int j = 0; j < NW; ++j) {
             if (WTAIL && j == NW - 1) wr[j] = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(wres, wtail, 0, 0));
@@ -432,8 +486,11 @@ __global__ __launch_bounds__(kThreads, 2) void k_conv_bx(const BxP p) {
 #pragma unroll
                 for (int a = 0; a < 4; ++a) {
                     if (S2) {
-                        const v4f lo = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(xres, goff[j], a * hw4, 0));
-                        const v4f hi = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(xres, goff[j], a * hw4 + 16, 0));
+                        // input columns c .. c + 3 and c + 3 .. c + 6 (c = 2 ox + kx - 1): the four the quad needs are c, c + 2 | c + 4, c + 6
+                        // and nothing is read beyond the last one -- no load runs over the end of a row
+                        const int vo_ = (ky0 && s2top[j]) ? kBxOut : goff[j] + tapoff + ((kx0 && s2left[j]) ? 4 : 0);
+                        const v4f lo = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(xres, vo_, a * hw4, 0));
+                        const v4f hi = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(xres, vo_, a * hw4 + 12, 0));
                         xr[(j * 4 + a) * 8 + 0] = lo.x; xr[(j * 4 + a) * 8 + 1] = lo.y; xr[(j * 4 + a) * 8 + 2] = lo.z; xr[(j * 4 + a) * 8 + 3] = lo.w;
                         xr[(j * 4 + a) * 8 + 4] = hi.x; xr[(j * 4 + a) * 8 + 5] = hi.y; xr[(j * 4 + a) * 8 + 6] = hi.z; xr[(j * 4 + a) * 8 + 7] = hi.w;
                     } else {
@@ -463,10 +520,19 @@ __global__ __launch_bounds__(kThreads, 2) void k_conv_bx(const BxP p) {
             for (int j = 0; j < NT; ++j)
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {                       // pixel i of the quad: channels a = 0..3
-                    constexpr int E = S2 ? 8 : 4, ST = S2 ? 2 : 1;
+                    constexpr int E = S2 ? 8 : 4;
+                    // stride 2: of the eight loaded values (columns c .. c + 3, c + 3 .. c + 6) pixel i is column c + 2 i; a task on
+                    // the left edge under a kx = 0 tap loaded from column 0 = c + 1: pixel i is one place further left, pixel 0 is zero
+                    constexpr int np_[4] = {0, 2, 5, 7}, ep_[4] = {0, 1, 3, 6};
+                    const bool edge = S2 && pend_kx0 && s2left[j];
+                    auto el = [&](int a) {
+                        if (!S2) return xr[(j * 4 + a) * E + i];
+                        const float nv = xr[(j * 4 + a) * E + np_[i]], ev = i == 0 ? 0.0f : xr[(j * 4 + a) * E + ep_[i]];
+                        return edge ? ev : nv;
+                    };
                     unsigned h0, m0_, l0, h1, m1, l1;
-                    bx_split2(xr[(j * 4 + 0) * E + i * ST], xr[(j * 4 + 1) * E + i * ST], h0, m0_, l0);
-                    bx_split2(xr[(j * 4 + 2) * E + i * ST], xr[(j * 4 + 3) * E + i * ST], h1, m1, l1);
+                    bx_split2(el(0), el(1), h0, m0_, l0);
+                    bx_split2(el(2), el(3), h1, m1, l1);
                     unsigned char* dst = sB + loff[j] + i * 36 * 16;
                     *reinterpret_cast<v2u*>(dst) = (v2u){h0, h1};
                     *reinterpret_cast<v2u*>(dst + bTerm) = (v2u){m0_, m1};
@@ -946,11 +1012,18 @@ extern "C" int mas_conv_bx_supported(int ksize, int stride, int dil, int Cin, in
         if (stride == 2) return H % 2 == 0 && W % 8 == 0;        // output quads stay inside a row and start 16-byte aligned
         return 0;
     }
+    if (ksize == 3 && stride == 2)      // nine shifted 1x1 stride-2 products: whole chunks of 32 channels, output quads as the 1x1 stride-2 form
+        return dil == 1 && Cin % 32 == 0 && H % 2 == 0 && W % 8 == 0 && W >= 8;
     if (ksize == 3) return stride == 1 && (dil == 1 || dil == 2) && W >= 32;
     return 0;
 }
 
 extern "C" long long mas_conv_bx_packed_bytes(int ksize, int Cin, int Cout, int role) {
+    if (role == 2) {                    // the forward product of the 3x3 stride-2 convolution: 9 x (Cin / 32) chunks of the 1x1 form
+        if (ksize != 3 || Cin <= 0 || Cout <= 0 || Cin % 32 != 0) return 0;
+        const int BM = bx_bm(1, Cout);
+        return (long long)((Cout + BM - 1) / BM) * 9 * (Cin / 32) * 3 * 4 * BM * 16;
+    }
     if ((ksize != 1 && ksize != 3) || Cin <= 0 || Cout <= 0 || (role != 0 && role != 1)) return 0;
     const int M = role ? Cin : Cout, K = role ? Cout : Cin;
     const int BM = bx_bm(ksize, M), ck = ksize == 1 ? 32 : 8, ga = ksize == 1 ? 4 : kBxTaps3;
@@ -963,6 +1036,12 @@ bool bx_fill_job(BxPackJob* jb, const float* w, const float* row_scale, int Cout
     if (bytes <= 0 || !w || !wp || (uintptr_t)wp % 16 != 0) return false;
     jb->w = w; jb->row_scale = row_scale; jb->out = static_cast<unsigned*>(wp); jb->Cout = Cout; jb->Cin = Cin; jb->taps = ksize * ksize; jb->role = role;
     jb->BM = bx_bm(ksize, role ? Cin : Cout); jb->units = bytes / 16; jb->first_block = first_block;
+    jb->t9 = 0;
+    if (role == 2) {
+        jb->role = 0;
+        jb->t9 = 1;
+        jb->BM = bx_bm(1, Cout);
+    }
     return true;
 }
 }  // namespace
@@ -970,7 +1049,7 @@ bool bx_fill_job(BxPackJob* jb, const float* w, const float* row_scale, int Cout
 extern "C" int mas_conv_bx_pack(const float* w, const float* row_scale, int Cout, int Cin, int ksize, int role, void* wp, void* stream) {
     if (!w || !wp) return MAS_ERR_NULL;
     if ((uintptr_t)wp % 16 != 0) return MAS_ERR_ALIGN;
-    if (row_scale && role != 0) return MAS_ERR_RANGE;
+    if (row_scale && role == 1) return MAS_ERR_RANGE;
     BxPackJob jb;
     if (!bx_fill_job(&jb, w, row_scale, Cout, Cin, ksize, role, wp, 0)) return MAS_ERR_SHAPE;
     hipLaunchKernelGGL(k_bx_pack, dim3((unsigned)((jb.units + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream), jb);
@@ -1006,13 +1085,18 @@ extern "C" int mas_conv_bx_fwd(const float* x, const void* wp, int N, int Cin, i
     hipStream_t st = static_cast<hipStream_t>(stream);
     BxP p;
     p.x = x; p.wp = static_cast<const v4f*>(wp); p.scale = scale; p.shift = shift; p.res = residual; p.y = y;
-    p.x2 = nullptr; p.wp2 = nullptr; p.Cin2 = 0; p.ksplit = 1; p.part = nullptr; p.x3 = nullptr; p.stats = nullptr; p.stat_slots = 0;
+    p.x2 = nullptr; p.wp2 = nullptr; p.Cin2 = 0; p.ksplit = 1; p.part = nullptr; p.x3 = nullptr; p.stats = nullptr; p.stat_slots = 0; p.t9 = 0;
     p.Cin = Cin; p.H = H; p.W = W; p.Cout = Cout; p.dil = dil; p.relu = relu;
 #ifdef BX_STAMPS
     p.stamps = g_bx_stamps;
 #endif
     p.Ho = (H - 1) / stride + 1;
     p.Wo = (W - 1) / stride + 1;
+    if (ksize == 3 && stride == 2) {        // (wp: the image of role 2) the stride-2 1x1 kernel with nine taps
+        if ((uintptr_t)x % 16 != 0) return MAS_ERR_ALIGN;
+        p.t9 = 1;
+        return bx_bm(1, Cout) == 128 ? bx_launch_r<1, 128, 128, 2>(p, N, st) : bx_launch_r<1, 64, 256, 2>(p, N, st);
+    }
     const int BM = bx_bm(ksize, Cout);
     if (ksize == 1) {
         if (stride == 2) return BM == 128 ? bx_launch_r<1, 128, 128, 2>(p, N, st) : bx_launch_r<1, 64, 256, 2>(p, N, st);
@@ -1038,7 +1122,7 @@ extern "C" int mas_conv_bx_fwd_dual(const float* x1, const void* wp1, int Cin1, 
     hipStream_t st = static_cast<hipStream_t>(stream);
     BxP p;
     p.x = x1; p.wp = static_cast<const v4f*>(wp1); p.scale = nullptr; p.shift = shift; p.res = nullptr; p.y = y;
-    p.x2 = x2; p.wp2 = static_cast<const v4f*>(wp2); p.Cin2 = Cin2; p.ksplit = 1; p.part = nullptr; p.x3 = nullptr; p.stats = nullptr; p.stat_slots = 0;
+    p.x2 = x2; p.wp2 = static_cast<const v4f*>(wp2); p.Cin2 = Cin2; p.ksplit = 1; p.part = nullptr; p.x3 = nullptr; p.stats = nullptr; p.stat_slots = 0; p.t9 = 0;
     p.Cin = Cin1; p.H = H; p.W = W; p.Cout = Cout; p.dil = 1; p.relu = relu;
 #ifdef BX_STAMPS
     p.stamps = g_bx_stamps;
@@ -1102,7 +1186,7 @@ extern "C" int mas_conv_bx_train(const float* x, const void* wp, int N, int Cin,
     hipStream_t st = static_cast<hipStream_t>(stream);
     BxP p;
     p.x = x; p.wp = static_cast<const v4f*>(wp); p.scale = nullptr; p.shift = nullptr; p.res = residual; p.y = y;
-    p.x2 = nullptr; p.wp2 = nullptr; p.Cin2 = 0; p.ksplit = ksplit; p.part = static_cast<float*>(workspace); p.x3 = nullptr;
+    p.x2 = nullptr; p.wp2 = nullptr; p.Cin2 = 0; p.ksplit = ksplit; p.part = static_cast<float*>(workspace); p.x3 = nullptr; p.t9 = 0;
     const int stat_slots = stats ? mas_conv_bx_train_stat_slots(N, H, W, Cout, ksize, dil, ksplit, tile_w) : 0;
     if (stats && stat_slots <= 0) return MAS_ERR_RANGE;
     p.stats = ksplit == 1 ? reinterpret_cast<double2*>(stats) : nullptr;       // (split K: formed by the reduction pass below)
@@ -1159,7 +1243,7 @@ extern "C" int mas_conv_bx_fwd_pre(const void* x3, const void* wp, int N, int Ci
     hipStream_t st = static_cast<hipStream_t>(stream);
     BxP p;
     p.x = nullptr; p.x3 = static_cast<const v4f*>(x3); p.wp = static_cast<const v4f*>(wp); p.scale = scale; p.shift = shift; p.res = residual; p.y = y;
-    p.x2 = nullptr; p.wp2 = nullptr; p.Cin2 = 0; p.ksplit = 1; p.part = nullptr; p.stats = nullptr; p.stat_slots = 0;
+    p.x2 = nullptr; p.wp2 = nullptr; p.Cin2 = 0; p.ksplit = 1; p.part = nullptr; p.stats = nullptr; p.stat_slots = 0; p.t9 = 0;
     p.Cin = Cin; p.H = H; p.W = W; p.Cout = Cout; p.dil = dil; p.relu = relu;
 #ifdef BX_STAMPS
     p.stamps = g_bx_stamps;

@@ -1168,12 +1168,18 @@ def conv_mfma(conv, x, bn=None, relu=False, residual=None):
 # ------------------------------------------------------------------------------------------------
 # the same convolutions on the bf16 matrix cores, f32 in / f32 out through exact three-term operand splits (csrc/conv_bx.hip)
 # ------------------------------------------------------------------------------------------------
+BX_ROLE_S2 = 2          # mas_conv_bx_pack role: the forward image of a 3x3 stride-2 convolution (nine shifted 1x1 stride-2 products)
+
+
 def conv_bx_supported(conv, x):
     """Shapes mas_conv_bx_fwd takes: 1x1 at stride 1 (any plane) / 2 (H even, W % 8 == 0), 3x3 stride 1 with dilation 1 / 2
-    (padding = dilation) on planes at least 32 wide; any channel counts; no groups, no bias."""
+    (padding = dilation) on planes at least 32 wide, 3x3 stride 2 (H even, W % 8 == 0, input channels a multiple of 32); any other
+    channel counts; no groups, no bias."""
     if not (x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and conv.groups == 1 and conv.bias is None):
         return False
     if conv.stride[0] == 2 and x.data_ptr() % 16:
+        return False
+    if conv.stride[0] == 2 and conv.kernel_size[0] == 3 and os.environ.get("MAS_BX_S2K3", "on") == "off":      # (A/B: the f32 pipe)
         return False
     k, s, d, pd = conv.kernel_size, conv.stride, conv.dilation, conv.padding
     if k[0] != k[1] or s[0] != s[1] or d[0] != d[1] or pd[0] != pd[1] or pd[0] != (d[0] if k[0] == 3 else 0) or x.shape[1] != conv.in_channels:
@@ -1191,12 +1197,13 @@ def _conv_bx_weight(conv):
         lib = _lib.load()
         w = conv.weight.detach().contiguous()
         M, K, kh, _ = w.shape
-        nbytes = lib.mas_conv_bx_packed_bytes(kh, K, M, 0)
+        role = BX_ROLE_S2 if (kh == 3 and conv.stride[0] == 2) else 0        # (the strided 3x3: tap-major chunks of the 1x1 form)
+        nbytes = lib.mas_conv_bx_packed_bytes(kh, K, M, role)
         if nbytes <= 0:
             raise ValueError("mas_conv_bx_pack does not take a %dx%d convolution with %d input channels" % (kh, kh, K))
         wp = torch.empty(nbytes, dtype=torch.uint8, device=w.device)
         with torch.cuda.device(w.device):
-            _lib.check(lib.mas_conv_bx_pack(w.data_ptr(), None, M, K, kh, 0, wp.data_ptr(), _stream(w)), "mas_conv_bx_pack")
+            _lib.check(lib.mas_conv_bx_pack(w.data_ptr(), None, M, K, kh, role, wp.data_ptr(), _stream(w)), "mas_conv_bx_pack")
         cache = conv._mas_conv_bx_pack = (key, wp)
     return cache[1]
 
@@ -1605,18 +1612,19 @@ def conv_bx_train_plan(x_shape, w_shape, dil=1, dgrad=False):
 
 
 def conv_bx_s2_raw(x, w, packed=None):
-    """y = conv2d(x, w, stride 2) for a 1x1 weight on the stride-2 form of csrc/conv_bx.hip (bare product of a training step)."""
+    """y = conv2d(x, w, stride 2[, padding 1]) for a 1x1 or 3x3 weight on the stride-2 form of csrc/conv_bx.hip (bare product of a
+    training step).  packed: the image of role 0 (1x1) / BX_ROLE_S2 (3x3)."""
     _need(x, "x", torch.float32)
     _need(w, "w", torch.float32)
     Cout, Cin, ks, _ = w.shape
     N, Cx, H, W = x.shape
-    if ks != 1 or Cx != Cin:
-        raise ValueError("conv_bx_s2_raw: a 1x1 weight on its input channels")
+    if ks not in (1, 3) or Cx != Cin:
+        raise ValueError("conv_bx_s2_raw: a 1x1 or 3x3 weight on its input channels")
     y = torch.empty((N, Cout, (H - 1) // 2 + 1, (W - 1) // 2 + 1), dtype=torch.float32, device=x.device)
     if packed is None:
-        packed = conv_bx_pack(w, 0)
+        packed = conv_bx_pack(w, 0 if ks == 1 else BX_ROLE_S2)
     with torch.cuda.device(x.device):
-        _lib.check(_lib.load().mas_conv_bx_fwd(x.data_ptr(), packed.data_ptr(), N, Cin, H, W, Cout, 1, 2, 1, None, None, None, 0, y.data_ptr(),
+        _lib.check(_lib.load().mas_conv_bx_fwd(x.data_ptr(), packed.data_ptr(), N, Cin, H, W, Cout, ks, 2, 1, None, None, None, 0, y.data_ptr(),
                                                _stream(x)), "mas_conv_bx_fwd")
     return y
 
@@ -1673,10 +1681,17 @@ def conv_bx_train_ok(x_shape, w_shape, stride, dil, dgrad):
     mode = os.environ.get("MAS_TRAIN_BX", "auto")
     Cout, Cin, ks, _ = w_shape
     N, _, H, W = x_shape
-    if mode not in ("off", "r04") and stride == 2 and ks == 1 and not dgrad:
-        # the 1x1 stride-2 `downsample` convolutions (resnet.py:215-223): the stride-2 form of the forward kernel (planes with even
-        # H and W % 8 == 0 -- the 768 crop; the 769 crop's odd planes stay on the stream-K kernel)
-        return bool(_lib.load().mas_conv_bx_supported(1, 2, 1, Cin, Cout, H, W)) and x_shape[0] > 0
+    if mode not in ("off", "r04") and stride == 2 and not dgrad and (ks == 1 or (ks == 3 and dil == 1 and os.environ.get("MAS_BX_S2K3", "on") != "off")):
+        # the 1x1 stride-2 `downsample` convolutions (resnet.py:215-223) and the 3x3 stride-2 conv2 of layer2.0 / layer3.0 (:140-150):
+        # the stride-2 form of the forward kernel (planes with even H and W % 8 == 0 -- the 768 crop; the 769 crop's odd planes stay
+        # on the stream-K kernel)
+        if not (_lib.load().mas_conv_bx_supported(ks, 2, 1, Cin, Cout, H, W) and x_shape[0] > 0):
+            return False
+        # (the strided 3x3 has no work splitting: below 256 workgroups -- layer3.0.conv2 on the 48 x 48 planes of the training crop,
+        #  144 of them with 72 chunks each -- the persistent stream-K kernel is faster: 114 against 142 us, tools/s2k3_probe.py)
+        bm = 128 if Cout % 128 == 0 else 64
+        wgs = (N * (H // 2) * (W // 2) + (32768 // bm) - 1) // (32768 // bm) * ((Cout + bm - 1) // bm)
+        return ks == 1 or wgs >= 256
     if mode == "off" or stride != 1:
         return False
     K, M = (Cout, Cin) if dgrad else (Cin, Cout)
@@ -1904,7 +1919,7 @@ class _ConvTrain(torch.autograd.Function):
             if own[0] and conv_bx_train_ok(x.shape, w.shape, stride, dil, False):
                 # split-bf16 kernel (csrc/conv_bx.hip); the BatchNorm partial sums then come from the separate reduction pass
                 if stride == 2:
-                    y = conv_bx_s2_raw(x, w, packed=bx_packed_weight(w, 0))
+                    y = conv_bx_s2_raw(x, w, packed=bx_packed_weight(w, 0 if w.shape[2] == 1 else BX_ROLE_S2))
                 elif stats:
                     # (the BatchNorm partial sums from the kernel's epilogue / the split-K reduction pass)
                     y, part = conv_bx_raw(x, w, dil, packed=bx_packed_weight(w, 0), stats=True)

@@ -36,6 +36,11 @@ CASES = [
     (64, 64, 3, 1, 1, 1, 49, 49),        # 3x3 on a 49-wide plane: the second tile column is half padding
     (64, 1024, 1, 1, 1, 4, 64, 128),     # many tiles: 2 048 workgroups, four rounds
     (48, 1024, 1, 1, 1, 4, 60, 130),     # Cin = 1.5 chunks, partial pixel tile, many M tiles
+    (128, 128, 3, 2, 1, 2, 24, 40),      # layer2.0.conv2: 3x3 stride 2 as nine shifted 1x1 stride-2 products (36 chunks), partial pixel tile
+    (256, 256, 3, 2, 1, 1, 18, 64),      # layer3.0.conv2
+    (64, 200, 3, 2, 1, 1, 10, 16),       # 64-row M tile (256 output pixels per tile), Cout 200, every output row starts a quad
+    (32, 64, 3, 2, 1, 3, 6, 8),          # one chunk per tap, 3 x 4 outputs: every quad touches the top or the left edge
+    (128, 128, 3, 2, 1, 4, 64, 128),     # many tiles
 ]
 
 
@@ -87,7 +92,8 @@ def test_conv_bx_exact_on_integers():
         pytest.skip("needs a GPU")
     from mulactseg_amd import ops
     g = torch.Generator(device='cuda').manual_seed(3)
-    for k, stride, dil, cout in ((1, 1, 1, 128), (1, 1, 1, 64), (3, 1, 1, 128), (3, 1, 2, 64), (1, 2, 1, 128), (1, 2, 1, 64), (1, 1, 1, 1024)):
+    for k, stride, dil, cout in ((1, 1, 1, 128), (1, 1, 1, 64), (3, 1, 1, 128), (3, 1, 2, 64), (1, 2, 1, 128), (1, 2, 1, 64), (1, 1, 1, 1024),
+                                 (3, 2, 1, 128), (3, 2, 1, 64)):
         conv = nn.Conv2d(64, cout, k, stride=stride, padding=dil if k == 3 else 0, dilation=dil, bias=False).cuda()
         with torch.no_grad():
             conv.weight.copy_(torch.randint(-3, 4, conv.weight.shape, generator=g, device='cuda').float())
