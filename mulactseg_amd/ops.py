@@ -1690,7 +1690,7 @@ def conv_bx_train_ok(x_shape, w_shape, stride, dil, dgrad):
         # (the strided 3x3 has no work splitting: below 256 workgroups -- layer3.0.conv2 on the 48 x 48 planes of the training crop,
         #  144 of them with 72 chunks each -- the persistent stream-K kernel is faster: 114 against 142 us, tools/s2k3_probe.py)
         bm = 128 if Cout % 128 == 0 else 64
-        wgs = (N * (H // 2) * (W // 2) + (32768 // bm) - 1) // (32768 // bm) * ((Cout + bm - 1) // bm)
+        wgs = (N * (H // 2) * (W // 2) + (16384 // bm) - 1) // (16384 // bm) * ((Cout + bm - 1) // bm)      # (pixel tile: 128 / 256)
         return ks == 1 or wgs >= 256
     if mode == "off" or stride != 1:
         return False

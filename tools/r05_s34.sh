@@ -1,0 +1,9 @@
+set -u; cd /tmp && export TMPDIR=/tmp && cd "${GRAFT_REPO_ROOT:?}"; O=gpurun_out/s34; mkdir -p $O
+V=$PWD/mulactseg_amd/libvar_p2.so
+MAS_LIB=$V timeout -k 10 900 python -m pytest tests/test_conv_bx_gpu.py -q -m gpu -x > $O/pytest_p2.log 2>&1; echo "pytest p2 rc $?"; grep -E "FAILED|passed|failed|Error" $O/pytest_p2.log | head -20
+timeout -k 10 900 python -m pytest tests/test_conv_bx_gpu.py tests/test_conv_train_gpu.py -q -m gpu -x > $O/pytest_base.log 2>&1; echo "pytest base rc $?"; grep -E "FAILED|passed|failed|Error" $O/pytest_base.log | head -20
+for rep in 1 2; do for L in libmulactseg_hip.so libvar_asm.so libvar_p2.so; do
+  MAS_LIB=$PWD/mulactseg_amd/$L timeout -k 10 300 python tools/bx_table.py --out $O/bx_table_${L%.so}_$rep.md 2>/dev/null | tail -2 | sed "s/^/$L: /"
+  MAS_LIB=$PWD/mulactseg_amd/$L timeout -k 10 300 python tools/bx_train_table.py --out $O/bx_train_${L%.so}_$rep.md 2>/dev/null | tail -2 | sed "s/^/$L: /"
+  echo "$L train:"; MAS_LIB=$PWD/mulactseg_amd/$L timeout -k 10 200 python tools/train_step_probe.py --modes own --streams main --steps 10 --crop 768 2>&1 | grep -E "^own" | tail -1
+done; done > $O/ab.log 2>&1; cat $O/ab.log
