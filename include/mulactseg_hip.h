@@ -51,8 +51,9 @@ extern "C" {
  * (mulactseg_amd/_lib.py:load does).  History: 1 = rounds 1-4 (the round-4 additions -- mas_sk_opts, the split-bf16 entry points --
  * should have bumped it and did not); 5 = round 5 (mas_single_pass_accum_lowres_opt replaces the process-wide
  * mas_single_pass_lowres_generic switch; mas_test_occupy moved to the test-support library; the BatchNorm-fused forms of
- * mas_conv_bx_fwd). */
-#define MAS_ABI_VERSION 5
+ * mas_conv_bx_fwd); 6 = role 2 of mas_conv_bx_pack / _packed_bytes / _pack_job and ksize 3 at stride 2 in mas_conv_bx_supported /
+ * mas_conv_bx_fwd (a library of version 5 answers "unsupported" to both). */
+#define MAS_ABI_VERSION 6
 int mas_abi_version(void);
 const char* mas_error_string(int code);
 
@@ -460,7 +461,10 @@ int mas_conv_fwd(const float* x, const float* wt, int N, int Cin, int H, int W, 
  * product is accumulated in f32 from its six partial products of order <= 2 (v_mfma_f32_32x32x16_bf16); the dropped terms are
  * below 2^-23 of the product, i.e. one f32 rounding -- same error bound as the f32 MFMA form, exact on integer data, 2.67x its
  * matrix peak.  Supported (mas_conv_bx_supported != 0): ksize 1 at stride 1 (any plane) or stride 2 (H even, W % 8 == 0, x 16-byte
- * aligned); ksize 3 with stride 1, dil 1 | 2 (padding = dil), W >= 32; any Cin (a last partial chunk is zero-padded), any Cout.
+ * aligned); ksize 3 with stride 1, dil 1 | 2 (padding = dil), W >= 32; ksize 3 with stride 2, dil 1 (padding 1: conv2 of
+ * layer2.0 / layer3.0, resnet.py:140-150), Cin % 32 == 0, H even, W % 8 == 0, x 16-byte aligned -- computed as nine shifted 1x1
+ * stride-2 products into one accumulator set, `wp` = the image of role 2; any Cin otherwise (a last partial chunk is
+ * zero-padded), any Cout.
  * `wp` is the weight [Cout][Cin][ksize][ksize] split and laid out ONCE (per checkpoint load) by mas_conv_bx_pack into
  * mas_conv_bx_packed_bytes(ksize, Cin, Cout) bytes of caller-owned, 16-byte aligned device memory: the sequence of LDS images
  * [M tile][chunk][term h|m|l][k group][BM rows][8 bf16] (1x1: chunk = 32 channels, k = channel; 3x3: chunk = 8 channels,
@@ -468,7 +472,9 @@ int mas_conv_fwd(const float* x, const float* wt, int N, int Cin, int H, int W, 
 int mas_conv_bx_supported(int ksize, int stride, int dil, int Cin, int Cout, int H, int W);
 long long mas_conv_bx_packed_bytes(int ksize, int Cin, int Cout, int role);
 int mas_conv_bx_pack(const float* w, const float* row_scale, int Cout, int Cin, int ksize, int role, void* wp, void* stream);
-/* role 0: the image of the forward product.  role 1: the image with which mas_conv_bx_fwd computes the INPUT GRADIENT of the
+/* role 0: the image of the forward product.  role 2 (ksize 3, Cin % 32 == 0): the forward image of the STRIDE-2 3x3 convolution --
+ * 9 x (Cin / 32) chunks of the 1x1 form in tap-major order [M tile][tap * (Cin / 32) + channel chunk][term][k group][BM][8]
+ * (BM as for ksize 1; `row_scale` allowed).  role 1: the image with which mas_conv_bx_fwd computes the INPUT GRADIENT of the
  * stride-1 convolution (the backward of the nn.Conv2d calls above inside trainer/active_joint_multi_predignore_lossdecomp.py:83-116):
  * channel axes swapped, taps mirrored -- call mas_conv_bx_fwd(dY, wp1, N, Cout, H, W, Cin, ksize, 1, dil, NULL, NULL, residual, 0, dX):
  * `residual` adds the gradient of x's other consumer.  In training the weights move every optimizer step: all images of a model

@@ -19,7 +19,7 @@ GRAD_FRAC = 44
 
 SK_DMA, SK_NOSPLIT = 1, 2
 LOWRES_GENERIC = 1
-ABI_VERSION = 5        # MAS_ABI_VERSION of include/mulactseg_hip.h this table was written against (load() refuses any other library)
+ABI_VERSION = 6        # MAS_ABI_VERSION of include/mulactseg_hip.h this table was written against (load() refuses any other library)
 
 _c = ctypes
 _vp, _i, _f, _i64, _d = _c.c_void_p, _c.c_int, _c.c_float, _c.c_int64, _c.c_double

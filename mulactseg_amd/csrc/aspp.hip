@@ -53,6 +53,113 @@ __global__ __launch_bounds__(kThreads) void k_dw3_fwd(const float* __restrict__ 
     }
 }
 
+// The same sums from a ZERO-PADDED plane in LDS (dilations D, 2D, 3D with D even -- ASPP's (6, 12, 18) / (12, 24, 36)): no bounds test
+// per tap, a thread owns four consecutive pixels of a row and reads every tap as two 8-byte LDS reads at compile-time offsets (the
+// column shift (b - 1) d is even, the row pitch and both pads are multiples of four floats), 16-byte global loads and stores.
+// k_dw3_fwd<true> spends its time in the 27 x (four compares, a select, an address) per pixel: 463 us per pool batch at 2.3 TB/s;
+// this form is at the bytes.  Per accumulator the same products in the same order (a padded tap adds k * 0): the same bits.
+// BWD: the input gradient -- the three planes are the three gradients, the taps are mirrored, one output plane.
+constexpr int kDwPadC(int d) { return (d + 3) / 4 * 4; }                                        // column pad: d rounded up to four floats
+// geometry of padded plane j of the backward form (its own dilation (j + 1) D only) / of the one plane of the forward form (3 D)
+struct DwPad { int pr, pc, pw, pp, base; };
+__device__ __host__ inline DwPad dw_pad_of(int H, int W, int d, int base) {
+    DwPad g;
+    g.pr = d; g.pc = kDwPadC(d); g.pw = W + 2 * g.pc; g.pp = (H + 2 * d) * g.pw; g.base = base;
+    return g;
+}
+template <int D, bool BWD>
+__global__ __launch_bounds__(kThreads) void k_dw3_pad(const float* __restrict__ x0, const float* __restrict__ x1, const float* __restrict__ x2,
+                                                       const float* __restrict__ w0, const float* __restrict__ w1, const float* __restrict__ w2,
+                                                       int C, int H, int W, float* __restrict__ y0, float* __restrict__ y1, float* __restrict__ y2) {
+    extern __shared__ __attribute__((aligned(16))) float s_pad[];
+    constexpr int NPL = BWD ? 3 : 1;
+    DwPad g[3];
+    g[0] = dw_pad_of(H, W, BWD ? D : 3 * D, 0);
+    g[1] = dw_pad_of(H, W, 2 * D, g[0].pp);
+    g[2] = dw_pad_of(H, W, 3 * D, g[0].pp + g[1].pp);
+    const int total = BWD ? g[2].base + g[2].pp : g[0].pp;              // (every plane a multiple of four floats: W % 4 == 0)
+    const size_t plane = (size_t)blockIdx.x * H * W;
+    const int c = blockIdx.x % C;
+    const float* src[3] = {x0 + plane, BWD ? x1 + plane : nullptr, BWD ? x2 + plane : nullptr};
+    float4* s4 = reinterpret_cast<float4*>(s_pad);
+    for (int i = threadIdx.x; i < total / 4; i += kThreads) s4[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    __syncthreads();
+    const int qrow = W / 4, quads = H * qrow;
+#pragma unroll
+    for (int pl = 0; pl < NPL; ++pl)
+        for (int q = threadIdx.x; q < quads; q += kThreads) {
+            const int py = q / qrow, px = (q - py * qrow) * 4;
+            *reinterpret_cast<float4*>(s_pad + g[pl].base + (py + g[pl].pr) * g[pl].pw + g[pl].pc + px) = *reinterpret_cast<const float4*>(src[pl] + py * W + px);
+        }
+    __syncthreads();
+    float k[3][9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) { k[0][t] = w0[c * 9 + t]; k[1][t] = w1[c * 9 + t]; k[2][t] = w2[c * 9 + t]; }
+    typedef float f2 __attribute__((ext_vector_type(2)));
+    for (int q = threadIdx.x; q < quads; q += kThreads) {
+        const int py = q / qrow, px = (q - py * qrow) * 4;
+        const float* ctr[3];                                            // 16-byte aligned
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            const DwPad& gg = g[BWD ? j : 0];
+            ctr[j] = s_pad + gg.base + (py + gg.pr) * gg.pw + gg.pc + px;
+        }
+        float4 acc[3];
+#pragma unroll
+        for (int j = 0; j < 3; ++j) acc[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int a = 0; a < 3; ++a)
+#pragma unroll
+            for (int b = 0; b < 3; ++b)
+#pragma unroll
+                for (int j = 0; j < 3; ++j) {
+                    const int d = (j + 1) * D, pw = g[BWD ? j : 0].pw;
+                    const int off = BWD ? -((a - 1) * d) * pw - (b - 1) * d : ((a - 1) * d) * pw + (b - 1) * d;     // (even: 8-byte aligned)
+                    const float* tp = ctr[j] + off;
+                    const f2 lo = *reinterpret_cast<const f2*>(tp), hi = *reinterpret_cast<const f2*>(tp + 2);
+                    float4& A = acc[BWD ? 0 : j];
+                    const float kk = k[j][a * 3 + b];
+                    A.x = mas_fmaf(kk, lo.x, A.x); A.y = mas_fmaf(kk, lo.y, A.y); A.z = mas_fmaf(kk, hi.x, A.z); A.w = mas_fmaf(kk, hi.y, A.w);
+                }
+        const size_t o = plane + (size_t)py * W + px;
+        *reinterpret_cast<float4*>(y0 + o) = acc[0];
+        if (!BWD) {
+            *reinterpret_cast<float4*>(y1 + o) = acc[1];
+            *reinterpret_cast<float4*>(y2 + o) = acc[2];
+        }
+    }
+}
+
+// does the padded form take this launch?  D = d0 even, (d1, d2) = (2 d0, 3 d0), rows of whole 16-byte groups, LDS for the padded plane(s)
+inline size_t dw3_pad_bytes(int H, int W, int D, bool bwd) {
+    if (!bwd) return sizeof(float) * (size_t)dw_pad_of(H, W, 3 * D, 0).pp;
+    return sizeof(float) * ((size_t)dw_pad_of(H, W, D, 0).pp + dw_pad_of(H, W, 2 * D, 0).pp + dw_pad_of(H, W, 3 * D, 0).pp);
+}
+inline bool dw3_pad_ok(const void* const* ptrs, int nptr, int H, int W, int d0, int d1, int d2, bool bwd) {
+    if ((d0 != 6 && d0 != 12) || d1 != 2 * d0 || d2 != 3 * d0 || W % 4 != 0) return false;
+    for (int i = 0; i < nptr; ++i)
+        if ((uintptr_t)ptrs[i] % 16 != 0) return false;
+    return dw3_pad_bytes(H, W, d0, bwd) <= 80 * 1024;
+}
+template <int D, bool BWD>
+int dw3_pad_launch(const float* x0, const float* x1, const float* x2, const float* w0, const float* w1, const float* w2, int N, int C, int H, int W,
+                   float* y0, float* y1, float* y2, hipStream_t st) {
+    const size_t smem = dw3_pad_bytes(H, W, D, BWD);
+    if (smem > 64 * 1024) {
+        static bool raised[64] = {};
+        int dev = 0;
+        hipError_t e = hipGetDevice(&dev);
+        if (e != hipSuccess) return (int)e;
+        if (dev < 0 || dev >= 64 || !raised[dev]) {
+            e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_dw3_pad<D, BWD>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+            if (e != hipSuccess) return (int)e;
+            if (dev >= 0 && dev < 64) raised[dev] = true;
+        }
+    }
+    hipLaunchKernelGGL((k_dw3_pad<D, BWD>), dim3((unsigned)(N * C)), dim3(kThreads), smem, st, x0, x1, x2, w0, w1, w2, C, H, W, y0, y1, y2);
+    return mas_launch_status();
+}
+
 template <bool USE_LDS>
 __global__ __launch_bounds__(kThreads) void k_dw3_bwd_x(const float* __restrict__ g0, const float* __restrict__ g1, const float* __restrict__ g2,
                                                          const float* __restrict__ w0, const float* __restrict__ w1, const float* __restrict__ w2,
@@ -302,6 +409,12 @@ extern "C" int mas_aspp_dw3_fwd(const float* x, const float* w0, const float* w1
     if (int e = check(N, C, H, W, d0, d1, d2)) return e;
     const size_t smem = sizeof(float) * (size_t)H * W;
     hipStream_t st = static_cast<hipStream_t>(stream);
+    {
+        const void* ptrs[4] = {x, y0, y1, y2};
+        if (dw3_pad_ok(ptrs, 4, H, W, d0, d1, d2, false))
+            return d0 == 6 ? dw3_pad_launch<6, false>(x, nullptr, nullptr, w0, w1, w2, N, C, H, W, y0, y1, y2, st)
+                           : dw3_pad_launch<12, false>(x, nullptr, nullptr, w0, w1, w2, N, C, H, W, y0, y1, y2, st);
+    }
     if (smem <= 64 * 1024)
         hipLaunchKernelGGL((k_dw3_fwd<true>), dim3((unsigned)(N * C)), dim3(kThreads), smem, st, x, w0, w1, w2, C, H, W, d0, d1, d2, y0, y1, y2);
     else
@@ -315,6 +428,12 @@ extern "C" int mas_aspp_dw3_bwd_x(const float* g0, const float* g1, const float*
     if (int e = check(N, C, H, W, d0, d1, d2)) return e;
     const size_t smem = sizeof(float) * 3 * (size_t)H * W;
     hipStream_t st = static_cast<hipStream_t>(stream);
+    {
+        const void* ptrs[4] = {g0, g1, g2, dx};
+        if (dw3_pad_ok(ptrs, 4, H, W, d0, d1, d2, true))
+            return d0 == 6 ? dw3_pad_launch<6, true>(g0, g1, g2, w0, w1, w2, N, C, H, W, dx, nullptr, nullptr, st)
+                           : dw3_pad_launch<12, true>(g0, g1, g2, w0, w1, w2, N, C, H, W, dx, nullptr, nullptr, st);
+    }
     if (smem <= 128 * 1024)
         hipLaunchKernelGGL((k_dw3_bwd_x<true>), dim3((unsigned)(N * C)), dim3(kThreads), smem, st, g0, g1, g2, w0, w1, w2, C, H, W, d0, d1, d2, dx);
     else
