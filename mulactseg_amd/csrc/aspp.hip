@@ -10,6 +10,8 @@
 //   k_dw3_fwd     y_d[n,c] = sum_{a,b} w_d[c,a,b] * x[n,c, i+(a-1)d, j+(b-1)d]      (zero padding)
 //   k_dw3_bwd_x   dx[n,c]  = sum_d sum_{a,b} w_d[c,a,b] * dy_d[n,c, i-(a-1)d, j-(b-1)d]
 //   k_dw3_bwd_w   dw_d[c,a,b] = sum_{n,i,j} dy_d[n,c,i,j] * x[n,c, i+(a-1)d, j+(b-1)d]   (fixed-order tree: deterministic)
+#include <cstdlib>
+
 #include "common.h"
 
 namespace {
@@ -127,6 +129,68 @@ __global__ __launch_bounds__(kThreads) void k_dw3_pad(const float* __restrict__ 
             *reinterpret_cast<float4*>(y1 + o) = acc[1];
             *reinterpret_cast<float4*>(y2 + o) = acc[2];
         }
+    }
+}
+
+// The weight gradients of the triple from the same padded plane: one workgroup per channel, the images in turn; a thread owns pixel
+// quads, loads its quad of the three gradients (16 bytes each) and adds g_d x (x at tap (a, b) of dilation d) into 27 sums -- two
+// 8-byte LDS reads and four fmas per tap instead of four bounds-tested scalar taps through L1.  The reduction tree of k_dw3_bwd_w.
+template <int D>
+__global__ __launch_bounds__(kThreads) void k_dw3_bwd_w_pad(const float* __restrict__ x, const float* __restrict__ g0, const float* __restrict__ g1,
+                                                             const float* __restrict__ g2, int N, int C, int H, int W, float* __restrict__ dw0,
+                                                             float* __restrict__ dw1, float* __restrict__ dw2) {
+    extern __shared__ __attribute__((aligned(16))) float s_pad[];
+    __shared__ float s_red[kThreads / MAS_WAVE][27];
+    const DwPad gm = dw_pad_of(H, W, 3 * D, 0);
+    const int c = blockIdx.x;
+    float acc[27];
+#pragma unroll
+    for (int t = 0; t < 27; ++t) acc[t] = 0.f;
+    float4* s4 = reinterpret_cast<float4*>(s_pad);
+    for (int i = threadIdx.x; i < gm.pp / 4; i += kThreads) s4[i] = make_float4(0.f, 0.f, 0.f, 0.f);       // (the halo stays zero)
+    const int qrow = W / 4, quads = H * qrow;
+    typedef float f2 __attribute__((ext_vector_type(2)));
+    for (int n = 0; n < N; ++n) {
+        const size_t plane = ((size_t)n * C + c) * H * W;
+        __syncthreads();                                    // (the previous image's taps are read / the zero fill is done)
+        for (int q = threadIdx.x; q < quads; q += kThreads) {
+            const int py = q / qrow, px = (q - py * qrow) * 4;
+            *reinterpret_cast<float4*>(s_pad + (py + gm.pr) * gm.pw + gm.pc + px) = *reinterpret_cast<const float4*>(x + plane + py * W + px);
+        }
+        __syncthreads();
+        for (int q = threadIdx.x; q < quads; q += kThreads) {
+            const int py = q / qrow, px = (q - py * qrow) * 4;
+            const float* ctr = s_pad + (py + gm.pr) * gm.pw + gm.pc + px;
+            const size_t o = plane + (size_t)py * W + px;
+            const float4 v[3] = {*reinterpret_cast<const float4*>(g0 + o), *reinterpret_cast<const float4*>(g1 + o), *reinterpret_cast<const float4*>(g2 + o)};
+#pragma unroll
+            for (int a = 0; a < 3; ++a)
+#pragma unroll
+                for (int b = 0; b < 3; ++b)
+#pragma unroll
+                    for (int j = 0; j < 3; ++j) {
+                        const int d = (j + 1) * D;
+                        const float* tp = ctr + ((a - 1) * d) * gm.pw + (b - 1) * d;
+                        const f2 lo = *reinterpret_cast<const f2*>(tp), hi = *reinterpret_cast<const f2*>(tp + 2);
+                        float s_ = acc[9 * j + a * 3 + b];
+                        s_ = mas_fmaf(v[j].x, lo.x, s_); s_ = mas_fmaf(v[j].y, lo.y, s_); s_ = mas_fmaf(v[j].z, hi.x, s_); s_ = mas_fmaf(v[j].w, hi.y, s_);
+                        acc[9 * j + a * 3 + b] = s_;
+                    }
+        }
+    }
+    const int lane = threadIdx.x & (MAS_WAVE - 1), wave = threadIdx.x / MAS_WAVE;
+#pragma unroll
+    for (int t = 0; t < 27; ++t) {
+        float v = acc[t];
+#pragma unroll
+        for (int off = MAS_WAVE / 2; off > 0; off >>= 1) v += __shfl_down(v, off, MAS_WAVE);
+        if (lane == 0) s_red[wave][t] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x < 27) {
+        float v = ((s_red[0][threadIdx.x] + s_red[1][threadIdx.x]) + s_red[2][threadIdx.x]) + s_red[3][threadIdx.x];
+        float* dst = threadIdx.x < 9 ? dw0 : (threadIdx.x < 18 ? dw1 : dw2);
+        dst[c * 9 + (threadIdx.x % 9)] = v;
     }
 }
 
@@ -388,6 +452,82 @@ __global__ __launch_bounds__(kThreads) void k_dw_bwd_w(const float* __restrict__
             ((s_red[0][threadIdx.x] + s_red[1][threadIdx.x]) + s_red[2][threadIdx.x]) + s_red[3][threadIdx.x];
 }
 
+// The undilated form (the decoder's two separable convolutions) the way k_dw_rows walks a plane: a thread owns four consecutive
+// columns and a run of rows, keeps three input rows (columns x0 - 1 .. x0 + 4) in registers and adds g[row] x (shifted x rows) into
+// its nine sums -- per row two 16-byte loads and two scalars instead of 36 bounds-tested taps through L1 (k_dw_bwd_w: 325 us per
+// training step at 2 TB/s).  One workgroup per (n, c) plane as before; the column groups of a row sit in consecutive lanes, the
+// plane's rows are dealt to the 256 / ceil(W / 4) row groups in contiguous runs.  Same reduction tree over the threads.
+template <bool ALIGNED>
+__global__ __launch_bounds__(kThreads) void k_dw_bwd_w_rows(const float* __restrict__ x, const float* __restrict__ g, int C, int H, int W,
+                                                             float* __restrict__ part) {
+    __shared__ float s_red[kThreads / MAS_WAVE][9];
+    const size_t plane = (size_t)blockIdx.x * H * W;           // blockIdx.x = n*C + c
+    const float* xp = x + plane;
+    const float* gp = g + plane;
+    const int qw = (W + 3) / 4, groups = kThreads / qw;         // (qw <= 256: checked by the host)
+    const int rg = threadIdx.x / qw, x0 = (threadIdx.x - rg * qw) * 4;
+    const int per = (H + groups - 1) / groups;
+    const int ys = rg * per, ye = (ys + per) < H ? (ys + per) : H;
+    float acc[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) acc[t] = 0.f;
+    if (rg < groups && ys < H) {
+        float r[3][6];
+        auto load4 = [&](const float* p, float (&dst)[4]) {
+            if (ALIGNED) {
+                const float4 v = *reinterpret_cast<const float4*>(p);
+                dst[0] = v.x; dst[1] = v.y; dst[2] = v.z; dst[3] = v.w;
+            } else if (x0 + 4 <= W) {
+                const dw_v4u v = *reinterpret_cast<const dw_v4u*>(p);
+                dst[0] = v[0]; dst[1] = v[1]; dst[2] = v[2]; dst[3] = v[3];
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) dst[j] = x0 + j < W ? p[j] : 0.0f;
+            }
+        };
+        auto load_row = [&](int gy, float (&dst)[6]) {
+            if (gy >= 0 && gy < H) {
+                const float* p = xp + (size_t)gy * W + x0;
+                float m[4];
+                load4(p, m);
+                dst[0] = x0 > 0 ? p[-1] : 0.0f;
+                dst[1] = m[0]; dst[2] = m[1]; dst[3] = m[2]; dst[4] = m[3];
+                dst[5] = x0 + 4 < W ? p[4] : 0.0f;
+            } else {
+#pragma unroll
+                for (int j = 0; j < 6; ++j) dst[j] = 0.0f;
+            }
+        };
+        load_row(ys - 1, r[0]);
+        load_row(ys, r[1]);
+        for (int gy = ys; gy < ye; ++gy) {
+            load_row(gy + 1, r[2]);
+            float v[4];
+            load4(gp + (size_t)gy * W + x0, v);
+#pragma unroll
+            for (int a = 0; a < 3; ++a)
+#pragma unroll
+                for (int b = 0; b < 3; ++b)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) acc[a * 3 + b] = mas_fmaf(v[j], r[a][j + b], acc[a * 3 + b]);
+#pragma unroll
+            for (int j = 0; j < 6; ++j) { r[0][j] = r[1][j]; r[1][j] = r[2][j]; }
+        }
+    }
+    const int lane = threadIdx.x & (MAS_WAVE - 1), wave = threadIdx.x / MAS_WAVE;
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+        float v = acc[t];
+#pragma unroll
+        for (int off = MAS_WAVE / 2; off > 0; off >>= 1) v += __shfl_down(v, off, MAS_WAVE);
+        if (lane == 0) s_red[wave][t] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x < 9)
+        part[(size_t)blockIdx.x * 9 + threadIdx.x] =
+            ((s_red[0][threadIdx.x] + s_red[1][threadIdx.x]) + s_red[2][threadIdx.x]) + s_red[3][threadIdx.x];
+}
+
 __global__ __launch_bounds__(kThreads) void k_dw_wsum(const float* __restrict__ part, int N, int C9, float* __restrict__ dw) {
     const int i = blockIdx.x * kThreads + threadIdx.x;
     if (i >= C9) return;
@@ -429,8 +569,11 @@ extern "C" int mas_aspp_dw3_bwd_x(const float* g0, const float* g1, const float*
     const size_t smem = sizeof(float) * 3 * (size_t)H * W;
     hipStream_t st = static_cast<hipStream_t>(stream);
     {
+        // (the padded form of the input gradient is SLOWER than the bounds-tested one on the 48 x 48 planes of the training crop --
+        //  173 against 139 us: three planes to stage for one to write -- and is kept for measurements only: MAS_DW3_BWD_PAD=1)
+        static const bool use_pad = [] { const char* e = getenv("MAS_DW3_BWD_PAD"); return e && e[0] == '1'; }();
         const void* ptrs[4] = {g0, g1, g2, dx};
-        if (dw3_pad_ok(ptrs, 4, H, W, d0, d1, d2, true))
+        if (use_pad && dw3_pad_ok(ptrs, 4, H, W, d0, d1, d2, true))
             return d0 == 6 ? dw3_pad_launch<6, true>(g0, g1, g2, w0, w1, w2, N, C, H, W, dx, nullptr, nullptr, st)
                            : dw3_pad_launch<12, true>(g0, g1, g2, w0, w1, w2, N, C, H, W, dx, nullptr, nullptr, st);
     }
@@ -445,6 +588,15 @@ extern "C" int mas_aspp_dw3_bwd_w(const float* x, const float* g0, const float* 
                                   int d1, int d2, float* dw0, float* dw1, float* dw2, void* stream) {
     if (!x || !g0 || !g1 || !g2 || !dw0 || !dw1 || !dw2) return MAS_ERR_NULL;
     if (int e = check(N, C, H, W, d0, d1, d2)) return e;
+    {
+        const void* ptrs[4] = {x, g0, g1, g2};
+        if (dw3_pad_ok(ptrs, 4, H, W, d0, d1, d2, false) && dw3_pad_bytes(H, W, d0, false) <= 60 * 1024) {
+            const size_t smem = dw3_pad_bytes(H, W, d0, false);
+            if (d0 == 6) hipLaunchKernelGGL(k_dw3_bwd_w_pad<6>, dim3((unsigned)C), dim3(kThreads), smem, static_cast<hipStream_t>(stream), x, g0, g1, g2, N, C, H, W, dw0, dw1, dw2);
+            else hipLaunchKernelGGL(k_dw3_bwd_w_pad<12>, dim3((unsigned)C), dim3(kThreads), smem, static_cast<hipStream_t>(stream), x, g0, g1, g2, N, C, H, W, dw0, dw1, dw2);
+            return mas_launch_status();
+        }
+    }
     hipLaunchKernelGGL(k_dw3_bwd_w, dim3((unsigned)C), dim3(kThreads), 0, static_cast<hipStream_t>(stream), x, g0, g1, g2, N, C, H, W, d0,
                        d1, d2, dw0, dw1, dw2);
     return mas_launch_status();
@@ -490,7 +642,12 @@ extern "C" int mas_depthwise3x3_bwd_w(const float* x, const float* dy, int N, in
     if (!x || !dy || !partial || !dw) return MAS_ERR_NULL;
     if (int e = check(N, C, H, W, dilation, dilation, dilation)) return e;
     hipStream_t st = static_cast<hipStream_t>(stream);
-    hipLaunchKernelGGL(k_dw_bwd_w, dim3((unsigned)(N * C)), dim3(kThreads), 0, st, x, dy, C, H, W, dilation, partial);
+    if (dilation == 1 && W >= 16 && W <= 4 * kThreads && (((uintptr_t)x | (uintptr_t)dy) & 3) == 0) {
+        const bool aligned = W % 4 == 0 && (((uintptr_t)x | (uintptr_t)dy) & 15) == 0;
+        if (aligned) hipLaunchKernelGGL(k_dw_bwd_w_rows<true>, dim3((unsigned)(N * C)), dim3(kThreads), 0, st, x, dy, C, H, W, partial);
+        else hipLaunchKernelGGL(k_dw_bwd_w_rows<false>, dim3((unsigned)(N * C)), dim3(kThreads), 0, st, x, dy, C, H, W, partial);
+    } else
+        hipLaunchKernelGGL(k_dw_bwd_w, dim3((unsigned)(N * C)), dim3(kThreads), 0, st, x, dy, C, H, W, dilation, partial);
     hipLaunchKernelGGL(k_dw_wsum, dim3((unsigned)((C * 9 + kThreads - 1) / kThreads)), dim3(kThreads), 0, st, partial, N, C * 9, dw);
     return mas_launch_status();
 }
