@@ -39,10 +39,14 @@ import csv, collections, sys, glob
 sys.path.insert(0, 'profiles')
 from summarize import short
 acc = collections.defaultdict(lambda: collections.defaultdict(float))
+dur, seen = collections.defaultdict(float), set()
 for r in csv.DictReader(open(glob.glob('gpurun_out/p5/p_mf/*counter_collection.csv')[0])):
     k = short(r['Kernel_Name'])
     if k.startswith('k_conv') or k.startswith('k_stem'):
         acc[k][r['Counter_Name']] += float(r['Counter_Value'])
+        if r['Dispatch_Id'] not in seen:
+            seen.add(r['Dispatch_Id'])
+            dur[k] += float(r['End_Timestamp']) - float(r['Start_Timestamp'])
 tot = collections.defaultdict(float)
 rows = []
 for k, v in acc.items():
@@ -54,9 +58,12 @@ out = ["# Matrix-pipe utilisation of the convolution kernels of the pool forward
        "MfmaUtil = SQ_VALU_MFMA_BUSY_CYCLES / (4 SIMDs x SQ_BUSY_CU_CYCLES): the share of the CU-busy cycles in which the matrix pipe of a SIMD is busy "
        "(a v_mfma_f32_32x32x16_bf16 holds it for 32 cycles, a v_mfma_f32_32x32x2_f32 for 64).", "",
        "all convolution kernels: MfmaUtil %.3f" % (tot['SQ_VALU_MFMA_BUSY_CYCLES'] / max(1.0, 4 * tot['SQ_BUSY_CU_CYCLES'])), "",
-       "| kernel | MfmaUtil | share of matrix-pipe cycles |", "|---|---|---|"]
+       "Clock = GRBM_GUI_ACTIVE / 8 XCDs / the kernel's wall time (MI355X_MICROARCH.md, DVFS give-back: reads high on dispatches well under 0.3 ms): "
+       "what the chip holds under this load, against the 2.4 GHz the 2.5 PFLOP/s bf16 figure is quoted at.", "",
+       "| kernel | MfmaUtil | share of matrix-pipe cycles | clock (GHz) |", "|---|---|---|---|"]
 for m, k, v in rows:
-    out.append("| %s | %.3f | %.1f %% |" % (k[:90], m / max(1.0, 4 * v['SQ_BUSY_CU_CYCLES']), 100 * m / max(1.0, tot['SQ_VALU_MFMA_BUSY_CYCLES'])))
+    out.append("| %s | %.3f | %.1f %% | %.2f |" % (k[:90], m / max(1.0, 4 * v['SQ_BUSY_CU_CYCLES']), 100 * m / max(1.0, tot['SQ_VALU_MFMA_BUSY_CYCLES']),
+                                                  v.get('GRBM_GUI_ACTIVE', 0.0) / 8.0 / max(1.0, dur[k])))
 open('gpurun_out/p5/l_pool_forward_mfma_pmc.md', 'w').write("\n".join(out) + "\n")
 print("\n".join(out))
 PY

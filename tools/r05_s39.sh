@@ -1,0 +1,13 @@
+set -u; cd /tmp && export TMPDIR=/tmp && cd "${GRAFT_REPO_ROOT:?}"; mkdir -p gpurun_out/p5 gpurun_out/s39
+timeout -k 10 900 bash tools/profile_r05.sh train > gpurun_out/p5/train.log 2>&1; echo "train rc $?"; head -14 gpurun_out/p5/c_train_768_steady.md
+timeout -k 10 600 python bench.py --gpus 1 --steps 20 --warmup 5 > gpurun_out/s39/bench.json 2> gpurun_out/s39/bench.err; echo "bench rc $?"
+python - <<'PY'
+import json
+d=json.loads(open('gpurun_out/s39/bench.json').read().strip().split('\n')[-1])
+for k in ('value','ms_per_step','train_iter_ms_768','train_iter_ms_769','pool_forward_ms_per_batch','loss_gpu_ms_fwd_bwd'):
+    print(k, d.get(k))
+print('roofline', d.get('roofline'))
+pr=d.get('pool_round') or {}
+print('scan_only', (pr.get('scan_only') or {}).get('seconds'), 'with model', (pr.get('with_model_forward') or {}).get('seconds'))
+print((pr.get('scan_only') or {}).get('rank0_breakdown_s'))
+PY
