@@ -12,14 +12,19 @@ def _need():
         pytest.skip("needs a GPU")
 
 
-@pytest.mark.parametrize("N,C,H,W", [(2, 64, 48, 48), (1, 32, 64, 128), (2, 16, 9, 13), (1, 8, 150, 130)])
-def test_depthwise_triple_matches_conv2d(N, C, H, W):
+@pytest.mark.parametrize("N,C,H,W,dil", [(2, 64, 48, 48, (6, 12, 18)), (1, 32, 64, 128, (6, 12, 18)), (2, 16, 9, 13, (6, 12, 18)), (1, 8, 150, 130, (6, 12, 18)),
+                                         (2, 8, 32, 64, (12, 24, 36)),      # output stride 8: the padded-plane kernels with D = 12
+                                         (3, 5, 20, 12, (6, 12, 18)),       # a plane narrower than the largest dilation (taps entirely in the padding)
+                                         (1, 4, 24, 32, (5, 10, 15)),       # odd dilations: the bounds-tested kernels
+                                         (1, 4, 49, 49, (6, 12, 18))])      # the 769 crop's plane: rows that are no whole 16-byte groups
+def test_depthwise_triple_matches_conv2d(N, C, H, W, dil):
+    """k_dw3_pad / k_dw3_bwd_w_pad (zero-padded LDS plane; W % 4 == 0, dilations D, 2D, 3D with D in {6, 12}) and the bounds-tested
+    kernels every other launch takes, against float64 conv2d."""
     _need()
     from mulactseg_amd import ops
     g = torch.Generator(device='cuda'); g.manual_seed(N * 100 + C)
     x = torch.randn((N, C, H, W), generator=g, device='cuda', requires_grad=True)
     ws = [torch.randn((C, 1, 3, 3), generator=g, device='cuda', requires_grad=True) for _ in range(3)]
-    dil = (6, 12, 18)
     ys = ops.aspp_depthwise3(x, ws[0], ws[1], ws[2], dil)
     # float64 reference on the CPU (independent of MIOpen's own algorithm choice)
     xr = x.detach().double().cpu().requires_grad_(True)
