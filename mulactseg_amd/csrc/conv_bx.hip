@@ -120,7 +120,8 @@ __device__ __forceinline__ void bx_halve(float (&v)[N], int lane) {
 // One job = one weight tensor in one role.  role 0: the forward product (M = Cout rows, K = Cin); role 1: the input gradient
 // of the stride-1 convolution, which is the same kernel on dY with the weight's channel axes swapped and the taps mirrored
 // (M = Cin rows, K = Cout):  a[m][k = (tap, c)] = w[c][m][8 - tap].
-// One thread per 16-byte unit [M tile][chunk][term][k group][row][8]; k = 8 g + j: 1x1 channel = chunk * 32 + k,
+// One thread per (M tile, chunk, k group, row): it reads its eight weights once and writes the three 16-byte units (terms h | m | l) of
+// [M tile][chunk][term][k group][row][8]; k = 8 g + j: 1x1 channel = chunk * 32 + k,
 // 3x3 tap = g (tap 9: zeros), channel = chunk * 8 + j; rows beyond M and channels beyond K are zeros.
 struct BxPackJob {
     const float* w;             // [Cout][Cin][taps] as PyTorch stores it
@@ -128,7 +129,7 @@ struct BxPackJob {
     unsigned* out;
     int Cout, Cin, taps, role, BM;
     int t9;                     // role 2: the 3x3 weight as 9 x (Cin / 32) chunks of the 1x1 form, tap-major (the strided 3x3 forward)
-    long long units;
+    long long units;            // threads of the job (16-byte units of the image / 3)
     unsigned first_block;       // (multi-job launch) the job's first 256-thread block
 };
 
@@ -139,13 +140,11 @@ __device__ __forceinline__ void bx_pack_unit(const BxPackJob& jb, long long u) {
         long long r = u / BM;
         const int g = (int)(r % 4);
         r /= 4;
-        const int term = (int)(r % 3);
-        r /= 3;
         const int cpt = jb.Cin / 32, nch = 9 * cpt;
         const int chunk = (int)(r % nch), mt = (int)(r / nch);
         const int tap = chunk / cpt, cc = chunk - tap * cpt;
         const int m = mt * BM + row;
-        unsigned o[4];
+        unsigned o[3][4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             float v0 = 0.0f, v1 = 0.0f;
@@ -155,11 +154,12 @@ __device__ __forceinline__ void bx_pack_unit(const BxPackJob& jb, long long u) {
                 v1 = jb.w[base + 9];
                 if (jb.row_scale) { v0 *= jb.row_scale[m]; v1 *= jb.row_scale[m]; }
             }
-            unsigned h, mm, l;
-            bx_split2(v0, v1, h, mm, l);
-            o[j] = term == 0 ? h : (term == 1 ? mm : l);
+            bx_split2(v0, v1, o[0][j], o[1][j], o[2][j]);
         }
-        *reinterpret_cast<uint4*>(jb.out + 4 * u) = make_uint4(o[0], o[1], o[2], o[3]);
+#pragma unroll
+        for (int term = 0; term < 3; ++term)
+            *reinterpret_cast<uint4*>(jb.out + 4 * (((((long long)mt * nch + chunk) * 3 + term) * 4 + g) * BM + row)) =
+                make_uint4(o[term][0], o[term][1], o[term][2], o[term][3]);
         return;
     }
     const int GA = taps == 1 ? 4 : kBxTaps3, CK = taps == 1 ? 32 : 8;
@@ -168,8 +168,6 @@ __device__ __forceinline__ void bx_pack_unit(const BxPackJob& jb, long long u) {
     long long r = u / BM;
     const int g = (int)(r % GA);
     r /= GA;
-    const int term = (int)(r % 3);
-    r /= 3;
     const int nch = (K + CK - 1) / CK;              // (a last, partial chunk carries zero weights for the channels that do not exist)
     const int chunk = (int)(r % nch);
     const int mt = (int)(r / nch);
@@ -187,14 +185,13 @@ __device__ __forceinline__ void bx_pack_unit(const BxPackJob& jb, long long u) {
         }
         v[j] = val;
     }
-    unsigned o[4];
+    unsigned o[3][4];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        unsigned h, mm, l;
-        bx_split2(v[2 * j], v[2 * j + 1], h, mm, l);
-        o[j] = term == 0 ? h : (term == 1 ? mm : l);
-    }
-    *reinterpret_cast<uint4*>(jb.out + 4 * u) = make_uint4(o[0], o[1], o[2], o[3]);
+    for (int j = 0; j < 4; ++j) bx_split2(v[2 * j], v[2 * j + 1], o[0][j], o[1][j], o[2][j]);
+#pragma unroll
+    for (int term = 0; term < 3; ++term)
+        *reinterpret_cast<uint4*>(jb.out + 4 * (((((long long)mt * nch + chunk) * 3 + term) * GA + g) * BM + row)) =
+            make_uint4(o[term][0], o[term][1], o[term][2], o[term][3]);
 }
 
 __global__ void k_bx_pack(const BxPackJob jb) {
@@ -1035,7 +1032,7 @@ bool bx_fill_job(BxPackJob* jb, const float* w, const float* row_scale, int Cout
     const long long bytes = mas_conv_bx_packed_bytes(ksize, Cin, Cout, role);
     if (bytes <= 0 || !w || !wp || (uintptr_t)wp % 16 != 0) return false;
     jb->w = w; jb->row_scale = row_scale; jb->out = static_cast<unsigned*>(wp); jb->Cout = Cout; jb->Cin = Cin; jb->taps = ksize * ksize; jb->role = role;
-    jb->BM = bx_bm(ksize, role ? Cin : Cout); jb->units = bytes / 16; jb->first_block = first_block;
+    jb->BM = bx_bm(ksize, role ? Cin : Cout); jb->units = bytes / 48; jb->first_block = first_block;       // threads: one per three units
     jb->t9 = 0;
     if (role == 2) {
         jb->role = 0;

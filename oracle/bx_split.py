@@ -47,7 +47,7 @@ def bx_bm(ksize, M):
 
 def pack_image(w, role=0, row_scale=None):
     """uint16 image [M tile][chunk][term][k group][row][8] of mas_conv_bx_pack for weight w [Cout, Cin, k, k] (numpy f32).
-    role 0: rows = Cout, K = Cin; role 1 (input gradient): rows = Cin, K = Cout, taps mirrored.  row_scale [Cout] (role 0): every
+    role 0: rows = Cout, K = Cin; role 1 (input gradient): rows = Cin, K = Cout, taps mirrored; role 2: the strided 3x3 forward.  row_scale [Cout] (role 0): every
     weight is multiplied by its output channel's entry (one f32 rounding) before the split."""
     w = np.asarray(w, dtype=np.float32)
     if row_scale is not None:
@@ -55,6 +55,24 @@ def pack_image(w, role=0, row_scale=None):
     Cout, Cin, ks, _ = w.shape
     taps = ks * ks
     wf = w.reshape(Cout, Cin, taps)
+    if role == 2:
+        # the forward image of the 3x3 STRIDE-2 convolution (csrc/conv_bx.hip: nine shifted 1x1 stride-2 products): the chunks of the
+        # 1x1 form in tap-major order, [M tile][tap * (Cin / 32) + channel chunk][term][k group 0..3][row][8], channel = chunk * 32 + 8 g + j
+        assert taps == 9 and Cin % 32 == 0
+        BM = bx_bm(1, Cout)
+        mtiles, cpt = (Cout + BM - 1) // BM, Cin // 32
+        val = np.zeros((mtiles, 9 * cpt, 4, BM, 8), dtype=np.float32)
+        for mt in range(mtiles):
+            rows = np.arange(BM) + mt * BM
+            ok = rows < Cout
+            for tap in range(9):
+                for cc in range(cpt):
+                    for g in range(4):
+                        for j in range(8):
+                            val[mt, tap * cpt + cc, g, ok, j] = wf[rows[ok], cc * 32 + 8 * g + j, tap]
+        img = np.zeros((mtiles, 9 * cpt, 3, 4, BM, 8), dtype=np.float32)
+        img[:, :, 0], img[:, :, 1], img[:, :, 2] = split3(val)
+        return bf16_bits(img).reshape(-1)
     M, K = (Cin, Cout) if role else (Cout, Cin)
     BM = bx_bm(ks, M)
     GA, CK = (4, 32) if taps == 1 else (10, 8)

@@ -72,3 +72,16 @@ def test_weight_image_layout():
     assert f[0, 1, 0, 4, 9, 2] == h3[9, 8 + 2, 4]                                    # tap 4, channel 10, output channel 9
     assert not f[:, :, :, 9].any()                                                   # the tenth tap is the zero tap
     assert d[0, 3, 0, 2, 5, 1] == h3[24 + 1, 5, 8 - 2]                               # mirrored tap, swapped channel axes
+
+
+def test_weight_image_layout_of_the_strided_3x3():
+    """Role 2: the 3x3 stride-2 weight as 9 x (Cin / 32) chunks of the 1x1 form, tap-major (csrc/conv_bx.hip: nine shifted 1x1 stride-2
+    products): w[m, c, tap] sits in chunk tap * (Cin / 32) + c // 32, k group (c % 32) // 8, element c % 8."""
+    rs = np.random.RandomState(5)
+    w = rs.standard_normal((200, 64, 3, 3)).astype(np.float32)             # Cout 200 -> four 64-row tiles, Cin 64 -> two chunks per tap
+    img = bx_split.pack_image(w, 2).reshape(4, 18, 3, 4, 64, 8)
+    h, m, l = (bx_split.bf16_bits(t).reshape(200, 64, 9) for t in bx_split.split3(w))
+    assert img[1, 7 * 2 + 1, 0, 2, 5, 3] == h[64 + 5, 32 + 16 + 3, 7]        # tile 1 row 5, tap 7, second channel chunk, k = 8 * 2 + 3
+    assert img[0, 0, 1, 0, 0, 0] == m[0, 0, 0] and img[3, 17, 2, 3, 7, 7] == l[192 + 7, 63, 8]
+    assert not img[3, :, :, :, 8:, :].any()                                # rows 200.. are zero
+    assert bx_split.pack_image(w, 2).size * 2 == 4 * 18 * 3 * 4 * 64 * 16   # = mas_conv_bx_packed_bytes(3, 64, 200, 2)

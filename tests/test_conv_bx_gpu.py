@@ -148,7 +148,7 @@ def test_conv_bx_weight_cache_follows_the_parameter():
     assert torch.allclose(b, 2 * a, rtol=1e-6, atol=1e-6)
 
 
-@pytest.mark.parametrize("seed", range(16))
+@pytest.mark.parametrize("seed", range(28))
 def test_conv_bx_randomised_geometries(seed):
     """Random supported geometries against conv2d in float64: partial tiles, halo clamps, the chunk walk, the padding of the
     output channels hold wherever conv_bx_supported says yes."""
@@ -157,12 +157,14 @@ def test_conv_bx_randomised_geometries(seed):
     from mulactseg_amd import ops
     rs = np.random.RandomState(2000 + seed)
     k = int(rs.choice([1, 3]))
-    stride = int(rs.choice([1, 2])) if k == 1 else 1
-    dil = 1 if k == 1 else int(rs.choice([1, 2]))
+    stride = int(rs.choice([1, 2])) if (k == 1 or seed >= 16) else 1          # (seeds 16..: the strided 3x3 too)
+    dil = 1 if (k == 1 or stride == 2) else int(rs.choice([1, 2]))
     cin = int(rs.choice([8, 12, 16, 24, 40, 64, 72, 128])) if k == 3 else int(rs.choice([32, 48, 64, 96, 100, 160]))
+    if k == 3 and stride == 2:
+        cin = int(rs.choice([32, 64, 96, 128]))
     cout = int(rs.choice([16, 48, 64, 80, 128, 192, 200, 256]))
     N = int(rs.randint(1, 4))
-    if k == 3:
+    if k == 3 and stride == 1:
         H, W = int(rs.randint(3, 40)), int(rs.randint(32, 90))
     elif stride == 2:
         H, W = 2 * int(rs.randint(2, 30)), 8 * int(rs.randint(1, 12))
@@ -230,7 +232,8 @@ def test_wgrad_bx_exact_on_integers_and_selected_by_conv_wgrad():
     assert torch.equal(ops.conv_wgrad(x, dy, 1, 1, 1)[:, :, 0, 0], ref)
 
 
-@pytest.mark.parametrize("shape,role", [((130, 40, 1, 1), 0), ((130, 40, 1, 1), 1), ((64, 20, 3, 3), 0), ((72, 16, 3, 3), 1), ((256, 304, 1, 1), 0)])
+@pytest.mark.parametrize("shape,role", [((130, 40, 1, 1), 0), ((130, 40, 1, 1), 1), ((64, 20, 3, 3), 0), ((72, 16, 3, 3), 1), ((256, 304, 1, 1), 0),
+                                        ((128, 64, 3, 3), 2), ((200, 32, 3, 3), 2)])       # role 2: tap-major chunks of the strided 3x3
 def test_weight_image_equals_the_numpy_restatement(shape, role):
     """mas_conv_bx_pack (and the multi-job pack the training step uses) against oracle/bx_split.py:pack_image, bit for bit: the
     split of every weight, the zero padding of rows / channels / the tenth tap, the mirrored taps of the input-gradient role."""
