@@ -1,0 +1,5 @@
+set -u; cd /tmp && export TMPDIR=/tmp && cd "${GRAFT_REPO_ROOT:?}"; O=gpurun_out/s46; mkdir -p $O
+timeout -k 10 900 python -m pytest tests/test_bn_gpu.py tests/test_train_golden.py tests/test_trainer_gpu.py -q -m gpu -x > $O/pytest.log 2>&1; echo "pytest rc $?"; tail -2 $O/pytest.log
+for rep in 1 2; do for m in apply launch; do
+  echo "MAS_BN_BWD_STATS=$m:"; MAS_BN_BWD_STATS=$m timeout -k 10 200 python tools/train_step_probe.py --modes own --streams main --steps 10 --crop 768 2>&1 | grep -E "^own" | tail -1
+done; done
