@@ -13,10 +13,19 @@
 #include <hip/hip_runtime.h>
 
 // two f32 -> one dword of two bf16 (low half = a, high half = b), round to nearest even
+// (-DBX_CVT_BUILTIN: the same instruction through the vector conversion the compiler selects it for -- visible to the scheduler, which
+//  an inline-asm statement is not; the measurement builds that interleave the split with MFMAs need it.  0.7-1.3 % slower in the
+//  shipped kernels, profiles/r05/p_bx_variants_ab.md.)
 static __device__ __forceinline__ unsigned bx_cvt_pk(float a, float b) {
+#ifdef BX_CVT_BUILTIN
+    typedef __bf16 bx_bf2 __attribute__((ext_vector_type(2)));
+    typedef float bx_f2 __attribute__((ext_vector_type(2)));
+    return __builtin_bit_cast(unsigned, __builtin_convertvector((bx_f2){a, b}, bx_bf2));
+#else
     unsigned r;
     asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
     return r;
+#endif
 }
 
 // (h, m, l) of two values, packed pairwise: dword = (bf16 of v1) << 16 | bf16 of v0

@@ -11,6 +11,8 @@
 // loads four consecutive pixels of a row, splits them and stores three 8-byte pieces -- no transposition anywhere.
 //   * tile 128 x 128 per workgroup of 4 waves (64 x 64 each), K in chunks of 32 pixels (two 16-k steps); chunk t + 1 travels
 //     global -> registers in front of the MFMAs of chunk t, registers -> (split) -> LDS behind them; two workgroups per CU.
+//     (that is k_wgrad_bx, built with -DWX_PIPE2=0; what runs since round 5 is k_wgrad_bx_p2 below: the same tile, operand images
+//     and product order, ONE workgroup per CU, staging interleaved by hand with the MFMAs.)
 //   * split K: the grid is (tiles) x S pixel ranges, every workgroup writes its partial tile to workspace [S][Cout][Cin] and
 //     k_wgx_reduce adds the slices in a fixed order (no atomics: run-to-run identical).  Workgroups of one range sit on one XCD.
 #include "common.h"
@@ -192,6 +194,192 @@ __global__ __launch_bounds__(kWxThreads, 2) void k_wgrad_bx(const WxP p) {
     }
 }
 
+#ifndef WX_PIPE2
+#define WX_PIPE2 1
+#endif
+#if WX_PIPE2
+// The kernel that runs (round 5; -DWX_PIPE2=0 builds the two-workgroup form above for A/B): ONE workgroup per CU, two LDS buffers
+// (static arrays), two sets of staging registers; the split + LDS stores of chunk t + 1 are interleaved BY HAND with the MFMAs of
+// chunk t in the wave's own instruction stream -- a wave hides about five of its own instructions between two of its own MFMAs,
+// but gets one issue slot per MFMA of its SIMD partner (round 4's stamps), which is what kept the two-workgroup form at MfmaUtil
+// 0.5: its 300 staging instructions per chunk ran at the partner's MFMA pace.  The chunk's 48 MFMAs are each followed by one of 48
+// slices of the next chunk's staging (five VALU instructions, or the three LDS stores of a quad), the order pinned with
+// sched_barrier; one barrier per chunk; 280 VGPRs.  Same products in the same order per accumulator.  1x1 weight gradients of a
+// training step 2 883 -> 2 718 us (-7 ... -24 % on the layers of up to 512 channels, nothing on the 1024 / 2048-channel layers,
+// which re-read their operands from L2 at 5.7 TB/s with 128 x 128 tiles); step -0.3 ms.
+__global__ __launch_bounds__(kWxThreads, 1) void k_wgrad_bx_p2(const WxP p) {
+    __shared__ __attribute__((aligned(16))) v4f wxb0[2 * kWxImg], wxb1[2 * kWxImg];
+    const int tid = threadIdx.x;
+    const int tiles = p.mtiles * p.ctiles;
+    int tile, s;
+    if (p.S % 8 == 0) {
+        const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+        tile = slot % tiles;
+        s = (slot / tiles) * 8 + xcd;
+    } else {
+        tile = blockIdx.x % tiles;
+        s = blockIdx.x / tiles;
+    }
+    const int mt = tile / p.ctiles, ct = tile - mt * p.ctiles;
+    const int m0 = mt * 128, c0 = ct * 128;
+    const int HW = p.HW;
+    int ga[4], gb[4], lo[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int q = tid + j * kWxThreads;
+        const int pq = q & 7, rr = q >> 3;
+        const int r = (rr & ~5) | ((rr & 1) << 2) | ((rr >> 2) & 1);
+        ga[j] = (m0 + r < p.Cout) ? ((m0 + r) * HW + pq * 4) * 4 : kWxOut;
+        gb[j] = (c0 + r < p.Cin) ? ((c0 + r) * HW + pq * 4) * 4 : kWxOut;
+        lo[j] = ((pq >> 1) * kWxGS + r) * 16 + (pq & 1) * 8;
+    }
+    const int wave = tid >> 6, lane = tid & 63, l31 = lane & 31, h = lane >> 5;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int aBase = h * kWxGS + wm * 64 + l31, bBase = h * kWxGS + wn * 64 + l31;
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+        for (int tn = 0; tn < 2; ++tn)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[tm][tn][r] = 0.0f;
+    const int cq = p.nch / p.S, cr = p.nch - cq * p.S;
+    const int c_lo = s * cq + (s < cr ? s : cr), c_hi = c_lo + cq + (s < cr ? 1 : 0);
+    v4f ra[2][4], rb[2][4];
+    int tail[2] = {0, 0};
+    auto fetch = [&](int cidx, int rs) {
+        cidx = __builtin_amdgcn_readfirstlane(cidx);
+        const int n = cidx / p.cpp, px0 = (cidx - n * p.cpp) * kWxKP;
+        tail[rs] = HW - px0 < kWxKP ? HW - px0 : kWxKP;
+        const __amdgpu_buffer_rsrc_t ares = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.dy + (size_t)n * p.Cout * HW + px0), 0,
+                                                                              (p.Cout * HW - px0) * 4, kWxRsrcFlags);
+        const __amdgpu_buffer_rsrc_t bres = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.x + (size_t)n * p.Cin * HW + px0), 0,
+                                                                              (p.Cin * HW - px0) * 4, kWxRsrcFlags);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) ra[rs][j] = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(ares, ga[j], 0, 0));
+#pragma unroll
+        for (int j = 0; j < 4; ++j) rb[rs][j] = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(bres, gb[j], 0, 0));
+    };
+    // ---- the staging of one chunk in 48 slices, one per MFMA of the chunk that is being multiplied --------------------------------
+    // quad q = 0..7 (four of dY, four of X), slice 6 q + ph:  ph 0 / 1: h and the first remainders of the pair (x, y) / (z, w);
+    // ph 2 / 3: m and the second remainders; ph 4: the two l, the three 8-byte LDS stores; ph 5: the tail selects of the next dY quad.
+    // (bx_split2 in pieces: the same operations on the same values.)
+    unsigned sh[2], sm[2], sl[2];
+    float sr[2][2];
+    auto slice = [&](int idx, int rs, int lb) {
+        const int q = idx / 6, ph = idx - 6 * q;
+        const bool isA = q < 4;
+        const int j = q & 3;
+        v4f& v = isA ? ra[rs][j] : rb[rs][j];
+        if (ph == 0 || ph == 1) {
+            const float v0 = ph ? v.z : v.x, v1 = ph ? v.w : v.y;
+            const unsigned hh = bx_cvt_pk(v0, v1);
+            sh[ph] = hh;
+            sr[ph][0] = v0 - __uint_as_float(hh << 16);
+            sr[ph][1] = v1 - __uint_as_float(hh & 0xffff0000u);
+        } else if (ph == 2 || ph == 3) {
+            const int k = ph - 2;
+            const unsigned mm = bx_cvt_pk(sr[k][0], sr[k][1]);
+            sm[k] = mm;
+            sr[k][0] = sr[k][0] - __uint_as_float(mm << 16);
+            sr[k][1] = sr[k][1] - __uint_as_float(mm & 0xffff0000u);
+        } else if (ph == 4) {
+            sl[0] = bx_cvt_pk(sr[0][0], sr[0][1]);
+            sl[1] = bx_cvt_pk(sr[1][0], sr[1][1]);
+            v4f* img = (lb ? wxb1 : wxb0) + (isA ? 0 : kWxImg);
+            unsigned char* dst = reinterpret_cast<unsigned char*>(img) + lo[j];
+            *reinterpret_cast<v2u*>(dst) = (v2u){sh[0], sh[1]};
+            *reinterpret_cast<v2u*>(dst + 4 * kWxGS * 16) = (v2u){sm[0], sm[1]};
+            *reinterpret_cast<v2u*>(dst + 8 * kWxGS * 16) = (v2u){sl[0], sl[1]};
+        } else if (q + 1 < 4) {                  // ph 5: a picture's last, partial chunk -- the pixels beyond the plane are zeroed on the dY side
+            const int left = tail[rs] - (tid & 7) * 4;
+            v4f& n = ra[rs][q + 1];
+            n.x = left > 0 ? n.x : 0.0f; n.y = left > 1 ? n.y : 0.0f; n.z = left > 2 ? n.z : 0.0f; n.w = left > 3 ? n.w : 0.0f;
+        }
+    };
+    auto mask_first = [&](int rs) {             // (the selects of dY quad 0, in front of slice 0)
+        const int left = tail[rs] - (tid & 7) * 4;
+        v4f& n = ra[rs][0];
+        n.x = left > 0 ? n.x : 0.0f; n.y = left > 1 ? n.y : 0.0f; n.z = left > 2 ? n.z : 0.0f; n.w = left > 3 ? n.w : 0.0f;
+    };
+    auto stage_all = [&](int rs, int lb) {      // (the first chunk of a workgroup: nothing to multiply yet)
+        mask_first(rs);
+#pragma unroll
+        for (int i = 0; i < 48; ++i) slice(i, rs, lb);
+    };
+    // ---- one step: the 48 MFMAs of the chunk in buffer b, each followed by one staging slice of the next chunk (registers of set
+    // 1 - b -> buffer 1 - b); the fragments of the second 16-k step are requested half a step ahead ---------------------------------
+    auto frags = [&](int lb, int st, bf8 (&a)[2][3], bf8 (&bb)[2][3]) {
+        const v4f* sA = lb ? wxb1 : wxb0;
+        const v4f* sB = sA + kWxImg;
+#pragma unroll
+        for (int term = 0; term < 3; ++term)
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                a[t][term] = __builtin_bit_cast(bf8, sA[(term * 4 + 2 * st) * kWxGS + aBase + t * 32]);
+                bb[t][term] = __builtin_bit_cast(bf8, sB[(term * 4 + 2 * st) * kWxGS + bBase + t * 32]);
+            }
+    };
+    const int c_first = __builtin_amdgcn_readfirstlane(c_lo), c_last = __builtin_amdgcn_readfirstlane(c_hi) - 1;
+    if (c_first <= c_last) {
+        fetch(c_first, 0);
+        fetch(c_first + 1 <= c_last ? c_first + 1 : c_last, 1);
+        stage_all(0, 0);
+        __syncthreads();
+        auto step = [&](int t, int b) {
+            fetch(t + 2 <= c_last ? t + 2 : c_last, b);     // (in front of the MFMAs: under them -- after the second -- measured 1 % slower)
+            bf8 fa[2][2][3], fb[2][2][3];
+            frags(b, 0, fa[0], fb[0]);
+            mask_first(1 - b);
+            __builtin_amdgcn_sched_barrier(0);
+            constexpr int ta[6] = {1, 0, 2, 0, 1, 0}, tb[6] = {1, 2, 0, 1, 0, 0};
+#pragma unroll
+            for (int st = 0; st < 2; ++st)
+#pragma unroll
+                for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+                    for (int tn = 0; tn < 2; ++tn)
+#pragma unroll
+                        for (int pr = 0; pr < 6; ++pr) {
+                            const int i = ((st * 2 + tm) * 2 + tn) * 6 + pr;
+                            acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[st][tm][ta[pr]], fb[st][tn][tb[pr]], acc[tm][tn], 0, 0, 0);
+                            slice(i, 1 - b, 1 - b);
+                            if (i == 8) frags(b, 1, fa[1], fb[1]);
+                            __builtin_amdgcn_sched_barrier(0);
+                        }
+            __syncthreads();
+        };
+        for (int t = c_first; t <= c_last; t += 2) {
+            step(t, 0);
+            if (t + 1 > c_last) break;
+            step(t + 1, 1);
+        }
+    }
+    const __amdgpu_buffer_rsrc_t pres = __builtin_amdgcn_make_buffer_rsrc(p.part + (size_t)s * p.Cout * p.Cin, 0, p.Cout * p.Cin * 4, kWxRsrcFlags);
+    const bool full = m0 + 128 <= p.Cout;
+    const int row4 = p.Cin * 4;
+#pragma unroll
+    for (int tn = 0; tn < 2; ++tn) {
+        const int c = c0 + wn * 64 + tn * 32 + l31;
+        const int vb = c < p.Cin ? c * 4 : kWxOut;
+#pragma unroll
+        for (int tm = 0; tm < 2; ++tm) {
+            const int mb = m0 + wm * 64 + tm * 32 + 4 * h;
+            const int vbase = vb + mb * row4;
+            if (full) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(acc[tm][tn][r]), pres, vbase, ((r & 3) + 8 * (r >> 2)) * row4, 0);
+            } else {
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(acc[tm][tn][r]), pres, vb + (mb + (r & 3) + 8 * (r >> 2)) * row4, 0, 0);
+            }
+        }
+    }
+}
+#endif
+
 __global__ __launch_bounds__(256) void k_wgx_reduce(const float* __restrict__ part, int S, size_t n, float* __restrict__ dw) {
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
@@ -218,7 +406,11 @@ inline int wx_pick_split(int tiles, int nch, size_t slice_bytes) {
     for (int S = 1; S <= smax; ++S) {
         if (S > 1 && (size_t)S * slice_bytes > kWxPartCap) break;
         const long long wg = (long long)tiles * S;
+#if WX_PIPE2
+        const long long rounds = (wg + 255) / 256;               // (one workgroup per CU)
+#else
         const long long rounds = (wg + 511) / 512;
+#endif
         const double per = (double)((nch + S - 1) / S);
         const double cost = (double)rounds * (per + 3.0) * 2.0 + (double)S * (double)slice_bytes * 2.0 / 3e6;      // microseconds
         if (cost < best_cost) {
@@ -264,9 +456,14 @@ extern "C" int mas_conv_wgrad_bx(const float* x, const float* dy, int N, int Cin
     while (p.S > 1 && (size_t)p.S * slice > workspace_bytes) --p.S;
     if ((size_t)p.S * slice > workspace_bytes) return MAS_ERR_WORKSPACE;
     const size_t smem = (size_t)2 * kWxImg * 16;
+    (void)smem;
     const long long nblk = (long long)p.S * p.mtiles * p.ctiles;
     if (nblk <= 0 || nblk > 0x7fffffffLL) return MAS_ERR_SHAPE;
+#if WX_PIPE2
+    hipLaunchKernelGGL(k_wgrad_bx_p2, dim3((unsigned)nblk), dim3(kWxThreads), 0, st, p);
+#else
     hipLaunchKernelGGL(k_wgrad_bx, dim3((unsigned)nblk), dim3(kWxThreads), smem, st, p);
+#endif
     int rc = mas_launch_status();
     if (rc != 0) return rc;
     const size_t n = (size_t)Cout * Cin;
