@@ -57,12 +57,17 @@ __device__ __forceinline__ void out_range(float inv_scale, int i, int n_out, int
     hi = hi > n_out - 1 ? n_out - 1 : hi;
 }
 
-// grid: (ceil(Wi / 64), Hi, NC), one wave per workgroup (input rows are 48 .. 512 wide)
-__global__ __launch_bounds__(MAS_WAVE) void k_upsample_bwd(const float* __restrict__ gy, int Hi, int Wi, int Ho, int Wo, float sh, float sw,
-                                                            float* __restrict__ gx) {
-    const int ix = blockIdx.x * MAS_WAVE + threadIdx.x;
-    if (ix >= Wi) return;
-    const int iy = blockIdx.y;
+// grid: (ceil(Wi / 64), ceil(Hi / 4), NC), four waves per workgroup, one input row each (input rows are 48 .. 512 wide)
+// FAST4 (Wo == 4 Wi, 16-byte aligned rows -- the x4 of the ASPP output, deeplabv3.py:116): an interior column's candidates 4 ix - 4 ..
+// 4 ix + 7 carry weight at positions 2 .. 9 only, i.e. output columns 4 ix - 2 .. 4 ix + 5: one 8-byte, one 16-byte and one 8-byte
+// load per gradient row instead of 16 tested scalar loads: 187 -> 151 us per training step; the same fmas in the same order.
+// (Also unrolling the eight weighted rows of an interior input row: 167 us.  The x4 forward with three loads per input row: 87 = 86 us.)
+template <bool FAST4>
+__global__ __launch_bounds__(4 * MAS_WAVE) void k_upsample_bwd(const float* __restrict__ gy, int Hi, int Wi, int Ho, int Wo, float sh, float sw,
+                                                                float* __restrict__ gx) {
+    const int ix = blockIdx.x * MAS_WAVE + (threadIdx.x & (MAS_WAVE - 1));
+    const int iy = blockIdx.y * 4 + (threadIdx.x / MAS_WAVE);
+    if (ix >= Wi || iy >= Hi) return;
     const size_t nc = blockIdx.z;
     int xlo, xhi, ylo, yhi;
     out_range(1.0f / sw, ix, Wo, xlo, xhi);
@@ -80,15 +85,27 @@ __global__ __launch_bounds__(MAS_WAVE) void k_upsample_bwd(const float* __restri
     }
     const float* g = gy + nc * Ho * Wo;
     float acc = 0.0f;
+    // (interior column of an exact x4: xlo = 4 ix - 4, the weights at k = 2 .. 9 are all non-zero, every other one is zero)
+    const bool fast = FAST4 && ix >= 1 && ix + 2 <= Wi && xlo == 4 * ix - 4;
     for (int oy = ylo; oy <= yhi; ++oy) {
         const Tap t = make_tap(sh, oy, Hi);
         const float wy = (t.i0 == iy ? t.l0 : 0.0f) + (t.i1 == iy ? t.l1 : 0.0f);
         if (wy == 0.0f) continue;
         float row = 0.0f;
+        if (fast) {
+            const float* q = g + (size_t)oy * Wo + 4 * ix;
+            const float2 a = *reinterpret_cast<const float2*>(q - 2);
+            const float4 b = *reinterpret_cast<const float4*>(q);
+            const float2 c = *reinterpret_cast<const float2*>(q + 4);
+            row = mas_fmaf(wx[2], a.x, row); row = mas_fmaf(wx[3], a.y, row);
+            row = mas_fmaf(wx[4], b.x, row); row = mas_fmaf(wx[5], b.y, row); row = mas_fmaf(wx[6], b.z, row); row = mas_fmaf(wx[7], b.w, row);
+            row = mas_fmaf(wx[8], c.x, row); row = mas_fmaf(wx[9], c.y, row);
+        } else {
 #pragma unroll
-        for (int k = 0; k < kMaxTaps; ++k) {
-            const int ox = xlo + k;
-            if (ox <= xhi && wx[k] != 0.0f) row = mas_fmaf(wx[k], g[(size_t)oy * Wo + ox], row);
+            for (int k = 0; k < kMaxTaps; ++k) {
+                const int ox = xlo + k;
+                if (ox <= xhi && wx[k] != 0.0f) row = mas_fmaf(wx[k], g[(size_t)oy * Wo + ox], row);
+            }
         }
         acc = mas_fmaf(wy, row, acc);
     }
@@ -115,7 +132,12 @@ extern "C" int mas_upsample_bilinear_bwd(const float* gy, int64_t NC, int Hi, in
     if (!gy || !gx) return MAS_ERR_NULL;
     if (int e = check(NC, Hi, Wi, Ho, Wo)) return e;
     if ((long long)Wo > 6LL * Wi) return MAS_ERR_RANGE;
-    hipLaunchKernelGGL(k_upsample_bwd, dim3((unsigned)((Wi + MAS_WAVE - 1) / MAS_WAVE), (unsigned)Hi, (unsigned)NC), dim3(MAS_WAVE), 0,
-                       static_cast<hipStream_t>(stream), gy, Hi, Wi, Ho, Wo, (float)Hi / (float)Ho, (float)Wi / (float)Wo, gx);
+    const dim3 grid((unsigned)((Wi + MAS_WAVE - 1) / MAS_WAVE), (unsigned)((Hi + 3) / 4), (unsigned)NC);
+    if (Wo == 4 * Wi && ((uintptr_t)gy & 15) == 0)
+        hipLaunchKernelGGL(k_upsample_bwd<true>, grid, dim3(4 * MAS_WAVE), 0, static_cast<hipStream_t>(stream), gy, Hi, Wi, Ho, Wo, (float)Hi / (float)Ho,
+                           (float)Wi / (float)Wo, gx);
+    else
+        hipLaunchKernelGGL(k_upsample_bwd<false>, grid, dim3(4 * MAS_WAVE), 0, static_cast<hipStream_t>(stream), gy, Hi, Wi, Ho, Wo, (float)Hi / (float)Ho,
+                           (float)Wi / (float)Wo, gx);
     return mas_launch_status();
 }
