@@ -15,6 +15,8 @@
 //     and product order, ONE workgroup per CU, staging interleaved by hand with the MFMAs.)
 //   * split K: the grid is (tiles) x S pixel ranges, every workgroup writes its partial tile to workspace [S][Cout][Cin] and
 //     k_wgx_reduce adds the slices in a fixed order (no atomics: run-to-run identical).  Workgroups of one range sit on one XCD.
+#include <cstdlib>
+
 #include "common.h"
 #include "bx_split.h"
 
@@ -207,8 +209,13 @@ __global__ __launch_bounds__(kWxThreads, 2) void k_wgrad_bx(const WxP p) {
 // sched_barrier; one barrier per chunk; 280 VGPRs.  Same products in the same order per accumulator.  1x1 weight gradients of a
 // training step 2 883 -> 2 718 us (-7 ... -24 % on the layers of up to 512 channels, nothing on the 1024 / 2048-channel layers,
 // which re-read their operands from L2 at 5.7 TB/s with 128 x 128 tiles); step -0.3 ms.
+// NB: the X side of the tile is NB blocks of 128 input channels (a wave owns 64 x 64 NB): NB = 2 where the input channels fill whole
+// pairs of blocks -- dY is then re-read by half as many column tiles and a chunk's 96 MFMAs carry 72 staging slices instead of 48 : 48.
+template <int NB>
 __global__ __launch_bounds__(kWxThreads, 1) void k_wgrad_bx_p2(const WxP p) {
-    __shared__ __attribute__((aligned(16))) v4f wxb0[2 * kWxImg], wxb1[2 * kWxImg];
+    constexpr int GSB = 128 * NB + 1, IMGB = 3 * 4 * GSB;        // units per k group / per image of the X operand
+    constexpr int NQB = 4 * NB, NTN = 2 * NB;
+    __shared__ __attribute__((aligned(16))) v4f wxb0[kWxImg + IMGB], wxb1[kWxImg + IMGB];
     const int tid = threadIdx.x;
     const int tiles = p.mtiles * p.ctiles;
     int tile, s;
@@ -221,31 +228,34 @@ __global__ __launch_bounds__(kWxThreads, 1) void k_wgrad_bx_p2(const WxP p) {
         s = blockIdx.x / tiles;
     }
     const int mt = tile / p.ctiles, ct = tile - mt * p.ctiles;
-    const int m0 = mt * 128, c0 = ct * 128;
+    const int m0 = mt * 128, c0 = ct * 128 * NB;
     const int HW = p.HW;
-    int ga[4], gb[4], lo[4];
+    int ga[4], gb[NQB], lo[4], lob[NQB];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
+    for (int j = 0; j < NQB; ++j) {
         const int q = tid + j * kWxThreads;
         const int pq = q & 7, rr = q >> 3;
         const int r = (rr & ~5) | ((rr & 1) << 2) | ((rr >> 2) & 1);
-        ga[j] = (m0 + r < p.Cout) ? ((m0 + r) * HW + pq * 4) * 4 : kWxOut;
+        if (j < 4) {
+            ga[j] = (m0 + r < p.Cout) ? ((m0 + r) * HW + pq * 4) * 4 : kWxOut;
+            lo[j] = ((pq >> 1) * kWxGS + r) * 16 + (pq & 1) * 8;
+        }
         gb[j] = (c0 + r < p.Cin) ? ((c0 + r) * HW + pq * 4) * 4 : kWxOut;
-        lo[j] = ((pq >> 1) * kWxGS + r) * 16 + (pq & 1) * 8;
+        lob[j] = ((pq >> 1) * GSB + r) * 16 + (pq & 1) * 8;
     }
     const int wave = tid >> 6, lane = tid & 63, l31 = lane & 31, h = lane >> 5;
     const int wm = wave >> 1, wn = wave & 1;
-    const int aBase = h * kWxGS + wm * 64 + l31, bBase = h * kWxGS + wn * 64 + l31;
-    f32x16 acc[2][2];
+    const int aBase = h * kWxGS + wm * 64 + l31, bBase = h * GSB + wn * 64 * NB + l31;
+    f32x16 acc[2][NTN];
 #pragma unroll
     for (int tm = 0; tm < 2; ++tm)
 #pragma unroll
-        for (int tn = 0; tn < 2; ++tn)
+        for (int tn = 0; tn < NTN; ++tn)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[tm][tn][r] = 0.0f;
     const int cq = p.nch / p.S, cr = p.nch - cq * p.S;
     const int c_lo = s * cq + (s < cr ? s : cr), c_hi = c_lo + cq + (s < cr ? 1 : 0);
-    v4f ra[2][4], rb[2][4];
+    v4f ra[2][4], rb[2][NQB];
     int tail[2] = {0, 0};
     auto fetch = [&](int cidx, int rs) {
         cidx = __builtin_amdgcn_readfirstlane(cidx);
@@ -258,10 +268,10 @@ __global__ __launch_bounds__(kWxThreads, 1) void k_wgrad_bx_p2(const WxP p) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) ra[rs][j] = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(ares, ga[j], 0, 0));
 #pragma unroll
-        for (int j = 0; j < 4; ++j) rb[rs][j] = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(bres, gb[j], 0, 0));
+        for (int j = 0; j < NQB; ++j) rb[rs][j] = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(bres, gb[j], 0, 0));
     };
     // ---- the staging of one chunk in 48 slices, one per MFMA of the chunk that is being multiplied --------------------------------
-    // quad q = 0..7 (four of dY, four of X), slice 6 q + ph:  ph 0 / 1: h and the first remainders of the pair (x, y) / (z, w);
+    // quad q = 0 .. 3 + 4 NB (four of dY, 4 NB of X), slice 6 q + ph:  ph 0 / 1: h and the first remainders of the pair (x, y) / (z, w);
     // ph 2 / 3: m and the second remainders; ph 4: the two l, the three 8-byte LDS stores; ph 5: the tail selects of the next dY quad.
     // (bx_split2 in pieces: the same operations on the same values.)
     unsigned sh[2], sm[2], sl[2];
@@ -269,7 +279,7 @@ __global__ __launch_bounds__(kWxThreads, 1) void k_wgrad_bx_p2(const WxP p) {
     auto slice = [&](int idx, int rs, int lb) {
         const int q = idx / 6, ph = idx - 6 * q;
         const bool isA = q < 4;
-        const int j = q & 3;
+        const int j = isA ? q : q - 4;
         v4f& v = isA ? ra[rs][j] : rb[rs][j];
         if (ph == 0 || ph == 1) {
             const float v0 = ph ? v.z : v.x, v1 = ph ? v.w : v.y;
@@ -287,10 +297,11 @@ __global__ __launch_bounds__(kWxThreads, 1) void k_wgrad_bx_p2(const WxP p) {
             sl[0] = bx_cvt_pk(sr[0][0], sr[0][1]);
             sl[1] = bx_cvt_pk(sr[1][0], sr[1][1]);
             v4f* img = (lb ? wxb1 : wxb0) + (isA ? 0 : kWxImg);
-            unsigned char* dst = reinterpret_cast<unsigned char*>(img) + lo[j];
+            unsigned char* dst = reinterpret_cast<unsigned char*>(img) + (isA ? lo[j] : lob[j]);
+            const int tstride = (isA ? kWxGS : GSB) * 4 * 16;          // bytes of one term of the image
             *reinterpret_cast<v2u*>(dst) = (v2u){sh[0], sh[1]};
-            *reinterpret_cast<v2u*>(dst + 4 * kWxGS * 16) = (v2u){sm[0], sm[1]};
-            *reinterpret_cast<v2u*>(dst + 8 * kWxGS * 16) = (v2u){sl[0], sl[1]};
+            *reinterpret_cast<v2u*>(dst + tstride) = (v2u){sm[0], sm[1]};
+            *reinterpret_cast<v2u*>(dst + 2 * tstride) = (v2u){sl[0], sl[1]};
         } else if (q + 1 < 4) {                  // ph 5: a picture's last, partial chunk -- the pixels beyond the plane are zeroed on the dY side
             const int left = tail[rs] - (tid & 7) * 4;
             v4f& n = ra[rs][q + 1];
@@ -305,19 +316,19 @@ __global__ __launch_bounds__(kWxThreads, 1) void k_wgrad_bx_p2(const WxP p) {
     auto stage_all = [&](int rs, int lb) {      // (the first chunk of a workgroup: nothing to multiply yet)
         mask_first(rs);
 #pragma unroll
-        for (int i = 0; i < 48; ++i) slice(i, rs, lb);
+        for (int i = 0; i < 6 * (4 + NQB); ++i) slice(i, rs, lb);
     };
     // ---- one step: the 48 MFMAs of the chunk in buffer b, each followed by one staging slice of the next chunk (registers of set
     // 1 - b -> buffer 1 - b); the fragments of the second 16-k step are requested half a step ahead ---------------------------------
-    auto frags = [&](int lb, int st, bf8 (&a)[2][3], bf8 (&bb)[2][3]) {
+    auto frags = [&](int lb, int st, bf8 (&a)[2][3], bf8 (&bb)[NTN][3]) {
         const v4f* sA = lb ? wxb1 : wxb0;
         const v4f* sB = sA + kWxImg;
 #pragma unroll
         for (int term = 0; term < 3; ++term)
 #pragma unroll
-            for (int t = 0; t < 2; ++t) {
-                a[t][term] = __builtin_bit_cast(bf8, sA[(term * 4 + 2 * st) * kWxGS + aBase + t * 32]);
-                bb[t][term] = __builtin_bit_cast(bf8, sB[(term * 4 + 2 * st) * kWxGS + bBase + t * 32]);
+            for (int t = 0; t < NTN; ++t) {
+                if (t < 2) a[t][term] = __builtin_bit_cast(bf8, sA[(term * 4 + 2 * st) * kWxGS + aBase + t * 32]);
+                bb[t][term] = __builtin_bit_cast(bf8, sB[(term * 4 + 2 * st) * GSB + bBase + t * 32]);
             }
     };
     const int c_first = __builtin_amdgcn_readfirstlane(c_lo), c_last = __builtin_amdgcn_readfirstlane(c_hi) - 1;
@@ -328,7 +339,7 @@ __global__ __launch_bounds__(kWxThreads, 1) void k_wgrad_bx_p2(const WxP p) {
         __syncthreads();
         auto step = [&](int t, int b) {
             fetch(t + 2 <= c_last ? t + 2 : c_last, b);     // (in front of the MFMAs: under them -- after the second -- measured 1 % slower)
-            bf8 fa[2][2][3], fb[2][2][3];
+            bf8 fa[2][2][3], fb[2][NTN][3];
             frags(b, 0, fa[0], fb[0]);
             mask_first(1 - b);
             __builtin_amdgcn_sched_barrier(0);
@@ -338,13 +349,13 @@ __global__ __launch_bounds__(kWxThreads, 1) void k_wgrad_bx_p2(const WxP p) {
 #pragma unroll
                 for (int tm = 0; tm < 2; ++tm)
 #pragma unroll
-                    for (int tn = 0; tn < 2; ++tn)
+                    for (int tn = 0; tn < NTN; ++tn)
 #pragma unroll
                         for (int pr = 0; pr < 6; ++pr) {
-                            const int i = ((st * 2 + tm) * 2 + tn) * 6 + pr;
+                            const int i = ((st * 2 + tm) * NTN + tn) * 6 + pr;
                             acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[st][tm][ta[pr]], fb[st][tn][tb[pr]], acc[tm][tn], 0, 0, 0);
-                            slice(i, 1 - b, 1 - b);
-                            if (i == 8) frags(b, 1, fa[1], fb[1]);
+                            if (i < 6 * (4 + NQB)) slice(i, 1 - b, 1 - b);
+                            if (i == (NB == 1 ? 8 : 24 * NB - 8)) frags(b, 1, fa[1], fb[1]);     // (NB 2: late, for the register budget)
                             __builtin_amdgcn_sched_barrier(0);
                         }
             __syncthreads();
@@ -359,8 +370,8 @@ __global__ __launch_bounds__(kWxThreads, 1) void k_wgrad_bx_p2(const WxP p) {
     const bool full = m0 + 128 <= p.Cout;
     const int row4 = p.Cin * 4;
 #pragma unroll
-    for (int tn = 0; tn < 2; ++tn) {
-        const int c = c0 + wn * 64 + tn * 32 + l31;
+    for (int tn = 0; tn < NTN; ++tn) {
+        const int c = c0 + wn * 64 * NB + tn * 32 + l31;
         const int vb = c < p.Cin ? c * 4 : kWxOut;
 #pragma unroll
         for (int tm = 0; tm < 2; ++tm) {
@@ -399,7 +410,7 @@ __global__ __launch_bounds__(256) void k_wgx_reduce(const float* __restrict__ pa
 constexpr size_t kWxPartCap = (size_t)64 << 20;
 // S pixel ranges: the chip holds 512 workgroups at a time (2 per CU); a workgroup pays about three chunk times of prologue and
 // epilogue, the slices are written once and read once
-inline int wx_pick_split(int tiles, int nch, size_t slice_bytes) {
+inline int wx_pick_split(int tiles, int nch, size_t slice_bytes, int nb = 1) {
     int best = 1;
     double best_cost = 1e30;
     const int smax = nch < 1024 ? nch : 1024;
@@ -411,7 +422,7 @@ inline int wx_pick_split(int tiles, int nch, size_t slice_bytes) {
 #else
         const long long rounds = (wg + 511) / 512;
 #endif
-        const double per = (double)((nch + S - 1) / S);
+        const double per = (double)nb * (double)((nch + S - 1) / S);       // (a chunk of a 128 x 256 tile: twice the MFMAs)
         const double cost = (double)rounds * (per + 3.0) * 2.0 + (double)S * (double)slice_bytes * 2.0 / 3e6;      // microseconds
         if (cost < best_cost) {
             best_cost = cost;
@@ -451,8 +462,19 @@ extern "C" int mas_conv_wgrad_bx(const float* x, const float* dy, int N, int Cin
     p.nch = N * p.cpp;
     p.mtiles = (Cout + 127) / 128;
     p.ctiles = (Cin + 127) / 128;
+    // the X side of the tile: 256 input channels where they come in whole pairs of 128-blocks AND the product has at least 64 tiles of
+    // 128 x 128 (1024 -> 2048, 512 <-> 2048: -3 ... -5 %; with fewer tiles the wide form loses 3 ... 18 % -- fewer, longer
+    // workgroups and more K ranges: gpurun_out/s57)
+    int nb = 1;
+#if WX_PIPE2
+    static const int nb_env = [] { const char* e = getenv("MAS_WGRAD_BX_NB"); return e ? atoi(e) : 0; }();      // (A/B: 1 = always 128 x 128, 2 = wide wherever possible)
+    if (p.ctiles % 2 == 0 && nb_env != 1 && (p.mtiles * p.ctiles >= 64 || nb_env == 2)) {
+        nb = 2;
+        p.ctiles /= 2;
+    }
+#endif
     const size_t slice = sizeof(float) * (size_t)Cout * Cin;
-    p.S = wx_pick_split(p.mtiles * p.ctiles, p.nch, slice);
+    p.S = wx_pick_split(p.mtiles * p.ctiles, p.nch, slice, nb);
     while (p.S > 1 && (size_t)p.S * slice > workspace_bytes) --p.S;
     if ((size_t)p.S * slice > workspace_bytes) return MAS_ERR_WORKSPACE;
     const size_t smem = (size_t)2 * kWxImg * 16;
@@ -460,7 +482,8 @@ extern "C" int mas_conv_wgrad_bx(const float* x, const float* dy, int N, int Cin
     const long long nblk = (long long)p.S * p.mtiles * p.ctiles;
     if (nblk <= 0 || nblk > 0x7fffffffLL) return MAS_ERR_SHAPE;
 #if WX_PIPE2
-    hipLaunchKernelGGL(k_wgrad_bx_p2, dim3((unsigned)nblk), dim3(kWxThreads), 0, st, p);
+    if (nb == 2) hipLaunchKernelGGL(k_wgrad_bx_p2<2>, dim3((unsigned)nblk), dim3(kWxThreads), 0, st, p);
+    else hipLaunchKernelGGL(k_wgrad_bx_p2<1>, dim3((unsigned)nblk), dim3(kWxThreads), 0, st, p);
 #else
     hipLaunchKernelGGL(k_wgrad_bx, dim3((unsigned)nblk), dim3(kWxThreads), smem, st, p);
 #endif
