@@ -8,6 +8,8 @@
 // proxies are wave-uniform operands.  The backward pass for the features is one more pass:
 //     dL/df = ( sum_k g_k p_k  -  (sum_k g_k logit_k) * f / n ) / n ,      n = max(|f|, eps)
 // (the proxy gradient is a [K x pixels] x [pixels x 256] GEMM and is left to hipBLASLt through torch.einsum).
+#include <cstdlib>
+
 #include "common.h"
 
 namespace {
@@ -41,7 +43,7 @@ __global__ __launch_bounds__(kThreads) void k_cosine_fwd(const float* __restrict
 // with IEEE semantics: every pixel's sums are the same fma chain, in channel order, as in k_cosine_fwd), four channels of
 // loads in flight per trip.  The one-pixel form above spends its time waiting for a single 4-B load per 21 fmas
 // (1.3 TB/s at [4,256,256,512]); this one is bound by the 2 x (K + 1) packed fmas per channel.
-template <int K>
+template <int K, int CF>                         // CF: channels of loads in flight per trip
 __global__ __launch_bounds__(kThreads) void k_cosine_fwd4(const float* __restrict__ f, const float* __restrict__ phat, int Ch, int HW,
                                                            float eps, float* __restrict__ logits, float* __restrict__ inv_norm) {
     const int p = (blockIdx.x * kThreads + threadIdx.x) * 4;
@@ -51,12 +53,12 @@ __global__ __launch_bounds__(kThreads) void k_cosine_fwd4(const float* __restric
     mas_v2f ssa = mas_splat(0.f), ssb = mas_splat(0.f), da[K], db[K];
 #pragma unroll
     for (int k = 0; k < K; ++k) { da[k] = mas_splat(0.f); db[k] = mas_splat(0.f); }
-    for (int c = 0; c < Ch; c += 4) {            // Ch % 4 == 0 (launcher)
-        float4 v[4];
+    for (int c = 0; c < Ch; c += CF) {           // Ch % CF == 0 (launcher)
+        float4 v[CF];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) v[u] = *reinterpret_cast<const float4*>(fp + (size_t)(c + u) * HW);
+        for (int u = 0; u < CF; ++u) v[u] = *reinterpret_cast<const float4*>(fp + (size_t)(c + u) * HW);
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
+        for (int u = 0; u < CF; ++u) {
             const mas_v2f va = {v[u].x, v[u].y}, vb = {v[u].z, v[u].w};
             ssa = mas_pk_fma(va, va, ssa);
             ssb = mas_pk_fma(vb, vb, ssb);
@@ -159,8 +161,14 @@ __global__ __launch_bounds__(kThreads) void k_cosine_bwd4(const float* __restric
 template <int K>
 int launch_fwd(const float* f, const float* phat, int N, int Ch, int HW, float eps, float* logits, float* inv_norm, hipStream_t st) {
     if (HW % 4 == 0 && Ch % 4 == 0 && (((uintptr_t)f | (uintptr_t)logits | (uintptr_t)inv_norm) & 15) == 0) {
-        hipLaunchKernelGGL((k_cosine_fwd4<K>), dim3((unsigned)((HW / 4 + kThreads - 1) / kThreads), (unsigned)N), dim3(kThreads), 0, st, f, phat, Ch,
-                           HW, eps, logits, inv_norm);
+        // eight channels of loads in flight per trip: 174 -> 152 us at [4,256,256,512], 122 -> 118 us at [4,256,192,192] (MAS_COSINE_CF=4: four)
+        static const bool cf8 = [] { const char* e = getenv("MAS_COSINE_CF"); return !(e && e[0] == '4'); }();
+        if (cf8 && Ch % 8 == 0)
+            hipLaunchKernelGGL((k_cosine_fwd4<K, 8>), dim3((unsigned)((HW / 4 + kThreads - 1) / kThreads), (unsigned)N), dim3(kThreads), 0, st, f, phat, Ch,
+                               HW, eps, logits, inv_norm);
+        else
+            hipLaunchKernelGGL((k_cosine_fwd4<K, 4>), dim3((unsigned)((HW / 4 + kThreads - 1) / kThreads), (unsigned)N), dim3(kThreads), 0, st, f, phat, Ch,
+                               HW, eps, logits, inv_norm);
         return mas_launch_status();
     }
     hipLaunchKernelGGL((k_cosine_fwd<K>), dim3((unsigned)((HW + kThreads - 1) / kThreads), (unsigned)N), dim3(kThreads), 0, st, f, phat, Ch, HW, eps,

@@ -21,13 +21,15 @@ worst, bad, ran = 0.0, 0, [0, 0, 0]
 for seed in range(seed0, seed0 + n):
     rs = np.random.RandomState(seed)
     k = int(rs.choice([1, 3]))
-    stride = int(rs.choice([1, 2])) if k == 1 else 1
-    dil = 1 if k == 1 else int(rs.choice([1, 2]))
+    stride = int(rs.choice([1, 2])) if k == 1 else (2 if rs.randint(4) == 0 else 1)       # (a quarter of the 3x3 draws: the strided form)
+    dil = 1 if (k == 1 or stride == 2) else int(rs.choice([1, 2]))
     cin = int(rs.choice([3, 8, 16, 20, 24, 40, 64, 72, 128, 256])) if k == 3 else int(rs.choice([16, 32, 48, 50, 64, 96, 160, 304, 512]))
+    if k == 3 and stride == 2:
+        cin = int(rs.choice([32, 64, 96, 128, 256]))
     cout = int(rs.choice([16, 48, 64, 80, 128, 192, 200, 256, 512]))
     N = int(rs.randint(1, 5))
     H, W = int(rs.randint(1, 140)), int(rs.randint(1, 200))
-    if k == 1 and stride == 2:
+    if stride == 2:
         H, W = 2 * int(rs.randint(1, 60)), 8 * int(rs.randint(1, 24))
     torch.manual_seed(seed)
     conv = nn.Conv2d(cin, cout, k, stride=stride, padding=dil if k == 3 else 0, dilation=dil, bias=False).cuda()
