@@ -273,6 +273,9 @@ F32_MFMA_PEAK_TF = 157.3        # dense f32 MFMA peak of MI355X (MI355X_MICROARC
 # `mfma_frac` <= 1); `f32_pipe_peak_TFLOPs` is printed beside it for reference only -- the f32 pipe alone could not reach the
 # achieved rate, so no fraction is formed against it.
 SPLIT_BF16_BOUND_TF = F32_MFMA_PEAK_TF * 16.0 / 6.0
+# (rounds 1-4 printed `mfma_frac` against the f32 peak; since round 5 it is the fraction of the split-bf16 bound.  Both ratios are printed
+#  under names that say which: compare `frac_of_f32_mfma_peak` with the rounds-1-4 `mfma_frac`.  The f32-pipe ratio may exceed 1.)
+MFMA_FRAC_IS = "frac_of_split_bf16_bound (since r05; r01-r04 lines quoted frac_of_f32_mfma_peak under this key)"
 MFMA_ARITH = ("f32 operands and f32 accumulation; layers marked hip_bx / '/bx' in layer_paths_per_step and the 1x1 / 3x3 stride-1 weight gradients run on "
               "v_mfma_f32_32x32x16_bf16 from exact three-term bf16 splits of both operands (six partial products, dropped terms <= 2^-23 "
               "of a product: csrc/bx_split.h), the others on v_mfma_f32_32x32x2_f32")
@@ -420,6 +423,9 @@ def train_iter_bench(args, dev, world, crop):
             "stream_k_error_word": sk_err,
             "mfma": {"flop_per_step": flop, "achieved_TFLOPs": flop / (it_ms * 1e-3) / 1e12, "peak_TFLOPs": SPLIT_BF16_BOUND_TF,
                      "mfma_frac": flop / (it_ms * 1e-3) / 1e12 / SPLIT_BF16_BOUND_TF,
+                     "frac_of_split_bf16_bound": flop / (it_ms * 1e-3) / 1e12 / SPLIT_BF16_BOUND_TF,
+                     "frac_of_f32_mfma_peak": flop / (it_ms * 1e-3) / 1e12 / F32_MFMA_PEAK_TF,
+                     "mfma_frac_is": MFMA_FRAC_IS,
                      "peak_is": "the matrix-core bound of f32 convolutions computed from three-term bf16 splits (16/6 x the f32 MFMA peak)",
                      "f32_pipe_peak_TFLOPs": F32_MFMA_PEAK_TF,
                      "arithmetic": MFMA_ARITH,
@@ -509,6 +515,9 @@ def acquisition_with_model_bench(args, dev, world):
             "ms_per_batch": ms, "forwards_per_image": 1, "layer_paths_per_step": paths,
             "mfma": {"flop_per_batch": flop, "achieved_TFLOPs": flop / (ms * 1e-3) / 1e12, "peak_TFLOPs": SPLIT_BF16_BOUND_TF,
                      "mfma_frac": flop / (ms * 1e-3) / 1e12 / SPLIT_BF16_BOUND_TF,
+                     "frac_of_split_bf16_bound": flop / (ms * 1e-3) / 1e12 / SPLIT_BF16_BOUND_TF,
+                     "frac_of_f32_mfma_peak": flop / (ms * 1e-3) / 1e12 / F32_MFMA_PEAK_TF,
+                     "mfma_frac_is": MFMA_FRAC_IS,
                      "peak_is": "the matrix-core bound of f32 convolutions computed from three-term bf16 splits (16/6 x the f32 MFMA peak)",
                      "f32_pipe_peak_TFLOPs": F32_MFMA_PEAK_TF,
                      "arithmetic": MFMA_ARITH,

@@ -148,6 +148,13 @@ def load():
     # resident before this library is mapped, otherwise two runtimes end up in the process and the second
     # one sees no device ("no ROCm-capable device is detected").
     import torch  # noqa: F401
+    # a variant build (tools/build_variant.sh, MAS_LIB) lives under build/, never beside the product library: a stale A/B library inside
+    # the package directory would travel with every snapshot and be one environment variable away from being the product
+    if os.environ.get("MAS_LIB"):
+        real = os.path.realpath(LIB_PATH)
+        if real.startswith(os.path.realpath(_HERE) + os.sep) and real != os.path.realpath(os.path.join(_HERE, "libmulactseg_hip.so")):
+            raise MulActSegHipError("MAS_LIB=%s points inside the package directory; variant builds belong under build/ "
+                                    "(tools/build_variant.sh)" % LIB_PATH)
     if not os.path.exists(LIB_PATH):
         raise MulActSegHipError(
             "libmulactseg_hip.so is not built (%s). Run `python -c 'import __graft_entry__ as g; g.build()'` "

@@ -360,9 +360,17 @@ class RegionActiveDataset:
                     _atomic_pickle(os.path.join(self.args.model_save_dir, fname), sample_region[:idx + 1])
                 break
         emptied = set()
+        psup = pool.suppix
         for key, row, gone, present in leaving.values():
             spx_path = key[2]
-            lst = pool.suppix[spx_path]
+            if isinstance(psup, LazySuppix) and isinstance(psup._raw(spx_path), _FromTable):
+                # a list nobody has built: it IS its row of the valid table, which the loop above has already edited (building it
+                # here would give the list AFTER the removals, and `gone` would be compared with what is left)
+                if not self._valid[row].any():
+                    dict.__delitem__(psup, spx_path)
+                    emptied.add(tuple(key))
+                continue
+            lst = psup[spx_path]
             if len(gone) < len(lst):
                 if len(gone) <= 4:                      # a handful: list.remove keeps the order and runs at C speed
                     for i in gone:
@@ -534,12 +542,13 @@ class RegionActiveDataset:
     # -- persistence ----------------------------------------------------------------------------
     def dump_datalist(self):
         self.wait_for_writes()
+        if not self._writes_files():        # every rank of a data-parallel run holds the same lists: rank 0 writes them (and only it builds the lazy ones)
+            return
         path = os.path.join(self.args.model_save_dir, 'datalist_%02d.pkl' % self.selection_iter)
-        with open(path, "wb") as f:
-            pickle.dump({'trg_label_im_idx': self.trg_label_dataset.im_idx,
-                         'trg_pool_im_idx': self.trg_pool_dataset.im_idx,
-                         'trg_label_suppix': self.trg_label_dataset.suppix,
-                         'trg_pool_suppix': self.trg_pool_dataset.suppix}, f)
+        _atomic_pickle(path, {'trg_label_im_idx': self.trg_label_dataset.im_idx,
+                              'trg_pool_im_idx': self.trg_pool_dataset.im_idx,
+                              'trg_label_suppix': self.trg_label_dataset.suppix,
+                              'trg_pool_suppix': self.trg_pool_dataset.suppix})
 
     def load_datalist(self, datalist_path=None):
         self.wait_for_writes()

@@ -1887,6 +1887,9 @@ class StreamKGaveUp(RuntimeError):
     (NaN).  Seen only when the GPU is shared with something that keeps CUs busy for seconds."""
 
 
+_SIDE_STREAMS = {}      # device -> the side stream of MAS_WGRAD_STREAM=side
+
+
 def _side_stream(dev):
     """The stream the weight gradients run on under MAS_WGRAD_STREAM=side (dW is a leaf of the backward graph; not the default:
     see _ConvTrain.backward)."""

@@ -267,6 +267,39 @@ def test_lists_nobody_reads_stay_arrays_and_still_equal_the_reference_loop(tmp_p
     assert pool.suppix == ref_pool['suppix'] and label.suppix == ref_label['suppix']
 
 
+def test_tuple_path_on_lists_nobody_has_built_equals_the_reference_loop(tmp_path):
+    """the tuple path of expand_training_set on pool lists LazySuppix has NOT built (pending() > 0).  Removing two
+    ids used to raise ValueError after half the state had been edited; removing 10 of 16 ids silently dropped the picture."""
+    import copy
+    from mulactseg_amd.dataloader.region_active_dataset import LazySuppix
+    args, names, mh, aset = _sets(tmp_path)
+    pool, label = aset.trg_pool_dataset, aset.trg_label_dataset
+    ref_pool = {'im_idx': copy.deepcopy(pool.im_idx), 'suppix': copy.deepcopy(pool.suppix)}
+    ref_label = {'im_idx': copy.deepcopy(label.im_idx), 'suppix': copy.deepcopy(label.suppix)}
+    ref_sel = np.zeros_like(pool.isselected)
+    index_of = lambda spx: label.id_to_index[spx.split('/')[-1].split('.')[0]]
+    aset.pool_valid_mask(args.nseg)
+    assert isinstance(pool.suppix, LazySuppix) and pool.suppix.pending() == 3
+    two = [(0.9, ','.join(names[1]), 3), (0.8, ','.join(names[1]), 9)]
+    ten = [(0.7 - 0.01 * i, ','.join(names[2]), i) for i in range(10)]
+    whole = [(0.5 - 0.01 * i, ','.join(names[0]), i) for i in range(2, args.nseg)]          # (0 and 1 are labelled from the start)
+    for rnd, order in enumerate([two, ten, whole]):
+        aset.selection_iter = rnd + 1
+        n_ref = _reference_loop(ref_pool, ref_label, ref_sel, index_of, mh, order, 10 ** 6)
+        assert aset.expand_training_set(order, 10 ** 6, 't') == n_ref
+        assert pool.suppix.pending() > 0                                # still nothing of the pool was built by the call itself
+        assert pool.im_idx == ref_pool['im_idx'] and list(pool.suppix) == list(ref_pool['suppix'])
+    assert names[0][2] not in pool.suppix and names[2][2] in pool.suppix
+    assert pool.suppix == ref_pool['suppix'] and label.suppix == ref_label['suppix']
+    assert pool.im_idx == ref_pool['im_idx'] and label.im_idx == ref_label['im_idx'] and np.array_equal(pool.isselected, ref_sel)
+    try:                                                                # an id that already left: raises BEFORE anything is edited
+        aset.expand_training_set([(1.0, ','.join(names[1]), 3)], 5, 't')
+        assert False
+    except ValueError:
+        pass
+    assert pool.suppix == ref_pool['suppix'] and label.suppix == ref_label['suppix']
+
+
 def test_lazy_suppix_reads_like_a_dict_of_lists():
     import copy
     import pickle

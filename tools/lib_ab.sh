@@ -1,10 +1,11 @@
 # A/B of library builds on the scan leg of bench.py in ONE GPU session (same box, same clocks):
-#   bash tools/lib_ab.sh libA.so libB.so ...     (names under mulactseg_amd/; each twice, interleaved)
+#   bash tools/lib_ab.sh libA.so libB.so ...     (names under build/variants/, or 'product' for the in-tree library; each twice, interleaved)
 set -u
 cd "${GRAFT_REPO_ROOT:-.}"
 for rep in 1 2; do
   for L in "$@"; do
-    MAS_LIB=$PWD/mulactseg_amd/$L python bench.py --no-cpu-baseline --no-pool --no-train --steps 200 --warmup 20 2>/dev/null | python -c "
+    if [ "$L" = product ]; then unset MAS_LIB; else export MAS_LIB=$PWD/build/variants/$L; fi
+    python bench.py --no-cpu-baseline --no-pool --no-train --steps 200 --warmup 20 2>/dev/null | python -c "
 import sys, json
 d = json.loads(sys.stdin.read().strip().splitlines()[-1])
 r = d['roofline']
