@@ -165,3 +165,46 @@ class DeviceTrainAugment:
 def get_device_transform(args):
     """The reference's ``'rescale_769_multi'`` training transform (``transform.py:67-89``) for resident data."""
     return DeviceTrainAugment(size=(768, 768), scale_range=(0.5, 2.0), pad_values=[args.ignore_idx, args.nseg])
+
+
+class DeviceResize(DeviceTrainAugment):
+    """The reference's deterministic transforms for pool / validation / evaluation pictures on the same kernel:
+    ``ExtResize((h, w))`` (``dataloader/__init__.py:124-136``: Cityscapes to 1024x2048 -- the identity for native pictures, every
+    bilinear weight is then exactly 1) or ``ExtResize(s)`` + ``ExtCenterCrop(s)`` (VOC, ``:156-170``: the shorter side to ``s``,
+    torchvision's ``int(s * long / short)`` for the other, crop origin ``int(round((side - s) / 2.))``), then to-tensor + normalise.
+    No random draw is consumed."""
+
+    def __init__(self, size, center_crop=None, pad_values=(255, 2048), **kw):
+        super().__init__(size=(1, 1), scale_range=(1.0, 1.0), pad_values=pad_values, **kw)
+        self.target = size
+        self.center_crop = center_crop
+
+    def geometry(self, H, W):
+        if isinstance(self.target, int):
+            s = int(self.target)
+            if W <= H:
+                tw, th = s, int(s * H / W)
+            else:
+                th, tw = s, int(s * W / H)
+        else:
+            th, tw = int(self.target[0]), int(self.target[1])
+        if self.center_crop is None:
+            return dict(scale=1.0, th=th, tw=tw, gap_y=0, gap_x=0, i=0, j=0, flip=False), (th, tw)
+        c = int(self.center_crop)
+        if th < c or tw < c:
+            raise ValueError("center crop %d larger than the resized picture %dx%d" % (c, th, tw))
+        return dict(scale=1.0, th=th, tw=tw, gap_y=0, gap_x=0, i=int(round((th - c) / 2.)), j=int(round((tw - c) / 2.)), flip=False), (c, c)
+
+    def __call__(self, img, maps=(), params=None):
+        p, self.size = self.geometry(int(img.shape[0]), int(img.shape[1]))
+        return super().__call__(img, maps, params=p)
+
+
+class DeviceResizeFlip(DeviceResize):
+    """``ExtResize(s)`` + ``ExtCenterCrop(s)`` + ``ExtRandomHorizontalFlip`` -- the VOC stage-2 training transform
+    (``transform_voc.py:52-61``, name ``rescale_769_nospx``): one ``random()`` draw per sample."""
+
+    def __call__(self, img, maps=(), params=None):
+        p, self.size = self.geometry(int(img.shape[0]), int(img.shape[1]))
+        p['flip'] = bool(self.rng.random() < 0.5)
+        return DeviceTrainAugment.__call__(self, img, maps, params=p)

@@ -99,6 +99,12 @@ class ResidentProvider:
 
     def _prepare(self):
         idx, new_epoch = self._draw()
+        # a file-backed dataset (picture_store.PictureStore) starts the decodes of the whole batch on its host threads first
+        base, sub = self.dataset, None
+        if isinstance(base, torch.utils.data.Subset):
+            base, sub = base.dataset, base.indices
+        if hasattr(base, 'prefetch'):
+            base.prefetch([i if sub is None else sub[i] for i in idx])
         if self._side is None:
             return collate_fn([self.dataset[i] for i in idx]), None, new_epoch
         self._side.wait_stream(torch.cuda.current_stream())       # resident tensors written on the main stream are visible

@@ -30,9 +30,13 @@ class ActiveTrainer(BaseTrainer):
         import torch.distributed as dist
         if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
             eval_dataset.im_idx = eval_dataset.im_idx[dist.get_rank()::dist.get_world_size()]
-        self.eval_dataset_loader = DataProvider(dataset=eval_dataset, batch_size=self.args.val_batch_size, shuffle=False,
-                                                num_workers=getattr(self.args, 'val_num_workers', 8), pin_memory=True,
-                                                drop_last=False)
+        if getattr(eval_dataset, 'device_resident', False):       # samples are made on the device (file-backed / resident datasets)
+            from ..dataloader.utils import ResidentProvider
+            self.eval_dataset_loader = ResidentProvider(eval_dataset, batch_size=self.args.val_batch_size, drop_last=False, shuffle=False)
+        else:
+            self.eval_dataset_loader = DataProvider(dataset=eval_dataset, batch_size=self.args.val_batch_size, shuffle=False,
+                                                    num_workers=getattr(self.args, 'val_num_workers', 8), pin_memory=True,
+                                                    drop_last=False)
         miou, table = self.inference(loader=self.eval_dataset_loader, prefix='evaluation')
         self.logger.info('[Evaluation Result]')
         self.logger.info('%s' % table)

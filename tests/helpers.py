@@ -206,3 +206,96 @@ def occupy_cus(blocks, lds_bytes, seconds, stream=None):
     from mulactseg_amd import _lib
     st = torch.cuda.current_stream() if stream is None else stream
     _lib.check(_test_lib().mas_test_occupy(int(blocks), int(lds_bytes), int(seconds * 1e8), st.cuda_stream), "mas_test_occupy")
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# a tiny Cityscapes-shaped directory tree in the reference's on-disk formats
+# ---------------------------------------------------------------------------------------------------------------------------
+CITY_TRAIN_IDS = [7, 8, 11, 12, 13, 17, 19, 20, 21, 22, 23, 24, 25, 26, 27, 28, 31, 32, 33]     # raw ids of the 19 training classes
+
+
+def write_cityscapes_tree(root, n=5, H=128, W=256, nseg=64, n_val=2, seed=0, trim=5):
+    """Writes pictures (``leftImg8bit/train/<city>/*_leftImg8bit.png``), raw label PNGs (``gtFine/train/<city>/*_gtFine_labelIds.png``),
+    superpixel pickles (``superpixel_seed/cityscapes/seeds_<nseg>/train/label/*.pkl`` = ``{'labels': int32 [H,W], 'valid_idxes': ...}``),
+    the multi-hot tensor + sizes (``.../gtFine_multi_tensor_trim_<k>x<k>/{multi_hot_cls,sp_size}.npy``), the target datalist
+    (``train_seed<nseg>_or.txt``: picture, ``gtFine_or/<stem>.npy``, superpixel file -- tab separated), the region dictionary
+    (``{spx path: [nseg, [missing ids]]}``) and a validation list (``val.txt``, whitespace separated, labelIds PNGs).
+    Returns a dict of the paths and the arrays that were written."""
+    import json
+    import os
+    import pickle
+    from PIL import Image
+    from mulactseg_amd import synth
+    rs = np.random.RandomState(seed)
+    cities = ['aachen', 'bochum']
+    out = {'root': str(root), 'pictures': [], 'raw_labels': [], 'train_ids': [], 'spx': [], 'stems': [], 'H': H, 'W': W, 'nseg': nseg, 'val_lines': []}
+    spx_dir = os.path.join(root, 'superpixel_seed/cityscapes/seeds_%d/train' % nseg)
+    os.makedirs(os.path.join(spx_dir, 'label'), exist_ok=True)
+    mt_dir = os.path.join(spx_dir, 'gtFine_multi_tensor_trim_%dx%d' % (trim, trim))
+    os.makedirs(mt_dir, exist_ok=True)
+    lines, region = [], {}
+    multi_hot = np.zeros((n, nseg, 20), dtype=np.uint8)
+    sizes = np.zeros((n, nseg), dtype=np.int32)
+    lut = np.full(256, 255, dtype=np.int64)
+    lut[CITY_TRAIN_IDS] = np.arange(19)
+    for k in range(n + n_val):
+        split = 'train' if k < n else 'val'
+        city = cities[k % 2]
+        stem = '%s_%06d_000019' % (city, k)
+        cls = synth.class_map(seed * 1000 + k, H, W, 19, blob=16)                       # training ids 0..18
+        raw = np.asarray(CITY_TRAIN_IDS, dtype=np.uint8)[cls]
+        raw[rs.uniform(size=raw.shape) < 0.04] = 3                                       # some "out of roi" pixels -> ignored (255)
+        pic = rs.randint(0, 256, size=(H, W, 3)).astype(np.uint8)
+        for sub in ('leftImg8bit', 'gtFine'):
+            os.makedirs(os.path.join(root, sub, split, city), exist_ok=True)
+        img_rel = 'leftImg8bit/%s/%s/%s_leftImg8bit.png' % (split, city, stem)
+        lbl_rel = 'gtFine/%s/%s/%s_gtFine_labelIds.png' % (split, city, stem)
+        Image.fromarray(pic).save(os.path.join(root, img_rel))
+        Image.fromarray(raw).save(os.path.join(root, lbl_rel))
+        if split == 'val':
+            out['val_lines'].append('%s %s %s' % (img_rel, lbl_rel, lbl_rel))
+            continue
+        spx = synth.superpixel_map(seed * 1000 + 500 + k, H, W, nseg).astype(np.int32)
+        spx_rel = 'superpixel_seed/cityscapes/seeds_%d/train/label/%s.pkl' % (nseg, stem)
+        with open(os.path.join(root, spx_rel), 'wb') as f:
+            pickle.dump({'labels': spx, 'valid_idxes': np.unique(spx)}, f)
+        tid = lut[raw]
+        col = np.where(tid == 255, 19, tid)
+        multi_hot[k, spx.reshape(-1), col.reshape(-1)] = 1
+        sizes[k] = np.bincount(spx.reshape(-1), minlength=nseg)[:nseg]
+        missing = sorted(set(range(nseg)) - set(np.unique(spx).tolist()))
+        region[spx_rel] = [nseg, missing]
+        lines.append('\t'.join([img_rel, 'superpixel_seed/cityscapes/seeds_%d/train/gtFine_or/%s.npy' % (nseg, stem), spx_rel]))
+        out['pictures'].append(pic), out['raw_labels'].append(raw), out['train_ids'].append(tid), out['spx'].append(spx), out['stems'].append(stem)
+    np.save(os.path.join(mt_dir, 'multi_hot_cls.npy'), multi_hot)
+    np.save(os.path.join(mt_dir, 'sp_size.npy'), sizes)
+    lists = os.path.join(root, 'lists')
+    os.makedirs(lists, exist_ok=True)
+    out['trg_datalist'] = os.path.join(lists, 'train_seed%d_or.txt' % nseg)
+    out['region_dict'] = os.path.join(lists, 'train_seed%d.dict' % nseg)
+    out['val_datalist'] = os.path.join(lists, 'val.txt')
+    with open(out['trg_datalist'], 'w') as f:
+        f.write('\n'.join(lines) + '\n')
+    with open(out['region_dict'], 'w') as f:
+        json.dump(region, f)
+    with open(out['val_datalist'], 'w') as f:
+        f.write('\n'.join(out['val_lines']) + '\n')
+    out['multi_hot'], out['sp_size'], out['lines'] = multi_hot, sizes, lines
+    return out
+
+
+def cityscapes_tree_args(tree, save_dir, extra=()):
+    """The flags of the stage-1 production run (``script/open_source/train_city_mul_res50.sh``) pointed at ``tree``."""
+    from mulactseg_amd.utils.common import get_parser
+    a = get_parser().parse_args([
+        '-m', 'deeplabv3pluswn_resnet50deepstem', '--separable_conv', '--method', 'active_joint_multi_predignore_lossdecomp',
+        '--active_method', 'my_bvsb_predclsbal_pwr_banignore', '--cls_weight_coeff', '6.0', '--or_labeling', '--fair_counting',
+        '--loss_type', 'joint_multi_loss', '--nseg', str(tree['nseg']), '--scheduler', 'poly', '--train_lr', '0.00002',
+        '--train_transform', 'rescale_769_multi_notrg', '--loader', 'region_cityscapes_or_tensor', '--multi_ce_temp', '0.1',
+        '--group_ce_temp', '0.1', '--ce_temp', '0.1', '--coeff', '16.0', '--coeff_mc', '8.0', '--coeff_gm', '1.0',
+        '--trim_kernel_size', '5', '--trim_multihot_boundary', '--trg_data_dir', tree['root'], '--trg_datalist', tree['trg_datalist'],
+        '--region_dict', tree['region_dict'], '--val_data_dir', tree['root'], '--val_datalist', tree['val_datalist'],
+        '--train_batch_size', '2', '--val_batch_size', '2', '--num_workers', '0', '--val_num_workers', '0', '--finetune_itrs', '2',
+        '--val_period', '2', '--log_period', '1', '--active_selection_size', '40', '-p', str(save_dir)] + list(extra))
+    a.pretrained_backbone = False
+    return a
