@@ -98,12 +98,33 @@ def _dist():
     return dist if dist.is_available() and dist.is_initialized() else None
 
 
+def device_sync():
+    """Drain the GPU; nothing to do when the host logic of a leg is rehearsed on the CPU (tests/test_bench_world2_cpu.py: gloo,
+    the oracle-backed stand-in for the HIP backend)."""
+    if torch.cuda.is_available():
+        torch.cuda.synchronize()
+
+
+class _NoEvent:
+    """torch.cuda.Event for a CPU rehearsal: records nothing."""
+
+    def record(self, *a):
+        pass
+
+    def elapsed_time(self, other):
+        return 0.0
+
+
+def timing_event(dev):
+    return torch.cuda.Event(enable_timing=True) if torch.device(dev).type == 'cuda' else _NoEvent()
+
+
 def fence():
-    torch.cuda.synchronize()
+    device_sync()
     d = _dist()
     if d is not None and d.get_world_size() > 1:
         d.barrier()
-        torch.cuda.synchronize()
+        device_sync()
 
 
 def max_over_ranks(seconds, dev):
@@ -136,12 +157,13 @@ class ScanRound:
         self.rank_t = torch.arange(self.n_img, dtype=torch.int32, device=dev)
         self.budget = max(1, int(POOL_CLICKS * self.n_img / POOL_IMAGES))
         self.events = []
-        self.tail_ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+        self.dev = dev
+        self.tail_ev = (timing_event(dev), timing_event(dev))
 
     def scan(self, i, timed):
         z, spx = self.bufs[i % len(self.bufs)]
         if timed:
-            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a, b = timing_event(self.dev), timing_event(self.dev)
             a.record()
         self.rnd.add_single_pass(i * self.args.batch, z, spx)
         if timed:
@@ -167,6 +189,29 @@ class ScanRound:
         return self.tail()
 
 
+def timed_scan_round(args, dev, rank, world, backend, bufs, ramp=None):
+    """The primary leg: W warm-up batches, then EXACTLY K timed batches of this rank's shard + the round's tail, bracketed by a
+    barrier + synchronize on both sides; the time is the MAX over ranks.  -> (the timed ScanRound, regions selected, seconds).
+    (tests/test_bench_world2_cpu.py runs this function under gloo with world 2 against world 1.)"""
+    if args.warmup:
+        ScanRound(args, dev, rank, world, backend, bufs, args.warmup).run(False)
+    timed = ScanRound(args, dev, rank, world, backend, bufs, args.steps)
+    timed.rnd.hw = args.height * args.width
+    timed.tail()            # untimed, on the still-empty accumulators: the timed round's buffers come out of torch's caching
+    #                         allocator instead of hipMalloc (a long-lived trainer process is in that state from round 2 on)
+    # untimed clock ramp, LAST thing before the timed region: the first ~50 launches after an idle period run ~20 % slower than the
+    # steady state (power management), and the set-up above (allocations, the warm-up round's tail with its host read) leaves the
+    # GPU idle for milliseconds.  Until round 4 the ramp ran BEFORE that set-up: the driver's 20 timed steps (3.2 ms) then started
+    # on a GPU that had just idled and read 166 us per scan where 200 steps read 153 (same code, same box).
+    if ramp is not None:
+        ramp()
+    fence()
+    t0 = time.perf_counter()
+    n_selected = timed.run(True)
+    fence()
+    return timed, n_selected, max_over_ranks(time.perf_counter() - t0, dev)
+
+
 # ------------------------------------------------------------------------------------------------------------------
 # fixed-pool round (strong scaling) through the selector plugin
 # ------------------------------------------------------------------------------------------------------------------
@@ -188,11 +233,13 @@ class ModelOnRotatingPictures(torch.nn.Module):
         return self.net(self.pictures[self.k % self.pictures.shape[0]][:indices.shape[0]])
 
 
-def pool_round_bench(args, dev, rank, world, with_model, n_images=POOL_IMAGES, clicks=POOL_CLICKS):
+def pool_round_bench(args, dev, rank, world, with_model, n_images=POOL_IMAGES, clicks=POOL_CLICKS, backend=None, save_dir=None):
     """BASELINE.json config 3 at its real size: 2 975 pictures x 2 048 superpixels, 100 000 clicks (fair counting), through
     RegionSelector.select_next_batch -- scan (+ model forward), two exchanges, device class weights, finalize + ban, K4 on
     6.09 M keys, RegionActiveDataset bookkeeping.  The pool is sharded over the ranks: strong scaling.
-    (n_images / clicks: the warm-up round on a small pool that precedes the timed one.)"""
+    (n_images / clicks: the warm-up round on a small pool that precedes the timed one.  backend / save_dir: the CPU rehearsal of this
+    function's host logic under gloo, tests/test_bench_world2_cpu.py -- the selector's HIP backend replaced by the oracle-backed
+    stand-in, the run directory named by the caller so that it can read the selection pickle.)"""
     from mulactseg_amd.active_selection import my_bvsb_predclsbal_pwr_banignore as banignore
     from mulactseg_amd.active_selection.engine import ShardPlan
     from mulactseg_amd.dataloader import RegionActiveDataset
@@ -207,7 +254,7 @@ def pool_round_bench(args, dev, rank, world, with_model, n_images=POOL_IMAGES, c
                                       B, H, W, dev)
     else:
         net = LogitSource(C, H, W, dev, nbuf=B + 2, window=(B, plan.batch_lo))        # three distinct resident batches, zero-copy
-    tmp = tempfile.mkdtemp(prefix="mas_pool_r%d_" % rank)
+    tmp = save_dir if save_dir is not None else tempfile.mkdtemp(prefix="mas_pool_r%d_" % rank)
     a = types.SimpleNamespace(val_batch_size=B, val_num_workers=0, nseg=S, active_method='pixbal', num_classes=C - 1, ce_temp=0.1,
                               cls_weight_coeff=6.0, method='active_joint_multi_predignore_lossdecomp', save_scores=False,
                               fair_counting=True, or_labeling=True, model_save_dir=tmp, finetune_itrs=1,
@@ -217,18 +264,20 @@ def pool_round_bench(args, dev, rank, world, with_model, n_images=POOL_IMAGES, c
     class Timed(banignore.RegionSelector):
         def calculate_scores_tensor(self, trainer, pool_set, want_hist=False):
             out = super().calculate_scores_tensor(trainer, pool_set, want_hist)
-            torch.cuda.synchronize()
+            device_sync()
             marks['scored'] = time.perf_counter()
             return out
 
     sel = Timed(a)
+    if backend is not None:
+        sel.backend = backend
     trainer = types.SimpleNamespace(net=net, device=dev, model_save_dir=tmp, selection_iter=1)
     active = RegionActiveDataset(a, pool, labels)
     active.selection_iter = 1
     expand = active.expand_training_set
 
     def timed_expand(*x, **k):
-        torch.cuda.synchronize()
+        device_sync()
         marks['selected'] = time.perf_counter()
         return expand(*x, **k)
     active.expand_training_set = timed_expand
@@ -796,24 +845,11 @@ def main():
     p0 = torch.zeros((B, C), dtype=torch.int64, device=dev)
     c0 = torch.zeros((B, S, C), dtype=torch.int64, device=dev)
     h0 = torch.zeros((B, S, C), dtype=torch.int32, device=dev)
-    if args.warmup:
-        ScanRound(args, dev, rank, world, backend, bufs, args.warmup).run(False)
-    timed = ScanRound(args, dev, rank, world, backend, bufs, args.steps)
-    timed.rnd.hw = H * W
-    timed.tail()            # untimed, on the still-empty accumulators: the timed round's buffers come out of torch's caching
-    #                         allocator instead of hipMalloc (a long-lived trainer process is in that state from round 2 on)
-    # untimed clock ramp, LAST thing before the timed region: the first ~50 launches after an idle period run ~20 % slower than the
-    # steady state (power management), and the set-up above (allocations, the warm-up round's tail with its host read) leaves the
-    # GPU idle for milliseconds.  Until round 4 the ramp ran BEFORE that set-up: the driver's 20 timed steps (3.2 ms) then started
-    # on a GPU that had just idled and read 166 us per scan where 200 steps read 153 (same code, same box).
-    for k in range(args.ramp):
-        z, spx = bufs[k % args.nbuf]
-        ops.single_pass_accum(z, spx, S, invT, prob_sum=p0, class_sum=c0, hist=h0)
-    fence()
-    t0 = time.perf_counter()
-    n_selected = timed.run(True)
-    fence()
-    dt = max_over_ranks(time.perf_counter() - t0, dev)
+    def ramp():
+        for k in range(args.ramp):
+            z, spx = bufs[k % args.nbuf]
+            ops.single_pass_accum(z, spx, S, invT, prob_sum=p0, class_sum=c0, hist=h0)
+    timed, n_selected, dt = timed_scan_round(args, dev, rank, world, backend, bufs, ramp)
 
     sp_ms = float(np.mean([a.elapsed_time(b) for a, b in timed.events]))
     tail_ms = float(timed.tail_ev[0].elapsed_time(timed.tail_ev[1]))

@@ -492,6 +492,19 @@ def gen_g10():
     loss classes) under the reference's own get_optim (trainer/base.py:64-69, AdamW with the classifier at cls_lr_scale x lr) and
     PolyLR (utils/scheduler.py:5-14).  Stored: logits and losses of both steps, a cut of every parameter gradient of step 1, every
     BatchNorm buffer after step 1 and after step 2, a cut of every parameter after step 2, the learning rates."""
+    _gen_train("g10", 101, 4, 20, 129, 161, 48, full=True)
+
+
+def gen_g11():
+    """The WELL-CONDITIONED twin of G10: the same two steps on a [4,3,513,513] batch -- 33 x 33 maps at stride 16,
+    so every BatchNorm of the deep layers averages over 4 x 1 089 = 4 356 samples per channel (G10: 4 x 99) and the f32 rounding of the
+    convolutions is no longer amplified by noisy batch statistics.  The logit tensors are too large to store: kept are a strided cut
+    (every third pixel of the quarter-resolution map, every twelfth of the full-resolution one) and the float64 norm of every
+    (picture, class) plane of both, which pins what the cut does not sample."""
+    _gen_train("g11", 211, 4, 20, 513, 513, 256, full=False)
+
+
+def _gen_train(tag, seed, N, C, H, W, S, full):
     import models as ref_models
     from models.segmentation.modeling import deeplabv3pluswn_resnet50deepstem
     from models.segmentation import convert_to_separable_conv
@@ -499,7 +512,7 @@ def gen_g10():
     from utils.scheduler import PolyLR
     from trainer.active_joint_multi_predignore_lossdecomp import OnehotCEMultihotChoice
     from trainer.active_joint_multi_predignore_mclossablation2 import GroupMultiLabelCE_onlymulti
-    seed, N, C, H, W, S, T = 101, 4, 20, 129, 161, 48, 0.1
+    T = 0.1
     net = deeplabv3pluswn_resnet50deepstem(num_classes=C, output_stride=16, pretrained_backbone=False)
     convert_to_separable_conv(net.classifier)
     ref_models.set_bn_momentum(net.backbone, momentum=0.1)
@@ -535,8 +548,14 @@ def gen_g10():
         ce, mc = pos_fn(preds, tt, ts, tm)
         loss = 16.0 * ce + 8.0 * mc + 1.0 * group
         loss.backward()
-        out['quarter%d' % step] = quarter['q'].numpy()
-        out['full_sub%d' % step] = preds.detach()[:, :, ::3, ::3].numpy()
+        if full:
+            out['quarter%d' % step] = quarter['q'].numpy()
+            out['full_sub%d' % step] = preds.detach()[:, :, ::3, ::3].numpy()
+        else:
+            out['quarter_cut%d' % step] = quarter['q'][:, :, ::3, ::3].numpy().copy()
+            out['quarter_norm%d' % step] = quarter['q'].double().flatten(2).norm(dim=2).numpy()
+            out['full_cut%d' % step] = preds.detach()[:, :, ::12, ::12].numpy().copy()
+            out['full_norm%d' % step] = preds.detach().double().flatten(2).norm(dim=2).numpy()
         out['losses%d' % step] = np.array([float(loss), float(ce), float(mc), float(group)], dtype=np.float32)
         if step == 1:
             for i, (n, p) in enumerate(net.named_parameters()):
@@ -550,14 +569,18 @@ def gen_g10():
     for i, (n, p) in enumerate(net.named_parameters()):
         out['param_%03d' % i] = sub256(p.detach().numpy())
     hook.remove()
-    np.savez_compressed(os.path.join(OUT, "g10_train.npz"), **out)
-    print("g10: losses", out['losses1'], out['losses2'], "lrs", out['lrs1'], out['lrs2'], "params", len(names), "dropouts", n_drop)
+    np.savez_compressed(os.path.join(OUT, "%s_train.npz" % tag), **out)
+    print(tag + ": losses", out['losses1'], out['losses2'], "lrs", out['lrs1'], out['lrs2'], "params", len(names), "dropouts", n_drop)
 
 
 if __name__ == "__main__":
     refshim.install()
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(1)      # the goldens do not depend on it; keeps the run reproducible
+    if len(sys.argv) > 1:         # python oracle/gen_golden.py g11 ... : only the named fixtures
+        for name in sys.argv[1:]:
+            globals()["gen_" + name]()
+        sys.exit(0)
     gen_g1()
     gen_g2()
     gen_g3()
@@ -568,5 +591,6 @@ if __name__ == "__main__":
     gen_g8()
     gen_g9()
     gen_g10()
+    gen_g11()
     for f in sorted(os.listdir(OUT)):
         print(f, os.path.getsize(os.path.join(OUT, f)))

@@ -75,7 +75,8 @@ class OracleBackend:
 
     def select(self, scores, valid, img_rank, img_of_rank, region_cost, budget, max_out):
         # reference semantics: Python tuple sort with the rank standing in for the path string
-        s, v = scores.numpy(), valid.numpy()
+        s = scores.numpy()
+        v = np.ones(s.shape, dtype=bool) if valid is None else valid.numpy()        # (None: every region is still in the pool)
         rank = img_rank.numpy()
         tuples = [(float(s[i, r]), int(rank[i]), r) for i in range(s.shape[0]) for r in range(s.shape[1]) if v[i, r]]
         inv = img_of_rank.numpy()
@@ -89,7 +90,8 @@ class OracleBackend:
     def select_sharded(self, plan, scores, valid, img_rank, img_of_rank, region_cost, budget, max_out):
         """The sharded K4 of engine.select_regions restated on tuples: local head of max_out regions, all-gather, merged walk."""
         import torch.distributed as dist
-        s, v = scores.numpy(), valid.numpy()
+        s = scores.numpy()
+        v = np.ones(s.shape, dtype=bool) if valid is None else valid.numpy()
         rank = img_rank.numpy()
         local = sorted(((float(s[i, r]), int(rank[i]), r) for i in range(plan.img_lo, plan.img_hi) for r in range(s.shape[1]) if v[i, r]),
                        reverse=True)[:max_out]

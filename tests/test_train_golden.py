@@ -28,6 +28,28 @@ from mulactseg_amd import synth
 from mulactseg_amd.models import get_model
 
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "g10_train.npz")
+# G11: the same two steps on [4,3,513,513] (oracle/gen_golden.py:gen_g11) -- 33 x 33 maps at stride 16, every deep BatchNorm averages
+# over 4 356 samples per channel: the WELL-CONDITIONED fixture, held to absolute bars (no vendor library as arbiter).  The logit
+# tensors are stored as strided cuts + the float64 norm of every (picture, class) plane.
+GOLDEN11 = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "g11_train.npz")
+
+
+def _logit_dev(g, step, quarter, full=None):
+    """max |difference| of the step's logits from the fixture, whichever way it stores them; for the cut form also the worst relative
+    deviation of the per-plane norms (what the cut does not sample)."""
+    if 'quarter%d' % step in g.files:
+        d = float(np.abs(quarter - g['quarter%d' % step]).max())
+        if full is not None:
+            d = max(d, float(np.abs(full[:, :, ::3, ::3] - g['full_sub%d' % step]).max()))
+        return d, 0.0
+    d = float(np.abs(quarter[:, :, ::3, ::3] - g['quarter_cut%d' % step]).max())
+    nq = np.sqrt((quarter.astype(np.float64) ** 2).reshape(quarter.shape[0], quarter.shape[1], -1).sum(axis=2))
+    rel = float(np.abs(nq / g['quarter_norm%d' % step] - 1.0).max())
+    if full is not None:
+        d = max(d, float(np.abs(full[:, :, ::12, ::12] - g['full_cut%d' % step]).max()))
+        nf = np.sqrt((full.astype(np.float64) ** 2).reshape(full.shape[0], full.shape[1], -1).sum(axis=2))
+        rel = max(rel, float(np.abs(nf / g['full_norm%d' % step] - 1.0).max()))
+    return d, rel
 
 
 def sub256(a):
@@ -119,21 +141,21 @@ def test_training_mode_network_and_two_optimizer_steps_match_the_reference_cpu()
         torch.set_num_threads(threads)
 
 
-def _two_steps_cpu(g, x, tgt, spx, msk, port):
+def _two_steps_cpu(g, x, tgt, spx, msk, port, steps=(1, 2), tol=1e-5):
     net, opt, sched = _build(g, 'cpu')
     xt, tt, ts, tm = torch.from_numpy(x), torch.from_numpy(tgt), torch.from_numpy(spx), torch.from_numpy(msk)
     S, T = int(g['S']), float(g['temp'])
     quarter = {}
     net.classifier.register_forward_hook(lambda m, i, o: quarter.__setitem__('q', o.detach()))
-    for step in (1, 2):
+    for step in steps:
         opt.zero_grad()
         preds = net(xt)
         group = port.group_max_ce(preds, tt, ts, tm, S, T, 'onlymulti')
         ce, mc = port.merged_positive_ce(preds, tt, ts, tm, T, 'decomp')
         loss = 16.0 * ce + 8.0 * mc + 1.0 * group
         loss.backward()
-        assert float(np.abs(quarter['q'].numpy() - g['quarter%d' % step]).max()) <= 1e-5
-        assert float(np.abs(preds.detach()[:, :, ::3, ::3].numpy() - g['full_sub%d' % step]).max()) <= 1e-5
+        d, rel = _logit_dev(g, step, quarter['q'].numpy(), preds.detach().numpy())
+        assert d <= tol and rel <= tol, ("logits of step %d" % step, d, rel)
         got = np.array([float(loss.detach()), float(ce.detach()), float(mc.detach()), float(group.detach())], dtype=np.float32)
         assert np.allclose(got, g['losses%d' % step], rtol=2e-5, atol=0), (got, g['losses%d' % step])
         if step == 1:
@@ -142,9 +164,37 @@ def _two_steps_cpu(g, x, tgt, spx, msk, port):
         opt.step()
         sched.step()
         assert [pg['lr'] for pg in opt.param_groups] == list(g['lrs%d' % step])              # poly schedule, both groups
-        _compare_buffers(g, net, step, 1e-5)
-    worst = max(float(np.abs(sub256(p.detach().numpy()) - g['param_%03d' % i]).max()) for i, (n, p) in enumerate(net.named_parameters()))
-    assert worst <= 1e-6, worst
+        _compare_buffers(g, net, step, tol)
+    if tuple(steps) == (1, 2):
+        worst = max(float(np.abs(sub256(p.detach().numpy()) - g['param_%03d' % i]).max()) for i, (n, p) in enumerate(net.named_parameters()))
+        assert worst <= 1e-6, worst
+
+
+# What the reference's OWN f32 arithmetic does to this step when only its summation order changes (this package's modules as plain
+# PyTorch ops reproduce the fixture bit for bit at one host thread; the same code at 8 threads -- ATen blocks its sums differently --
+# measured in the build container, tools/g11_probe.py):
+#   step-1 logits 1.1e-5 (plane norms 1.7e-5), losses 2.2e-7 relative, gradient cuts 8.2e-3 relative L2 (worst layer 9.8e-3),
+#   gradient norms 1.9e-3.
+# The gradient of this objective is chaotic in f32 even at 513 x 513: the group loss back-propagates through the arg-max pixel of
+# every (superpixel, class) at temperature 0.1 and through the ReLU / max-pool gates of a randomly initialised 50-layer network.  The
+# reference's self-deviation is therefore the yardstick for the gradient bars below -- not a vendor library.
+G11_SELF = {'logits': 1.1e-5, 'grads': 8.2e-3, 'gnorm': 1.9e-3}
+
+
+def test_well_conditioned_fixture_g11_step_one_cpu():
+    """G11 on the host, one thread (as the fixture was generated): step 1 of the [4,3,513,513] fixture -- forward, losses, every
+    gradient cut and norm, the AdamW / PolyLR step, the running statistics -- with this package's modules as plain PyTorch ops and
+    the losses of oracle/port.py.  Observed: every quantity equal to the fixture bit for bit."""
+    from oracle import port
+    g = np.load(GOLDEN11)
+    x, tgt, spx, msk = _inputs(g)
+    assert (int(g['H']), int(g['W'])) == (513, 513)
+    threads = torch.get_num_threads()
+    torch.set_num_threads(1)
+    try:
+        _two_steps_cpu(g, x, tgt, spx, msk, port, steps=(1,), tol=1e-6)
+    finally:
+        torch.set_num_threads(threads)
 
 
 def _two_steps_gpu(g, mode):
@@ -169,7 +219,7 @@ def _two_steps_gpu(g, mode):
             total, group, ce, mc = crit.weighted_lowres(zq, (H, W), tt, ts, tm, 16.0, 8.0, 1.0)
             total.backward()
             out['paths%d' % step] = deeplab.path_report(reset=True)
-            out['logits%d' % step] = float(np.abs(zq.detach().cpu().numpy() - g['quarter%d' % step]).max())
+            out['logits%d' % step], out['logit_norms%d' % step] = _logit_dev(g, step, zq.detach().cpu().numpy())
             if step == 1:
                 out['zq1'] = zq.detach().cpu().numpy()
             got = np.array([float(total.detach()), float(ce), float(mc), float(group)], dtype=np.float64)
@@ -244,3 +294,41 @@ def test_training_mode_network_and_two_optimizer_steps_match_the_reference_gpu()
     #  moves its parameter by 2 lr; the step-2 loss then sits 1.2e-3 ... 1.9e-3 from the fixture on either path, run by run)
     assert own['losses2'] <= max(1e-3, 2.0 * ref['losses2']), (own['losses2'], ref['losses2'])
     assert own['buffers2'] <= max(1e-4, 1.5 * ref['buffers2']), (own['buffers2'], ref['buffers2'])
+
+
+@pytest.mark.gpu
+def test_well_conditioned_fixture_g11_on_the_gpu_absolute_bars():
+    """the production path (own convolutions, fused BatchNorm, fused quarter-resolution loss scans, fused AdamW) on
+    the well-conditioned fixture, with NO vendor library in the loop.  The arbiter for the logits is exact arithmetic: the same
+    forward in float64 on the host.  Measured (profiles/r06/g11_layers.md, module by module): this randomly initialised 50-layer
+    network amplifies rounding by ~1.27x per block whatever the implementation -- the reference's own f32 logits sit 6.5e-5 (cut;
+    8.1e-5 whole tensor) from exact arithmetic, the own kernels 1.1e-4, i.e. 1.3x the reference's distance at every depth from the
+    first block on; two f32 implementations that are each ~1e-4 from exact cannot be 1e-4 from each other (observed 1.85e-4).
+    Bars: own-vs-float64 <= 1.75 x reference-vs-float64 and <= 1.5e-4 absolute; own-vs-fixture <= 2.5e-4; step-1 losses and
+    running statistics <= 1e-4 (the north-star tolerance; observed 8e-6 / 3.3e-5); step-1 gradients within 5x (cuts) / 10x (norms)
+    of the reference's own self-deviation G11_SELF (observed 3.2e-2 = 3.9x; 1.1e-2 = 5.8x); after the AdamW step (first update =
+    lr * sign(g) for every element: each near-zero gradient whose sign a rounding flips moves its parameter by 2 lr) step-2 logits
+    <= 3e-2, losses <= 2e-3, every parameter within 4 lr of the fixture."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    g = np.load(GOLDEN11)
+    own = _two_steps_gpu(g, "own")
+    zq_own = own.pop('zq1')
+    print("G11 on the GPU, own kernels:", {k: v for k, v in own.items() if not k.startswith('paths')})
+    x, _, _, _ = _inputs(g)
+    net64, _, _ = _build(g, 'cpu')
+    with torch.no_grad():
+        zq64 = net64.double()(torch.from_numpy(x).double(), lowres=True).numpy()
+    d_fix = float(np.abs(g['quarter_cut1'].astype(np.float64) - zq64[:, :, ::3, ::3]).max())
+    d_own = float(np.abs(zq_own.astype(np.float64) - zq64).max())
+    print("G11 step-1 logits against the float64 forward: fixture (reference, f32; cut) %.3g, own kernels (whole tensor) %.3g" % (d_fix, d_own))
+    assert ("train:fdw" in own["paths1"]["conv_bn_act"] or "train:fdw/bx" in own["paths1"]["conv_bn_act"]) and "miopen+bn" not in own["paths1"]["conv_bn_act"], own["paths1"]
+    assert not any(k.startswith("train:-") for k in own["paths1"]["conv_bn_act"]), own["paths1"]      # no forward product on a vendor library
+    assert own['sk_error'] == 0
+    assert d_own <= 1.75 * d_fix and d_own <= 1.5e-4, (d_own, d_fix)
+    assert own['logits1'] <= 2.5e-4 and own['logit_norms1'] <= 4e-4, own
+    assert own['losses1'] <= 1e-4 and own['buffers1'] <= 1e-4, own
+    assert own['grads'] <= 5 * G11_SELF['grads'], own['grads']
+    assert own['gnorm'][0] <= 10 * G11_SELF['gnorm'], own['gnorm']
+    assert own['update_worst_in_lr'] <= 4.0, own
+    assert own['logits2'] <= 3e-2 and own['losses2'] <= 2e-3 and own['buffers2'] <= 3e-2, own
