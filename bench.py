@@ -442,8 +442,12 @@ def train_iter_bench(args, dev, world, crop):
     loss_gpu_ms, low_gpu_ms = gpu_time(full_raw), gpu_time(low_raw)
 
     net = get_model('deeplabv3pluswn_resnet50deepstem', C, 16, True, pretrained_backbone=False).to(dev).train()
-    opt = torch.optim.AdamW([{'params': net.backbone.parameters(), 'lr': 2e-5},
-                             {'params': net.classifier.parameters(), 'lr': 2e-4}], lr=2e-5, weight_decay=1e-5, fused=True)
+    groups = [{'params': list(net.backbone.parameters()), 'lr': 2e-5}, {'params': list(net.classifier.parameters()), 'lr': 2e-4}]
+    if os.environ.get("MAS_ADAMW", "own") == "own":       # what trainer/base.py:get_optim builds on the GPU (csrc/optim.hip: one launch)
+        from mulactseg_amd.utils.optim import FusedAdamW
+        opt = FusedAdamW(groups, lr=2e-5, weight_decay=1e-5)
+    else:
+        opt = torch.optim.AdamW(groups, lr=2e-5, weight_decay=1e-5, fused=True)
     if _dist() is not None:       # data parallel as the trainers run it: gradients all-reduced over RCCL
         net = torch.nn.parallel.DistributedDataParallel(net, device_ids=[dev.index], output_device=dev.index)
     images = torch.randn((N, 3, crop, crop), generator=g, device=dev)

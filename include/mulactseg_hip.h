@@ -53,7 +53,7 @@ extern "C" {
  * mas_single_pass_lowres_generic switch; mas_test_occupy moved to the test-support library; the BatchNorm-fused forms of
  * mas_conv_bx_fwd); 6 = role 2 of mas_conv_bx_pack / _packed_bytes / _pack_job and ksize 3 at stride 2 in mas_conv_bx_supported /
  * mas_conv_bx_fwd (a library of version 5 answers "unsupported" to both). */
-#define MAS_ABI_VERSION 6
+#define MAS_ABI_VERSION 7
 int mas_abi_version(void);
 const char* mas_error_string(int code);
 
@@ -634,6 +634,23 @@ int mas_conv_wgrad(const float* x, const float* dy, int N, int Cin, int H, int W
  * (scale / shift, both or neither) and ReLU in the epilogue.  Cout % 16 == 0, W % 8 == 0, 16-byte aligned tensors. */
 int mas_stem_conv_fwd(const float* x, const float* w, int N, int H, int W, int Cout, const float* scale, const float* shift, int relu,
                       float* y, void* stream);
+
+/* =============================================================================================
+ * AdamW over all parameter tensors of the model in ONE launch -- the optimizer of trainer/base.py:64-66
+ * (`optim.AdamW(params=[backbone @ lr, classifier @ cls_lr_scale * lr], weight_decay=wd)`, torch 1.11's single-tensor update:
+ * p *= 1 - lr wd;  m = m b1 + g (1 - b1);  v = v b2 + (1 - b2) g g;  p -= lr / (1 - b1^t) * m / (sqrt(v) / sqrt(1 - b2^t) + eps), f32, every
+ * operation rounded separately).  One job record per parameter tensor (mas_adamw_job fills a host record of mas_adamw_job_bytes()
+ * bytes and returns the job's block count, 0 if it rejects the arguments; `group` < mas_adamw_max_groups() names the tensor's
+ * parameter group; records in ascending first_block order; the table is then copied to the device).  `lr_host[ngroups]`: the
+ * groups' learning rates of THIS step (host memory; the poly schedule of utils/scheduler.py:5-14 moves them every step).  `step_dev`: device float, the number of steps taken so far -- the launch uses t = *step_dev + 1 and then
+ * increments it.  `skip_dev` (NULL or a device float): non-zero leaves parameters, moments and the step count untouched (the
+ * stream-K give-up word of mas_conv_sk, trainer/base.py:guard_optimizer_step).  p, g, m, v: f32, n elements each.
+ * ============================================================================================= */
+size_t mas_adamw_job_bytes(void);
+int mas_adamw_max_groups(void);
+unsigned mas_adamw_job(void* job_host, float* p, const float* g, float* m, float* v, long long n, int group, unsigned first_block);
+int mas_adamw_multi(const void* jobs_dev, int njobs, unsigned nblocks, const float* lr_host, int ngroups, double beta1, double beta2, double eps,
+                    double weight_decay, float* step_dev, const float* skip_dev, void* stream);
 
 #ifdef __cplusplus
 }

@@ -19,7 +19,7 @@ GRAD_FRAC = 44
 
 SK_DMA, SK_NOSPLIT = 1, 2
 LOWRES_GENERIC = 1
-ABI_VERSION = 6        # MAS_ABI_VERSION of include/mulactseg_hip.h this table was written against (load() refuses any other library)
+ABI_VERSION = 7        # MAS_ABI_VERSION of include/mulactseg_hip.h this table was written against (load() refuses any other library)
 
 _c = ctypes
 _vp, _i, _f, _i64, _d = _c.c_void_p, _c.c_int, _c.c_float, _c.c_int64, _c.c_double
@@ -129,6 +129,10 @@ SIGNATURES = {
     "mas_fix_to_float": (_i, [_vp, _i64, _i, _vp, _vp]),
     "mas_partial_loss_work_bytes": (_c.c_size_t, [_i, _i, _i, _i]),
     "mas_partial_loss_fwd_fused": (_i, [_vp, _i, _i, _vp, _i, _vp, _vp, _i, _i, _vp, _i, _i, _i, _i, _i, _f, _i, _vp, _vp, _c.c_size_t, _vp, _vp]),
+    "mas_adamw_job_bytes": (_c.c_size_t, []),
+    "mas_adamw_max_groups": (_i, []),
+    "mas_adamw_job": (_c.c_uint, [_vp, _vp, _vp, _vp, _vp, _c.c_longlong, _i, _c.c_uint]),
+    "mas_adamw_multi": (_i, [_vp, _i, _c.c_uint, _vp, _i, _d, _d, _d, _d, _vp, _vp, _vp]),
     "mas_partial_loss_bwd_fused": (_i, [_vp, _i, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _i, _vp, _vp, _vp]),
 }
 

@@ -1337,11 +1337,12 @@ _WGRAD_WS = {}
 
 
 def _wgrad_workspace(dev, nbytes):
-    """One split-K workspace per device, grown on demand (the kernels of one stream run in order, so consecutive weight
-    gradients can share it)."""
-    ws = _WGRAD_WS.get(dev)
+    """One split-K workspace per (device, stream), grown on demand (the kernels of one stream run in order, so consecutive weight
+    gradients can share it; the weight gradients of a backward pass run on a side stream, _ConvTrain.backward)."""
+    key = (dev, torch.cuda.current_stream(dev).cuda_stream)
+    ws = _WGRAD_WS.get(key)
     if ws is None or ws.numel() < nbytes:
-        ws = _WGRAD_WS[dev] = torch.empty(int(nbytes), dtype=torch.uint8, device=dev)
+        ws = _WGRAD_WS[key] = torch.empty(int(nbytes), dtype=torch.uint8, device=dev)
     return ws
 
 
@@ -1899,6 +1900,33 @@ def _side_stream(dev):
     return st
 
 
+_JOIN_QUEUED = set()
+
+
+def _async_wgrad_ok(w):
+    """The weight gradient may finish on the side stream after its autograd node has returned only if NOTHING reads it before the
+    end-of-backward join: w.grad is None (AccumulateGrad then only stores the tensor; with a gradient buffer in place it adds on the
+    main stream), no gradient hooks on w, and no data-parallel reducer (DistributedDataParallel copies / all-reduces a gradient the
+    moment its AccumulateGrad node has run)."""
+    if w.grad is not None or getattr(w, '_post_accumulate_grad_hooks', None) or getattr(w, '_backward_hooks', None):
+        return False
+    import torch.distributed as dist
+    return not (dist.is_available() and dist.is_initialized())      # (any process group: a reducer hooks the AccumulateGrad nodes, not the tensors)
+
+
+def _join_side_after_backward(dev):
+    """Queue ONE callback per backward pass (torch.autograd's engine runs it when the pass has finished, before .backward() returns):
+    the main stream waits for the side stream there."""
+    if dev in _JOIN_QUEUED:
+        return
+    _JOIN_QUEUED.add(dev)
+
+    def join():
+        _JOIN_QUEUED.discard(dev)
+        torch.cuda.current_stream(dev).wait_stream(_side_stream(dev))
+    torch.autograd.Variable._execution_engine.queue_callback(join)
+
+
 def _aten_pad(ks, dil):
     return (dil, dil) if ks == 3 else (0, 0)
 
@@ -1962,17 +1990,29 @@ class _ConvTrain(torch.autograd.Function):
         side = None
         if need_dw and own[2]:
             main = torch.cuda.current_stream(x.device)
-            # MAS_WGRAD_STREAM=side puts dW on a second stream beside the input gradient of the same layer.  Both are kernels that fill
-            # the chip (one 8-wave workgroup per CU, 90-140 KB of LDS): side by side they only take CUs from each other, and the
-            # stream-K hand-off of k_conv_sk waits for workgroups that are not resident yet -- measured 34.1 vs 32.4 ms per step at
-            # the 768 crop, 39.3 vs 37.7 at 769.  Default: one stream.
-            if need_dx and os.environ.get("MAS_WGRAD_STREAM", "main") == "side":
+            # MAS_WGRAD_STREAM: main = one stream; side = dW on a second stream, joined behind the input gradient of the SAME layer
+            # (round 3, persistent one-workgroup-per-CU kernels: 34.1 vs 32.4 ms; round 6, tile kernels: 27.2 vs 25.0 ms -- it loses
+            # either way); async (the default where _async_wgrad_ok) = the second stream joined once per backward pass.
+            mode = os.environ.get("MAS_WGRAD_STREAM", "async")
+            if mode == "async" and not _async_wgrad_ok(w):
+                mode = "main"
+            if mode == "async" or (mode == "side" and need_dx):
                 side = _side_stream(x.device)
                 side.wait_stream(main)                      # dy (and x) are ready on the main stream
                 with torch.cuda.stream(side):
                     dw = conv_wgrad(x, dy, ks, stride, dil)
                 x.record_stream(side)
                 dy.record_stream(side)
+                if mode == "async":
+                    # dW is a LEAF of the backward graph: nothing downstream of this node reads it before the optimizer does.  The side
+                    # stream is joined ONCE, when the whole backward pass has been queued (engine callback), so the weight gradients
+                    # of all layers drain beside the chain of input gradients and BatchNorm backward passes -- most of whose launches
+                    # leave CUs idle (144 workgroups of a 48 x 48 layer on 256 CUs) -- instead of being waited for layer by layer:
+                    # 25.0 -> 23.8 ms per step at the 768 crop, same bits (profiles/r06/wgrad_stream_ab.md).  ("side", the per-layer
+                    # join: 27.2 ms -- the join makes every layer wait for the slower of its two products.)
+                    dw.record_stream(main)
+                    _join_side_after_backward(x.device)
+                    side = None
             else:
                 dw = conv_wgrad(x, dy, ks, stride, dil)
         if need_dx:

@@ -73,7 +73,11 @@ class BaseTrainer(object):
         if self.args.optimizer == 'adamw':
             # same update rule as the reference's optim.AdamW (trainer/base.py:64-66); on the GPU the single-kernel form
             on_gpu = any(p.is_cuda for g in groups for p in g['params'])
-            self.optimizer = optim.AdamW(params=groups, lr=my_lr, weight_decay=self.args.weight_decay, fused=on_gpu)
+            if on_gpu and os.environ.get("MAS_ADAMW", "own") == "own":
+                from ..utils.optim import FusedAdamW        # one launch over all parameters (csrc/optim.hip)
+                self.optimizer = FusedAdamW(params=groups, lr=my_lr, weight_decay=self.args.weight_decay)
+            else:
+                self.optimizer = optim.AdamW(params=groups, lr=my_lr, weight_decay=self.args.weight_decay, fused=on_gpu)
         elif self.args.optimizer == 'sgd':
             self.optimizer = optim.SGD(params=groups, lr=my_lr, momentum=0.9, weight_decay=self.args.weight_decay)
         else:

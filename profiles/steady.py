@@ -36,8 +36,23 @@ def main():
         acc[k][0] += 1
         acc[k][1] += (int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e3
     tot = sum(v[1] for v in acc.values())
+    # kernels of two streams overlap (round 6: the weight gradients run beside the input-gradient chain): the union of the busy
+    # intervals is the time in which SOME kernel runs, the sum of the durations counts overlapped time once per kernel
+    iv = sorted((int(r['Start_Timestamp']), int(r['End_Timestamp'])) for r in rows[a + 1:b + 1])
+    union, cur_s, cur_e = 0, None, None
+    for s_, e_ in iv:
+        if cur_e is None or s_ > cur_e:
+            if cur_e is not None:
+                union += cur_e - cur_s
+            cur_s, cur_e = s_, e_
+        else:
+            cur_e = max(cur_e, e_)
+    if cur_e is not None:
+        union += cur_e - cur_s
     lines = ["# steady-state kernel breakdown (last %d steps, marker `%s`)" % (n, marker), "",
-             "command: `%s`" % cmd, "", "wall %.2f ms/step, GPU busy %.2f ms/step" % (wall, tot / n / 1e3), "",
+             "command: `%s`" % cmd, "",
+             "wall %.2f ms/step, some kernel running %.2f ms/step, sum of kernel durations %.2f ms/step (kernels of two streams overlap)"
+             % (wall, union / n / 1e6, tot / n / 1e3), "",
              "| kernel | calls/step | us/step | % |", "|---|---|---|---|"]
     for k, v in sorted(acc.items(), key=lambda kv: -kv[1][1]):          # (every kernel of the step: no row cut-off)
         lines.append("| %s | %.1f | %.1f | %.1f |" % (k[:100], v[0] / n, v[1] / n, 100 * v[1] / tot))

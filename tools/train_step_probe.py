@@ -19,6 +19,7 @@ def main():
     ap.add_argument("--modes", default="miopen,auto,own")
     ap.add_argument("--streams", default="side")
     ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--adamw", default="own", choices=["own", "aten"])
     args = ap.parse_args()
     from mulactseg_amd import synth
     from mulactseg_amd.models import deeplab, get_model
@@ -40,8 +41,12 @@ def main():
             os.environ["MAS_WGRAD_STREAM"] = st
             torch.manual_seed(0)
             net = get_model('deeplabv3pluswn_resnet50deepstem', C, 16, True, pretrained_backbone=False).to(dev).train()
-            opt = torch.optim.AdamW([{'params': net.backbone.parameters(), 'lr': 2e-5}, {'params': net.classifier.parameters(), 'lr': 2e-4}],
-                                    lr=2e-5, weight_decay=1e-5, fused=True)
+            groups = [{'params': list(net.backbone.parameters()), 'lr': 2e-5}, {'params': list(net.classifier.parameters()), 'lr': 2e-4}]
+            if args.adamw == "own":
+                from mulactseg_amd.utils.optim import FusedAdamW
+                opt = FusedAdamW(groups, lr=2e-5, weight_decay=1e-5)
+            else:
+                opt = torch.optim.AdamW(groups, lr=2e-5, weight_decay=1e-5, fused=True)
 
             def step():
                 opt.zero_grad(set_to_none=True)
