@@ -186,6 +186,15 @@ class Bottleneck(nn.Module):
         if y is None:
             # x has two consumers (conv1 and the residual branch): see _conv_bn_act(fork=True)
             y, x = _conv_bn_act(self.conv1, self.bn1, x, fork=True)
+        if self.downsample is not None and x.is_cuda and self.training and torch.is_grad_enabled():
+            from .. import ops
+            st = ops.branch_stream(x.device, 0)
+            if st is not None:
+                # training: the identity branch on its own stream beside conv2 (forward) / beside the conv3-conv2 chain (backward)
+                idn = ops.run_on_branch(st, lambda t: _run(self.downsample, t), x)
+                y = _conv_bn_act(self.conv2, self.bn2, y)
+                ops.join_branch(st, idn)
+                return _conv_bn_act(self.conv3, self.bn3, y, True, idn)
         y = _conv_bn_act(self.conv2, self.bn2, y)
         if self.downsample is not None:
             if (x.is_cuda and not self.training and not torch.is_grad_enabled() and _INFER_BX() and len(self.downsample) == 2
@@ -350,11 +359,27 @@ class ASPP(nn.Module):
         fused = self._fused_depthwise(x)
         if fused is None:                          # CPU reference form (parity tests), or a non-separable head
             return self.project(torch.cat([conv(x) for conv in self.convs], dim=1))
-        outs = [_run(self.convs[0], x)]
+        streams = [None] * 5
+        if x.is_cuda and self.training and torch.is_grad_enabled():
+            from .. import ops
+            # training: the five branches are independent 2048 -> 256 products on 48 x 48 planes (144 workgroups each): three streams
+            streams = [None, ops.branch_stream(x.device, 1), ops.branch_stream(x.device, 2), None, ops.branch_stream(x.device, 1)]
+
+        def on(k, fn, t):
+            if streams[k] is None:
+                return fn(t)
+            from .. import ops
+            return ops.run_on_branch(streams[k], fn, t)
+        outs = [None] * 5
         for i, y in zip((1, 2, 3), fused):
             branch = self.convs[i]
-            outs.append(_conv_bn_act(branch[0].body[1], branch[1], y))      # pointwise 1x1 -> BN + ReLU
-        outs.append(self.convs[4](x))
+            outs[i] = on(i, lambda t, b=branch: _conv_bn_act(b[0].body[1], b[1], t), y)      # pointwise 1x1 -> BN + ReLU
+        outs[4] = on(4, self.convs[4], x)
+        outs[0] = on(0, lambda t: _run(self.convs[0], t), x)
+        for k in (1, 2, 4):
+            if streams[k] is not None:
+                from .. import ops
+                ops.join_branch(streams[k], outs[k])
         return _run(self.project, torch.cat(outs, dim=1))
 
 
@@ -377,8 +402,17 @@ class DeepLabHeadV3PlusWN(nn.Module):
                 nn.init.constant_(m.bias, 0)
 
     def point_feature(self, feature):
-        low = _run(self.project, feature['low_level'])
-        x = self.aspp(feature['out'])
+        st = None
+        if feature['low_level'].is_cuda and self.training and torch.is_grad_enabled():
+            from .. import ops
+            st = ops.branch_stream(feature['low_level'].device, 3)
+        if st is not None:          # training: the low-level projection (256 -> 48 at 192 x 192) beside the ASPP
+            low = ops.run_on_branch(st, lambda t: _run(self.project, t), feature['low_level'])
+            x = self.aspp(feature['out'])
+            ops.join_branch(st, low)
+        else:
+            low = _run(self.project, feature['low_level'])
+            x = self.aspp(feature['out'])
         if x.is_cuda and not torch.is_grad_enabled():
             from .. import ops
             if ops.upsample_bilinear_supported(x, low.shape[2:]):

@@ -1900,6 +1900,43 @@ def _side_stream(dev):
     return st
 
 
+_BRANCH_STREAMS = {}
+
+
+def branch_stream(dev, k):
+    """Stream number k for an independent BRANCH of the network in a training step (the downsample path of a Bottleneck beside its
+    conv1-conv2-conv3 chain, the ASPP branches, the decoder's low-level projection): most layers of the 48 x 48 / 96 x 96 planes
+    launch fewer workgroups than the chip has slots, so two independent layers side by side finish sooner than one after the other.
+    autograd replays every node's backward on the stream of its forward and orders the streams itself, so the backward pass of a
+    branch overlaps the same way.  None when MAS_BRANCH_STREAMS=off."""
+    if os.environ.get("MAS_BRANCH_STREAMS", "on") == "off":
+        return None
+    key = (dev, int(k))
+    st = _BRANCH_STREAMS.get(key)
+    if st is None:
+        st = _BRANCH_STREAMS[key] = torch.cuda.Stream(device=dev)
+    return st
+
+
+def run_on_branch(stream, fn, *tensors):
+    """fn(*tensors) on `stream` (which first waits for the current stream: the inputs are ready there); the caller joins with
+    join_branch(stream, outputs) before the outputs are used on the current stream."""
+    cur = torch.cuda.current_stream(tensors[0].device)
+    stream.wait_stream(cur)
+    with torch.cuda.stream(stream):
+        out = fn(*tensors)
+    for t in tensors:
+        t.record_stream(stream)
+    return out
+
+
+def join_branch(stream, *outputs):
+    cur = torch.cuda.current_stream(outputs[0].device)
+    cur.wait_stream(stream)
+    for t in outputs:
+        t.record_stream(cur)
+
+
 _JOIN_QUEUED = set()
 
 

@@ -32,9 +32,10 @@ def _torch_1_11_step(p, g, m, v, step, lr, b1=0.9, b2=0.999, eps=1e-8, wd=1e-5):
 
 
 def test_matches_the_single_tensor_update_of_torch_over_several_steps():
-    """Against (a) the reference's update rule restated with torch ops on the same device -- moments within 3 ulp (ATen may contract
-    a * b + c into an fma, csrc/optim.hip never does), parameters within 2 ulp of the UPDATE plus one of the parameter -- and (b)
-    today's torch.optim.AdamW (its first moment is a lerp, another rounding of the same number)."""
+    """(a) The kernel's moments equal its documented arithmetic bit for bit (separate roundings, from its own previous moments);
+    (b) against the reference's update rule restated with torch ops on the same device, and against today's torch.optim.AdamW:
+    parameters within 2 ulp of the UPDATE plus one of the parameter (observed: bit-equal over five steps), moments within the
+    few ulp that ATen's fma contraction / lerp leave in a moving average."""
     dev = _gpu()
     from mulactseg_amd.utils.optim import FusedAdamW
     a, b, c = _params(dev, 1), _params(dev, 1), [q.detach().clone() for q in _params(dev, 1)]
@@ -42,6 +43,8 @@ def test_matches_the_single_tensor_update_of_torch_over_several_steps():
     own = FusedAdamW(mk(a), lr=2e-5, weight_decay=1e-5)
     ref = torch.optim.AdamW(mk(b), lr=2e-5, weight_decay=1e-5, foreach=False, fused=False)
     cm, cv = [torch.zeros_like(q) for q in c], [torch.zeros_like(q) for q in c]
+    prev_m, prev_v = [torch.zeros_like(q) for q in c], [torch.zeros_like(q) for q in c]
+    gmax = [0.0] * len(c)
     g = torch.Generator(device='cpu').manual_seed(7)
     for step in range(5):
         grads = []
@@ -59,15 +62,21 @@ def test_matches_the_single_tensor_update_of_torch_over_several_steps():
             lr = lrs[0 if i < 5 else 1]
             _torch_1_11_step(c[i], grads[i], cm[i], cv[i], step + 1, lr)
             sa = own.state[pa]
-            # 3 ulp of the LARGER of the two terms of m b1 + g (1 - b1) (they may cancel), relative for the sum of squares
-            bound_m = 3.6e-7 * torch.maximum(cm[i].abs(), 0.2 * grads[i].abs()) + 1e-37
-            assert bool(((sa['exp_avg'] - cm[i]).abs() <= bound_m + 3.6e-7 * (sa['exp_avg'] - 0.1 * grads[i]).abs()).all()), (step, i)
+            # the kernel's own arithmetic, exactly: every product and sum rounded separately, from ITS previous moments
+            m_sep = prev_m[i] * 0.9 + grads[i] * torch.tensor(0.1, device=dev)
+            v_sep = prev_v[i] * 0.999 + torch.tensor(0.001, device=dev) * (grads[i] * grads[i])
+            assert torch.equal(sa['exp_avg'], m_sep) and torch.equal(sa['exp_avg_sq'], v_sep), (step, i)
+            prev_m[i], prev_v[i] = sa['exp_avg'].clone(), sa['exp_avg_sq'].clone()
+            # against ATen's sequence (which contracts a * b + c into an fma: one rounding less per step, and the difference rides
+            # along in the moving averages): a few ulp of the largest gradient the tensor has seen; parameters: observed bit-equal
+            gmax[i] = max(gmax[i], float(grads[i].abs().max()))
+            d_m = float((sa['exp_avg'] - cm[i]).abs().max())
             rel_v = float(((sa['exp_avg_sq'] - cv[i]).abs() / cv[i].abs().clamp_min(1e-37)).max())
-            assert rel_v <= 3.6e-7, (step, i, rel_v)
-            tol = 2.4e-7 * lr * 4 + 2 ** -23 * float(c[i].abs().max())          # |update| <= ~lr per step here (|m / sqrt(v)| of order 1)
-            assert float((pa.detach() - c[i]).abs().max()) <= tol, (step, i, float((pa.detach() - c[i]).abs().max()), tol)
-            assert float((pa.detach() - pb.detach()).abs().max()) <= 8 * tol, (step, i)
-            assert torch.allclose(sa['exp_avg'], ref.state[pb]['exp_avg'], rtol=2e-6, atol=1e-30)
+            tol = 2.4e-7 * lr * 8 + 2 ** -22 * float(c[i].abs().max())          # |update| <= ~lr per step here (|m / sqrt(v)| of order 1)
+            d_p = float((pa.detach() - c[i]).abs().max())
+            d_ref = float((pa.detach() - pb.detach()).abs().max())
+            report = dict(step=step, i=i, d_m=d_m, gmax=gmax[i], rel_v=rel_v, d_p=d_p, tol=tol, d_ref=d_ref)
+            assert d_m <= 1e-6 * gmax[i] and rel_v <= 2e-6 and d_p <= tol and d_ref <= 8 * tol, report
     assert float(own.state[a[0]]['step']) == 5.0 and float(ref.state[b[0]]['step']) == 5.0
 
 
