@@ -315,6 +315,7 @@ def pool_round_bench(args, dev, rank, world, with_model, n_images=POOL_IMAGES, c
 # ------------------------------------------------------------------------------------------------------------------
 # model legs
 # ------------------------------------------------------------------------------------------------------------------
+LOSS_PMC_BYTES = (61.1 + 280.6) * 1e6      # k_partial_loss_fwd + k_partial_loss_bwd at [4,20,768,768], 8 % selected: profiles/r06/n_loss_hbm_pmc.md
 F32_MFMA_PEAK_TF = 157.3        # dense f32 MFMA peak of MI355X (MI355X_MICROARCH.md), TFLOP/s
 # The convolutions that run on csrc/conv_bx.hip / conv_wgrad_bx.hip compute the same f32 products from exact three-term bf16 splits
 # of both operands: six bf16 MFMAs (16x the f32 rate) per sixteen f32 ones -- the matrix-core bound of an f32 convolution done that
@@ -499,10 +500,15 @@ def train_iter_bench(args, dev, world, crop):
                           "bytes": loss_bytes,
                           "gpu_ms_fwd_bwd": loss_gpu_ms, "gpu_algorithmic_GBs": loss_bytes / (loss_gpu_ms * 1e-3) / 1e9,
                           "gpu_frac_of_hbm_peak": loss_bytes / (loss_gpu_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                          # the bytes the two scans really move (PMC, profiles/r06/n_loss_hbm_pmc.md at this shape and selected fraction: forward
+                          # 61.1 MB -- it reads the mask and the logits of the SELECTED pixels only --, backward 280.6 MB -- it writes dz
+                          # completely): the figure above prices the kernels on SURVEY section 8(d)'s full-tensor bytes, this one on the traffic
+                          "pmc_bytes_fwd_bwd": LOSS_PMC_BYTES if crop == 768 else None,
+                          "gpu_frac_of_hbm_peak_on_pmc_bytes": (LOSS_PMC_BYTES / (loss_gpu_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if crop == 768 else None,
                           "note": "full-resolution logits as the leaf.  ms_fwd_bwd: wall clock of the loss modules through autograd, the objective "
                                   "composed with torch arithmetic (host-bound when the GPU has nothing else to do); gpu_ms_fwd_bwd: the same two "
                                   "directions through the fused entry points, HIP events (prep + forward scan + finalize, backward scan); "
-                                  "per-kernel times and PMC bytes: profiles/r05/n_loss_*.md"},
+                                  "per-kernel times and PMC bytes: profiles/r06/n_loss_*.md"},
             "loss_from_quarter_logits": {"ms_fwd_bwd_fused": low_ms, "gpu_ms_fwd_bwd_fused": low_gpu_ms,
                                          "ms_fwd_bwd_upsample_then_loss": mat_ms, "quarter_logits": [N, C, q, q],
                                          "note": "leaf = the model's quarter-resolution logits: fused = bilinear x4 evaluated inside both scans "

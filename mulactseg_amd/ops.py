@@ -1658,6 +1658,9 @@ def conv_bx_raw(x, w, dil=1, dgrad=False, residual=None, packed=None, ksplit=0, 
         plan = conv_bx_train_plan(x.shape, w.shape, dil, dgrad)
         ksplit = ksplit or plan[0]
         tile_w = tile_w or plan[1]
+        cap = os.environ.get("MAS_BX_KSPLIT_DGRAD" if dgrad else "MAS_BX_KSPLIT_FWD")       # (A/B: cap the plan's K split)
+        if cap:
+            ksplit = max(1, min(ksplit, int(cap)))
     if ksplit > 1 and (y.numel() % 4 != 0):
         ksplit = 1                                   # (the reduction pass walks 16-byte groups)
     ws = part = None
