@@ -301,3 +301,51 @@ def cityscapes_tree_args(tree, save_dir, extra=()):
         '--val_period', '2', '--log_period', '1', '--active_selection_size', '40', '-p', str(save_dir)] + list(extra))
     a.pretrained_backbone = False
     return a
+
+
+def write_voc_tree(root, n=4, nseg=150, seed=0, trim=5, sizes=((120, 160), (150, 110), (96, 128), (130, 130))):
+    """A tiny PASCAL-VOC-shaped tree in the reference's layout (dataloader/region_voc.py:75-84, region_voc_or_tensor.py:30-62):
+    ``VOC2012/JPEGImages/<name>.jpg``, ``VOC2012/SegmentationClass/<name>.png`` (palette PNG of class indices, 255 = void),
+    ``superpixels/pascal_voc_seg/seeds_32/train/label/<name>.pkl``, the multi-hot tensor with its "undefined" column
+    (``.../gtFine_multi_tensor_trim_<k>x<k>/multi_hot_cls.npy`` u8 [n, nseg, 22]), a datalist of bare names and a region dictionary
+    keyed by them.  Pictures have DIFFERENT sizes, as in VOC."""
+    import json
+    import os
+    import pickle
+    from PIL import Image
+    from mulactseg_amd import synth
+    rs = np.random.RandomState(seed)
+    out = {'root': str(root), 'names': [], 'classes': [], 'spx': [], 'nseg': nseg}
+    for d in ('VOC2012/JPEGImages', 'VOC2012/SegmentationClass', 'superpixels/pascal_voc_seg/seeds_32/train/label',
+              'superpixels/pascal_voc_seg/seeds_32/train/gtFine_multi_tensor_trim_%dx%d' % (trim, trim), 'lists'):
+        os.makedirs(os.path.join(root, d), exist_ok=True)
+    mh = np.zeros((n, nseg, 22), dtype=np.uint8)
+    region = {}
+    for k in range(n):
+        H, W = sizes[k % len(sizes)]
+        name = '2007_%06d' % (32 + 7 * k)
+        cls = synth.class_map(seed * 100 + k, H, W, 21, blob=12).astype(np.uint8)
+        cls[rs.uniform(size=cls.shape) < 0.05] = 255
+        n_ids = 40 + 10 * k
+        spx = (synth.superpixel_map(seed * 100 + 50 + k, H, W, n_ids) % n_ids).astype(np.int32)
+        Image.fromarray(rs.randint(0, 256, size=(H, W, 3)).astype(np.uint8)).save(os.path.join(root, 'VOC2012/JPEGImages', name + '.jpg'), quality=95)
+        pal = Image.fromarray(cls, mode='P')
+        pal.putpalette([v for i in range(256) for v in ((i * 37) % 256, (i * 91) % 256, (i * 13) % 256)])
+        pal.save(os.path.join(root, 'VOC2012/SegmentationClass', name + '.png'))
+        with open(os.path.join(root, 'superpixels/pascal_voc_seg/seeds_32/train/label', name + '.pkl'), 'wb') as f:
+            pickle.dump({'labels': spx}, f)
+        col = np.where(cls == 255, 21, cls)
+        mh[k, spx.reshape(-1), col.reshape(-1)] = 1
+        region[name] = [int(spx.max()) + 1, sorted(set(range(int(spx.max()) + 1)) - set(np.unique(spx).tolist()))]
+        out['names'].append(name), out['classes'].append(cls), out['spx'].append(spx)
+    np.save(os.path.join(root, 'superpixels/pascal_voc_seg/seeds_32/train/gtFine_multi_tensor_trim_%dx%d' % (trim, trim), 'multi_hot_cls.npy'), mh)
+    out['trg_datalist'] = os.path.join(root, 'lists', 'train_seed%d_or.txt' % nseg)
+    out['region_dict'] = os.path.join(root, 'lists', 'train_seed%d.dict' % nseg)
+    out['val_datalist'] = os.path.join(root, 'lists', 'val.txt')
+    for path, names in ((out['trg_datalist'], out['names']), (out['val_datalist'], out['names'][:2])):
+        with open(path, 'w') as f:
+            f.write('\n'.join(names) + '\n')
+    with open(out['region_dict'], 'w') as f:
+        json.dump(region, f)
+    out['multi_hot'] = mh
+    return out

@@ -161,3 +161,28 @@ def test_transform_names_and_their_geometry():
     assert (p['th'], p['tw'], p['i'], p['j']) == (int(513 * 500 / 333), 513, int(round((int(513 * 500 / 333) - 513) / 2.)), 0)
     p, size = get_val_transform('cityscapes').geometry(512, 1024)
     assert (p['th'], p['tw'], size) == (1024, 2048, (1024, 2048))
+
+
+def test_voc_loaders_compose_the_paths_and_drop_the_undefined_column(tmp_path):
+    """dataloader/region_voc.py:75-84 (three paths from a bare name), region_voc_or_tensor.py:30-62 (seeds_32 for --nseg 150, the last
+    column of the label tensor dropped, rows by bare name)."""
+    from mulactseg_amd.dataloader import get_active_dataset
+    from mulactseg_amd.utils.common import get_parser
+    tree = helpers.write_voc_tree(str(tmp_path / 'voc'), n=3)
+    a = get_parser().parse_args(['--src_dataset', 'voc', '--loader', 'region_voc_or_tensor', '--train_transform', 'rescale_513_multi_notrg',
+                                 '--or_labeling', '--fair_counting', '--nseg', '150', '--num_classes', '21', '--trim_multihot_boundary',
+                                 '--trim_kernel_size', '5', '--trg_data_dir', tree['root'], '--trg_datalist', tree['trg_datalist'],
+                                 '--region_dict', tree['region_dict'], '-p', str(tmp_path / 'run')])
+    aset = get_active_dataset(a, train_transform=a.train_transform)
+    pool, label = aset.trg_pool_dataset, aset.trg_label_dataset
+    assert type(pool).__name__ == 'RegionVOCOr' and len(pool) == 3 and len(label) == 0
+    n0 = tree['names'][0]
+    assert pool.im_idx[0] == [os.path.join(tree['root'], 'VOC2012/JPEGImages', n0 + '.jpg'),
+                              os.path.join(tree['root'], 'VOC2012/SegmentationClass', n0 + '.png'),
+                              os.path.join(tree['root'], 'superpixels/pascal_voc_seg/seeds_32/train/label', n0 + '.pkl')]
+    assert pool.suppix[pool.im_idx[0][2]] == sorted(np.unique(tree['spx'][0]).tolist())
+    assert tuple(pool.multi_hot_cls.shape) == (3, 150, 21) and np.array_equal(pool.multi_hot_cls.numpy(), tree['multi_hot'][:, :, :21])
+    assert pool.id_to_index == {n: k for k, n in enumerate(tree['names'])}
+    assert label.transform.size == (513, 513) and label.transform.pad_values == [150]
+    assert pool.transform.geometry(120, 160)[1] == (513, 513)
+    assert pool.encode_target(np.array([[3, 255]], dtype=np.uint8)).tolist() == [[3, 255]]

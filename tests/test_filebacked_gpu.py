@@ -230,3 +230,71 @@ def test_stage2_round_from_png_to_training_step(tmp_path):
     assert abs(float(value) - float(ref)) <= 1e-4 * max(1.0, abs(float(ref)))      # MyCrossEntropyLoss (utils/loss.py:10-21), north-star tolerance
     moved = sum(float((q.detach() - b).abs().sum()) for q, b in zip(tr.net.parameters(), before))
     assert moved > 0 and np.isfinite(moved)
+
+
+def test_voc_samples_equal_the_pillow_pipeline(tmp_path):
+    """The VOC twins (region_voc_or_tensor / eval_region_voc_all / region_voc_plbl / dataset.VOC): JPEG pictures of different sizes,
+    palette class PNGs, ``ExtResize(513) + ExtCenterCrop(513)`` for pool / evaluation samples, 513 x 513 random crops for training --
+    every sample against the Pillow restatement on the PIL-decoded files."""
+    _gpu()
+    from PIL import Image
+    from oracle import augment
+    from mulactseg_amd import dataloader
+    from mulactseg_amd.utils.common import get_parser
+    dataloader.register_dataset_factory(None)
+    tree = helpers.write_voc_tree(str(tmp_path / 'voc'), n=4)
+    base = ['--src_dataset', 'voc', '--or_labeling', '--fair_counting', '--nseg', '150', '--num_classes', '21', '--trim_multihot_boundary',
+            '--trim_kernel_size', '5', '--trg_data_dir', tree['root'], '--trg_datalist', tree['trg_datalist'], '--region_dict', tree['region_dict'],
+            '--val_dataset', 'voc', '--val_data_dir', tree['root'], '--val_datalist', tree['val_datalist'], '-p', str(tmp_path / 'run')]
+    a = get_parser().parse_args(base + ['--loader', 'region_voc_or_tensor', '--train_transform', 'rescale_513_multi_notrg'])
+    os.makedirs(a.model_save_dir, exist_ok=True)
+    aset = dataloader.get_active_dataset(a, train_transform=a.train_transform)
+    pool, label = aset.trg_pool_dataset, aset.trg_label_dataset
+
+    def decoded(k):
+        name = tree['names'][k]
+        pic = np.array(Image.open(os.path.join(tree['root'], 'VOC2012/JPEGImages', name + '.jpg')).convert('RGB'))
+        return pic, tree['spx'][k], tree['classes'][k]
+
+    def centre(pic, maps, pads):
+        H, W = pic.shape[:2]
+        p, size = pool.transform.geometry(H, W)
+        return augment.train_augment(pic, maps, pads, p, size, MEAN, STD)
+    for k in (0, 1):                                    # a landscape and a portrait picture
+        pic, spx, cls = decoded(k)
+        s = pool[k]
+        img, (m,) = centre(pic, [spx], [150])
+        assert tuple(s['images'].shape) == (3, 513, 513) and np.array_equal(s['images'].cpu().numpy(), img)
+        assert np.array_equal(s['spx'].cpu().numpy(), m) and tuple(s['labels'].shape) == (150, 21)
+    # a labelled sample: 513 x 513 crop of a U(0.5, 2) rescale, pad id 150 never selected
+    aset.selection_iter = 1
+    ids = pool.suppix[pool.im_idx[2][2]][:7]
+    aset.expand_training_set([(1.0 - 0.01 * i, ','.join(pool.im_idx[2]), s) for i, s in enumerate(ids)], 10 ** 6, 'x')
+    label.transform.rng = random.Random(4)
+    twin = random.Random(4)
+    pic, spx, cls = decoded(2)
+    for _ in range(2):
+        s = label[0]
+        p = augment.draw_params(twin, pic.shape[0], pic.shape[1], (513, 513))
+        img, (m,) = augment.train_augment(pic, [spx], [150], p, (513, 513), MEAN, STD)
+        assert np.array_equal(s['images'].cpu().numpy(), img) and np.array_equal(s['spx'].cpu().numpy(), m)
+        assert np.array_equal(s['spmask'].cpu().numpy(), np.isin(m, ids)) and not bool(s['spmask'][s['spx'] == 150].any())
+    # validation set (dataset.VOC): labels as stored, 255 = void
+    val = dataloader.get_dataset(a, name='voc', data_root=a.val_data_dir, datalist=a.val_datalist, imageset='val')
+    v = val[1]
+    pic, spx, cls = decoded(1)
+    img, (lab,) = centre(pic, [cls], [255])
+    assert np.array_equal(v['images'].cpu().numpy(), img) and np.array_equal(v['labels'].cpu().numpy(), lab) and v['labels'].dtype == torch.int64
+    # the stage-2 generator's view (eval_region_voc_all): void -> class 21, only selected regions that carry a class, the picture's (w, h)
+    a2 = get_parser().parse_args(base + ['--loader', 'eval_region_voc_all', '--train_transform', 'eval_spx', '--method', 'eval_save_cosplbl_prop_includeonehot_voc'])
+    set2 = dataloader.get_active_dataset(a2, train_transform=a2.train_transform)
+    set2.trg_label_dataset.im_idx = [list(k) for k in label.im_idx]
+    set2.trg_label_dataset.suppix = {k: list(v_) for k, v_ in label.suppix.items()}
+    e = set2.trg_label_dataset[0]
+    pic, spx, cls = decoded(2)
+    img, (lab, m) = centre(pic, [cls, spx], [255, 150])
+    assert np.array_equal(e['labels'].cpu().numpy(), np.where(lab == 255, 21, lab)) and np.array_equal(e['spx'].cpu().numpy(), m)
+    has_cls = tree['multi_hot'][2, :, :21].sum(axis=1) != 0
+    want = np.isin(m, [i for i in ids if has_cls[i]])
+    assert np.array_equal(e['spmask'].cpu().numpy(), want) and e['imsizes'] == (pic.shape[1], pic.shape[0])
+    assert tuple(e['target'].shape) == (150, 21)
