@@ -1983,6 +1983,10 @@ class _ConvTrain(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, w, stride, dil, own, stats=False, fork=False):
+        if _JOIN_QUEUED:                    # a backward pass that raised before its end-of-pass callback ran: join the side stream now
+            for dev in list(_JOIN_QUEUED):
+                _JOIN_QUEUED.discard(dev)
+                torch.cuda.current_stream(dev).wait_stream(_side_stream(dev))
         x = x.contiguous()
         ks = w.shape[2]
         part = None

@@ -500,3 +500,60 @@ def test_caches_follow_a_fused_optimizer_step():
         opt.step()
         opt.zero_grad()
         assert conv.weight._version == v0 or True          # (fused: unchanged; the epoch hook is what the caches see)
+
+
+def test_weight_gradient_stream_modes_and_branch_streams_give_the_same_bits():
+    """Round 6: the weight gradients run on a second stream joined once per backward pass (MAS_WGRAD_STREAM=async, the default in a
+    single-GPU process), independent branches on branch streams (MAS_BRANCH_STREAMS).  Logits and every gradient equal the one-stream
+    step bit for bit; with a gradient buffer in place (accumulation: w.grad is not None) the weight gradients stay on the main stream
+    and a second backward pass exactly doubles every gradient."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from mulactseg_amd import ops
+    from mulactseg_amd.models import get_model
+    dev = torch.device('cuda:0')
+    torch.manual_seed(5)
+    net = get_model('deeplabv3pluswn_resnet50deepstem', 20, 16, True, pretrained_backbone=False).to(dev).train()
+    for m in net.modules():
+        if isinstance(m, torch.nn.Dropout):
+            m.p = 0.0
+    state = {k: v.clone() for k, v in net.state_dict().items()}
+    x = torch.randn(2, 3, 256, 256, generator=torch.Generator(device=dev).manual_seed(9), device=dev)
+    wts = torch.linspace(-1.0, 1.0, 2 * 20 * 64 * 64, device=dev).view(2, 20, 64, 64)
+
+    def step(zero=True):
+        if zero:
+            for p in net.parameters():
+                p.grad = None
+        z = net(x, lowres=True)
+        (z * wts).sum().backward()
+        torch.cuda.synchronize()
+        return z.detach().clone(), {n: p.grad.detach().clone() for n, p in net.named_parameters()}
+    runs = {}
+    keep = {k: os.environ.get(k) for k in ("MAS_WGRAD_STREAM", "MAS_BRANCH_STREAMS")}
+    try:
+        for tag, wg, br in (("main", "main", "off"), ("async", "async", "off"), ("async+branches", "async", "on"), ("side", "side", "on")):
+            os.environ["MAS_WGRAD_STREAM"], os.environ["MAS_BRANCH_STREAMS"] = wg, br
+            net.load_state_dict(state)
+            step()                                      # (first call in a mode: streams and workspaces are created)
+            net.load_state_dict(state)
+            runs[tag] = step()
+        for tag in ("async", "async+branches", "side"):
+            assert torch.equal(runs[tag][0], runs["main"][0]), tag
+            bad = [n for n in runs["main"][1] if not torch.equal(runs[tag][1][n], runs["main"][1][n])]
+            assert not bad, (tag, len(bad), bad[:4])
+        # accumulation: a second backward pass on top of existing gradients (AccumulateGrad adds on the main stream)
+        os.environ["MAS_WGRAD_STREAM"], os.environ["MAS_BRANCH_STREAMS"] = "async", "on"
+        net.load_state_dict(state)
+        _, g1 = step()
+        assert not ops._async_wgrad_ok(net.backbone.layer4[0].conv2.weight)         # a gradient buffer is in place now
+        net.load_state_dict(state)
+        _, g2 = step(zero=False)
+        bad = [n for n in g1 if not torch.equal(g2[n], g1[n] * 2)]
+        assert not bad, (len(bad), bad[:4])
+    finally:
+        for k, v in keep.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
