@@ -1911,8 +1911,12 @@ def branch_stream(dev, k):
     conv1-conv2-conv3 chain, the ASPP branches, the decoder's low-level projection): most layers of the 48 x 48 / 96 x 96 planes
     launch fewer workgroups than the chip has slots, so two independent layers side by side finish sooner than one after the other.
     autograd replays every node's backward on the stream of its forward and orders the streams itself, so the backward pass of a
-    branch overlaps the same way.  None when MAS_BRANCH_STREAMS=off."""
-    if os.environ.get("MAS_BRANCH_STREAMS", "on") == "off":
+    branch overlaps the same way.  MAS_BRANCH_STREAMS=on; the DEFAULT IS OFF (None): the step gains 0.2 ms (23.95 -> 23.74 at the 768
+    crop, same bits), but the autograd engine record_stream()s every gradient that crosses streams, and blocks freed with a recorded
+    stream use cannot serve the next step's allocations while the host runs ahead of the device -- 1.7 hipMalloc calls per step in
+    steady state, reserved memory 9.6 -> 16.6 GB (profiles/r06/wgrad_stream_ab.md).  A 1 % gain is not worth an allocator that
+    never settles."""
+    if os.environ.get("MAS_BRANCH_STREAMS", "off") != "on":
         return None
     key = (dev, int(k))
     st = _BRANCH_STREAMS.get(key)
@@ -1928,19 +1932,18 @@ def run_on_branch(stream, fn, *tensors):
     stream.wait_stream(cur)
     with torch.cuda.stream(stream):
         out = fn(*tensors)
-    for t in tensors:
-        t.record_stream(stream)
+    # (no Tensor.record_stream -- see _ConvTrain.backward: the inputs are activations that live on until the backward pass, i.e. past
+    #  join_branch, after which every free on the current stream is ordered behind the branch's reads; the outputs come from the branch
+    #  stream's pool and their blocks are reused by that stream only after it has waited for the current stream again)
     return out
 
 
 def join_branch(stream, *outputs):
-    cur = torch.cuda.current_stream(outputs[0].device)
-    cur.wait_stream(stream)
-    for t in outputs:
-        t.record_stream(cur)
+    torch.cuda.current_stream(outputs[0].device).wait_stream(stream)
 
 
 _JOIN_QUEUED = set()
+_KEEP_UNTIL_JOIN = {}          # device -> [(x, dy), ...] of the weight gradients queued on the side stream in this backward pass
 
 
 def _async_wgrad_ok(w):
@@ -1964,6 +1967,7 @@ def _join_side_after_backward(dev):
     def join():
         _JOIN_QUEUED.discard(dev)
         torch.cuda.current_stream(dev).wait_stream(_side_stream(dev))
+        _KEEP_UNTIL_JOIN.pop(dev, None)             # (only now may the operands of the weight gradients be freed: see _ConvTrain.backward)
     torch.autograd.Variable._execution_engine.queue_callback(join)
 
 
@@ -1987,6 +1991,7 @@ class _ConvTrain(torch.autograd.Function):
             for dev in list(_JOIN_QUEUED):
                 _JOIN_QUEUED.discard(dev)
                 torch.cuda.current_stream(dev).wait_stream(_side_stream(dev))
+                _KEEP_UNTIL_JOIN.pop(dev, None)
         x = x.contiguous()
         ks = w.shape[2]
         part = None
@@ -2045,8 +2050,14 @@ class _ConvTrain(torch.autograd.Function):
                 side.wait_stream(main)                      # dy (and x) are ready on the main stream
                 with torch.cuda.stream(side):
                     dw = conv_wgrad(x, dy, ks, stride, dil)
-                x.record_stream(side)
-                dy.record_stream(side)
+                # Lifetimes across the two streams WITHOUT Tensor.record_stream: a block freed with a recorded stream use is held back
+                # until an event has completed, and when the host runs ahead of the device (a step queues in 17 ms, runs in 23) those
+                # held-back blocks cannot serve the next step's allocations -- the caching allocator then calls hipMalloc in steady
+                # state (measured: 12-15 calls per step, reserved memory growing with the run-ahead depth, and on some boxes a 769 step
+                # of 38 ms instead of 26).  Instead: x and dy are kept ALIVE until the join (a reference in _KEEP_UNTIL_JOIN), so their
+                # blocks return to the main stream's pool only after the main stream has waited for the side stream; dW is allocated
+                # from the side stream's pool, read by the optimizer behind the join, and its block is reused by the side stream only
+                # after that stream has waited for the main stream again (the wait above, one step later).
                 if mode == "async":
                     # dW is a LEAF of the backward graph: nothing downstream of this node reads it before the optimizer does.  The side
                     # stream is joined ONCE, when the whole backward pass has been queued (engine callback), so the weight gradients
@@ -2054,7 +2065,7 @@ class _ConvTrain(torch.autograd.Function):
                     # leave CUs idle (144 workgroups of a 48 x 48 layer on 256 CUs) -- instead of being waited for layer by layer:
                     # 25.0 -> 23.8 ms per step at the 768 crop, same bits (profiles/r06/wgrad_stream_ab.md).  ("side", the per-layer
                     # join: 27.2 ms -- the join makes every layer wait for the slower of its two products.)
-                    dw.record_stream(main)
+                    _KEEP_UNTIL_JOIN.setdefault(x.device, []).append((x, dy))
                     _join_side_after_backward(x.device)
                     side = None
             else:
@@ -2088,8 +2099,7 @@ class _ConvTrain(torch.autograd.Function):
             dw = torch.ops.aten.convolution_backward(dy, x, w, None, (stride, stride), _aten_pad(ks, dil), (dil, dil), False, (0, 0), 1,
                                                      (False, True, False))[1]
         if side is not None:
-            main.wait_stream(side)                          # dW joins the main stream behind the input gradient
-            dw.record_stream(main)
+            main.wait_stream(side)                          # dW joins the main stream behind the input gradient (x, dy: alive until here)
         if g_other is not None:
             dx = g_other if dx is None else dx + g_other
         return dx, dw, None, None, None, None, None

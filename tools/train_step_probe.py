@@ -65,6 +65,17 @@ def main():
             step()
             paths = deeplab.path_report(reset=True)
             torch.cuda.synchronize()
+            if os.environ.get("MAS_PROBE_ALLOC"):       # per-step allocator counters (diagnostic)
+                for k in range(12):
+                    a = torch.cuda.memory_stats(dev)
+                    step()
+                    torch.cuda.synchronize()
+                    b = torch.cuda.memory_stats(dev)
+                    print("   step %2d: device mallocs %d frees %d retries %d reserved %.2f GB active %.2f GB inactive_split %.2f GB" % (
+                        k, b["num_device_alloc"] - a["num_device_alloc"], b["num_device_free"] - a["num_device_free"],
+                        b["num_alloc_retries"] - a["num_alloc_retries"], b["reserved_bytes.all.current"] / 2 ** 30,
+                        b["active_bytes.all.current"] / 2 ** 30, b["inactive_split_bytes.all.current"] / 2 ** 30), flush=True)
+            seg0 = torch.cuda.memory_stats(dev).get("segment.all.allocated", 0)      # hipMalloc calls of the caching allocator so far
             t0 = time.perf_counter()
             for _ in range(args.steps):
                 loss = step()
@@ -72,7 +83,9 @@ def main():
             torch.cuda.synchronize()
             ms = (time.perf_counter() - t0) / args.steps * 1e3
             out["%s/%s" % (mode, st)] = {"ms_per_step": ms, "host_ms_per_step": host_ms, "loss": float(loss), "conv_paths": paths.get("conv_bn_act")}
-            print(mode, st, "%.2f ms" % ms, "(host %.2f ms)" % host_ms, float(loss), paths.get("conv_bn_act"), flush=True)
+            segs = torch.cuda.memory_stats(dev).get("segment.all.allocated", 0) - seg0
+            print(mode, st, "%.2f ms" % ms, "(host %.2f ms)" % host_ms, float(loss), "hipMallocs in the timed steps: %d, reserved %.1f GB" %
+                  (segs, torch.cuda.memory_reserved(dev) / 2 ** 30), paths.get("conv_bn_act"), flush=True)
             if ctx is not None:
                 ctx.__exit__(None, None, None)
             del net, opt
