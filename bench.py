@@ -66,7 +66,7 @@ def parse():
     ap.add_argument("--no-train", action="store_true", help="skip the model legs (train-iter, acquisition with model, stage 2)")
     ap.add_argument("--no-trainleg", action="store_true", help="skip the train-iter and stage-2 legs but keep the acquisition leg with the model forward")
     ap.add_argument("--no-pool", action="store_true", help="skip the fixed-pool (strong scaling) acquisition round")
-    ap.add_argument("--train-steps", type=int, default=8)
+    ap.add_argument("--train-steps", type=int, default=20)
     ap.add_argument("--acq-steps", type=int, default=8, help="steps of the secondary model-forward + scan measurement")
     ap.add_argument("--crop", type=int, default=768, help="training crop (reference: 768, transform.py:107)")
     ap.add_argument("--cpu-images", type=int, default=32, help="pictures of the CPU-baseline scorer sample (SURVEY 8(d): >= 32)")
@@ -458,23 +458,27 @@ def train_iter_bench(args, dev, world, crop):
         (lowres_step(net(images, lowres=True)) * world).backward()          # as the production trainer's train_impl does
         opt.step()
 
-    for _ in range(2):
+    for _ in range(5):                  # (the leg starts from an empty caching allocator: it settles within these steps)
         full_step()
     deeplab.path_report(reset=True)
     full_step()
     paths = deeplab.path_report(reset=True)
     fence()
+    mallocs0 = torch.cuda.memory_stats(dev).get("num_device_alloc", 0)
     t0 = time.perf_counter()
     for _ in range(args.train_steps):
         full_step()
     fence()
     it_ms = max_over_ranks(time.perf_counter() - t0, dev) / args.train_steps * 1e3
+    mallocs = torch.cuda.memory_stats(dev).get("num_device_alloc", 0) - mallocs0
     sk_err = ops.conv_sk_error(dev)         # (synchronises; the trainers read the same word with the loss)
     if sk_err != 0:
         raise ops.StreamKGaveUp("bench train leg: a stream-K convolution gave up (error word %d): the timed steps are invalid" % sk_err)
     flop = train_step_flop(net.module if hasattr(net, "module") else net, N, crop)
     return {"metric": "train-iter images/sec", "value": N * world / (it_ms * 1e-3), "unit": "images/s", "ms_per_iter": it_ms,
-            "stream_k_error_word": sk_err,
+            "stream_k_error_word": sk_err, "timed_steps": args.train_steps,
+            "hipMalloc_calls_in_the_timed_steps": mallocs, "reserved_GB": torch.cuda.memory_reserved(dev) / 2 ** 30,
+            "weight_gradient_stream": os.environ.get("MAS_WGRAD_STREAM", "async") if _dist() is None else "main (torch.distributed)",
             "mfma": {"flop_per_step": flop, "achieved_TFLOPs": flop / (it_ms * 1e-3) / 1e12, "peak_TFLOPs": SPLIT_BF16_BOUND_TF,
                      "mfma_frac": flop / (it_ms * 1e-3) / 1e12 / SPLIT_BF16_BOUND_TF,
                      "frac_of_split_bf16_bound": flop / (it_ms * 1e-3) / 1e12 / SPLIT_BF16_BOUND_TF,
