@@ -27,6 +27,7 @@ scaling), scan-only and with the model forward; "train_iter" / "train_iter_769" 
 Prints ONE JSON line on rank 0.
 """
 import argparse
+import contextlib
 import gc
 import json
 import os
@@ -67,7 +68,7 @@ def parse():
     ap.add_argument("--no-trainleg", action="store_true", help="skip the train-iter and stage-2 legs but keep the acquisition leg with the model forward")
     ap.add_argument("--no-pool", action="store_true", help="skip the fixed-pool (strong scaling) acquisition round")
     ap.add_argument("--train-steps", type=int, default=20)
-    ap.add_argument("--acq-steps", type=int, default=8, help="steps of the secondary model-forward + scan measurement")
+    ap.add_argument("--acq-steps", type=int, default=16, help="steps of the secondary model-forward + scan measurement")
     ap.add_argument("--crop", type=int, default=768, help="training crop (reference: 768, transform.py:107)")
     ap.add_argument("--cpu-images", type=int, default=32, help="pictures of the CPU-baseline scorer sample (SURVEY 8(d): >= 32)")
     ap.add_argument("--cpu-reps", type=int, default=3, help="repetitions at the reference's 20 threads (median reported; 8(d): 3)")
@@ -536,15 +537,24 @@ def acquisition_with_model_bench(args, dev, world):
     csum = torch.zeros((B, S, C), dtype=torch.int64, device=dev)
     hist = torch.zeros((B, S, C), dtype=torch.int32, device=dev)
 
+    from mulactseg_amd.active_selection.my_bvsb import pool_streams
+    streams = pool_streams(dev)         # consecutive pool batches alternate between two streams, as RegionSelector._iterate runs them
+    for st in streams:
+        st.wait_stream(torch.cuda.current_stream(dev))
+    count = [0]
+
     def step():
         # as the PixBal selectors run it: quarter-resolution logits out of the model, the final x4 bilinear upsampling
         # (models/segmentation/utils.py:25) evaluated inside the scan -- bit-identical to scanning the upsampled tensor
-        with torch.no_grad():
+        ctx = torch.cuda.stream(streams[count[0] % len(streams)]) if streams else contextlib.nullcontext()
+        count[0] += 1
+        with ctx, torch.no_grad():
             zq = net(images, lowres=True)
-        ops.single_pass_accum_lowres(zq.contiguous(), (H, W), spx, S, invT, prob_sum=prob, class_sum=csum, hist=hist)
+            ops.single_pass_accum_lowres(zq.contiguous(), (H, W), spx, S, invT, prob_sum=prob, class_sum=csum, hist=hist)
 
     for _ in range(4):              # MIOpen's find runs on the first calls of every new shape
         step()
+    torch.cuda.synchronize()
     deeplab.path_report(reset=True)
     step()
     paths = deeplab.path_report(reset=True)
@@ -587,7 +597,7 @@ def acquisition_with_model_bench(args, dev, world):
                      "note": "2 * taps * Cin * Cout * output pixels of every dense convolution of one forward, over the whole batch's wall time"},
             "config": {"workload": "eval forward (matrix-core convolutions with BatchNorm / residual / ReLU epilogues -- hip_bx: f32 products from three-term "
                                    "bf16 splits, hip_mfma: f32 MFMA -- + HIP memory-bound layers, no MIOpen kernel: see layer_paths_per_step) of [%d,3,%d,%d] + single-pass scan of the quarter-resolution "
-                                   "logits; the reference structure runs the forward twice per pool image" % (B, H, W)}}
+                                   "logits; the reference structure runs the forward twice per pool image; consecutive batches alternate between %d HIP streams, as RegionSelector._iterate runs the pool (MAS_POOL_STREAMS)" % (B, H, W, max(1, len(streams)))}}
 
 
 def stage2_bench(args, dev):

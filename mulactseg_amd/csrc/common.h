@@ -72,6 +72,21 @@ typedef float mas_v2f __attribute__((ext_vector_type(2)));
 
 __device__ __forceinline__ mas_v2f mas_pk_fma(mas_v2f a, mas_v2f b, mas_v2f c) { return __builtin_elementwise_fma(a, b, c); }
 __device__ __forceinline__ mas_v2f mas_splat(float v) { return (mas_v2f){v, v}; }
+// {p.x * w.x, p.x * w.y} and {p.y * w.x, p.y * w.y}: one half of the register pair `p` times both halves of `w`, with the half
+// selected on SRC0.  Written as instructions because the compiler's own choice for "{s, s} * w" may be the src1 form
+// (v_pk_mul_f32 d, w, p op_sel:[0,1]), and on this part a packed-f32 instruction whose VGPR src1 is read with op_sel[1] = 1 returns
+// wrong results in lanes 48-63 while a wave of ANOTHER kernel on the same SIMD runs MFMAs with AGPR accumulators (measured:
+// profiles/r06/p_pk_opsel_probe.md, tools/pk_opsel_probe.py; tests/test_isa_cpu.py keeps the library free of that form).
+__device__ __forceinline__ mas_v2f mas_pk_mul_lo(mas_v2f p, mas_v2f w) {
+    mas_v2f r;
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[0,1]" : "=v"(r) : "v"(p), "v"(w));
+    return r;
+}
+__device__ __forceinline__ mas_v2f mas_pk_mul_hi(mas_v2f p, mas_v2f w) {
+    mas_v2f r;
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel:[1,0]" : "=v"(r) : "v"(p), "v"(w));
+    return r;
+}
 
 // single v_max_f32 (no canonicalising pre-ops); operands are never NaN here
 __device__ __forceinline__ float mas_vmax(float a, float b) {

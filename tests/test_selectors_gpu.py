@@ -141,3 +141,57 @@ def test_pixbal_selector_under_an_initialised_rccl_group():
             assert np.allclose(s2.cpu().numpy(), s1.cpu().numpy(), rtol=1e-6, atol=1e-9)
     finally:
         dist.destroy_process_group()
+
+
+def test_pool_batches_on_two_streams_give_the_same_bits():
+    """Round 6: consecutive pool batches alternate between two HIP streams (RegionSelector._iterate, MAS_POOL_STREAMS): with a REAL
+    model in the loop (seeded DeepLabv3+ on resident pictures, four batches, a short last one) scores, histograms and class weights
+    equal the one-stream round bit for bit -- every accumulator of the scans is an integer sum or a per-picture row."""
+    _need_gpu()
+    from mulactseg_amd import synth
+    from mulactseg_amd.active_selection import my_bvsb_predclsbal_pwr_banignore as banignore
+    from mulactseg_amd.models import get_model
+    dev = torch.device('cuda:0')
+    n_img, H, W, S, B = 7, 256, 512, 64, 2          # (16 x 32 planes at stride 16: every convolution on this package's kernels -- checked
+    #                                                  below; narrower planes go to MIOpen, whose solver choice is not run-to-run stable)
+    torch.manual_seed(3)
+    net = get_model('deeplabv3pluswn_resnet50deepstem', 20, 16, True, pretrained_backbone=False).to(dev).eval()
+    g = torch.Generator(device=dev).manual_seed(5)
+    pics = torch.randn((n_img, 3, H, W), generator=g, device=dev)
+    maps = torch.from_numpy(np.stack([synth.superpixel_map(900 + i, H, W, S) for i in range(n_img)])).to(dev)
+
+    class Pool(torch.utils.data.Dataset):
+        device_resident = True
+        im_idx = [["i/%03d.png" % i, "l/%03d.png" % i, "s/spx_%04d.pkl" % i] for i in range(n_img)]
+        suppix = {k[2]: list(range(S)) for k in im_idx}
+
+        def __len__(self):
+            return n_img
+
+        def __getitem__(self, i):
+            return {'images': pics[i], 'spx': maps[i]}
+    out = {}
+    keep = os.environ.get("MAS_POOL_STREAMS")
+    try:
+        for n in ("1", "2", "3"):
+            os.environ["MAS_POOL_STREAMS"] = n
+            tmp = tempfile.mkdtemp()
+            args = selector_args(val_batch_size=B, nseg=S, model_save_dir=tmp, active_method='pixbal')
+            sel = banignore.RegionSelector(args)
+            tr = types.SimpleNamespace(net=net, device=dev, model_save_dir=tmp, selection_iter=1)
+            from mulactseg_amd.models import deeplab
+            deeplab.path_report(reset=True)
+            scores, hist = sel.calculate_scores_tensor(tr, Pool(), want_hist=True)
+            torch.cuda.synchronize()
+            paths = deeplab.path_report(reset=True)
+            assert "miopen+bn" not in paths.get("conv_bn_act", {}), paths
+            out[n] = (scores.cpu().numpy().copy(), hist.cpu().numpy().copy(), sel.cls_weight.cpu().numpy().copy())
+    finally:
+        if keep is None:
+            os.environ.pop("MAS_POOL_STREAMS", None)
+        else:
+            os.environ["MAS_POOL_STREAMS"] = keep
+    assert float(out["1"][0].max()) > 0 and out["1"][1].sum() == n_img * H * W
+    for n in ("2", "3"):
+        for a, b in zip(out["1"], out[n]):
+            assert np.array_equal(a, b), n
