@@ -303,7 +303,7 @@ def test_lowres_scan_equals_the_scan_of_the_upsampled_logits(B, C, h, w, H, W, S
 
 def test_lowres_scan_beside_the_convolutions_of_another_stream_gives_the_same_bits():
     """Round 6: the x4 form of the scan shared compute units with k_conv_bx of a second stream and miscounted (lanes 48-63 of a packed-f32
-    multiply whose VGPR src1 was read with op_sel[1] = 1, next to another kernel's MFMA waves: NOTEBOOK.md section 16.6).  The kernel now
+    multiply whose VGPR src1 was read with op_sel[1] = 1, next to another kernel's MFMA waves: NOTEBOOK.md section 16.7).  The kernel now
     selects on src0 (common.h: mas_pk_mul_lo / _hi); quad-sized regions make every pixel's arg-max class and margin visible."""
     from mulactseg_amd import ops
     B, C, H, W = 2, 20, 256, 512

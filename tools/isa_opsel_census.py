@@ -1,13 +1,14 @@
 #!/usr/bin/env python
 """Census, in the BUILT library, of the packed-f32 instructions that are unsafe next to another kernel's MFMA waves on the same SIMD.
 
-Round 6 (NOTEBOOK.md section 16.6, profiles/r06/p_pk_opsel_probe.md): on the MI355X boxes of this pool `v_pk_{mul,add,fma}_f32` with a
+Round 6 (NOTEBOOK.md section 16.7, profiles/r06/p_pk_opsel_probe.md): on the MI355X boxes of this pool `v_pk_{mul,add,fma}_f32` with a
 VGPR src1 read with op_sel[1] = 1 (the LOW result takes src1's HIGH register) returns wrong values in lanes 48-63 while a wave of another
 kernel on the same SIMD runs MFMAs with AGPR accumulators (k_conv_bx, k_wgrad_bx*).  Alone on the SIMD, or with the select on src0 / src2 /
 an SGPR source, the instruction is right.  The library must not contain the form: any of its kernels may share a CU with the convolutions
 of another stream (weight gradients beside the backward pass; pool batches on two streams).
 
     python tools/isa_opsel_census.py [path/to/lib.so]       # default: mulactseg_amd/libmulactseg_hip.so; exit status 1 if any is found
+    python tools/isa_opsel_census.py $(python -c "import torch, os; print(os.path.dirname(torch.__file__))")/lib/libtorch_hip.so   # ~5 min
 
 tests/test_isa_cpu.py runs the same census on the library `__graft_entry__.build()` produced."""
 import os
@@ -19,6 +20,7 @@ import tempfile
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 OBJDUMP = "/opt/rocm/lib/llvm/bin/llvm-objdump"
+BUNDLER = "/opt/rocm/lib/llvm/bin/clang-offload-bundler"
 MAGIC = b"__CLANG_OFFLOAD_BUNDLE__"
 PK = re.compile(r"^\s+(v_pk_(?:mul|add|fma)_f32)\s+([^/;]*)")
 OPSEL = re.compile(r"op_sel:\[([01,]+)\]")
@@ -56,6 +58,20 @@ def code_objects(path, arch="gfx950"):
             q += tl
             if size and triple.endswith(arch):
                 out.append(data[base + off:base + off + size])
+    # compressed bundles ("CCOB", version 2: u16 version, u16 method, u32 total size, u32 uncompressed size, u64 hash, payload) -- how
+    # PyTorch's own libraries ship their kernels; clang-offload-bundler unpacks them
+    for m in re.finditer(b"CCOB", data):
+        i = m.start()
+        ver, _meth, total, _unc, _hash = struct.unpack_from("<HHIIQ", data, i + 4)
+        if ver != 2 or total <= 24 or i + total > len(data):
+            continue
+        with tempfile.TemporaryDirectory() as tmp:
+            blob, co = os.path.join(tmp, "b.bin"), os.path.join(tmp, "b.co")
+            open(blob, "wb").write(data[i:i + total])
+            r = subprocess.run([BUNDLER, "--unbundle", "--type=o", "--targets=hipv4-amdgcn-amd-amdhsa--" + arch, "--input=" + blob, "--output=" + co],
+                               capture_output=True)
+            if r.returncode == 0 and os.path.exists(co) and os.path.getsize(co):
+                out.append(open(co, "rb").read())
     return out
 
 

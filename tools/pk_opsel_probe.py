@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """Which packed-f32 operand-select forms return wrong results in lanes 48-63 while a workgroup of ANOTHER kernel shares the compute unit.
 
-Found in round 6 (NOTEBOOK.md section 16.6): `k_single_pass<..., LOWRES, X4>` miscounted next to `k_conv_bx` on a second stream.  The probe
+Found in round 6 (NOTEBOOK.md section 16.7): `k_single_pass<..., LOWRES, X4>` miscounted next to `k_conv_bx` on a second stream.  The probe
 kernel (mulactseg_amd/csrc/test_support.hip: k_test_pk_opsel -- test infrastructure, tests/libmulactseg_test.so) evaluates ONE instruction
 form per launch on pseudo-random operands against scalar instructions and counts the differing results per lane; the neighbours keep one
 kind of unit busy (matrix cores / LDS / vector ALUs) or are this package's convolution kernel.

@@ -1,6 +1,6 @@
 #!/usr/bin/env python
 """Are the gradients of a training step on TWO streams (MAS_WGRAD_STREAM=async, the default) the bits of the one-stream step, at the bench
-size?  (Round 6, NOTEBOOK.md section 16.6: kernels of different streams share compute units; a kernel holding an instruction form that
+size?  (Round 6, NOTEBOOK.md section 16.7: kernels of different streams share compute units; a kernel holding an instruction form that
 is wrong beside another kernel's MFMA waves would show here.)
 
     python tools/stream_bits_check.py [--crop 768] [--reps 8]"""
