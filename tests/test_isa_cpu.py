@@ -32,7 +32,9 @@ def test_the_pattern_matcher_on_disassembly_lines():
 
 @pytest.mark.skipif(not os.path.exists(census.OBJDUMP), reason="llvm-objdump of the ROCm toolchain is not installed")
 def test_the_library_has_no_packed_f32_instruction_with_a_high_half_select_on_a_vgpr_src1():
-    assert os.path.exists(LIB), "%s is not built: run __graft_entry__.build()" % LIB
+    if not os.path.exists(LIB):
+        import __graft_entry__
+        __graft_entry__.build()
     found, kernels, packed = census.census_library(LIB)
     assert kernels > 500 and packed > 10000, "the disassembly did not see the library's kernels (%d functions, %d packed instructions)" % (kernels, packed)
     assert not found, "unsafe packed-f32 operand select (see mulactseg_amd/csrc/common.h: mas_pk_mul_lo) in: %s" % sorted(found.items())[:10]
