@@ -427,17 +427,20 @@ class DeepLabHeadV3PlusWN(nn.Module):
         x = _upsample(x, low.shape[2:])
         return _run(self.classifier, torch.cat([low, x], dim=1))
 
-    def forward(self, feature):
+    def forward(self, feature, return_feat=None):
+        """``return_feat``: None = the module's flag (the reference's ``set_return_feat`` protocol); True / False = for this call only
+        (callers that run on several threads must not flip a flag on the shared module)."""
+        want_feat = self.return_feat if return_feat is None else return_feat
         pf = self.point_feature(feature)
         if pf.is_cuda:
             from .. import ops
             if ops.cosine_head_supported(pf, self.proxy):
                 _took("cosine_head", "hip")
                 out = ops.cosine_head(pf, self.proxy)            # K8: one pass over the features (csrc/head.hip)
-                return (F.normalize(pf), out) if self.return_feat else out
+                return (F.normalize(pf), out) if want_feat else out
         feat = F.normalize(pf)                                   # over channels, eps 1e-12
         out = F.conv2d(feat, F.normalize(self.proxy, dim=1))     # cosine similarity in [-1, 1]
-        return (feat, out) if self.return_feat else out
+        return (feat, out) if want_feat else out
 
 
 class DeepLabV3PlusWN(nn.Module):
@@ -480,22 +483,12 @@ class DeepLabV3PlusWN(nn.Module):
         what the stage-2 pseudo-label kernels consume -- they interpolate the features per pixel instead of
         materialising feat_forward's 256-channel full-resolution tensor (2.1 GB per Cityscapes image)."""
         size = x.shape[-2:]
-        keep = self.classifier.return_feat
-        self.classifier.return_feat = True
-        try:
-            feat, prob = self.classifier(self.backbone(x))
-        finally:
-            self.classifier.return_feat = keep
+        feat, prob = self.classifier(self.backbone(x), return_feat=True)
         return feat, _upsample(prob, size)
 
     def feat_forward(self, x):
         size = x.shape[-2:]
-        keep = self.classifier.return_feat
-        self.classifier.return_feat = True
-        try:
-            feat, prob = self.classifier(self.backbone(x))
-        finally:
-            self.classifier.return_feat = keep
+        feat, prob = self.classifier(self.backbone(x), return_feat=True)
         return _upsample(feat, size), _upsample(prob, size)
 
 

@@ -5,9 +5,14 @@ The reference materialises ``feat_forward``'s 256-channel full-resolution featur
 walks the selected superpixels in Python with a CPU dilation each; here the quarter-resolution features go straight
 into the K9 kernels (``ops.stage2_pseudo_labels``, ``csrc/stage2.hip``)."""
 import os
+import queue
+import threading
 
+import numpy as np
+import torch
 
 from .. import ops
+from ..utils.miou import MeanIoU
 from . import eval_within_multihot
 
 
@@ -38,6 +43,77 @@ class ActiveTrainer(eval_within_multihot.ActiveTrainer):
         """Same signature as the reference (:121); ``feats`` may be the quarter-resolution map."""
         return ops.stage2_pseudo_labels(feats.contiguous(), inputs.contiguous(), targets.contiguous(), spmasks.contiguous(),
                                         superpixels.contiguous(), include_onehot=self.include_onehot)
+
+    def inference(self, loader, prefix=''):
+        """The loop of ``eval_within_multihot.inference`` (:55-71) with the pictures dealt to ``MAS_STAGE2_WORKERS`` (default 4) threads,
+        each on its own HIP stream: a picture's generation has host waits in it (the prototype list is a ``nonzero``, the label map
+        goes to the host, the PNG is encoded there), so one picture at a time leaves the GPU idle for 60 % of the loop -- 33 ms per
+        1024 x 2048 picture for 13 ms of kernels; 10.9 ms with four threads (``tools/stage2_loop_probe.py``).  The loader is read by the calling thread, in order; a PNG is a per-picture file and
+        the IoU counters are integer sums, so neither depends on which thread took which picture.  The first picture runs on the
+        caller's stream (everything the model derives lazily from its weights is built there).  Subclasses that replace
+        ``pseudo_labels`` (the sliding-window form keeps state between calls) run the one-thread loop."""
+        workers = int(os.environ.get("MAS_STAGE2_WORKERS", "4"))
+        dev = torch.device(self.device)
+        if workers <= 1 or dev.type != 'cuda' or type(self).pseudo_labels is not ActiveTrainer.pseudo_labels or len(loader) < 2:
+            return super().inference(loader, prefix)
+        meter = MeanIoU(self.num_classes + 1, self.args.ignore_idx)
+        meter._before_epoch()
+        self.net.eval()
+        self._save_dir()
+        jobs, errors = queue.Queue(maxsize=2 * workers), []
+
+        def one(batch):
+            images, labels, superpixels, spmasks, targets = self._batch(batch)
+            plbl = self.pseudo_labels(images, labels, targets, spmasks, superpixels)
+            meter._after_step({'outputs': plbl, 'targets': labels})
+            self.after_batch(batch, plbl)               # (ends with the label map on the host: this stream has drained)
+
+        def work(stream):
+            torch.cuda.set_device(dev)
+            with torch.cuda.stream(stream), torch.no_grad():
+                while True:
+                    item = jobs.get()
+                    if item is None:
+                        return
+                    if errors:
+                        continue
+                    batch, ready = item
+                    try:
+                        stream.wait_event(ready)
+                        one(batch)
+                        stream.synchronize()
+                    except BaseException as e:          # noqa: BLE001 (re-raised by the calling thread)
+                        errors.append(e)
+        threads = []
+        with torch.no_grad():
+            for k in range(len(loader)):
+                batch = next(loader)
+                if k == 0:
+                    one(batch)
+                    main = torch.cuda.current_stream(dev)
+                    for _ in range(workers):
+                        st = torch.cuda.Stream(device=dev)
+                        st.wait_stream(main)
+                        threads.append(threading.Thread(target=work, args=(st,), daemon=True))
+                        threads[-1].start()
+                    continue
+                if errors:
+                    break
+                ready = torch.cuda.Event()
+                ready.record(torch.cuda.current_stream(dev))    # the batch was made (or copied) by work queued so far on this stream
+                jobs.put((batch, ready))
+        for _ in threads:
+            jobs.put(None)
+        for t in threads:
+            t.join()
+        if errors:
+            raise errors[0]
+        meter.all_reduce(self.device)
+        ious = meter._after_epoch()
+        miou = np.mean(ious)
+        table = ','.join(['%.2f' % miou] + ['%.2f' % v for v in ious])
+        print("\n[AL {}-round]: {}\n{}".format(self.selection_iter, prefix, table), flush=True)
+        return miou, table
 
     def after_batch(self, batch, plbl):
         from PIL import Image
