@@ -579,9 +579,11 @@ __global__ __launch_bounds__(kThreads, 2) void k_conv_bx(const BxP p) {
                 for (int tm = 0; tm < 2; ++tm)
 #pragma unroll
                     for (int tn = 0; tn < 2; ++tn) {
+#ifndef BX_PROBE_3OF6       // (measurement build, WRONG results: three of the six products, as a two-term split would issue -- NOTEBOOK 16.2)
                         acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[st][tm][1], fb[st][tn][1], acc[tm][tn], 0, 0, 0);
                         acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[st][tm][0], fb[st][tn][2], acc[tm][tn], 0, 0, 0);
                         acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[st][tm][2], fb[st][tn][0], acc[tm][tn], 0, 0, 0);
+#endif
                         acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[st][tm][0], fb[st][tn][1], acc[tm][tn], 0, 0, 0);
                         acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[st][tm][1], fb[st][tn][0], acc[tm][tn], 0, 0, 0);
                         acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[st][tm][0], fb[st][tn][0], acc[tm][tn], 0, 0, 0);
@@ -632,9 +634,11 @@ __global__ __launch_bounds__(kThreads, 2) void k_conv_bx(const BxP p) {
                 // the six products of order <= 2, smallest first
 #pragma unroll
                 for (int tn = 0; tn < 2; ++tn) {
+#ifndef BX_PROBE_3OF6
                     acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], b[tn][1], acc[tm][tn], 0, 0, 0);
                     acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[tn][2], acc[tm][tn], 0, 0, 0);
                     acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[2], b[tn][0], acc[tm][tn], 0, 0, 0);
+#endif
                     acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[tn][1], acc[tm][tn], 0, 0, 0);
                     acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], b[tn][0], acc[tm][tn], 0, 0, 0);
                     acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[tn][0], acc[tm][tn], 0, 0, 0);
