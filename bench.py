@@ -640,7 +640,53 @@ def stage2_bench(args, dev):
             lab = fn()
         torch.cuda.synchronize()
         res[name] = {"ms_per_image": (time.perf_counter() - t0) / 3 * 1e3, "labelled_fraction": float((lab != 255).float().mean())}
+    res["generation_loop"] = stage2_loop(net, image, spx, tgt, msk, C, dev)
     return {"metric": "stage-2 pseudo-label generation, ms per 1024x2048 image (model forward + K9 kernels)", **res}
+
+
+def stage2_loop(net, image, spx, tgt, msk, C, dev, pictures=32):
+    """The LOOP the product runs over the labelled pictures (trainer/eval_save_cosplbl_prop_includeonehot.inference: forward at batch 1,
+    K9 kernels, IoU counters, one PNG per picture) on `pictures` copies of the leg's synthetic picture: wall time per picture with the
+    pictures dealt to MAS_STAGE2_WORKERS threads on their own streams (the default) and one picture at a time (rounds 1-5, the reference)."""
+    import shutil
+    from mulactseg_amd.trainer import eval_save_cosplbl_prop_includeonehot as G
+    labels = torch.zeros((1,) + tuple(spx.shape[-2:]), dtype=torch.long, device=dev)
+
+    class Loader:
+        def __init__(self, n):
+            self.n, self.k = n, 0
+
+        def __len__(self):
+            return self.n
+
+        def __next__(self):
+            self.k += 1
+            return {'images': image, 'labels': labels, 'spx': spx, 'spmask': msk, 'target': tgt,
+                    'fnames': [["i/p%05d.png" % self.k, "l/p%05d.png" % self.k, "s/p%05d.pkl" % self.k]]}
+    out = {}
+    keep = os.environ.get("MAS_STAGE2_WORKERS")
+    try:
+        for name, workers, n in (("ms_per_picture", keep or "4", pictures), ("ms_per_picture_one_at_a_time", "1", pictures // 2)):
+            os.environ["MAS_STAGE2_WORKERS"] = workers
+            tmp = tempfile.mkdtemp(prefix="mas_s2loop_")
+            tr = object.__new__(G.ActiveTrainer)
+            tr.args = types.SimpleNamespace(ignore_idx=255, init_checkpoint=os.path.join(tmp, "checkpoint01.tar"), plbl_type=None, val_batch_size=1)
+            tr.net, tr.device, tr.num_classes, tr.selection_iter, tr.save_dir = net, dev, C - 1, 1, None
+            with contextlib.redirect_stdout(sys.stderr):            # (the trainer prints its IoU table)
+                tr.inference(Loader(6))
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                tr.inference(Loader(n))
+                torch.cuda.synchronize()
+            out[name] = (time.perf_counter() - t0) / n * 1e3
+            shutil.rmtree(tmp, ignore_errors=True)
+        out["worker_threads"] = int(keep or "4")
+    finally:
+        if keep is None:
+            os.environ.pop("MAS_STAGE2_WORKERS", None)
+        else:
+            os.environ["MAS_STAGE2_WORKERS"] = keep
+    return out
 
 
 # ------------------------------------------------------------------------------------------------------------------
